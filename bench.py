@@ -1,0 +1,270 @@
+#!/usr/bin/env python
+"""bench.py -- register+fuse throughput of the MI355X hot path on a 3D tile grid.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on
+rank 0.  For N>1 it is launched by ``python -m torch.distributed.run`` with one rank per GPU.
+
+Workload (BASELINE.json north_star): a 4x4x4 grid of 512^3 uint16 tiles, 20 % overlap, per-tile
+integer jitter unknown to the stage metadata; one "step" = pairwise phase-correlation registration
+of all face-neighbour pairs + fusion of the whole mosaic (cosine-blend weighted average), tiles
+resident in HBM.  Each rank owns one such mosaic (independent positions of a multi-position
+acquisition): units shard with no data-path collective -> "scaling": "weak".
+
+value   = fused output Mvoxels/s over all ranks (register + fuse time, max over ranks)
+roofline = algorithmic HBM bytes of the dominant kernel (fuse: every input voxel once + every
+           output voxel once) / its HIP-event duration, vs 8 TB/s
+cpu_baseline = the numpy/scipy oracle timed on this box on a bounded sample (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--grid", type=str, default="4,4,4", help="tiles in z,y,x")
+    ap.add_argument("--tile", type=str, default="512,512,512", help="tile shape z,y,x")
+    ap.add_argument("--overlap-frac", type=float, default=0.2)
+    ap.add_argument("--no-register", action="store_true", help="time fusion only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=str, default="96,256,256", help="output region of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def make_mosaic_on_device(torch, dev, grid, tile, overlap, seed, max_jitter=3):
+    """Seeded synthetic mosaic generated in HBM: smoothed uniform noise ground truth (uint16, 0..4095)
+    cut into overlapping tiles with an integer jitter the metadata does not know."""
+    grid, tile, overlap = np.asarray(grid), np.asarray(tile), np.asarray(overlap)
+    step = tile - overlap
+    pad = max_jitter + 1
+    gt_shape = step * (grid - 1) + tile + 2 * pad
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    F = torch.nn.functional
+    gt = torch.empty(tuple(int(s) for s in gt_shape), dtype=torch.uint16, device=dev)
+    zslab = 64
+    halo = 4
+    for z0 in range(0, int(gt_shape[0]), zslab):
+        z1 = min(z0 + zslab, int(gt_shape[0]))
+        # smooth per slab with its own halo so slabs are independent (content only has to be
+        # spatially correlated and identical wherever tiles overlap, which the cut below guarantees)
+        gs = torch.Generator(device=dev)
+        gs.manual_seed(seed * 7919 + z0)
+        noise = torch.rand((1, 1, z1 - z0 + 2 * halo, int(gt_shape[1]), int(gt_shape[2])), generator=gs, device=dev)
+        for _ in range(2):
+            noise = F.avg_pool3d(noise, 5, stride=1, padding=2, count_include_pad=False)
+        sm = noise[0, 0, halo:halo + (z1 - z0)]
+        lo, hi = 0.35, 0.65
+        sm = ((sm - lo) / (hi - lo)).clamp_(0, 1) * 4095.0
+        gt[z0:z1] = sm.to(torch.int32).to(torch.uint16)
+        del noise, sm
+    rng = np.random.default_rng(seed + 1)
+    tiles, jitters, origins = [], [], []
+    for idx in np.ndindex(*grid):
+        idx = np.asarray(idx)
+        jit = rng.integers(-max_jitter, max_jitter + 1, size=3)
+        if not idx.any():
+            jit[:] = 0
+        start = idx * step + pad + jit
+        sl = tuple(slice(int(s), int(s + n)) for s, n in zip(start, tile))
+        tiles.append(gt[sl].contiguous())
+        jitters.append(jit)
+        origins.append((idx * step).astype(float))
+    del gt
+    return tiles, np.array(jitters), np.array(origins)
+
+
+def build_sims(tiles, origins, dev_index):
+    from multiview_stitcher_amd import spatial_image_utils as si
+    from multiview_stitcher_amd.device import DeviceArray
+
+    sims = []
+    for t, o in zip(tiles, origins):
+        da = DeviceArray.from_pointer(t.data_ptr(), tuple(t.shape), np.uint16, dev_index, owner=t)
+        sim = si.to_spatial_image(da, dims=["z", "y", "x"], scale={"z": 1.0, "y": 1.0, "x": 1.0},
+                                  translation=dict(zip("zyx", o)))
+        si.set_sim_affine(sim, np.eye(4), si.DEFAULT_TRANSFORM_KEY)
+        sims.append(sim)
+    return sims
+
+
+def cpu_baseline(args, grid, tile, overlap):
+    """Time the numpy/scipy oracle (the reference's own scipy calls) on a bounded sample of the same
+    workload: fusion of one output region around an 8-tile corner + one pairwise registration."""
+    from multiview_stitcher_amd import sample_data
+    from oracle import fuse_oracle as fo
+
+    region = np.array([int(v) for v in args.cpu_sample.split(",")])
+    ts = np.minimum(tile, 160)                     # small tiles with the same overlap fraction
+    ov = np.maximum((ts * args.overlap_frac).astype(int), 1)
+    sims, _, _ = sample_data.generate_tiled_dataset(ndim=3, tile_shape=ts, tiles=(2, 2, 2), overlap=ov, dtype=np.uint16, seed=5)
+    from tests.helpers import sim_to_view, squeeze_field
+
+    sims = [squeeze_field(s) for s in sims]
+    views, bbs = zip(*[sim_to_view(s) for s in sims])
+    params = [np.eye(4) for _ in sims]
+    origin = (ts - ov) - region // 2                # region centred on the 8-tile corner
+    out_bb = fo.bb(origin.astype(float), np.ones(3), region)
+    t0 = time.perf_counter()
+    fo.fuse_np(list(views), params, out_bb, full_view_bbs=list(bbs))
+    t_fuse = time.perf_counter() - t0
+    vox = float(np.prod(region))
+    res = {"value": vox / t_fuse / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+           "sample": f"oracle fuse_np (scipy 1.15 affine_transform path) of one {region.tolist()} output region "
+                     f"covered by 8 uint16 tiles of {ts.tolist()}, 1 thread, {t_fuse:.1f} s; fusion only"}
+    try:
+        from oracle import reg_oracle as ro
+
+        a, b = ro.make_pair_for_bench(ts, ov, seed=3)
+        t0 = time.perf_counter()
+        ro.phase_correlation_registration(a, b)
+        t_reg = time.perf_counter() - t0
+        res["register_pair_s"] = t_reg
+        res["sample"] += f"; + one pairwise registration of a {list(a.shape)} overlap in {t_reg:.1f} s (reported separately)"
+    except Exception as e:  # registration oracle not present yet
+        res["register_note"] = f"registration baseline unavailable: {type(e).__name__}"
+    return res
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from multiview_stitcher_amd import _lib, fusion
+    from multiview_stitcher_amd import spatial_image_utils as si
+
+    _lib.init(local_rank)
+    grid = np.array([int(v) for v in args.grid.split(",")])
+    tile = np.array([int(v) for v in args.tile.split(",")])
+    overlap = np.round(tile * args.overlap_frac).astype(int)
+
+    tiles, jitters, origins = make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=1000 + rank)
+    sims = build_sims(tiles, origins, local_rank)
+    torch.cuda.synchronize()
+
+    do_register = not args.no_register
+    registration = None
+    if do_register:
+        try:
+            from multiview_stitcher_amd import registration  # noqa: F811
+            if not hasattr(registration, "register"):
+                raise ImportError("register() not available")
+        except ImportError:
+            registration, do_register = None, False
+
+    key_in, key_out = si.DEFAULT_TRANSFORM_KEY, "registered"
+    out_holder = {}
+    kernel_ms = []
+    reg_ms = []
+
+    def step():
+        t_reg0 = time.perf_counter()
+        key = key_in
+        if do_register:
+            registration.register(sims, transform_key=key_in, new_transform_key=key_out, device=local_rank,
+                                  pre_registration_pruning_method="keep_axis_aligned")
+            key = key_out
+        t_reg1 = time.perf_counter()
+        fused = fusion.fuse(sims, transform_key=key, output_chunksize={d: 1 << 30 for d in "zyx"},
+                            output_on_backend=True, device=local_rank)
+        out_holder["fused"] = fused
+        kernel_ms.append(_lib.last_kernel_ms(local_rank))
+        reg_ms.append((t_reg1 - t_reg0) * 1e3)
+        return fused
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms.clear()
+    reg_ms.clear()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fused = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    out_shape = fused.shape
+    out_vox = float(np.prod(out_shape))
+    in_vox = float(len(tiles) * np.prod(tile))
+    es = 2
+    alg_bytes = in_vox * es + out_vox * es
+    k_ms = float(np.mean(kernel_ms))
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    ms_per_step = elapsed / args.steps * 1e3
+    value = out_vox * world / (elapsed / args.steps) / 1e6
+
+    if rank == 0:
+        result = {
+            "metric": "Mvoxels/s register+fuse, 3D tile grid" if do_register else "Mvoxels/s fuse only, 3D tile grid",
+            "value": value,
+            "unit": "Mvoxels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u16 in/out, f32 accumulate, f64 coordinates",
+            "data": "synthetic (seeded smoothed noise mosaic generated in HBM, integer jitter unknown to metadata)",
+            "config": {
+                "workload": f"{'x'.join(map(str, grid))} grid (z,y,x) of {'x'.join(map(str, tile))} uint16 tiles, "
+                            f"{int(args.overlap_frac * 100)}% overlap, "
+                            + ("phase-correlation register of face-neighbour pairs + " if do_register else "")
+                            + "cosine-blend weighted-average fuse; one mosaic per GPU",
+                "output_shape": [int(s) for s in out_shape],
+                "tiles_per_gpu": len(tiles),
+                "register_ms_per_step": float(np.mean(reg_ms)) if do_register else None,
+                "fuse_kernel_ms": k_ms,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "fuse_kernel<u16,u16,order1,weighted_average>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": alg_bytes,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, grid, tile, overlap)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,159 @@
+/* mvs_hip.h -- C ABI of libmvs_hip.so: the MI355X (gfx950) register+fuse hot path
+ * for multiview-stitcher workflows.
+ *
+ * Every entry point below replaces (sits directly beneath) one Python call
+ * site of the reference; citations are relative to the reference checkout
+ * (src/multiview_stitcher/...).  Nothing in these signatures is a torch type:
+ * plain pointers, sizes and POD structs, so the library can be bound from
+ * ctypes (what this repo ships), cffi, pybind11 or cgo alike.
+ *
+ * Conventions
+ *   - Arrays are C-contiguous along x; axis order is z,y,x.  2D data is passed
+ *     as 3D with shape[0] == 1 (the reference drops a singleton z the same way,
+ *     registration.py:2414-2464, fusion/_core.py:701-704).
+ *   - "matrix"/"offset" follow scipy.ndimage.affine_transform: they map OUTPUT
+ *     pixel indices to INPUT pixel coordinates, in_coord = matrix @ out_idx + offset,
+ *     and are produced on the host exactly as transformation.py:37-83 does
+ *     (double precision, rounded to 10 decimals, near-integer offsets snapped).
+ *   - Return value: 0 = ok, negative = error; the message is available from
+ *     mvs_last_error(device).  The Python shim raises RuntimeError.
+ *   - Threading: one context per device; calls on the same device serialise on
+ *     an internal mutex and run on that context's HIP stream; calls on
+ *     different devices are fully concurrent.
+ *   - Ownership: the caller owns every pointer it passes for the duration of
+ *     the call.  Device allocations made by mvs_malloc / mvs_upload_tile belong
+ *     to the library until mvs_free.
+ */
+#ifndef MVS_HIP_H
+#define MVS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVS_OK 0
+#define MVS_ERR_INVALID_ARG (-1)
+#define MVS_ERR_HIP (-2)
+#define MVS_ERR_NOT_INITIALISED (-3)
+#define MVS_ERR_UNSUPPORTED (-4)
+
+enum mvs_dtype { MVS_U8 = 0, MVS_U16 = 1, MVS_F32 = 2 };
+enum mvs_mem { MVS_MEM_HOST = 0, MVS_MEM_DEVICE = 1 };
+/* fusion_func: fusion/_core.py:61-94 (weighted_average_fusion, the default),
+ * :42-58 (max_fusion), :97-131 (simple_average_fusion) */
+enum mvs_fusion { MVS_FUSE_WEIGHTED_AVERAGE = 0, MVS_FUSE_MAX = 1, MVS_FUSE_SIMPLE_AVERAGE = 2 };
+/* weights_func: None | weights.content_based (weights.py:22-74) */
+enum mvs_weights { MVS_WEIGHTS_NONE = 0, MVS_WEIGHTS_CONTENT_BASED = 1 };
+
+/* One input view slab of one output chunk: what fuse_np receives per view as
+ * (sims[i], params[i], full_view_bbs[i])  -- fusion/_core.py:1513-1531, 1621-1646. */
+typedef struct mvs_view_t {
+    const void* data;      /* slab voxels, host or device pointer (see mem)            */
+    int32_t dtype;         /* enum mvs_dtype; all views of one call share one dtype    */
+    int32_t mem;           /* enum mvs_mem                                            */
+    int64_t shape[3];      /* slab shape z,y,x                                        */
+    int64_t stride[3];     /* element strides z,y,x; stride[2] must be 1             */
+    double matrix[9];      /* out px -> slab px  (transformation.py:53-83)           */
+    double offset[3];
+    double w_matrix[9];    /* out px -> coordinates on the 5^ndim blending support grid */
+    double w_offset[3];    /*   (weights.py:448-481 through transformation.py:53-83)  */
+    float edt[125];        /* support table, (nz,5,5) row-major, nz = 5 (3D) or 1 (2D);
+                              distance_transform_edt of weights.py:459-464 cast to f32 */
+    int32_t reserved;
+} mvs_view_t;
+
+typedef struct mvs_fuse_opts_t {
+    int32_t ndim;          /* 2 or 3                                                  */
+    int32_t order;         /* interpolation_order 0 | 1  (_core.py:1521, 1627)        */
+    int32_t fusion;        /* enum mvs_fusion                                         */
+    int32_t weights;       /* enum mvs_weights                                        */
+    int64_t out_shape[3];  /* chunk shape INCLUDING halo (output_properties["shape"]) */
+    int64_t trim[3];       /* trim_overlap_in_pixels per axis (_core.py:1687-1711)    */
+    float sigma_1;         /* content_based sigmas (weights.py:26-27)                 */
+    float sigma_2;
+    int32_t out_dtype;     /* dtype of the result = input dtype (_core.py:1713)       */
+    int32_t out_mem;       /* where `out` lives                                       */
+} mvs_fuse_opts_t;
+
+/* ---- context ---------------------------------------------------------------- */
+const char* mvs_version(void);
+int mvs_device_count(void);
+/* Creates the per-device context (stream, events, scratch pool). Idempotent. */
+int mvs_init(int device);
+void mvs_shutdown(int device);
+const char* mvs_last_error(int device);
+/* Run this device's work on an externally owned hipStream_t (e.g. torch's
+ * current stream) instead of the context's own stream; NULL restores it. */
+int mvs_set_stream(int device, void* hip_stream);
+int mvs_synchronize(int device);
+/* Device time (ms, hipEvent) spent in the kernels of the most recent compute
+ * call on this device; blocks until that work has finished. */
+double mvs_last_kernel_ms(int device);
+
+/* ---- device memory / tile residency ----------------------------------------- *
+ * The reference moves every chunk across PCIe twice (cp.asarray on entry,
+ * cp.asnumpy on exit: fusion/_core.py:1584-1587, 1716-1721).  These handles let
+ * register() and fuse() share ONE upload per tile. */
+int mvs_malloc(int device, uint64_t nbytes, void** dev_ptr);
+int mvs_free(int device, void* dev_ptr);
+int mvs_memcpy_h2d(int device, void* dst_dev, const void* src_host, uint64_t nbytes);
+int mvs_memcpy_d2h(int device, void* dst_host, const void* src_dev, uint64_t nbytes);
+int mvs_upload_tile(int device, const void* host, int32_t dtype, const int64_t shape[3], void** dev_ptr);
+
+/* ---- fusion ------------------------------------------------------------------ *
+ * mvs_fuse_chunk == the body of fusion.fuse_np (fusion/_core.py:1608-1713) for
+ * the built-in fusion_func / weights_func: per view affine resample
+ * (transformation.py:136-139 -> scipy.ndimage.affine_transform, cval = NaN),
+ * blending weights (weights.py:391-511), mask by ~isnan + normalise
+ * (_core.py:1648-1649, weights.py:325-345), optional content-based weights,
+ * fusion_func, trim halo, nan_to_num, cast to the input dtype -- as ONE fused
+ * kernel (no per-view float32 temporaries).  `out` has shape out_shape - 2*trim. */
+int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_views,
+                   const mvs_fuse_opts_t* opts, void* out);
+
+/* Single-view resample == transformation.transform_sim's scipy call
+ * (transformation.py:136-139) with order 0|1, mode="constant", cval; float32
+ * output.  Used for registration's pre-transform (registration.py:318-338) and
+ * for fusion with user-supplied fusion_func/weights_func callables.
+ * Only matrix/offset/data/shape/stride/dtype/mem of `view` are read. */
+int mvs_resample(int device, const mvs_view_t* view, const int64_t out_shape[3],
+                 int32_t order, float cval, float* out, int32_t out_mem);
+
+/* Blending-weight volume of one view == weights.get_blending_weights
+ * (weights.py:391-511): resampled 5^ndim support + cosine ramp, NOT normalised. */
+int mvs_blend_weights(int device, const mvs_view_t* view, int32_t ndim,
+                      const int64_t out_shape[3], float* out, int32_t out_mem);
+
+/* ---- registration ------------------------------------------------------------ *
+ * mvs_phasecorr == skimage.registration.phase_cross_correlation(fixed, moving,
+ * normalization=None|"phase", upsample_factor=u, disambiguate=False)[0] as
+ * called from registration.py:422-431:  F=fftn(a), G=fftn(b), P=F*conj(G),
+ * [P /= max(|P|, 100 eps)], cc = ifftn(P), integer peak = argmax|cc| (lowest
+ * flat index wins ties), wrap to signed shift, then upsampled-DFT refinement.
+ * Inputs are float32, NaN-free, same shape; complex64 arithmetic.
+ *   shift_out[3]      final (sub-pixel) shift, z,y,x (0 for the unused z in 2D)
+ *   peak_index_out[3] integer argmax index before wrapping (bit-exact target)
+ *   peak_abs_out      |cc| at that index                                        */
+int mvs_phasecorr(int device, const float* fixed, const float* moving, int32_t mem,
+                  int32_t ndim, const int64_t shape[3], int32_t normalization,
+                  int32_t upsample_factor, double shift_out[3],
+                  int64_t peak_index_out[3], float* peak_abs_out);
+
+/* Candidate scoring == the loop of registration.py:493-556 for n translation
+ * candidates t (z,y,x rows): moving resampled by t (order 1, NaN outside),
+ * masks, bounding-box region (region_mode 0 = "union", 1 = "intersection"),
+ * SSIM (ssim_out) and masked Spearman correlation (spearman_out).  A skipped
+ * candidate reports code_out = 1 (mask empty / <10% valid -> both metrics -1),
+ * 2 (the `continue` of registration.py:530-533, no metric appended), else 0. */
+int mvs_score_candidates(int device, const float* fixed, const float* moving, int32_t mem,
+                         int32_t ndim, const int64_t shape[3],
+                         const double* t_candidates, int32_t n_candidates,
+                         int32_t region_mode, double data_range, double im1_min,
+                         double* ssim_out, double* spearman_out, int32_t* code_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVS_HIP_H */

@@ -1,0 +1,215 @@
+// mvs_context.hip -- device contexts, error reporting, memory helpers of libmvs_hip.so.
+#include "mvs_internal.h"
+
+#include <cstring>
+
+static MvsContext g_ctx[MVS_MAX_DEVICES];
+
+MvsContext* mvs_ctx(int device) {
+    if (device < 0 || device >= MVS_MAX_DEVICES) return nullptr;
+    return &g_ctx[device];
+}
+
+int mvs_fail(MvsContext* c, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->last_error = buf;
+    return code;
+}
+
+int mvs_check_ready(int device, MvsContext** out) {
+    MvsContext* c = mvs_ctx(device);
+    if (!c) return MVS_ERR_INVALID_ARG;
+    if (!c->ready) {
+        int rc = mvs_init(device);
+        if (rc != MVS_OK) return rc;
+    }
+    *out = c;
+    return MVS_OK;
+}
+
+void* mvs_scratch(MvsContext* c, int slot, size_t nbytes) {
+    MvsScratch& s = c->dev[slot];
+    if (nbytes <= s.cap && s.ptr) return s.ptr;
+    if (s.ptr) {
+        hipStreamSynchronize(c->stream);
+        hipFree(s.ptr);
+        s.ptr = nullptr;
+        s.cap = 0;
+    }
+    size_t cap = nbytes + (nbytes >> 3) + 4096;
+    hipError_t e = hipMalloc(&s.ptr, cap);
+    if (e != hipSuccess) {
+        mvs_fail(c, MVS_ERR_HIP, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+        s.ptr = nullptr;
+        return nullptr;
+    }
+    s.cap = cap;
+    return s.ptr;
+}
+
+void* mvs_pinned(MvsContext* c, size_t nbytes) {
+    if (nbytes <= c->pinned_cap && c->pinned) return c->pinned;
+    if (c->pinned) {
+        hipStreamSynchronize(c->stream);
+        hipHostFree(c->pinned);
+        c->pinned = nullptr;
+        c->pinned_cap = 0;
+    }
+    size_t cap = nbytes * 2 + 4096;
+    hipError_t e = hipHostMalloc(&c->pinned, cap, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        mvs_fail(c, MVS_ERR_HIP, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+        c->pinned = nullptr;
+        return nullptr;
+    }
+    c->pinned_cap = cap;
+    return c->pinned;
+}
+
+extern "C" {
+
+const char* mvs_version(void) { return "mvs_hip 0.1 (gfx950)"; }
+
+int mvs_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mvs_init(int device) {
+    MvsContext* c = mvs_ctx(device);
+    if (!c) return MVS_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->ready) return MVS_OK;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || device >= n)
+        return mvs_fail(c, MVS_ERR_HIP, "no HIP device %d (count=%d, %s)", device, n,
+                        hipGetErrorString(e));
+    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    MVS_HIP_TRY(c, hipEventCreate(&c->ev_start));
+    MVS_HIP_TRY(c, hipEventCreate(&c->ev_stop));
+    c->stream = c->own_stream;
+    c->device = device;
+    c->ready = true;
+    c->last_error.clear();
+    return MVS_OK;
+}
+
+void mvs_shutdown(int device) {
+    MvsContext* c = mvs_ctx(device);
+    if (!c || !c->ready) return;
+    std::lock_guard<std::mutex> lock(c->mu);
+    hipSetDevice(device);
+    hipStreamSynchronize(c->stream);
+    for (auto& s : c->dev) {
+        if (s.ptr) hipFree(s.ptr);
+        s.ptr = nullptr;
+        s.cap = 0;
+    }
+    if (c->pinned) hipHostFree(c->pinned);
+    c->pinned = nullptr;
+    c->pinned_cap = 0;
+    hipEventDestroy(c->ev_start);
+    hipEventDestroy(c->ev_stop);
+    hipStreamDestroy(c->own_stream);
+    c->own_stream = c->stream = nullptr;
+    c->ready = false;
+}
+
+const char* mvs_last_error(int device) {
+    MvsContext* c = mvs_ctx(device);
+    if (!c) return "invalid device index";
+    return c->last_error.c_str();
+}
+
+int mvs_set_stream(int device, void* hip_stream) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return MVS_OK;
+}
+
+int mvs_synchronize(int device) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MVS_OK;
+}
+
+double mvs_last_kernel_ms(int device) {
+    MvsContext* c = mvs_ctx(device);
+    if (!c || !c->ready || !c->timing_valid) return -1.0;
+    std::lock_guard<std::mutex> lock(c->mu);
+    hipSetDevice(device);
+    if (hipEventSynchronize(c->ev_stop) != hipSuccess) return -1.0;
+    float ms = -1.f;
+    if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+int mvs_malloc(int device, uint64_t nbytes, void** dev_ptr) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    if (!dev_ptr) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_malloc: dev_ptr is NULL");
+    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipMalloc(dev_ptr, nbytes ? nbytes : 1));
+    return MVS_OK;
+}
+
+int mvs_free(int device, void* dev_ptr) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    if (!dev_ptr) return MVS_OK;
+    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    MVS_HIP_TRY(c, hipFree(dev_ptr));
+    return MVS_OK;
+}
+
+int mvs_memcpy_h2d(int device, void* dst_dev, const void* src_host, uint64_t nbytes) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipMemcpyAsync(dst_dev, src_host, nbytes, hipMemcpyHostToDevice, c->stream));
+    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MVS_OK;
+}
+
+int mvs_memcpy_d2h(int device, void* dst_host, const void* src_dev, uint64_t nbytes) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipMemcpyAsync(dst_host, src_dev, nbytes, hipMemcpyDeviceToHost, c->stream));
+    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MVS_OK;
+}
+
+int mvs_upload_tile(int device, const void* host, int32_t dtype, const int64_t shape[3],
+                    void** dev_ptr) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    size_t es = mvs_dtype_size(dtype);
+    if (!es || !host || !dev_ptr || !shape)
+        return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_upload_tile: bad argument");
+    uint64_t n = (uint64_t)shape[0] * (uint64_t)shape[1] * (uint64_t)shape[2] * es;
+    rc = mvs_malloc(device, n, dev_ptr);
+    if (rc) return rc;
+    return mvs_memcpy_h2d(device, *dev_ptr, host, n);
+}
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// mvs_internal.h -- per-device context shared by the translation units of libmvs_hip.so.
+// Not part of the ABI (that is include/mvs_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "mvs_hip.h"
+
+#define MVS_MAX_DEVICES 16
+
+struct MvsScratch {
+    void* ptr = nullptr;
+    size_t cap = 0;
+};
+
+struct MvsContext {
+    int device = -1;
+    bool ready = false;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;  // the stream work is issued on (own or external)
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timing_valid = false;
+    std::mutex mu;
+    std::string last_error;
+    // grow-only device scratch buffers (slot-indexed) and one pinned host staging buffer
+    MvsScratch dev[8];
+    void* pinned = nullptr;
+    size_t pinned_cap = 0;
+};
+
+MvsContext* mvs_ctx(int device);                       // nullptr if out of range
+int mvs_fail(MvsContext* c, int code, const char* fmt, ...);
+int mvs_check_ready(int device, MvsContext** out);     // locks nothing; returns code
+void* mvs_scratch(MvsContext* c, int slot, size_t nbytes);   // nullptr on failure (error set)
+void* mvs_pinned(MvsContext* c, size_t nbytes);
+
+#define MVS_HIP_TRY(c, expr)                                                         \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess)                                                        \
+            return mvs_fail((c), MVS_ERR_HIP, "%s failed: %s (%s:%d)", #expr,        \
+                            hipGetErrorString(_e), __FILE__, __LINE__);              \
+    } while (0)
+
+static inline size_t mvs_dtype_size(int dtype) {
+    switch (dtype) {
+        case MVS_U8: return 1;
+        case MVS_U16: return 2;
+        case MVS_F32: return 4;
+        default: return 0;
+    }
+}

@@ -1,0 +1,114 @@
+"""Device-resident arrays: the tile residency the reference lacks.
+
+The reference's CuPy backend copies every chunk host->device->host
+(fusion/_core.py:1584-1587, 1716-1721).  A ``DeviceArray`` keeps a tile (or a
+fused result) in HBM so that registration and fusion share one upload; basic
+slicing returns a zero-copy strided window, which is how chunk slabs are handed
+to ``mvs_fuse_chunk``.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceArray:
+    def __init__(self, buf, ptr, shape, strides, dtype, device):
+        self._buf = buf            # DeviceBuffer keeping the allocation alive (or any owner object)
+        self.ptr = int(ptr)
+        self.shape = tuple(int(s) for s in shape)
+        self.strides = tuple(int(s) for s in strides)   # in elements
+        self.dtype = np.dtype(dtype)
+        self.device = int(device)
+
+    ndim = property(lambda self: len(self.shape))
+    size = property(lambda self: int(np.prod(self.shape)))
+    nbytes = property(lambda self: self.size * self.dtype.itemsize)
+
+    @classmethod
+    def from_host(cls, array, device=0):
+        array = np.ascontiguousarray(array)
+        if array.dtype not in _lib.DTYPE_CODES:
+            raise TypeError(f"unsupported dtype {array.dtype} (uint8/uint16/float32)")
+        buf = _lib.DeviceBuffer(device, max(array.nbytes, 1)).upload(array)
+        strides = [s // array.itemsize for s in array.strides]
+        return cls(buf, buf.ptr, array.shape, strides, array.dtype, device)
+
+    @classmethod
+    def empty(cls, shape, dtype, device=0):
+        dtype = np.dtype(dtype)
+        shape = tuple(int(s) for s in shape)
+        buf = _lib.DeviceBuffer(device, max(int(np.prod(shape)) * dtype.itemsize, 1))
+        strides = [int(np.prod(shape[i + 1:])) for i in range(len(shape))]
+        return cls(buf, buf.ptr, shape, strides, dtype, device)
+
+    @classmethod
+    def from_pointer(cls, ptr, shape, dtype, device=0, owner=None):
+        """Wrap foreign device memory (e.g. ``torch_tensor.data_ptr()``); ``owner`` is kept alive."""
+        shape = tuple(int(s) for s in shape)
+        strides = [int(np.prod(shape[i + 1:])) for i in range(len(shape))]
+        return cls(owner, ptr, shape, strides, dtype, device)
+
+    def is_contiguous(self):
+        expect = [int(np.prod(self.shape[i + 1:])) for i in range(self.ndim)]
+        return all(s == e or n == 1 for s, e, n in zip(self.strides, expect, self.shape))
+
+    def __getitem__(self, key):
+        if not isinstance(key, tuple):
+            key = (key,)
+        key = key + (slice(None),) * (self.ndim - len(key))
+        off = 0
+        shape, strides = [], []
+        for k, n, st in zip(key, self.shape, self.strides):
+            if isinstance(k, (int, np.integer)):
+                k = int(k) + (n if k < 0 else 0)
+                off += k * st
+            elif isinstance(k, slice):
+                lo, hi, step = k.indices(n)
+                if step != 1:
+                    raise IndexError("DeviceArray supports unit-step slices only")
+                off += lo * st
+                shape.append(max(hi - lo, 0))
+                strides.append(st)
+            else:
+                raise IndexError("DeviceArray supports ints and slices only")
+        return DeviceArray(self._buf, self.ptr + off * self.dtype.itemsize, shape, strides, self.dtype, self.device)
+
+    def get(self):
+        """Copy to a numpy array."""
+        if self.is_contiguous():
+            out = np.empty(self.shape, dtype=self.dtype)
+            _lib.check(_lib.load().mvs_memcpy_d2h(self.device, out.ctypes.data, self.ptr, out.nbytes), self.device, "d2h")
+            return out
+        # strided window: fetch the spanned range and view it
+        span = sum((n - 1) * st for n, st in zip(self.shape, self.strides)) + 1
+        flat = np.empty(span, dtype=self.dtype)
+        _lib.check(_lib.load().mvs_memcpy_d2h(self.device, flat.ctypes.data, self.ptr, flat.nbytes), self.device, "d2h")
+        return np.lib.stride_tricks.as_strided(
+            flat, self.shape, [s * self.dtype.itemsize for s in self.strides]
+        ).copy()
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.get()
+        return a.astype(dtype) if dtype is not None else a
+
+    def astype(self, dtype):
+        if np.dtype(dtype) == self.dtype:
+            return self
+        raise TypeError("DeviceArray.astype: dtype conversion happens inside the kernels")
+
+    def __repr__(self):
+        return f"<DeviceArray {self.shape} {self.dtype} dev{self.device}>"
+
+
+def is_device_array(x):
+    return isinstance(x, DeviceArray)
+
+
+def to_device(sim, device=0):
+    """Return a copy of a SpatialImage whose data lives on ``device``."""
+    if is_device_array(sim.data):
+        return sim
+    return sim.copy(data=DeviceArray.from_host(sim.data, device))

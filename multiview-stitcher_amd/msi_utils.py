@@ -1,0 +1,110 @@
+"""Multiscale spatial images for the register+fuse path (mirror of msi_utils call shapes).
+
+Reference: src/multiview_stitcher/msi_utils.py (xr.DataTree of ``scaleN/image``
+plus transforms as data variables, msi_utils.py:351-430, 596-617).  Here a
+MultiscaleSpatialImage is a small container {"scaleN": SpatialImage} with one
+transforms dict shared by all scales; pyramid levels beyond scale0 are built by
+block-mean downsampling on request (msi_utils.py:49-79).
+"""
+
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+
+from . import param_utils
+from . import spatial_image_utils as si_utils
+
+
+class MultiscaleSpatialImage:
+    def __init__(self, sims, transforms=None):
+        self.scales = {f"scale{i}": s for i, s in enumerate(sims)}
+        self.transforms = transforms if transforms is not None else {}
+
+    def keys(self):
+        return list(self.scales.keys())
+
+    def __getitem__(self, key):
+        if key.endswith("/image"):
+            key = key[: -len("/image")]
+        return self.scales[key]
+
+    def __repr__(self):
+        return f"<MultiscaleSpatialImage scales={self.keys()} transforms={list(self.transforms)}>"
+
+
+def is_msim(obj):
+    return isinstance(obj, MultiscaleSpatialImage)
+
+
+def get_sorted_scale_keys(msim):
+    return sorted(msim.keys(), key=lambda k: int(k.split("scale")[-1]))
+
+
+def get_ndim(msim):
+    return si_utils.get_ndim_from_sim(msim["scale0/image"])
+
+
+def _downsample_sim(sim, factors):
+    """Block-mean downsample along the spatial dims (msi_utils.py:49-79), cast back to dtype."""
+    sdims = si_utils.get_spatial_dims_from_sim(sim)
+    data = np.asarray(sim.data)
+    sl = []
+    for d in sim.dims:
+        f = int(factors.get(d, 1)) if d in sdims else 1
+        n = (data.shape[sim.dims.index(d)] // f) * f
+        sl.append(slice(0, n))
+    data = data[tuple(sl)]
+    new_shape = []
+    axes = []
+    for ax, d in enumerate(sim.dims):
+        f = int(factors.get(d, 1)) if d in sdims else 1
+        new_shape += [data.shape[ax] // f, f]
+        axes.append(2 * ax + 1)
+    out = data.reshape(new_shape).mean(axis=tuple(axes)).astype(sim.dtype)
+    sp, o = si_utils.get_spacing_from_sim(sim), si_utils.get_origin_from_sim(sim)
+    scale = {d: sp[d] * factors.get(d, 1) for d in sdims}
+    trans = {d: o[d] + (factors.get(d, 1) - 1) * sp[d] / 2 for d in sdims}
+    res = si_utils.to_spatial_image(out, sim.dims, scale, trans, sim.coords.get("c"), sim.coords.get("t"))
+    res.attrs["transforms"] = dict(sim.attrs.get("transforms", {}))
+    return res
+
+
+def get_msim_from_sim(sim, scale_factors=None, chunks=None):
+    """msi_utils.get_msim_from_sim (msi_utils.py:373-430); default: scale0 only."""
+    sims = [sim]
+    for sf in scale_factors or []:
+        if not isinstance(sf, dict):
+            sf = {d: sf for d in si_utils.get_spatial_dims_from_sim(sim)}
+        sims.append(_downsample_sim(sims[-1], sf))
+    return MultiscaleSpatialImage(sims, copy.deepcopy(sim.attrs.get("transforms", {})))
+
+
+def get_sim_from_msim(msim, scale="scale0"):
+    """msi_utils.get_sim_from_msim (msi_utils.py:351-370): the sim at ``scale`` with all transforms."""
+    sim = msim[scale].copy()
+    sim.attrs["transforms"] = dict(msim.transforms)
+    return sim
+
+
+def get_transform_from_msim(msim, transform_key=None):
+    return msim.transforms[transform_key]
+
+
+def get_transforms_from_dataset_as_dict(msim):
+    return dict(msim.transforms)
+
+
+def set_affine_transform(msim, xaffine=None, transform_key=None, base_transform_key=None):
+    """msi_utils.set_affine_transform (msi_utils.py:596-617)."""
+    if transform_key is None:
+        raise ValueError("transform_key must be provided")
+    if xaffine is None:
+        xaffine = param_utils.identity_transform(get_ndim(msim))
+    xaffine = np.asarray(xaffine, dtype=np.float64)
+    if base_transform_key is not None:
+        xaffine = param_utils.rebase_affine(xaffine, get_transform_from_msim(msim, base_transform_key))
+    msim.transforms[transform_key] = xaffine
+    for s in msim.scales.values():
+        s.attrs.setdefault("transforms", {})[transform_key] = xaffine

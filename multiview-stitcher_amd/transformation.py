@@ -1,0 +1,154 @@
+"""Affine resampling on the HIP backend (mirror of the reference's transformation.py).
+
+``get_pixel_affine`` restates the host-side parameter derivation of
+``transform_sim`` (src/multiview_stitcher/transformation.py:37-83); the
+resampling itself (transformation.py:136-139 -> scipy.ndimage.affine_transform)
+runs in ``mvs_resample`` (csrc/mvs_fuse.hip).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib, param_utils
+from . import spatial_image_utils as si_utils
+
+
+def _as_zyx(value, sdims):
+    """dict keyed by dim name (reference style) or sequence -> float64 array in sdims order."""
+    if isinstance(value, dict):
+        return np.array([value[d] for d in sdims], dtype=np.float64)
+    return np.asarray(value, dtype=np.float64)
+
+
+def get_pixel_affine(p, input_origin, input_spacing, output_origin, output_spacing):
+    """(matrix', offset') mapping OUTPUT pixel indices to INPUT pixel coordinates.
+
+    transformation.py:37-83: matrix' = Sy^-1 M Sx; offset' = Sy^-1 (t + (M - I) Ox - (Oy - Ox)),
+    both origins expressed relative to the output origin; rounded to 10 decimals;
+    offsets within 1e-6 of an integer are snapped to it.
+    """
+    p = np.asarray(p, dtype=np.float64)
+    ndim = p.shape[0] - 1
+    M, t = p[:ndim, :ndim], p[:ndim, ndim]
+    Sx = np.diag(np.asarray(output_spacing, dtype=np.float64))
+    Sy = np.diag(np.asarray(input_spacing, dtype=np.float64))
+    Ox = np.asarray(output_origin, dtype=np.float64)
+    Oy = np.asarray(input_origin, dtype=np.float64)
+    matrix_prime = np.linalg.solve(Sy, np.dot(M, Sx))
+    local_offset = t + np.dot(M - np.eye(ndim), Ox)
+    offset_prime = np.linalg.solve(Sy, local_offset - (Oy - Ox))
+    matrix_prime = np.around(matrix_prime, decimals=10)
+    offset_prime = np.around(offset_prime, decimals=10)
+    nearest = np.round(offset_prime)
+    snap = np.isclose(offset_prime, nearest, rtol=0, atol=1e-6)
+    offset_prime[snap] = nearest[snap]
+    return matrix_prime, offset_prime
+
+
+def embed3(matrix, offset):
+    """Embed an ndim-D pixel affine into the 3D (z,y,x) form the C ABI takes (2D: z -> z)."""
+    ndim = len(offset)
+    m3 = np.eye(3)
+    o3 = np.zeros(3)
+    k = 3 - ndim
+    m3[k:, k:] = matrix
+    o3[k:] = offset
+    return m3, o3
+
+
+def shape3(shape):
+    shape = [int(s) for s in shape]
+    return [1] * (3 - len(shape)) + shape
+
+
+def fill_view_geometry(view, data_ptr, dtype_code, mem, shape, strides_elems, matrix, offset):
+    """Fill the data/geometry half of an ``mvs_view_t``."""
+    m3, o3 = embed3(matrix, offset)
+    s3 = shape3(shape)
+    st3 = [int(s) for s in strides_elems]
+    if len(st3) == 2:  # 2D slab: a single z plane
+        st3 = [st3[0] * s3[1], st3[0], st3[1]]
+    view.data = data_ptr
+    view.dtype = dtype_code
+    view.mem = mem
+    view.shape[:] = s3
+    view.stride[:] = st3
+    view.offset[:] = o3.tolist()
+    view.matrix[:] = m3.reshape(-1).tolist()
+
+
+def resample_array(data, matrix, offset, output_shape, order=1, cval=0.0, device=0):
+    """scipy.ndimage.affine_transform(data, matrix, offset, output_shape, order, 'constant', cval)
+    for order 0|1 on the GPU; float32 result (transformation.py:136-139)."""
+    lib = _lib.init(device)
+    data = np.ascontiguousarray(data)
+    if data.dtype not in _lib.DTYPE_CODES:
+        data = data.astype(np.float32)
+    view = _lib.mvs_view_t()
+    strides = [s // data.itemsize for s in data.strides]
+    fill_view_geometry(view, data.ctypes.data, _lib.DTYPE_CODES[data.dtype], _lib.MVS_MEM_HOST, data.shape, strides, matrix, offset)
+    out = np.empty(tuple(int(s) for s in output_shape), dtype=np.float32)
+    rc = lib.mvs_resample(device, C.byref(view), _lib.i64x3(shape3(output_shape)), int(order), float(cval),
+                          out.ctypes.data, _lib.MVS_MEM_HOST)
+    _lib.check(rc, device, "mvs_resample")
+    return out
+
+
+def transform_sim(
+    sim,
+    p=None,
+    output_stack_properties=None,
+    keep_transform_keys=False,
+    input_spacing=None,
+    device=0,
+    **affine_transform_kwargs,
+):
+    """transformation.transform_sim (transformation.py:15-148) on the HIP backend.
+
+    Same arguments and result conventions; ``order`` 0|1, ``cval`` and
+    ``mode="constant"`` are honoured, the output is float32 unless the no-op
+    shortcut (transformation.py:102-119) returns the input data unchanged."""
+    sdims = si_utils.get_spatial_dims_from_sim(sim)
+    ndim = len(sdims)
+    if p is None:
+        p = param_utils.identity_transform(ndim)
+    if input_spacing is None:
+        input_spacing = si_utils.get_spacing_from_sim(sim)
+    matrix_prime, offset_prime = get_pixel_affine(
+        p,
+        si_utils.get_origin_from_sim(sim, asarray=True),
+        _as_zyx(input_spacing, sdims),
+        _as_zyx(output_stack_properties["origin"], sdims),
+        _as_zyx(output_stack_properties["spacing"], sdims),
+    )
+    kwargs = {"mode": "constant", "cval": 0.0, "order": 1} | affine_transform_kwargs
+    if kwargs["mode"] != "constant":
+        raise NotImplementedError("HIP resampler implements mode='constant' only")
+    out_shape = tuple(int(output_stack_properties["shape"][d]) for d in sdims) if isinstance(
+        output_stack_properties["shape"], dict) else tuple(int(s) for s in output_stack_properties["shape"])
+    in_shape = tuple(si_utils.get_shape_from_sim(sim, asarray=True))
+    is_noop = (
+        out_shape == in_shape
+        and np.allclose(matrix_prime, np.eye(ndim), rtol=0, atol=1e-10)
+        and np.allclose(offset_prime, 0, rtol=0, atol=1e-10)
+    )
+    if is_noop:
+        out_data = sim.data
+    else:
+        out_data = resample_array(sim.data, matrix_prime, offset_prime, out_shape, kwargs["order"], kwargs["cval"], device)
+    scale = output_stack_properties["spacing"]
+    trans = output_stack_properties["origin"]
+    if not isinstance(scale, dict):
+        scale = dict(zip(sdims, scale))
+        trans = dict(zip(sdims, trans))
+    return si_utils.to_spatial_image(out_data, dims=sim.dims, scale=scale, translation=trans)
+
+
+def transform_pts(pts, affine):
+    """transformation.transform_pts (transformation.py:150-161)."""
+    pts = np.asarray(pts, dtype=np.float64)
+    pts = np.concatenate([pts, np.ones((pts.shape[0], 1))], axis=1)
+    return np.dot(pts, np.asarray(affine).T)[:, :-1]

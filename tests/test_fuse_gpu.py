@@ -1,0 +1,153 @@
+"""GPU parity: mvs_fuse_chunk (through fusion.fuse_np) against the oracle's fuse_np."""
+import numpy as np
+import pytest
+
+from oracle import fuse_oracle as fo
+from tests.helpers import assert_fused_close, bb_to_dicts, sim_to_view, squeeze_field, union_bb
+
+pytestmark = pytest.mark.gpu
+
+
+def _grid_case(ndim, dtype, tiles, tile_shape, overlap, frac_shift, seed=0, spacing=None):
+    from multiview_stitcher_amd import sample_data, spatial_image_utils as si
+
+    sims, jit, _ = sample_data.generate_tiled_dataset(
+        ndim=ndim, tile_shape=tile_shape, tiles=tiles, overlap=overlap, dtype=dtype, seed=seed, spacing=spacing
+    )
+    sims = [squeeze_field(s) for s in sims]
+    rng = np.random.default_rng(seed + 7)
+    params = []
+    for s in sims:
+        p = np.eye(ndim + 1)
+        if frac_shift:
+            p[:ndim, ndim] = rng.uniform(-2, 2, ndim)
+        params.append(p)
+    return sims, params
+
+
+def _run_both(sims, params, out_bb, **kw):
+    from multiview_stitcher_amd import fusion, spatial_image_utils as si
+
+    sdims = si.get_spatial_dims_from_sim(sims[0])
+    views, bbs = zip(*[sim_to_view(s) for s in sims])
+    okw = dict(kw)
+    fusion_name = okw.pop("fusion", "weighted_average")
+    want, want_f = fo.fuse_np(list(views), params, out_bb, fusion=fusion_name, full_view_bbs=list(bbs),
+                              return_float=True, **okw)
+    ffunc = {"weighted_average": fusion.weighted_average_fusion, "max": fusion.max_fusion,
+             "simple_average": fusion.simple_average_fusion}[fusion_name]
+    got = fusion.fuse_np(
+        list(sims), params, bb_to_dicts(out_bb, sdims), fusion_func=ffunc,
+        full_view_bbs=[bb_to_dicts(b, sdims) for b in bbs],
+        interpolation_order=kw.get("interpolation_order", 1),
+        trim_overlap_in_pixels=kw.get("trim_overlap_in_pixels", 0),
+        blending_widths=kw.get("blending_widths"),
+    )
+    return got, want, want_f
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32, np.uint8])
+@pytest.mark.parametrize("frac_shift", [False, True])
+def test_fuse_2d_grid(hip_device, dtype, frac_shift):
+    sims, params = _grid_case(2, dtype, (2, 3), (96, 80), 17, frac_shift)
+    if dtype == np.uint8:
+        sims = [s.copy(data=(np.asarray(s.data) >> 4).astype(np.uint8)) for s in sims]
+    _, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(2))
+    got, want, want_f = _run_both(sims, params, out_bb)
+    assert_fused_close(got, want, want_f)
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+@pytest.mark.parametrize("frac_shift", [False, True])
+def test_fuse_3d_grid(hip_device, dtype, frac_shift):
+    sims, params = _grid_case(3, dtype, (2, 2, 2), (24, 40, 72), (6, 9, 15), frac_shift)
+    _, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(3))
+    got, want, want_f = _run_both(sims, params, out_bb)
+    assert_fused_close(got, want, want_f)
+
+
+@pytest.mark.parametrize("fusion_name", ["max", "simple_average"])
+@pytest.mark.parametrize("order", [0, 1])
+def test_fuse_modes_and_order(hip_device, fusion_name, order):
+    sims, params = _grid_case(3, np.uint16, (1, 2, 2), (20, 33, 47), (0, 7, 11), True)
+    _, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(3))
+    got, want, want_f = _run_both(sims, params, out_bb, fusion=fusion_name, interpolation_order=order)
+    assert_fused_close(got, want, want_f)
+
+
+def test_fuse_order0_weighted(hip_device):
+    sims, params = _grid_case(2, np.float32, (2, 2), (50, 61), 9, True)
+    _, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(2))
+    got, want, want_f = _run_both(sims, params, out_bb, interpolation_order=0)
+    assert_fused_close(got, want, want_f)
+
+
+def test_fuse_full_affine_two_views_anisotropic(hip_device):
+    """Config C4 in miniature: two views, the second with a full 3x4 affine and z spacing 2."""
+    from multiview_stitcher_amd import sample_data, spatial_image_utils as si
+
+    gt = sample_data.make_ground_truth((40, 56, 64), np.float32, seed=3)
+    v0 = si.get_sim_from_array(gt, dims=["z", "y", "x"], scale={"z": 1.0, "y": 1.0, "x": 1.0})
+    v1 = si.get_sim_from_array(
+        np.ascontiguousarray(gt[::2] * 0.9 + 0.05), dims=["z", "y", "x"], scale={"z": 2.0, "y": 1.0, "x": 1.0},
+        translation={"z": 0.5, "y": -1.0, "x": 2.0},
+    )
+    sims = [squeeze_field(v0), squeeze_field(v1)]
+    th = np.deg2rad(7.0)
+    R = np.array([[1, 0, 0], [0, np.cos(th), -np.sin(th)], [0, np.sin(th), np.cos(th)]])
+    S = np.diag([1.01, 0.99, 1.0])
+    c = np.array([20.0, 28.0, 32.0])
+    p1 = np.eye(4)
+    p1[:3, :3] = R @ S
+    p1[:3, 3] = c - p1[:3, :3] @ c + np.array([3.3, -2.1, 4.7])
+    params = [np.eye(4), p1]
+    _, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.array([1.0, 1.0, 1.0]))
+    got, want, want_f = _run_both(sims, params, out_bb, blending_widths={"z": 4.0, "y": 6.0, "x": 6.0})
+    assert_fused_close(got, want, want_f)
+
+
+def test_fuse_trim_and_output_spacing(hip_device):
+    """Chunk with halo trimmed (trim_overlap_in_pixels) and an output spacing != input spacing."""
+    sims, params = _grid_case(3, np.uint16, (1, 2, 2), (18, 40, 44), (0, 8, 8), True)
+    _, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.array([1.0, 0.75, 1.25]))
+    got, want, want_f = _run_both(sims, params, out_bb, trim_overlap_in_pixels=3)
+    assert got.shape == tuple(out_bb["shape"] - 6)
+    assert_fused_close(got, want, want_f)
+
+
+def test_single_view_is_exact_including_corner_quirk(hip_device):
+    """One view, identity: every voxel equals the input except where the blending weight rounds
+    to 0 in float32 (tile corners; weights.py:502-507) -> the reference outputs 0 there."""
+    sims, params = _grid_case(3, np.uint16, (1, 1, 1), (33, 65, 130), 0, False)
+    _, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(3))
+    got, want, _ = _run_both(sims, params, out_bb)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_device_resident_slabs_and_output(hip_device):
+    """Strided device windows in, device array out == host path."""
+    from multiview_stitcher_amd import device, fusion, spatial_image_utils as si
+
+    sims, params = _grid_case(3, np.uint16, (1, 2, 2), (16, 48, 52), (0, 10, 12), True)
+    sdims = ["z", "y", "x"]
+    _, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(3))
+    host = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims),
+                          full_view_bbs=[bb_to_dicts(b, sdims) for b in bbs])
+    dsims = [device.to_device(s, 0) for s in sims]
+    # crop a window of every tile: zero-copy strided slabs with shifted origins
+    dsl = [s.isel({"y": slice(2, None), "x": slice(3, None)}) for s in dsims]
+    hsl = [s.isel({"y": slice(2, None), "x": slice(3, None)}) for s in sims]
+    a = fusion.fuse_np(hsl, params, bb_to_dicts(out_bb, sdims), full_view_bbs=[bb_to_dicts(b, sdims) for b in bbs])
+    b = fusion.fuse_np(dsl, params, bb_to_dicts(out_bb, sdims), full_view_bbs=[bb_to_dicts(b_, sdims) for b_ in bbs],
+                       output_on_backend=True)
+    assert device.is_device_array(b)
+    np.testing.assert_array_equal(a, b.get())
+    assert host.shape == a.shape

@@ -1,0 +1,61 @@
+"""CPU tests: the product's host-side parameter derivation against the oracle's restatement
+(two independent restatements of transformation.py:37-83 and weights.py:430-470)."""
+import numpy as np
+import pytest
+
+from oracle import fuse_oracle as fo
+from multiview_stitcher_amd import transformation, weights
+
+
+def random_affine(rng, ndim, scale=0.05):
+    A = np.eye(ndim + 1)
+    A[:ndim, :ndim] += rng.normal(0, scale, (ndim, ndim))
+    A[:ndim, ndim] = rng.normal(0, 20, ndim)
+    return A
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_pixel_affine_matches_oracle(ndim):
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        p = random_affine(rng, ndim)
+        in_o, in_s = rng.normal(0, 100, ndim), rng.uniform(0.2, 3, ndim)
+        out = fo.bb(rng.normal(0, 100, ndim), rng.uniform(0.2, 3, ndim), [5] * ndim)
+        m0, o0 = fo.transform_params(p, in_o, in_s, out)
+        m1, o1 = transformation.get_pixel_affine(p, in_o, in_s, out["origin"], out["spacing"])
+        np.testing.assert_array_equal(m0, m1)
+        np.testing.assert_array_equal(o0, o1)
+
+
+def test_pixel_affine_large_origin_kat():
+    """Restates the reference KAT T/test_transformation.py:41-87: a large shared origin must not
+    leak round-off into the offset (to 1e-8) and a small scale must survive the 10-decimal rounding."""
+    origin = 1e7 + 0.123456789
+    scale = 0.13810709635416665
+    p = np.eye(3)
+    m, o = transformation.get_pixel_affine(p, [0.0, origin], [scale, scale], [0.0, origin - 9 * scale], [scale, scale])
+    np.testing.assert_allclose(m, np.eye(2), atol=1e-10)
+    np.testing.assert_allclose(o, [0.0, -9.0], atol=1e-8)
+    assert o[1] == -9.0  # snapped to the integer
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+@pytest.mark.parametrize("shrink", [0, 1.5])
+def test_blending_support_closed_form_equals_scipy_edt(ndim, shrink):
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        shape = rng.integers(8, 600, ndim)
+        src = fo.bb(rng.normal(0, 50, ndim), rng.uniform(0.2, 3, ndim), shape)
+        bw = dict(zip(["z", "y", "x"][-ndim:], rng.uniform(1, 20, ndim)))
+        t0, o0, s0 = fo.edt_support(src, bw, shrink)
+        o0, s0 = fo.coords_origin_spacing(o0, s0, t0.shape)
+        t1, o1, s1 = weights.blending_support(src, bw, shrink)
+        np.testing.assert_array_equal(t0.astype(np.float32), t1)
+        np.testing.assert_array_equal(o0, o1)
+        np.testing.assert_array_equal(s0, s1)
+
+
+def test_embed3_2d():
+    m, o = transformation.embed3(np.array([[1.0, 0.1], [0.2, 0.9]]), np.array([3.0, 4.0]))
+    np.testing.assert_array_equal(m, [[1, 0, 0], [0, 1.0, 0.1], [0, 0.2, 0.9]])
+    np.testing.assert_array_equal(o, [0, 3, 4])
