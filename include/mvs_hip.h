@@ -88,6 +88,9 @@ const char* mvs_last_error(int device);
  * current stream) instead of the context's own stream; NULL restores it. */
 int mvs_set_stream(int device, void* hip_stream);
 int mvs_synchronize(int device);
+/* Tuning / test switches. "force_generic" = 1: mvs_fuse_chunk never takes the translation fast
+ * path (both paths must agree; tests compare them). */
+int mvs_set_option(int device, const char* key, int64_t value);
 /* Device time (ms, hipEvent) spent in the kernels of the most recent compute
  * call on this device; blocks until that work has finished. */
 double mvs_last_kernel_ms(int device);

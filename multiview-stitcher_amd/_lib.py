@@ -65,6 +65,7 @@ SIGNATURES = {
     "mvs_last_error": (C.c_char_p, [C.c_int]),
     "mvs_set_stream": (C.c_int, [C.c_int, C.c_void_p]),
     "mvs_synchronize": (C.c_int, [C.c_int]),
+    "mvs_set_option": (C.c_int, [C.c_int, C.c_char_p, C.c_int64]),
     "mvs_last_kernel_ms": (C.c_double, [C.c_int]),
     "mvs_malloc": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mvs_free": (C.c_int, [C.c_int, C.c_void_p]),
@@ -174,3 +175,7 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def set_option(key, value, device=0):
+    check(init(device).mvs_set_option(int(device), key.encode(), int(value)), device, "mvs_set_option")

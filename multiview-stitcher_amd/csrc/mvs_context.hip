@@ -137,6 +137,19 @@ int mvs_set_stream(int device, void* hip_stream) {
     return MVS_OK;
 }
 
+int mvs_set_option(int device, const char* key, int64_t value) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    if (!key) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_set_option: NULL key");
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!strcmp(key, "force_generic")) {
+        c->force_generic = value != 0;
+        return MVS_OK;
+    }
+    return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_set_option: unknown key '%s'", key);
+}
+
 int mvs_synchronize(int device) {
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);

@@ -43,7 +43,13 @@ struct DevView {
     double wm[9];
     double woff[3];
     float edt[125];
-    float pad[3];
+    // ---- translation fast path (valid when tr_ok): matrix == I, diagonal support map ----
+    int tr_ok;
+    int io[3];        // input index = chunk index + io
+    float fw[3];      // fractional interpolation weights (0 => single tap on that axis)
+    int lo[3], hi[3]; // chunk-index range where the view is in bounds, exact per scipy's test
+    float ws[3];      // tent scales of the closed-form support table edt = min_d(ws_d * tent(i_d))
+    float pad[2];
 };
 
 struct FuseParams {
@@ -116,7 +122,11 @@ __device__ __forceinline__ float blend_ramp(float x) {
     s = fmaf(s, a2, 8.3333333333333333e-03f);
     s = fmaf(s, a2, -1.6666666666666666e-01f);
     s = fmaf(s * a2, a, a);
-    return s * s;
+    // The reference rounds cos((1-x)pi) to float32 before the "+1, /2", which quantises the
+    // ramp to multiples of 2^-25 near 0 (and makes weights below 2^-26 exactly 0 -- e.g. the
+    // corner voxels of a tile).  Reproduce that rounding: c = fl(2w - 1), w' = (c + 1) / 2.
+    const float c = fmaf(2.f, s * s, -1.f);
+    return (c + 1.f) * 0.5f;
 }
 
 // Blend weight of one view at support-grid coordinates (weights.py:475-509):
@@ -138,6 +148,29 @@ __device__ __forceinline__ float blend_weight(const float* __restrict__ tab, int
     float b0 = fmaf(a01, wy, a00 * uy);
     float b1 = fmaf(a11, wy, a10 * uy);
     return blend_ramp(fmaf(b1, wz, b0 * uz));
+}
+
+// Weighted-average accumulator with an exact single-contributor state.
+// The reference normalises first (w/sum(w), weights.py:325-345) and then sums v*w (_core.py:92-94):
+// a voxel seen by ONE view gets weight w/w == 1 and comes out as v exactly (or 0 if w == 0).
+// (acc, den) encodes: den == +0 -> empty; signbit(den) -> single view so far (acc = v, |den| = w);
+// den > 0 -> two or more views (acc = sum w*v, den = sum w).
+__device__ __forceinline__ void wa_update(float& acc, float& den, float w, float v) {
+    const float dabs = fabsf(den);
+    if (signbit(den)) {
+        if (dabs == 0.f) { acc = v; den = -w; }
+        else { acc = fmaf(w, v, acc * dabs); den = dabs + w; }
+    } else if (den == 0.f) {
+        acc = v;
+        den = -w;
+    } else {
+        acc = fmaf(w, v, acc);
+        den += w;
+    }
+}
+__device__ __forceinline__ float wa_result(float acc, float den) {
+    if (signbit(den)) return (den < 0.f) ? acc : 0.f;
+    return (den > 0.f) ? acc / den : 0.f;
 }
 
 template <typename TOut> __device__ __forceinline__ TOut cast_out(float v);
@@ -168,6 +201,9 @@ __device__ __forceinline__ bool brick_hits_view(const DevView& V, const int lo[3
     }
     return true;
 }
+
+template <typename TOut>
+__device__ __forceinline__ void store_row4(TOut* out, long long row, int x0, int ox, const float r[4]);
 
 template <typename TIn, typename TOut, int ORDER, int FUSION>
 __global__ __launch_bounds__(256) void fuse_kernel(FuseParams P) {
@@ -266,8 +302,7 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseParams P) {
                     float w;
                     if (a < kLdsTables) w = blend_weight<true>(s_edt[a], V.wnz, cwz, cwy, cwx);
                     else w = blend_weight<false>(V.edt, V.wnz, cwz, cwy, cwx);
-                    acc[j] = fmaf(w, val, acc[j]);
-                    den[j] += w;
+                    wa_update(acc[j], den[j], w, val);
                 } else if (FUSION == MVS_FUSE_MAX) {
                     acc[j] = fmaxf(acc[j], val);
                     den[j] = 1.f;
@@ -285,13 +320,17 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseParams P) {
     for (int j = 0; j < kVPT; ++j) {
         float o;
         if (FUSION == MVS_FUSE_MAX) o = (den[j] > 0.f) ? acc[j] : 0.f;
+        else if (FUSION == MVS_FUSE_WEIGHTED_AVERAGE) o = wa_result(acc[j], den[j]);
         else o = (den[j] > 0.f) ? acc[j] / den[j] : 0.f;
         if (o != o) o = 0.f;   // nan_to_num
         r[j] = o;
     }
-    TOut* out = (TOut*)P.out;
-    const long long row = ((long long)z * P.oy + y) * (long long)P.ox;
-    if (x0 + kVPT <= P.ox && ((row + x0) & 3) == 0) {
+    store_row4<TOut>((TOut*)P.out, ((long long)z * P.oy + y) * (long long)P.ox, x0, P.ox, r);
+}
+
+template <typename TOut>
+__device__ __forceinline__ void store_row4(TOut* out, long long row, int x0, int ox, const float r[4]) {
+    if (x0 + kVPT <= ox && ((row + x0) & 3) == 0) {
         typename Vec4<TOut>::type v4;
         v4.x = cast_out<TOut>(r[0]);
         v4.y = cast_out<TOut>(r[1]);
@@ -301,8 +340,298 @@ __global__ __launch_bounds__(256) void fuse_kernel(FuseParams P) {
     } else {
 #pragma unroll
         for (int j = 0; j < kVPT; ++j)
-            if (x0 + j < P.ox) out[row + x0 + j] = cast_out<TOut>(r[j]);
+            if (x0 + j < ox) out[row + x0 + j] = cast_out<TOut>(r[j]);
     }
+}
+
+
+// =============================================================================================
+// Translation fast path.  When every view's pixel matrix is the identity (tile grids: stage
+// translations, integer or fractional) the resample degenerates to a fixed 2x2x2 stencil with
+// per-view constant weights, the in-bounds test to an integer box test (the box is derived on the
+// host from scipy's double-precision test, see prepare_translation_view), and the blend weight to
+// a 1-D piecewise-linear function of x per output row:
+//     table T[i][j][k] = min(sz*t_i, sy*t_j, sx*t_k), t = {0,1,2,1,0}
+//     W(z,y,x) = sum_r wx_r * G(ax_r),   G(a) = sum_pq wz_p wy_q min(min(az_p, ay_q), a)
+// ax_r only takes the values {0, sx, 2sx}, so per (row, view) G1 = G(sx), G2 = G(2sx) are wave
+// uniform and W(x) = lerp over the nodes {0, G1, G2, G1, 0} at the support coordinate of x.
+// A wavefront owns one output row segment of 256 voxels (z, y uniform -> scalar registers),
+// a lane 4 consecutive voxels: inputs arrive as (unaligned) 8/16-byte vector loads per stencil
+// row, the result leaves as one aligned 8/16-byte store.
+// =============================================================================================
+constexpr int kTrBrickX = 256;
+
+template <typename T> struct RowVec;
+template <> struct RowVec<unsigned short> { typedef unsigned short v4 __attribute__((ext_vector_type(4), aligned(2))); };
+template <> struct RowVec<unsigned char> { typedef unsigned char v4 __attribute__((ext_vector_type(4), aligned(1))); };
+template <> struct RowVec<float> { typedef float v4 __attribute__((ext_vector_type(4), aligned(4))); };
+
+// x-interpolated values of 4 consecutive output voxels from one input row.
+// p points at the first tap of voxel 0.  full: all 4 voxels (and their second taps) are in bounds.
+template <typename TIn>
+__device__ __forceinline__ void row_taps(const TIn* p, bool fracx, float wx, bool full, int jlo, int jhi, float r[4]) {
+    float e[5];
+    if (full) {
+        typename RowVec<TIn>::v4 v = *reinterpret_cast<const typename RowVec<TIn>::v4*>(p);
+        e[0] = (float)v.x; e[1] = (float)v.y; e[2] = (float)v.z; e[3] = (float)v.w;
+        e[4] = fracx ? (float)p[4] : 0.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const bool need = (j >= jlo && j <= jhi) || (fracx && j - 1 >= jlo && j - 1 <= jhi);
+            e[j] = need ? (float)p[j] : 0.f;
+        }
+    }
+    if (fracx) {
+        const float ux = 1.f - wx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = fmaf(e[j + 1], wx, e[j] * ux);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = e[j];
+    }
+}
+
+__device__ __forceinline__ float tent5(int i) { return (float)min(i, 4 - i); }
+
+// Row-uniform part of the blend weight: nodes G1, G2 (see header comment). Returns false if the
+// row lies outside the support along z or y (weight 0 everywhere, cval of the table resample).
+__device__ __forceinline__ bool blend_row_nodes(const DevView& V, double pz, double py, float& G1, float& G2) {
+    float az0 = INFINITY, az1 = INFINITY, fz = 0.f;
+    if (V.wnz > 1) {
+        const double cz = pz * V.wm[0] + V.woff[0];
+        if (cz < 0.0 || cz > 4.0) return false;
+        const double f = floor(cz);
+        const int i = (int)f;
+        fz = (float)(cz - f);
+        az0 = V.ws[0] * tent5(i);
+        az1 = V.ws[0] * tent5(min(i + 1, 4));
+    }
+    const double cy = py * V.wm[4] + V.woff[1];
+    if (cy < 0.0 || cy > 4.0) return false;
+    const double fy_ = floor(cy);
+    const int iy = (int)fy_;
+    const float fy = (float)(cy - fy_);
+    const float ay0 = V.ws[1] * tent5(iy), ay1 = V.ws[1] * tent5(min(iy + 1, 4));
+    const float uz = 1.f - fz, uy = 1.f - fy;
+    const float m00 = fminf(az0, ay0), m01 = fminf(az0, ay1), m10 = fminf(az1, ay0), m11 = fminf(az1, ay1);
+    const float a1 = V.ws[2], a2 = 2.f * V.ws[2];
+    // same association as the table interpolation: lerp along y, then along z
+    float g0 = fmaf(fminf(m01, a1), fy, fminf(m00, a1) * uy);
+    float g1 = fmaf(fminf(m11, a1), fy, fminf(m10, a1) * uy);
+    G1 = fmaf(g1, fz, g0 * uz);
+    g0 = fmaf(fminf(m01, a2), fy, fminf(m00, a2) * uy);
+    g1 = fmaf(fminf(m11, a2), fy, fminf(m10, a2) * uy);
+    G2 = fmaf(g1, fz, g0 * uz);
+    return true;
+}
+
+template <typename TIn, typename TOut, int FUSION>
+__global__ __launch_bounds__(256) void fuse_tr_kernel(FuseParams P) {
+    __shared__ int s_act[64];
+    __shared__ int s_nact;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    int b = blockIdx.x;
+    const int bx = b % P.nbx;
+    b /= P.nbx;
+    const int byi = b % P.nby;
+    const int bzi = b / P.nby;
+    int z, y;
+    if (P.bz == 2) {
+        z = bzi * 2 + (wave >> 1);
+        y = byi * 2 + (wave & 1);
+    } else {
+        z = bzi;
+        y = byi * 4 + wave;
+    }
+    const int x0 = bx * kTrBrickX + lane * kVPT;
+    const bool row_ok = (z < P.oz) && (y < P.oy);
+    const int zc = z + P.tz, yc = y + P.ty, xc0 = x0 + P.tx;   // chunk indices
+    // brick box in chunk indices (for culling)
+    const int bz0 = bzi * P.bz + P.tz, bz1 = min(bzi * P.bz + P.bz, P.oz) - 1 + P.tz;
+    const int by0 = byi * P.by + P.ty, by1 = min(byi * P.by + P.by, P.oy) - 1 + P.ty;
+    const int bx0 = bx * kTrBrickX + P.tx, bx1 = min(bx * kTrBrickX + kTrBrickX, P.ox) - 1 + P.tx;
+
+    float acc[kVPT], den[kVPT];
+#pragma unroll
+    for (int j = 0; j < kVPT; ++j) {
+        acc[j] = (FUSION == MVS_FUSE_MAX) ? -INFINITY : 0.f;
+        den[j] = 0.f;
+    }
+
+    for (int base = 0; base < P.nviews; base += 64) {
+        __syncthreads();
+        if (wave == 0) {
+            const int v = base + lane;
+            bool act = false;
+            if (v < P.nviews) {
+                const DevView& V = P.views[v];
+                act = V.lo[0] <= bz1 && V.hi[0] >= bz0 && V.lo[1] <= by1 && V.hi[1] >= by0 && V.lo[2] <= bx1 &&
+                      V.hi[2] >= bx0;
+            }
+            const unsigned long long mask = __ballot(act);
+            if (act) s_act[__popcll(mask & ((1ull << lane) - 1ull))] = v;
+            if (lane == 0) s_nact = __popcll(mask);
+        }
+        __syncthreads();
+        const int nact = s_nact;
+        if (!row_ok) continue;
+
+        for (int a = 0; a < nact; ++a) {
+            const int vi = __builtin_amdgcn_readfirstlane(s_act[a]);
+            const DevView& V = P.views[vi];
+            if (zc < V.lo[0] || zc > V.hi[0] || yc < V.lo[1] || yc > V.hi[1]) continue;   // wave uniform
+            const int xlo = V.lo[2], xhi = V.hi[2];
+            const int jlo = max(xlo - xc0, 0), jhi = min(xhi - xc0, kVPT - 1);
+            const bool any = jlo <= jhi;
+            const bool full = (jlo == 0) && (jhi == kVPT - 1);
+            float G1 = 0.f, G2 = 0.f;
+            bool wrow = true;
+            if (FUSION == MVS_FUSE_WEIGHTED_AVERAGE) wrow = blend_row_nodes(V, (double)zc, (double)yc, G1, G2);
+            if (!any) continue;
+
+            const float wz = V.fw[0], wy = V.fw[1], wx = V.fw[2];
+            const bool fracz = wz > 0.f, fracy = wy > 0.f, fracx = wx > 0.f;
+            const TIn* p00 = (const TIn*)V.data + (long long)(zc + V.io[0]) * V.stride_z +
+                             (long long)(yc + V.io[1]) * V.stride_y + (xc0 + V.io[2]);
+            float val[kVPT];
+            row_taps<TIn>(p00, fracx, wx, full, jlo, jhi, val);
+            if (fracy) {
+                float t[kVPT];
+                row_taps<TIn>(p00 + V.stride_y, fracx, wx, full, jlo, jhi, t);
+                const float uy = 1.f - wy;
+#pragma unroll
+                for (int j = 0; j < kVPT; ++j) val[j] = fmaf(t[j], wy, val[j] * uy);
+            }
+            if (fracz) {
+                float v1[kVPT];
+                row_taps<TIn>(p00 + V.stride_z, fracx, wx, full, jlo, jhi, v1);
+                if (fracy) {
+                    float t[kVPT];
+                    row_taps<TIn>(p00 + V.stride_z + V.stride_y, fracx, wx, full, jlo, jhi, t);
+                    const float uy = 1.f - wy;
+#pragma unroll
+                    for (int j = 0; j < kVPT; ++j) v1[j] = fmaf(t[j], wy, v1[j] * uy);
+                }
+                const float uz = 1.f - wz;
+#pragma unroll
+                for (int j = 0; j < kVPT; ++j) val[j] = fmaf(v1[j], wz, val[j] * uz);
+            }
+
+            double cw0 = 0.0;
+            const double dwx = V.wm[8];
+            float dG = 0.f;
+            if (FUSION == MVS_FUSE_WEIGHTED_AVERAGE) {
+                cw0 = (double)xc0 * dwx + V.woff[2];
+                dG = G2 - G1;
+            }
+#pragma unroll
+            for (int j = 0; j < kVPT; ++j) {
+                if (j < jlo || j > jhi) continue;
+                const float v = val[j];
+                if (v != v) continue;
+                if (FUSION == MVS_FUSE_WEIGHTED_AVERAGE) {
+                    float w = 0.f;
+                    const double cw = cw0 + (double)j * dwx;
+                    if (wrow && cw >= 0.0 && cw <= 4.0) {
+                        const float u = (float)fmin(cw, 4.0 - cw);
+                        const float W = (u <= 1.f) ? u * G1 : fmaf(u - 1.f, dG, G1);
+                        w = blend_ramp(W);
+                    }
+                    wa_update(acc[j], den[j], w, v);
+                } else if (FUSION == MVS_FUSE_MAX) {
+                    acc[j] = fmaxf(acc[j], v);
+                    den[j] = 1.f;
+                } else {
+                    acc[j] += v;
+                    den[j] += 1.f;
+                }
+            }
+        }
+    }
+    if (!row_ok || x0 >= P.ox) return;
+    float r[kVPT];
+#pragma unroll
+    for (int j = 0; j < kVPT; ++j) {
+        float o;
+        if (FUSION == MVS_FUSE_MAX) o = (den[j] > 0.f) ? acc[j] : 0.f;
+        else if (FUSION == MVS_FUSE_WEIGHTED_AVERAGE) o = wa_result(acc[j], den[j]);
+        else o = (den[j] > 0.f) ? acc[j] / den[j] : 0.f;
+        if (o != o) o = 0.f;
+        r[j] = o;
+    }
+    store_row4<TOut>((TOut*)P.out, ((long long)z * P.oy + y) * (long long)P.ox, x0, P.ox, r);
+}
+
+// ---- host side of the fast path ---------------------------------------------------------------
+// c(i) = fl(i + off) is what the generic kernel (and scipy) test against [0, n-1] for an identity
+// matrix; it is monotone in i, so the in-bounds set is an integer interval found exactly here.
+static void exact_valid_range(double off, int n, int n_out, int* lo_out, int* hi_out) {
+    auto c = [off](long long i) { return (double)i + off; };
+    long long lo = (long long)ceil(-off);
+    while (lo > 0 && c(lo - 1) >= 0.0) --lo;
+    while (c(lo) < 0.0) ++lo;
+    long long hi = (long long)floor((double)(n - 1) - off);
+    while (c(hi + 1) <= (double)(n - 1)) ++hi;
+    while (c(hi) > (double)(n - 1)) --hi;
+    if (lo < 0) lo = 0;
+    if (hi > n_out - 1) hi = n_out - 1;
+    *lo_out = (int)lo;
+    *hi_out = (int)hi;   // lo > hi: the view never contributes
+}
+
+// Decide whether a view qualifies for the translation fast path and derive its constants.
+static void prepare_translation_view(DevView* d, int order, int fusion, const int64_t chunk_shape[3]) {
+    d->tr_ok = 0;
+    static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 9; ++k)
+        if (d->m[k] != I9[k]) return;
+    const int n[3] = {d->nz, d->ny, d->nx};
+    for (int k = 0; k < 3; ++k) {
+        if (!(fabs(d->off[k]) < 65536.0) || n[k] > 65536 || chunk_shape[k] > 65536) return;
+    }
+    if (fusion == MVS_FUSE_WEIGHTED_AVERAGE) {
+        const int offd[6] = {1, 2, 3, 5, 6, 7};
+        for (int k : offd)
+            if (d->wm[k] != 0.0) return;
+        // closed-form check of the support table: edt == min_d(ws_d * tent(i_d))
+        const int nz = d->wnz;
+        float sz = INFINITY, sy, sx;
+        if (nz == 5) {
+            sz = d->edt[(1 * 5 + 2) * 5 + 2];
+            sy = d->edt[(2 * 5 + 1) * 5 + 2];
+            sx = d->edt[(2 * 5 + 2) * 5 + 1];
+        } else {
+            sy = d->edt[1 * 5 + 2];
+            sx = d->edt[2 * 5 + 1];
+        }
+        for (int i = 0; i < nz; ++i)
+            for (int j = 0; j < 5; ++j)
+                for (int k = 0; k < 5; ++k) {
+                    float t = fminf(sy * (float)std::min(j, 4 - j), sx * (float)std::min(k, 4 - k));
+                    if (nz == 5) t = fminf(t, sz * (float)std::min(i, 4 - i));
+                    if (t != d->edt[(i * 5 + j) * 5 + k]) return;
+                }
+        d->ws[0] = (nz == 5) ? sz : 0.f;
+        d->ws[1] = sy;
+        d->ws[2] = sx;
+    }
+    for (int k = 0; k < 3; ++k) {
+        const double off = d->off[k];
+        if (order == 0) {
+            d->io[k] = (int)floor(off + 0.5);
+            d->fw[k] = 0.f;
+        } else {
+            const double f = floor(off);
+            d->io[k] = (int)f;
+            d->fw[k] = (float)(off - f);
+        }
+        exact_valid_range(off, n[k], (int)chunk_shape[k], &d->lo[k], &d->hi[k]);
+    }
+    d->tr_ok = 1;
 }
 
 // Single-view resample to float32 with an arbitrary cval (transformation.py:136-139).
@@ -374,6 +703,16 @@ void launch_fuse(const FuseParams& P, int order, int fusion, int nblocks, hipStr
         else MVS_LAUNCH(1, MVS_FUSE_SIMPLE_AVERAGE);
     }
 #undef MVS_LAUNCH
+}
+
+template <typename TIn, typename TOut>
+void launch_fuse_tr(const FuseParams& P, int fusion, int nblocks, hipStream_t s) {
+    if (fusion == MVS_FUSE_WEIGHTED_AVERAGE)
+        hipLaunchKernelGGL((fuse_tr_kernel<TIn, TOut, MVS_FUSE_WEIGHTED_AVERAGE>), dim3(nblocks), dim3(256), 0, s, P);
+    else if (fusion == MVS_FUSE_MAX)
+        hipLaunchKernelGGL((fuse_tr_kernel<TIn, TOut, MVS_FUSE_MAX>), dim3(nblocks), dim3(256), 0, s, P);
+    else
+        hipLaunchKernelGGL((fuse_tr_kernel<TIn, TOut, MVS_FUSE_SIMPLE_AVERAGE>), dim3(nblocks), dim3(256), 0, s, P);
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -453,7 +792,10 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
         }
         rc = fill_dev_view(c, views[i], opts->ndim, dptr, &hviews[i]);
         if (rc) return rc;
+        prepare_translation_view(&hviews[i], opts->order, opts->fusion, opts->out_shape);
     }
+    bool use_tr = !c->force_generic;
+    for (int i = 0; i < n_views && use_tr; ++i) use_tr = hviews[i].tr_ok != 0;
     MVS_HIP_TRY(c, hipMemcpyAsync(dviews, hviews, params_bytes, hipMemcpyHostToDevice, c->stream));
 
     const size_t out_bytes = (size_t)os[0] * os[1] * os[2] * es;
@@ -469,19 +811,33 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
     P.out = dout;
     P.oz = (int)os[0]; P.oy = (int)os[1]; P.ox = (int)os[2];
     P.tz = (int)opts->trim[0]; P.ty = (int)opts->trim[1]; P.tx = (int)opts->trim[2];
-    P.bz = (os[0] > 1) ? 4 : 1;
-    P.by = (os[0] > 1) ? 4 : 16;
+    if (use_tr) {
+        P.bz = (os[0] > 1) ? 2 : 1;
+        P.by = (os[0] > 1) ? 2 : 4;
+    } else {
+        P.bz = (os[0] > 1) ? 4 : 1;
+        P.by = (os[0] > 1) ? 4 : 16;
+    }
+    const int brick_x = use_tr ? kTrBrickX : kBrickX;
     P.nbz = (P.oz + P.bz - 1) / P.bz;
     P.nby = (P.oy + P.by - 1) / P.by;
-    P.nbx = (P.ox + kBrickX - 1) / kBrickX;
+    P.nbx = (P.ox + brick_x - 1) / brick_x;
     const long long nblocks = (long long)P.nbz * P.nby * P.nbx;
     if (nblocks > 0x7fffffffLL) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "chunk too large for one launch");
 
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
-    switch (dtype) {
-        case MVS_U8: launch_fuse<unsigned char, unsigned char>(P, opts->order, opts->fusion, (int)nblocks, c->stream); break;
-        case MVS_U16: launch_fuse<unsigned short, unsigned short>(P, opts->order, opts->fusion, (int)nblocks, c->stream); break;
-        default: launch_fuse<float, float>(P, opts->order, opts->fusion, (int)nblocks, c->stream); break;
+    if (use_tr) {
+        switch (dtype) {
+            case MVS_U8: launch_fuse_tr<unsigned char, unsigned char>(P, opts->fusion, (int)nblocks, c->stream); break;
+            case MVS_U16: launch_fuse_tr<unsigned short, unsigned short>(P, opts->fusion, (int)nblocks, c->stream); break;
+            default: launch_fuse_tr<float, float>(P, opts->fusion, (int)nblocks, c->stream); break;
+        }
+    } else {
+        switch (dtype) {
+            case MVS_U8: launch_fuse<unsigned char, unsigned char>(P, opts->order, opts->fusion, (int)nblocks, c->stream); break;
+            case MVS_U16: launch_fuse<unsigned short, unsigned short>(P, opts->order, opts->fusion, (int)nblocks, c->stream); break;
+            default: launch_fuse<float, float>(P, opts->order, opts->fusion, (int)nblocks, c->stream); break;
+        }
     }
     MVS_HIP_TRY(c, hipGetLastError());
     MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));

@@ -271,6 +271,7 @@ def fuse_np(
     blending_widths=None,
     shrink_distance=0,
     return_float=False,
+    return_debug=False,
 ):
     """fusion.fuse_np (_core.py:1513-1733) for the built-in fusion/weight funcs.
 
@@ -318,9 +319,11 @@ def fuse_np(
             ]
         )
         field_ws_t = field_ws_t * ~np.isnan(field_ims_t)
+        raw_ws_t = field_ws_t
         field_ws_t = normalize_weights(field_ws_t)
     else:
         field_ws_t = None
+        raw_ws_t = None
 
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", category=RuntimeWarning)
@@ -341,6 +344,10 @@ def fuse_np(
         ]
     fused_f = np.nan_to_num(fused)
     out = fused_f.astype(input_dtype)
+    if return_debug:
+        # float32 result plus what a test needs to bound the reference's OWN rounding noise:
+        # the masked, un-normalised blending weights and the resampled views (untrimmed)
+        return out, fused_f, {"raw_weights": raw_ws_t, "views": field_ims_t, "trim": trim}
     if return_float:
         return out, fused_f
     return out

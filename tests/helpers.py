@@ -37,7 +37,29 @@ def union_bb(views_bbs, params, spacing):
     return fo.bb(lo, spacing, shape)
 
 
-def assert_fused_close(got, want, want_float=None, rtol=1e-4, data_range=None, max_bad_frac=0.0):
+def reference_noise_floor(debug, fused_f, eps_w=1.2e-7):
+    """Bound on the reference's OWN float32 rounding noise per voxel.
+
+    The reference evaluates the cosine ramp as (cos((1-x)pi)+1)/2 in float32
+    (weights.py:502-507): cos() near -1 is rounded to 2^-24, so every ramp weight
+    carries an absolute error of ~6e-8 regardless of its size.  Where all
+    contributing weights are tiny (tile corners facing the mosaic border) that
+    noise is amplified by 1/sum(w):  |d out| <= sum_v |I_v - out| * eps_w / sum_v w_v.
+    The HIP kernel evaluates the same ramp as sin^2(pi x/2) (no cancellation), so
+    it can differ from the reference by up to this floor; the parity tolerance is
+    rtol*|want| + this floor."""
+    w, views, trim = debug["raw_weights"], debug["views"], debug["trim"]
+    if w is None:
+        return np.zeros_like(fused_f, dtype=np.float64)
+    sl = (slice(None),) + tuple(slice(t, -t) if t > 0 else slice(None) for t in trim)
+    w = w[sl].astype(np.float64)
+    v = np.nan_to_num(views[sl].astype(np.float64))
+    wsum = w.sum(0)
+    spread = (np.abs(v - fused_f.astype(np.float64)[None]) * (w > 0)).sum(0)
+    return np.where(wsum > 0, spread * eps_w / np.maximum(wsum, 1e-30), 0.0)
+
+
+def assert_fused_close(got, want, want_float=None, rtol=1e-4, data_range=None, max_bad_frac=0.0, noise_floor=None):
     """Parity bar of north_star: float32 fused voxels within 1e-4 relative; integer outputs within
     +-1 LSB (truncating cast after float accumulate) and exact where the float value is not within
     1e-4*range of an integer boundary."""
@@ -49,12 +71,15 @@ def assert_fused_close(got, want, want_float=None, rtol=1e-4, data_range=None, m
         assert diff.max() <= 1, f"integer output differs by {diff.max()} LSB"
         if want_float is not None and diff.max() == 1:
             frac = want_float - np.floor(want_float)
-            near = np.minimum(frac, 1 - frac) <= 1e-4 * np.maximum(np.abs(want_float), 1.0)
+            near = np.minimum(frac, 1 - frac) <= 1e-4 * np.maximum(np.abs(want_float), 1.0) + (
+                noise_floor if noise_floor is not None else 0.0)
             assert np.all(near[diff == 1]), "1-LSB flips away from an integer boundary"
         return
     rng = float(data_range) if data_range is not None else float(np.nanmax(np.abs(want)) or 1.0)
     err = np.abs(got.astype(np.float64) - want.astype(np.float64))
     tol = rtol * np.maximum(np.abs(want), 1e-3 * rng)
+    if noise_floor is not None:
+        tol = tol + noise_floor
     bad = err > tol
     assert bad.mean() <= max_bad_frac, (
         f"{bad.sum()} / {bad.size} voxels beyond rtol={rtol}; worst rel err "
