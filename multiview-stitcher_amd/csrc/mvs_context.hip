@@ -147,6 +147,10 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         c->force_generic = value != 0;
         return MVS_OK;
     }
+    if (!strcmp(key, "ablate")) {
+        c->ablate = (int)value;
+        return MVS_OK;
+    }
     return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_set_option: unknown key '%s'", key);
 }
 

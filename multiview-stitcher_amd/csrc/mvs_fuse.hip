@@ -25,6 +25,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 
 namespace {
 
@@ -49,7 +50,13 @@ struct DevView {
     float fw[3];      // fractional interpolation weights (0 => single tap on that axis)
     int lo[3], hi[3]; // chunk-index range where the view is in bounds, exact per scipy's test
     float ws[3];      // tent scales of the closed-form support table edt = min_d(ws_d * tent(i_d))
-    float pad[2];
+    float sup_k[3];   // support nodes per output pixel (= w_matrix diagonal)
+    // chunk-index coordinates of support nodes 0 and 4, split as ilo + flo and ihi - fhi with
+    // integer ilo/ihi and fractions in [0,1): distances to them are exact in float
+    int sup_ilo[3], sup_ihi[3];
+    float sup_flo[3], sup_fhi[3];
+    long long span;   // elements from data[0] to the last voxel of the slab, + 1
+    float pad[3];
 };
 
 struct FuseParams {
@@ -59,7 +66,9 @@ struct FuseParams {
     int oz, oy, ox;        // shape of the (trimmed) result
     int tz, ty, tx;        // trim: chunk index = result index + trim
     int nbz, nby, nbx;     // brick grid
-    int bz, by;            // brick extent along z and y (4,4) or (1,16)
+    int bz, by;            // brick extent along z and y
+    const int* cull;       // fast path: [6][nviews] valid chunk-index boxes (zlo,zhi,ylo,yhi,xlo,xhi)
+    int ablate;            // profiling only: 1 skip weights, 2 skip loads, 4 skip epilogue math, 8 skip accumulate
 };
 
 template <typename T> __device__ __forceinline__ float load_as_float(const T* p, long long i);
@@ -359,20 +368,29 @@ __device__ __forceinline__ void store_row4(TOut* out, long long row, int x0, int
 // a lane 4 consecutive voxels: inputs arrive as (unaligned) 8/16-byte vector loads per stencil
 // row, the result leaves as one aligned 8/16-byte store.
 // =============================================================================================
-constexpr int kTrBrickX = 256;
+constexpr int kTrBrickX = 256;   // voxels along x per wavefront (64 lanes x 4)
+constexpr int kTrRows = 4;       // consecutive y rows per wavefront
+constexpr int kTrPlanes = 4;     // z planes per workgroup (one per wavefront)
+
+#define MVS_GLOBAL __attribute__((address_space(1)))
 
 template <typename T> struct RowVec;
 template <> struct RowVec<unsigned short> { typedef unsigned short v4 __attribute__((ext_vector_type(4), aligned(2))); };
 template <> struct RowVec<unsigned char> { typedef unsigned char v4 __attribute__((ext_vector_type(4), aligned(1))); };
 template <> struct RowVec<float> { typedef float v4 __attribute__((ext_vector_type(4), aligned(4))); };
 
-// x-interpolated values of 4 consecutive output voxels from one input row.
-// p points at the first tap of voxel 0.  full: all 4 voxels (and their second taps) are in bounds.
+// x-interpolated values of a lane's 4 consecutive output voxels from one input row; p points at
+// the first tap of voxel 0.  `vec`: the 5-element window p[0..4] lies inside the slab allocation,
+// so it is fetched with one (unaligned) vector load + one scalar load even if some of the lane's
+// voxels are out of bounds (their values are discarded by the caller).  Otherwise (first/last
+// elements of a slab) every element is guarded.
 template <typename TIn>
-__device__ __forceinline__ void row_taps(const TIn* p, bool fracx, float wx, bool full, int jlo, int jhi, float r[4]) {
+__device__ __forceinline__ void row_taps(const MVS_GLOBAL TIn* p, bool fracx, float wx, bool vec, int jlo, int jhi,
+                                         float r[4]) {
     float e[5];
-    if (full) {
-        typename RowVec<TIn>::v4 v = *reinterpret_cast<const typename RowVec<TIn>::v4*>(p);
+    if (vec) {
+        typedef typename RowVec<TIn>::v4 V4;
+        const V4 v = *reinterpret_cast<const MVS_GLOBAL V4*>(p);
         e[0] = (float)v.x; e[1] = (float)v.y; e[2] = (float)v.z; e[3] = (float)v.w;
         e[4] = fracx ? (float)p[4] : 0.f;
     } else {
@@ -392,178 +410,484 @@ __device__ __forceinline__ void row_taps(const TIn* p, bool fracx, float wx, boo
     }
 }
 
-__device__ __forceinline__ float tent5(int i) { return (float)min(i, 4 - i); }
-
-// Row-uniform part of the blend weight: nodes G1, G2 (see header comment). Returns false if the
-// row lies outside the support along z or y (weight 0 everywhere, cval of the table resample).
-__device__ __forceinline__ bool blend_row_nodes(const DevView& V, double pz, double py, float& G1, float& G2) {
-    float az0 = INFINITY, az1 = INFINITY, fz = 0.f;
-    if (V.wnz > 1) {
-        const double cz = pz * V.wm[0] + V.woff[0];
-        if (cz < 0.0 || cz > 4.0) return false;
-        const double f = floor(cz);
-        const int i = (int)f;
-        fz = (float)(cz - f);
-        az0 = V.ws[0] * tent5(i);
-        az1 = V.ws[0] * tent5(min(i + 1, 4));
-    }
-    const double cy = py * V.wm[4] + V.woff[1];
-    if (cy < 0.0 || cy > 4.0) return false;
-    const double fy_ = floor(cy);
-    const int iy = (int)fy_;
-    const float fy = (float)(cy - fy_);
-    const float ay0 = V.ws[1] * tent5(iy), ay1 = V.ws[1] * tent5(min(iy + 1, 4));
-    const float uz = 1.f - fz, uy = 1.f - fy;
-    const float m00 = fminf(az0, ay0), m01 = fminf(az0, ay1), m10 = fminf(az1, ay0), m11 = fminf(az1, ay1);
-    const float a1 = V.ws[2], a2 = 2.f * V.ws[2];
-    // same association as the table interpolation: lerp along y, then along z
-    float g0 = fmaf(fminf(m01, a1), fy, fminf(m00, a1) * uy);
-    float g1 = fmaf(fminf(m11, a1), fy, fminf(m10, a1) * uy);
-    G1 = fmaf(g1, fz, g0 * uz);
-    g0 = fmaf(fminf(m01, a2), fy, fminf(m00, a2) * uy);
-    g1 = fmaf(fminf(m11, a2), fy, fminf(m10, a2) * uy);
-    G2 = fmaf(g1, fz, g0 * uz);
-    return true;
+// ---- blend weight in "distance" form -----------------------------------------------------------
+// Along one axis the support grid has nodes 0..4 at chunk indices sup_lo .. sup_hi.  With
+// dl = x - sup_lo and dh = sup_hi - x (output pixels; computed as (float)(x - ilo) - flo so that the
+// subtraction of the large parts is exact), the folded grid coordinate is u = min(dl, dh) * k in
+// [0,2] (k = nodes per pixel; u < 0: outside the support, weight 0).  The table is symmetric, so
+// nodes 3,4 fold onto 1,0.
+__device__ __forceinline__ float fold_u(int x, int ilo, float flo, int ihi, float fhi, float k) {
+    const float dl = (float)(x - ilo) - flo;
+    const float dh = (float)(ihi - x) - fhi;
+    return fminf(dl, dh) * k;
+}
+// Tent nodes bracketing folded coordinate u: a0 = s*i, a1 = s*(i+1), weight f = u - i, i in {0,1}.
+__device__ __forceinline__ void tent_cell(float u, float s, float& a0, float& a1, float& f) {
+    const float i = (u >= 1.f) ? 1.f : 0.f;
+    a0 = s * i;
+    a1 = s * (i + 1.f);
+    f = u - i;
+}
+// W along x from the row nodes: lerp over {0, G1, G2} at folded coordinate u.
+__device__ __forceinline__ float row_profile(float u, float G1, float dG) {
+    return (u <= 1.f) ? u * G1 : fmaf(u - 1.f, dG, G1);
+}
+// branch-free cosine ramp (same arithmetic as blend_ramp)
+__device__ __forceinline__ float blend_ramp_nb(float x) {
+    const float xc = fminf(fmaxf(x, 0.f), 1.f);
+    const float a = xc * kPiHalf;
+    const float a2 = a * a;
+    float s = fmaf(a2, 1.6059043836821613e-10f, -2.5052108385441720e-08f);
+    s = fmaf(s, a2, 2.7557319223985893e-06f);
+    s = fmaf(s, a2, -1.9841269841269841e-04f);
+    s = fmaf(s, a2, 8.3333333333333333e-03f);
+    s = fmaf(s, a2, -1.6666666666666666e-01f);
+    s = fmaf(s * a2, a, a);
+    const float c = fmaf(2.f, s * s, -1.f);
+    const float w = (c + 1.f) * 0.5f;
+    return (x >= 1.f) ? 1.f : w;
 }
 
+constexpr int kRowValid = 1, kRowInside = 2, kRowAllOne = 4;
+constexpr int kCand = 16;   // candidate views evaluated per round (16 views x 4 rows = 64 lanes)
+
+// Compact per-view record of the fast path (160 bytes = 10 x 16-byte loads per lane).
+struct alignas(16) TrView {
+    int lo[3], hi[3];            // valid chunk-index box (inclusive), exact per scipy's in-bounds test
+    int io[3];                   // input index = chunk index + io
+    int wnz;                     // 5 (3D support) or 1 (2D)
+    float fw[3];                 // fractional interpolation weights (0: single tap)
+    float pad0;
+    unsigned long long data;     // device pointer of the slab
+    long long span;              // elements from data[0] to the last voxel, + 1
+    int stride_y, stride_z;      // elements
+    int sup_ilo[3], sup_ihi[3];  // support nodes 0 / 4 in chunk-index units: ilo + flo, ihi - fhi
+    float sup_flo[3], sup_fhi[3];
+    float sup_k[3];              // support nodes per output pixel
+    float ws[3];                 // tent scales of the closed-form support table
+    int pad1[2];
+};
+static_assert(sizeof(TrView) == 160, "TrView layout");
+
+struct TrParams {
+    const TrView* views;
+    const int* cull;       // SoA [6][nviews]: zlo, zhi, ylo, yhi, xlo, xhi
+    int nviews;
+    void* out;
+    int oz, oy, ox;
+    int tz, ty, tx;
+    int nbz, nby, nbx;
+    int is3d;
+    int ablate;
+};
+
+union F4I4 {
+    float4 f;
+    int4 i;
+};
+
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+// Raw stencil-row fetch through a buffer resource: 4 consecutive elements (+ the 5th for the
+// x interpolation) per lane, any alignment, hardware bounds check (out-of-slab reads return 0).
+// The raw dwords live in a plain register array w[5]; decode() turns them into 5 floats.
+template <typename T, bool FIVE> struct RowIO;
+template <bool FIVE> struct RowIO<unsigned short, FIVE> {
+    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int vo, unsigned int (&w)[5]) {
+        const u32x2_t a = __builtin_amdgcn_raw_buffer_load_b64(r, vo, 0, 0);
+        w[0] = a.x; w[1] = a.y;
+        if (FIVE) w[2] = __builtin_amdgcn_raw_buffer_load_b16(r, vo + 8, 0, 0);
+    }
+    static __device__ __forceinline__ void decode(const unsigned int (&w)[5], float (&v)[5]) {
+        v[0] = (float)(w[0] & 0xffffu); v[1] = (float)(w[0] >> 16); v[2] = (float)(w[1] & 0xffffu); v[3] = (float)(w[1] >> 16);
+        v[4] = FIVE ? (float)(w[2] & 0xffffu) : 0.f;
+    }
+};
+template <bool FIVE> struct RowIO<unsigned char, FIVE> {
+    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int vo, unsigned int (&w)[5]) {
+        w[0] = __builtin_amdgcn_raw_buffer_load_b32(r, vo, 0, 0);
+        if (FIVE) w[1] = __builtin_amdgcn_raw_buffer_load_b8(r, vo + 4, 0, 0);
+    }
+    static __device__ __forceinline__ void decode(const unsigned int (&w)[5], float (&v)[5]) {
+        v[0] = (float)(w[0] & 0xffu); v[1] = (float)((w[0] >> 8) & 0xffu); v[2] = (float)((w[0] >> 16) & 0xffu); v[3] = (float)(w[0] >> 24);
+        v[4] = FIVE ? (float)(w[1] & 0xffu) : 0.f;
+    }
+};
+template <bool FIVE> struct RowIO<float, FIVE> {
+    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int vo, unsigned int (&w)[5]) {
+        const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(r, vo, 0, 0);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+        if (FIVE) w[4] = __builtin_amdgcn_raw_buffer_load_b32(r, vo + 16, 0, 0);
+    }
+    static __device__ __forceinline__ void decode(const unsigned int (&w)[5], float (&v)[5]) {
+        v[0] = __uint_as_float(w[0]); v[1] = __uint_as_float(w[1]); v[2] = __uint_as_float(w[2]); v[3] = __uint_as_float(w[3]);
+        v[4] = FIVE ? __uint_as_float(w[4]) : 0.f;
+    }
+};
+
+__device__ __forceinline__ int rl(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ float rlf(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+
+// A vector buffer load whose byte range is not entirely inside the slab (it starts before the
+// first byte, ends after the last one, or a dword straddles either) comes back as 0 from the
+// bounds check although part of it is in range.  Only windows touching the very first / last
+// elements of a slab are affected; they are re-fetched element by element here.
+template <typename TIn>
+__device__ __forceinline__ void row_refetch(__amdgpu_buffer_rsrc_t r, int o, unsigned int (&w)[5]) {
+    float v[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int oj = o + j * (int)sizeof(TIn);
+        if (sizeof(TIn) == 2) v[j] = (float)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, oj, 0, 0);
+        else if (sizeof(TIn) == 1) v[j] = (float)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(r, oj, 0, 0);
+        else {
+            v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, oj, 0, 0));
+            // keep the dword loads separate: merged into one dwordx4 they would fail the range
+            // check as a whole again
+            asm volatile("" ::: "memory");
+        }
+    }
+    if (sizeof(TIn) == 2) {
+        w[0] = (unsigned)v[0] | ((unsigned)v[1] << 16);
+        w[1] = (unsigned)v[2] | ((unsigned)v[3] << 16);
+        w[2] = (unsigned)v[4];
+    } else if (sizeof(TIn) == 1) {
+        w[0] = (unsigned)v[0] | ((unsigned)v[1] << 8) | ((unsigned)v[2] << 16) | ((unsigned)v[3] << 24);
+        w[1] = (unsigned)v[4];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) w[j] = __float_as_uint(v[j]);
+    }
+}
+
+constexpr int kTrGroups = 8;   // row groups (of kTrRows rows) a wavefront walks with one culled view list
+
+// Wavefront-independent fast-path kernel: no hand-offs between wavefronts, no barriers.
+// Each wavefront owns a column of kTrGroups x kTrRows consecutive y rows x 256 voxels of one z plane.
+//  1. lanes test 64 views at a time against the column's box (coalesced SoA loads + ballot);
+//  2. up to 16 surviving views are spread over the lanes (lane>>2 = view slot): every lane gathers
+//     its view's record once; per row group, lane (slot, r) evaluates the row-uniform part of the
+//     blend weight of row r (nodes G1, dG, flags) from registers;
+//  3. per group a uniform loop walks the candidates: per-view constants and row nodes come out of
+//     the lanes with v_readlane (scalar registers), all stencil rows of the view are fetched
+//     back-to-back with bounds-checked buffer loads (one memory round trip per view and group),
+//     then interpolated and accumulated.
+// Accumulators per voxel: num = sum w*v, den = sum w, and (last, wlast) = value/weight of the last
+// view that contributed with a ramp weight.  A voxel whose only contributor has weight w < 1 must
+// come out as v exactly (normalised weight w/w == 1 in the reference): that is den == wlast.
 template <typename TIn, typename TOut, int FUSION>
-__global__ __launch_bounds__(256) void fuse_tr_kernel(FuseParams P) {
-    __shared__ int s_act[64];
-    __shared__ int s_nact;
+__global__ __launch_bounds__(256) void fuse_tr_kernel(TrParams P) {
+    __shared__ int s_list[4][64];
+    constexpr bool ISF = std::is_floating_point<TIn>::value;
+    constexpr int ES = (int)sizeof(TIn);
+    constexpr bool WA = (FUSION == MVS_FUSE_WEIGHTED_AVERAGE);
+    constexpr int kColRows = kTrGroups * kTrRows;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int b = blockIdx.x;
     const int bx = b % P.nbx;
     b /= P.nbx;
     const int byi = b % P.nby;
     const int bzi = b / P.nby;
-    int z, y;
-    if (P.bz == 2) {
-        z = bzi * 2 + (wave >> 1);
-        y = byi * 2 + (wave & 1);
-    } else {
-        z = bzi;
-        y = byi * 4 + wave;
-    }
+    const int z = P.is3d ? bzi * kTrPlanes + wave : bzi;
+    const int ycol = P.is3d ? byi * kColRows : (byi * 4 + wave) * kColRows;   // first row of the column
     const int x0 = bx * kTrBrickX + lane * kVPT;
-    const bool row_ok = (z < P.oz) && (y < P.oy);
-    const int zc = z + P.tz, yc = y + P.ty, xc0 = x0 + P.tx;   // chunk indices
-    // brick box in chunk indices (for culling)
-    const int bz0 = bzi * P.bz + P.tz, bz1 = min(bzi * P.bz + P.bz, P.oz) - 1 + P.tz;
-    const int by0 = byi * P.by + P.ty, by1 = min(byi * P.by + P.by, P.oy) - 1 + P.ty;
+    if (z >= P.oz || ycol >= P.oy) return;   // wave uniform; no barriers below
+    const int zc = z + P.tz, xc0 = x0 + P.tx;   // chunk indices
+    const int ycA = ycol + P.ty, ycB = min(ycol + kColRows, P.oy) - 1 + P.ty;
     const int bx0 = bx * kTrBrickX + P.tx, bx1 = min(bx * kTrBrickX + kTrBrickX, P.ox) - 1 + P.tx;
 
-    float acc[kVPT], den[kVPT];
-#pragma unroll
-    for (int j = 0; j < kVPT; ++j) {
-        acc[j] = (FUSION == MVS_FUSE_MAX) ? -INFINITY : 0.f;
-        den[j] = 0.f;
-    }
-
+    // ---- 1. cull: all views whose box meets this column (view order preserved) ----
+    int ntot = 0;
     for (int base = 0; base < P.nviews; base += 64) {
-        __syncthreads();
-        if (wave == 0) {
-            const int v = base + lane;
-            bool act = false;
-            if (v < P.nviews) {
-                const DevView& V = P.views[v];
-                act = V.lo[0] <= bz1 && V.hi[0] >= bz0 && V.lo[1] <= by1 && V.hi[1] >= by0 && V.lo[2] <= bx1 &&
-                      V.hi[2] >= bx0;
-            }
-            const unsigned long long mask = __ballot(act);
-            if (act) s_act[__popcll(mask & ((1ull << lane) - 1ull))] = v;
-            if (lane == 0) s_nact = __popcll(mask);
+        const int v = base + lane;
+        bool act = false;
+        if (v < P.nviews) {
+            const int* cb = P.cull + v;
+            const int nv = P.nviews;
+            act = cb[0] <= zc && cb[nv] >= zc && cb[2 * nv] <= ycB && cb[3 * nv] >= ycA && cb[4 * nv] <= bx1 &&
+                  cb[5 * nv] >= bx0;
         }
-        __syncthreads();
-        const int nact = s_nact;
-        if (!row_ok) continue;
+        const unsigned long long m = __ballot(act);
+        const int pos = ntot + __popcll(m & ((1ull << lane) - 1ull));
+        if (act && pos < 64) s_list[wave][pos] = v;
+        ntot += (int)__popcll(m);
+    }
+    // more than 64 views on one column: beyond this kernel's list (the host falls back to the
+    // generic kernel when a chunk has that many mutually overlapping views; see mvs_fuse_chunk)
+    ntot = min(ntot, 64);
 
-        for (int a = 0; a < nact; ++a) {
-            const int vi = __builtin_amdgcn_readfirstlane(s_act[a]);
-            const DevView& V = P.views[vi];
-            if (zc < V.lo[0] || zc > V.hi[0] || yc < V.lo[1] || yc > V.hi[1]) continue;   // wave uniform
-            const int xlo = V.lo[2], xhi = V.hi[2];
-            const int jlo = max(xlo - xc0, 0), jhi = min(xhi - xc0, kVPT - 1);
-            const bool any = jlo <= jhi;
-            const bool full = (jlo == 0) && (jhi == kVPT - 1);
-            float G1 = 0.f, G2 = 0.f;
-            bool wrow = true;
-            if (FUSION == MVS_FUSE_WEIGHTED_AVERAGE) wrow = blend_row_nodes(V, (double)zc, (double)yc, G1, G2);
-            if (!any) continue;
+    for (int g = 0; g < kTrGroups; ++g) {
+        const int y0 = ycol + g * kTrRows;
+        if (y0 >= P.oy) break;
+        const int yc0 = y0 + P.ty;
+        const int yc1 = min(y0 + kTrRows, P.oy) - 1 + P.ty;
 
-            const float wz = V.fw[0], wy = V.fw[1], wx = V.fw[2];
-            const bool fracz = wz > 0.f, fracy = wy > 0.f, fracx = wx > 0.f;
-            const TIn* p00 = (const TIn*)V.data + (long long)(zc + V.io[0]) * V.stride_z +
-                             (long long)(yc + V.io[1]) * V.stride_y + (xc0 + V.io[2]);
-            float val[kVPT];
-            row_taps<TIn>(p00, fracx, wx, full, jlo, jhi, val);
-            if (fracy) {
-                float t[kVPT];
-                row_taps<TIn>(p00 + V.stride_y, fracx, wx, full, jlo, jhi, t);
-                const float uy = 1.f - wy;
+        float num[kTrRows][kVPT], den[kTrRows][kVPT], last[kTrRows][kVPT], wlast[kTrRows][kVPT];
 #pragma unroll
-                for (int j = 0; j < kVPT; ++j) val[j] = fmaf(t[j], wy, val[j] * uy);
-            }
-            if (fracz) {
-                float v1[kVPT];
-                row_taps<TIn>(p00 + V.stride_z, fracx, wx, full, jlo, jhi, v1);
-                if (fracy) {
-                    float t[kVPT];
-                    row_taps<TIn>(p00 + V.stride_z + V.stride_y, fracx, wx, full, jlo, jhi, t);
-                    const float uy = 1.f - wy;
-#pragma unroll
-                    for (int j = 0; j < kVPT; ++j) v1[j] = fmaf(t[j], wy, v1[j] * uy);
-                }
-                const float uz = 1.f - wz;
-#pragma unroll
-                for (int j = 0; j < kVPT; ++j) val[j] = fmaf(v1[j], wz, val[j] * uz);
-            }
-
-            double cw0 = 0.0;
-            const double dwx = V.wm[8];
-            float dG = 0.f;
-            if (FUSION == MVS_FUSE_WEIGHTED_AVERAGE) {
-                cw0 = (double)xc0 * dwx + V.woff[2];
-                dG = G2 - G1;
-            }
+        for (int r = 0; r < kTrRows; ++r)
 #pragma unroll
             for (int j = 0; j < kVPT; ++j) {
-                if (j < jlo || j > jhi) continue;
-                const float v = val[j];
-                if (v != v) continue;
-                if (FUSION == MVS_FUSE_WEIGHTED_AVERAGE) {
-                    float w = 0.f;
-                    const double cw = cw0 + (double)j * dwx;
-                    if (wrow && cw >= 0.0 && cw <= 4.0) {
-                        const float u = (float)fmin(cw, 4.0 - cw);
-                        const float W = (u <= 1.f) ? u * G1 : fmaf(u - 1.f, dG, G1);
-                        w = blend_ramp(W);
+                num[r][j] = (FUSION == MVS_FUSE_MAX) ? -INFINITY : 0.f;
+                den[r][j] = 0.f;
+                last[r][j] = 0.f;
+                wlast[r][j] = 0.f;
+            }
+
+        for (int c0 = 0; c0 < ntot; c0 += kCand) {
+            const int ncand = min(ntot - c0, kCand);
+            // ---- 2. lane (c, r) = (lane >> 2, lane & 3): record of candidate c, row-uniform part of row r ----
+            const int c_ = lane >> 2, r_ = lane & 3;
+            const bool has = c_ < ncand;
+            const int myv = s_list[wave][c0 + (has ? c_ : 0)];
+            const float4* rec = reinterpret_cast<const float4*>(P.views + myv);
+            F4I4 q0, q1, q2, q3, q4, q5, q6, q7, q8, q9;
+            q0.f = rec[0]; q1.f = rec[1]; q2.f = rec[2]; q3.f = rec[3]; q4.f = rec[4];
+            q5.f = rec[5]; q6.f = rec[6]; q7.f = rec[7]; q8.f = rec[8]; q9.f = rec[9];
+            // field map (dwords): 0-2 lo, 3-5 hi, 6-8 io, 9 wnz, 10-12 fw, 13 pad, 14-15 data, 16-17 span,
+            // 18 stride_y, 19 stride_z, 20-22 sup_ilo, 23-25 sup_ihi, 26-28 sup_flo, 29-31 sup_fhi,
+            // 32-34 sup_k, 35-37 ws
+            const int lo_z = q0.i.x, lo_y = q0.i.y, lo_x = q0.i.z, hi_z = q0.i.w, hi_y = q1.i.x, hi_x = q1.i.y;
+            const int io_z = q1.i.z, io_y = q1.i.w, io_x = q2.i.x, wnz = q2.i.y;
+            const float fw_z = q2.f.z, fw_y = q2.f.w, fw_x = q3.f.x;
+            const int data_lo = q3.i.z, data_hi = q3.i.w, span_lo = q4.i.x;
+            const int st_y = q4.i.z, st_z = q4.i.w;
+            const int silo_z = q5.i.x, silo_y = q5.i.y, silo_x = q5.i.z, sihi_z = q5.i.w, sihi_y = q6.i.x, sihi_x = q6.i.y;
+            const float sflo_z = q6.f.z, sflo_y = q6.f.w, sflo_x = q7.f.x, sfhi_z = q7.f.y, sfhi_y = q7.f.z, sfhi_x = q7.f.w;
+            const float sk_z = q8.f.x, sk_y = q8.f.y, sk_x = q8.f.z, ws_z = q8.f.w, ws_y = q9.f.x, ws_x = q9.f.y;
+
+            int flags = 0;
+            float G1 = 0.f, dG = 0.f;
+            {
+                const int ry = yc0 + r_;
+                const int xa = max(bx0, lo_x), xb = min(bx1, hi_x);
+                if (has && zc >= lo_z && zc <= hi_z && ry >= lo_y && ry <= hi_y && ry <= yc1 && xa <= xb) {
+                    flags = kRowValid;
+                    if (WA) {
+                        float az0 = INFINITY, az1 = INFINITY, fz = 0.f, uz = 0.f;
+                        const bool has_z = wnz > 1;
+                        if (has_z) {
+                            uz = fold_u(zc, silo_z, sflo_z, sihi_z, sfhi_z, sk_z);
+                            tent_cell(fmaxf(uz, 0.f), ws_z, az0, az1, fz);
+                        }
+                        const float uy = fold_u(ry, silo_y, sflo_y, sihi_y, sfhi_y, sk_y);
+                        if (uz >= 0.f && uy >= 0.f) {
+                            flags |= kRowInside;
+                            float ay0, ay1, fy;
+                            tent_cell(uy, ws_y, ay0, ay1, fy);
+                            const float uz_ = 1.f - fz, uy_ = 1.f - fy;
+                            const float m00 = fminf(az0, ay0), m01 = fminf(az0, ay1), m10 = fminf(az1, ay0), m11 = fminf(az1, ay1);
+                            const float a1 = ws_x, a2 = 2.f * ws_x;
+                            // same association as the table interpolation: lerp along y, then z
+                            float g0 = fmaf(fminf(m01, a1), fy, fminf(m00, a1) * uy_);
+                            float g1 = fmaf(fminf(m11, a1), fy, fminf(m10, a1) * uy_);
+                            G1 = has_z ? fmaf(g1, fz, g0 * uz_) : g0;
+                            g0 = fmaf(fminf(m01, a2), fy, fminf(m00, a2) * uy_);
+                            g1 = fmaf(fminf(m11, a2), fy, fminf(m10, a2) * uy_);
+                            const float G2 = has_z ? fmaf(g1, fz, g0 * uz_) : g0;
+                            dG = G2 - G1;
+                            // W(x) is concave piecewise linear along the row: >= 1 at both ends of the
+                            // covered part of the segment => every voxel's weight is exactly 1.
+                            const float ua = fold_u(xa, silo_x, sflo_x, sihi_x, sfhi_x, sk_x);
+                            const float ub = fold_u(xb, silo_x, sflo_x, sihi_x, sfhi_x, sk_x);
+                            if (ua >= 0.f && ub >= 0.f && row_profile(ua, G1, dG) >= 1.f && row_profile(ub, G1, dG) >= 1.f)
+                                flags |= kRowAllOne;
+                        }
                     }
-                    wa_update(acc[j], den[j], w, v);
-                } else if (FUSION == MVS_FUSE_MAX) {
-                    acc[j] = fmaxf(acc[j], v);
-                    den[j] = 1.f;
+                }
+            }
+
+            // ---- 3. uniform walk over the candidates ----
+            if (P.ablate & 16) {   // profiling: stop after the row-uniform part
+                num[0][0] += G1 + dG + (float)flags;
+                continue;
+            }
+            for (int c = 0; c < ncand; ++c) {
+                const int l0 = c * 4;
+                int fl[kTrRows];
+                int anyf = 0, needw = 0;
+#pragma unroll
+                for (int r = 0; r < kTrRows; ++r) {
+                    fl[r] = rl(flags, l0 + r);
+                    anyf |= fl[r];
+                    needw |= (fl[r] & kRowValid) && !(fl[r] & kRowAllOne);
+                }
+                if (!(anyf & kRowValid)) continue;
+                const int xlo = rl(lo_x, l0), xhi = rl(hi_x, l0);
+                const bool fullseg = (xlo <= bx0) && (xhi >= bx1);   // every lane of the segment is inside the view
+                const float wz = rlf(fw_z, l0), wy = rlf(fw_y, l0), wx = rlf(fw_x, l0);
+                const bool anyfrac = (wz > 0.f) || (wy > 0.f) || (wx > 0.f);
+                const int sy = rl(st_y, l0), sz = rl(st_z, l0);
+                const unsigned long long dptr = ((unsigned long long)(unsigned)rl(data_hi, l0) << 32) | (unsigned)rl(data_lo, l0);
+                const int nbytes = rl(span_lo, l0) * ES;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dptr, 0, nbytes, 0x00020000);
+                // byte offset of voxel 0's first tap; lanes far outside the slab get a sentinel (reads return 0)
+                const long long ebytes = ((long long)(zc + rl(io_z, l0)) * sz + (long long)(yc0 + rl(io_y, l0)) * sy +
+                                          (xc0 + rl(io_x, l0))) * ES;
+                const bool e_ok = (ebytes > -(1ll << 29)) && (ebytes < (1ll << 30) + (1ll << 29));
+                const int vo = e_ok ? (int)ebytes : 0x7f000000;
+                constexpr int WB = 5 * ES;   // bytes of one 5-element window
+
+                if (P.ablate & 32) {   // profiling: stop after the per-view scalar setup
+                    num[0][1] += (float)vo + wz + wy + wx + (float)xlo + (float)fullseg;
+                    continue;
+                }
+                float S[kTrRows + 1][kVPT];
+                if (anyfrac) {
+                    unsigned int raw0[kTrRows + 1][5], raw1[kTrRows + 1][5];
+#pragma unroll
+                    for (int k = 0; k <= kTrRows; ++k) {
+                        RowIO<TIn, true>::load(rsrc, vo + k * sy * ES, raw0[k]);
+                        RowIO<TIn, true>::load(rsrc, vo + (k * sy + sz) * ES, raw1[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k <= kTrRows; ++k) {
+                        const int o0 = vo + k * sy * ES, o1 = vo + (k * sy + sz) * ES;
+                        if (__any((o0 < 0 && o0 + WB > 0) || (o0 < nbytes && o0 + WB > nbytes))) row_refetch<TIn>(rsrc, o0, raw0[k]);
+                        if (__any((o1 < 0 && o1 + WB > 0) || (o1 < nbytes && o1 + WB > nbytes))) row_refetch<TIn>(rsrc, o1, raw1[k]);
+                    }
+                    const float ux = 1.f - wx, uz = 1.f - wz;
+#pragma unroll
+                    for (int k = 0; k <= kTrRows; ++k) {
+                        float e[5], f[5];
+                        RowIO<TIn, true>::decode(raw0[k], e);
+                        RowIO<TIn, true>::decode(raw1[k], f);
+#pragma unroll
+                        for (int j = 0; j < kVPT; ++j) {
+                            const float t0 = fmaf(e[j + 1], wx, e[j] * ux);
+                            const float t1 = fmaf(f[j + 1], wx, f[j] * ux);
+                            S[k][j] = fmaf(t1, wz, t0 * uz);
+                        }
+                    }
                 } else {
-                    acc[j] += v;
-                    den[j] += 1.f;
+                    unsigned int raw0[kTrRows][5];
+#pragma unroll
+                    for (int k = 0; k < kTrRows; ++k) RowIO<TIn, false>::load(rsrc, vo + k * sy * ES, raw0[k]);
+#pragma unroll
+                    for (int k = 0; k < kTrRows; ++k) {
+                        const int o0 = vo + k * sy * ES;
+                        if (__any((o0 < 0 && o0 + WB > 0) || (o0 < nbytes && o0 + WB > nbytes))) row_refetch<TIn>(rsrc, o0, raw0[k]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < kTrRows; ++k) {
+                        float e[5];
+                        RowIO<TIn, false>::decode(raw0[k], e);
+#pragma unroll
+                        for (int j = 0; j < kVPT; ++j) S[k][j] = e[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < kVPT; ++j) S[kTrRows][j] = 0.f;
+                }
+                if (P.ablate & 2) {
+#pragma unroll
+                    for (int k = 0; k <= kTrRows; ++k)
+#pragma unroll
+                        for (int j = 0; j < kVPT; ++j) S[k][j] = (float)(j + k);
+                }
+
+                bool okj[kVPT];
+                {
+                    const int jlo = xlo - xc0, jw = xhi - xlo;
+#pragma unroll
+                    for (int j = 0; j < kVPT; ++j) okj[j] = (unsigned)(j - jlo) <= (unsigned)jw;
+                }
+                float dl0 = 0.f, dh0 = 0.f, kx = 0.f;
+                if (WA && needw) {
+                    kx = rlf(sk_x, l0);
+                    dl0 = (float)(xc0 - rl(silo_x, l0)) - rlf(sflo_x, l0);
+                    dh0 = (float)(rl(sihi_x, l0) - xc0) - rlf(sfhi_x, l0);
+                }
+                const float uy = 1.f - wy;
+
+#pragma unroll
+                for (int r = 0; r < kTrRows; ++r) {
+                    if (!(fl[r] & kRowValid)) continue;   // wave uniform
+                    float val[kVPT];
+#pragma unroll
+                    for (int j = 0; j < kVPT; ++j) val[j] = anyfrac ? fmaf(S[r + 1][j], wy, S[r][j] * uy) : S[r][j];
+
+                    if (WA) {
+                        if (P.ablate & 8) {
+#pragma unroll
+                            for (int j = 0; j < kVPT; ++j) num[r][j] += val[j];
+                            continue;
+                        }
+                        const bool allone = (fl[r] & kRowAllOne) || (P.ablate & 1);
+                        if (allone && fullseg && !ISF) {
+#pragma unroll
+                            for (int j = 0; j < kVPT; ++j) {
+                                num[r][j] += val[j];
+                                den[r][j] += 1.f;
+                            }
+                        } else if (allone) {
+#pragma unroll
+                            for (int j = 0; j < kVPT; ++j) {
+                                const bool ok = ISF ? (okj[j] && val[j] == val[j]) : okj[j];
+                                num[r][j] += ok ? val[j] : 0.f;
+                                den[r][j] += ok ? 1.f : 0.f;
+                            }
+                        } else {
+                            const float G1r = rlf(G1, l0 + r), dGr = rlf(dG, l0 + r);
+                            const bool inside = fl[r] & kRowInside;
+#pragma unroll
+                            for (int j = 0; j < kVPT; ++j) {
+                                const float u = fminf(dl0 + (float)j, dh0 - (float)j) * kx;
+                                const float W = row_profile(u, G1r, dGr);
+                                float w = (u >= 0.f && inside) ? blend_ramp_nb(W) : 0.f;
+                                const bool ok = ISF ? (okj[j] && val[j] == val[j]) : okj[j];
+                                w = ok ? w : 0.f;
+                                const bool pos = w > 0.f;
+                                const float ve = pos ? val[j] : 0.f;
+                                num[r][j] = fmaf(w, ve, num[r][j]);
+                                den[r][j] += w;
+                                // bit-select instead of ?: -- hipcc turns the paired float selects into a select
+                                // between two stack slots (scratch traffic)
+                                const int pm = pos ? -1 : 0;
+                                last[r][j] = __int_as_float((__float_as_int(val[j]) & pm) | (__float_as_int(last[r][j]) & ~pm));
+                                wlast[r][j] = __int_as_float((__float_as_int(w) & pm) | (__float_as_int(wlast[r][j]) & ~pm));
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < kVPT; ++j) {
+                            const bool ok = ISF ? (okj[j] && val[j] == val[j]) : okj[j];
+                            if (FUSION == MVS_FUSE_MAX) num[r][j] = ok ? fmaxf(num[r][j], val[j]) : num[r][j];
+                            else num[r][j] += ok ? val[j] : 0.f;
+                            den[r][j] += ok ? 1.f : 0.f;
+                        }
+                    }
+                }
+            }
+        }
+
+        // ---- epilogue of this row group ----
+        if (x0 < P.ox) {
+#pragma unroll
+            for (int r = 0; r < kTrRows; ++r) {
+                const int y = y0 + r;
+                if (y < P.oy) {
+                    float o[kVPT];
+#pragma unroll
+                    for (int j = 0; j < kVPT; ++j) {
+                        float q;
+                        if (P.ablate & 4) q = num[r][j] + den[r][j] + last[r][j] + wlast[r][j];
+                        else if (FUSION == MVS_FUSE_MAX) q = (den[r][j] > 0.f) ? num[r][j] : 0.f;
+                        else if (WA) {
+                            q = num[r][j] * __builtin_amdgcn_rcpf(den[r][j]);
+                            // only contributor had a ramp weight: its normalised weight is w/w == 1 -> the value itself
+                            q = (den[r][j] == wlast[r][j]) ? last[r][j] : q;
+                        } else q = num[r][j] / den[r][j];
+                        if (!(fabsf(q) <= 3.4028234e38f)) q = 0.f;   // 0/0, x/0, NaN -> nan_to_num; no view -> 0
+                        o[j] = q;
+                    }
+                    store_row4<TOut>((TOut*)P.out, ((long long)z * P.oy + y) * (long long)P.ox, x0, P.ox, o);
                 }
             }
         }
     }
-    if (!row_ok || x0 >= P.ox) return;
-    float r[kVPT];
-#pragma unroll
-    for (int j = 0; j < kVPT; ++j) {
-        float o;
-        if (FUSION == MVS_FUSE_MAX) o = (den[j] > 0.f) ? acc[j] : 0.f;
-        else if (FUSION == MVS_FUSE_WEIGHTED_AVERAGE) o = wa_result(acc[j], den[j]);
-        else o = (den[j] > 0.f) ? acc[j] / den[j] : 0.f;
-        if (o != o) o = 0.f;
-        r[j] = o;
-    }
-    store_row4<TOut>((TOut*)P.out, ((long long)z * P.oy + y) * (long long)P.ox, x0, P.ox, r);
 }
 
 // ---- host side of the fast path ---------------------------------------------------------------
@@ -618,7 +942,26 @@ static void prepare_translation_view(DevView* d, int order, int fusion, const in
         d->ws[0] = (nz == 5) ? sz : 0.f;
         d->ws[1] = sy;
         d->ws[2] = sx;
+        for (int k = 0; k < 3; ++k) {
+            d->sup_k[k] = 0.f;
+            d->sup_ilo[k] = d->sup_ihi[k] = 0;
+            d->sup_flo[k] = d->sup_fhi[k] = 0.f;
+            if (k == 0 && nz == 1) continue;
+            const double wm = d->wm[k * 4], wo = d->woff[k];
+            if (!(wm > 0.0)) return;
+            const double lo = -wo / wm;          // chunk index where the support coordinate is 0
+            const double hi = (4.0 - wo) / wm;   // ... and 4
+            if (!(fabs(lo) < 1e6) || !(fabs(hi) < 1e6)) return;
+            d->sup_k[k] = (float)wm;
+            d->sup_ilo[k] = (int)floor(lo);
+            d->sup_flo[k] = (float)(lo - floor(lo));
+            d->sup_ihi[k] = (int)ceil(hi);
+            d->sup_fhi[k] = (float)(ceil(hi) - hi);
+        }
     }
+    d->span = (long long)(d->nz - 1) * d->stride_z + (long long)(d->ny - 1) * d->stride_y + d->nx;
+    if (d->stride_z > 0x7fffffffLL || d->stride_y > 0x7fffffffLL || d->stride_z < 0 || d->stride_y < 0) return;
+    if (d->span * 4 >= (1ll << 30)) return;   // 32-bit byte offsets in the buffer loads (any dtype <= 4 B)
     for (int k = 0; k < 3; ++k) {
         const double off = d->off[k];
         if (order == 0) {
@@ -705,8 +1048,29 @@ void launch_fuse(const FuseParams& P, int order, int fusion, int nblocks, hipStr
 #undef MVS_LAUNCH
 }
 
+static void fill_tr_view(const DevView& d, TrView* t) {
+    memset(t, 0, sizeof(*t));
+    for (int k = 0; k < 3; ++k) {
+        t->lo[k] = d.lo[k];
+        t->hi[k] = d.hi[k];
+        t->io[k] = d.io[k];
+        t->fw[k] = d.fw[k];
+        t->sup_ilo[k] = d.sup_ilo[k];
+        t->sup_ihi[k] = d.sup_ihi[k];
+        t->sup_flo[k] = d.sup_flo[k];
+        t->sup_fhi[k] = d.sup_fhi[k];
+        t->sup_k[k] = d.sup_k[k];
+        t->ws[k] = d.ws[k];
+    }
+    t->wnz = d.wnz;
+    t->data = (unsigned long long)d.data;
+    t->span = d.span;
+    t->stride_y = (int)d.stride_y;
+    t->stride_z = (int)d.stride_z;
+}
+
 template <typename TIn, typename TOut>
-void launch_fuse_tr(const FuseParams& P, int fusion, int nblocks, hipStream_t s) {
+void launch_fuse_tr(const TrParams& P, int fusion, int nblocks, hipStream_t s) {
     if (fusion == MVS_FUSE_WEIGHTED_AVERAGE)
         hipLaunchKernelGGL((fuse_tr_kernel<TIn, TOut, MVS_FUSE_WEIGHTED_AVERAGE>), dim3(nblocks), dim3(256), 0, s, P);
     else if (fusion == MVS_FUSE_MAX)
@@ -775,7 +1139,9 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
         slab_base = (char*)mvs_scratch(c, 0, host_bytes);
         if (!slab_base) return MVS_ERR_HIP;
     }
-    const size_t params_bytes = sizeof(DevView) * (size_t)n_views;
+    const size_t views_bytes = align_up(sizeof(DevView) * (size_t)n_views, 256);
+    const size_t cull_bytes = align_up(sizeof(int) * 6 * (size_t)n_views, 256);
+    const size_t params_bytes = views_bytes + cull_bytes + sizeof(TrView) * (size_t)n_views;
     DevView* hviews = (DevView*)mvs_pinned(c, params_bytes);
     if (!hviews) return MVS_ERR_HIP;
     DevView* dviews = (DevView*)mvs_scratch(c, 2, params_bytes);
@@ -796,6 +1162,16 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
     }
     bool use_tr = !c->force_generic;
     for (int i = 0; i < n_views && use_tr; ++i) use_tr = hviews[i].tr_ok != 0;
+    int* hcull = (int*)((char*)hviews + views_bytes);
+    TrView* htr = (TrView*)((char*)hviews + views_bytes + cull_bytes);
+    if (use_tr)
+        for (int i = 0; i < n_views; ++i) {
+            for (int k = 0; k < 3; ++k) {
+                hcull[(2 * k) * n_views + i] = hviews[i].lo[k];
+                hcull[(2 * k + 1) * n_views + i] = hviews[i].hi[k];
+            }
+            fill_tr_view(hviews[i], &htr[i]);
+        }
     MVS_HIP_TRY(c, hipMemcpyAsync(dviews, hviews, params_bytes, hipMemcpyHostToDevice, c->stream));
 
     const size_t out_bytes = (size_t)os[0] * os[1] * os[2] * es;
@@ -811,9 +1187,11 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
     P.out = dout;
     P.oz = (int)os[0]; P.oy = (int)os[1]; P.ox = (int)os[2];
     P.tz = (int)opts->trim[0]; P.ty = (int)opts->trim[1]; P.tx = (int)opts->trim[2];
+    P.cull = (const int*)((const char*)dviews + views_bytes);
+    P.ablate = c->ablate;
     if (use_tr) {
-        P.bz = (os[0] > 1) ? 2 : 1;
-        P.by = (os[0] > 1) ? 2 : 4;
+        P.bz = (os[0] > 1) ? kTrPlanes : 1;
+        P.by = (os[0] > 1) ? kTrRows * kTrGroups : 4 * kTrRows * kTrGroups;
     } else {
         P.bz = (os[0] > 1) ? 4 : 1;
         P.by = (os[0] > 1) ? 4 : 16;
@@ -827,10 +1205,20 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
 
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     if (use_tr) {
+        TrParams T;
+        T.views = (const TrView*)((const char*)dviews + views_bytes + cull_bytes);
+        T.cull = P.cull;
+        T.nviews = n_views;
+        T.out = dout;
+        T.oz = P.oz; T.oy = P.oy; T.ox = P.ox;
+        T.tz = P.tz; T.ty = P.ty; T.tx = P.tx;
+        T.nbz = P.nbz; T.nby = P.nby; T.nbx = P.nbx;
+        T.is3d = (os[0] > 1) ? 1 : 0;
+        T.ablate = c->ablate;
         switch (dtype) {
-            case MVS_U8: launch_fuse_tr<unsigned char, unsigned char>(P, opts->fusion, (int)nblocks, c->stream); break;
-            case MVS_U16: launch_fuse_tr<unsigned short, unsigned short>(P, opts->fusion, (int)nblocks, c->stream); break;
-            default: launch_fuse_tr<float, float>(P, opts->fusion, (int)nblocks, c->stream); break;
+            case MVS_U8: launch_fuse_tr<unsigned char, unsigned char>(T, opts->fusion, (int)nblocks, c->stream); break;
+            case MVS_U16: launch_fuse_tr<unsigned short, unsigned short>(T, opts->fusion, (int)nblocks, c->stream); break;
+            default: launch_fuse_tr<float, float>(T, opts->fusion, (int)nblocks, c->stream); break;
         }
     } else {
         switch (dtype) {

@@ -26,6 +26,7 @@ struct MvsContext {
     hipStream_t stream = nullptr;  // the stream work is issued on (own or external)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timing_valid = false;
+    int ablate = 0;               // profiling only (see FuseParams)
     bool force_generic = false;   // debug/test switch: never take the translation fast path
     std::mutex mu;
     std::string last_error;

@@ -1,0 +1,38 @@
+"""Minimal driver for profiling the fuse kernel alone (few other kernels, so PMC passes stay short).
+usage: python tools/fuse_probe.py [reps] [frac]   (frac=1: fractional registered-like offsets)"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from multiview_stitcher_amd import _lib, fusion, spatial_image_utils as si
+from multiview_stitcher_amd.device import DeviceArray
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+frac = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+grid = np.array([int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "4,4,4").split(",")])
+tile = np.array([int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "512,512,512").split(",")])
+dev = torch.device("cuda", 0)
+_lib.init(0)
+step = tile - np.round(tile * 0.2).astype(int)
+rng = np.random.default_rng(0)
+sims, keep = [], []
+for idx in np.ndindex(*grid):
+    t = torch.randint(0, 4096, tuple(int(s) for s in tile), dtype=torch.int16, device=dev).view(torch.uint16)
+    keep.append(t)
+    da = DeviceArray.from_pointer(t.data_ptr(), tuple(t.shape), np.uint16, 0, owner=t)
+    o = np.asarray(idx) * step
+    sim = si.to_spatial_image(da, dims=["z", "y", "x"], scale=dict(zip("zyx", [1.0] * 3)), translation=dict(zip("zyx", o.astype(float))))
+    p = np.eye(4)
+    if frac:
+        p[:3, 3] = np.round(rng.uniform(-2, 2, 3), 3)
+    si.set_sim_affine(sim, p, "k")
+    sims.append(sim)
+torch.cuda.synchronize()
+_lib.set_option("ablate", int(os.environ.get("MVS_ABLATE", "0")))
+ms = []
+for _ in range(reps):
+    out = fusion.fuse(sims, transform_key="k", output_chunksize={d: 1 << 30 for d in "zyx"}, output_on_backend=True, device=0)
+    ms.append(_lib.last_kernel_ms(0))
+vox = float(np.prod(out.shape))
+byt = len(sims) * float(np.prod(tile)) * 2 + vox * 2
+print("shape", out.shape, "kernel ms", ms, "GB/s", byt / (min(ms) * 1e-3) / 1e9)
