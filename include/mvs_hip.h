@@ -144,6 +144,13 @@ int mvs_phasecorr(int device, const float* fixed, const float* moving, int32_t m
                   int32_t upsample_factor, double shift_out[3],
                   int64_t peak_index_out[3], float* peak_abs_out);
 
+/* Intensity normalisation of one registration input == skimage.exposure.rescale_intensity(im,
+ * in_range=(nanmin(im), nanmax(im)), out_range=(0, 1)) as called at registration.py:381-389:
+ * float32 in/out, NaN preserved; also reports nanmin, nanmax and the number of non-NaN voxels
+ * (valid_pixels1 of registration.py:400). */
+int mvs_rescale_intensity(int device, const float* in, int32_t mem, int64_t n, float* out, int32_t out_mem,
+                          float* min_out, float* max_out, int64_t* nvalid_out);
+
 /* Candidate scoring == the loop of registration.py:493-556 for n translation
  * candidates t (z,y,x rows): moving resampled by t (order 1, NaN outside),
  * masks, bounding-box region (region_mode 0 = "union", 1 = "intersection"),

@@ -1,0 +1,65 @@
+"""Thin array-level wrappers of the registration entry points of libmvs_hip.so."""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, is_device_array
+from .transformation import shape3
+
+
+def _ptr_mem(a):
+    if is_device_array(a):
+        if not a.is_contiguous() or a.dtype != np.float32:
+            raise TypeError("registration kernels need contiguous float32 device arrays")
+        return a.ptr, _lib.MVS_MEM_DEVICE, a
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a.ctypes.data, _lib.MVS_MEM_HOST, a
+
+
+def rescale_intensity(im, device=0, out_on_device=False):
+    """skimage.exposure.rescale_intensity(im, in_range=(nanmin, nanmax), out_range=(0, 1)) on the GPU.
+    Returns (rescaled float32, nanmin, nanmax, n_valid)."""
+    lib = _lib.init(device)
+    ptr, mem, keep = _ptr_mem(im)
+    n = int(np.prod(im.shape))
+    mn, mx, nv = C.c_float(), C.c_float(), C.c_int64()
+    if out_on_device:
+        out = DeviceArray.empty(im.shape, np.float32, device)
+        optr, omem = out.ptr, _lib.MVS_MEM_DEVICE
+    else:
+        out = np.empty(im.shape, dtype=np.float32)
+        optr, omem = out.ctypes.data, _lib.MVS_MEM_HOST
+    rc = lib.mvs_rescale_intensity(device, ptr, mem, n, optr, omem, C.byref(mn), C.byref(mx), C.byref(nv))
+    _lib.check(rc, device, "mvs_rescale_intensity")
+    return out, float(mn.value), float(mx.value), int(nv.value)
+
+
+def phase_cross_correlation(reference_image, moving_image, upsample_factor=1, normalization="phase", device=0,
+                            return_debug=False):
+    """skimage.registration.phase_cross_correlation(ref, mov, upsample_factor=, normalization=,
+    disambiguate=False)[0] on the GPU (NaN-free float32 inputs of equal shape)."""
+    lib = _lib.init(device)
+    if tuple(reference_image.shape) != tuple(moving_image.shape):
+        raise ValueError("images must be same shape")
+    if normalization not in ("phase", None):
+        raise ValueError("normalization must be either phase or None")
+    shape = tuple(int(s) for s in reference_image.shape)
+    ndim = len(shape)
+    p0, m0, k0 = _ptr_mem(reference_image)
+    p1, m1, k1 = _ptr_mem(moving_image)
+    if m0 != m1:
+        raise TypeError("both images must live on the same side (host or device)")
+    shift = (C.c_double * 3)()
+    peak = (C.c_int64 * 3)()
+    pabs = C.c_float()
+    rc = lib.mvs_phasecorr(device, p0, p1, m0, ndim, _lib.i64x3(shape3(shape)), 1 if normalization == "phase" else 0,
+                           int(upsample_factor), shift, peak, C.byref(pabs))
+    _lib.check(rc, device, "mvs_phasecorr")
+    s = np.array(list(shift)[3 - ndim:], dtype=np.float32)
+    if return_debug:
+        return s, {"peak_index": np.array(list(peak)[3 - ndim:]), "peak_abs": float(pabs.value)}
+    return s

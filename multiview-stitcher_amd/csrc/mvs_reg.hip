@@ -1,14 +1,368 @@
-// mvs_reg.hip -- registration entry points (placeholder; see mvs_hip.h).
-#include "mvs_internal.h"
+// mvs_reg.hip -- pairwise phase correlation on the GPU (gfx950).
+//
+// mvs_phasecorr == skimage.registration.phase_cross_correlation(a, b, normalization=None|"phase",
+// upsample_factor=u, disambiguate=False)[0] as called from the reference's
+// registration.phase_correlation_registration (src/multiview_stitcher/registration.py:422-431):
+//   F = fftn(a), G = fftn(b)                         (complex64, mvs_fft.hip)
+//   P = F * conj(G);  "phase": P /= max(|P|, 100 eps)
+//   cc = ifftn(P);  integer peak = argmax |cc|  (lowest flat index wins ties, like np.argmax)
+//   wrap to signed shift, then the matrix-multiply upsampled DFT around round(shift*u)/u
+// mvs_rescale_intensity == skimage.exposure.rescale_intensity(im, in_range=(nanmin, nanmax),
+// out_range=(0,1)) (registration.py:381-389).
+#include "mvs_fft.h"
 
-extern "C" int mvs_phasecorr(int device, const float*, const float*, int32_t, int32_t, const int64_t*, int32_t,
-                             int32_t, double*, int64_t*, float*) {
-    MvsContext* c = mvs_ctx(device);
-    return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_phasecorr: not built yet");
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+namespace {
+
+__global__ void to_complex_kernel(const float* __restrict__ src, float2* __restrict__ dst, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = src[i];
+        if (v != v) v = 0.f;   // np.nan_to_num (registration.py:403-408)
+        dst[i] = make_float2(v, 0.f);
+    }
 }
 
-extern "C" int mvs_score_candidates(int device, const float*, const float*, int32_t, int32_t, const int64_t*,
-                                    const double*, int32_t, int32_t, double, double, double*, double*, int32_t*) {
-    MvsContext* c = mvs_ctx(device);
-    return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_score_candidates: not built yet");
+// P = F * conj(G), optionally divided by max(|P|, 100 eps); written to P and (a copy) to C
+__global__ void xpower_kernel(const float2* __restrict__ F, const float2* __restrict__ G, float2* __restrict__ P,
+                              float2* __restrict__ C, long long n, int normalize) {
+    const float floor_ = 100.f * FLT_EPSILON;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float2 f = F[i], g = G[i];
+        float2 p = make_float2(f.x * g.x + f.y * g.y, f.y * g.x - f.x * g.y);
+        if (normalize) {
+            const float a = fmaxf(hypotf(p.x, p.y), floor_);
+            p.x /= a;
+            p.y /= a;
+        }
+        P[i] = p;
+        C[i] = p;
+    }
+}
+
+// argmax |c| with np.argmax's tie-break (lowest flat index): per-block partial results
+__global__ __launch_bounds__(256) void argmax_abs_kernel(const float2* __restrict__ c, long long n, float* __restrict__ pval,
+                                                         long long* __restrict__ pidx) {
+    float best = -1.f;
+    long long bi = 0x7fffffffffffffffLL;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float2 v = c[i];
+        const float a = hypotf(v.x, v.y);
+        if (a > best || (a == best && i < bi)) { best = a; bi = i; }
+    }
+    // wavefront shuffle reduction, then across the 4 wavefronts through LDS
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_down(best, off);
+        const long long oi = __shfl_down(bi, off);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    __shared__ float sv[4];
+    __shared__ long long si[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        pval[blockIdx.x] = best;
+        pidx[blockIdx.x] = bi;
+    }
+}
+
+// Upsampled DFT, stage 1: contract the last (x) axis with kernel K (U x nx), input conj(P).
+// out[(row) * U + a] = sum_x K[a][x] * conj(P[row][x]); one wavefront per row.
+__global__ __launch_bounds__(256) void updft_x_kernel(const float2* __restrict__ P, const float2* __restrict__ K,
+                                                      float2* __restrict__ out, long long nrows, int nx, int U) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    for (int a = 0; a < U; ++a) {
+        float2 acc = make_float2(0.f, 0.f);
+        for (int x = lane; x < nx; x += 64) {
+            const float2 p = P[row * nx + x];
+            const float2 k = K[a * nx + x];
+            // k * conj(p)
+            acc.x += k.x * p.x + k.y * p.y;
+            acc.y += k.y * p.x - k.x * p.y;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            acc.x += __shfl_down(acc.x, off);
+            acc.y += __shfl_down(acc.y, off);
+        }
+        if (lane == 0) out[row * U + a] = acc;
+    }
+}
+
+// Generic later stage: in has shape (n_outer, n_red, n_inner) -> out (n_outer, U, n_inner):
+// out[o][b][i] = sum_r K[b][r] * in[o][r][i]; one thread per output element (sizes are tiny here).
+__global__ void updft_mid_kernel(const float2* __restrict__ in, const float2* __restrict__ K, float2* __restrict__ out,
+                                 int n_outer, int n_red, int n_inner, int U) {
+    const long long total = (long long)n_outer * U * n_inner;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(t % n_inner);
+        const int b = (int)((t / n_inner) % U);
+        const int o = (int)(t / ((long long)n_inner * U));
+        float2 acc = make_float2(0.f, 0.f);
+        for (int r = 0; r < n_red; ++r) {
+            const float2 v = in[((long long)o * n_red + r) * n_inner + i];
+            const float2 k = K[b * n_red + r];
+            acc.x += k.x * v.x - k.y * v.y;
+            acc.y += k.x * v.y + k.y * v.x;
+        }
+        out[t] = acc;
+    }
+}
+
+// nanmin / nanmax per block (float), finished on the host
+__global__ __launch_bounds__(256) void nanminmax_kernel(const float* __restrict__ a, long long n, float* __restrict__ pmin,
+                                                        float* __restrict__ pmax, long long* __restrict__ pvalid) {
+    float mn = INFINITY, mx = -INFINITY;
+    long long nv = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = a[i];
+        if (v == v) { mn = fminf(mn, v); mx = fmaxf(mx, v); ++nv; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_down(mn, off));
+        mx = fmaxf(mx, __shfl_down(mx, off));
+        nv += __shfl_down(nv, off);
+    }
+    __shared__ float smn[4], smx[4];
+    __shared__ long long snv[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { smn[wave] = mn; smx[wave] = mx; snv[wave] = nv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); nv += snv[w]; }
+        pmin[blockIdx.x] = mn; pmax[blockIdx.x] = mx; pvalid[blockIdx.x] = nv;
+    }
+}
+
+// (clip(im, lo, hi) - lo) / (hi - lo) * 1 + 0 in float32, NaN preserved (skimage rescale_intensity)
+__global__ void rescale_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n, float lo, float hi, int degenerate) {
+    const float d = hi - lo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = src[i];
+        if (v == v) {
+            v = fminf(fmaxf(v, lo), hi);
+            if (!degenerate) v = (v - lo) / d;
+            v = v * 1.0f + 0.0f;
+        }
+        dst[i] = v;
+    }
+}
+
+inline int grid_for(long long n) { return (int)std::min<long long>((n + 255) / 256, 256 * 8); }
+
+// fftfreq(n, d)[x] as numpy defines it
+inline double fftfreq(int n, double d, int x) {
+    const int half = (n - 1) / 2 + 1;
+    return (double)(x < half ? x : x - n) / ((double)n * d);
+}
+
+}  // namespace
+
+int mvs_device_nanminmax(MvsContext* c, const float* d_in, long long n, float* mn, float* mx, long long* nvalid) {
+    const int nb = grid_for(n);
+    char* scratch = (char*)mvs_scratch(c, 3, (size_t)nb * 16);
+    if (!scratch) return MVS_ERR_HIP;
+    float* pmin = (float*)scratch;
+    float* pmax = pmin + nb;
+    long long* pval = (long long*)(scratch + (size_t)nb * 8);
+    hipLaunchKernelGGL(nanminmax_kernel, dim3(nb), dim3(256), 0, c->stream, d_in, n, pmin, pmax, pval);
+    MVS_HIP_TRY(c, hipGetLastError());
+    std::vector<char> h((size_t)nb * 16);
+    MVS_HIP_TRY(c, hipMemcpyAsync(h.data(), scratch, h.size(), hipMemcpyDeviceToHost, c->stream));
+    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const float* hmin = (const float*)h.data();
+    const float* hmax = hmin + nb;
+    const long long* hval = (const long long*)(h.data() + (size_t)nb * 8);
+    float a = INFINITY, b = -INFINITY;
+    long long v = 0;
+    for (int i = 0; i < nb; ++i) { a = std::min(a, hmin[i]); b = std::max(b, hmax[i]); v += hval[i]; }
+    if (v == 0) { a = NAN; b = NAN; }
+    *mn = a; *mx = b; *nvalid = v;
+    return MVS_OK;
+}
+
+// device-resident building blocks (used by mvs_phasecorr and mvs_score.hip)
+int mvs_stage_float_volume(MvsContext* c, const float* src, int32_t mem, long long n, int slot, float** dptr) {
+    if (mem == MVS_MEM_DEVICE) { *dptr = (float*)src; return MVS_OK; }
+    float* d = (float*)mvs_scratch(c, slot, (size_t)n * 4);
+    if (!d) return MVS_ERR_HIP;
+    MVS_HIP_TRY(c, hipMemcpyAsync(d, src, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    *dptr = d;
+    return MVS_OK;
+}
+
+extern "C" int mvs_rescale_intensity(int device, const float* in, int32_t mem, int64_t n, float* out, int32_t out_mem,
+                                     float* min_out, float* max_out, int64_t* nvalid_out) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!in || !out || n < 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_rescale_intensity: bad argument");
+    MVS_HIP_TRY(c, hipSetDevice(device));
+    float* din;
+    rc = mvs_stage_float_volume(c, in, mem, n, 4, &din);
+    if (rc) return rc;
+    float mn, mx;
+    long long nv;
+    rc = mvs_device_nanminmax(c, din, n, &mn, &mx, &nv);
+    if (rc) return rc;
+    float* dout = out;
+    if (out_mem == MVS_MEM_HOST) {
+        dout = (float*)mvs_scratch(c, 5, (size_t)n * 4);
+        if (!dout) return MVS_ERR_HIP;
+    }
+    hipLaunchKernelGGL(rescale_kernel, dim3(grid_for(n)), dim3(256), 0, c->stream, din, dout, (long long)n, mn, mx, mn == mx ? 1 : 0);
+    MVS_HIP_TRY(c, hipGetLastError());
+    if (out_mem == MVS_MEM_HOST) MVS_HIP_TRY(c, hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (min_out) *min_out = mn;
+    if (max_out) *max_out = mx;
+    if (nvalid_out) *nvalid_out = nv;
+    return MVS_OK;
+}
+
+extern "C" int mvs_phasecorr(int device, const float* fixed, const float* moving, int32_t mem, int32_t ndim,
+                             const int64_t shape[3], int32_t normalization, int32_t upsample_factor,
+                             double shift_out[3], int64_t peak_index_out[3], float* peak_abs_out) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!fixed || !moving || !shape || !shift_out)
+        return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_phasecorr: NULL argument");
+    if (ndim != 2 && ndim != 3) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_phasecorr: ndim must be 2 or 3");
+    if (upsample_factor < 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_phasecorr: upsample_factor < 1");
+    for (int k = 0; k < 3; ++k)
+        if (shape[k] < 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_phasecorr: bad shape");
+    if (ndim == 2 && shape[0] != 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_phasecorr: 2D needs shape[0]==1");
+    MVS_HIP_TRY(c, hipSetDevice(device));
+    const long long n = (long long)shape[0] * shape[1] * shape[2];
+    const int nz = (int)shape[0], ny = (int)shape[1], nx = (int)shape[2];
+
+    float *da, *db;
+    rc = mvs_stage_float_volume(c, fixed, mem, n, 4, &da);
+    if (rc) return rc;
+    rc = mvs_stage_float_volume(c, moving, mem, n, 5, &db);
+    if (rc) return rc;
+    // complex work volumes: F, G (G is reused for cc), P
+    float2* F = (float2*)mvs_scratch(c, 6, (size_t)n * 8 * 3);
+    if (!F) return MVS_ERR_HIP;
+    float2* G = F + n;
+    float2* P = G + n;
+
+    MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+    const int gb = grid_for(n);
+    hipLaunchKernelGGL(to_complex_kernel, dim3(gb), dim3(256), 0, c->stream, da, F, n);
+    hipLaunchKernelGGL(to_complex_kernel, dim3(gb), dim3(256), 0, c->stream, db, G, n);
+    rc = mvs_fft3_c2c(c, F, shape, false);
+    if (rc) return rc;
+    rc = mvs_fft3_c2c(c, G, shape, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(xpower_kernel, dim3(gb), dim3(256), 0, c->stream, F, G, P, G, n, normalization ? 1 : 0);
+    rc = mvs_fft3_c2c(c, G, shape, true);   // cc (unnormalised inverse: argmax is scale invariant)
+    if (rc) return rc;
+    char* red = (char*)mvs_scratch(c, 3, (size_t)gb * 16);
+    if (!red) return MVS_ERR_HIP;
+    float* pval = (float*)red;
+    long long* pidx = (long long*)(red + (size_t)gb * 8);
+    hipLaunchKernelGGL(argmax_abs_kernel, dim3(gb), dim3(256), 0, c->stream, G, n, pval, pidx);
+    MVS_HIP_TRY(c, hipGetLastError());
+    std::vector<char> h((size_t)gb * 16);
+    MVS_HIP_TRY(c, hipMemcpyAsync(h.data(), red, h.size(), hipMemcpyDeviceToHost, c->stream));
+    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float best = -1.f;
+    long long bi = 0;
+    {
+        const float* hv = (const float*)h.data();
+        const long long* hi = (const long long*)(h.data() + (size_t)gb * 8);
+        for (int i = 0; i < gb; ++i)
+            if (hv[i] > best || (hv[i] == best && hi[i] < bi)) { best = hv[i]; bi = hi[i]; }
+    }
+    const long long pz = bi / ((long long)ny * nx), py = (bi / nx) % ny, px = bi % nx;
+    const long long peak[3] = {pz, py, px};
+    if (peak_index_out) { peak_index_out[0] = pz; peak_index_out[1] = py; peak_index_out[2] = px; }
+    if (peak_abs_out) *peak_abs_out = best / (float)n;   // ifftn's 1/N
+
+    // ---- signed shift, float32 arithmetic like skimage ----
+    float shift[3];
+    for (int k = 0; k < 3; ++k) {
+        shift[k] = (float)peak[k];
+        const float mid = truncf((float)shape[k] / 2.f);   // np.fix(axis_size / 2)
+        if (shift[k] > mid) shift[k] -= (float)shape[k];
+    }
+    if (upsample_factor > 1) {
+        const float uf = (float)upsample_factor;
+        const int U = (int)ceilf(uf * 1.5f);
+        const float dftshift = truncf((float)U / 2.f);
+        float offs[3];
+        for (int k = 0; k < 3; ++k) {
+            shift[k] = nearbyintf(shift[k] * uf) / uf;            // np.round: half to even
+            offs[k] = dftshift - shift[k] * uf;
+        }
+        // kernels exp(-2 pi i (a - off) * fftfreq(n, uf)[x]) computed in double, cast to complex64
+        const int k0 = (ndim == 3) ? 0 : 1;
+        std::vector<float2> hk;
+        size_t koff[3] = {0, 0, 0};
+        for (int k = k0; k < 3; ++k) {
+            koff[k] = hk.size();
+            const int nn = (int)shape[k];
+            for (int a = 0; a < U; ++a)
+                for (int x = 0; x < nn; ++x) {
+                    const double ph = -2.0 * M_PI * ((double)a - (double)offs[k]) * fftfreq(nn, (double)uf, x);
+                    hk.push_back(make_float2((float)cos(ph), (float)sin(ph)));
+                }
+        }
+        const size_t kbytes = hk.size() * sizeof(float2);
+        const long long nrows = (long long)nz * ny;
+        const size_t s1 = (size_t)nrows * U, s2 = (size_t)nz * U * U, s3 = (size_t)U * U * U;
+        float2* dk = (float2*)mvs_scratch(c, 7, kbytes + (s1 + s2 + s3) * sizeof(float2) + 1024);
+        if (!dk) return MVS_ERR_HIP;
+        float2* o1 = (float2*)((char*)dk + ((kbytes + 255) / 256) * 256);
+        float2* o2 = o1 + s1;
+        float2* o3 = o2 + s2;
+        MVS_HIP_TRY(c, hipMemcpyAsync(dk, hk.data(), kbytes, hipMemcpyHostToDevice, c->stream));
+        // stage 1: x  -> (z, y, ux)
+        hipLaunchKernelGGL(updft_x_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, P, dk + koff[2], o1, nrows, nx, U);
+        // stage 2: y  -> (z, uy, ux)
+        hipLaunchKernelGGL(updft_mid_kernel, dim3(grid_for((long long)s2)), dim3(256), 0, c->stream, o1, dk + koff[1], o2, nz, ny, U, U);
+        size_t nout = s2;
+        float2* res = o2;
+        if (ndim == 3) {
+            // stage 3: z -> (uz, uy, ux)
+            hipLaunchKernelGGL(updft_mid_kernel, dim3(grid_for((long long)s3)), dim3(256), 0, c->stream, o2, dk + koff[0], o3, 1, nz, U * U, U);
+            nout = s3;
+            res = o3;
+        }
+        MVS_HIP_TRY(c, hipGetLastError());
+        std::vector<float2> hres(nout);
+        MVS_HIP_TRY(c, hipMemcpyAsync(hres.data(), res, nout * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+        MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        // argmax |.| (conj does not change the modulus), lowest flat index
+        float bu = -1.f;
+        size_t iu = 0;
+        for (size_t i = 0; i < nout; ++i) {
+            const float a = hypotf(hres[i].x, hres[i].y);
+            if (a > bu) { bu = a; iu = i; }
+        }
+        int m[3] = {0, 0, 0};
+        m[2] = (int)(iu % U);
+        m[1] = (int)((iu / U) % U);
+        if (ndim == 3) m[0] = (int)(iu / ((size_t)U * U));
+        for (int k = k0; k < 3; ++k) shift[k] += ((float)m[k] - dftshift) / uf;
+    } else {
+        MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+    }
+    c->timing_valid = true;
+    for (int k = 0; k < 3; ++k) {
+        if (shape[k] == 1) shift[k] = 0.f;
+        shift_out[k] = (double)shift[k];
+    }
+    return MVS_OK;
 }

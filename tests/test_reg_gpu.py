@@ -1,0 +1,74 @@
+"""GPU parity: registration kernels (rescale, FFT phase correlation) against oracle/reg_oracle.py."""
+import numpy as np
+import pytest
+from scipy import ndimage
+
+from oracle import reg_oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(shape, shift, seed=0, sigma=1.0, noise=0.0):
+    rng = np.random.default_rng(seed)
+    pad = 12
+    big = ndimage.gaussian_filter(rng.random(tuple(s + 2 * pad for s in shape)), sigma).astype(np.float32)
+    a = np.ascontiguousarray(big[tuple(slice(pad, pad + s) for s in shape)])
+    b = np.ascontiguousarray(big[tuple(slice(pad + d, pad + d + s) for d, s in zip(shift, shape))])
+    if noise:
+        b = b + noise * rng.standard_normal(shape).astype(np.float32)
+    return a, b
+
+
+# power-of-two, odd, prime and mixed sizes: the transform length is the overlap shape itself
+SHAPES = [((64, 128), (3, -5)), ((53, 104), (-4, 6)), ((97, 411), (7, -11)), ((16, 32, 64), (1, -2, 3)),
+          ((27, 40, 52), (2, 3, -4)), ((9, 131, 17), (-1, 5, 2)), ((1, 60, 70), (0, 2, -3))]
+
+
+@pytest.mark.parametrize("shape,shift", SHAPES)
+@pytest.mark.parametrize("normalization", ["phase", None])
+def test_phasecorr_peak_index_bit_exact_and_shift(hip_device, shape, shift, normalization):
+    from multiview_stitcher_amd import _reg_ops
+
+    a, b = _pair(shape, shift, noise=0.002)
+    up = 10 if len(shape) == 2 else 2
+    want, wdbg = ro.phase_cross_correlation(a, b, upsample_factor=up, normalization=normalization, return_debug=True)
+    got, gdbg = _reg_ops.phase_cross_correlation(a, b, upsample_factor=up, normalization=normalization, return_debug=True)
+    np.testing.assert_array_equal(gdbg["peak_index"], wdbg["peak_index"])          # integer argmax: bit exact
+    np.testing.assert_array_equal(np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64))
+    assert abs(gdbg["peak_abs"] - wdbg["peak_abs"]) <= 1e-4 * abs(wdbg["peak_abs"]) + 1e-7
+
+
+def test_phasecorr_upsample_one(hip_device):
+    from multiview_stitcher_amd import _reg_ops
+
+    a, b = _pair((48, 80), (4, -7))
+    want = ro.phase_cross_correlation(a, b, upsample_factor=1, normalization=None)
+    got = _reg_ops.phase_cross_correlation(a, b, upsample_factor=1, normalization=None)
+    np.testing.assert_array_equal(np.asarray(got, np.float64), np.asarray(want, np.float64))
+
+
+def test_argmax_tie_break_lowest_index(hip_device):
+    """Identical constant-free periodic inputs: cc has its peak at index 0; a delta image makes every
+    |cc| equal for the phase-normalised case -> np.argmax picks flat index 0."""
+    from multiview_stitcher_amd import _reg_ops
+
+    a = np.zeros((8, 16), np.float32)
+    a[0, 0] = 1.0
+    want, wd = ro.phase_cross_correlation(a, a, upsample_factor=1, normalization=None, return_debug=True)
+    got, gd = _reg_ops.phase_cross_correlation(a, a, upsample_factor=1, normalization=None, return_debug=True)
+    np.testing.assert_array_equal(gd["peak_index"], wd["peak_index"])
+    np.testing.assert_array_equal(gd["peak_index"], [0, 0])
+
+
+@pytest.mark.parametrize("shape", [(40, 50), (7, 33, 21)])
+def test_rescale_intensity(hip_device, shape):
+    from multiview_stitcher_amd import _reg_ops
+
+    rng = np.random.default_rng(3)
+    im = (rng.random(shape).astype(np.float32) * 937 + 11).astype(np.float32)
+    im[..., :3] = np.nan
+    want = ro.rescale_intensity_01(im)
+    got, mn, mx, nv = _reg_ops.rescale_intensity(im)
+    assert mn == np.nanmin(im) and mx == np.nanmax(im) and nv == np.sum(~np.isnan(im))
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(got[~np.isnan(got)], want[~np.isnan(want)], rtol=0, atol=1.2e-7)
