@@ -63,3 +63,28 @@ def phase_cross_correlation(reference_image, moving_image, upsample_factor=1, no
     if return_debug:
         return s, {"peak_index": np.array(list(peak)[3 - ndim:]), "peak_abs": float(pabs.value)}
     return s
+
+
+def score_candidates(im0, im1, t_candidates, region_mode, data_range, im1_min, device=0):
+    """The candidate loop of registration.py:493-556 on the GPU.  im0 / im1: rescaled float32 images
+    (NaN = outside).  Returns (ssim, spearman, code) arrays; code 1 = (-1,-1) appended, 2 = `continue`."""
+    lib = _lib.init(device)
+    shape = tuple(int(s) for s in im0.shape)
+    ndim = len(shape)
+    p0, m0, k0 = _ptr_mem(im0)
+    p1, m1, k1 = _ptr_mem(im1)
+    if m0 != m1:
+        raise TypeError("both images must live on the same side (host or device)")
+    t = np.ascontiguousarray(np.asarray(t_candidates, dtype=np.float64).reshape(-1, ndim))
+    n = t.shape[0]
+    ssim = np.empty(n, dtype=np.float64)
+    spear = np.empty(n, dtype=np.float64)
+    code = np.empty(n, dtype=np.int32)
+    rc = lib.mvs_score_candidates(
+        device, p0, p1, m0, ndim, _lib.i64x3(shape3(shape)), t.ctypes.data_as(C.POINTER(C.c_double)), n,
+        {"union": 0, "intersection": 1}[region_mode], float(data_range), float(im1_min),
+        ssim.ctypes.data_as(C.POINTER(C.c_double)), spear.ctypes.data_as(C.POINTER(C.c_double)),
+        code.ctypes.data_as(C.POINTER(C.c_int32)),
+    )
+    _lib.check(rc, device, "mvs_score_candidates")
+    return ssim, spear, code

@@ -72,3 +72,84 @@ def test_rescale_intensity(hip_device, shape):
     assert mn == np.nanmin(im) and mx == np.nanmax(im) and nv == np.sum(~np.isnan(im))
     np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
     np.testing.assert_allclose(got[~np.isnan(got)], want[~np.isnan(want)], rtol=0, atol=1.2e-7)
+
+
+def _check_scores(a, b, t_cands, region_mode):
+    """mvs_score_candidates against the oracle's candidate loop on rescaled inputs."""
+    from multiview_stitcher_amd import _reg_ops
+
+    im0, im1 = ro.rescale_intensity_01(a), ro.rescale_intensity_01(b)
+    im0nm = np.isnan(im0)
+    data_range = np.nanmax([im0, im1]) - np.nanmin([im0, im1])
+    im1_min = np.nanmin(im1)
+    valid1 = np.sum(~np.isnan(im1))
+    im0_bb = ro.get_bb_from_nanmask(~im0nm)
+    ssim, spear, codes = _reg_ops.score_candidates(im0, im1, t_cands, region_mode, data_range, im1_min)
+    for i, t in enumerate(t_cands):
+        code, s, q = ro.score_candidate(im0, im1, im0nm, t, valid1, region_mode, data_range, im1_min, im0_bb)
+        assert codes[i] == code, (i, t, codes[i], code)
+        if code == 0:
+            assert abs(ssim[i] - s) <= 2e-5 * max(abs(s), 1e-3), (i, t, ssim[i], s)
+            assert abs(spear[i] - q) <= 1e-5, (i, t, spear[i], q)
+        elif code == 1:
+            assert ssim[i] == -1 and spear[i] == -1
+
+
+@pytest.mark.parametrize("shape,shift", [((60, 104), (3, -5)), ((24, 40, 36), (2, -3, 4)), ((1, 50, 64), (0, 4, 2))])
+def test_score_candidates_no_nan(hip_device, shape, shift):
+    a, b = _pair(shape, shift)
+    nd = len(shape)
+    cands = [list(np.zeros(nd)), list(-np.asarray(shift, float)), list(np.asarray(shift, float) + 0.5),
+             [s * 0.9 for s in shape][:nd], [-(shift[d] - shape[d]) for d in range(nd)]]
+    _check_scores(a, b, cands, "union")
+
+
+def test_score_candidates_with_nan_borders(hip_device):
+    a, b = _pair((40, 90), (2, 3))
+    a = a.copy(); b = b.copy()
+    a[:3] = np.nan
+    b[:, -5:] = np.nan
+    cands = [[0.0, 0.0], [-2.0, -3.0], [-2.5, -3.5], [35.0, 0.0], [1.0, -80.0]]
+    _check_scores(a, b, cands, "intersection")
+    _check_scores(a, b, cands, "union")
+
+
+@pytest.mark.parametrize("shape,shift", [((60, 104), (3, -5)), ((53, 97), (-6, 2)), ((24, 64, 56), (2, -3, 4)),
+                                         ((9, 70, 66), (1, 4, -5))])
+def test_phase_correlation_registration_matches_oracle(hip_device, shape, shift):
+    """End to end: same selected candidate (bit-exact translation) and the same quality."""
+    from multiview_stitcher_amd import registration
+
+    a, b = _pair(shape, shift)
+    want = ro.phase_correlation_registration(a, b, return_debug=True)
+    got = registration.phase_correlation_registration(a, b, return_debug=True)
+    np.testing.assert_array_equal(got["debug"]["t_candidates"], want["debug"]["t_candidates"])
+    assert got["debug"]["codes"] == want["debug"]["codes"]
+    assert got["debug"]["argmax_index"] == want["debug"]["argmax_index"]
+    np.testing.assert_array_equal(got["affine_matrix"], want["affine_matrix"])
+    assert abs(got["quality"] - want["quality"]) <= 1e-5
+
+
+def test_phase_correlation_registration_with_nans(hip_device):
+    from multiview_stitcher_amd import registration
+
+    a, b = _pair((50, 90), (2, 3))
+    b = b.copy()
+    b[:, :4] = np.nan
+    want = ro.phase_correlation_registration(a, b, return_debug=True)
+    got = registration.phase_correlation_registration(a, b, return_debug=True)
+    assert got["debug"]["region_mode"] == want["debug"]["region_mode"] == "intersection"
+    np.testing.assert_array_equal(got["debug"]["t_candidates"], want["debug"]["t_candidates"])
+    np.testing.assert_array_equal(got["affine_matrix"], want["affine_matrix"])
+    assert abs(got["quality"] - want["quality"]) <= 1e-5
+
+
+def test_device_resident_inputs(hip_device):
+    from multiview_stitcher_amd import registration
+    from multiview_stitcher_amd.device import DeviceArray
+
+    a, b = _pair((20, 48, 40), (1, -2, 3))
+    host = registration.phase_correlation_registration(a, b)
+    dev = registration.phase_correlation_registration(DeviceArray.from_host(a), DeviceArray.from_host(b))
+    np.testing.assert_array_equal(host["affine_matrix"], dev["affine_matrix"])
+    assert host["quality"] == dev["quality"]
