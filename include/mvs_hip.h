@@ -151,6 +151,11 @@ int mvs_phasecorr(int device, const float* fixed, const float* moving, int32_t m
 int mvs_rescale_intensity(int device, const float* in, int32_t mem, int64_t n, float* out, int32_t out_mem,
                           float* min_out, float* max_out, int64_t* nvalid_out);
 
+/* Block-mean binning of one view == sim.coarsen(bins, boundary="trim").mean().astype(dtype)
+ * (registration.py:1732-1741): out shape = shape // bin, mean in double, cast like astype. */
+int mvs_bin_mean(int device, const void* in, int32_t dtype, int32_t mem, const int64_t shape[3],
+                 const int64_t stride[3], const int64_t bin[3], void* out, int32_t out_mem);
+
 /* Candidate scoring == the loop of registration.py:493-556 for n translation
  * candidates t (z,y,x rows): moving resampled by t (order 1, NaN outside),
  * masks, bounding-box region (region_mode 0 = "union", 1 = "intersection"),

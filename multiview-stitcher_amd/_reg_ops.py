@@ -88,3 +88,31 @@ def score_candidates(im0, im1, t_candidates, region_mode, data_range, im1_min, d
     )
     _lib.check(rc, device, "mvs_score_candidates")
     return ssim, spear, code
+
+
+def bin_mean(data, bins, device=0):
+    """``coarsen(bins, boundary="trim").mean().astype(dtype)`` (registration.py:1732-1741) on the GPU.
+    ``data``: numpy array or (strided) DeviceArray, spatial dims only; ``bins``: per-axis ints."""
+    lib = _lib.init(device)
+    nd = data.ndim
+    bins = [int(b) for b in bins]
+    shape = [int(s) for s in data.shape]
+    oshape = [s // b for s, b in zip(shape, bins)]
+    dtype = np.dtype(data.dtype)
+    if dtype not in _lib.DTYPE_CODES:
+        raise TypeError(f"unsupported dtype {dtype}")
+    if is_device_array(data):
+        ptr, mem, strides = data.ptr, _lib.MVS_MEM_DEVICE, list(data.strides)
+        out = DeviceArray.empty(oshape, dtype, device)
+        optr, omem = out.ptr, _lib.MVS_MEM_DEVICE
+    else:
+        data = np.ascontiguousarray(data)
+        ptr, mem, strides = data.ctypes.data, _lib.MVS_MEM_HOST, [int(np.prod(data.shape[k + 1:])) for k in range(nd)]
+        out = np.empty(oshape, dtype=dtype)
+        optr, omem = out.ctypes.data, _lib.MVS_MEM_HOST
+    s3 = shape3(shape)
+    st3 = strides if nd == 3 else [strides[0] * s3[1], strides[0], strides[1]]
+    b3 = [1] * (3 - nd) + bins
+    rc = lib.mvs_bin_mean(device, ptr, _lib.DTYPE_CODES[dtype], mem, _lib.i64x3(s3), _lib.i64x3(st3), _lib.i64x3(b3), optr, omem)
+    _lib.check(rc, device, "mvs_bin_mean")
+    return out

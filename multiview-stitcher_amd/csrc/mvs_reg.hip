@@ -366,3 +366,74 @@ extern "C" int mvs_phasecorr(int device, const float* fixed, const float* moving
     }
     return MVS_OK;
 }
+
+// ---- block-mean binning == sim.coarsen(bins, boundary="trim").mean().astype(dtype) (registration.py:1732-1741) ----
+namespace {
+template <typename T>
+__global__ void bin_mean_kernel(const T* __restrict__ in, long long sz, long long sy, T* __restrict__ out, int oz, int oy, int ox,
+                                int bz, int by, int bx) {
+    const long long n = (long long)oz * oy * ox;
+    const double inv = 1.0 / ((double)bz * by * bx);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % ox);
+        const long long t = i / ox;
+        const int y = (int)(t % oy), z = (int)(t / oy);
+        double acc = 0.0;
+        for (int dz = 0; dz < bz; ++dz)
+            for (int dy = 0; dy < by; ++dy) {
+                const T* row = in + (long long)(z * bz + dz) * sz + (long long)(y * by + dy) * sy + (long long)x * bx;
+                for (int dx = 0; dx < bx; ++dx) acc += (double)row[dx];
+            }
+        const double m = acc * inv;
+        out[i] = (T)m;   // astype: truncation for integer dtypes
+    }
+}
+}  // namespace
+
+extern "C" int mvs_bin_mean(int device, const void* in, int32_t dtype, int32_t mem, const int64_t shape[3],
+                            const int64_t stride[3], const int64_t bin[3], void* out, int32_t out_mem) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!in || !out || !shape || !stride || !bin) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_bin_mean: NULL argument");
+    const size_t es = mvs_dtype_size(dtype);
+    if (!es) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_bin_mean: bad dtype");
+    if (stride[2] != 1) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_bin_mean: x stride must be 1");
+    int o[3];
+    for (int k = 0; k < 3; ++k) {
+        if (bin[k] < 1 || shape[k] < bin[k]) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_bin_mean: bad bin/shape on axis %d", k);
+        o[k] = (int)(shape[k] / bin[k]);
+    }
+    MVS_HIP_TRY(c, hipSetDevice(device));
+    const void* din = in;
+    long long sz = stride[0], sy = stride[1];
+    if (mem == MVS_MEM_HOST) {
+        if (stride[1] != shape[2] || stride[0] != shape[1] * shape[2])
+            return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_bin_mean: host input must be C-contiguous");
+        const size_t nb = (size_t)shape[0] * shape[1] * shape[2] * es;
+        void* s = mvs_scratch(c, 4, nb);
+        if (!s) return MVS_ERR_HIP;
+        MVS_HIP_TRY(c, hipMemcpyAsync(s, in, nb, hipMemcpyHostToDevice, c->stream));
+        din = s;
+    }
+    const long long n = (long long)o[0] * o[1] * o[2];
+    void* dout = out;
+    if (out_mem == MVS_MEM_HOST) {
+        dout = mvs_scratch(c, 5, (size_t)n * es);
+        if (!dout) return MVS_ERR_HIP;
+    }
+    const int gb = grid_for(n);
+#define MVS_BIN(T) hipLaunchKernelGGL(bin_mean_kernel<T>, dim3(gb), dim3(256), 0, c->stream, (const T*)din, sz, sy, (T*)dout, \
+                                      o[0], o[1], o[2], (int)bin[0], (int)bin[1], (int)bin[2])
+    switch (dtype) {
+        case MVS_U8: MVS_BIN(unsigned char); break;
+        case MVS_U16: MVS_BIN(unsigned short); break;
+        default: MVS_BIN(float); break;
+    }
+#undef MVS_BIN
+    MVS_HIP_TRY(c, hipGetLastError());
+    if (out_mem == MVS_MEM_HOST) MVS_HIP_TRY(c, hipMemcpyAsync(out, dout, (size_t)n * es, hipMemcpyDeviceToHost, c->stream));
+    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MVS_OK;
+}

@@ -1,0 +1,98 @@
+"""Multi-GPU farms behind the reference's own seams: independent pairs and output chunks,
+no collectives.
+
+``DevicePairExecutor``  -> ``registration.register(..., pairwise_executor=...)``   (registration.py:2634-2655)
+``fuse_on_devices``     -> the role of ``batch_options["batch_func"]``            (fusion/_core.py:1133-1141)
+``shard_units``         -> rank-local work list for one-process-per-GPU launches (torch.distributed ranks)
+"""
+
+from __future__ import annotations
+
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+
+def shard_units(n_units, world_size, rank, weights=None):
+    """Indices of the units rank ``rank`` owns.  Without weights: contiguous blocks (keeps neighbouring
+    chunks, hence shared tiles, on one GPU).  With weights (e.g. overlap voxels): greedy longest-first."""
+    if weights is None:
+        bounds = np.linspace(0, n_units, world_size + 1).astype(int)
+        return list(range(bounds[rank], bounds[rank + 1]))
+    order = np.argsort(-np.asarray(weights, dtype=float), kind="stable")
+    loads = np.zeros(world_size)
+    owner = np.empty(n_units, dtype=int)
+    for u in order:
+        r = int(np.argmin(loads))
+        owner[u] = r
+        loads[r] += weights[u]
+    return [int(u) for u in range(n_units) if owner[u] == rank]
+
+
+class DevicePairExecutor:
+    """pairwise_executor: registers edge k on device ``devices[k % len(devices)]`` from one host thread per
+    device (the library serialises per device and releases the GIL inside calls)."""
+
+    def __init__(self, devices=(0,)):
+        self.devices = list(devices)
+
+    def __call__(self, msims, edges, register_kwargs):
+        from . import registration
+        from .device import DeviceArray, is_device_array
+
+        n = len(self.devices)
+        buckets = [[k for k in range(len(edges)) if k % n == d] for d in range(n)]
+        results = [None] * len(edges)
+
+        def work(d):
+            dev = self.devices[d]
+            cache = {}
+            for k in buckets[d]:
+                i, j = edges[k]
+                a, b = msims[i], msims[j]
+
+                def local(m):
+                    data = m.data if not hasattr(m, "scales") else None
+                    if data is not None and is_device_array(data) and data.device != dev:
+                        return m.copy(data=DeviceArray.from_host(data.get(), dev))   # peer copy via host
+                    return m
+
+                results[k] = registration.register_pair_of_msims(local(a), local(b), device=dev, _bin_cache=cache, **register_kwargs)
+
+        with ThreadPoolExecutor(max_workers=n) as ex:
+            list(ex.map(work, range(n)))
+        return results
+
+
+def fuse_on_devices(sims, devices=(0,), **fuse_kwargs):
+    """Fuse with the output chunks farmed over several GPUs of one process: chunk b goes to device
+    ``devices[b % n]`` (z-major block order keeps a device's chunks adjacent); the host array is assembled
+    from the per-device partial results.  Equivalent to fusion.fuse on one device."""
+    from . import fusion
+
+    n = len(devices)
+    counter = {}
+
+    def make_filter(d):
+        def f(block_index):
+            key = tuple(block_index)
+            if key not in counter:
+                counter[key] = len(counter)
+            return counter[key] % n == d
+        return f
+
+    # enumerate blocks deterministically first (single pass with a rejecting filter)
+    fusion.fuse(sims, chunk_filter=lambda bi: counter.setdefault(tuple(bi), len(counter)) < 0, device=devices[0], **fuse_kwargs)
+    parts = [None] * n
+
+    def work(d):
+        parts[d] = fusion.fuse(sims, chunk_filter=lambda bi: counter[tuple(bi)] % n == d, device=devices[d], **fuse_kwargs)
+
+    with ThreadPoolExecutor(max_workers=n) as ex:
+        list(ex.map(work, range(n)))
+    out = parts[0]
+    data = np.asarray(out.data).copy()
+    for p in parts[1:]:
+        data += np.asarray(p.data)   # disjoint chunks, untouched ones are zero
+    out.data = data
+    return out

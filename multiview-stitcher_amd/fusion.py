@@ -150,8 +150,9 @@ def fuse_np(
                                data.shape, data.strides, matrix, offset)
         else:
             data = np.ascontiguousarray(data, dtype=input_dtype)
+            cstrides = [int(np.prod(data.shape[k + 1:])) for k in range(data.ndim)]   # numpy's strides of size-1 axes are arbitrary
             fill_view_geometry(views[i], data.ctypes.data, _lib.DTYPE_CODES[input_dtype], _lib.MVS_MEM_HOST,
-                               data.shape, [s // data.itemsize for s in data.strides], matrix, offset)
+                               data.shape, cstrides, matrix, offset)
         keep.append(data)
         weights.fill_view_weights(views[i], _bb_dicts(full_view_bbs[i], sdims), param, out_origin, out_spacing,
                                   blending_widths, shrink_distance)

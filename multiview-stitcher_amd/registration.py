@@ -162,3 +162,350 @@ def _smoke(device=0):
     assert np.array_equal(got["affine_matrix"], want["affine_matrix"]), (got, want)
     assert abs(got["quality"] - want["quality"]) < 1e-5
     print("smoke: pairwise registration shift", got["affine_matrix"][:-1, -1], "quality", got["quality"], "matches oracle")
+
+
+# =====================================================================================================
+# Pair preparation and the register() workflow (host glue around the kernels)
+# =====================================================================================================
+def _is_axis_aligned(affine, tol=1e-9):
+    A = np.asarray(affine)[:-1, :-1]
+    return bool(np.all(np.abs(A - np.diag(np.diag(A))) < tol))
+
+
+def _get_overlap_bboxes(sim1, sim2, input_transform_key=None, output_transform_key=None, overlap_tolerance=None):
+    """registration._get_overlap_bboxes (registration.py:194-277) for axis-aligned views.
+
+    The reference intersects the two view boxes as halfspaces (Qhull, mv_graph.py:301-338); for
+    axis-aligned views that polytope is the intersection of the world AABBs, whose corners are mapped
+    back into each view's intrinsic frame.  Returns None when the views do not overlap."""
+    from . import mv_graph
+    from . import spatial_image_utils as si_utils
+
+    sims = [sim1, sim2]
+    affines = [param_utils.select_time(si_utils.get_affine_from_sim(s, input_transform_key), 0) for s in sims]
+    if not all(_is_axis_aligned(a) for a in affines):
+        raise NotImplementedError("pairwise registration of rotated / sheared views is not part of this path yet")
+    sps = [si_utils.get_stack_properties_from_sim(s) for s in sims]
+    if overlap_tolerance is not None:
+        sps = [si_utils_extend(sp, overlap_tolerance) for sp in sps]
+    res = mv_graph.get_overlap_aabb(sps[0], affines[0], sps[1], affines[1])
+    if res is None:
+        return None
+    lo, hi = res
+    ndim = len(lo)
+    corners = np.array(list(np.ndindex(*([2] * ndim)))) * (hi - lo) + lo
+    if output_transform_key is None:
+        from .transformation import transform_pts
+
+        cts = [transform_pts(corners, np.linalg.inv(a)) for a in affines]
+    elif output_transform_key == input_transform_key:
+        cts = [corners, corners]
+    else:
+        raise NotImplementedError
+    return {"lowers": [np.min(c, axis=0) for c in cts], "uppers": [np.max(c, axis=0) for c in cts],
+            "vol": float(np.prod(hi - lo))}
+
+
+def si_utils_extend(stack_props, extend_by):
+    """spatial_image_utils.extend_stack_props (spatial_image_utils.py:889-913) on a copy."""
+    sp = {k: dict(v) for k, v in stack_props.items()}
+    if not isinstance(extend_by, dict):
+        extend_by = {d: extend_by for d in sp["spacing"]}
+    for d, val in extend_by.items():
+        sp["shape"][d] += int(np.ceil(2 * val / sp["spacing"][d]))
+        sp["origin"][d] -= val
+    return sp
+
+
+def _bin_sim(sim, binning, device):
+    """sim.coarsen(binning, boundary="trim").mean().astype(dtype) incl. the coarsened coordinates
+    (registration.py:1732-1741)."""
+    from . import spatial_image_utils as si_utils
+
+    sdims = si_utils.get_spatial_dims_from_sim(sim)
+    bins = [int(binning.get(d, 1)) for d in sdims]
+    if max(bins) == 1:
+        return sim
+    data = _reg_ops.bin_mean(sim.data, bins, device)
+    coords = {}
+    for d, b, n in zip(sdims, bins, data.shape):
+        c = sim.coords[d][: n * b].reshape(n, b).mean(axis=1)
+        coords[d] = c
+    out = si_utils.SpatialImage(data, sdims, coords, {"transforms": dict(sim.attrs.get("transforms", {}))})
+    return out
+
+
+def sims_to_intrinsic_coord_system(sim1, sim2, transform_key, overlap_bboxes, device=0):
+    """registration.sims_to_intrinsic_coord_system (registration.py:280-350): both views resampled (float32,
+    NaN outside) onto the fixed view's pixel grid over the overlap box."""
+    from . import spatial_image_utils as si_utils
+    from .transformation import transform_sim
+
+    sdims = si_utils.get_spatial_dims_from_sim(sim1)
+    lowers, uppers = overlap_bboxes
+    spacing = np.max([si_utils.get_spacing_from_sim(s, asarray=True) for s in [sim1, sim2]], axis=0)
+    affines = [param_utils.select_time(s.attrs["transforms"][transform_key], 0) for s in [sim1, sim2]]
+    transf_affine = np.matmul(np.linalg.inv(affines[1]), affines[0])
+    shape = np.floor(np.array(uppers[0] - lowers[0]) / spacing + 1).astype(np.uint64)
+    osp = {
+        "origin": {d: float(lowers[0][i]) for i, d in enumerate(sdims)},
+        "spacing": {d: float(spacing[i]) for i, d in enumerate(sdims)},
+        "shape": {d: int(shape[i]) for i, d in enumerate(sdims)},
+    }
+    out = []
+    for isim, sim in enumerate([sim1, sim2]):
+        # allow_noop=False: the reference's no-op shortcut would hand back the input (already float32 there,
+        # transformation.py:102-119); resampling on an identical grid yields the same values as float32
+        t = transform_sim(sim, [None, transf_affine][isim], output_stack_properties=osp, mode="constant", cval=np.nan,
+                          device=device, allow_noop=False)
+        si_utils.set_sim_affine(t, si_utils.get_affine_from_sim(sim1, transform_key), transform_key)
+        out.append(t)
+    return out[0], out[1]
+
+
+def get_affine_from_intrinsic_affine(data_affine, sim_fixed, sim_moving, transform_key_fixed=None, transform_key_moving=None):
+    """registration.get_affine_from_intrinsic_affine (registration.py:1382-1474), including its use of
+    ``transform_key_moving`` for the fixed view (:1423-1425)."""
+    from . import spatial_image_utils as si_utils
+
+    n = data_affine.shape[0]
+    p2w_fixed = np.eye(n) if transform_key_fixed is None else param_utils.select_time(sim_fixed.attrs["transforms"][transform_key_moving], 0)
+    p2w_moving = np.eye(n) if transform_key_moving is None else param_utils.select_time(sim_moving.attrs["transforms"][transform_key_moving], 0)
+
+    def d_to_p(sim):
+        return np.matmul(
+            param_utils.affine_from_translation(si_utils.get_origin_from_sim(sim, asarray=True)),
+            np.diag(list(si_utils.get_spacing_from_sim(sim, asarray=True)) + [1]),
+        )
+
+    D_to_W_f = np.matmul(p2w_moving, d_to_p(sim_moving))
+    D_to_W_c = np.matmul(p2w_fixed, d_to_p(sim_fixed))
+    return np.matmul(D_to_W_f, np.matmul(data_affine, np.linalg.inv(D_to_W_c)))
+
+
+def dispatch_pairwise_reg_func(pairwise_reg_func, fixed_data=None, moving_data=None, skip_constant_check=False, device=0,
+                               **pairwise_reg_func_kwargs):
+    """registration.dispatch_pairwise_reg_func (registration.py:1477-1544): constant-image guard + call."""
+    if fixed_data is not None and moving_data is not None and not skip_constant_check:
+        for name, im in (("fixed", fixed_data), ("moving", moving_data)):
+            _, mn, mx, _ = _reg_ops.rescale_intensity(_as_array(im), device, out_on_device=is_device_array(_as_array(im)))
+            if mn == mx:
+                warnings.warn(
+                    "An overlap region between tiles/views is all zero or constant. Assuming identity transform.",
+                    UserWarning, stacklevel=2,
+                )
+                nd = _as_array(fixed_data).ndim
+                return {"affine_matrix": param_utils.identity_transform(nd), "quality": np.nan}
+    if fixed_data is not None:
+        pairwise_reg_func_kwargs["fixed_data"] = fixed_data
+        pairwise_reg_func_kwargs["moving_data"] = moving_data
+    try:
+        return pairwise_reg_func(device=device, **pairwise_reg_func_kwargs)
+    except TypeError as e:
+        if "device" not in str(e):
+            raise
+        return pairwise_reg_func(**pairwise_reg_func_kwargs)
+
+
+def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=None, overlap_tolerance=None,
+                           pairwise_reg_func=phase_correlation_registration, pairwise_reg_func_kwargs=None, device=0,
+                           _bin_cache=None):
+    """registration.register_pair_of_msims (registration.py:1547-2058) for pixel-space registration functions
+    (the form the reference's phase correlation has): returns {"transform", "quality", "bbox"}."""
+    from . import msi_utils
+    from . import spatial_image_utils as si_utils
+
+    pairwise_reg_func_kwargs = dict(pairwise_reg_func_kwargs or {})
+    sim1 = msi_utils.get_sim_from_msim(msim1) if msi_utils.is_msim(msim1) else msim1
+    sim2 = msi_utils.get_sim_from_msim(msim2) if msi_utils.is_msim(msim2) else msim2
+    sdims = si_utils.get_spatial_dims_from_sim(sim1)
+    ndim = len(sdims)
+    if overlap_tolerance is None:
+        overlap_tolerance = {d: 0.0 for d in sdims}
+    elif isinstance(overlap_tolerance, (int, float)):
+        overlap_tolerance = {d: float(overlap_tolerance) for d in sdims}
+    else:
+        overlap_tolerance = {d: float(overlap_tolerance.get(d, 0.0)) for d in sdims}
+    if registration_binning is None:
+        registration_binning = get_optimal_registration_binning(sim1, sim2)
+
+    def binned(sim):
+        if max(registration_binning.values()) <= 1:
+            return sim
+        key = (id(sim.data), tuple(sorted(registration_binning.items())))
+        if _bin_cache is not None and key in _bin_cache:
+            return _bin_cache[key]
+        b = _bin_sim(sim, registration_binning, device)
+        if _bin_cache is not None:
+            _bin_cache[key] = b
+        return b
+
+    reg_sims_b = [binned(sim1), binned(sim2)]
+    ov = _get_overlap_bboxes(reg_sims_b[0], reg_sims_b[1], transform_key, None, overlap_tolerance)
+    if ov is None:
+        raise ValueError("views do not overlap")
+    lowers, uppers = ov["lowers"], ov["uppers"]
+    spacings = [si_utils.get_spacing_from_sim(s) for s in reg_sims_b]
+    tol = 1e-6
+    reg_sims_b = [
+        si_utils.sim_sel_coords(
+            sim, {d: slice(lowers[i][k] - tol - spacings[i][d], uppers[i][k] + tol + spacings[i][d]) for k, d in enumerate(sdims)}
+        )
+        for i, sim in enumerate(reg_sims_b)
+    ]
+    fixed, moving = sims_to_intrinsic_coord_system(reg_sims_b[0], reg_sims_b[1], transform_key, (lowers, uppers), device)
+    res = dispatch_pairwise_reg_func(pairwise_reg_func, fixed_data=fixed, moving_data=moving, device=device,
+                                     **pairwise_reg_func_kwargs)
+    if isinstance(res, list):   # Q2: the reference's `[zeros(ndim)]` return is unusable downstream; surface it
+        raise RuntimeError("phase correlation produced no admissible shift candidate (registration.py:479-480)")
+    affine = np.asarray(res["affine_matrix"], dtype=np.float64)
+    affine_phys = get_affine_from_intrinsic_affine(affine, fixed, moving, transform_key, transform_key)
+    ovp = _get_overlap_bboxes(sim1, sim2, transform_key, transform_key, overlap_tolerance)
+    return {"transform": affine_phys, "quality": float(res["quality"]) if res["quality"] is not None else np.nan,
+            "bbox": np.array([ovp["lowers"][0], ovp["uppers"][0]])}
+
+
+def compute_pairwise_registrations(msims, edges, transform_key, registration_binning=None, overlap_tolerance=0.0,
+                                   pairwise_reg_func=phase_correlation_registration, pairwise_reg_func_kwargs=None,
+                                   pairwise_executor=None, device=0):
+    """registration.compute_pairwise_registrations (registration.py:2622-2714): either hand all edges to a
+    user ``pairwise_executor(msims, edges, register_kwargs)`` or loop over them on one device."""
+    register_kwargs = dict(transform_key=transform_key, registration_binning=registration_binning,
+                           overlap_tolerance=overlap_tolerance, pairwise_reg_func=pairwise_reg_func,
+                           pairwise_reg_func_kwargs=pairwise_reg_func_kwargs)
+    if pairwise_executor is not None:
+        results = pairwise_executor(msims, list(edges), register_kwargs)
+        if len(results) != len(edges):
+            raise ValueError("pairwise_executor must return one result per edge")
+        return results
+    cache = {}
+    return [register_pair_of_msims(msims[i], msims[j], device=device, _bin_cache=cache, **register_kwargs) for i, j in edges]
+
+
+def resolve_translations(n_views, edges, pair_results, reference_view=0, weights=None):
+    """Minimal groupwise resolution for translation-only pairwise results: least squares on
+    tau_j - tau_i = -d_ij with tau_ref = 0 (each connected component gets its own reference).
+
+    Stand-in for param_resolution.groupwise_resolution(method="global_optimization")
+    (src/multiview_stitcher/param_resolution/__init__.py:44-150): the reference iterates virtual-bead fits and
+    prunes inconsistent edges; for consistent translation graphs both reduce to this linear system."""
+    ndim = np.asarray(pair_results[0]["transform"]).shape[0] - 1 if pair_results else 0
+    params = [np.eye(ndim + 1) for _ in range(n_views)]
+    if not edges:
+        return params
+    adj = {v: set() for v in range(n_views)}
+    for i, j in edges:
+        adj[i].add(j)
+        adj[j].add(i)
+    seen = set()
+    for start in range(n_views):
+        if start in seen:
+            continue
+        comp, stack = [], [start]
+        seen.add(start)
+        while stack:
+            v = stack.pop()
+            comp.append(v)
+            for w in adj[v]:
+                if w not in seen:
+                    seen.add(w)
+                    stack.append(w)
+        comp = sorted(comp)
+        if len(comp) == 1:
+            continue
+        ref = reference_view if reference_view in comp else comp[0]
+        idx = {v: k for k, v in enumerate(comp)}
+        rows, rhs, wts = [], [], []
+        for k, (i, j) in enumerate(edges):
+            if i not in idx:
+                continue
+            r = np.zeros(len(comp))
+            r[idx[j]] = 1.0
+            r[idx[i]] = -1.0
+            rows.append(r)
+            rhs.append(-np.asarray(pair_results[k]["transform"])[:ndim, ndim])
+            wts.append(1.0 if weights is None else float(weights[k]))
+        A = np.array(rows) * np.sqrt(np.array(wts))[:, None]
+        B = np.array(rhs) * np.sqrt(np.array(wts))[:, None]
+        anchor = np.zeros((1, len(comp)))
+        anchor[0, idx[ref]] = 1e3
+        A = np.vstack([A, anchor])
+        B = np.vstack([B, np.zeros((1, ndim))])
+        tau, *_ = np.linalg.lstsq(A, B, rcond=None)
+        tau -= tau[idx[ref]]
+        for v in comp:
+            params[v] = param_utils.affine_from_translation(tau[idx[v]])
+    return params
+
+
+def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None, new_transform_key=None,
+             registration_binning=None, overlap_tolerance=0.0, pairwise_reg_func=phase_correlation_registration,
+             pairwise_reg_func_kwargs=None, groupwise_resolution_method="global_optimization",
+             groupwise_resolution_kwargs=None, pre_registration_pruning_method="alternating_pattern",
+             post_registration_do_quality_filter=False, post_registration_quality_threshold=0.2, pairs=None,
+             n_parallel_pairwise_regs=None, pairwise_executor=None, return_dict=False, device=0):
+    """Register views to a common coordinate system (registration.register, registration.py:2227-2620).
+
+    Flow as in the reference: (1) overlap graph, (2) pairwise registrations of the selected edges,
+    (3) groupwise resolution, (4) write ``new_transform_key`` (rebased on ``transform_key``).
+    Accepts MultiscaleSpatialImages or SpatialImages (numpy- or DeviceArray-backed).  Host-side
+    stand-ins, documented in DESIGN.md: the overlap graph is built from world AABBs (axis-aligned
+    views) and every pruning method keeps the face-sharing neighbours; the groupwise resolution is
+    the linear translation solve of ``resolve_translations``."""
+    from . import msi_utils, mv_graph
+    from . import spatial_image_utils as si_utils
+
+    if transform_key is None:
+        raise ValueError("transform_key must be provided")
+    sims = [msi_utils.get_sim_from_msim(m) if msi_utils.is_msim(m) else m for m in msims]
+    if "c" in sims[0].dims and sims[0].sizes["c"] > 1:
+        if reg_channel is None and reg_channel_index is None:
+            raise Exception("Please choose a registration channel.")
+        ci = reg_channel_index if reg_channel is None else int(np.nonzero(sims[0].coords["c"] == reg_channel)[0][0])
+        sims_reg = [s.isel({"c": ci}) for s in sims]
+    else:
+        sims_reg = [s.isel({"c": 0}) if "c" in s.dims else s for s in sims]
+    nt = sims_reg[0].sizes.get("t", 1) if "t" in sims_reg[0].dims else 1
+
+    # (1) graph
+    sps = [si_utils.get_stack_properties_from_sim(s) for s in sims_reg]
+    affs = [param_utils.select_time(si_utils.get_affine_from_sim(s, transform_key), 0) for s in sims_reg]
+    if pairs is None:
+        cand = mv_graph.build_view_adjacency_pairs(sps, affs)
+        if pre_registration_pruning_method is not None:
+            cand = mv_graph.prune_to_axis_aligned(cand, sps, affs)
+        edges = [(i, j) for i, j, _ in cand]
+    else:
+        edges = [tuple(p) for p in pairs]
+
+    # (2) pairwise registrations per time point
+    params_t, all_results = [], []
+    for it in range(nt):
+        fields = [s.isel({"t": it}) if "t" in s.dims else s for s in sims_reg]
+        for f, s in zip(fields, sims_reg):
+            f.attrs["transforms"] = {k: param_utils.select_time(v, it) for k, v in s.attrs.get("transforms", {}).items()}
+        results = compute_pairwise_registrations(
+            fields, edges, transform_key, registration_binning, overlap_tolerance, pairwise_reg_func,
+            pairwise_reg_func_kwargs, pairwise_executor, device,
+        )
+        keep = list(range(len(edges)))
+        if post_registration_do_quality_filter:
+            keep = [k for k in keep if results[k]["quality"] >= post_registration_quality_threshold]
+        # (3) groupwise resolution
+        params_t.append(resolve_translations(len(sims), [edges[k] for k in keep], [results[k] for k in keep]))
+        all_results.append(results)
+    params = [np.stack([params_t[it][v] for it in range(nt)], axis=0) if "t" in sims_reg[0].dims else params_t[0][v]
+              for v in range(len(sims))]
+
+    # (4) write back
+    if new_transform_key is not None:
+        for m, p in zip(msims, params):
+            if msi_utils.is_msim(m):
+                msi_utils.set_affine_transform(m, p, transform_key=new_transform_key, base_transform_key=transform_key)
+            else:
+                si_utils.set_sim_affine(m, p, new_transform_key, base_transform_key=transform_key)
+    if return_dict:
+        return {"params": params,
+                "pairwise_registration": {"edges": edges, "results": all_results,
+                                          "metrics": {"qualities": {e: r["quality"] for e, r in zip(edges, all_results[0])}}}}
+    return params

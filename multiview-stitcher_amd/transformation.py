@@ -80,20 +80,39 @@ def fill_view_geometry(view, data_ptr, dtype_code, mem, shape, strides_elems, ma
     view.matrix[:] = m3.reshape(-1).tolist()
 
 
-def resample_array(data, matrix, offset, output_shape, order=1, cval=0.0, device=0):
+def resample_array(data, matrix, offset, output_shape, order=1, cval=0.0, device=0, out_on_device=None):
     """scipy.ndimage.affine_transform(data, matrix, offset, output_shape, order, 'constant', cval)
-    for order 0|1 on the GPU; float32 result (transformation.py:136-139)."""
+    for order 0|1 on the GPU; float32 result (transformation.py:136-139).  ``data`` may be a numpy
+    array or a (possibly strided) DeviceArray; the result stays on the device in the latter case."""
+    from .device import DeviceArray, is_device_array
+
     lib = _lib.init(device)
-    data = np.ascontiguousarray(data)
-    if data.dtype not in _lib.DTYPE_CODES:
-        data = data.astype(np.float32)
     view = _lib.mvs_view_t()
-    strides = [s // data.itemsize for s in data.strides]
-    fill_view_geometry(view, data.ctypes.data, _lib.DTYPE_CODES[data.dtype], _lib.MVS_MEM_HOST, data.shape, strides, matrix, offset)
-    out = np.empty(tuple(int(s) for s in output_shape), dtype=np.float32)
-    rc = lib.mvs_resample(device, C.byref(view), _lib.i64x3(shape3(output_shape)), int(order), float(cval),
-                          out.ctypes.data, _lib.MVS_MEM_HOST)
+    on_dev = is_device_array(data)
+    if out_on_device is None:
+        out_on_device = on_dev
+    if on_dev:
+        if data.dtype not in _lib.DTYPE_CODES:
+            raise TypeError(f"unsupported dtype {data.dtype}")
+        fill_view_geometry(view, data.ptr, _lib.DTYPE_CODES[data.dtype], _lib.MVS_MEM_DEVICE, data.shape, data.strides, matrix, offset)
+        keep = data
+    else:
+        data = np.ascontiguousarray(data)
+        if data.dtype not in _lib.DTYPE_CODES:
+            data = data.astype(np.float32)
+        strides = [int(np.prod(data.shape[k + 1:])) for k in range(data.ndim)]   # C order; size-1 axes have arbitrary numpy strides
+        fill_view_geometry(view, data.ctypes.data, _lib.DTYPE_CODES[data.dtype], _lib.MVS_MEM_HOST, data.shape, strides, matrix, offset)
+        keep = data
+    oshape = tuple(int(s) for s in output_shape)
+    if out_on_device:
+        out = DeviceArray.empty(oshape, np.float32, device)
+        optr, omem = out.ptr, _lib.MVS_MEM_DEVICE
+    else:
+        out = np.empty(oshape, dtype=np.float32)
+        optr, omem = out.ctypes.data, _lib.MVS_MEM_HOST
+    rc = lib.mvs_resample(device, C.byref(view), _lib.i64x3(shape3(output_shape)), int(order), float(cval), optr, omem)
     _lib.check(rc, device, "mvs_resample")
+    del keep
     return out
 
 
@@ -104,6 +123,7 @@ def transform_sim(
     keep_transform_keys=False,
     input_spacing=None,
     device=0,
+    allow_noop=True,
     **affine_transform_kwargs,
 ):
     """transformation.transform_sim (transformation.py:15-148) on the HIP backend.
@@ -131,7 +151,8 @@ def transform_sim(
         output_stack_properties["shape"], dict) else tuple(int(s) for s in output_stack_properties["shape"])
     in_shape = tuple(si_utils.get_shape_from_sim(sim, asarray=True))
     is_noop = (
-        out_shape == in_shape
+        allow_noop
+        and out_shape == in_shape
         and np.allclose(matrix_prime, np.eye(ndim), rtol=0, atol=1e-10)
         and np.allclose(offset_prime, 0, rtol=0, atol=1e-10)
     )
