@@ -138,6 +138,19 @@ def cpu_baseline(args, grid, tile, overlap):
     return res
 
 
+def fuse_traffic_bytes(grid, tile):
+    """HBM bytes per fuse launch from the committed PMC pass (FETCH_SIZE x2 per the calibration + WRITE_SIZE,
+    profiles/round1_summary.md); only valid for the workload it was measured on."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "round1_fuse_traffic.json")) as f:
+            t = json.load(f)
+        if list(grid) == [4, 4, 4] and list(tile) == [512, 512, 512]:
+            return t["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     args = parse_args()
     import torch
@@ -222,6 +235,11 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = out_vox * world / (elapsed / args.steps) / 1e6
 
+    reg_err = None
+    if do_register:
+        from multiview_stitcher_amd import param_utils
+        rec = np.array([param_utils.select_time(si.get_affine_from_sim(s, key_out), 0)[:3, 3] for s in sims])
+        reg_err = float(np.max(np.abs(rec - (jitters - jitters[0]))))
     if rank == 0:
         result = {
             "metric": "Mvoxels/s register+fuse, 3D tile grid" if do_register else "Mvoxels/s fuse only, 3D tile grid",
@@ -245,15 +263,16 @@ def main():
                 "tiles_per_gpu": len(tiles),
                 "register_ms_per_step": float(np.mean(reg_ms)) if do_register else None,
                 "fuse_kernel_ms": k_ms,
+                "registration_max_abs_error_px": reg_err,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fuse_kernel<u16,u16,order1,weighted_average>",
+                "kernel": "fuse_tr_kernel<u16,u16,weighted_average>",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": fuse_traffic_bytes(grid, tile),
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
         }
