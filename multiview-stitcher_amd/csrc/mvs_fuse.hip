@@ -448,7 +448,8 @@ __device__ __forceinline__ float blend_ramp_nb(float x) {
     return (x >= 1.f) ? 1.f : w;
 }
 
-constexpr int kRowValid = 1, kRowInside = 2, kRowAllOne = 4;
+constexpr int kRowValid = 1, kRowInside = 2, kRowAllOne = 4, kRowXTab = 8;
+constexpr int kXTabMargin = 4;   // table entries kept on either side of [lo_x, hi_x] (a lane reads 4 consecutive ones)
 constexpr int kCand = 16;   // candidate views evaluated per round (16 views x 4 rows = 64 lanes)
 
 // Compact per-view record of the fast path (160 bytes = 10 x 16-byte loads per lane).
@@ -457,7 +458,7 @@ struct alignas(16) TrView {
     int io[3];                   // input index = chunk index + io
     int wnz;                     // 5 (3D support) or 1 (2D)
     float fw[3];                 // fractional interpolation weights (0: single tap)
-    float pad0;
+    int xtab_off;                // index of this view's x-weight table entry for chunk x = lo[2] (see xweight_table_kernel)
     unsigned long long data;     // device pointer of the slab
     long long span;              // elements from data[0] to the last voxel, + 1
     int stride_y, stride_z;      // elements
@@ -472,6 +473,7 @@ static_assert(sizeof(TrView) == 160, "TrView layout");
 struct TrParams {
     const TrView* views;
     const int* cull;       // SoA [6][nviews]: zlo, zhi, ylo, yhi, xlo, xhi
+    const float* xtab;     // per-view blend weight along x for rows in the yz interior of the view
     int nviews;
     void* out;
     int oz, oy, ox;
@@ -480,6 +482,22 @@ struct TrParams {
     int is3d;
     int ablate;
 };
+
+// Blend weight along x of one view for rows whose bracketing (z, y) support nodes are all >= sx (and sx >= 1):
+// there G1 = sx, the ramp zone lies in the first cell where W(x) = u(x) * sx, and the weight is 1 beyond it --
+// the same profile for all such rows, tabulated once per call: tab[off + (x - lo_x)], x in [lo_x - margin, hi_x + margin].
+__global__ void xweight_table_kernel(const TrView* __restrict__ views, int nviews, float* __restrict__ tab) {
+    const int v = blockIdx.y;
+    if (v >= nviews) return;
+    const TrView& V = views[v];
+    const int len = V.hi[2] - V.lo[2] + 1;
+    if (len <= 0) return;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x - kXTabMargin; i < len + kXTabMargin; i += gridDim.x * blockDim.x) {
+        const int x = V.lo[2] + i;
+        const float u = fold_u(x, V.sup_ilo[2], V.sup_flo[2], V.sup_ihi[2], V.sup_fhi[2], V.sup_k[2]);
+        tab[V.xtab_off + i] = (u >= 0.f) ? blend_ramp_nb(u * V.ws[2]) : 0.f;
+    }
+}
 
 union F4I4 {
     float4 f;
@@ -653,6 +671,7 @@ __global__ __launch_bounds__(256) void fuse_tr_kernel(TrParams P) {
             const int lo_z = q0.i.x, lo_y = q0.i.y, lo_x = q0.i.z, hi_z = q0.i.w, hi_y = q1.i.x, hi_x = q1.i.y;
             const int io_z = q1.i.z, io_y = q1.i.w, io_x = q2.i.x, wnz = q2.i.y;
             const float fw_z = q2.f.z, fw_y = q2.f.w, fw_x = q3.f.x;
+            const int xtab_off = q3.i.y;
             const int data_lo = q3.i.z, data_hi = q3.i.w, span_lo = q4.i.x;
             const int st_y = q4.i.z, st_z = q4.i.w;
             const int silo_z = q5.i.x, silo_y = q5.i.y, silo_x = q5.i.z, sihi_z = q5.i.w, sihi_y = q6.i.x, sihi_x = q6.i.y;
@@ -689,6 +708,13 @@ __global__ __launch_bounds__(256) void fuse_tr_kernel(TrParams P) {
                             g1 = fmaf(fminf(m11, a2), fy, fminf(m10, a2) * uy_);
                             const float G2 = has_z ? fmaf(g1, fz, g0 * uz_) : g0;
                             dG = G2 - G1;
+                            // every bracketing (z,y) node is at least sx from the border, so G1 == sx exactly and G2 >= G1;
+                            // with sx >= 1 the ramp zone (W < 1) lies inside the first cell where W = u * sx, and beyond
+                            // it the weight is 1 whatever G2 is: the row follows the view's tabulated x profile
+                            if (fminf(fminf(m00, m01), fminf(m10, m11)) >= a1 && a1 >= 1.f) {
+                                G1 = a1;
+                                flags |= kRowXTab;
+                            }
                             // W(x) is concave piecewise linear along the row: >= 1 at both ends of the
                             // covered part of the segment => every voxel's weight is exactly 1.
                             const float ua = fold_u(xa, silo_x, sflo_x, sihi_x, sfhi_x, sk_x);
@@ -708,12 +734,13 @@ __global__ __launch_bounds__(256) void fuse_tr_kernel(TrParams P) {
             for (int c = 0; c < ncand; ++c) {
                 const int l0 = c * 4;
                 int fl[kTrRows];
-                int anyf = 0, needw = 0;
+                int anyf = 0, needw = 0, needt = 0;
 #pragma unroll
                 for (int r = 0; r < kTrRows; ++r) {
                     fl[r] = rl(flags, l0 + r);
                     anyf |= fl[r];
-                    needw |= (fl[r] & kRowValid) && !(fl[r] & kRowAllOne);
+                    needw |= (fl[r] & kRowValid) && !(fl[r] & (kRowAllOne | kRowXTab));
+                    needt |= (fl[r] & kRowValid) && (fl[r] & kRowXTab) && !(fl[r] & kRowAllOne);
                 }
                 if (!(anyf & kRowValid)) continue;
                 const int xlo = rl(lo_x, l0), xhi = rl(hi_x, l0);
@@ -801,6 +828,15 @@ __global__ __launch_bounds__(256) void fuse_tr_kernel(TrParams P) {
                     dh0 = (float)(rl(sihi_x, l0) - xc0) - rlf(sfhi_x, l0);
                 }
                 const float uy = 1.f - wy;
+                float wt[kVPT] = {1.f, 1.f, 1.f, 1.f};
+                if (WA && needt) {
+                    // the view's x profile, shared by all yz-interior rows of this group
+                    const int len = xhi - xlo + 1;
+                    int ti = xc0 - xlo;
+                    ti = min(max(ti, -kXTabMargin), len + kXTabMargin - kVPT);   // lanes off the view read a clamped window (masked below)
+                    const float4 t4 = *reinterpret_cast<const float4*>(P.xtab + rl(xtab_off, l0) + ti);
+                    wt[0] = t4.x; wt[1] = t4.y; wt[2] = t4.z; wt[3] = t4.w;
+                }
 
 #pragma unroll
                 for (int r = 0; r < kTrRows; ++r) {
@@ -830,13 +866,24 @@ __global__ __launch_bounds__(256) void fuse_tr_kernel(TrParams P) {
                                 den[r][j] += ok ? 1.f : 0.f;
                             }
                         } else {
+                            const bool xtab = fl[r] & kRowXTab;
                             const float G1r = rlf(G1, l0 + r), dGr = rlf(dG, l0 + r);
                             const bool inside = fl[r] & kRowInside;
+                            float wr[kVPT];
+                            if (xtab) {
+#pragma unroll
+                                for (int j = 0; j < kVPT; ++j) wr[j] = wt[j];
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < kVPT; ++j) {
+                                    const float u = fminf(dl0 + (float)j, dh0 - (float)j) * kx;
+                                    const float W = row_profile(u, G1r, dGr);
+                                    wr[j] = (u >= 0.f && inside) ? blend_ramp_nb(W) : 0.f;
+                                }
+                            }
 #pragma unroll
                             for (int j = 0; j < kVPT; ++j) {
-                                const float u = fminf(dl0 + (float)j, dh0 - (float)j) * kx;
-                                const float W = row_profile(u, G1r, dGr);
-                                float w = (u >= 0.f && inside) ? blend_ramp_nb(W) : 0.f;
+                                float w = wr[j];
                                 const bool ok = ISF ? (okj[j] && val[j] == val[j]) : okj[j];
                                 w = ok ? w : 0.f;
                                 const bool pos = w > 0.f;
@@ -1067,6 +1114,7 @@ static void fill_tr_view(const DevView& d, TrView* t) {
     t->span = d.span;
     t->stride_y = (int)d.stride_y;
     t->stride_z = (int)d.stride_z;
+    t->xtab_off = 0;
 }
 
 template <typename TIn, typename TOut>
@@ -1162,6 +1210,7 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
     }
     bool use_tr = !c->force_generic;
     for (int i = 0; i < n_views && use_tr; ++i) use_tr = hviews[i].tr_ok != 0;
+    size_t xtab_total = 0;
     int* hcull = (int*)((char*)hviews + views_bytes);
     TrView* htr = (TrView*)((char*)hviews + views_bytes + cull_bytes);
     if (use_tr)
@@ -1171,6 +1220,8 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
                 hcull[(2 * k + 1) * n_views + i] = hviews[i].hi[k];
             }
             fill_tr_view(hviews[i], &htr[i]);
+            htr[i].xtab_off = (int)xtab_total + kXTabMargin;
+            xtab_total += (size_t)std::max(hviews[i].hi[2] - hviews[i].lo[2] + 1, 0) + 2 * kXTabMargin;
         }
     MVS_HIP_TRY(c, hipMemcpyAsync(dviews, hviews, params_bytes, hipMemcpyHostToDevice, c->stream));
 
@@ -1215,6 +1266,12 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
         T.nbz = P.nbz; T.nby = P.nby; T.nbx = P.nbx;
         T.is3d = (os[0] > 1) ? 1 : 0;
         T.ablate = c->ablate;
+        float* xtab = (float*)mvs_scratch(c, 3, (xtab_total + 64) * sizeof(float));
+        if (!xtab) return MVS_ERR_HIP;
+        T.xtab = xtab;
+        if (opts->fusion == MVS_FUSE_WEIGHTED_AVERAGE) {
+            hipLaunchKernelGGL(xweight_table_kernel, dim3(16, n_views), dim3(256), 0, c->stream, T.views, n_views, xtab);
+        }
         switch (dtype) {
             case MVS_U8: launch_fuse_tr<unsigned char, unsigned char>(T, opts->fusion, (int)nblocks, c->stream); break;
             case MVS_U16: launch_fuse_tr<unsigned short, unsigned short>(T, opts->fusion, (int)nblocks, c->stream); break;
