@@ -22,6 +22,7 @@
 // in-bounds test (c < 0 || c > n-1 -> cval) classifies every voxel exactly as
 // NI_GeometricTransform does; interpolation and accumulation are float32.
 #include "mvs_internal.h"
+#include "mvs_fuse_dev.h"
 
 #include <cmath>
 #include <cstring>
@@ -33,31 +34,6 @@ constexpr int kBrickX = 64;      // voxels along x per brick (16 lanes x 4 voxel
 constexpr int kVPT = 4;          // voxels per thread along x
 constexpr int kLdsTables = 8;    // blend tables staged in LDS per pass
 constexpr float kPiHalf = 1.57079632679489661923f;
-
-struct DevView {
-    const void* data;
-    long long stride_z, stride_y;   // elements
-    int nz, ny, nx;                 // slab shape
-    int wnz;                        // z extent of the support table: 5 (3D) or 1 (2D)
-    double m[9];
-    double off[3];
-    double wm[9];
-    double woff[3];
-    float edt[125];
-    // ---- translation fast path (valid when tr_ok): matrix == I, diagonal support map ----
-    int tr_ok;
-    int io[3];        // input index = chunk index + io
-    float fw[3];      // fractional interpolation weights (0 => single tap on that axis)
-    int lo[3], hi[3]; // chunk-index range where the view is in bounds, exact per scipy's test
-    float ws[3];      // tent scales of the closed-form support table edt = min_d(ws_d * tent(i_d))
-    float sup_k[3];   // support nodes per output pixel (= w_matrix diagonal)
-    // chunk-index coordinates of support nodes 0 and 4, split as ilo + flo and ihi - fhi with
-    // integer ilo/ihi and fractions in [0,1): distances to them are exact in float
-    int sup_ilo[3], sup_ihi[3];
-    float sup_flo[3], sup_fhi[3];
-    long long span;   // elements from data[0] to the last voxel of the slab, + 1
-    float pad[3];
-};
 
 struct FuseParams {
     const DevView* views;
@@ -1390,4 +1366,29 @@ extern "C" int mvs_blend_weights(int device, const mvs_view_t* view, int32_t ndi
         MVS_HIP_TRY(c, hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MVS_OK;
+}
+
+
+// ---- helpers shared with mvs_gauss.hip (content-based weights) --------------------------------
+int mvs_fill_dev_view(MvsContext* c, const mvs_view_t& v, int ndim, const void* dev_data, DevView* d) {
+    return fill_dev_view(c, v, ndim, dev_data, d);
+}
+
+void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, float cval, float* out, const int64_t shape[3]) {
+    const long long n = (long long)shape[0] * shape[1] * shape[2];
+    const int nblocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
+#define MVS_RS(T, O) hipLaunchKernelGGL((resample_kernel<T, O>), dim3(nblocks), dim3(256), 0, c->stream, d, out, \
+                                        (int)shape[0], (int)shape[1], (int)shape[2], cval)
+    switch (dtype) {
+        case MVS_U8: if (order) MVS_RS(unsigned char, 1); else MVS_RS(unsigned char, 0); break;
+        case MVS_U16: if (order) MVS_RS(unsigned short, 1); else MVS_RS(unsigned short, 0); break;
+        default: if (order) MVS_RS(float, 1); else MVS_RS(float, 0); break;
+    }
+#undef MVS_RS
+}
+
+void mvs_launch_blend(MvsContext* c, const DevView& d, float* out, const int64_t shape[3]) {
+    const long long n = (long long)shape[0] * shape[1] * shape[2];
+    const int nblocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(blend_kernel, dim3(nblocks), dim3(256), 0, c->stream, d, out, (int)shape[0], (int)shape[1], (int)shape[2]);
 }

@@ -1,0 +1,34 @@
+// mvs_fuse_dev.h -- internal: device-side view record of the generic fuse path and launch helpers
+// shared between mvs_fuse.hip and mvs_gauss.hip.
+#pragma once
+#include "mvs_internal.h"
+
+struct DevView {
+    const void* data;
+    long long stride_z, stride_y;   // elements
+    int nz, ny, nx;                 // slab shape
+    int wnz;                        // z extent of the support table: 5 (3D) or 1 (2D)
+    double m[9];
+    double off[3];
+    double wm[9];
+    double woff[3];
+    float edt[125];
+    // ---- translation fast path (valid when tr_ok): matrix == I, diagonal support map ----
+    int tr_ok;
+    int io[3];        // input index = chunk index + io
+    float fw[3];      // fractional interpolation weights (0 => single tap on that axis)
+    int lo[3], hi[3]; // chunk-index range where the view is in bounds, exact per scipy's test
+    float ws[3];      // tent scales of the closed-form support table edt = min_d(ws_d * tent(i_d))
+    float sup_k[3];   // support nodes per output pixel (= w_matrix diagonal)
+    // chunk-index coordinates of support nodes 0 and 4, split as ilo + flo and ihi - fhi with
+    // integer ilo/ihi and fractions in [0,1): distances to them are exact in float
+    int sup_ilo[3], sup_ihi[3];
+    float sup_flo[3], sup_fhi[3];
+    long long span;   // elements from data[0] to the last voxel of the slab, + 1
+    float pad[3];
+};
+
+
+int mvs_fill_dev_view(MvsContext* c, const mvs_view_t& v, int ndim, const void* dev_data, DevView* d);
+void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, float cval, float* out, const int64_t shape[3]);
+void mvs_launch_blend(MvsContext* c, const DevView& d, float* out, const int64_t shape[3]);

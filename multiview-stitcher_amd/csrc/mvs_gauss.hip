@@ -1,7 +1,276 @@
-// mvs_gauss.hip -- content-based fusion weights (weights.py:22-74). Placeholder until the
-// separable NaN-aware Gaussian kernels land; reports MVS_ERR_UNSUPPORTED loudly.
-#include "mvs_internal.h"
+// mvs_gauss.hip -- content-based fusion weights (Preibisch) on the GPU (gfx950).
+//
+// mvs_fuse_chunk with weights == MVS_WEIGHTS_CONTENT_BASED reproduces, per output chunk (incl. halo),
+// the reference's fuse_np with weights_func=weights.content_based (src/multiview_stitcher/):
+//   field_ims_t[v]  = affine_transform(view v, cval=NaN)                         fusion/_core.py:1621-1633
+//   field_ws_t[v]   = blending weights * ~isnan, normalised over views           _core.py:1636-1649
+//   content_based:  I[bw < 1e-7] = NaN;  F_v = NG_s2((I - NG_s1(I))^2);  F = normalise(F)   weights.py:22-74
+//     NG_s(U) = gaussian(U with NaN->0) / gaussian(valid mask), NaN kept            weights.py:293-322
+//     gaussian = scipy.ndimage.gaussian_filter(sigma, mode="reflect", truncate=4): separable correlate1d,
+//     float64 kernel and accumulation, float32 output after every axis
+//   weighted_average_fusion: A = bw * F, normalise, sum_v I_v * A_v               _core.py:85-94
+//   trim halo, nan_to_num, astype(input dtype)                                     _core.py:1687-1713
+// The halo (2*sigma_2, weights.py:22) and the chunk grid are the caller's (fusion.fuse mirrors the
+// reference's), because the reflect boundary of the Gaussians makes results depend on the chunking.
+#include "mvs_fuse_dev.h"
 
-int mvs_fuse_content_based(MvsContext* c, const mvs_view_t*, int32_t, const mvs_fuse_opts_t*, void*) {
-    return mvs_fail(c, MVS_ERR_UNSUPPORTED, "content_based weights: HIP kernels not built yet");
+#include <cmath>
+#include <vector>
+
+namespace {
+
+inline int grid_for(long long n) { return (int)std::min<long long>((n + 255) / 256, 256 * 16); }
+
+struct Shape3 { int nz, ny, nx; };
+
+// bw[v] *= ~isnan(I[v]) ; then normalise over views: wsum = sum_v bw (float32, view order), 0 -> 1
+__global__ void mask_normalize_kernel(float* __restrict__ bw, const float* __restrict__ im, long long n, int nviews) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float wsum = 0.f;
+        for (int v = 0; v < nviews; ++v) {
+            float w = bw[(long long)v * n + i];
+            const float x = im[(long long)v * n + i];
+            if (x != x) w = 0.f;   // w * False
+            bw[(long long)v * n + i] = w;
+            wsum += w;             // np.nansum over axis 0 adds view by view in float32
+        }
+        if (wsum == 0.f) wsum = 1.f;
+        for (int v = 0; v < nviews; ++v) bw[(long long)v * n + i] /= wsum;
+    }
+}
+
+// A = I with NaN where the (normalised) blending weight < 1e-7 (weights.py:54-55); V0 = A with NaN -> 0; M = valid mask
+__global__ void prep_kernel(const float* __restrict__ im, const float* __restrict__ bw, long long n, float* __restrict__ A,
+                            float* __restrict__ V0, float* __restrict__ M) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float x = im[i];
+        if (bw[i] < 1e-7f) x = NAN;
+        const bool ok = (x == x);
+        A[i] = x;
+        V0[i] = ok ? x : 0.f;
+        M[i] = ok ? 1.f : 0.f;
+    }
+}
+
+// scipy.ndimage.correlate1d with a symmetric kernel along one axis, mode="reflect": double accumulation in
+// scipy's order (centre tap, then pairs from the farthest to the nearest), float32 output
+__global__ __launch_bounds__(256) void gauss1d_kernel(const float* __restrict__ src, float* __restrict__ dst, Shape3 S, int axis,
+                                                      int radius, const double* __restrict__ fw) {
+    const long long n = (long long)S.nz * S.ny * S.nx;
+    const int dims[3] = {S.nz, S.ny, S.nx};
+    const long long strides[3] = {(long long)S.ny * S.nx, S.nx, 1};
+    const int len = dims[axis];
+    const long long st = strides[axis];
+    const int period = 2 * len;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % S.nx);
+        const long long t = i / S.nx;
+        const int y = (int)(t % S.ny), z = (int)(t / S.ny);
+        const int pos = (axis == 0) ? z : (axis == 1) ? y : x;
+        const long long base = i - (long long)pos * st;
+        double acc = (double)src[i] * fw[radius];
+        for (int j = radius; j >= 1; --j) {
+            int p0 = pos - j, p1 = pos + j;
+            if (len == 1) { p0 = 0; p1 = 0; }
+            else {
+                p0 %= period; if (p0 < 0) p0 += period; if (p0 >= len) p0 = period - 1 - p0;
+                p1 %= period; if (p1 >= len) p1 = period - 1 - p1;
+            }
+            acc += ((double)src[base + (long long)p0 * st] + (double)src[base + (long long)p1 * st]) * fw[radius - j];
+        }
+        dst[i] = (float)acc;
+    }
+}
+
+// Z = VV / WW with WW[nan] = 1, Z[nan] = NaN (weights.py:314-320); then D = (A - Z)^2, V1 = D with NaN -> 0
+__global__ void ng_finish_sq_kernel(const float* __restrict__ VV, const float* __restrict__ WW, const float* __restrict__ A,
+                                    long long n, float* __restrict__ V1) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float a = A[i];
+        if (a != a) { V1[i] = 0.f; continue; }
+        const float zv = VV[i] / WW[i];
+        const float d = a - zv;
+        const float q = d * d;
+        V1[i] = (q == q) ? q : 0.f;   // a finite -> q finite unless WW == 0 (cannot happen where a is valid)
+    }
+}
+
+// F = VV2 / WW2 with NaN where A is NaN
+__global__ void ng_finish_kernel(const float* __restrict__ VV, const float* __restrict__ WW, const float* __restrict__ A,
+                                 long long n, float* __restrict__ F) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float a = A[i];
+        F[i] = (a == a) ? VV[i] / WW[i] : NAN;
+    }
+}
+
+template <typename TOut> __device__ __forceinline__ TOut cast_cb(float v);
+template <> __device__ __forceinline__ float cast_cb<float>(float v) { return v; }
+template <> __device__ __forceinline__ unsigned short cast_cb<unsigned short>(float v) { return (unsigned short)(int)v; }
+template <> __device__ __forceinline__ unsigned char cast_cb<unsigned char>(float v) { return (unsigned char)(int)v; }
+
+// normalise F over views (nansum, 0 -> 1), A = bw * Fn, normalise A, out = nansum(I * A); trimmed, nan_to_num, cast
+template <typename TOut>
+__global__ void cb_fuse_kernel(const float* __restrict__ im, const float* __restrict__ bw, const float* __restrict__ F, long long n,
+                               int nviews, Shape3 S, int tz, int ty, int tx, Shape3 O, TOut* __restrict__ out) {
+    const long long no = (long long)O.nz * O.ny * O.nx;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < no; o += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(o % O.nx);
+        const long long t = o / O.nx;
+        const int y = (int)(t % O.ny), z = (int)(t / O.ny);
+        const long long i = ((long long)(z + tz) * S.ny + (y + ty)) * S.nx + (x + tx);
+        float fsum = 0.f;
+        for (int v = 0; v < nviews; ++v) {
+            const float f = F[(long long)v * n + i];
+            if (f == f) fsum += f;
+        }
+        if (fsum == 0.f) fsum = 1.f;
+        float asum = 0.f;
+        for (int v = 0; v < nviews; ++v) {
+            const float a = bw[(long long)v * n + i] * (F[(long long)v * n + i] / fsum);
+            if (a == a) asum += a;
+        }
+        if (asum == 0.f) asum = 1.f;
+        float acc = 0.f;
+        for (int v = 0; v < nviews; ++v) {
+            const float a = bw[(long long)v * n + i] * (F[(long long)v * n + i] / fsum);
+            const float p = im[(long long)v * n + i] * (a / asum);
+            if (p == p) acc += p;
+        }
+        if (!(fabsf(acc) <= 3.4028234e38f)) acc = 0.f;
+        out[o] = cast_cb<TOut>(acc);
+    }
+}
+
+// scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, radius), radius = int(truncate * sigma + 0.5)
+void gaussian_kernel(double sigma, int* radius_out, std::vector<double>* w) {
+    const int radius = (int)(4.0 * sigma + 0.5);
+    w->resize(2 * radius + 1);
+    const double sigma2 = sigma * sigma;
+    double sum = 0.0;
+    for (int k = -radius; k <= radius; ++k) {
+        const double v = exp(-0.5 / sigma2 * (double)k * (double)k);
+        (*w)[k + radius] = v;
+        sum += v;
+    }
+    for (auto& v : *w) v /= sum;
+    *radius_out = radius;
+}
+
+}  // namespace
+
+int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_views, const mvs_fuse_opts_t* opts, void* out) {
+    if (opts->order != 0 && opts->order != 1) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "content_based: order 0|1 only");
+    const int dtype = views[0].dtype;
+    const size_t es = mvs_dtype_size(dtype);
+    const int64_t* cs = opts->out_shape;
+    const Shape3 S = {(int)cs[0], (int)cs[1], (int)cs[2]};
+    const long long n = (long long)S.nz * S.ny * S.nx;
+    int64_t os[3];
+    for (int k = 0; k < 3; ++k) os[k] = cs[k] - 2 * opts->trim[k];
+    const Shape3 O = {(int)os[0], (int)os[1], (int)os[2]};
+    const long long no = (long long)O.nz * O.ny * O.nx;
+
+    // ---- scratch layout (slot 6): I[V], BW[V], F[V], A, V0, M, T0, T1, T2 + filter kernels ----
+    const size_t vol = (size_t)n * 4;   // views are addressed as v * n floats in the kernels
+    const size_t need = vol * (3 * (size_t)n_views + 6) + 64 * 1024;
+    char* base = (char*)mvs_scratch(c, 6, need);
+    if (!base) return MVS_ERR_HIP;
+    float* I = (float*)base;
+    float* BW = (float*)(base + vol * n_views);
+    float* F = (float*)(base + vol * 2 * n_views);
+    float* A = (float*)(base + vol * 3 * n_views);
+    float* V0 = (float*)((char*)A + vol);
+    float* M = (float*)((char*)V0 + vol);
+    float* T0 = (float*)((char*)M + vol);
+    float* T1 = (float*)((char*)T0 + vol);
+    float* T2 = (float*)((char*)T1 + vol);
+    double* dfw = (double*)(base + ((vol * (3 * (size_t)n_views + 6) + 255) / 256) * 256);
+
+    // host slabs -> device (slot 0)
+    size_t host_bytes = 0;
+    for (int i = 0; i < n_views; ++i)
+        if (views[i].mem == MVS_MEM_HOST) {
+            if (views[i].stride[1] != views[i].shape[2] || views[i].stride[0] != views[i].shape[1] * views[i].shape[2])
+                return mvs_fail(c, MVS_ERR_UNSUPPORTED, "host slabs must be C-contiguous");
+            host_bytes += ((size_t)views[i].shape[0] * views[i].shape[1] * views[i].shape[2] * es + 255) / 256 * 256;
+        }
+    char* slab_base = nullptr;
+    if (host_bytes) {
+        slab_base = (char*)mvs_scratch(c, 0, host_bytes);
+        if (!slab_base) return MVS_ERR_HIP;
+    }
+    int r1, r2;
+    std::vector<double> w1, w2;
+    gaussian_kernel((double)opts->sigma_1, &r1, &w1);
+    gaussian_kernel((double)opts->sigma_2, &r2, &w2);
+    double* dfw1 = dfw;
+    double* dfw2 = dfw + w1.size();
+    MVS_HIP_TRY(c, hipMemcpyAsync(dfw1, w1.data(), w1.size() * 8, hipMemcpyHostToDevice, c->stream));
+    MVS_HIP_TRY(c, hipMemcpyAsync(dfw2, w2.data(), w2.size() * 8, hipMemcpyHostToDevice, c->stream));
+
+    MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+    size_t cursor = 0;
+    for (int i = 0; i < n_views; ++i) {
+        const void* dptr = views[i].data;
+        if (views[i].mem == MVS_MEM_HOST) {
+            const size_t nb = (size_t)views[i].shape[0] * views[i].shape[1] * views[i].shape[2] * es;
+            MVS_HIP_TRY(c, hipMemcpyAsync(slab_base + cursor, views[i].data, nb, hipMemcpyHostToDevice, c->stream));
+            dptr = slab_base + cursor;
+            cursor += (nb + 255) / 256 * 256;
+        }
+        DevView d;
+        int rc = mvs_fill_dev_view(c, views[i], opts->ndim, dptr, &d);
+        if (rc) return rc;
+        mvs_launch_resample(c, d, dtype, opts->order, NAN, I + (size_t)i * n, cs);
+        mvs_launch_blend(c, d, BW + (size_t)i * n, cs);
+    }
+    const int gb = grid_for(n);
+    hipLaunchKernelGGL(mask_normalize_kernel, dim3(gb), dim3(256), 0, c->stream, BW, I, n, n_views);
+
+    const int ndim = opts->ndim;
+    auto gauss = [&](const float* src, float* dst, int radius, const double* fw) {
+        // scipy filters axis 0, 1, 2 in turn; a 2D chunk has no z axis
+        const float* cur = src;
+        float* tmp[2] = {T1, T2};
+        int pass = 0;
+        for (int axis = 3 - ndim; axis < 3; ++axis, ++pass) {
+            float* d = (axis == 2) ? dst : tmp[pass & 1];
+            hipLaunchKernelGGL(gauss1d_kernel, dim3(gb), dim3(256), 0, c->stream, cur, d, S, axis, radius, fw);
+            cur = d;
+        }
+    };
+    for (int v = 0; v < n_views; ++v) {
+        const float* Iv = I + (size_t)v * n;
+        const float* Bv = BW + (size_t)v * n;
+        float* Fv = F + (size_t)v * n;
+        hipLaunchKernelGGL(prep_kernel, dim3(gb), dim3(256), 0, c->stream, Iv, Bv, n, A, V0, M);
+        gauss(V0, T0, r1, dfw1);           // VV  (T0)
+        gauss(M, Fv, r1, dfw1);            // WW  (Fv used as temporary)
+        hipLaunchKernelGGL(ng_finish_sq_kernel, dim3(gb), dim3(256), 0, c->stream, T0, Fv, A, n, V0);   // V0 <- (A - Z)^2, NaN -> 0
+        gauss(V0, T0, r2, dfw2);           // VV2 (T0)
+        gauss(M, V0, r2, dfw2);            // WW2 (V0)
+        hipLaunchKernelGGL(ng_finish_kernel, dim3(gb), dim3(256), 0, c->stream, T0, V0, A, n, Fv);
+    }
+    MVS_HIP_TRY(c, hipGetLastError());
+
+    const size_t out_bytes = (size_t)no * es;
+    void* dout = out;
+    if (opts->out_mem == MVS_MEM_HOST) {
+        dout = mvs_scratch(c, 1, out_bytes);
+        if (!dout) return MVS_ERR_HIP;
+    }
+    const int gbo = grid_for(no);
+    const int tz = (int)opts->trim[0], ty = (int)opts->trim[1], tx = (int)opts->trim[2];
+    switch (dtype) {
+        case MVS_U8: hipLaunchKernelGGL(cb_fuse_kernel<unsigned char>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, n, n_views, S, tz, ty, tx, O, (unsigned char*)dout); break;
+        case MVS_U16: hipLaunchKernelGGL(cb_fuse_kernel<unsigned short>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, n, n_views, S, tz, ty, tx, O, (unsigned short*)dout); break;
+        default: hipLaunchKernelGGL(cb_fuse_kernel<float>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, n, n_views, S, tz, ty, tx, O, (float*)dout); break;
+    }
+    MVS_HIP_TRY(c, hipGetLastError());
+    MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+    c->timing_valid = true;
+    if (opts->out_mem == MVS_MEM_HOST) MVS_HIP_TRY(c, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MVS_OK;
 }

@@ -164,3 +164,46 @@ def test_device_resident_slabs_and_output(hip_device):
     assert device.is_device_array(b)
     np.testing.assert_array_equal(a, b.get())
     assert host.shape == a.shape
+
+
+@pytest.mark.parametrize("ndim,dtype", [(3, np.uint16), (2, np.float32)])
+def test_fuse_content_based_weights(hip_device, ndim, dtype, kernel_path):
+    """weights_func=content_based (weights.py:22-74) with its halo (2*sigma_2) trimmed: chunk-level parity."""
+    from multiview_stitcher_amd import fusion, spatial_image_utils as si
+
+    if kernel_path == "generic":
+        pytest.skip("content-based weights have a single implementation")
+    if ndim == 3:
+        sims, params = _grid_case(3, dtype, (1, 2, 2), (20, 40, 44), (0, 12, 14), True, seed=4)
+        sig = {"sigma_1": 1.5, "sigma_2": 3.0}
+    else:
+        sims, params = _grid_case(2, dtype, (2, 2), (60, 70), (20, 22), True, seed=5)
+        sig = {"sigma_1": 2.0, "sigma_2": 4.0}
+    sdims = si.get_spatial_dims_from_sim(sims[0])
+    views, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(ndim))
+    halo = int(2 * sig["sigma_2"])
+    want, want_f, dbg = fo.fuse_np(list(views), params, out_bb, full_view_bbs=list(bbs), weights="content_based",
+                                   weights_kwargs=sig, trim_overlap_in_pixels=halo, return_debug=True)
+    got = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), weights_func=fusion.content_based,
+                         weights_func_kwargs=sig, full_view_bbs=[bb_to_dicts(b, sdims) for b in bbs],
+                         trim_overlap_in_pixels=halo)
+    assert got.shape == want.shape
+    if np.issubdtype(dtype, np.integer):
+        d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+        assert d.max() <= 1 and (d > 0).mean() < 0.02
+    else:
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
+
+
+def test_fuse_content_based_chunked_workflow(hip_device, kernel_path):
+    """fusion.fuse(weights_func=content_based): halo = 2*sigma_2 from required_overlap, chunks trimmed (T/test_fusion.py:845-896)."""
+    from multiview_stitcher_amd import fusion, sample_data
+
+    if kernel_path == "generic":
+        pytest.skip("content-based weights have a single implementation")
+    sims, _, _ = sample_data.generate_tiled_dataset(ndim=3, tile_shape=(12, 40, 40), tiles=(1, 2, 2), overlap=(0, 10, 10), max_jitter=0)
+    fused = fusion.fuse(sims, transform_key=sample_data.METADATA_TRANSFORM_KEY, weights_func=fusion.content_based,
+                        weights_func_kwargs={"sigma_1": 1, "sigma_2": 2}, output_chunksize={"z": 12, "y": 32, "x": 32})
+    d = np.asarray(fused.data)[0, 0]
+    assert d.shape == (12, 70, 70) and d[:, 2:-2, 2:-2].min() > 0
