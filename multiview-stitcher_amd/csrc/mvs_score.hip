@@ -19,6 +19,7 @@
 #include <vector>
 
 int mvs_stage_float_volume(MvsContext* c, const float* src, int32_t mem, long long n, int slot, float** dptr);   // mvs_reg.hip
+int mvs_device_nanminmax(MvsContext* c, const float* d_in, long long n, float* mn, float* mx, long long* nvalid);   // mvs_reg.hip
 
 namespace {
 
@@ -146,8 +147,10 @@ __global__ __launch_bounds__(256) void region_kernel(const float* __restrict__ i
     }
 }
 
-// scipy.ndimage.uniform_filter1d(size=win, mode="reflect") along one axis: double accumulation, float32 output
-__global__ __launch_bounds__(256) void box1d_kernel(const float* __restrict__ src, float* __restrict__ dst, Shape3 R, int axis, int win) {
+// scipy.ndimage.uniform_filter1d(size=win, mode="reflect") along one axis for the five SSIM inputs at once:
+// double accumulation, float32 output
+struct Five { const float* src[5]; float* dst[5]; };
+__global__ __launch_bounds__(256) void box1d_kernel(Five P, Shape3 R, int axis, int win) {
     const long long n = (long long)R.nz * R.ny * R.nx;
     const int dims[3] = {R.nz, R.ny, R.nx};
     const long long strides[3] = {(long long)R.ny * R.nx, R.nx, 1};
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256) void box1d_kernel(const float* __restrict__ sr
         const int y = (int)(t % R.ny), z = (int)(t / R.ny);
         const int pos = (axis == 0) ? z : (axis == 1) ? y : x;
         const long long base = i - (long long)pos * st;
-        double acc = 0.0;
+        double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
         for (int k = -h; k <= h; ++k) {
             int p = pos + k;
             // reflect: d c b a | a b c d | d c b a  (period 2*len)
@@ -171,9 +174,12 @@ __global__ __launch_bounds__(256) void box1d_kernel(const float* __restrict__ sr
                 if (p < 0) p += period;
                 if (p >= len) p = period - 1 - p;
             }
-            acc += (double)src[base + (long long)p * st];
+            const long long o = base + (long long)p * st;
+#pragma unroll
+            for (int a = 0; a < 5; ++a) acc[a] += (double)P.src[a][o];
         }
-        dst[i] = (float)(acc / (double)win);
+#pragma unroll
+        for (int a = 0; a < 5; ++a) P.dst[a][i] = (float)(acc[a] / (double)win);
     }
 }
 
@@ -206,17 +212,49 @@ __global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ ux,
     if (threadIdx.x == 0) partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-// compaction of the jointly valid voxels: kx = im0[mask], ky = im1t[mask] - 1 (float32, like the reference)
+// compaction of the jointly valid voxels: kx = im0[mask], ky = im1t[mask] - 1 (float32, like the reference).
+// Each thread takes 8 consecutive voxels; a workgroup reserves its output range with ONE atomic (the order of
+// the compacted pairs is irrelevant to a rank correlation).
 __global__ __launch_bounds__(256) void compact_kernel(const float* __restrict__ im0, const float* __restrict__ im1t, long long n,
                                                       float* __restrict__ kx, float* __restrict__ ky,
                                                       unsigned int* __restrict__ counter) {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float a = im0[i], b = im1t[i];
-        if (a == a && b == b) {
-            const unsigned int p = atomicAdd(counter, 1u);
-            kx[p] = a;
-            ky[p] = b - 1.0f;
+    constexpr int K = 8;
+    __shared__ unsigned int s_wave[4];
+    __shared__ unsigned int s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long tile = 256LL * K;
+    for (long long t0 = (long long)blockIdx.x * tile; t0 < n; t0 += (long long)gridDim.x * tile) {
+        const long long i0 = t0 + (long long)threadIdx.x * K;
+        float a[K], b[K];
+        unsigned int cnt = 0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const long long i = i0 + k;
+            a[k] = (i < n) ? im0[i] : NAN;
+            b[k] = (i < n) ? im1t[i] : NAN;
+            cnt += (a[k] == a[k] && b[k] == b[k]) ? 1u : 0u;
         }
+        // exclusive scan of cnt over the workgroup
+        unsigned int incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned int o = __shfl_up(incl, off);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        unsigned int wbase = 0;
+        for (int w = 0; w < wave; ++w) wbase += s_wave[w];
+        if (threadIdx.x == 255) s_base = atomicAdd(counter, wbase + incl);
+        __syncthreads();
+        unsigned int p = s_base + wbase + incl - cnt;
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            if (a[k] == a[k] && b[k] == b[k]) {
+                kx[p] = a[k];
+                ky[p] = b[k] - 1.0f;
+                ++p;
+            }
+        __syncthreads();
     }
 }
 
@@ -336,18 +374,17 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     // valid voxels of im1 and bbox of im0 (registration.py:400, 491)
     const int bb_init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1};
     MVS_HIP_TRY(c, hipMemcpyAsync(d_bbox0, bb_init, sizeof(bb_init), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(bbox_kernel, dim3(gb), dim3(256), 0, c->stream, im0, S, d_bbox0);
+    hipLaunchKernelGGL(bbox_kernel, dim3(std::min(gb, 512)), dim3(256), 0, c->stream, im0, S, d_bbox0);
     MVS_HIP_TRY(c, hipMemcpyAsync(d_bbox, bb_init, sizeof(bb_init), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(bbox_kernel, dim3(gb), dim3(256), 0, c->stream, im1, S, d_bbox);
-    // count valid voxels of im1 through the compaction counter trick: reuse shift stats with zero shift is wasteful,
-    // so count directly
-    MVS_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 4, c->stream));
-    hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, c->stream, im1, im1, n, T0, T1, d_counter);
-    int bb0[6];
-    unsigned int valid1 = 0;
+    hipLaunchKernelGGL(bbox_kernel, dim3(std::min(gb, 512)), dim3(256), 0, c->stream, im1, S, d_bbox);
+    int bb0[6], bbm[6];
     MVS_HIP_TRY(c, hipMemcpyAsync(bb0, d_bbox0, sizeof(bb0), hipMemcpyDeviceToHost, c->stream));
-    MVS_HIP_TRY(c, hipMemcpyAsync(&valid1, d_counter, 4, hipMemcpyDeviceToHost, c->stream));
-    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    MVS_HIP_TRY(c, hipMemcpyAsync(bbm, d_bbox, sizeof(bbm), hipMemcpyDeviceToHost, c->stream));
+    float mn1, mx1;
+    long long nv1 = 0;
+    rc = mvs_device_nanminmax(c, im1, n, &mn1, &mx1, &nv1);   // synchronises the stream
+    if (rc) return rc;
+    const unsigned int valid1 = (unsigned int)nv1;
 
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     for (int ic = 0; ic < n_candidates; ++ic) {
@@ -357,9 +394,26 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         spearman_out[ic] = -1.0;
         code_out[ic] = 0;
 
+        // Upper bound of the mask count from the valid bounding boxes: im1t can only be valid where x + t lies in
+        // im1's valid box.  If even the bound fails the 10 % test the candidate is rejected exactly as the
+        // reference rejects it (registration.py:503-505) without touching the volume.
+        {
+            double bound = 1.0;
+            const int dimv[3] = {S.nz, S.ny, S.nx};
+            for (int k = 0; k < 3; ++k) {
+                const double lo1 = std::ceil((double)bbm[k] - t[k] - 1.0), hi1 = std::floor((double)bbm[3 + k] - t[k] + 1.0);
+                const double lo = std::max(std::max(lo1, (double)bb0[k]), 0.0);
+                const double hi = std::min(std::min(hi1, (double)bb0[3 + k]), (double)(dimv[k] - 1));
+                bound *= std::max(hi - lo + 1.0, 0.0);
+            }
+            if (valid1 == 0 || bound == 0.0 || bound / (double)valid1 < 0.1) {
+                code_out[ic] = 1;
+                continue;
+            }
+        }
         MVS_HIP_TRY(c, hipMemsetAsync(d_count, 0, 8, c->stream));
         MVS_HIP_TRY(c, hipMemcpyAsync(d_bbox, bb_init, sizeof(bb_init), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(shift_kernel, dim3(gb), dim3(256), 0, c->stream, im1, im0, im1t, S, t[0], t[1], t[2], d_count, d_bbox);
+        hipLaunchKernelGGL(shift_kernel, dim3(std::min(gb, 1024)), dim3(256), 0, c->stream, im1, im0, im1t, S, t[0], t[1], t[2], d_count, d_bbox);
         unsigned long long cnt = 0;
         int bb1[6];
         MVS_HIP_TRY(c, hipMemcpyAsync(&cnt, d_count, 8, hipMemcpyDeviceToHost, c->stream));
@@ -406,19 +460,19 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         if (win < 3 || region_max <= (float)im1_min) {
             ssim_out[ic] = -1.0;
         } else {
-            float* srcs[5] = {X, Y, XX, YY, XY};
-            float* dsts[5] = {UX, UY, UXX, UYY, UXY};
+            // ping-pong between the input set {X,Y,XX,YY,XY} and the output set {UX,..}: 2 or 3 passes
+            float* setA[5] = {X, Y, XX, YY, XY};
+            float* setB[5] = {UX, UY, UXX, UYY, UXY};
             const int rgb = grid_for(rn);
-            for (int a = 0; a < 5; ++a) {
-                const float* cur = srcs[a];
-                int pass = 0;
-                const int npass = ndim;
-                for (int axis = k0; axis < 3; ++axis, ++pass) {
-                    float* dst = (pass == npass - 1) ? dsts[a] : ((pass & 1) ? T1 : T0);
-                    hipLaunchKernelGGL(box1d_kernel, dim3(rgb), dim3(256), 0, c->stream, cur, dst, R, axis, win);
-                    cur = dst;
-                }
+            float** cur = setA;
+            float** nxt = setB;
+            for (int axis = k0; axis < 3; ++axis) {
+                Five P5;
+                for (int a = 0; a < 5; ++a) { P5.src[a] = cur[a]; P5.dst[a] = nxt[a]; }
+                hipLaunchKernelGGL(box1d_kernel, dim3(rgb), dim3(256), 0, c->stream, P5, R, axis, win);
+                float** tmp = cur; cur = nxt; nxt = tmp;
             }
+            float** fin = cur;   // holds the filtered arrays
             double NP = 1.0;
             for (int k = 0; k < ndim; ++k) NP *= (double)win;
             const float cov_norm = (float)(NP / (NP - 1.0));
@@ -427,7 +481,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             const float C1 = (0.01f * Rf) * (0.01f * Rf);
             const float C2 = (0.03f * Rf) * (0.03f * Rf);
             const int pad = (win - 1) / 2;
-            hipLaunchKernelGGL(ssim_kernel, dim3(rgb), dim3(256), 0, c->stream, UX, UY, UXX, UYY, UXY, R, pad, ndim, cov_norm, C1, C2, partial);
+            hipLaunchKernelGGL(ssim_kernel, dim3(rgb), dim3(256), 0, c->stream, fin[0], fin[1], fin[2], fin[3], fin[4], R, pad, ndim, cov_norm, C1, C2, partial);
             std::vector<double> hp(rgb);
             MVS_HIP_TRY(c, hipMemcpyAsync(hp.data(), partial, sizeof(double) * rgb, hipMemcpyDeviceToHost, c->stream));
             MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
