@@ -450,6 +450,7 @@ struct TrParams {
     const TrView* views;
     const int* cull;       // SoA [6][nviews]: zlo, zhi, ylo, yhi, xlo, xhi
     const float* xtab;     // per-view blend weight along x for rows in the yz interior of the view
+    int* overflow;         // set to 1 if a column meets more than 64 views (the launch is then redone generically)
     int nviews;
     void* out;
     int oz, oy, ox;
@@ -610,9 +611,12 @@ __global__ __launch_bounds__(256) void fuse_tr_kernel(TrParams P) {
         if (act && pos < 64) s_list[wave][pos] = v;
         ntot += (int)__popcll(m);
     }
-    // more than 64 views on one column: beyond this kernel's list (the host falls back to the
-    // generic kernel when a chunk has that many mutually overlapping views; see mvs_fuse_chunk)
-    ntot = min(ntot, 64);
+    // more than 64 views on one column: beyond this kernel's list -- flag it, mvs_fuse_chunk redoes the chunk
+    // with the generic kernel (only possible when the chunk has more than 64 views at all)
+    if (ntot > 64) {
+        if (lane == 0) atomicExch(P.overflow, 1);
+        ntot = 64;
+    }
 
     for (int g = 0; g < kTrGroups; ++g) {
         const int y0 = ycol + g * kTrRows;
@@ -1231,6 +1235,7 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
     if (nblocks > 0x7fffffffLL) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "chunk too large for one launch");
 
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+    int* tr_overflow_ptr = nullptr;
     if (use_tr) {
         TrParams T;
         T.views = (const TrView*)((const char*)dviews + views_bytes + cull_bytes);
@@ -1242,9 +1247,12 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
         T.nbz = P.nbz; T.nby = P.nby; T.nbx = P.nbx;
         T.is3d = (os[0] > 1) ? 1 : 0;
         T.ablate = c->ablate;
-        float* xtab = (float*)mvs_scratch(c, 3, (xtab_total + 64) * sizeof(float));
+        float* xtab = (float*)mvs_scratch(c, 3, (xtab_total + 64) * sizeof(float) + 256);
         if (!xtab) return MVS_ERR_HIP;
         T.xtab = xtab;
+        T.overflow = (int*)(xtab + xtab_total + 64);
+        MVS_HIP_TRY(c, hipMemsetAsync(T.overflow, 0, sizeof(int), c->stream));
+        tr_overflow_ptr = T.overflow;
         if (opts->fusion == MVS_FUSE_WEIGHTED_AVERAGE) {
             hipLaunchKernelGGL(xweight_table_kernel, dim3(16, n_views), dim3(256), 0, c->stream, T.views, n_views, xtab);
         }
@@ -1261,6 +1269,27 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
         }
     }
     MVS_HIP_TRY(c, hipGetLastError());
+    if (use_tr && n_views > 64) {
+        int ovf = 0;
+        MVS_HIP_TRY(c, hipMemcpyAsync(&ovf, tr_overflow_ptr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (ovf) {
+            // a column met more than 64 views: redo the chunk with the generic kernel (bricks of 4x4x64)
+            P.bz = (os[0] > 1) ? 4 : 1;
+            P.by = (os[0] > 1) ? 4 : 16;
+            P.nbz = (P.oz + P.bz - 1) / P.bz;
+            P.nby = (P.oy + P.by - 1) / P.by;
+            P.nbx = (P.ox + kBrickX - 1) / kBrickX;
+            const long long nb2 = (long long)P.nbz * P.nby * P.nbx;
+            if (nb2 > 0x7fffffffLL) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "chunk too large for one launch");
+            switch (dtype) {
+                case MVS_U8: launch_fuse<unsigned char, unsigned char>(P, opts->order, opts->fusion, (int)nb2, c->stream); break;
+                case MVS_U16: launch_fuse<unsigned short, unsigned short>(P, opts->order, opts->fusion, (int)nb2, c->stream); break;
+                default: launch_fuse<float, float>(P, opts->order, opts->fusion, (int)nb2, c->stream); break;
+            }
+            MVS_HIP_TRY(c, hipGetLastError());
+        }
+    }
     MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
     c->timing_valid = true;
 

@@ -207,3 +207,22 @@ def test_fuse_content_based_chunked_workflow(hip_device, kernel_path):
                         weights_func_kwargs={"sigma_1": 1, "sigma_2": 2}, output_chunksize={"z": 12, "y": 32, "x": 32})
     d = np.asarray(fused.data)[0, 0]
     assert d.shape == (12, 70, 70) and d[:, 2:-2, 2:-2].min() > 0
+
+
+def test_more_than_64_views_on_one_column_falls_back(hip_device, kernel_path):
+    """The fast kernel lists at most 64 views per column; a chunk where more overlap is redone generically."""
+    from multiview_stitcher_amd import fusion, spatial_image_utils as si
+
+    rng = np.random.default_rng(0)
+    sims, params = [], []
+    for i in range(70):
+        arr = rng.integers(100, 4000, (24, 40)).astype(np.uint16)
+        s = si.get_sim_from_array(arr, dims=["y", "x"], scale={"y": 1.0, "x": 1.0}, translation={"y": 0.0, "x": 0.0})
+        sims.append(squeeze_field(s))
+        p = np.eye(3)
+        p[:2, 2] = rng.integers(-3, 4, 2)
+        params.append(p)
+    _, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(2))
+    got, want, want_f = _run_both(sims, params, out_bb)
+    assert_fused_close(got, want, want_f[0], noise_floor=want_f[1])
