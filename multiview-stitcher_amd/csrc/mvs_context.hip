@@ -51,24 +51,28 @@ void* mvs_scratch(MvsContext* c, int slot, size_t nbytes) {
     return s.ptr;
 }
 
-void* mvs_pinned(MvsContext* c, size_t nbytes) {
-    if (nbytes <= c->pinned_cap && c->pinned) return c->pinned;
-    if (c->pinned) {
+void* mvs_pinned_slot(MvsContext* c, int slot, size_t nbytes) {
+    void*& p = slot ? c->pinned2 : c->pinned;
+    size_t& pc = slot ? c->pinned2_cap : c->pinned_cap;
+    if (nbytes <= pc && p) return p;
+    if (p) {
         hipStreamSynchronize(c->stream);
-        hipHostFree(c->pinned);
-        c->pinned = nullptr;
-        c->pinned_cap = 0;
+        hipHostFree(p);
+        p = nullptr;
+        pc = 0;
     }
     size_t cap = nbytes * 2 + 4096;
-    hipError_t e = hipHostMalloc(&c->pinned, cap, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(&p, cap, hipHostMallocDefault);
     if (e != hipSuccess) {
         mvs_fail(c, MVS_ERR_HIP, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
-        c->pinned = nullptr;
+        p = nullptr;
         return nullptr;
     }
-    c->pinned_cap = cap;
-    return c->pinned;
+    pc = cap;
+    return p;
 }
+
+void* mvs_pinned(MvsContext* c, size_t nbytes) { return mvs_pinned_slot(c, 0, nbytes); }
 
 extern "C" {
 
@@ -113,8 +117,9 @@ void mvs_shutdown(int device) {
         s.cap = 0;
     }
     if (c->pinned) hipHostFree(c->pinned);
-    c->pinned = nullptr;
-    c->pinned_cap = 0;
+    if (c->pinned2) hipHostFree(c->pinned2);
+    c->pinned = c->pinned2 = nullptr;
+    c->pinned_cap = c->pinned2_cap = 0;
     hipEventDestroy(c->ev_start);
     hipEventDestroy(c->ev_stop);
     hipStreamDestroy(c->own_stream);
@@ -145,6 +150,10 @@ int mvs_set_option(int device, const char* key, int64_t value) {
     std::lock_guard<std::mutex> lock(c->mu);
     if (!strcmp(key, "force_generic")) {
         c->force_generic = value != 0;
+        return MVS_OK;
+    }
+    if (!strcmp(key, "no_regions")) {
+        c->no_regions = value != 0;
         return MVS_OK;
     }
     if (!strcmp(key, "ablate")) {

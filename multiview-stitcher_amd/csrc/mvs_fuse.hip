@@ -23,6 +23,7 @@
 // NI_GeometricTransform does; interpolation and accumulation are float32.
 #include "mvs_internal.h"
 #include "mvs_fuse_dev.h"
+#include "mvs_fuse_tr.h"
 
 #include <cmath>
 #include <cstring>
@@ -33,7 +34,6 @@ namespace {
 constexpr int kBrickX = 64;      // voxels along x per brick (16 lanes x 4 voxels)
 constexpr int kVPT = 4;          // voxels per thread along x
 constexpr int kLdsTables = 8;    // blend tables staged in LDS per pass
-constexpr float kPiHalf = 1.57079632679489661923f;
 
 struct FuseParams {
     const DevView* views;
@@ -386,65 +386,11 @@ __device__ __forceinline__ void row_taps(const MVS_GLOBAL TIn* p, bool fracx, fl
     }
 }
 
-// ---- blend weight in "distance" form -----------------------------------------------------------
-// Along one axis the support grid has nodes 0..4 at chunk indices sup_lo .. sup_hi.  With
-// dl = x - sup_lo and dh = sup_hi - x (output pixels; computed as (float)(x - ilo) - flo so that the
-// subtraction of the large parts is exact), the folded grid coordinate is u = min(dl, dh) * k in
-// [0,2] (k = nodes per pixel; u < 0: outside the support, weight 0).  The table is symmetric, so
-// nodes 3,4 fold onto 1,0.
-__device__ __forceinline__ float fold_u(int x, int ilo, float flo, int ihi, float fhi, float k) {
-    const float dl = (float)(x - ilo) - flo;
-    const float dh = (float)(ihi - x) - fhi;
-    return fminf(dl, dh) * k;
-}
-// Tent nodes bracketing folded coordinate u: a0 = s*i, a1 = s*(i+1), weight f = u - i, i in {0,1}.
-__device__ __forceinline__ void tent_cell(float u, float s, float& a0, float& a1, float& f) {
-    const float i = (u >= 1.f) ? 1.f : 0.f;
-    a0 = s * i;
-    a1 = s * (i + 1.f);
-    f = u - i;
-}
-// W along x from the row nodes: lerp over {0, G1, G2} at folded coordinate u.
-__device__ __forceinline__ float row_profile(float u, float G1, float dG) {
-    return (u <= 1.f) ? u * G1 : fmaf(u - 1.f, dG, G1);
-}
-// branch-free cosine ramp (same arithmetic as blend_ramp)
-__device__ __forceinline__ float blend_ramp_nb(float x) {
-    const float xc = fminf(fmaxf(x, 0.f), 1.f);
-    const float a = xc * kPiHalf;
-    const float a2 = a * a;
-    float s = fmaf(a2, 1.6059043836821613e-10f, -2.5052108385441720e-08f);
-    s = fmaf(s, a2, 2.7557319223985893e-06f);
-    s = fmaf(s, a2, -1.9841269841269841e-04f);
-    s = fmaf(s, a2, 8.3333333333333333e-03f);
-    s = fmaf(s, a2, -1.6666666666666666e-01f);
-    s = fmaf(s * a2, a, a);
-    const float c = fmaf(2.f, s * s, -1.f);
-    const float w = (c + 1.f) * 0.5f;
-    return (x >= 1.f) ? 1.f : w;
-}
-
 constexpr int kRowValid = 1, kRowInside = 2, kRowAllOne = 4, kRowXTab = 8;
 constexpr int kXTabMargin = 4;   // table entries kept on either side of [lo_x, hi_x] (a lane reads 4 consecutive ones)
 constexpr int kCand = 16;   // candidate views evaluated per round (16 views x 4 rows = 64 lanes)
 
-// Compact per-view record of the fast path (160 bytes = 10 x 16-byte loads per lane).
-struct alignas(16) TrView {
-    int lo[3], hi[3];            // valid chunk-index box (inclusive), exact per scipy's in-bounds test
-    int io[3];                   // input index = chunk index + io
-    int wnz;                     // 5 (3D support) or 1 (2D)
-    float fw[3];                 // fractional interpolation weights (0: single tap)
-    int xtab_off;                // index of this view's x-weight table entry for chunk x = lo[2] (see xweight_table_kernel)
-    unsigned long long data;     // device pointer of the slab
-    long long span;              // elements from data[0] to the last voxel, + 1
-    int stride_y, stride_z;      // elements
-    int sup_ilo[3], sup_ihi[3];  // support nodes 0 / 4 in chunk-index units: ilo + flo, ihi - fhi
-    float sup_flo[3], sup_fhi[3];
-    float sup_k[3];              // support nodes per output pixel
-    float ws[3];                 // tent scales of the closed-form support table
-    int pad1[2];
-};
-static_assert(sizeof(TrView) == 160, "TrView layout");
+
 
 struct TrParams {
     const TrView* views;
@@ -1111,6 +1057,9 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
 
+int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_views, int dtype, void* dout, const int64_t os[3],
+                     const int64_t trim[3], bool* done);   // mvs_fuse_region.hip
+
 int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_views,
                            const mvs_fuse_opts_t* opts, void* out);   // mvs_gauss.hip
 
@@ -1236,7 +1185,15 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
 
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     int* tr_overflow_ptr = nullptr;
-    if (use_tr) {
+    bool regions_done = false;
+    if (use_tr && opts->fusion == MVS_FUSE_WEIGHTED_AVERAGE && !c->no_regions) {
+        rc = mvs_fuse_regions(c, htr, (const TrView*)((const char*)dviews + views_bytes + cull_bytes), n_views, dtype, dout, os,
+                              opts->trim, &regions_done);
+        if (rc) return rc;
+    }
+    if (regions_done) {
+        // fused by the region kernel
+    } else if (use_tr) {
         TrParams T;
         T.views = (const TrView*)((const char*)dviews + views_bytes + cull_bytes);
         T.cull = P.cull;
@@ -1269,7 +1226,7 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
         }
     }
     MVS_HIP_TRY(c, hipGetLastError());
-    if (use_tr && n_views > 64) {
+    if (use_tr && !regions_done && n_views > 64) {
         int ovf = 0;
         MVS_HIP_TRY(c, hipMemcpyAsync(&ovf, tr_overflow_ptr, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -1,0 +1,565 @@
+// mvs_fuse_region.hip -- region-decomposed translation fast path of mvs_fuse_chunk (gfx950).
+//
+// For translation-only views (tile grids) the output chunk decomposes along every axis at the view
+// borders into boxes ("regions") inside which the set of contributing views is CONSTANT and every
+// voxel of the box is in bounds for each of them.  The host enumerates the regions (O(#views^3) tiny
+// work), classifies per (region, view) whether the blend weight is 1 everywhere in the box (the weight
+// profile is concave, so its minimum sits at a corner) and cuts every region into bricks of
+// 4 planes x 32 rows x 128 voxels.  A wavefront takes one brick: lane (r, c) = (lane >> 4, lane & 15)
+// owns row r of each 4-row group and 8 consecutive voxels at x = x0 + 8 c (one 16-byte store for u16).
+// Compared with the column kernel (mvs_fuse.hip) this removes per-wave view culling, per-voxel validity
+// masks and most weight evaluations:
+//   * one view, weight 1            -> resample and store (no accumulators, no division)
+//   * n views, all weights 1        -> plain average
+//   * otherwise                     -> weighted accumulate; ramp weights only for the views that need them,
+//                                      row-uniform nodes (G1, dG) evaluated once per plane by 32 lanes
+// The unrolled NV = 1, 2, 4 instantiations keep all per-view constants in scalar registers.
+#include "mvs_fuse_tr.h"
+
+#include <algorithm>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+namespace {
+
+constexpr int kRB = 4;       // planes per brick
+constexpr int kRG = 8;       // 4-row groups per brick
+constexpr int kRV = 8;       // voxels per lane
+constexpr int kRX = 128;     // voxels along x per brick (16 lanes x 8)
+constexpr int kMaxRV = 8;    // views per region handled here
+
+struct Region {
+    int z0, z1, y0, y1, x0, x1;   // chunk-index box, end exclusive
+    int nviews;
+    int allone_mask;              // bits 0-15: view ids[v] has blend weight 1 everywhere in the box;
+                                  // bits 16-31: view ids[v] covers the box only partially (per-voxel bounds test)
+    int ids[kMaxRV];
+};
+static_assert(sizeof(Region) == 64, "Region layout");
+
+struct Item { int region_bx, by_bz; };   // region | bx << 16 ; by | bz << 16
+
+struct RegionParams {
+    const TrView* views;
+    const Region* regions;
+    const Item* items;
+    int nitems;
+    void* out;
+    int oz, oy, ox;
+    int tz, ty, tx;
+};
+
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+// 8 consecutive elements (+ the 9th when NINE) of one row through a bounds-checked buffer load
+template <typename T, bool NINE> struct Row8;
+template <bool NINE> struct Row8<unsigned short, NINE> {
+    static constexpr int NW = 5;
+    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int vo, unsigned int (&w)[9]) {
+        const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(r, vo, 0, 0);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+        if (NINE) w[4] = __builtin_amdgcn_raw_buffer_load_b16(r, vo + 16, 0, 0);
+    }
+    static __device__ __forceinline__ void decode(const unsigned int (&w)[9], float (&v)[9]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[2 * k] = (float)(w[k] & 0xffffu); v[2 * k + 1] = (float)(w[k] >> 16); }
+        v[8] = NINE ? (float)(w[4] & 0xffffu) : 0.f;
+    }
+};
+template <bool NINE> struct Row8<unsigned char, NINE> {
+    static constexpr int NW = 3;
+    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int vo, unsigned int (&w)[9]) {
+        const u32x2_t a = __builtin_amdgcn_raw_buffer_load_b64(r, vo, 0, 0);
+        w[0] = a.x; w[1] = a.y;
+        if (NINE) w[2] = __builtin_amdgcn_raw_buffer_load_b8(r, vo + 8, 0, 0);
+    }
+    static __device__ __forceinline__ void decode(const unsigned int (&w)[9], float (&v)[9]) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (float)((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        v[8] = NINE ? (float)(w[2] & 0xffu) : 0.f;
+    }
+};
+template <bool NINE> struct Row8<float, NINE> {
+    static constexpr int NW = 9;
+    static __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t r, int vo, unsigned int (&w)[9]) {
+        const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(r, vo, 0, 0);
+        const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(r, vo + 16, 0, 0);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        if (NINE) w[8] = __builtin_amdgcn_raw_buffer_load_b32(r, vo + 32, 0, 0);
+    }
+    static __device__ __forceinline__ void decode(const unsigned int (&w)[9], float (&v)[9]) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __uint_as_float(w[k]);
+        v[8] = NINE ? __uint_as_float(w[8]) : 0.f;
+    }
+};
+
+// element-wise re-fetch of a window that touches the first / last bytes of the slab (see row_refetch in mvs_fuse.hip)
+template <typename TIn>
+__device__ __forceinline__ void row8_refetch(__amdgpu_buffer_rsrc_t r, int o, float (&v)[9]) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) {
+        const int oj = o + j * (int)sizeof(TIn);
+        if (sizeof(TIn) == 2) v[j] = (float)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, oj, 0, 0);
+        else if (sizeof(TIn) == 1) v[j] = (float)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(r, oj, 0, 0);
+        else {
+            v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, oj, 0, 0));
+            asm volatile("" ::: "memory");
+        }
+    }
+}
+
+__device__ __forceinline__ int rli(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+
+template <typename TOut> __device__ __forceinline__ TOut cast_r(float v);
+template <> __device__ __forceinline__ float cast_r<float>(float v) { return v; }
+template <> __device__ __forceinline__ unsigned short cast_r<unsigned short>(float v) { return (unsigned short)(int)v; }
+template <> __device__ __forceinline__ unsigned char cast_r<unsigned char>(float v) { return (unsigned char)(int)v; }
+
+template <typename T> struct Out8;
+template <> struct Out8<unsigned short> { typedef unsigned short v8 __attribute__((ext_vector_type(8), aligned(2))); };
+template <> struct Out8<unsigned char> { typedef unsigned char v8 __attribute__((ext_vector_type(8), aligned(1))); };
+template <> struct Out8<float> { typedef float v8 __attribute__((ext_vector_type(8), aligned(4))); };
+
+template <typename TOut>
+__device__ __forceinline__ void store8(TOut* p, const float (&q)[kRV], int nvalid) {
+    if (nvalid >= kRV) {
+        typename Out8<TOut>::v8 v;
+#pragma unroll
+        for (int j = 0; j < kRV; ++j) v[j] = cast_r<TOut>(q[j]);
+        *reinterpret_cast<typename Out8<TOut>::v8*>(p) = v;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kRV; ++j)
+            if (j < nvalid) p[j] = cast_r<TOut>(q[j]);
+    }
+}
+
+// The per-view record fields live in lanes: lane (v * 10 + q) of set A (views 0..5) / set B (views 6, 7) holds
+// float4 q of view v's TrView; field f (dword index) = component f & 3 of float4 f >> 2.
+struct RecRegs { float4 a, b; };
+template <int F>
+__device__ __forceinline__ int rec_field(const RecRegs& R, int v) {
+    const int q = F >> 2;
+    float4 src = R.a;
+    int lane = v * 10 + q;
+    if (v >= 6) { src = R.b; lane = (v - 6) * 10 + q; }
+    const float c = ((F & 3) == 0) ? src.x : ((F & 3) == 1) ? src.y : ((F & 3) == 2) ? src.z : src.w;
+    return __builtin_amdgcn_readlane(__float_as_int(c), lane);
+}
+template <int F> __device__ __forceinline__ float rec_fieldf(const RecRegs& R, int v) { return __int_as_float(rec_field<F>(R, v)); }
+// TrView dword indices
+enum { F_LO_Z = 0, F_LO_Y, F_LO_X, F_HI_Z, F_HI_Y, F_HI_X, F_IO_Z, F_IO_Y, F_IO_X, F_WNZ, F_FW_Z, F_FW_Y, F_FW_X, F_XTAB,
+       F_DATA_LO, F_DATA_HI, F_SPAN_LO, F_SPAN_HI, F_ST_Y, F_ST_Z, F_SILO_Z, F_SILO_Y, F_SILO_X, F_SIHI_Z, F_SIHI_Y, F_SIHI_X,
+       F_SFLO_Z, F_SFLO_Y, F_SFLO_X, F_SFHI_Z, F_SFHI_Y, F_SFHI_X, F_SK_Z, F_SK_Y, F_SK_X, F_WS_Z, F_WS_Y, F_WS_X };
+
+// Row-uniform nodes of view v at plane zc for brick row `row` (evaluated by lane `row`): G1, dG and whether the
+// row lies inside the support along z and y.
+__device__ __forceinline__ void row_nodes(const RecRegs& R, int v, int zc, int yc, float& G1, float& dG, bool& inside) {
+    const float wsz = rec_fieldf<F_WS_Z>(R, v), wsy = rec_fieldf<F_WS_Y>(R, v), wsx = rec_fieldf<F_WS_X>(R, v);
+    float az0 = INFINITY, az1 = INFINITY, fz = 0.f, uz = 0.f;
+    const bool has_z = rec_field<F_WNZ>(R, v) > 1;
+    if (has_z) {
+        uz = fold_u(zc, rec_field<F_SILO_Z>(R, v), rec_fieldf<F_SFLO_Z>(R, v), rec_field<F_SIHI_Z>(R, v), rec_fieldf<F_SFHI_Z>(R, v),
+                    rec_fieldf<F_SK_Z>(R, v));
+        tent_cell(fmaxf(uz, 0.f), wsz, az0, az1, fz);
+    }
+    const float uy = fold_u(yc, rec_field<F_SILO_Y>(R, v), rec_fieldf<F_SFLO_Y>(R, v), rec_field<F_SIHI_Y>(R, v),
+                            rec_fieldf<F_SFHI_Y>(R, v), rec_fieldf<F_SK_Y>(R, v));
+    inside = (uz >= 0.f) && (uy >= 0.f);
+    float ay0, ay1, fy;
+    tent_cell(fmaxf(uy, 0.f), wsy, ay0, ay1, fy);
+    const float uz_ = 1.f - fz, uy_ = 1.f - fy;
+    const float m00 = fminf(az0, ay0), m01 = fminf(az0, ay1), m10 = fminf(az1, ay0), m11 = fminf(az1, ay1);
+    const float a1 = wsx, a2 = 2.f * wsx;
+    float g0 = fmaf(fminf(m01, a1), fy, fminf(m00, a1) * uy_);
+    float g1 = fmaf(fminf(m11, a1), fy, fminf(m10, a1) * uy_);
+    G1 = has_z ? fmaf(g1, fz, g0 * uz_) : g0;
+    g0 = fmaf(fminf(m01, a2), fy, fminf(m00, a2) * uy_);
+    g1 = fmaf(fminf(m11, a2), fy, fminf(m10, a2) * uy_);
+    const float G2 = has_z ? fmaf(g1, fz, g0 * uz_) : g0;
+    dG = G2 - G1;
+}
+
+// One brick of a region with at most NV views: the view loop is unrolled, so per-view constants end up in scalar
+// registers and the row nodes of ramp-weighted views in per-view vector registers.
+template <typename TIn, typename TOut, int NV>
+__device__ __forceinline__ void region_brick(const RegionParams& P, const RecRegs& R, int nviews, int masks, int z0b, int z1,
+                                             int y0b, int y1, int x0b, int x1, int lane) {
+    constexpr bool ISF = std::is_floating_point<TIn>::value;
+    constexpr int ES = (int)sizeof(TIn);
+    const int nv = nviews;   // <= NV
+    const int r = lane >> 4, c = lane & 15;
+    const int xq = x0b + kRV * c;
+    const int nvalid_x = min(max(x1 - xq, 0), kRV);
+    const int xl = (nvalid_x > 0) ? xq : x0b;      // lanes beyond the region read a valid window, nothing is stored
+    const int allone_mask = masks & 0xffff, partial_mask = (masks >> 16) & 0xffff;
+    const bool all_unit = (allone_mask & ((1 << nv) - 1)) == ((1 << nv) - 1);
+    TOut* out = (TOut*)P.out;
+
+    for (int p = 0; p < kRB; ++p) {
+        const int zc = z0b + p;
+        if (zc >= z1) break;
+        // ---- row nodes of the views with ramp weights, for the 32 rows of this brick plane (lane = row) ----
+        float nG1[NV], ndG[NV];
+        int nin[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) { nG1[v] = 0.f; ndG[v] = 0.f; nin[v] = 0; }
+        if (!all_unit) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (v < nv && !((allone_mask >> v) & 1)) {
+                    bool inside;
+                    row_nodes(R, v, zc, min(y0b + (lane & 31), y1 - 1), nG1[v], ndG[v], inside);
+                    nin[v] = inside ? 1 : 0;
+                }
+            }
+        }
+        for (int g = 0; g < kRG; ++g) {
+            const int yg = y0b + 4 * g;
+            if (yg >= y1) break;
+            const int yc = yg + r;
+            const bool row_ok = yc < y1;
+            const int yl = row_ok ? yc : y1 - 1;
+
+            float num[kRV], den[kRV], last[kRV], wlast[kRV];
+#pragma unroll
+            for (int j = 0; j < kRV; ++j) { num[j] = 0.f; den[j] = 0.f; last[j] = 0.f; wlast[j] = 0.f; }
+
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                if (v >= nv) break;
+                const float wz = rec_fieldf<F_FW_Z>(R, v), wy = rec_fieldf<F_FW_Y>(R, v), wx = rec_fieldf<F_FW_X>(R, v);
+                const bool anyfrac = (wz > 0.f) || (wy > 0.f) || (wx > 0.f);
+                const int sy = rec_field<F_ST_Y>(R, v), sz = rec_field<F_ST_Z>(R, v);
+                const unsigned long long dptr = ((unsigned long long)(unsigned)rec_field<F_DATA_HI>(R, v) << 32) | (unsigned)rec_field<F_DATA_LO>(R, v);
+                const int nbytes = rec_field<F_SPAN_LO>(R, v) * ES;
+                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dptr, 0, nbytes, 0x00020000);
+                const int vo = (((zc + rec_field<F_IO_Z>(R, v)) * sz + (yl + rec_field<F_IO_Y>(R, v)) * sy) + (xl + rec_field<F_IO_X>(R, v))) * ES;
+                constexpr int WB = 9 * ES;
+
+                float val[kRV];
+                if (anyfrac) {
+                    unsigned int w00[9], w01[9], w10[9], w11[9];
+                    Row8<TIn, true>::load(rsrc, vo, w00);
+                    Row8<TIn, true>::load(rsrc, vo + sy * ES, w01);
+                    Row8<TIn, true>::load(rsrc, vo + sz * ES, w10);
+                    Row8<TIn, true>::load(rsrc, vo + (sz + sy) * ES, w11);
+                    float e00[9], e01[9], e10[9], e11[9];
+                    Row8<TIn, true>::decode(w00, e00);
+                    Row8<TIn, true>::decode(w01, e01);
+                    Row8<TIn, true>::decode(w10, e10);
+                    Row8<TIn, true>::decode(w11, e11);
+                    const int olast = vo + (sz + sy) * ES;
+                    if (__any(vo < 0 || olast + WB > nbytes)) {   // windows touching the first / last bytes of the slab
+                        const int o1 = vo + sy * ES, o2 = vo + sz * ES;
+                        if (__any((vo < 0 && vo + WB > 0) || (vo < nbytes && vo + WB > nbytes))) row8_refetch<TIn>(rsrc, vo, e00);
+                        if (__any((o1 < 0 && o1 + WB > 0) || (o1 < nbytes && o1 + WB > nbytes))) row8_refetch<TIn>(rsrc, o1, e01);
+                        if (__any((o2 < 0 && o2 + WB > 0) || (o2 < nbytes && o2 + WB > nbytes))) row8_refetch<TIn>(rsrc, o2, e10);
+                        if (__any((olast < 0 && olast + WB > 0) || (olast < nbytes && olast + WB > nbytes))) row8_refetch<TIn>(rsrc, olast, e11);
+                    }
+                    const float ux = 1.f - wx, uy = 1.f - wy, uz = 1.f - wz;
+#pragma unroll
+                    for (int j = 0; j < kRV; ++j) {
+                        const float a00 = fmaf(e00[j + 1], wx, e00[j] * ux), a01 = fmaf(e01[j + 1], wx, e01[j] * ux);
+                        const float a10 = fmaf(e10[j + 1], wx, e10[j] * ux), a11 = fmaf(e11[j + 1], wx, e11[j] * ux);
+                        const float s0 = fmaf(a10, wz, a00 * uz), s1 = fmaf(a11, wz, a01 * uz);
+                        val[j] = fmaf(s1, wy, s0 * uy);
+                    }
+                } else {
+                    unsigned int w00[9];
+                    Row8<TIn, false>::load(rsrc, vo, w00);
+                    float e00[9];
+                    Row8<TIn, false>::decode(w00, e00);
+                    if (__any((vo < 0 && vo + WB > 0) || (vo < nbytes && vo + WB > nbytes))) row8_refetch<TIn>(rsrc, vo, e00);
+#pragma unroll
+                    for (int j = 0; j < kRV; ++j) val[j] = e00[j];
+                }
+
+                // views that cover the box only partly: per-voxel in-bounds test against the view's valid box
+                const bool partial = (partial_mask >> v) & 1;
+                bool inb[kRV];
+#pragma unroll
+                for (int j = 0; j < kRV; ++j) inb[j] = true;
+                if (partial) {
+                    const bool zy_ok = (zc >= rec_field<F_LO_Z>(R, v)) && (zc <= rec_field<F_HI_Z>(R, v)) &&
+                                       (yc >= rec_field<F_LO_Y>(R, v)) && (yc <= rec_field<F_HI_Y>(R, v));
+                    const int jlo = rec_field<F_LO_X>(R, v) - xq, jw = rec_field<F_HI_X>(R, v) - rec_field<F_LO_X>(R, v);
+#pragma unroll
+                    for (int j = 0; j < kRV; ++j) inb[j] = zy_ok && ((unsigned)(j - jlo) <= (unsigned)jw);
+                }
+                const bool unit = (allone_mask >> v) & 1;
+                if (unit) {
+#pragma unroll
+                    for (int j = 0; j < kRV; ++j) {
+                        const bool ok = (ISF ? (val[j] == val[j]) : true) && inb[j];
+                        num[j] += ok ? val[j] : 0.f;
+                        den[j] += ok ? 1.f : 0.f;
+                    }
+                } else {
+                    float w[kRV];
+                    {
+                        // nodes of my row come from lane (4 g + r) of the per-view node registers
+                        const int src = 4 * g + r;
+                        const float G1 = __shfl(nG1[v], src), dG = __shfl(ndG[v], src);
+                        const bool inside = __shfl(nin[v], src) != 0;
+                        const float kx = rec_fieldf<F_SK_X>(R, v);
+                        const float dl0 = (float)(xl - rec_field<F_SILO_X>(R, v)) - rec_fieldf<F_SFLO_X>(R, v);
+                        const float dh0 = (float)(rec_field<F_SIHI_X>(R, v) - xl) - rec_fieldf<F_SFHI_X>(R, v);
+                        float Wm = 2.f;
+#pragma unroll
+                        for (int j = 0; j < kRV; ++j) {
+                            const float u = fminf(dl0 + (float)j, dh0 - (float)j) * kx;
+                            const float W = (u >= 0.f && inside) ? row_profile(u, G1, dG) : 0.f;
+                            w[j] = W;
+                            Wm = fminf(Wm, W);
+                        }
+                        if (__any(Wm < 1.f)) {
+#pragma unroll
+                            for (int j = 0; j < kRV; ++j) w[j] = blend_ramp_nb(w[j]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < kRV; ++j) w[j] = 1.f;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < kRV; ++j) {
+                        const bool ok = (ISF ? (val[j] == val[j]) : true) && inb[j];
+                        const float we = ok ? w[j] : 0.f;
+                        const bool pos = we > 0.f;
+                        const float ve = pos ? val[j] : 0.f;
+                        num[j] = fmaf(we, ve, num[j]);
+                        den[j] += we;
+                        const bool ramp = pos && (we < 1.f);
+                        const int pm = ramp ? -1 : 0;   // bit-select (see mvs_fuse.hip)
+                        last[j] = __int_as_float((__float_as_int(val[j]) & pm) | (__float_as_int(last[j]) & ~pm));
+                        wlast[j] = __int_as_float((__float_as_int(we) & pm) | (__float_as_int(wlast[j]) & ~pm));
+                    }
+                }
+            }
+
+            // ---- epilogue of this row group ----
+            float q[kRV];
+#pragma unroll
+            for (int j = 0; j < kRV; ++j) {
+                float o;
+                if (nv == 1 && all_unit && !partial_mask && !ISF) o = num[j];      // a single full view with weight 1
+                else {
+                    o = num[j] * __builtin_amdgcn_rcpf(den[j]);
+                    o = (den[j] == wlast[j]) ? last[j] : o;                        // single ramp contributor: exact value
+                }
+                if (!(fabsf(o) <= 3.4028234e38f)) o = 0.f;
+                q[j] = o;
+            }
+            if (row_ok && nvalid_x > 0) {
+                const long long oi = ((long long)(zc - P.tz) * P.oy + (yc - P.ty)) * (long long)P.ox + (xq - P.tx);
+                store8<TOut>(out + oi, q, nvalid_x);
+            }
+        }
+    }
+}
+
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void fuse_region_kernel(RegionParams P) {
+    const int lane = threadIdx.x & 63;
+    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= P.nitems) return;
+    const Item it = P.items[item];
+    const int rid = it.region_bx & 0xffff, bx = (unsigned)it.region_bx >> 16, by = it.by_bz & 0xffff, bz = (unsigned)it.by_bz >> 16;
+    // region descriptor: lane l < 16 loads dword l, fields are pulled out with readlane
+    const int rw = reinterpret_cast<const int*>(P.regions + rid)[lane & 15];
+    const int z0 = rli(rw, 0), z1 = rli(rw, 1), y0 = rli(rw, 2), y1 = rli(rw, 3), x0 = rli(rw, 4), x1 = rli(rw, 5);
+    const int nviews = rli(rw, 6), masks = rli(rw, 7);
+    const int z0b = z0 + kRB * bz, y0b = y0 + 4 * kRG * by, x0b = x0 + kRX * bx;
+
+    if (nviews == 0) {   // nothing contributes: zeros (np.nansum of nothing, nan_to_num)
+        const int r = lane >> 4, c = lane & 15, xq = x0b + kRV * c;
+        const int nvx = min(max(x1 - xq, 0), kRV);
+        float q[kRV] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < kRB && z0b + p < z1; ++p)
+            for (int g = 0; g < kRG; ++g) {
+                const int yc = y0b + 4 * g + r;
+                if (yc < y1 && nvx > 0)
+                    store8<TOut>((TOut*)P.out + ((long long)(z0b + p - P.tz) * P.oy + (yc - P.ty)) * (long long)P.ox + (xq - P.tx), q, nvx);
+            }
+        return;
+    }
+    // gather the records of the region's views into lanes: set A lanes (v*10 + q), v < 6; set B views 6, 7
+    RecRegs R;
+    {
+        const int va = lane / 10, qa = lane - va * 10;
+        const int ida = __shfl(rw, 8 + min(va, 7));
+        const int idb = __shfl(rw, 8 + min(6 + va, 7));
+        R.a = make_float4(0.f, 0.f, 0.f, 0.f);
+        R.b = R.a;
+        if (va < min(nviews, 6)) R.a = reinterpret_cast<const float4*>(P.views + ida)[qa];
+        if (nviews > 6 && va < nviews - 6) R.b = reinterpret_cast<const float4*>(P.views + idb)[qa];
+    }
+    switch (nviews) {
+        case 1: region_brick<TIn, TOut, 1>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane); break;
+        case 2: region_brick<TIn, TOut, 2>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane); break;
+        case 3: region_brick<TIn, TOut, 3>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane); break;
+        case 4: region_brick<TIn, TOut, 4>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane); break;
+        default: region_brick<TIn, TOut, 8>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane); break;
+    }
+}
+
+}  // namespace
+
+// ---- host: region enumeration, brick list, launch ------------------------------------------------------------
+namespace {
+struct PlanCache {
+    unsigned long long hash = 0;
+    int nitems = 0;
+    size_t rbytes = 0;
+    bool valid = false;
+};
+PlanCache g_plan[MVS_MAX_DEVICES];
+
+unsigned long long fnv1a(const void* p, size_t n, unsigned long long h) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
+// Break points of one axis.  View borders that lie within `tol` of each other (tiles of one grid row/column after
+// registration differ by a few pixels) are clustered: a cluster of lower borders contributes its minimum, a cluster
+// of upper borders (hi + 1) its maximum, so the sliver between the clustered borders falls into the overlap cell,
+// where the affected views are flagged "partial", and the single-view interior cells keep full coverage.
+void axis_breakpoints(const TrView* htr, int n_views, int d, int t, int o, std::vector<int>* out) {
+    std::vector<std::pair<int, int>> ev;   // (position, kind) kind 0 = lower border, 1 = upper border + 1
+    for (int v = 0; v < n_views; ++v) {
+        if (htr[v].lo[d] > htr[v].hi[d]) continue;
+        ev.push_back({std::min(std::max(htr[v].lo[d], t), t + o), 0});
+        ev.push_back({std::min(std::max(htr[v].hi[d] + 1, t), t + o), 1});
+    }
+    std::sort(ev.begin(), ev.end());
+    const int tol = 16;
+    out->clear();
+    out->push_back(t);
+    size_t i = 0;
+    while (i < ev.size()) {
+        size_t j = i;
+        bool has_lo = false, has_hi = false;
+        while (j < ev.size() && ev[j].first - ev[i].first <= tol) {
+            (ev[j].second ? has_hi : has_lo) = true;
+            ++j;
+        }
+        const int cmin = ev[i].first, cmax = ev[j - 1].first;
+        if (has_lo) out->push_back(cmin);
+        if (has_hi) out->push_back(cmax);
+        i = j;
+    }
+    out->push_back(t + o);
+    std::sort(out->begin(), out->end());
+    out->erase(std::unique(out->begin(), out->end()), out->end());
+}
+}  // namespace
+
+// Returns MVS_OK and sets *done = true when the chunk was fused by the region kernel; *done = false means the
+// caller must use the column kernel (more than kMaxRV views on one region, or too many regions/bricks).
+int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_views, int dtype, void* dout, const int64_t os[3],
+                     const int64_t trim[3], bool* done) {
+    *done = false;
+    const int t[3] = {(int)trim[0], (int)trim[1], (int)trim[2]};
+    const int o[3] = {(int)os[0], (int)os[1], (int)os[2]};
+    unsigned long long h = fnv1a(htr, sizeof(TrView) * (size_t)n_views, 1469598103934665603ull);
+    h = fnv1a(t, sizeof(t), h);
+    h = fnv1a(o, sizeof(o), h);
+    PlanCache& pc = g_plan[c->device];
+    char* dbuf = nullptr;
+    int nitems = 0;
+    size_t rbytes = 0;
+    if (pc.valid && pc.hash == h && c->dev[8].ptr) {
+        dbuf = (char*)c->dev[8].ptr;      // same geometry as the previous call: the plan is still on the device
+        nitems = pc.nitems;
+        rbytes = pc.rbytes;
+    } else {
+        std::vector<int> pts[3];
+        for (int d = 0; d < 3; ++d) axis_breakpoints(htr, n_views, d, t[d], o[d], &pts[d]);
+        const size_t ncell = (pts[0].size() - 1) * (pts[1].size() - 1) * (pts[2].size() - 1);
+        if (ncell == 0 || ncell > 60000) return MVS_OK;
+        std::vector<Region> regions;
+        std::vector<Item> items;
+        regions.reserve(ncell);
+        std::vector<int> zviews, yviews;
+        for (size_t iz = 0; iz + 1 < pts[0].size(); ++iz) {
+            zviews.clear();
+            for (int v = 0; v < n_views; ++v)
+                if (htr[v].lo[0] < pts[0][iz + 1] && htr[v].hi[0] >= pts[0][iz] && htr[v].lo[1] <= htr[v].hi[1] && htr[v].lo[2] <= htr[v].hi[2]) zviews.push_back(v);
+            for (size_t iy = 0; iy + 1 < pts[1].size(); ++iy) {
+                yviews.clear();
+                for (int v : zviews)
+                    if (htr[v].lo[1] < pts[1][iy + 1] && htr[v].hi[1] >= pts[1][iy]) yviews.push_back(v);
+                for (size_t ix = 0; ix + 1 < pts[2].size(); ++ix) {
+                    Region R;
+                    memset(&R, 0, sizeof(R));
+                    R.z0 = pts[0][iz]; R.z1 = pts[0][iz + 1];
+                    R.y0 = pts[1][iy]; R.y1 = pts[1][iy + 1];
+                    R.x0 = pts[2][ix]; R.x1 = pts[2][ix + 1];
+                    int nv = 0;
+                    for (int v : yviews) {
+                        if (!(htr[v].lo[2] < R.x1 && htr[v].hi[2] >= R.x0)) continue;   // does not touch the box
+                        if (nv == kMaxRV) return MVS_OK;                              // too many views: column kernel
+                        const bool full = htr[v].lo[0] <= R.z0 && htr[v].hi[0] >= R.z1 - 1 && htr[v].lo[1] <= R.y0 &&
+                                          htr[v].hi[1] >= R.y1 - 1 && htr[v].lo[2] <= R.x0 && htr[v].hi[2] >= R.x1 - 1;
+                        bool unit = full;   // weight 1 everywhere? the profile is concave: check the 8 corners
+                        for (int k = 0; k < 8 && unit; ++k) {
+                            const int z = (k & 4) ? R.z1 - 1 : R.z0, y = (k & 2) ? R.y1 - 1 : R.y0, x = (k & 1) ? R.x1 - 1 : R.x0;
+                            unit = tr_weight_profile(htr[v], z, y, x) >= 1.f;
+                        }
+                        if (unit) R.allone_mask |= 1 << nv;
+                        if (!full) R.allone_mask |= 1 << (16 + nv);
+                        R.ids[nv++] = v;
+                    }
+                    R.nviews = nv;
+                    const int rid = (int)regions.size();
+                    if (rid >= 65536) return MVS_OK;
+                    regions.push_back(R);
+                    const int nbz = (R.z1 - R.z0 + kRB - 1) / kRB, nby = (R.y1 - R.y0 + 4 * kRG - 1) / (4 * kRG), nbx = (R.x1 - R.x0 + kRX - 1) / kRX;
+                    if (nbz >= 65536 || nby >= 65536 || nbx >= 65536) return MVS_OK;
+                    // z fastest so that consecutive bricks reuse the upper plane of their neighbour
+                    for (int by = 0; by < nby; ++by)
+                        for (int bx = 0; bx < nbx; ++bx)
+                            for (int bz = 0; bz < nbz; ++bz) items.push_back({rid | (bx << 16), by | (bz << 16)});
+                }
+            }
+        }
+        if (items.empty() || items.size() > (1u << 28)) return MVS_OK;
+        rbytes = (regions.size() * sizeof(Region) + 255) / 256 * 256;
+        const size_t ibytes = items.size() * sizeof(Item);
+        char* hbuf = (char*)mvs_pinned_slot(c, 1, rbytes + ibytes + 256);   // slot 0 holds the view parameters still in flight
+        if (!hbuf) return MVS_ERR_HIP;
+        pc.valid = false;
+        dbuf = (char*)mvs_scratch(c, 8, rbytes + ibytes + 256);
+        if (!dbuf) return MVS_ERR_HIP;
+        memcpy(hbuf, regions.data(), regions.size() * sizeof(Region));
+        memcpy(hbuf + rbytes, items.data(), ibytes);
+        MVS_HIP_TRY(c, hipMemcpyAsync(dbuf, hbuf, rbytes + ibytes, hipMemcpyHostToDevice, c->stream));
+        nitems = (int)items.size();
+        pc.hash = h;
+        pc.nitems = nitems;
+        pc.rbytes = rbytes;
+        pc.valid = true;
+    }
+    RegionParams P;
+    P.views = dtr;
+    P.regions = (const Region*)dbuf;
+    P.items = (const Item*)(dbuf + rbytes);
+    P.nitems = nitems;
+    P.out = dout;
+    P.oz = o[0]; P.oy = o[1]; P.ox = o[2];
+    P.tz = t[0]; P.ty = t[1]; P.tx = t[2];
+    const int nblocks = (P.nitems + 3) / 4;
+    MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));   // kernel time only (the plan is host work, cached per geometry)
+    switch (dtype) {
+        case MVS_U8: hipLaunchKernelGGL((fuse_region_kernel<unsigned char, unsigned char>), dim3(nblocks), dim3(256), 0, c->stream, P); break;
+        case MVS_U16: hipLaunchKernelGGL((fuse_region_kernel<unsigned short, unsigned short>), dim3(nblocks), dim3(256), 0, c->stream, P); break;
+        default: hipLaunchKernelGGL((fuse_region_kernel<float, float>), dim3(nblocks), dim3(256), 0, c->stream, P); break;
+    }
+    MVS_HIP_TRY(c, hipGetLastError());
+    *done = true;
+    return MVS_OK;
+}

@@ -31,9 +31,12 @@ struct MvsContext {
     std::mutex mu;
     std::string last_error;
     // grow-only device scratch buffers (slot-indexed) and one pinned host staging buffer
-    MvsScratch dev[8];
+    MvsScratch dev[12];
     void* pinned = nullptr;
     size_t pinned_cap = 0;
+    void* pinned2 = nullptr;
+    size_t pinned2_cap = 0;
+    bool no_regions = false;      // test switch: skip the region kernel (use the column kernel)
 };
 
 MvsContext* mvs_ctx(int device);                       // nullptr if out of range
@@ -41,6 +44,7 @@ int mvs_fail(MvsContext* c, int code, const char* fmt, ...);
 int mvs_check_ready(int device, MvsContext** out);     // locks nothing; returns code
 void* mvs_scratch(MvsContext* c, int slot, size_t nbytes);   // nullptr on failure (error set)
 void* mvs_pinned(MvsContext* c, size_t nbytes);
+void* mvs_pinned_slot(MvsContext* c, int slot, size_t nbytes);   // slot 0 == mvs_pinned
 
 #define MVS_HIP_TRY(c, expr)                                                         \
     do {                                                                             \
