@@ -96,22 +96,37 @@ template <bool NINE> struct Row8<float, NINE> {
     }
 };
 
-// element-wise re-fetch of a window that touches the first / last bytes of the slab (see row_refetch in mvs_fuse.hip)
+// Element-wise re-fetch of a 9-element window that touches the first / last bytes of the slab (a vector buffer load
+// that is not entirely in range comes back as 0, see row_refetch in mvs_fuse.hip).  Rare (first / last rows of a
+// slab only), so it is kept out of line and hands the values over through a wavefront-private LDS strip.
 template <typename TIn>
-__device__ __forceinline__ void row8_refetch(__amdgpu_buffer_rsrc_t r, int o, float (&v)[9]) {
-#pragma unroll
+__device__ __noinline__ void row8_refetch_lds(__amdgpu_buffer_rsrc_t r, int o, float* strip) {
     for (int j = 0; j < 9; ++j) {
         const int oj = o + j * (int)sizeof(TIn);
-        if (sizeof(TIn) == 2) v[j] = (float)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, oj, 0, 0);
-        else if (sizeof(TIn) == 1) v[j] = (float)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(r, oj, 0, 0);
-        else {
-            v[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, oj, 0, 0));
-            asm volatile("" ::: "memory");
-        }
+        float v;
+        if (sizeof(TIn) == 2) v = (float)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(r, oj, 0, 0);
+        else if (sizeof(TIn) == 1) v = (float)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(r, oj, 0, 0);
+        else v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, oj, 0, 0));
+        strip[j * 64] = v;
     }
+}
+template <typename TIn>
+__device__ __forceinline__ void row8_refetch(__amdgpu_buffer_rsrc_t r, int o, float (&v)[9], float* strip) {
+    row8_refetch_lds<TIn>(r, o, strip);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) v[j] = strip[j * 64];
 }
 
 __device__ __forceinline__ int rli(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+
+// Lane layout of a brick: 2^lxb lanes side by side along x (8 voxels each), the rest of the 64 lanes stacked along y.
+//   lxb = 4: 4 rows x 128 voxels per group, 8 groups per brick   (regular regions)
+//   lxb = 1: 32 rows x 16 voxels, one group                      (thin ramp zones next to a view border)
+struct LaneMap {
+    int r, c, RG, NG, BXW;
+    __device__ __forceinline__ LaneMap(int lane, int lxb)
+        : r(lane >> lxb), c(lane & ((1 << lxb) - 1)), RG(64 >> lxb), NG(32 / (64 >> lxb)), BXW(kRV << lxb) {}
+};
 
 template <typename TOut> __device__ __forceinline__ TOut cast_r(float v);
 template <> __device__ __forceinline__ float cast_r<float>(float v) { return v; }
@@ -183,15 +198,69 @@ __device__ __forceinline__ void row_nodes(const RecRegs& R, int v, int zc, int y
     dG = G2 - G1;
 }
 
+// Values of view v at the lane's 8 voxels of row (zc, yl) starting at chunk x = xl: all stencil rows of the view are
+// fetched back-to-back with bounds-checked buffer loads, then interpolated (x, then z, then y).
+template <typename TIn>
+__device__ __forceinline__ void fetch_val(const RecRegs& R, int v, int zc, int yl, int xl, float* strip, float (&val)[kRV]) {
+    constexpr int ES = (int)sizeof(TIn);
+    const float wz = rec_fieldf<F_FW_Z>(R, v), wy = rec_fieldf<F_FW_Y>(R, v), wx = rec_fieldf<F_FW_X>(R, v);
+    const bool anyfrac = (wz > 0.f) || (wy > 0.f) || (wx > 0.f);
+    const int sy = rec_field<F_ST_Y>(R, v), sz = rec_field<F_ST_Z>(R, v);
+    const unsigned long long dptr = ((unsigned long long)(unsigned)rec_field<F_DATA_HI>(R, v) << 32) | (unsigned)rec_field<F_DATA_LO>(R, v);
+    const int nbytes = rec_field<F_SPAN_LO>(R, v) * ES;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dptr, 0, nbytes, 0x00020000);
+    const int vo = (((zc + rec_field<F_IO_Z>(R, v)) * sz + (yl + rec_field<F_IO_Y>(R, v)) * sy) + (xl + rec_field<F_IO_X>(R, v))) * ES;
+    constexpr int WB = 9 * ES;
+
+    if (anyfrac) {
+        unsigned int w00[9], w01[9], w10[9], w11[9];
+        Row8<TIn, true>::load(rsrc, vo, w00);
+        Row8<TIn, true>::load(rsrc, vo + sy * ES, w01);
+        Row8<TIn, true>::load(rsrc, vo + sz * ES, w10);
+        Row8<TIn, true>::load(rsrc, vo + (sz + sy) * ES, w11);
+        float e00[9], e01[9], e10[9], e11[9];
+        Row8<TIn, true>::decode(w00, e00);
+        Row8<TIn, true>::decode(w01, e01);
+        Row8<TIn, true>::decode(w10, e10);
+        Row8<TIn, true>::decode(w11, e11);
+        const int olast = vo + (sz + sy) * ES;
+        if (__any(vo < 0 || olast + WB > nbytes)) {   // windows touching the first / last bytes of the slab
+            const int o1 = vo + sy * ES, o2 = vo + sz * ES;
+            if (__any((vo < 0 && vo + WB > 0) || (vo < nbytes && vo + WB > nbytes))) row8_refetch<TIn>(rsrc, vo, e00, strip);
+            if (__any((o1 < 0 && o1 + WB > 0) || (o1 < nbytes && o1 + WB > nbytes))) row8_refetch<TIn>(rsrc, o1, e01, strip);
+            if (__any((o2 < 0 && o2 + WB > 0) || (o2 < nbytes && o2 + WB > nbytes))) row8_refetch<TIn>(rsrc, o2, e10, strip);
+            if (__any((olast < 0 && olast + WB > 0) || (olast < nbytes && olast + WB > nbytes))) row8_refetch<TIn>(rsrc, olast, e11, strip);
+        }
+        const float ux = 1.f - wx, uy = 1.f - wy, uz = 1.f - wz;
+#pragma unroll
+        for (int j = 0; j < kRV; ++j) {
+            const float a00 = fmaf(e00[j + 1], wx, e00[j] * ux), a01 = fmaf(e01[j + 1], wx, e01[j] * ux);
+            const float a10 = fmaf(e10[j + 1], wx, e10[j] * ux), a11 = fmaf(e11[j + 1], wx, e11[j] * ux);
+            const float s0 = fmaf(a10, wz, a00 * uz), s1 = fmaf(a11, wz, a01 * uz);
+            val[j] = fmaf(s1, wy, s0 * uy);
+        }
+    } else {
+        unsigned int w00[9];
+        Row8<TIn, false>::load(rsrc, vo, w00);
+        float e00[9];
+        Row8<TIn, false>::decode(w00, e00);
+        if (__any((vo < 0 && vo + WB > 0) || (vo < nbytes && vo + WB > nbytes))) row8_refetch<TIn>(rsrc, vo, e00, strip);
+#pragma unroll
+        for (int j = 0; j < kRV; ++j) val[j] = e00[j];
+    }
+
+}
+
 // One brick of a region with at most NV views: the view loop is unrolled, so per-view constants end up in scalar
 // registers and the row nodes of ramp-weighted views in per-view vector registers.
 template <typename TIn, typename TOut, int NV>
 __device__ __forceinline__ void region_brick(const RegionParams& P, const RecRegs& R, int nviews, int masks, int z0b, int z1,
-                                             int y0b, int y1, int x0b, int x1, int lane) {
+                                             int y0b, int y1, int x0b, int x1, int lane, int lxb, float* strip) {
     constexpr bool ISF = std::is_floating_point<TIn>::value;
     constexpr int ES = (int)sizeof(TIn);
     const int nv = nviews;   // <= NV
-    const int r = lane >> 4, c = lane & 15;
+    const LaneMap L(lane, lxb);
+    const int r = L.r, c = L.c;
     const int xq = x0b + kRV * c;
     const int nvalid_x = min(max(x1 - xq, 0), kRV);
     const int xl = (nvalid_x > 0) ? xq : x0b;      // lanes beyond the region read a valid window, nothing is stored
@@ -217,8 +286,8 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
                 }
             }
         }
-        for (int g = 0; g < kRG; ++g) {
-            const int yg = y0b + 4 * g;
+        for (int g = 0; g < L.NG; ++g) {
+            const int yg = y0b + L.RG * g;
             if (yg >= y1) break;
             const int yc = yg + r;
             const bool row_ok = yc < y1;
@@ -231,52 +300,8 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 if (v >= nv) break;
-                const float wz = rec_fieldf<F_FW_Z>(R, v), wy = rec_fieldf<F_FW_Y>(R, v), wx = rec_fieldf<F_FW_X>(R, v);
-                const bool anyfrac = (wz > 0.f) || (wy > 0.f) || (wx > 0.f);
-                const int sy = rec_field<F_ST_Y>(R, v), sz = rec_field<F_ST_Z>(R, v);
-                const unsigned long long dptr = ((unsigned long long)(unsigned)rec_field<F_DATA_HI>(R, v) << 32) | (unsigned)rec_field<F_DATA_LO>(R, v);
-                const int nbytes = rec_field<F_SPAN_LO>(R, v) * ES;
-                const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dptr, 0, nbytes, 0x00020000);
-                const int vo = (((zc + rec_field<F_IO_Z>(R, v)) * sz + (yl + rec_field<F_IO_Y>(R, v)) * sy) + (xl + rec_field<F_IO_X>(R, v))) * ES;
-                constexpr int WB = 9 * ES;
-
                 float val[kRV];
-                if (anyfrac) {
-                    unsigned int w00[9], w01[9], w10[9], w11[9];
-                    Row8<TIn, true>::load(rsrc, vo, w00);
-                    Row8<TIn, true>::load(rsrc, vo + sy * ES, w01);
-                    Row8<TIn, true>::load(rsrc, vo + sz * ES, w10);
-                    Row8<TIn, true>::load(rsrc, vo + (sz + sy) * ES, w11);
-                    float e00[9], e01[9], e10[9], e11[9];
-                    Row8<TIn, true>::decode(w00, e00);
-                    Row8<TIn, true>::decode(w01, e01);
-                    Row8<TIn, true>::decode(w10, e10);
-                    Row8<TIn, true>::decode(w11, e11);
-                    const int olast = vo + (sz + sy) * ES;
-                    if (__any(vo < 0 || olast + WB > nbytes)) {   // windows touching the first / last bytes of the slab
-                        const int o1 = vo + sy * ES, o2 = vo + sz * ES;
-                        if (__any((vo < 0 && vo + WB > 0) || (vo < nbytes && vo + WB > nbytes))) row8_refetch<TIn>(rsrc, vo, e00);
-                        if (__any((o1 < 0 && o1 + WB > 0) || (o1 < nbytes && o1 + WB > nbytes))) row8_refetch<TIn>(rsrc, o1, e01);
-                        if (__any((o2 < 0 && o2 + WB > 0) || (o2 < nbytes && o2 + WB > nbytes))) row8_refetch<TIn>(rsrc, o2, e10);
-                        if (__any((olast < 0 && olast + WB > 0) || (olast < nbytes && olast + WB > nbytes))) row8_refetch<TIn>(rsrc, olast, e11);
-                    }
-                    const float ux = 1.f - wx, uy = 1.f - wy, uz = 1.f - wz;
-#pragma unroll
-                    for (int j = 0; j < kRV; ++j) {
-                        const float a00 = fmaf(e00[j + 1], wx, e00[j] * ux), a01 = fmaf(e01[j + 1], wx, e01[j] * ux);
-                        const float a10 = fmaf(e10[j + 1], wx, e10[j] * ux), a11 = fmaf(e11[j + 1], wx, e11[j] * ux);
-                        const float s0 = fmaf(a10, wz, a00 * uz), s1 = fmaf(a11, wz, a01 * uz);
-                        val[j] = fmaf(s1, wy, s0 * uy);
-                    }
-                } else {
-                    unsigned int w00[9];
-                    Row8<TIn, false>::load(rsrc, vo, w00);
-                    float e00[9];
-                    Row8<TIn, false>::decode(w00, e00);
-                    if (__any((vo < 0 && vo + WB > 0) || (vo < nbytes && vo + WB > nbytes))) row8_refetch<TIn>(rsrc, vo, e00);
-#pragma unroll
-                    for (int j = 0; j < kRV; ++j) val[j] = e00[j];
-                }
+                fetch_val<TIn>(R, v, zc, yl, xl, strip, val);
 
                 // views that cover the box only partly: per-voxel in-bounds test against the view's valid box
                 const bool partial = (partial_mask >> v) & 1;
@@ -302,7 +327,7 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
                     float w[kRV];
                     {
                         // nodes of my row come from lane (4 g + r) of the per-view node registers
-                        const int src = 4 * g + r;
+                        const int src = L.RG * g + r;
                         const float G1 = __shfl(nG1[v], src), dG = __shfl(ndG[v], src);
                         const bool inside = __shfl(nin[v], src) != 0;
                         const float kx = rec_fieldf<F_SK_X>(R, v);
@@ -361,26 +386,202 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
     }
 }
 
+// Regions with more than 4 views (3D corners, clustered borders): not unrolled, no per-view registers; the blend
+// profile of non-unit views is evaluated per voxel from the record in memory.  Rare, so compact beats fast here.
 template <typename TIn, typename TOut>
-__global__ __launch_bounds__(256) void fuse_region_kernel(RegionParams P) {
+__device__ __forceinline__ void region_brick_generic(const RegionParams& P, const RecRegs& R, int rw, int nviews, int masks, int z0b, int z1,
+                                                  int y0b, int y1, int x0b, int x1, int lane, int lxb, float* strip) {
+    constexpr bool ISF = std::is_floating_point<TIn>::value;
+    const LaneMap L(lane, lxb);
+    const int r = L.r, c = L.c;
+    const int xq = x0b + kRV * c;
+    const int nvalid_x = min(max(x1 - xq, 0), kRV);
+    const int xl = (nvalid_x > 0) ? xq : x0b;
+    const int allone_mask = masks & 0xffff, partial_mask = (masks >> 16) & 0xffff;
+    TOut* out = (TOut*)P.out;
+    for (int p = 0; p < kRB; ++p) {
+        const int zc = z0b + p;
+        if (zc >= z1) break;
+        for (int g = 0; g < L.NG; ++g) {
+            const int yg = y0b + L.RG * g;
+            if (yg >= y1) break;
+            const int yc = yg + r;
+            const bool row_ok = yc < y1;
+            const int yl = row_ok ? yc : y1 - 1;
+            float num[kRV], den[kRV], last[kRV], wlast[kRV];
+#pragma unroll
+            for (int j = 0; j < kRV; ++j) { num[j] = 0.f; den[j] = 0.f; last[j] = 0.f; wlast[j] = 0.f; }
+#pragma nounroll
+            for (int v = 0; v < nviews; ++v) {
+                float val[kRV];
+                fetch_val<TIn>(R, v, zc, yl, xl, strip, val);
+                const TrView& V = P.views[rli(rw, 8 + v)];
+                const bool partial = (partial_mask >> v) & 1, unit = (allone_mask >> v) & 1;
+                const bool zy_ok = !partial || (zc >= V.lo[0] && zc <= V.hi[0] && yc >= V.lo[1] && yc <= V.hi[1]);
+#pragma unroll
+                for (int j = 0; j < kRV; ++j) {
+                    const int x = xq + j;
+                    bool ok = zy_ok && (!partial || (x >= V.lo[2] && x <= V.hi[2]));
+                    if (ISF) ok = ok && (val[j] == val[j]);
+                    float we = 1.f;
+                    if (!unit) we = blend_ramp_nb(tr_weight_profile(V, zc, yl, xl + j));
+                    we = ok ? we : 0.f;
+                    const bool pos = we > 0.f;
+                    num[j] = fmaf(we, pos ? val[j] : 0.f, num[j]);
+                    den[j] += we;
+                    const int pm = (pos && we < 1.f) ? -1 : 0;
+                    last[j] = __int_as_float((__float_as_int(val[j]) & pm) | (__float_as_int(last[j]) & ~pm));
+                    wlast[j] = __int_as_float((__float_as_int(we) & pm) | (__float_as_int(wlast[j]) & ~pm));
+                }
+            }
+            float q[kRV];
+#pragma unroll
+            for (int j = 0; j < kRV; ++j) {
+                float o = num[j] * __builtin_amdgcn_rcpf(den[j]);
+                o = (den[j] == wlast[j]) ? last[j] : o;
+                if (!(fabsf(o) <= 3.4028234e38f)) o = 0.f;
+                q[j] = o;
+            }
+            if (row_ok && nvalid_x > 0)
+                store8<TOut>(out + ((long long)(zc - P.tz) * P.oy + (yc - P.ty)) * (long long)P.ox + (xq - P.tx), q, nvalid_x);
+        }
+    }
+}
+
+// Class A bricks: ONE view that covers the whole box with blend weight 1 (the interior of every tile: more than half
+// of a 20 %-overlap mosaic).  The result is the resampled value itself -- no accumulators, no weights, no division.
+// All constants are hoisted into scalar registers, the 8 row-group loads of a plane are issued back-to-back before
+// the first one is consumed (integer offsets), so a wavefront keeps 8 KiB in flight.
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void copy_region_kernel(RegionParams P, int item0, int nitems) {
+    constexpr int ES = (int)sizeof(TIn);
+    __shared__ float s_strip[4][9 * 64];
     const int lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= P.nitems) return;
-    const Item it = P.items[item];
+    const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (li >= nitems) return;
+    const Item it = P.items[item0 + li];
+    const int rid = it.region_bx & 0xffff, bx = (unsigned)it.region_bx >> 16, by = it.by_bz & 0xffff, bz = (unsigned)it.by_bz >> 16;
+    const int rw = reinterpret_cast<const int*>(P.regions + rid)[lane & 15];
+    const int z1 = rli(rw, 1), y1 = rli(rw, 3), x1 = rli(rw, 5);
+    const int lxb = (rli(rw, 6) >> 8) & 7;
+    const LaneMap L(lane, lxb);
+    const int z0b = rli(rw, 0) + kRB * bz, y0b = rli(rw, 2) + 32 * by, x0b = rli(rw, 4) + L.BXW * bx;
+    float* strip = &s_strip[threadIdx.x >> 6][lane];
+    // the view's record: lane q < 10 holds float4 q
+    RecRegs R;
+    R.a = make_float4(0.f, 0.f, 0.f, 0.f);
+    R.b = R.a;
+    {
+        const int id = rli(rw, 8);
+        if (lane < 10) R.a = reinterpret_cast<const float4*>(P.views + id)[lane];
+    }
+    const float wz = rec_fieldf<F_FW_Z>(R, 0), wy = rec_fieldf<F_FW_Y>(R, 0), wx = rec_fieldf<F_FW_X>(R, 0);
+    const bool anyfrac = (wz > 0.f) || (wy > 0.f) || (wx > 0.f);
+    const int sy = rec_field<F_ST_Y>(R, 0), sz = rec_field<F_ST_Z>(R, 0);
+    const unsigned long long dptr = ((unsigned long long)(unsigned)rec_field<F_DATA_HI>(R, 0) << 32) | (unsigned)rec_field<F_DATA_LO>(R, 0);
+    const int nbytes = rec_field<F_SPAN_LO>(R, 0) * ES;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dptr, 0, nbytes, 0x00020000);
+    const int ioz = rec_field<F_IO_Z>(R, 0), ioy = rec_field<F_IO_Y>(R, 0), iox = rec_field<F_IO_X>(R, 0);
+
+    const int r = L.r, c = L.c;
+    const int xq = x0b + kRV * c;
+    const int nvalid_x = min(max(x1 - xq, 0), kRV);
+    const int xl = (nvalid_x > 0) ? xq : x0b;
+    constexpr int WB = 9 * ES;
+    TOut* out = (TOut*)P.out;
+
+    for (int p = 0; p < kRB; ++p) {
+        const int zc = z0b + p;
+        if (zc >= z1) break;
+        const int vo_p = ((zc + ioz) * sz + ioy * sy + (xl + iox)) * ES;   // + row * sy * ES
+        if (!anyfrac && lxb == 4) {
+            unsigned int raw[kRG][9];
+            int vo[kRG];
+#pragma unroll
+            for (int g = 0; g < kRG; ++g) {
+                const int yl = min(y0b + 4 * g + r, y1 - 1);
+                vo[g] = vo_p + yl * sy * ES;
+                Row8<TIn, false>::load(rsrc, vo[g], raw[g]);
+            }
+#pragma unroll
+            for (int g = 0; g < kRG; ++g) {
+                const int yc = y0b + 4 * g + r;
+                float e[9];
+                Row8<TIn, false>::decode(raw[g], e);
+                if (__any((vo[g] < 0 && vo[g] + WB > 0) || (vo[g] < nbytes && vo[g] + WB > nbytes))) row8_refetch<TIn>(rsrc, vo[g], e, strip);
+                float q[kRV];
+#pragma unroll
+                for (int j = 0; j < kRV; ++j) q[j] = (e[j] == e[j]) ? e[j] : 0.f;   // nan_to_num (float tiles)
+                if (yc < y1 && nvalid_x > 0)
+                    store8<TOut>(out + ((long long)(zc - P.tz) * P.oy + (yc - P.ty)) * (long long)P.ox + (xq - P.tx), q, nvalid_x);
+            }
+        } else {
+            const float ux = 1.f - wx, uy = 1.f - wy, uz = 1.f - wz;
+#pragma unroll 2
+            for (int g = 0; g < L.NG; ++g) {
+                const int yc = y0b + L.RG * g + r;
+                if (y0b + L.RG * g >= y1) break;
+                const int yl = min(yc, y1 - 1);
+                const int v0 = vo_p + yl * sy * ES;
+                unsigned int w00[9], w01[9], w10[9], w11[9];
+                Row8<TIn, true>::load(rsrc, v0, w00);
+                Row8<TIn, true>::load(rsrc, v0 + sy * ES, w01);
+                Row8<TIn, true>::load(rsrc, v0 + sz * ES, w10);
+                Row8<TIn, true>::load(rsrc, v0 + (sz + sy) * ES, w11);
+                float e00[9], e01[9], e10[9], e11[9];
+                Row8<TIn, true>::decode(w00, e00);
+                Row8<TIn, true>::decode(w01, e01);
+                Row8<TIn, true>::decode(w10, e10);
+                Row8<TIn, true>::decode(w11, e11);
+                const int olast = v0 + (sz + sy) * ES;
+                if (__any(v0 < 0 || olast + WB > nbytes)) {
+                    const int o1 = v0 + sy * ES, o2 = v0 + sz * ES;
+                    if (__any((v0 < 0 && v0 + WB > 0) || (v0 < nbytes && v0 + WB > nbytes))) row8_refetch<TIn>(rsrc, v0, e00, strip);
+                    if (__any((o1 < 0 && o1 + WB > 0) || (o1 < nbytes && o1 + WB > nbytes))) row8_refetch<TIn>(rsrc, o1, e01, strip);
+                    if (__any((o2 < 0 && o2 + WB > 0) || (o2 < nbytes && o2 + WB > nbytes))) row8_refetch<TIn>(rsrc, o2, e10, strip);
+                    if (__any((olast < 0 && olast + WB > 0) || (olast < nbytes && olast + WB > nbytes))) row8_refetch<TIn>(rsrc, olast, e11, strip);
+                }
+                float q[kRV];
+#pragma unroll
+                for (int j = 0; j < kRV; ++j) {
+                    const float a00 = fmaf(e00[j + 1], wx, e00[j] * ux), a01 = fmaf(e01[j + 1], wx, e01[j] * ux);
+                    const float a10 = fmaf(e10[j + 1], wx, e10[j] * ux), a11 = fmaf(e11[j + 1], wx, e11[j] * ux);
+                    const float s0 = fmaf(a10, wz, a00 * uz), s1 = fmaf(a11, wz, a01 * uz);
+                    const float vv = fmaf(s1, wy, s0 * uy);
+                    q[j] = (vv == vv) ? vv : 0.f;
+                }
+                if (yc < y1 && nvalid_x > 0)
+                    store8<TOut>(out + ((long long)(zc - P.tz) * P.oy + (yc - P.ty)) * (long long)P.ox + (xq - P.tx), q, nvalid_x);
+            }
+        }
+    }
+}
+
+// One kernel per view-count class (NVC = 1, 2, 4: regions with <= NVC views, unrolled; NVC = 0: any count), so every
+// class gets its own register allocation and a small instruction footprint.  Items of a class are contiguous.
+template <typename TIn, typename TOut, int NVC>
+__global__ __launch_bounds__(256) void fuse_region_kernel(RegionParams P, int item0, int nitems) {
+    __shared__ float s_strip[4][9 * 64];
+    const int lane = threadIdx.x & 63;
+    const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (li >= nitems) return;
+    const Item it = P.items[item0 + li];
     const int rid = it.region_bx & 0xffff, bx = (unsigned)it.region_bx >> 16, by = it.by_bz & 0xffff, bz = (unsigned)it.by_bz >> 16;
     // region descriptor: lane l < 16 loads dword l, fields are pulled out with readlane
     const int rw = reinterpret_cast<const int*>(P.regions + rid)[lane & 15];
-    const int z0 = rli(rw, 0), z1 = rli(rw, 1), y0 = rli(rw, 2), y1 = rli(rw, 3), x0 = rli(rw, 4), x1 = rli(rw, 5);
-    const int nviews = rli(rw, 6), masks = rli(rw, 7);
-    const int z0b = z0 + kRB * bz, y0b = y0 + 4 * kRG * by, x0b = x0 + kRX * bx;
+    const int z1 = rli(rw, 1), y1 = rli(rw, 3), x1 = rli(rw, 5);
+    const int nviews = rli(rw, 6) & 0xff, lxb = (rli(rw, 6) >> 8) & 7, masks = rli(rw, 7);
+    const LaneMap L(lane, lxb);
+    const int z0b = rli(rw, 0) + kRB * bz, y0b = rli(rw, 2) + 32 * by, x0b = rli(rw, 4) + L.BXW * bx;
+    float* strip = &s_strip[threadIdx.x >> 6][lane];
 
     if (nviews == 0) {   // nothing contributes: zeros (np.nansum of nothing, nan_to_num)
-        const int r = lane >> 4, c = lane & 15, xq = x0b + kRV * c;
+        const int r = L.r, c = L.c, xq = x0b + kRV * c;
         const int nvx = min(max(x1 - xq, 0), kRV);
         float q[kRV] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int p = 0; p < kRB && z0b + p < z1; ++p)
-            for (int g = 0; g < kRG; ++g) {
-                const int yc = y0b + 4 * g + r;
+            for (int g = 0; g < L.NG; ++g) {
+                const int yc = y0b + L.RG * g + r;
                 if (yc < y1 && nvx > 0)
                     store8<TOut>((TOut*)P.out + ((long long)(z0b + p - P.tz) * P.oy + (yc - P.ty)) * (long long)P.ox + (xq - P.tx), q, nvx);
             }
@@ -395,15 +596,10 @@ __global__ __launch_bounds__(256) void fuse_region_kernel(RegionParams P) {
         R.a = make_float4(0.f, 0.f, 0.f, 0.f);
         R.b = R.a;
         if (va < min(nviews, 6)) R.a = reinterpret_cast<const float4*>(P.views + ida)[qa];
-        if (nviews > 6 && va < nviews - 6) R.b = reinterpret_cast<const float4*>(P.views + idb)[qa];
+        if ((NVC == 0 || NVC > 6) && nviews > 6 && va < nviews - 6) R.b = reinterpret_cast<const float4*>(P.views + idb)[qa];
     }
-    switch (nviews) {
-        case 1: region_brick<TIn, TOut, 1>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane); break;
-        case 2: region_brick<TIn, TOut, 2>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane); break;
-        case 3: region_brick<TIn, TOut, 3>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane); break;
-        case 4: region_brick<TIn, TOut, 4>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane); break;
-        default: region_brick<TIn, TOut, 8>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane); break;
-    }
+    if (NVC == 0) region_brick_generic<TIn, TOut>(P, R, rw, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane, lxb, strip);
+    else region_brick<TIn, TOut, (NVC ? NVC : 1)>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane, lxb, strip);
 }
 
 }  // namespace
@@ -413,6 +609,7 @@ namespace {
 struct PlanCache {
     unsigned long long hash = 0;
     int nitems = 0;
+    int class_count[5] = {0, 0, 0, 0, 0};   // bricks of regions with <=1, 2, <=4, >4 views, and copy-class bricks (contiguous, in this order)
     size_t rbytes = 0;
     bool valid = false;
 };
@@ -429,28 +626,45 @@ unsigned long long fnv1a(const void* p, size_t n, unsigned long long h) {
 // of upper borders (hi + 1) its maximum, so the sliver between the clustered borders falls into the overlap cell,
 // where the affected views are flagged "partial", and the single-view interior cells keep full coverage.
 void axis_breakpoints(const TrView* htr, int n_views, int d, int t, int o, std::vector<int>* out) {
-    std::vector<std::pair<int, int>> ev;   // (position, kind) kind 0 = lower border, 1 = upper border + 1
+    // kinds: 0 lower border (cluster -> min), 1 upper border + 1 (-> max),
+    //        2 end of the lower ramp zone (-> max), 3 start of the upper ramp zone (-> min)
+    std::vector<std::pair<int, int>> ev;
+    auto clampi = [&](int v) { return std::min(std::max(v, t), t + o); };
     for (int v = 0; v < n_views; ++v) {
-        if (htr[v].lo[d] > htr[v].hi[d]) continue;
-        ev.push_back({std::min(std::max(htr[v].lo[d], t), t + o), 0});
-        ev.push_back({std::min(std::max(htr[v].hi[d] + 1, t), t + o), 1});
+        const int lo = htr[v].lo[d], hi = htr[v].hi[d];
+        if (lo > hi) continue;
+        ev.push_back({clampi(lo), 0});
+        ev.push_back({clampi(hi + 1), 1});
+        // A thin shell next to every border: inside it the blend weight of the view can round to 0 (the reference
+        // outputs 0 there even for a single view, weights.py:502-507); outside it a voxel seen by ONE view is simply
+        // the resampled value whatever the weight is, so single-view boxes off the shell need no weights at all.
+        const int shell = 4;
+        if (2 * shell + 8 < hi - lo + 1) {
+            ev.push_back({clampi(lo + shell), 2});
+            ev.push_back({clampi(hi + 1 - shell), 3});
+        }
     }
-    std::sort(ev.begin(), ev.end());
     const int tol = 16;
     out->clear();
     out->push_back(t);
-    size_t i = 0;
-    while (i < ev.size()) {
-        size_t j = i;
-        bool has_lo = false, has_hi = false;
-        while (j < ev.size() && ev[j].first - ev[i].first <= tol) {
-            (ev[j].second ? has_hi : has_lo) = true;
-            ++j;
+    for (int kind_group = 0; kind_group < 2; ++kind_group) {
+        // borders and zone ends are clustered separately so that a zone end never merges with a border
+        std::vector<std::pair<int, int>> e2;
+        for (auto& e : ev)
+            if ((e.second >= 2) == (kind_group == 1)) e2.push_back(e);
+        std::sort(e2.begin(), e2.end());
+        size_t i = 0;
+        while (i < e2.size()) {
+            size_t j = i;
+            bool want_min = false, want_max = false;
+            while (j < e2.size() && e2[j].first - e2[i].first <= tol) {
+                if (e2[j].second == 0 || e2[j].second == 3) want_min = true; else want_max = true;
+                ++j;
+            }
+            if (want_min) out->push_back(e2[i].first);
+            if (want_max) out->push_back(e2[j - 1].first);
+            i = j;
         }
-        const int cmin = ev[i].first, cmax = ev[j - 1].first;
-        if (has_lo) out->push_back(cmin);
-        if (has_hi) out->push_back(cmax);
-        i = j;
     }
     out->push_back(t + o);
     std::sort(out->begin(), out->end());
@@ -482,7 +696,7 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
         const size_t ncell = (pts[0].size() - 1) * (pts[1].size() - 1) * (pts[2].size() - 1);
         if (ncell == 0 || ncell > 60000) return MVS_OK;
         std::vector<Region> regions;
-        std::vector<Item> items;
+        std::vector<Item> items_by_class[5];
         regions.reserve(ncell);
         std::vector<int> zviews, yviews;
         for (size_t iz = 0; iz + 1 < pts[0].size(); ++iz) {
@@ -500,32 +714,45 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
                     R.y0 = pts[1][iy]; R.y1 = pts[1][iy + 1];
                     R.x0 = pts[2][ix]; R.x1 = pts[2][ix + 1];
                     int nv = 0;
+                    bool positive_full = false;
                     for (int v : yviews) {
                         if (!(htr[v].lo[2] < R.x1 && htr[v].hi[2] >= R.x0)) continue;   // does not touch the box
                         if (nv == kMaxRV) return MVS_OK;                              // too many views: column kernel
                         const bool full = htr[v].lo[0] <= R.z0 && htr[v].hi[0] >= R.z1 - 1 && htr[v].lo[1] <= R.y0 &&
                                           htr[v].hi[1] >= R.y1 - 1 && htr[v].lo[2] <= R.x0 && htr[v].hi[2] >= R.x1 - 1;
-                        bool unit = full;   // weight 1 everywhere? the profile is concave: check the 8 corners
-                        for (int k = 0; k < 8 && unit; ++k) {
+                        // the profile is concave, so its minimum over the box sits at one of the 8 corners
+                        float wmin = INFINITY;
+                        for (int k = 0; k < 8; ++k) {
                             const int z = (k & 4) ? R.z1 - 1 : R.z0, y = (k & 2) ? R.y1 - 1 : R.y0, x = (k & 1) ? R.x1 - 1 : R.x0;
-                            unit = tr_weight_profile(htr[v], z, y, x) >= 1.f;
+                            wmin = fminf(wmin, tr_weight_profile(htr[v], z, y, x));
                         }
+                        const bool unit = full && wmin >= 1.f;          // weight exactly 1 everywhere
+                        if (full && wmin >= 1e-3f) positive_full = true;   // weight > 0 everywhere (ramp(1e-3) = 2.5e-6 > 2^-26)
                         if (unit) R.allone_mask |= 1 << nv;
                         if (!full) R.allone_mask |= 1 << (16 + nv);
                         R.ids[nv++] = v;
                     }
-                    R.nviews = nv;
+                    const int lxb = (R.x1 - R.x0 <= 32) ? 1 : 4;   // thin boxes (ramp zones): 16-voxel-wide bricks
+                    R.nviews = nv | (lxb << 8);
                     const int rid = (int)regions.size();
                     if (rid >= 65536) return MVS_OK;
                     regions.push_back(R);
-                    const int nbz = (R.z1 - R.z0 + kRB - 1) / kRB, nby = (R.y1 - R.y0 + 4 * kRG - 1) / (4 * kRG), nbx = (R.x1 - R.x0 + kRX - 1) / kRX;
+                    const int bxw = kRV << lxb;
+                    const int nbz = (R.z1 - R.z0 + kRB - 1) / kRB, nby = (R.y1 - R.y0 + 31) / 32, nbx = (R.x1 - R.x0 + bxw - 1) / bxw;
                     if (nbz >= 65536 || nby >= 65536 || nbx >= 65536) return MVS_OK;
                     // z fastest so that consecutive bricks reuse the upper plane of their neighbour
+                    const bool copy_class = (nv == 1) && positive_full;   // one full view with positive weight everywhere
+                    std::vector<Item>& dst = items_by_class[copy_class ? 4 : nv <= 1 ? 0 : nv == 2 ? 1 : nv <= 4 ? 2 : 3];
                     for (int by = 0; by < nby; ++by)
                         for (int bx = 0; bx < nbx; ++bx)
-                            for (int bz = 0; bz < nbz; ++bz) items.push_back({rid | (bx << 16), by | (bz << 16)});
+                            for (int bz = 0; bz < nbz; ++bz) dst.push_back({rid | (bx << 16), by | (bz << 16)});
                 }
             }
+        }
+        std::vector<Item> items;
+        for (int k = 0; k < 5; ++k) {
+            pc.class_count[k] = (int)items_by_class[k].size();
+            items.insert(items.end(), items_by_class[k].begin(), items_by_class[k].end());
         }
         if (items.empty() || items.size() > (1u << 28)) return MVS_OK;
         rbytes = (regions.size() * sizeof(Region) + 255) / 256 * 256;
@@ -552,12 +779,24 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
     P.out = dout;
     P.oz = o[0]; P.oy = o[1]; P.ox = o[2];
     P.tz = t[0]; P.ty = t[1]; P.tx = t[2];
-    const int nblocks = (P.nitems + 3) / 4;
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));   // kernel time only (the plan is host work, cached per geometry)
-    switch (dtype) {
-        case MVS_U8: hipLaunchKernelGGL((fuse_region_kernel<unsigned char, unsigned char>), dim3(nblocks), dim3(256), 0, c->stream, P); break;
-        case MVS_U16: hipLaunchKernelGGL((fuse_region_kernel<unsigned short, unsigned short>), dim3(nblocks), dim3(256), 0, c->stream, P); break;
-        default: hipLaunchKernelGGL((fuse_region_kernel<float, float>), dim3(nblocks), dim3(256), 0, c->stream, P); break;
+    int item0 = 0;
+    for (int k = 0; k < 5; ++k) {
+        const int cnt = pc.class_count[k];
+        if (cnt && k == 4) {
+            const dim3 grid((cnt + 3) / 4), block(256);
+            if (dtype == MVS_U8) hipLaunchKernelGGL((copy_region_kernel<unsigned char, unsigned char>), grid, block, 0, c->stream, P, item0, cnt);
+            else if (dtype == MVS_U16) hipLaunchKernelGGL((copy_region_kernel<unsigned short, unsigned short>), grid, block, 0, c->stream, P, item0, cnt);
+            else hipLaunchKernelGGL((copy_region_kernel<float, float>), grid, block, 0, c->stream, P, item0, cnt);
+        } else if (cnt) {
+            const dim3 grid((cnt + 3) / 4), block(256);
+#define MVS_RK(T, NVC) hipLaunchKernelGGL((fuse_region_kernel<T, T, NVC>), grid, block, 0, c->stream, P, item0, cnt)
+#define MVS_RKD(NVC) do { if (dtype == MVS_U8) MVS_RK(unsigned char, NVC); else if (dtype == MVS_U16) MVS_RK(unsigned short, NVC); else MVS_RK(float, NVC); } while (0)
+            if (k == 0) MVS_RKD(1); else if (k == 1) MVS_RKD(2); else if (k == 2) MVS_RKD(4); else MVS_RKD(8);
+#undef MVS_RKD
+#undef MVS_RK
+        }
+        item0 += cnt;
     }
     MVS_HIP_TRY(c, hipGetLastError());
     *done = true;
