@@ -161,11 +161,15 @@ int mvs_bin_mean(int device, const void* in, int32_t dtype, int32_t mem, const i
  * masks, bounding-box region (region_mode 0 = "union", 1 = "intersection"),
  * SSIM (ssim_out) and masked Spearman correlation (spearman_out).  A skipped
  * candidate reports code_out = 1 (mask empty / <10% valid -> both metrics -1),
- * 2 (the `continue` of registration.py:530-533, no metric appended), else 0. */
+ * 2 (the `continue` of registration.py:530-533, no metric appended), else 0.
+ * quality_for_all = 0: the rank correlation is evaluated only for the candidate(s)
+ * holding the best SSIM -- the only one the reference reports (registration.py:543-556) --
+ * and spearman_out is NaN for the other scored candidates; 1: for every candidate. */
 int mvs_score_candidates(int device, const float* fixed, const float* moving, int32_t mem,
                          int32_t ndim, const int64_t shape[3],
                          const double* t_candidates, int32_t n_candidates,
                          int32_t region_mode, double data_range, double im1_min,
+                         int32_t quality_for_all,
                          double* ssim_out, double* spearman_out, int32_t* code_out);
 
 #ifdef __cplusplus

@@ -93,7 +93,7 @@ SIGNATURES = {
     "mvs_score_candidates": (
         C.c_int,
         [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_double),
-         C.c_int32, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
+         C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
          C.POINTER(C.c_int32)],
     ),
 }

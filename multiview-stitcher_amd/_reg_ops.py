@@ -65,9 +65,11 @@ def phase_cross_correlation(reference_image, moving_image, upsample_factor=1, no
     return s
 
 
-def score_candidates(im0, im1, t_candidates, region_mode, data_range, im1_min, device=0):
+def score_candidates(im0, im1, t_candidates, region_mode, data_range, im1_min, device=0, quality_for_all=True):
     """The candidate loop of registration.py:493-556 on the GPU.  im0 / im1: rescaled float32 images
-    (NaN = outside).  Returns (ssim, spearman, code) arrays; code 1 = (-1,-1) appended, 2 = `continue`."""
+    (NaN = outside).  Returns (ssim, spearman, code) arrays; code 1 = (-1,-1) appended, 2 = `continue`.
+    ``quality_for_all=False`` evaluates the Spearman coefficient only for the best-SSIM candidate(s) (NaN
+    elsewhere) -- the only value the reference's result uses."""
     lib = _lib.init(device)
     shape = tuple(int(s) for s in im0.shape)
     ndim = len(shape)
@@ -75,19 +77,24 @@ def score_candidates(im0, im1, t_candidates, region_mode, data_range, im1_min, d
     p1, m1, k1 = _ptr_mem(im1)
     if m0 != m1:
         raise TypeError("both images must live on the same side (host or device)")
-    t = np.ascontiguousarray(np.asarray(t_candidates, dtype=np.float64).reshape(-1, ndim))
+    t_all = np.asarray(t_candidates, dtype=np.float64).reshape(-1, ndim)
+    # both phase-correlation variants usually agree, so the enumeration holds exact duplicates; scoring is a
+    # pure function of t: evaluate each distinct vector once and scatter (list order / nanargmax unchanged)
+    t_uniq, inverse = np.unique(t_all, axis=0, return_inverse=True)
+    t = np.ascontiguousarray(t_uniq)
+    inverse = np.asarray(inverse).reshape(-1)
     n = t.shape[0]
     ssim = np.empty(n, dtype=np.float64)
     spear = np.empty(n, dtype=np.float64)
     code = np.empty(n, dtype=np.int32)
     rc = lib.mvs_score_candidates(
         device, p0, p1, m0, ndim, _lib.i64x3(shape3(shape)), t.ctypes.data_as(C.POINTER(C.c_double)), n,
-        {"union": 0, "intersection": 1}[region_mode], float(data_range), float(im1_min),
+        {"union": 0, "intersection": 1}[region_mode], float(data_range), float(im1_min), int(bool(quality_for_all)),
         ssim.ctypes.data_as(C.POINTER(C.c_double)), spear.ctypes.data_as(C.POINTER(C.c_double)),
         code.ctypes.data_as(C.POINTER(C.c_int32)),
     )
     _lib.check(rc, device, "mvs_score_candidates")
-    return ssim, spear, code
+    return ssim[inverse], spear[inverse], code[inverse]
 
 
 def bin_mean(data, bins, device=0):

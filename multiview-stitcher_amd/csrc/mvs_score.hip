@@ -80,7 +80,21 @@ __global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im
         mnz = min(mnz, __shfl_down(mnz, off)); mny = min(mny, __shfl_down(mny, off)); mnx = min(mnx, __shfl_down(mnx, off));
         mxz = max(mxz, __shfl_down(mxz, off)); mxy = max(mxy, __shfl_down(mxy, off)); mxx = max(mxx, __shfl_down(mxx, off));
     }
+    // one set of atomics per workgroup (the per-wavefront version spent most of the kernel in atomic contention)
+    __shared__ unsigned long long s_cnt[4];
+    __shared__ int s_bb[4][6];
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
+        s_cnt[wave] = cnt;
+        s_bb[wave][0] = mnz; s_bb[wave][1] = mny; s_bb[wave][2] = mnx; s_bb[wave][3] = mxz; s_bb[wave][4] = mxy; s_bb[wave][5] = mxx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            cnt += s_cnt[w];
+            mnz = min(mnz, s_bb[w][0]); mny = min(mny, s_bb[w][1]); mnx = min(mnx, s_bb[w][2]);
+            mxz = max(mxz, s_bb[w][3]); mxy = max(mxy, s_bb[w][4]); mxx = max(mxx, s_bb[w][5]);
+        }
         if (cnt) atomicAdd(count, cnt);
         if (mxz >= 0) {
             atomicMin(&bbox[0], mnz); atomicMin(&bbox[1], mny); atomicMin(&bbox[2], mnx);
@@ -107,9 +121,21 @@ __global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ im,
         mnz = min(mnz, __shfl_down(mnz, off)); mny = min(mny, __shfl_down(mny, off)); mnx = min(mnx, __shfl_down(mnx, off));
         mxz = max(mxz, __shfl_down(mxz, off)); mxy = max(mxy, __shfl_down(mxy, off)); mxx = max(mxx, __shfl_down(mxx, off));
     }
-    if ((threadIdx.x & 63) == 0 && mxz >= 0) {
-        atomicMin(&bbox[0], mnz); atomicMin(&bbox[1], mny); atomicMin(&bbox[2], mnx);
-        atomicMax(&bbox[3], mxz); atomicMax(&bbox[4], mxy); atomicMax(&bbox[5], mxx);
+    __shared__ int s_bb[4][6];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_bb[wave][0] = mnz; s_bb[wave][1] = mny; s_bb[wave][2] = mnx; s_bb[wave][3] = mxz; s_bb[wave][4] = mxy; s_bb[wave][5] = mxx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) {
+            mnz = min(mnz, s_bb[w][0]); mny = min(mny, s_bb[w][1]); mnx = min(mnx, s_bb[w][2]);
+            mxz = max(mxz, s_bb[w][3]); mxy = max(mxy, s_bb[w][4]); mxx = max(mxx, s_bb[w][5]);
+        }
+        if (mxz >= 0) {
+            atomicMin(&bbox[0], mnz); atomicMin(&bbox[1], mny); atomicMin(&bbox[2], mnx);
+            atomicMax(&bbox[3], mxz); atomicMax(&bbox[4], mxy); atomicMax(&bbox[5], mxx);
+        }
     }
 }
 
@@ -138,7 +164,12 @@ __global__ __launch_bounds__(256) void region_kernel(const float* __restrict__ i
         mx = fmaxf(mx, __shfl_down(mx, off));
         hn |= __shfl_down(hn, off);
     }
-    if ((threadIdx.x & 63) == 0) {
+    __shared__ float s_mx[4];
+    __shared__ int s_hn[4];
+    if ((threadIdx.x & 63) == 0) { s_mx[threadIdx.x >> 6] = mx; s_hn[threadIdx.x >> 6] = hn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { mx = fmaxf(mx, s_mx[w]); hn |= s_hn[w]; }
         // order-preserving float -> uint mapping so atomicMax works for negative values too
         unsigned int u = __float_as_uint(mx);
         u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -268,12 +299,28 @@ __global__ __launch_bounds__(256) void ranks_kernel(const float* __restrict__ so
                                                     unsigned int n, float* __restrict__ rank_out) {
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float k = sorted[i];
-        unsigned int lo = 0, hi = i;          // first position with key == k
-        while (lo < hi) { const unsigned int m = (lo + hi) >> 1; if (sorted[m] < k) lo = m + 1; else hi = m; }
-        const unsigned int first = lo;
-        lo = i + 1; hi = n;                   // first position with key > k
-        while (lo < hi) { const unsigned int m = (lo + hi) >> 1; if (sorted[m] <= k) lo = m + 1; else hi = m; }
-        const unsigned int last = lo;
+        const bool tie_l = (i > 0) && (sorted[i - 1] == k), tie_r = (i + 1 < n) && (sorted[i + 1] == k);
+        if (!tie_l && !tie_r) {               // no tie (the common case for float images): rank = position + 1
+            rank_out[idx[i]] = (float)((double)i + 1.0);
+            continue;
+        }
+        // galloping search outwards from i: runs of equal keys are short compared with n, and the probes
+        // stay in the cache lines around i instead of bouncing over the whole array
+        unsigned int first = i, last = i + 1, lo, hi;
+        if (tie_l) {
+            unsigned int pos = i, step = 1;
+            while (pos >= step && sorted[pos - step] == k) { pos -= step; step <<= 1; }
+            lo = pos >= step ? pos - step + 1 : 0; hi = pos;          // first index with key == k in [lo, hi]
+            while (lo < hi) { const unsigned int m = (lo + hi) >> 1; if (sorted[m] < k) lo = m + 1; else hi = m; }
+            first = lo;
+        }
+        if (tie_r) {
+            unsigned int pos = i, step = 1;
+            while (pos + step < n && sorted[pos + step] == k) { pos += step; step <<= 1; }
+            lo = pos + 1; hi = min(pos + step, n);                    // first index with key > k in [lo, hi]
+            while (lo < hi) { const unsigned int m = (lo + hi) >> 1; if (sorted[m] <= k) lo = m + 1; else hi = m; }
+            last = lo;
+        }
         // ranks up to 2^32: keep them exact by storing (first + last + 1) / 2 as float pairs would lose bits,
         // so store as float the doubled rank split: exact for n < 2^24, else rounded (documented)
         rank_out[idx[i]] = (float)(0.5 * ((double)first + (double)last + 1.0));
@@ -323,8 +370,8 @@ int rank_vector(MvsContext* c, float* keys, unsigned int n, float* keys_sorted, 
 
 extern "C" int mvs_score_candidates(int device, const float* fixed, const float* moving, int32_t mem, int32_t ndim,
                                     const int64_t shape[3], const double* t_candidates, int32_t n_candidates,
-                                    int32_t region_mode, double data_range, double im1_min, double* ssim_out,
-                                    double* spearman_out, int32_t* code_out) {
+                                    int32_t region_mode, double data_range, double im1_min, int32_t quality_for_all,
+                                    double* ssim_out, double* spearman_out, int32_t* code_out) {
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
@@ -385,6 +432,27 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     rc = mvs_device_nanminmax(c, im1, n, &mn1, &mx1, &nv1);   // synchronises the stream
     if (rc) return rc;
     const unsigned int valid1 = (unsigned int)nv1;
+
+    // ---- Spearman over the jointly valid voxels of the candidate whose shifted image is in im1t ----
+    std::vector<unsigned long long> cnts((size_t)std::max(n_candidates, 1), 0ull);
+    auto spearman_of_current = [&](int ic) -> int {
+        MVS_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 4, c->stream));
+        hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, c->stream, im0, im1t, n, X, Y, d_counter);
+        const unsigned int m = (unsigned int)cnts[ic];
+        int r = rank_vector(c, X, m, XX, IDX, (unsigned int*)UXY, sort_temp, sort_temp_bytes, UX);
+        if (r) return r;
+        r = rank_vector(c, Y, m, YY, IDX, (unsigned int*)UXY, sort_temp, sort_temp_bytes, UY);
+        if (r) return r;
+        const int mgb = grid_for(m);
+        hipLaunchKernelGGL(rankcorr_kernel, dim3(mgb), dim3(256), 0, c->stream, UX, UY, m, 0.5 * ((double)m + 1.0), partial);
+        std::vector<double> hp((size_t)mgb * 3);
+        MVS_HIP_TRY(c, hipMemcpyAsync(hp.data(), partial, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, c->stream));
+        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        double sxy = 0, sxx = 0, syy = 0;
+        for (int i = 0; i < mgb; ++i) { sxy += hp[i * 3]; sxx += hp[i * 3 + 1]; syy += hp[i * 3 + 2]; }
+        spearman_out[ic] = sxy / std::sqrt(sxx * syy);
+        return MVS_OK;
+    };
 
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     for (int ic = 0; ic < n_candidates; ++ic) {
@@ -491,22 +559,29 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             for (int k = k0; k < 3; ++k) cropn *= (double)((&R.nz)[k] - 2 * pad);
             ssim_out[ic] = sum / cropn;
         }
-        // ---- Spearman over the jointly valid voxels ----
-        MVS_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 4, c->stream));
-        hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, c->stream, im0, im1t, n, X, Y, d_counter);
-        const unsigned int m = (unsigned int)cnt;
-        rc = rank_vector(c, X, m, XX, IDX, (unsigned int*)UXY, sort_temp, sort_temp_bytes, UX);
+        cnts[ic] = cnt;
+        if (!quality_for_all) continue;
+        rc = spearman_of_current(ic);
         if (rc) return rc;
-        rc = rank_vector(c, Y, m, YY, IDX, (unsigned int*)UXY, sort_temp, sort_temp_bytes, UY);
-        if (rc) return rc;
-        const int mgb = grid_for(m);
-        hipLaunchKernelGGL(rankcorr_kernel, dim3(mgb), dim3(256), 0, c->stream, UX, UY, m, 0.5 * ((double)m + 1.0), partial);
-        std::vector<double> hp((size_t)mgb * 3);
-        MVS_HIP_TRY(c, hipMemcpyAsync(hp.data(), partial, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, c->stream));
-        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-        double sxy = 0, sxx = 0, syy = 0;
-        for (int i = 0; i < mgb; ++i) { sxy += hp[i * 3]; sxx += hp[i * 3 + 1]; syy += hp[i * 3 + 2]; }
-        spearman_out[ic] = sxy / std::sqrt(sxx * syy);
+    }
+    if (!quality_for_all) {
+        // The reference reports the Spearman coefficient of the SSIM-argmax candidate only (registration.py:
+        // 543-556), so the rank correlation is evaluated for the candidates that hold the best SSIM (all of
+        // them when several tie) and is NaN for the others.
+        double best = -INFINITY;
+        for (int ic = 0; ic < n_candidates; ++ic)
+            if (code_out[ic] != 2 && ssim_out[ic] > best) best = ssim_out[ic];
+        for (int ic = 0; ic < n_candidates; ++ic) {
+            if (code_out[ic] != 0) continue;
+            if (!(ssim_out[ic] == best)) { spearman_out[ic] = NAN; continue; }
+            double t[3] = {0.0, 0.0, 0.0};
+            for (int k = 0; k < ndim; ++k) t[k0 + k] = t_candidates[ic * ndim + k];
+            MVS_HIP_TRY(c, hipMemsetAsync(d_count, 0, 8, c->stream));
+            MVS_HIP_TRY(c, hipMemcpyAsync(d_bbox, bb_init, sizeof(bb_init), hipMemcpyHostToDevice, c->stream));
+            hipLaunchKernelGGL(shift_kernel, dim3(std::min(gb, 1024)), dim3(256), 0, c->stream, im1, im0, im1t, S, t[0], t[1], t[2], d_count, d_bbox);
+            rc = spearman_of_current(ic);
+            if (rc) return rc;
+        }
     }
     MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
     c->timing_valid = true;

@@ -100,7 +100,10 @@ def phase_correlation_registration(fixed_data, moving_data, disambiguate_region_
     if not len(t_candidates):
         return [np.zeros(ndim)]
 
-    ssim, spear, codes = _reg_ops.score_candidates(im0, im1, t_candidates, disambiguate_region_mode, data_range, im1_min, device)
+    # only the Spearman value of the winning candidate is reported, so it is only evaluated for that one
+    # (all of them when the debug lists are requested)
+    ssim, spear, codes = _reg_ops.score_candidates(im0, im1, t_candidates, disambiguate_region_mode, data_range, im1_min,
+                                                   device, quality_for_all=return_debug)
     # metric lists exactly as the reference builds them: code 2 (`continue`, registration.py:530-533) appends nothing
     disambiguate_metric_vals = [float(ssim[i]) for i in range(len(codes)) if codes[i] != 2]
     quality_metric_vals = [float(spear[i]) for i in range(len(codes)) if codes[i] != 2]

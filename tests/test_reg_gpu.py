@@ -93,6 +93,18 @@ def _check_scores(a, b, t_cands, region_mode):
             assert abs(spear[i] - q) <= 1e-5, (i, t, spear[i], q)
         elif code == 1:
             assert ssim[i] == -1 and spear[i] == -1
+    # quality_for_all=False: same SSIM / codes; Spearman only for the best-SSIM candidate(s), NaN for the rest
+    ssim2, spear2, codes2 = _reg_ops.score_candidates(im0, im1, t_cands, region_mode, data_range, im1_min, quality_for_all=False)
+    np.testing.assert_array_equal(codes2, codes)
+    np.testing.assert_array_equal(ssim2, ssim)
+    listed = [i for i in range(len(codes)) if codes[i] != 2]
+    if listed:
+        best = np.nanmax([ssim[i] for i in listed])
+        for i in listed:
+            if ssim[i] == best or codes[i] == 1:
+                assert spear2[i] == spear[i], (i, spear2[i], spear[i])
+            else:
+                assert np.isnan(spear2[i])
 
 
 @pytest.mark.parametrize("shape,shift", [((60, 104), (3, -5)), ((24, 40, 36), (2, -3, 4)), ((1, 50, 64), (0, 4, 2))])
@@ -102,6 +114,7 @@ def test_score_candidates_no_nan(hip_device, shape, shift):
     cands = [list(np.zeros(nd)), list(-np.asarray(shift, float)), list(np.asarray(shift, float) + 0.5),
              [s * 0.9 for s in shape][:nd], [-(shift[d] - shape[d]) for d in range(nd)]]
     _check_scores(a, b, cands, "union")
+    _check_scores(a, b, cands + cands[:2], "union")     # exact duplicates are scored once and scattered
 
 
 def test_score_candidates_with_nan_borders(hip_device):
