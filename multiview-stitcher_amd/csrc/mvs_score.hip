@@ -23,64 +23,26 @@ int mvs_device_nanminmax(MvsContext* c, const float* d_in, long long n, float* m
 
 namespace {
 
+constexpr int kStatBlocks = 512;     // workgroups (= partial results per candidate) of the statistics kernels
+constexpr int kMaxResident = 16;     // shifted copies of the moving image kept per batch of candidates
+constexpr int kChunk = 8;            // outputs one thread produces along the filtered axis
+
 inline int grid_for(long long n) { return (int)std::min<long long>((n + 255) / 256, 256 * 8); }
 
 struct Shape3 { int nz, ny, nx; };
 
-// ---- shifted copy of im1 with scipy's affine_transform semantics (order 1, cval NaN) ------------
-__device__ __forceinline__ int tap2(int i0, int n) {
-    int i1 = i0 + 1;
-    if (i1 >= n) i1 = (n > 1) ? n - 2 : 0;   // mirrored edge offset, weight 0 there
-    return i1;
-}
+// #valid voxels + bounding box of the valid voxels (min z,y,x, max z,y,x)
+struct VoxStats { unsigned long long cnt; int bb[6]; };
+// nanmax / has-NaN of the moving image over the SSIM region, and the sum of the SSIM map over its cropped interior
+struct RegionStats { float mx; int hasnan; double ssim_sum; };
 
-// Stats gathered while shifting: [0] #(valid im1t & valid im0), [1..6] bbox of valid im1t (min z,y,x, max z,y,x)
-__global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im1, const float* __restrict__ im0,
-                                                    float* __restrict__ out, Shape3 S, double tz, double ty, double tx,
-                                                    unsigned long long* __restrict__ count, int* __restrict__ bbox) {
-    const long long n = (long long)S.nz * S.ny * S.nx;
-    unsigned long long cnt = 0;
-    int mnz = 0x7fffffff, mny = 0x7fffffff, mnx = 0x7fffffff, mxz = -1, mxy = -1, mxx = -1;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % S.nx);
-        const long long t = i / S.nx;
-        const int y = (int)(t % S.ny);
-        const int z = (int)(t / S.ny);
-        // identity matrix rows: ((z*1 + y*0) + x*0) + t  -- same rounding as scipy's loop
-        const double cz = (double)z + tz, cy = (double)y + ty, cx = (double)x + tx;
-        float r = NAN;
-        if (!(cz < 0.0 || cz > (double)(S.nz - 1) || cy < 0.0 || cy > (double)(S.ny - 1) || cx < 0.0 || cx > (double)(S.nx - 1))) {
-            const double fz = floor(cz), fy = floor(cy), fx = floor(cx);
-            const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
-            const double wz = cz - fz, wy = cy - fy, wx = cx - fx;
-            const int iz1 = tap2(iz, S.nz), iy1 = tap2(iy, S.ny), ix1 = tap2(ix, S.nx);
-            const long long sy = S.nx, sz = (long long)S.ny * S.nx;
-            double acc = 0.0;
-            // scipy accumulates coeff * wz * wy * wx over the taps in z-major order
-            acc += (double)im1[iz * sz + iy * sy + ix] * (1.0 - wz) * (1.0 - wy) * (1.0 - wx);
-            acc += (double)im1[iz * sz + iy * sy + ix1] * (1.0 - wz) * (1.0 - wy) * wx;
-            acc += (double)im1[iz * sz + iy1 * sy + ix] * (1.0 - wz) * wy * (1.0 - wx);
-            acc += (double)im1[iz * sz + iy1 * sy + ix1] * (1.0 - wz) * wy * wx;
-            acc += (double)im1[iz1 * sz + iy * sy + ix] * wz * (1.0 - wy) * (1.0 - wx);
-            acc += (double)im1[iz1 * sz + iy * sy + ix1] * wz * (1.0 - wy) * wx;
-            acc += (double)im1[iz1 * sz + iy1 * sy + ix] * wz * wy * (1.0 - wx);
-            acc += (double)im1[iz1 * sz + iy1 * sy + ix1] * wz * wy * wx;
-            r = (float)acc;
-        }
-        out[i] = r;
-        if (r == r) {
-            mnz = min(mnz, z); mny = min(mny, y); mnx = min(mnx, x);
-            mxz = max(mxz, z); mxy = max(mxy, y); mxx = max(mxx, x);
-            const float a = im0[i];
-            if (a == a) ++cnt;
-        }
-    }
+__device__ __forceinline__ void block_reduce_voxstats(unsigned long long cnt, int mnz, int mny, int mnx, int mxz, int mxy, int mxx,
+                                                      VoxStats* __restrict__ out) {
     for (int off = 32; off > 0; off >>= 1) {
         cnt += __shfl_down(cnt, off);
         mnz = min(mnz, __shfl_down(mnz, off)); mny = min(mny, __shfl_down(mny, off)); mnx = min(mnx, __shfl_down(mnx, off));
         mxz = max(mxz, __shfl_down(mxz, off)); mxy = max(mxy, __shfl_down(mxy, off)); mxx = max(mxx, __shfl_down(mxx, off));
     }
-    // one set of atomics per workgroup (the per-wavefront version spent most of the kernel in atomic contention)
     __shared__ unsigned long long s_cnt[4];
     __shared__ int s_bb[4][6];
     const int wave = threadIdx.x >> 6;
@@ -95,70 +57,177 @@ __global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im
             mnz = min(mnz, s_bb[w][0]); mny = min(mny, s_bb[w][1]); mnx = min(mnx, s_bb[w][2]);
             mxz = max(mxz, s_bb[w][3]); mxy = max(mxy, s_bb[w][4]); mxx = max(mxx, s_bb[w][5]);
         }
-        if (cnt) atomicAdd(count, cnt);
-        if (mxz >= 0) {
-            atomicMin(&bbox[0], mnz); atomicMin(&bbox[1], mny); atomicMin(&bbox[2], mnx);
-            atomicMax(&bbox[3], mxz); atomicMax(&bbox[4], mxy); atomicMax(&bbox[5], mxx);
-        }
+        out->cnt = cnt;
+        out->bb[0] = mnz; out->bb[1] = mny; out->bb[2] = mnx; out->bb[3] = mxz; out->bb[4] = mxy; out->bb[5] = mxx;
     }
 }
 
-// bbox of the non-NaN voxels of one image (get_bb_from_nanmask, registration.py:482-489)
-__global__ __launch_bounds__(256) void bbox_kernel(const float* __restrict__ im, Shape3 S, int* __restrict__ bbox) {
-    const long long n = (long long)S.nz * S.ny * S.nx;
+// second stage: one workgroup per statistics record folds the kStatBlocks partials (no atomics anywhere: the
+// same-address atomics of a one-stage reduction cost more than the voxel work of these kernels)
+__global__ __launch_bounds__(256) void finish_voxstats_kernel(const VoxStats* __restrict__ partial, VoxStats* __restrict__ out) {
+    const VoxStats* p = partial + (size_t)blockIdx.x * kStatBlocks;
+    unsigned long long cnt = 0;
     int mnz = 0x7fffffff, mny = 0x7fffffff, mnx = 0x7fffffff, mxz = -1, mxy = -1, mxx = -1;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float v = im[i];
-        if (v == v) {
-            const int x = (int)(i % S.nx);
-            const long long t = i / S.nx;
-            const int y = (int)(t % S.ny), z = (int)(t / S.ny);
-            mnz = min(mnz, z); mny = min(mny, y); mnx = min(mnx, x);
-            mxz = max(mxz, z); mxy = max(mxy, y); mxx = max(mxx, x);
-        }
+    for (int i = threadIdx.x; i < kStatBlocks; i += 256) {
+        cnt += p[i].cnt;
+        mnz = min(mnz, p[i].bb[0]); mny = min(mny, p[i].bb[1]); mnx = min(mnx, p[i].bb[2]);
+        mxz = max(mxz, p[i].bb[3]); mxy = max(mxy, p[i].bb[4]); mxx = max(mxx, p[i].bb[5]);
     }
-    for (int off = 32; off > 0; off >>= 1) {
-        mnz = min(mnz, __shfl_down(mnz, off)); mny = min(mny, __shfl_down(mny, off)); mnx = min(mnx, __shfl_down(mnx, off));
-        mxz = max(mxz, __shfl_down(mxz, off)); mxy = max(mxy, __shfl_down(mxy, off)); mxx = max(mxx, __shfl_down(mxx, off));
-    }
-    __shared__ int s_bb[4][6];
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        s_bb[wave][0] = mnz; s_bb[wave][1] = mny; s_bb[wave][2] = mnx; s_bb[wave][3] = mxz; s_bb[wave][4] = mxy; s_bb[wave][5] = mxx;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) {
-            mnz = min(mnz, s_bb[w][0]); mny = min(mny, s_bb[w][1]); mnx = min(mnx, s_bb[w][2]);
-            mxz = max(mxz, s_bb[w][3]); mxy = max(mxy, s_bb[w][4]); mxx = max(mxx, s_bb[w][5]);
-        }
-        if (mxz >= 0) {
-            atomicMin(&bbox[0], mnz); atomicMin(&bbox[1], mny); atomicMin(&bbox[2], mnx);
-            atomicMax(&bbox[3], mxz); atomicMax(&bbox[4], mxy); atomicMax(&bbox[5], mxx);
-        }
-    }
+    block_reduce_voxstats(cnt, mnz, mny, mnx, mxz, mxy, mxx, out + blockIdx.x);
 }
 
-// Extract the region [lo, lo+R) of im0 / im1t: x = nan_to_num(im0), y = nan_to_num(im1t), products, and
-// the region's nanmax(im1t) / "has NaN" flags (for registration.py:530, 539).
-__global__ __launch_bounds__(256) void region_kernel(const float* __restrict__ im0, const float* __restrict__ im1t, Shape3 S,
-                                                     int lz, int ly, int lx, Shape3 R, float* __restrict__ X,
-                                                     float* __restrict__ Y, float* __restrict__ XX, float* __restrict__ YY,
-                                                     float* __restrict__ XY, unsigned int* __restrict__ maxbits,
-                                                     int* __restrict__ hasnan) {
-    const long long n = (long long)R.nz * R.ny * R.nx;
+// ---- shifted copy of im1 with scipy's affine_transform semantics (order 1, cval NaN) ------------
+__device__ __forceinline__ int tap2(int i0, int n) {
+    int i1 = i0 + 1;
+    if (i1 >= n) i1 = (n > 1) ? n - 2 : 0;   // mirrored edge offset, weight 0 there
+    return i1;
+}
+
+// Stats gathered while shifting: #(valid im1t & valid im0) and the bbox of valid im1t.  Each thread takes 4
+// consecutive voxels (one index decode, one 16-byte store).
+__global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im1, const float* __restrict__ im0,
+                                                    float* __restrict__ out, Shape3 S, double tz, double ty, double tx,
+                                                    VoxStats* __restrict__ partial) {
+    const unsigned int n = (unsigned int)S.nz * S.ny * S.nx;
+    const unsigned int ngroups = (n + 3) / 4;
+    unsigned long long cnt = 0;
+    int mnz = 0x7fffffff, mny = 0x7fffffff, mnx = 0x7fffffff, mxz = -1, mxy = -1, mxx = -1;
+    const int sy = S.nx, sz = S.ny * S.nx;
+    for (unsigned int g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x) {
+        const unsigned int i0 = g * 4;
+        int x = (int)(i0 % (unsigned int)S.nx);
+        const unsigned int t = i0 / (unsigned int)S.nx;
+        int y = (int)(t % (unsigned int)S.ny), z = (int)(t / (unsigned int)S.ny);
+        float r4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float r = NAN;
+            if (i0 + k < n) {
+                // identity matrix rows: ((z*1 + y*0) + x*0) + t  -- same rounding as scipy's loop
+                const double cz = (double)z + tz, cy = (double)y + ty, cx = (double)x + tx;
+                if (!(cz < 0.0 || cz > (double)(S.nz - 1) || cy < 0.0 || cy > (double)(S.ny - 1) || cx < 0.0 || cx > (double)(S.nx - 1))) {
+                    const double fz = floor(cz), fy = floor(cy), fx = floor(cx);
+                    const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
+                    const double wz = cz - fz, wy = cy - fy, wx = cx - fx;
+                    const int iz1 = tap2(iz, S.nz), iy1 = tap2(iy, S.ny), ix1 = tap2(ix, S.nx);
+                    double acc = 0.0;
+                    // scipy accumulates coeff * wz * wy * wx over the taps in z-major order
+                    acc += (double)im1[iz * sz + iy * sy + ix] * (1.0 - wz) * (1.0 - wy) * (1.0 - wx);
+                    acc += (double)im1[iz * sz + iy * sy + ix1] * (1.0 - wz) * (1.0 - wy) * wx;
+                    acc += (double)im1[iz * sz + iy1 * sy + ix] * (1.0 - wz) * wy * (1.0 - wx);
+                    acc += (double)im1[iz * sz + iy1 * sy + ix1] * (1.0 - wz) * wy * wx;
+                    acc += (double)im1[iz1 * sz + iy * sy + ix] * wz * (1.0 - wy) * (1.0 - wx);
+                    acc += (double)im1[iz1 * sz + iy * sy + ix1] * wz * (1.0 - wy) * wx;
+                    acc += (double)im1[iz1 * sz + iy1 * sy + ix] * wz * wy * (1.0 - wx);
+                    acc += (double)im1[iz1 * sz + iy1 * sy + ix1] * wz * wy * wx;
+                    r = (float)acc;
+                }
+                if (r == r) {
+                    mnz = min(mnz, z); mny = min(mny, y); mnx = min(mnx, x);
+                    mxz = max(mxz, z); mxy = max(mxy, y); mxx = max(mxx, x);
+                    const float a = im0[i0 + k];
+                    if (a == a) ++cnt;
+                }
+                if (++x == S.nx) { x = 0; if (++y == S.ny) { y = 0; ++z; } }
+            }
+            r4[k] = r;
+        }
+        if (i0 + 3 < n) *reinterpret_cast<float4*>(out + i0) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        else
+            for (int k = 0; k < 4; ++k) if (i0 + k < n) out[i0 + k] = r4[k];
+    }
+    block_reduce_voxstats(cnt, mnz, mny, mnx, mxz, mxy, mxx, partial + blockIdx.x);
+}
+
+// #valid voxels and their bbox for one image (get_bb_from_nanmask, registration.py:482-489; valid_pixels1 :400)
+__global__ __launch_bounds__(256) void image_stats_kernel(const float* __restrict__ im, Shape3 S, VoxStats* __restrict__ partial) {
+    const unsigned int n = (unsigned int)S.nz * S.ny * S.nx;
+    const unsigned int ngroups = (n + 3) / 4;
+    unsigned long long cnt = 0;
+    int mnz = 0x7fffffff, mny = 0x7fffffff, mnx = 0x7fffffff, mxz = -1, mxy = -1, mxx = -1;
+    for (unsigned int g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x) {
+        const unsigned int i0 = g * 4;
+        int x = (int)(i0 % (unsigned int)S.nx);
+        const unsigned int t = i0 / (unsigned int)S.nx;
+        int y = (int)(t % (unsigned int)S.ny), z = (int)(t / (unsigned int)S.ny);
+        for (int k = 0; k < 4 && i0 + k < n; ++k) {
+            const float v = im[i0 + k];
+            if (v == v) {
+                ++cnt;
+                mnz = min(mnz, z); mny = min(mny, y); mnx = min(mnx, x);
+                mxz = max(mxz, z); mxy = max(mxy, y); mxx = max(mxx, x);
+            }
+            if (++x == S.nx) { x = 0; if (++y == S.ny) { y = 0; ++z; } }
+        }
+    }
+    block_reduce_voxstats(cnt, mnz, mny, mnx, mxz, mxy, mxx, partial + blockIdx.x);
+}
+
+// ---- SSIM: skimage.metrics.structural_similarity on nan_to_num'd float32 crops ------------------------------
+// uniform_filter (mode="reflect", size=win) runs axis by axis with a float32 result per pass and double
+// accumulation; the five filtered quantities are x, y, x*x, y*y, x*y.  Pass 1 reads the region straight out of
+// im0 / im1t (nan_to_num + products on the fly, and the region's nanmax / has-NaN flags needed by
+// registration.py:530, 539), the last pass (x axis) feeds the SSIM formula and its interior sum directly, so
+// the only arrays that touch memory are the 5 outputs of pass 1 and, in 3D, of pass 2.
+__device__ __forceinline__ int reflect_index(int p, int len) {
+    // scipy "reflect": d c b a | a b c d | d c b a  (period 2*len)
+    if (len == 1) return 0;
+    const int period = 2 * len;
+    p %= period;
+    if (p < 0) p += period;
+    if (p >= len) p = period - 1 - p;
+    return p;
+}
+
+struct Five { const float* src[5]; float* dst[5]; };
+
+// pass 1: filter along `axis` (0 = z, 1 = y) of the region [lo, lo + R) of im0 / im1t
+template <int WIN>
+__global__ __launch_bounds__(256) void ssim_first_pass_kernel(const float* __restrict__ im0, const float* __restrict__ im1t, Shape3 S,
+                                                              int lz, int ly, int lx, Shape3 R, int axis, Five P,
+                                                              float* __restrict__ pmax, int* __restrict__ phasnan) {
+    constexpr int H = WIN / 2, NL = kChunk + 2 * H;
+    const int len = axis == 0 ? R.nz : R.ny;
+    const int nchunks = (len + kChunk - 1) / kChunk;
+    const unsigned int other = axis == 0 ? (unsigned int)R.ny : (unsigned int)R.nz;   // the non-filtered one of (z, y)
+    const unsigned int items = (unsigned int)nchunks * other * (unsigned int)R.nx;
+    const int src_stride = axis == 0 ? S.ny * S.nx : S.nx;
+    const int dst_stride = axis == 0 ? R.ny * R.nx : R.nx;
     float mx = -INFINITY;
     int hn = 0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % R.nx);
-        const long long t = i / R.nx;
-        const int y = (int)(t % R.ny), z = (int)(t / R.ny);
-        const long long src = ((long long)(z + lz) * S.ny + (y + ly)) * S.nx + (x + lx);
-        float a = im0[src], b = im1t[src];
-        if (b == b) mx = fmaxf(mx, b); else hn = 1;
-        if (a != a) a = 0.f;
-        if (b != b) b = 0.f;
-        X[i] = a; Y[i] = b; XX[i] = a * a; YY[i] = b * b; XY[i] = a * b;
+    for (unsigned int w = blockIdx.x * blockDim.x + threadIdx.x; w < items; w += gridDim.x * blockDim.x) {
+        const int x = (int)(w % (unsigned int)R.nx);
+        const unsigned int t = w / (unsigned int)R.nx;
+        int z, y, p0;
+        if (axis == 0) { y = (int)(t % other); p0 = (int)(t / other) * kChunk; z = 0; }
+        else { p0 = (int)(t % (unsigned int)nchunks) * kChunk; z = (int)(t / (unsigned int)nchunks); y = 0; }
+        const int src_base = ((z + lz) * S.ny + (y + ly)) * S.nx + (x + lx);
+        float va[NL], vb[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int p = reflect_index(p0 - H + k, len);
+            float a = im0[src_base + p * src_stride], b = im1t[src_base + p * src_stride];
+            if (k >= H && k < H + kChunk && p0 + (k - H) < len) {   // this voxel is the centre of one output
+                if (b == b) mx = fmaxf(mx, b); else hn = 1;
+            }
+            va[k] = (a != a) ? 0.f : a;
+            vb[k] = (b != b) ? 0.f : b;
+        }
+        const int dst_base = (z * R.ny + y) * R.nx + x;
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) {
+            if (p0 + k >= len) break;
+            double sa = 0.0, sb = 0.0, saa = 0.0, sbb = 0.0, sab = 0.0;
+#pragma unroll
+            for (int j = 0; j < WIN; ++j) {
+                const float a = va[k + j], b = vb[k + j];
+                sa += (double)a; sb += (double)b; saa += (double)(a * a); sbb += (double)(b * b); sab += (double)(a * b);
+            }
+            const int o = dst_base + (p0 + k) * dst_stride;
+            P.dst[0][o] = (float)(sa / (double)WIN); P.dst[1][o] = (float)(sb / (double)WIN);
+            P.dst[2][o] = (float)(saa / (double)WIN); P.dst[3][o] = (float)(sbb / (double)WIN);
+            P.dst[4][o] = (float)(sab / (double)WIN);
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         mx = fmaxf(mx, __shfl_down(mx, off));
@@ -170,71 +239,89 @@ __global__ __launch_bounds__(256) void region_kernel(const float* __restrict__ i
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w) { mx = fmaxf(mx, s_mx[w]); hn |= s_hn[w]; }
-        // order-preserving float -> uint mapping so atomicMax works for negative values too
-        unsigned int u = __float_as_uint(mx);
-        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-        atomicMax(maxbits, u);
-        if (hn) atomicOr(hasnan, 1);
+        pmax[blockIdx.x] = mx;
+        phasnan[blockIdx.x] = hn;
     }
 }
 
-// scipy.ndimage.uniform_filter1d(size=win, mode="reflect") along one axis for the five SSIM inputs at once:
-// double accumulation, float32 output
-struct Five { const float* src[5]; float* dst[5]; };
-__global__ __launch_bounds__(256) void box1d_kernel(Five P, Shape3 R, int axis, int win) {
-    const long long n = (long long)R.nz * R.ny * R.nx;
-    const int dims[3] = {R.nz, R.ny, R.nx};
-    const long long strides[3] = {(long long)R.ny * R.nx, R.nx, 1};
-    const int len = dims[axis];
-    const long long st = strides[axis];
-    const int h = win / 2;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % R.nx);
-        const long long t = i / R.nx;
-        const int y = (int)(t % R.ny), z = (int)(t / R.ny);
-        const int pos = (axis == 0) ? z : (axis == 1) ? y : x;
-        const long long base = i - (long long)pos * st;
-        double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        for (int k = -h; k <= h; ++k) {
-            int p = pos + k;
-            // reflect: d c b a | a b c d | d c b a  (period 2*len)
-            if (len == 1) p = 0;
-            else {
-                const int period = 2 * len;
-                p %= period;
-                if (p < 0) p += period;
-                if (p >= len) p = period - 1 - p;
-            }
-            const long long o = base + (long long)p * st;
+// middle pass (3D only): the five arrays filtered along y
+template <int WIN>
+__global__ __launch_bounds__(256) void ssim_mid_pass_kernel(Five P, Shape3 R) {
+    constexpr int H = WIN / 2, NL = kChunk + 2 * H;
+    const int len = R.ny;
+    const int nchunks = (len + kChunk - 1) / kChunk;
+    const unsigned int items = (unsigned int)nchunks * (unsigned int)R.nz * (unsigned int)R.nx;
+    for (unsigned int w = blockIdx.x * blockDim.x + threadIdx.x; w < items; w += gridDim.x * blockDim.x) {
+        const int x = (int)(w % (unsigned int)R.nx);
+        const unsigned int t = w / (unsigned int)R.nx;
+        const int p0 = (int)(t % (unsigned int)nchunks) * kChunk, z = (int)(t / (unsigned int)nchunks);
+        const int base = z * R.ny * R.nx + x;
+        int off[NL];
 #pragma unroll
-            for (int a = 0; a < 5; ++a) acc[a] += (double)P.src[a][o];
+        for (int k = 0; k < NL; ++k) off[k] = base + reflect_index(p0 - H + k, len) * R.nx;
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            float v[NL];
+#pragma unroll
+            for (int k = 0; k < NL; ++k) v[k] = P.src[a][off[k]];
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k) {
+                if (p0 + k >= len) break;
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < WIN; ++j) s += (double)v[k + j];
+                P.dst[a][base + (p0 + k) * R.nx] = (float)(s / (double)WIN);
+            }
+        }
+    }
+}
+
+// last pass (x axis) + SSIM map + sum over the cropped interior (float32 map, float64 mean like skimage)
+template <int WIN>
+__global__ __launch_bounds__(256) void ssim_last_pass_kernel(Five P, Shape3 R, int ndim, float cov_norm, float C1, float C2,
+                                                             double* __restrict__ partial) {
+    constexpr int H = WIN / 2, NL = kChunk + 2 * H, pad = (WIN - 1) / 2;
+    const int len = R.nx;
+    const int nchunks = (len + kChunk - 1) / kChunk;
+    const unsigned int rows = (unsigned int)R.nz * (unsigned int)R.ny;
+    const unsigned int items = (unsigned int)nchunks * rows;
+    double acc = 0.0;
+    for (unsigned int w = blockIdx.x * blockDim.x + threadIdx.x; w < items; w += gridDim.x * blockDim.x) {
+        const int p0 = (int)(w % (unsigned int)nchunks) * kChunk;
+        const unsigned int r = w / (unsigned int)nchunks;
+        const int y = (int)(r % (unsigned int)R.ny), z = (int)(r / (unsigned int)R.ny);
+        const bool row_in = (y >= pad && y < R.ny - pad) && (ndim == 2 || (z >= pad && z < R.nz - pad));
+        if (!row_in) continue;
+        const int base = (int)r * R.nx;
+        int off[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) off[k] = base + reflect_index(p0 - H + k, len);
+        float f[5][kChunk];
+#pragma unroll
+        for (int a = 0; a < 5; ++a) {
+            float v[NL];
+#pragma unroll
+            for (int k = 0; k < NL; ++k) v[k] = P.src[a][off[k]];
+#pragma unroll
+            for (int k = 0; k < kChunk; ++k) {
+                double s = 0.0;
+#pragma unroll
+                for (int j = 0; j < WIN; ++j) s += (double)v[k + j];
+                f[a][k] = (float)(s / (double)WIN);
+            }
         }
 #pragma unroll
-        for (int a = 0; a < 5; ++a) P.dst[a][i] = (float)(acc[a] / (double)win);
-    }
-}
-
-// SSIM map and the sum over the cropped interior (skimage structural_similarity, float32 map, float64 mean)
-__global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ ux, const float* __restrict__ uy,
-                                                   const float* __restrict__ uxx, const float* __restrict__ uyy,
-                                                   const float* __restrict__ uxy, Shape3 R, int pad, int ndim, float cov_norm,
-                                                   float C1, float C2, double* __restrict__ partial) {
-    const long long n = (long long)R.nz * R.ny * R.nx;
-    double acc = 0.0;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int x = (int)(i % R.nx);
-        const long long t = i / R.nx;
-        const int y = (int)(t % R.ny), z = (int)(t / R.ny);
-        const bool in = (x >= pad && x < R.nx - pad) && (y >= pad && y < R.ny - pad) && (ndim == 2 || (z >= pad && z < R.nz - pad));
-        if (!in) continue;
-        const float a = ux[i], b = uy[i];
-        const float vx = cov_norm * (uxx[i] - a * a);
-        const float vy = cov_norm * (uyy[i] - b * b);
-        const float vxy = cov_norm * (uxy[i] - a * b);
-        const float A1 = 2.f * a * b + C1, A2 = 2.f * vxy + C2;
-        const float B1 = a * a + b * b + C1, B2 = vx + vy + C2;
-        const float Sv = (A1 * A2) / (B1 * B2);
-        acc += (double)Sv;
+        for (int k = 0; k < kChunk; ++k) {
+            const int x = p0 + k;
+            if (x < pad || x >= R.nx - pad) continue;
+            const float a = f[0][k], b = f[1][k];
+            const float vx = cov_norm * (f[2][k] - a * a);
+            const float vy = cov_norm * (f[3][k] - b * b);
+            const float vxy = cov_norm * (f[4][k] - a * b);
+            const float A1 = 2.f * a * b + C1, A2 = 2.f * vxy + C2;
+            const float B1 = a * a + b * b + C1, B2 = vx + vy + C2;
+            acc += (double)((A1 * A2) / (B1 * B2));
+        }
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     __shared__ double s[4];
@@ -243,9 +330,31 @@ __global__ __launch_bounds__(256) void ssim_kernel(const float* __restrict__ ux,
     if (threadIdx.x == 0) partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-// compaction of the jointly valid voxels: kx = im0[mask], ky = im1t[mask] - 1 (float32, like the reference).
-// Each thread takes 8 consecutive voxels; a workgroup reserves its output range with ONE atomic (the order of
-// the compacted pairs is irrelevant to a rank correlation).
+// folds the per-workgroup partials of one candidate's SSIM passes
+__global__ __launch_bounds__(256) void finish_region_kernel(const float* __restrict__ pmax, const int* __restrict__ phasnan,
+                                                            const double* __restrict__ psum, RegionStats* __restrict__ out) {
+    const size_t o = (size_t)blockIdx.x * kStatBlocks;
+    float mx = -INFINITY;
+    int hn = 0;
+    double sum = 0.0;
+    for (int i = threadIdx.x; i < kStatBlocks; i += 256) { mx = fmaxf(mx, pmax[o + i]); hn |= phasnan[o + i]; sum += psum[o + i]; }
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmaxf(mx, __shfl_down(mx, off)); hn |= __shfl_down(hn, off); sum += __shfl_down(sum, off);
+    }
+    __shared__ float s_mx[4];
+    __shared__ int s_hn[4];
+    __shared__ double s_sum[4];
+    if ((threadIdx.x & 63) == 0) { s_mx[threadIdx.x >> 6] = mx; s_hn[threadIdx.x >> 6] = hn; s_sum[threadIdx.x >> 6] = sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { mx = fmaxf(mx, s_mx[w]); hn |= s_hn[w]; sum += s_sum[w]; }
+        out[blockIdx.x].mx = mx; out[blockIdx.x].hasnan = hn; out[blockIdx.x].ssim_sum = sum;
+    }
+}
+
+// ---- Spearman: compaction of the jointly valid voxels, two chained radix sorts, rank correlation ------------
+// kx = im0[mask], ky = im1t[mask] - 1 (float32, like the reference).  Each thread takes 8 consecutive voxels; a
+// workgroup reserves its output range with ONE atomic (the order of the pairs is irrelevant to a rank correlation).
 __global__ __launch_bounds__(256) void compact_kernel(const float* __restrict__ im0, const float* __restrict__ im1t, long long n,
                                                       float* __restrict__ kx, float* __restrict__ ky,
                                                       unsigned int* __restrict__ counter) {
@@ -289,50 +398,43 @@ __global__ __launch_bounds__(256) void compact_kernel(const float* __restrict__ 
     }
 }
 
-__global__ void iota_kernel(unsigned int* __restrict__ v, unsigned int n) {
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) v[i] = i;
-}
-
-// average ranks (scipy.stats.rankdata method="average") from sorted keys: rank = (lo + hi + 1) / 2 where
-// [lo, hi) is the run of equal keys around sorted position i; scattered back to the original order
-__global__ __launch_bounds__(256) void ranks_kernel(const float* __restrict__ sorted, const unsigned int* __restrict__ idx,
-                                                    unsigned int n, float* __restrict__ rank_out) {
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const float k = sorted[i];
-        const bool tie_l = (i > 0) && (sorted[i - 1] == k), tie_r = (i + 1 < n) && (sorted[i + 1] == k);
-        if (!tie_l && !tie_r) {               // no tie (the common case for float images): rank = position + 1
-            rank_out[idx[i]] = (float)((double)i + 1.0);
-            continue;
-        }
-        // galloping search outwards from i: runs of equal keys are short compared with n, and the probes
-        // stay in the cache lines around i instead of bouncing over the whole array
-        unsigned int first = i, last = i + 1, lo, hi;
-        if (tie_l) {
-            unsigned int pos = i, step = 1;
-            while (pos >= step && sorted[pos - step] == k) { pos -= step; step <<= 1; }
-            lo = pos >= step ? pos - step + 1 : 0; hi = pos;          // first index with key == k in [lo, hi]
-            while (lo < hi) { const unsigned int m = (lo + hi) >> 1; if (sorted[m] < k) lo = m + 1; else hi = m; }
-            first = lo;
-        }
-        if (tie_r) {
-            unsigned int pos = i, step = 1;
-            while (pos + step < n && sorted[pos + step] == k) { pos += step; step <<= 1; }
-            lo = pos + 1; hi = min(pos + step, n);                    // first index with key > k in [lo, hi]
-            while (lo < hi) { const unsigned int m = (lo + hi) >> 1; if (sorted[m] <= k) lo = m + 1; else hi = m; }
-            last = lo;
-        }
-        // ranks up to 2^32: keep them exact by storing (first + last + 1) / 2 as float pairs would lose bits,
-        // so store as float the doubled rank split: exact for n < 2^24, else rounded (documented)
-        rank_out[idx[i]] = (float)(0.5 * ((double)first + (double)last + 1.0));
+// average rank (scipy.stats.rankdata method="average") of sorted position i: (first + last + 1) / 2 where
+// [first, last) is the run of equal keys around i.  Galloping search outwards from i: runs are short compared
+// with n and the probes stay in the cache lines around i.
+__device__ __forceinline__ double average_rank(const float* __restrict__ sorted, unsigned int i, unsigned int n) {
+    const float k = sorted[i];
+    unsigned int first = i, last = i + 1, lo, hi;
+    if (i > 0 && sorted[i - 1] == k) {
+        unsigned int pos = i, step = 1;
+        while (pos >= step && sorted[pos - step] == k) { pos -= step; step <<= 1; }
+        lo = pos >= step ? pos - step + 1 : 0; hi = pos;          // first index with key == k in [lo, hi]
+        while (lo < hi) { const unsigned int m = (lo + hi) >> 1; if (sorted[m] < k) lo = m + 1; else hi = m; }
+        first = lo;
     }
+    if (i + 1 < n && sorted[i + 1] == k) {
+        unsigned int pos = i, step = 1;
+        while (pos + step < n && sorted[pos + step] == k) { pos += step; step <<= 1; }
+        lo = pos + 1; hi = min(pos + step, n);                    // first index with key > k in [lo, hi]
+        while (lo < hi) { const unsigned int m = (lo + hi) >> 1; if (sorted[m] <= k) lo = m + 1; else hi = m; }
+        last = lo;
+    }
+    return 0.5 * ((double)first + (double)last + 1.0);
 }
 
-// sums for the Pearson correlation of the two rank vectors (both have mean (n+1)/2)
-__global__ __launch_bounds__(256) void rankcorr_kernel(const float* __restrict__ rx, const float* __restrict__ ry, unsigned int n,
+// ranks of the x keys in x-sorted order (they then ride along the second sort as its payload, so nothing is
+// ever scattered back to voxel order).  Stored as float like scipy's float64 ranks rounded: exact for n < 2^24.
+__global__ __launch_bounds__(256) void ranks_sorted_kernel(const float* __restrict__ sorted, unsigned int n, float* __restrict__ rank_out) {
+    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+        rank_out[i] = (float)average_rank(sorted, i, n);
+}
+
+// in y-sorted order: rank of y computed on the fly, rank of x from the payload; sums for the Pearson
+// correlation of the two rank vectors (both have mean (n+1)/2)
+__global__ __launch_bounds__(256) void rankcorr_kernel(const float* __restrict__ ysorted, const float* __restrict__ rx, unsigned int n,
                                                        double mean, double* __restrict__ partial) {
     double sxy = 0.0, sxx = 0.0, syy = 0.0;
     for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const double a = (double)rx[i] - mean, b = (double)ry[i] - mean;
+        const double a = (double)rx[i] - mean, b = (double)(float)average_rank(ysorted, i, n) - mean;
         sxy += a * b; sxx += a * a; syy += b * b;
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -356,14 +458,23 @@ struct DeviceBump {   // bump allocator over one scratch slot
     }
 };
 
-int rank_vector(MvsContext* c, float* keys, unsigned int n, float* keys_sorted, unsigned int* idx_in, unsigned int* idx_out,
-                void* temp, size_t temp_bytes, float* ranks) {
-    const int gb = grid_for(n);
-    hipLaunchKernelGGL(iota_kernel, dim3(gb), dim3(256), 0, c->stream, idx_in, n);
-    MVS_HIP_TRY(c, rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_sorted, idx_in, idx_out, (size_t)n, 0, 32, c->stream));
-    hipLaunchKernelGGL(ranks_kernel, dim3(gb), dim3(256), 0, c->stream, keys_sorted, idx_out, n, ranks);
-    MVS_HIP_TRY(c, hipGetLastError());
-    return MVS_OK;
+template <int WIN>
+void launch_ssim_passes(hipStream_t stream, const float* im0, const float* im1t, Shape3 S, const int lo[3], Shape3 R, int ndim,
+                        float* const setA[5], float* const setB[5], float cov_norm, float C1, float C2, float* pmax, int* phasnan,
+                        double* psum) {
+    Five P1, P2, P3;
+    for (int a = 0; a < 5; ++a) { P1.src[a] = nullptr; P1.dst[a] = setA[a]; }
+    hipLaunchKernelGGL(ssim_first_pass_kernel<WIN>, dim3(kStatBlocks), dim3(256), 0, stream, im0, im1t, S, lo[0], lo[1], lo[2], R,
+                       ndim == 3 ? 0 : 1, P1, pmax, phasnan);
+    float* const* last_src = setA;
+    if (ndim == 3) {
+        for (int a = 0; a < 5; ++a) { P2.src[a] = setA[a]; P2.dst[a] = setB[a]; }
+        const long long items = (long long)((R.ny + kChunk - 1) / kChunk) * R.nz * R.nx;
+        hipLaunchKernelGGL(ssim_mid_pass_kernel<WIN>, dim3(grid_for(items)), dim3(256), 0, stream, P2, R);
+        last_src = setB;
+    }
+    for (int a = 0; a < 5; ++a) { P3.src[a] = last_src[a]; P3.dst[a] = nullptr; }
+    hipLaunchKernelGGL(ssim_last_pass_kernel<WIN>, dim3(kStatBlocks), dim3(256), 0, stream, P3, R, ndim, cov_norm, C1, C2, psum);
 }
 
 }  // namespace
@@ -383,7 +494,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     MVS_HIP_TRY(c, hipSetDevice(device));
     const Shape3 S = {(int)shape[0], (int)shape[1], (int)shape[2]};
     const long long n = (long long)S.nz * S.ny * S.nx;
-    if (n >= (1ll << 31)) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_score_candidates: volume too large");
+    if (n >= (1ll << 31) - 8) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_score_candidates: volume too large");
     const int k0 = 3 - ndim;
 
     float *im0, *im1;
@@ -392,59 +503,88 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     rc = mvs_stage_float_volume(c, moving, mem, n, 5, &im1);
     if (rc) return rc;
 
+    // Candidates that survive the analytic pre-test are evaluated in batches: all their shifted copies of the
+    // moving image stay resident (one host round trip for the masks / boxes of the whole batch, a second one
+    // for the SSIM sums), and the winner's copy is still there for the rank correlation.
+    const int nres = (int)std::max<long long>(1, std::min<long long>(std::min(kMaxResident, std::max(n_candidates, 1)),
+                                                                     (4ll << 30) / (n * 4)));
     size_t sort_temp_bytes = 0;
-    MVS_HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, sort_temp_bytes, (float*)nullptr, (float*)nullptr, (unsigned int*)nullptr,
-                                            (unsigned int*)nullptr, (size_t)n, 0, 32, c->stream));
+    MVS_HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, sort_temp_bytes, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                                            (float*)nullptr, (size_t)n, 0, 32, c->stream));
     const int gb = grid_for(n);
-    const size_t need = (size_t)n * 4 * 14 + sort_temp_bytes + (size_t)gb * 64 + 64 * 1024;
+    const size_t stat_bytes = (size_t)(kMaxResident + 2) * kStatBlocks * (sizeof(VoxStats) + 4 + 4 + 8) + (kMaxResident + 2) * 64;
+    const size_t need = (size_t)n * 4 * (10 + nres) + 256 * (12 + nres) + sort_temp_bytes + (size_t)gb * 32 + stat_bytes + 64 * 1024;
     char* base = (char*)mvs_scratch(c, 6, need);
     if (!base) return MVS_ERR_HIP;
     DeviceBump B{base, need, 0};
-    float* im1t = B.take<float>(n);
-    float* X = B.take<float>(n);  float* Y = B.take<float>(n);
-    float* XX = B.take<float>(n); float* YY = B.take<float>(n); float* XY = B.take<float>(n);
-    float* T0 = B.take<float>(n); float* T1 = B.take<float>(n);   // filter ping-pong; reused as sort outputs
-    float* UX = B.take<float>(n); float* UY = B.take<float>(n);
-    float* UXX = B.take<float>(n); float* UYY = B.take<float>(n); float* UXY = B.take<float>(n);
-    unsigned int* IDX = (unsigned int*)B.take<float>(n);
+    std::vector<float*> im1t_buf(nres);
+    for (int i = 0; i < nres; ++i) im1t_buf[i] = B.take<float>(n);
+    float* setA[5]; float* setB[5];
+    for (int a = 0; a < 5; ++a) setA[a] = B.take<float>(n);
+    for (int a = 0; a < 5; ++a) setB[a] = B.take<float>(n);
     void* sort_temp = B.take<char>(sort_temp_bytes);
     double* partial = B.take<double>((size_t)gb * 4);
-    char* small = B.take<char>(4096);
-    if (!small) return mvs_fail(c, MVS_ERR_HIP, "mvs_score_candidates: scratch layout");
-    unsigned long long* d_count = (unsigned long long*)small;
-    int* d_bbox = (int*)(small + 64);
-    int* d_bbox0 = (int*)(small + 128);
-    unsigned int* d_maxbits = (unsigned int*)(small + 192);
-    int* d_hasnan = (int*)(small + 196);
-    unsigned int* d_counter = (unsigned int*)(small + 200);
+    VoxStats* vox_partial = B.take<VoxStats>((size_t)(kMaxResident + 2) * kStatBlocks);
+    VoxStats* vox_out = B.take<VoxStats>(kMaxResident + 2);
+    float* pmax = B.take<float>((size_t)kMaxResident * kStatBlocks);
+    int* phasnan = B.take<int>((size_t)kMaxResident * kStatBlocks);
+    double* psum = B.take<double>((size_t)kMaxResident * kStatBlocks);
+    RegionStats* reg_out = B.take<RegionStats>(kMaxResident);
+    unsigned int* d_counter = B.take<unsigned int>(64);
+    if (!d_counter) return mvs_fail(c, MVS_ERR_HIP, "mvs_score_candidates: scratch layout");
 
-    // valid voxels of im1 and bbox of im0 (registration.py:400, 491)
-    const int bb_init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, -1, -1, -1};
-    MVS_HIP_TRY(c, hipMemcpyAsync(d_bbox0, bb_init, sizeof(bb_init), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(bbox_kernel, dim3(std::min(gb, 512)), dim3(256), 0, c->stream, im0, S, d_bbox0);
-    MVS_HIP_TRY(c, hipMemcpyAsync(d_bbox, bb_init, sizeof(bb_init), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(bbox_kernel, dim3(std::min(gb, 512)), dim3(256), 0, c->stream, im1, S, d_bbox);
-    int bb0[6], bbm[6];
-    MVS_HIP_TRY(c, hipMemcpyAsync(bb0, d_bbox0, sizeof(bb0), hipMemcpyDeviceToHost, c->stream));
-    MVS_HIP_TRY(c, hipMemcpyAsync(bbm, d_bbox, sizeof(bbm), hipMemcpyDeviceToHost, c->stream));
-    float mn1, mx1;
-    long long nv1 = 0;
-    rc = mvs_device_nanminmax(c, im1, n, &mn1, &mx1, &nv1);   // synchronises the stream
-    if (rc) return rc;
-    const unsigned int valid1 = (unsigned int)nv1;
+    // valid voxels of im1 and the bboxes of both images (registration.py:400, 491)
+    hipLaunchKernelGGL(image_stats_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im0, S, vox_partial);
+    hipLaunchKernelGGL(image_stats_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im1, S, vox_partial + kStatBlocks);
+    hipLaunchKernelGGL(finish_voxstats_kernel, dim3(2), dim3(256), 0, c->stream, vox_partial, vox_out);
+    VoxStats h_im[2];
+    MVS_HIP_TRY(c, hipMemcpyAsync(h_im, vox_out, sizeof(h_im), hipMemcpyDeviceToHost, c->stream));
+    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int* bb0 = h_im[0].bb;
+    const int* bbm = h_im[1].bb;
+    const unsigned int valid1 = (unsigned int)h_im[1].cnt;
 
-    // ---- Spearman over the jointly valid voxels of the candidate whose shifted image is in im1t ----
+    MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+    // analytic pre-test: upper bound of the mask count from the valid bounding boxes -- im1t can only be valid
+    // where x + t lies in im1's valid box.  If even the bound fails the 10 % test the candidate is rejected
+    // exactly as the reference rejects it (registration.py:503-505) without touching the volume.
+    std::vector<int> todo;
+    for (int ic = 0; ic < n_candidates; ++ic) {
+        double t[3] = {0.0, 0.0, 0.0};
+        for (int k = 0; k < ndim; ++k) t[k0 + k] = t_candidates[ic * ndim + k];
+        ssim_out[ic] = -1.0;
+        spearman_out[ic] = -1.0;
+        code_out[ic] = 0;
+        double bound = 1.0;
+        const int dimv[3] = {S.nz, S.ny, S.nx};
+        for (int k = 0; k < 3; ++k) {
+            const double lo1 = std::ceil((double)bbm[k] - t[k] - 1.0), hi1 = std::floor((double)bbm[3 + k] - t[k] + 1.0);
+            const double lo = std::max(std::max(lo1, (double)bb0[k]), 0.0);
+            const double hi = std::min(std::min(hi1, (double)bb0[3 + k]), (double)(dimv[k] - 1));
+            bound *= std::max(hi - lo + 1.0, 0.0);
+        }
+        if (valid1 == 0 || bound == 0.0 || bound / (double)valid1 < 0.1) code_out[ic] = 1;
+        else todo.push_back(ic);
+    }
+
     std::vector<unsigned long long> cnts((size_t)std::max(n_candidates, 1), 0ull);
-    auto spearman_of_current = [&](int ic) -> int {
+    std::vector<int> resident((size_t)std::max(n_candidates, 1), -1);   // buffer holding the candidate's im1t, if still there
+    const float Rf = (float)data_range;
+    // (K1 * R) ** 2 with R a float32 scalar: numpy keeps this in float32
+    const float C1 = (0.01f * Rf) * (0.01f * Rf);
+    const float C2 = (0.03f * Rf) * (0.03f * Rf);
+
+    // Spearman over the jointly valid voxels of candidate ic, whose shifted image is `im1t`: compaction, sort by x
+    // carrying y, ranks of x in sorted order, sort by y carrying rank(x), correlation sums in y-sorted order
+    auto spearman_from = [&](int ic, const float* im1t) -> int {
         MVS_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 4, c->stream));
-        hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, c->stream, im0, im1t, n, X, Y, d_counter);
+        hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, c->stream, im0, im1t, n, setA[0], setA[1], d_counter);
         const unsigned int m = (unsigned int)cnts[ic];
-        int r = rank_vector(c, X, m, XX, IDX, (unsigned int*)UXY, sort_temp, sort_temp_bytes, UX);
-        if (r) return r;
-        r = rank_vector(c, Y, m, YY, IDX, (unsigned int*)UXY, sort_temp, sort_temp_bytes, UY);
-        if (r) return r;
+        MVS_HIP_TRY(c, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, setA[0], setA[2], setA[1], setA[3], (size_t)m, 0, 32, c->stream));
+        hipLaunchKernelGGL(ranks_sorted_kernel, dim3(grid_for(m)), dim3(256), 0, c->stream, setA[2], m, setA[4]);
+        MVS_HIP_TRY(c, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, setA[3], setB[0], setA[4], setB[1], (size_t)m, 0, 32, c->stream));
         const int mgb = grid_for(m);
-        hipLaunchKernelGGL(rankcorr_kernel, dim3(mgb), dim3(256), 0, c->stream, UX, UY, m, 0.5 * ((double)m + 1.0), partial);
+        hipLaunchKernelGGL(rankcorr_kernel, dim3(mgb), dim3(256), 0, c->stream, setB[0], setB[1], m, 0.5 * ((double)m + 1.0), partial);
         std::vector<double> hp((size_t)mgb * 3);
         MVS_HIP_TRY(c, hipMemcpyAsync(hp.data(), partial, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, c->stream));
         MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -454,115 +594,108 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         return MVS_OK;
     };
 
-    MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
-    for (int ic = 0; ic < n_candidates; ++ic) {
-        double t[3] = {0.0, 0.0, 0.0};
-        for (int k = 0; k < ndim; ++k) t[k0 + k] = t_candidates[ic * ndim + k];
-        ssim_out[ic] = -1.0;
-        spearman_out[ic] = -1.0;
-        code_out[ic] = 0;
+    for (size_t b0 = 0; b0 < todo.size(); b0 += (size_t)nres) {
+        const int nb = (int)std::min<size_t>((size_t)nres, todo.size() - b0);
+        std::fill(resident.begin(), resident.end(), -1);
+        // ---- phase A: shifted copies + mask counts / bboxes of the whole batch ----
+        for (int j = 0; j < nb; ++j) {
+            const int ic = todo[b0 + j];
+            double t[3] = {0.0, 0.0, 0.0};
+            for (int k = 0; k < ndim; ++k) t[k0 + k] = t_candidates[ic * ndim + k];
+            hipLaunchKernelGGL(shift_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im1, im0, im1t_buf[j], S, t[0], t[1], t[2],
+                               vox_partial + (size_t)j * kStatBlocks);
+            resident[ic] = j;
+        }
+        hipLaunchKernelGGL(finish_voxstats_kernel, dim3(nb), dim3(256), 0, c->stream, vox_partial, vox_out);
+        VoxStats h_vs[kMaxResident];
+        MVS_HIP_TRY(c, hipMemcpyAsync(h_vs, vox_out, sizeof(VoxStats) * nb, hipMemcpyDeviceToHost, c->stream));
+        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
 
-        // Upper bound of the mask count from the valid bounding boxes: im1t can only be valid where x + t lies in
-        // im1's valid box.  If even the bound fails the 10 % test the candidate is rejected exactly as the
-        // reference rejects it (registration.py:503-505) without touching the volume.
-        {
-            double bound = 1.0;
-            const int dimv[3] = {S.nz, S.ny, S.nx};
-            for (int k = 0; k < 3; ++k) {
-                const double lo1 = std::ceil((double)bbm[k] - t[k] - 1.0), hi1 = std::floor((double)bbm[3 + k] - t[k] + 1.0);
-                const double lo = std::max(std::max(lo1, (double)bb0[k]), 0.0);
-                const double hi = std::min(std::min(hi1, (double)bb0[3 + k]), (double)(dimv[k] - 1));
-                bound *= std::max(hi - lo + 1.0, 0.0);
-            }
-            if (valid1 == 0 || bound == 0.0 || bound / (double)valid1 < 0.1) {
+        // ---- phase B: SSIM passes of every candidate that keeps enough jointly valid voxels ----
+        Shape3 Rs[kMaxResident];
+        int wins[kMaxResident];
+        bool scored[kMaxResident];
+        for (int j = 0; j < nb; ++j) {
+            const int ic = todo[b0 + j];
+            const unsigned long long cnt = h_vs[j].cnt;
+            const int* bb1 = h_vs[j].bb;
+            scored[j] = false;
+            wins[j] = 0;
+            Rs[j] = {0, 0, 0};
+            cnts[ic] = cnt;
+            if (cnt == 0 || (double)cnt / (double)valid1 < 0.1) {   // registration.py:503-505
                 code_out[ic] = 1;
                 continue;
             }
-        }
-        MVS_HIP_TRY(c, hipMemsetAsync(d_count, 0, 8, c->stream));
-        MVS_HIP_TRY(c, hipMemcpyAsync(d_bbox, bb_init, sizeof(bb_init), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(shift_kernel, dim3(std::min(gb, 1024)), dim3(256), 0, c->stream, im1, im0, im1t, S, t[0], t[1], t[2], d_count, d_bbox);
-        unsigned long long cnt = 0;
-        int bb1[6];
-        MVS_HIP_TRY(c, hipMemcpyAsync(&cnt, d_count, 8, hipMemcpyDeviceToHost, c->stream));
-        MVS_HIP_TRY(c, hipMemcpyAsync(bb1, d_bbox, sizeof(bb1), hipMemcpyDeviceToHost, c->stream));
-        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (cnt == 0 || (double)cnt / (double)valid1 < 0.1) {   // registration.py:503-505
-            code_out[ic] = 1;
-            continue;
-        }
-        // region slices (registration.py:509-528)
-        int lo[3], hi[3];
-        for (int k = 0; k < 3; ++k) {
-            if (region_mode == 0) { lo[k] = std::min(bb0[k], bb1[k]); hi[k] = std::max(bb0[3 + k], bb1[3 + k]) + 1; }
-            else { lo[k] = std::max(bb0[k], bb1[k]); hi[k] = std::min(bb0[3 + k], bb1[3 + k]) + 1; }
-        }
-        Shape3 R = {std::max(hi[0] - lo[0], 0), std::max(hi[1] - lo[1], 0), std::max(hi[2] - lo[2], 0)};
-        const long long rn = (long long)R.nz * R.ny * R.nx;
-        float region_nanmax = NAN;
-        int region_hasnan = 0;
-        if (rn > 0) {
-            MVS_HIP_TRY(c, hipMemsetAsync(d_maxbits, 0, 8, c->stream));   // maxbits + hasnan
-            hipLaunchKernelGGL(region_kernel, dim3(grid_for(rn)), dim3(256), 0, c->stream, im0, im1t, S, lo[0], lo[1], lo[2], R,
-                               X, Y, XX, YY, XY, d_maxbits, d_hasnan);
-            unsigned int mb[2];
-            MVS_HIP_TRY(c, hipMemcpyAsync(mb, d_maxbits, 8, hipMemcpyDeviceToHost, c->stream));
-            MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-            region_hasnan = (int)mb[1];
-            if (mb[0] != 0) {
-                unsigned int u = (mb[0] & 0x80000000u) ? (mb[0] & 0x7fffffffu) : ~mb[0];
-                memcpy(&region_nanmax, &u, 4);
-                if (region_nanmax == -INFINITY) region_nanmax = NAN;   // all-NaN region
+            // region slices (registration.py:509-528)
+            int lo[3], hi[3];
+            for (int k = 0; k < 3; ++k) {
+                if (region_mode == 0) { lo[k] = std::min(bb0[k], bb1[k]); hi[k] = std::max(bb0[3 + k], bb1[3 + k]) + 1; }
+                else { lo[k] = std::max(bb0[k], bb1[k]); hi[k] = std::min(bb0[3 + k], bb1[3 + k]) + 1; }
             }
-        }
-        // `if np.nanmax(im1t[mask_slices]) <= im1_min: continue` (Q3: nothing is appended)
-        if (region_nanmax <= (float)im1_min) {
-            code_out[ic] = 2;
-            continue;
-        }
-        // ---- SSIM ----
-        int min_shape = 0x7fffffff;
-        for (int k = k0; k < 3; ++k) min_shape = std::min(min_shape, (&R.nz)[k]);
-        int win = std::min(7, min_shape - ((min_shape - 1) % 2));
-        const float region_max = region_hasnan ? NAN : region_nanmax;   // np.max propagates NaN
-        if (win < 3 || region_max <= (float)im1_min) {
-            ssim_out[ic] = -1.0;
-        } else {
-            // ping-pong between the input set {X,Y,XX,YY,XY} and the output set {UX,..}: 2 or 3 passes
-            float* setA[5] = {X, Y, XX, YY, XY};
-            float* setB[5] = {UX, UY, UXX, UYY, UXY};
-            const int rgb = grid_for(rn);
-            float** cur = setA;
-            float** nxt = setB;
-            for (int axis = k0; axis < 3; ++axis) {
-                Five P5;
-                for (int a = 0; a < 5; ++a) { P5.src[a] = cur[a]; P5.dst[a] = nxt[a]; }
-                hipLaunchKernelGGL(box1d_kernel, dim3(rgb), dim3(256), 0, c->stream, P5, R, axis, win);
-                float** tmp = cur; cur = nxt; nxt = tmp;
-            }
-            float** fin = cur;   // holds the filtered arrays
+            const Shape3 R = {std::max(hi[0] - lo[0], 0), std::max(hi[1] - lo[1], 0), std::max(hi[2] - lo[2], 0)};
+            Rs[j] = R;
+            const long long rn = (long long)R.nz * R.ny * R.nx;
+            if (rn <= 0) continue;
+            int min_shape = 0x7fffffff;
+            for (int k = k0; k < 3; ++k) min_shape = std::min(min_shape, (&R.nz)[k]);
+            int win = std::min(7, min_shape - ((min_shape - 1) % 2));
+            if (win < 3) win = 3;   // SSIM is -1 then (decided below); the pass still yields the region statistics
+            wins[j] = win;
             double NP = 1.0;
             for (int k = 0; k < ndim; ++k) NP *= (double)win;
             const float cov_norm = (float)(NP / (NP - 1.0));
-            // (K1 * R) ** 2 with R a float32 scalar: numpy keeps this in float32
-            const float Rf = (float)data_range;
-            const float C1 = (0.01f * Rf) * (0.01f * Rf);
-            const float C2 = (0.03f * Rf) * (0.03f * Rf);
-            const int pad = (win - 1) / 2;
-            hipLaunchKernelGGL(ssim_kernel, dim3(rgb), dim3(256), 0, c->stream, fin[0], fin[1], fin[2], fin[3], fin[4], R, pad, ndim, cov_norm, C1, C2, partial);
-            std::vector<double> hp(rgb);
-            MVS_HIP_TRY(c, hipMemcpyAsync(hp.data(), partial, sizeof(double) * rgb, hipMemcpyDeviceToHost, c->stream));
-            MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-            double sum = 0.0;
-            for (double v : hp) sum += v;
-            double cropn = 1.0;
-            for (int k = k0; k < 3; ++k) cropn *= (double)((&R.nz)[k] - 2 * pad);
-            ssim_out[ic] = sum / cropn;
+            float* pm = pmax + (size_t)j * kStatBlocks;
+            int* ph = phasnan + (size_t)j * kStatBlocks;
+            double* ps = psum + (size_t)j * kStatBlocks;
+            if (win == 7) launch_ssim_passes<7>(c->stream, im0, im1t_buf[j], S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps);
+            else if (win == 5) launch_ssim_passes<5>(c->stream, im0, im1t_buf[j], S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps);
+            else launch_ssim_passes<3>(c->stream, im0, im1t_buf[j], S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps);
+            scored[j] = true;
         }
-        cnts[ic] = cnt;
-        if (!quality_for_all) continue;
-        rc = spearman_of_current(ic);
-        if (rc) return rc;
+        RegionStats h_rs[kMaxResident];
+        bool any = false;
+        for (int j = 0; j < nb; ++j) any = any || scored[j];
+        if (any) {
+            hipLaunchKernelGGL(finish_region_kernel, dim3(nb), dim3(256), 0, c->stream, pmax, phasnan, psum, reg_out);
+            MVS_HIP_TRY(c, hipMemcpyAsync(h_rs, reg_out, sizeof(RegionStats) * nb, hipMemcpyDeviceToHost, c->stream));
+            MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        for (int j = 0; j < nb; ++j) {
+            const int ic = todo[b0 + j];
+            if (code_out[ic] != 0) continue;
+            float region_nanmax = NAN;
+            int region_hasnan = 0;
+            if (scored[j]) {
+                region_hasnan = h_rs[j].hasnan;
+                region_nanmax = (h_rs[j].mx == -INFINITY) ? NAN : h_rs[j].mx;   // all-NaN region
+            }
+            // `if np.nanmax(im1t[mask_slices]) <= im1_min: continue` (Q3: nothing is appended)
+            if (region_nanmax <= (float)im1_min) {
+                code_out[ic] = 2;
+                continue;
+            }
+            const Shape3 R = Rs[j];
+            int min_shape = 0x7fffffff;
+            for (int k = k0; k < 3; ++k) min_shape = std::min(min_shape, (&R.nz)[k]);
+            const int win = std::min(7, min_shape - ((min_shape - 1) % 2));
+            const float region_max = region_hasnan ? NAN : region_nanmax;   // np.max propagates NaN
+            if (win < 3 || region_max <= (float)im1_min || !scored[j]) {
+                ssim_out[ic] = -1.0;
+            } else {
+                const int pad = (win - 1) / 2;
+                double cropn = 1.0;
+                for (int k = k0; k < 3; ++k) cropn *= (double)((&R.nz)[k] - 2 * pad);
+                ssim_out[ic] = h_rs[j].ssim_sum / cropn;
+            }
+        }
+        if (quality_for_all)
+            for (int j = 0; j < nb; ++j) {
+                const int ic = todo[b0 + j];
+                if (code_out[ic] != 0) continue;
+                rc = spearman_from(ic, im1t_buf[j]);
+                if (rc) return rc;
+            }
     }
     if (!quality_for_all) {
         // The reference reports the Spearman coefficient of the SSIM-argmax candidate only (registration.py:
@@ -574,12 +707,16 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         for (int ic = 0; ic < n_candidates; ++ic) {
             if (code_out[ic] != 0) continue;
             if (!(ssim_out[ic] == best)) { spearman_out[ic] = NAN; continue; }
-            double t[3] = {0.0, 0.0, 0.0};
-            for (int k = 0; k < ndim; ++k) t[k0 + k] = t_candidates[ic * ndim + k];
-            MVS_HIP_TRY(c, hipMemsetAsync(d_count, 0, 8, c->stream));
-            MVS_HIP_TRY(c, hipMemcpyAsync(d_bbox, bb_init, sizeof(bb_init), hipMemcpyHostToDevice, c->stream));
-            hipLaunchKernelGGL(shift_kernel, dim3(std::min(gb, 1024)), dim3(256), 0, c->stream, im1, im0, im1t, S, t[0], t[1], t[2], d_count, d_bbox);
-            rc = spearman_of_current(ic);
+            float* im1t = im1t_buf[0];
+            if (resident[ic] >= 0) im1t = im1t_buf[resident[ic]];
+            else {
+                double t[3] = {0.0, 0.0, 0.0};
+                for (int k = 0; k < ndim; ++k) t[k0 + k] = t_candidates[ic * ndim + k];
+                hipLaunchKernelGGL(shift_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im1, im0, im1t, S, t[0], t[1], t[2], vox_partial);
+                std::fill(resident.begin(), resident.end(), -1);
+                resident[ic] = 0;
+            }
+            rc = spearman_from(ic, im1t);
             if (rc) return rc;
         }
     }
