@@ -89,7 +89,9 @@ const char* mvs_last_error(int device);
 int mvs_set_stream(int device, void* hip_stream);
 int mvs_synchronize(int device);
 /* Tuning / test switches. "force_generic" = 1: mvs_fuse_chunk never takes the translation fast
- * path (both paths must agree; tests compare them). */
+ * path (both paths must agree; tests compare them).  "no_regions" = 1: skip the region kernels.
+ * "pool_cache_limit_mb": bytes (MiB) mvs_free may keep cached for later mvs_malloc calls
+ * (default 32768; 0 = release immediately). */
 int mvs_set_option(int device, const char* key, int64_t value);
 /* Device time (ms, hipEvent) spent in the kernels of the most recent compute
  * call on this device; blocks until that work has finished. */
@@ -99,6 +101,10 @@ double mvs_last_kernel_ms(int device);
  * The reference moves every chunk across PCIe twice (cp.asarray on entry,
  * cp.asnumpy on exit: fusion/_core.py:1584-1587, 1716-1721).  These handles let
  * register() and fuse() share ONE upload per tile. */
+/* mvs_malloc / mvs_free go through a caching pool (a pairwise registration allocates a handful of
+ * overlap-sized buffers per pair; hipMalloc/hipFree would cost more than its kernels): memory is
+ * uninitialised, and a freed block may be handed out again while earlier work on the context's
+ * stream is still queued -- which is safe because all work of this library is ordered on that stream. */
 int mvs_malloc(int device, uint64_t nbytes, void** dev_ptr);
 int mvs_free(int device, void* dev_ptr);
 int mvs_memcpy_h2d(int device, void* dst_dev, const void* src_host, uint64_t nbytes);

@@ -1,6 +1,7 @@
 // mvs_context.hip -- device contexts, error reporting, memory helpers of libmvs_hip.so.
 #include "mvs_internal.h"
 
+#include <algorithm>
 #include <cstring>
 
 static MvsContext g_ctx[MVS_MAX_DEVICES];
@@ -74,6 +75,21 @@ void* mvs_pinned_slot(MvsContext* c, int slot, size_t nbytes) {
 
 void* mvs_pinned(MvsContext* c, size_t nbytes) { return mvs_pinned_slot(c, 0, nbytes); }
 
+static size_t pool_round(uint64_t nbytes) {
+    if (nbytes == 0) nbytes = 1;
+    const size_t q = nbytes >= ((size_t)1 << 20) ? ((size_t)2 << 20) : 4096;
+    return (nbytes + q - 1) / q * q;
+}
+
+// really release every cached block (stream first: a cached block may still be read by queued work)
+static void pool_flush(MvsContext* c) {
+    if (c->pool_free.empty()) return;
+    hipStreamSynchronize(c->stream);
+    for (auto& kv : c->pool_free) hipFree(kv.second);
+    c->pool_free.clear();
+    c->pool_cached_bytes = 0;
+}
+
 extern "C" {
 
 const char* mvs_version(void) { return "mvs_hip 0.1 (gfx950)"; }
@@ -111,6 +127,13 @@ void mvs_shutdown(int device) {
     std::lock_guard<std::mutex> lock(c->mu);
     hipSetDevice(device);
     hipStreamSynchronize(c->stream);
+    {
+        std::lock_guard<std::mutex> plock(c->pool_mu);
+        for (auto& kv : c->pool_free) hipFree(kv.second);
+        c->pool_free.clear();
+        c->pool_cached_bytes = 0;
+        c->pool_live.clear();     // blocks still held by the caller die with the context's device memory owner
+    }
     for (auto& s : c->dev) {
         if (s.ptr) hipFree(s.ptr);
         s.ptr = nullptr;
@@ -138,7 +161,13 @@ int mvs_set_stream(int device, void* hip_stream) {
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    hipStream_t next = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    if (next != c->stream) {
+        // recycled allocations and scratch are only ordered within one stream: drain the old one first
+        MVS_HIP_TRY(c, hipSetDevice(device));
+        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->stream = next;
     return MVS_OK;
 }
 
@@ -150,6 +179,12 @@ int mvs_set_option(int device, const char* key, int64_t value) {
     std::lock_guard<std::mutex> lock(c->mu);
     if (!strcmp(key, "force_generic")) {
         c->force_generic = value != 0;
+        return MVS_OK;
+    }
+    if (!strcmp(key, "pool_cache_limit_mb")) {
+        std::lock_guard<std::mutex> plock(c->pool_mu);
+        c->pool_cache_limit = (size_t)std::max<int64_t>(value, 0) << 20;
+        if (c->pool_cached_bytes > c->pool_cache_limit) pool_flush(c);
         return MVS_OK;
     }
     if (!strcmp(key, "no_regions")) {
@@ -189,7 +224,23 @@ int mvs_malloc(int device, uint64_t nbytes, void** dev_ptr) {
     if (rc) return rc;
     if (!dev_ptr) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_malloc: dev_ptr is NULL");
     MVS_HIP_TRY(c, hipSetDevice(device));
-    MVS_HIP_TRY(c, hipMalloc(dev_ptr, nbytes ? nbytes : 1));
+    const size_t want = pool_round(nbytes);
+    std::lock_guard<std::mutex> lock(c->pool_mu);
+    auto it = c->pool_free.lower_bound(want);
+    if (it != c->pool_free.end() && it->first <= want + want / 4 + ((size_t)1 << 20)) {
+        *dev_ptr = it->second;
+        c->pool_live[it->second] = it->first;
+        c->pool_cached_bytes -= it->first;
+        c->pool_free.erase(it);
+        return MVS_OK;
+    }
+    hipError_t e = hipMalloc(dev_ptr, want);
+    if (e != hipSuccess) {           // out of memory: give the cache back and retry once
+        (void)hipGetLastError();
+        pool_flush(c);
+        MVS_HIP_TRY(c, hipMalloc(dev_ptr, want));
+    }
+    c->pool_live[*dev_ptr] = want;
     return MVS_OK;
 }
 
@@ -199,8 +250,22 @@ int mvs_free(int device, void* dev_ptr) {
     if (rc) return rc;
     if (!dev_ptr) return MVS_OK;
     MVS_HIP_TRY(c, hipSetDevice(device));
-    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    MVS_HIP_TRY(c, hipFree(dev_ptr));
+    std::lock_guard<std::mutex> lock(c->pool_mu);
+    auto it = c->pool_live.find(dev_ptr);
+    if (it == c->pool_live.end()) {   // not ours (or freed twice): behave like hipFree
+        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        MVS_HIP_TRY(c, hipFree(dev_ptr));
+        return MVS_OK;
+    }
+    const size_t sz = it->second;
+    c->pool_live.erase(it);
+    if (c->pool_cached_bytes + sz > c->pool_cache_limit) {
+        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        MVS_HIP_TRY(c, hipFree(dev_ptr));
+        return MVS_OK;
+    }
+    c->pool_free.emplace(sz, dev_ptr);
+    c->pool_cached_bytes += sz;
     return MVS_OK;
 }
 

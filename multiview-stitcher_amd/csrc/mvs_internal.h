@@ -6,7 +6,9 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <mutex>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -37,6 +39,14 @@ struct MvsContext {
     void* pinned2 = nullptr;
     size_t pinned2_cap = 0;
     bool no_regions = false;      // test switch: skip the region kernel (use the column kernel)
+    // caching device allocator behind mvs_malloc / mvs_free: freed blocks are kept (size-keyed) and handed out
+    // again, because hipMalloc / hipFree cost ~0.4 ms each and the registration path allocates per pair.
+    // Work of this library is stream-ordered on `stream`, so a recycled block is never touched out of order.
+    std::mutex pool_mu;
+    std::multimap<size_t, void*> pool_free;
+    std::unordered_map<void*, size_t> pool_live;
+    size_t pool_cached_bytes = 0;
+    size_t pool_cache_limit = (size_t)32 << 30;
 };
 
 MvsContext* mvs_ctx(int device);                       // nullptr if out of range

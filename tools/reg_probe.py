@@ -21,3 +21,12 @@ for r in range(reps + 1):
                           pre_registration_pruning_method="keep_axis_aligned")
     torch.cuda.synchronize()
     print("register pair: %.2f ms" % ((time.perf_counter() - t0) * 1e3), flush=True)
+if os.environ.get("MVS_PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for r in range(10):
+        registration.register(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, new_transform_key="reg", device=0,
+                              pre_registration_pruning_method="keep_axis_aligned")
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
