@@ -149,6 +149,14 @@ int mvs_phasecorr(int device, const float* fixed, const float* moving, int32_t m
                   int32_t ndim, const int64_t shape[3], int32_t normalization,
                   int32_t upsample_factor, double shift_out[3],
                   int64_t peak_index_out[3], float* peak_abs_out);
+/* The same for n_norm normalisations of ONE image pair (the reference calls phase_cross_correlation
+ * with "phase" and None on the same inputs, registration.py:413-431): the two forward transforms
+ * are computed once.  shifts_out: n_norm x 3, peak_indices_out: n_norm x 3 (may be NULL),
+ * peak_abs_out: n_norm (may be NULL). */
+int mvs_phasecorr_multi(int device, const float* fixed, const float* moving, int32_t mem,
+                        int32_t ndim, const int64_t shape[3], const int32_t* normalizations,
+                        int32_t n_norm, int32_t upsample_factor, double* shifts_out,
+                        int64_t* peak_indices_out, float* peak_abs_out);
 
 /* Intensity normalisation of one registration input == skimage.exposure.rescale_intensity(im,
  * in_range=(nanmin(im), nanmax(im)), out_range=(0, 1)) as called at registration.py:381-389:

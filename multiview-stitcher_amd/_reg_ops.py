@@ -65,6 +65,36 @@ def phase_cross_correlation(reference_image, moving_image, upsample_factor=1, no
     return s
 
 
+def phase_cross_correlation_multi(reference_image, moving_image, upsample_factor=1, normalizations=("phase", None), device=0):
+    """``phase_cross_correlation`` for several normalisations of one image pair; the forward transforms are
+    shared (mvs_phasecorr_multi).  Returns a list of (shift, debug) like ``phase_cross_correlation(return_debug=True)``."""
+    lib = _lib.init(device)
+    if tuple(reference_image.shape) != tuple(moving_image.shape):
+        raise ValueError("images must be same shape")
+    for normalization in normalizations:
+        if normalization not in ("phase", None):
+            raise ValueError("normalization must be either phase or None")
+    shape = tuple(int(s) for s in reference_image.shape)
+    ndim = len(shape)
+    p0, m0, k0 = _ptr_mem(reference_image)
+    p1, m1, k1 = _ptr_mem(moving_image)
+    if m0 != m1:
+        raise TypeError("both images must live on the same side (host or device)")
+    nn = len(normalizations)
+    norms = (C.c_int32 * nn)(*[1 if v == "phase" else 0 for v in normalizations])
+    shift = (C.c_double * (3 * nn))()
+    peak = (C.c_int64 * (3 * nn))()
+    pabs = (C.c_float * nn)()
+    rc = lib.mvs_phasecorr_multi(device, p0, p1, m0, ndim, _lib.i64x3(shape3(shape)), norms, nn, int(upsample_factor),
+                                 shift, peak, pabs)
+    _lib.check(rc, device, "mvs_phasecorr_multi")
+    out = []
+    for i in range(nn):
+        s = np.array(list(shift)[3 * i + 3 - ndim:3 * i + 3], dtype=np.float32)
+        out.append((s, {"peak_index": np.array(list(peak)[3 * i + 3 - ndim:3 * i + 3]), "peak_abs": float(pabs[i])}))
+    return out
+
+
 def score_candidates(im0, im1, t_candidates, region_mode, data_range, im1_min, device=0, quality_for_all=True):
     """The candidate loop of registration.py:493-556 on the GPU.  im0 / im1: rescaled float32 images
     (NaN = outside).  Returns (ssim, spearman, code) arrays; code 1 = (-1,-1) appended, 2 = `continue`.

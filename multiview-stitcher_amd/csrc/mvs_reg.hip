@@ -230,11 +230,19 @@ extern "C" int mvs_rescale_intensity(int device, const float* in, int32_t mem, i
 extern "C" int mvs_phasecorr(int device, const float* fixed, const float* moving, int32_t mem, int32_t ndim,
                              const int64_t shape[3], int32_t normalization, int32_t upsample_factor,
                              double shift_out[3], int64_t peak_index_out[3], float* peak_abs_out) {
+    return mvs_phasecorr_multi(device, fixed, moving, mem, ndim, shape, &normalization, 1, upsample_factor, shift_out,
+                               peak_index_out, peak_abs_out);
+}
+
+extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* moving, int32_t mem, int32_t ndim,
+                                   const int64_t shape[3], const int32_t* normalizations, int32_t n_norm,
+                                   int32_t upsample_factor, double* shifts_out, int64_t* peak_indices_out,
+                                   float* peak_abs_out_all) {
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
-    if (!fixed || !moving || !shape || !shift_out)
+    if (!fixed || !moving || !shape || !shifts_out || !normalizations || n_norm < 1)
         return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_phasecorr: NULL argument");
     if (ndim != 2 && ndim != 3) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_phasecorr: ndim must be 2 or 3");
     if (upsample_factor < 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_phasecorr: upsample_factor < 1");
@@ -250,11 +258,12 @@ extern "C" int mvs_phasecorr(int device, const float* fixed, const float* moving
     if (rc) return rc;
     rc = mvs_stage_float_volume(c, moving, mem, n, 5, &db);
     if (rc) return rc;
-    // complex work volumes: F, G (G is reused for cc), P
-    float2* F = (float2*)mvs_scratch(c, 6, (size_t)n * 8 * 3);
+    // complex work volumes: F, G (the two forward transforms, shared by every normalisation), P, CC
+    float2* F = (float2*)mvs_scratch(c, 6, (size_t)n * 8 * 4);
     if (!F) return MVS_ERR_HIP;
     float2* G = F + n;
     float2* P = G + n;
+    float2* CC = P + n;
 
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     const int gb = grid_for(n);
@@ -264,14 +273,19 @@ extern "C" int mvs_phasecorr(int device, const float* fixed, const float* moving
     if (rc) return rc;
     rc = mvs_fft3_c2c(c, G, shape, false);
     if (rc) return rc;
-    hipLaunchKernelGGL(xpower_kernel, dim3(gb), dim3(256), 0, c->stream, F, G, P, G, n, normalization ? 1 : 0);
-    rc = mvs_fft3_c2c(c, G, shape, true);   // cc (unnormalised inverse: argmax is scale invariant)
+  for (int inorm = 0; inorm < n_norm; ++inorm) {
+    const int normalization = normalizations[inorm];
+    double* shift_out = shifts_out + 3 * inorm;
+    int64_t* peak_index_out = peak_indices_out ? peak_indices_out + 3 * inorm : nullptr;
+    float* peak_abs_out = peak_abs_out_all ? peak_abs_out_all + inorm : nullptr;
+    hipLaunchKernelGGL(xpower_kernel, dim3(gb), dim3(256), 0, c->stream, F, G, P, CC, n, normalization ? 1 : 0);
+    rc = mvs_fft3_c2c(c, CC, shape, true);   // cc (unnormalised inverse: argmax is scale invariant)
     if (rc) return rc;
     char* red = (char*)mvs_scratch(c, 3, (size_t)gb * 16);
     if (!red) return MVS_ERR_HIP;
     float* pval = (float*)red;
     long long* pidx = (long long*)(red + (size_t)gb * 8);
-    hipLaunchKernelGGL(argmax_abs_kernel, dim3(gb), dim3(256), 0, c->stream, G, n, pval, pidx);
+    hipLaunchKernelGGL(argmax_abs_kernel, dim3(gb), dim3(256), 0, c->stream, CC, n, pval, pidx);
     MVS_HIP_TRY(c, hipGetLastError());
     std::vector<char> h((size_t)gb * 16);
     MVS_HIP_TRY(c, hipMemcpyAsync(h.data(), red, h.size(), hipMemcpyDeviceToHost, c->stream));
@@ -364,6 +378,7 @@ extern "C" int mvs_phasecorr(int device, const float* fixed, const float* moving
         if (shape[k] == 1) shift[k] = 0.f;
         shift_out[k] = (double)shift[k];
     }
+  }
     return MVS_OK;
 }
 

@@ -46,7 +46,7 @@ def _enumerate_candidates(shift_candidates, shape, ndim):
 
 
 def phase_correlation_registration(fixed_data, moving_data, disambiguate_region_mode=None, device=0,
-                                   return_debug=False, **skimage_phase_corr_kwargs):
+                                   return_debug=False, _constant_check=False, **skimage_phase_corr_kwargs):
     """Translation between two same-shape overlap crops (float32, NaN = outside the view).
 
     Returns ``{"affine_matrix": (ndim+1, ndim+1) translation mapping fixed px -> moving px,
@@ -63,6 +63,14 @@ def phase_correlation_registration(fixed_data, moving_data, disambiguate_region_
     # normalise (registration.py:381-389); the kernel also reports nanmin/nanmax/#valid of the INPUT
     im0, min0, max0, nvalid0 = _reg_ops.rescale_intensity(im0, device, out_on_device=on_dev)
     im1, min1, max1, nvalid1 = _reg_ops.rescale_intensity(im1, device, out_on_device=on_dev)
+    if _constant_check and (min0 == max0 or min1 == max1):
+        # dispatch_pairwise_reg_func's guard (registration.py:1500-1520), folded in here so that the
+        # nanmin / nanmax pass over both crops is not run twice
+        warnings.warn(
+            "An overlap region between tiles/views is all zero or constant. Assuming identity transform.",
+            UserWarning, stacklevel=3,
+        )
+        return {"affine_matrix": param_utils.identity_transform(ndim), "quality": np.nan}
     n = int(np.prod(shape))
     has_nan = (nvalid0 < n) or (nvalid1 < n)
     if disambiguate_region_mode is None:
@@ -74,8 +82,7 @@ def phase_correlation_registration(fixed_data, moving_data, disambiguate_region_
     # strategy of the reference: phase correlation with and without normalisation, the candidate with
     # the best structural similarity wins (registration.py:413-431). NaNs -> 0 happens in the kernel.
     shift_candidates, pcc_debug = [], []
-    for normalization in ["phase", None]:
-        s, dbg = _reg_ops.phase_cross_correlation(im0, im1, upsample_factor, normalization, device, return_debug=True)
+    for s, dbg in _reg_ops.phase_cross_correlation_multi(im0, im1, upsample_factor, ("phase", None), device):
         shift_candidates.append(s)
         pcc_debug.append(dbg)
     if has_nan:
@@ -289,6 +296,10 @@ def get_affine_from_intrinsic_affine(data_affine, sim_fixed, sim_moving, transfo
 def dispatch_pairwise_reg_func(pairwise_reg_func, fixed_data=None, moving_data=None, skip_constant_check=False, device=0,
                                **pairwise_reg_func_kwargs):
     """registration.dispatch_pairwise_reg_func (registration.py:1477-1544): constant-image guard + call."""
+    if pairwise_reg_func is phase_correlation_registration and fixed_data is not None and moving_data is not None \
+            and not skip_constant_check:
+        return pairwise_reg_func(fixed_data=fixed_data, moving_data=moving_data, device=device, _constant_check=True,
+                                 **pairwise_reg_func_kwargs)
     if fixed_data is not None and moving_data is not None and not skip_constant_check:
         for name, im in (("fixed", fixed_data), ("moving", moving_data)):
             _, mn, mx, _ = _reg_ops.rescale_intensity(_as_array(im), device, out_on_device=is_device_array(_as_array(im)))

@@ -166,3 +166,25 @@ def test_device_resident_inputs(hip_device):
     dev = registration.phase_correlation_registration(DeviceArray.from_host(a), DeviceArray.from_host(b))
     np.testing.assert_array_equal(host["affine_matrix"], dev["affine_matrix"])
     assert host["quality"] == dev["quality"]
+
+
+def test_constant_overlap_gives_identity_with_warning(hip_device):
+    """registration.dispatch_pairwise_reg_func (registration.py:1500-1520): a constant crop -> warning + identity, NaN quality."""
+    from multiview_stitcher_amd import registration
+
+    a = np.full((20, 30), 3.0, np.float32)
+    b = np.random.default_rng(0).random((20, 30)).astype(np.float32)
+    with pytest.warns(UserWarning, match="constant"):
+        res = registration.dispatch_pairwise_reg_func(registration.phase_correlation_registration, fixed_data=a, moving_data=b)
+    np.testing.assert_array_equal(res["affine_matrix"], np.eye(3))
+    assert np.isnan(res["quality"])
+    # and the multi-normalisation entry point agrees with the single calls
+    from multiview_stitcher_amd import _reg_ops
+    a2, b2 = _pair((24, 40, 36), (2, -3, 4))
+    a2, b2 = np.nan_to_num(ro.rescale_intensity_01(a2)), np.nan_to_num(ro.rescale_intensity_01(b2))
+    multi = _reg_ops.phase_cross_correlation_multi(a2, b2, 2, ("phase", None))
+    for (s, dbg), norm in zip(multi, ("phase", None)):
+        s1, dbg1 = _reg_ops.phase_cross_correlation(a2, b2, 2, norm, return_debug=True)
+        np.testing.assert_array_equal(s, s1)
+        np.testing.assert_array_equal(dbg["peak_index"], dbg1["peak_index"])
+        assert dbg["peak_abs"] == dbg1["peak_abs"]
