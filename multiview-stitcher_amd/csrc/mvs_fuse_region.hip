@@ -17,6 +17,7 @@
 #include "mvs_fuse_tr.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -26,13 +27,13 @@ namespace {
 constexpr int kRB = 4;       // planes per brick
 constexpr int kRG = 8;       // 4-row groups per brick
 constexpr int kRV = 8;       // voxels per lane
-constexpr int kRX = 128;     // voxels along x per brick (16 lanes x 8)
 constexpr int kMaxRV = 8;    // views per region handled here
 
 struct Region {
     int z0, z1, y0, y1, x0, x1;   // chunk-index box, end exclusive
     int nviews;
-    int allone_mask;              // bits 0-15: view ids[v] has blend weight 1 everywhere in the box;
+    int allone_mask;              // bits 0-7: view ids[v] has blend weight 1 everywhere in the box; bit 15: every view is in
+                                  // bounds with a strictly positive weight everywhere (plain weighted sums suffice);
                                   // bits 16-31: view ids[v] covers the box only partially (per-voxel bounds test)
     int ids[kMaxRV];
 };
@@ -251,22 +252,125 @@ __device__ __forceinline__ void fetch_val(const RecRegs& R, int v, int zc, int y
 
 }
 
+// Lean path of a brick on which every view is in bounds, has blend weight 1 and an integer offset (the bulk of the
+// overlap zones of a tile grid): the result is the plain mean of the views' values.  All row loads of a batch of row
+// groups are issued back-to-back for all views before the first one is consumed.
+template <typename TIn, typename TOut, int NV>
+__device__ __forceinline__ void region_brick_avg(const RegionParams& P, const RecRegs& R, int nv, int z0b, int z1, int y0b, int y1,
+                                                 int x0b, int x1, int lane, int lxb, float* strip) {
+    constexpr int ES = (int)sizeof(TIn);
+    constexpr int G = NV <= 2 ? 4 : NV <= 4 ? 2 : 1;   // row groups per batch
+    constexpr int WB = 9 * ES;
+    const LaneMap L(lane, lxb);
+    const int r = L.r, c = L.c;
+    const int xq = x0b + kRV * c;
+    const int nvalid_x = min(max(x1 - xq, 0), kRV);
+    const int xl = (nvalid_x > 0) ? xq : x0b;
+    TOut* out = (TOut*)P.out;
+    __amdgpu_buffer_rsrc_t rsrc[NV];
+    int base[NV], sy[NV], sz[NV], nbytes[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int vv = v < nv ? v : 0;
+        sy[v] = rec_field<F_ST_Y>(R, vv) * ES; sz[v] = rec_field<F_ST_Z>(R, vv) * ES;
+        const unsigned long long dptr = ((unsigned long long)(unsigned)rec_field<F_DATA_HI>(R, vv) << 32) | (unsigned)rec_field<F_DATA_LO>(R, vv);
+        nbytes[v] = rec_field<F_SPAN_LO>(R, vv) * ES;
+        rsrc[v] = __builtin_amdgcn_make_buffer_rsrc((void*)dptr, 0, nbytes[v], 0x00020000);
+        base[v] = rec_field<F_IO_Z>(R, vv) * sz[v] + rec_field<F_IO_Y>(R, vv) * sy[v] + (xl + rec_field<F_IO_X>(R, vv)) * ES;
+    }
+    const float rn = __builtin_amdgcn_rcpf((float)nv);
+    for (int p = 0; p < kRB; ++p) {
+        const int zc = z0b + p;
+        if (zc >= z1) break;
+        for (int gb = 0; gb < L.NG; gb += G) {
+            if (y0b + L.RG * gb >= y1) break;
+            unsigned int raw[NV][G][9];
+            int vo[NV][G];
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                if (v < nv) {
+#pragma unroll
+                    for (int g = 0; g < G; ++g) {
+                        const int yl = min(y0b + L.RG * (gb + g) + r, y1 - 1);
+                        vo[v][g] = base[v] + zc * sz[v] + yl * sy[v];
+                        Row8<TIn, false>::load(rsrc[v], vo[v][g], raw[v][g]);
+                    }
+                }
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int yc = y0b + L.RG * (gb + g) + r;
+                float num[kRV];
+#pragma unroll
+                for (int j = 0; j < kRV; ++j) num[j] = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    if (v < nv) {
+                        float e[9];
+                        Row8<TIn, false>::decode(raw[v][g], e);
+                        if (__any((vo[v][g] < 0 && vo[v][g] + WB > 0) || (vo[v][g] < nbytes[v] && vo[v][g] + WB > nbytes[v])))
+                            row8_refetch<TIn>(rsrc[v], vo[v][g], e, strip);
+#pragma unroll
+                        for (int j = 0; j < kRV; ++j) num[j] += e[j];
+                    }
+                float q[kRV];
+#pragma unroll
+                for (int j = 0; j < kRV; ++j) q[j] = num[j] * rn;
+                if (yc < y1 && nvalid_x > 0)
+                    store8<TOut>(out + ((long long)(zc - P.tz) * P.oy + (yc - P.ty)) * (long long)P.ox + (xq - P.tx), q, nvalid_x);
+            }
+        }
+    }
+}
+
 // One brick of a region with at most NV views: the view loop is unrolled, so per-view constants end up in scalar
 // registers and the row nodes of ramp-weighted views in per-view vector registers.
 template <typename TIn, typename TOut, int NV>
 __device__ __forceinline__ void region_brick(const RegionParams& P, const RecRegs& R, int nviews, int masks, int z0b, int z1,
                                              int y0b, int y1, int x0b, int x1, int lane, int lxb, float* strip) {
     constexpr bool ISF = std::is_floating_point<TIn>::value;
-    constexpr int ES = (int)sizeof(TIn);
     const int nv = nviews;   // <= NV
     const LaneMap L(lane, lxb);
     const int r = L.r, c = L.c;
     const int xq = x0b + kRV * c;
     const int nvalid_x = min(max(x1 - xq, 0), kRV);
     const int xl = (nvalid_x > 0) ? xq : x0b;      // lanes beyond the region read a valid window, nothing is stored
-    const int allone_mask = masks & 0xffff, partial_mask = (masks >> 16) & 0xffff;
+    int allone_mask = masks & 0xff;
+    const int partial_mask = (masks >> 16) & 0xff;
+    const bool allpos = (masks >> 15) & 1;   // host: every view covers the box with weight > 0 everywhere
+    // The host classified whole regions; the set {weight == 1} is curved (near an edge of a view the profile is a
+    // product of the axis coordinates), so most of a region can be "unit" without the region being so.  Refine per
+    // brick: the profile is concave along every axis line, hence its minimum over the brick sits at one of the 8
+    // brick corners -- lane k & 7 evaluates corner k, and a view whose 8 corner values are all >= 1 needs no weights.
+    if ((allone_mask & ((1 << nv) - 1)) != ((1 << nv) - 1)) {
+        const int k = lane & 7;
+        const int zk = (k & 4) ? min(z0b + kRB, z1) - 1 : z0b;
+        const int yk = (k & 2) ? min(y0b + 32, y1) - 1 : y0b;
+        const int xk = (k & 1) ? min(x0b + L.BXW, x1) - 1 : x0b;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (v < nv && !((allone_mask >> v) & 1) && !((partial_mask >> v) & 1)) {
+                float G1, dG;
+                bool inside;
+                row_nodes(R, v, zk, yk, G1, dG, inside);
+                const float u = fold_u(xk, rec_field<F_SILO_X>(R, v), rec_fieldf<F_SFLO_X>(R, v), rec_field<F_SIHI_X>(R, v),
+                                       rec_fieldf<F_SFHI_X>(R, v), rec_fieldf<F_SK_X>(R, v));
+                const float W = (u >= 0.f && inside) ? row_profile(u, G1, dG) : 0.f;
+                if (!__any(!(W >= 1.f))) allone_mask |= 1 << v;
+            }
+        }
+    }
     const bool all_unit = (allone_mask & ((1 << nv) - 1)) == ((1 << nv) - 1);
     TOut* out = (TOut*)P.out;
+    if (all_unit && !partial_mask && !ISF) {
+        bool allint = true;
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (v < nv) allint = allint && !(rec_fieldf<F_FW_Z>(R, v) > 0.f || rec_fieldf<F_FW_Y>(R, v) > 0.f || rec_fieldf<F_FW_X>(R, v) > 0.f);
+        if (allint) {
+            region_brick_avg<TIn, TOut, NV>(P, R, nv, z0b, z1, y0b, y1, x0b, x1, lane, lxb, strip);
+            return;
+        }
+    }
 
     for (int p = 0; p < kRB; ++p) {
         const int zc = z0b + p;
@@ -315,7 +419,32 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
 #pragma unroll
                     for (int j = 0; j < kRV; ++j) inb[j] = zy_ok && ((unsigned)(j - jlo) <= (unsigned)jw);
                 }
-                const bool unit = (allone_mask >> v) & 1;
+                bool unit = (allone_mask >> v) & 1;
+                float w[kRV];
+                if (!unit) {
+                    // nodes of my row come from lane (RG g + r) of the per-view node registers
+                    const int src = L.RG * g + r;
+                    const float G1 = __shfl(nG1[v], src), dG = __shfl(ndG[v], src);
+                    const int inside = __shfl(nin[v], src);
+                    const float kx = rec_fieldf<F_SK_X>(R, v);
+                    const float dl0 = (float)(xl - rec_field<F_SILO_X>(R, v)) - rec_fieldf<F_SFLO_X>(R, v);
+                    const float dh0 = (float)(rec_field<F_SIHI_X>(R, v) - xl) - rec_fieldf<F_SFHI_X>(R, v);
+                    // The profile is concave along x, so over the lane's 8 voxels its minimum sits at voxel 0 or 7:
+                    // two evaluations tell whether the whole segment has weight 1.
+                    const float u0 = fminf(dl0, dh0) * kx, u7 = fminf(dl0 + 7.f, dh0 - 7.f) * kx;
+                    const float W0 = (u0 >= 0.f && inside) ? row_profile(u0, G1, dG) : 0.f;
+                    const float W7 = (u7 >= 0.f && inside) ? row_profile(u7, G1, dG) : 0.f;
+                    const bool lane_unit = fminf(W0, W7) >= 1.f;
+                    if (!__any(!lane_unit)) unit = true;
+                    else {
+#pragma unroll
+                        for (int j = 0; j < kRV; ++j) {
+                            const float u = fminf(dl0 + (float)j, dh0 - (float)j) * kx;
+                            const float W = (u >= 0.f && inside) ? row_profile(u, G1, dG) : 0.f;
+                            w[j] = blend_ramp_nb(W);
+                        }
+                    }
+                }
                 if (unit) {
 #pragma unroll
                     for (int j = 0; j < kRV; ++j) {
@@ -323,32 +452,14 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
                         num[j] += ok ? val[j] : 0.f;
                         den[j] += ok ? 1.f : 0.f;
                     }
-                } else {
-                    float w[kRV];
-                    {
-                        // nodes of my row come from lane (4 g + r) of the per-view node registers
-                        const int src = L.RG * g + r;
-                        const float G1 = __shfl(nG1[v], src), dG = __shfl(ndG[v], src);
-                        const bool inside = __shfl(nin[v], src) != 0;
-                        const float kx = rec_fieldf<F_SK_X>(R, v);
-                        const float dl0 = (float)(xl - rec_field<F_SILO_X>(R, v)) - rec_fieldf<F_SFLO_X>(R, v);
-                        const float dh0 = (float)(rec_field<F_SIHI_X>(R, v) - xl) - rec_fieldf<F_SFHI_X>(R, v);
-                        float Wm = 2.f;
+                } else if (allpos && !ISF) {
+                    // every view of the region is in bounds with a strictly positive weight everywhere: plain weighted sums
 #pragma unroll
-                        for (int j = 0; j < kRV; ++j) {
-                            const float u = fminf(dl0 + (float)j, dh0 - (float)j) * kx;
-                            const float W = (u >= 0.f && inside) ? row_profile(u, G1, dG) : 0.f;
-                            w[j] = W;
-                            Wm = fminf(Wm, W);
-                        }
-                        if (__any(Wm < 1.f)) {
-#pragma unroll
-                            for (int j = 0; j < kRV; ++j) w[j] = blend_ramp_nb(w[j]);
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < kRV; ++j) w[j] = 1.f;
-                        }
+                    for (int j = 0; j < kRV; ++j) {
+                        num[j] = fmaf(w[j], val[j], num[j]);
+                        den[j] += w[j];
                     }
+                } else {
 #pragma unroll
                     for (int j = 0; j < kRV; ++j) {
                         const bool ok = (ISF ? (val[j] == val[j]) : true) && inb[j];
@@ -371,6 +482,7 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
             for (int j = 0; j < kRV; ++j) {
                 float o;
                 if (nv == 1 && all_unit && !partial_mask && !ISF) o = num[j];      // a single full view with weight 1
+                else if (allpos && !ISF) o = num[j] * __builtin_amdgcn_rcpf(den[j]);
                 else {
                     o = num[j] * __builtin_amdgcn_rcpf(den[j]);
                     o = (den[j] == wlast[j]) ? last[j] : o;                        // single ramp contributor: exact value
@@ -397,7 +509,7 @@ __device__ __forceinline__ void region_brick_generic(const RegionParams& P, cons
     const int xq = x0b + kRV * c;
     const int nvalid_x = min(max(x1 - xq, 0), kRV);
     const int xl = (nvalid_x > 0) ? xq : x0b;
-    const int allone_mask = masks & 0xffff, partial_mask = (masks >> 16) & 0xffff;
+    const int allone_mask = masks & 0xff, partial_mask = (masks >> 16) & 0xff;
     TOut* out = (TOut*)P.out;
     for (int p = 0; p < kRB; ++p) {
         const int zc = z0b + p;
@@ -457,7 +569,11 @@ __global__ __launch_bounds__(256) void copy_region_kernel(RegionParams P, int it
     constexpr int ES = (int)sizeof(TIn);
     __shared__ float s_strip[4][9 * 64];
     const int lane = threadIdx.x & 63;
-    const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD k takes the k-th
+    // contiguous eighth of the brick list -- neighbouring bricks, which share the cache lines at their edges and (with
+    // fractional offsets) whole planes, then meet in ONE L2 instead of being fetched once per XCD.
+    const int wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int li = wg * 4 + (threadIdx.x >> 6);
     if (li >= nitems) return;
     const Item it = P.items[item0 + li];
     const int rid = it.region_bx & 0xffff, bx = (unsigned)it.region_bx >> 16, by = it.by_bz & 0xffff, bz = (unsigned)it.by_bz >> 16;
@@ -494,18 +610,20 @@ __global__ __launch_bounds__(256) void copy_region_kernel(RegionParams P, int it
         const int zc = z0b + p;
         if (zc >= z1) break;
         const int vo_p = ((zc + ioz) * sz + ioy * sy + (xl + iox)) * ES;   // + row * sy * ES
-        if (!anyfrac && lxb == 4) {
+        if (!anyfrac && lxb >= 4) {
+          for (int gb = 0; gb < L.NG; gb += kRG) {
+            if (y0b + L.RG * gb >= y1) break;
             unsigned int raw[kRG][9];
             int vo[kRG];
 #pragma unroll
             for (int g = 0; g < kRG; ++g) {
-                const int yl = min(y0b + 4 * g + r, y1 - 1);
+                const int yl = min(y0b + L.RG * (gb + g) + r, y1 - 1);
                 vo[g] = vo_p + yl * sy * ES;
                 Row8<TIn, false>::load(rsrc, vo[g], raw[g]);
             }
 #pragma unroll
             for (int g = 0; g < kRG; ++g) {
-                const int yc = y0b + 4 * g + r;
+                const int yc = y0b + L.RG * (gb + g) + r;
                 float e[9];
                 Row8<TIn, false>::decode(raw[g], e);
                 if (__any((vo[g] < 0 && vo[g] + WB > 0) || (vo[g] < nbytes && vo[g] + WB > nbytes))) row8_refetch<TIn>(rsrc, vo[g], e, strip);
@@ -515,6 +633,7 @@ __global__ __launch_bounds__(256) void copy_region_kernel(RegionParams P, int it
                 if (yc < y1 && nvalid_x > 0)
                     store8<TOut>(out + ((long long)(zc - P.tz) * P.oy + (yc - P.ty)) * (long long)P.ox + (xq - P.tx), q, nvalid_x);
             }
+          }
         } else {
             const float ux = 1.f - wx, uy = 1.f - wy, uz = 1.f - wz;
 #pragma unroll 2
@@ -563,7 +682,11 @@ template <typename TIn, typename TOut, int NVC>
 __global__ __launch_bounds__(256) void fuse_region_kernel(RegionParams P, int item0, int nitems) {
     __shared__ float s_strip[4][9 * 64];
     const int lane = threadIdx.x & 63;
-    const int li = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD k takes the k-th
+    // contiguous eighth of the brick list -- neighbouring bricks, which share the cache lines at their edges and (with
+    // fractional offsets) whole planes, then meet in ONE L2 instead of being fetched once per XCD.
+    const int wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int li = wg * 4 + (threadIdx.x >> 6);
     if (li >= nitems) return;
     const Item it = P.items[item0 + li];
     const int rid = it.region_bx & 0xffff, bx = (unsigned)it.region_bx >> 16, by = it.by_bz & 0xffff, bz = (unsigned)it.by_bz >> 16;
@@ -638,26 +761,41 @@ void axis_breakpoints(const TrView* htr, int n_views, int d, int t, int o, std::
         // A thin shell next to every border: inside it the blend weight of the view can round to 0 (the reference
         // outputs 0 there even for a single view, weights.py:502-507); outside it a voxel seen by ONE view is simply
         // the resampled value whatever the weight is, so single-view boxes off the shell need no weights at all.
+        // Along x a 4-voxel sliver costs a whole cache line per row and view, so the shell is only cut where it matters:
+        // next to a border that no other view covers (the rim of the mosaic).  Inside an overlap the box simply is not
+        // flagged "positive" if a weight can vanish there (it cannot, away from the edges of the view).
         const int shell = 4;
+        bool cut_lo = true, cut_hi = true;
+        if (d == 2) {
+            for (int w = 0; w < n_views; ++w) {
+                if (w == v || htr[w].lo[2] > htr[w].hi[2]) continue;
+                const bool touches = htr[w].lo[0] <= htr[v].hi[0] && htr[w].hi[0] >= htr[v].lo[0] && htr[w].lo[1] <= htr[v].hi[1] &&
+                                     htr[w].hi[1] >= htr[v].lo[1];
+                if (!touches) continue;
+                if (htr[w].lo[2] <= lo - 8 && htr[w].hi[2] >= lo + shell + 8) cut_lo = false;
+                if (htr[w].lo[2] <= hi - shell - 8 && htr[w].hi[2] >= hi + 8) cut_hi = false;
+            }
+        }
         if (2 * shell + 8 < hi - lo + 1) {
-            ev.push_back({clampi(lo + shell), 2});
-            ev.push_back({clampi(hi + 1 - shell), 3});
+            if (cut_lo) ev.push_back({clampi(lo + shell), 2});
+            if (cut_hi) ev.push_back({clampi(hi + 1 - shell), 3});
         }
     }
     const int tol = 16;
     out->clear();
     out->push_back(t);
     for (int kind_group = 0; kind_group < 2; ++kind_group) {
-        // borders and zone ends are clustered separately so that a zone end never merges with a border
+        // borders and shell ends are clustered separately so that a shell end never merges with a border
         std::vector<std::pair<int, int>> e2;
         for (auto& e : ev)
-            if ((e.second >= 2) == (kind_group == 1)) e2.push_back(e);
+            if (e.second / 2 == kind_group) e2.push_back(e);
         std::sort(e2.begin(), e2.end());
         size_t i = 0;
         while (i < e2.size()) {
             size_t j = i;
             bool want_min = false, want_max = false;
             while (j < e2.size() && e2[j].first - e2[i].first <= tol) {
+                // lower borders and the starts of upper shells cluster to their minimum, the rest to the maximum
                 if (e2[j].second == 0 || e2[j].second == 3) want_min = true; else want_max = true;
                 ++j;
             }
@@ -714,7 +852,7 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
                     R.y0 = pts[1][iy]; R.y1 = pts[1][iy + 1];
                     R.x0 = pts[2][ix]; R.x1 = pts[2][ix + 1];
                     int nv = 0;
-                    bool positive_full = false;
+                    bool positive_full = false, all_positive = true;
                     for (int v : yviews) {
                         if (!(htr[v].lo[2] < R.x1 && htr[v].hi[2] >= R.x0)) continue;   // does not touch the box
                         if (nv == kMaxRV) return MVS_OK;                              // too many views: column kernel
@@ -728,11 +866,16 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
                         }
                         const bool unit = full && wmin >= 1.f;          // weight exactly 1 everywhere
                         if (full && wmin >= 1e-3f) positive_full = true;   // weight > 0 everywhere (ramp(1e-3) = 2.5e-6 > 2^-26)
+                        else all_positive = false;
                         if (unit) R.allone_mask |= 1 << nv;
                         if (!full) R.allone_mask |= 1 << (16 + nv);
                         R.ids[nv++] = v;
                     }
-                    const int lxb = (R.x1 - R.x0 <= 32) ? 1 : 4;   // thin boxes (ramp zones): 16-voxel-wide bricks
+                    if (nv > 0 && all_positive) R.allone_mask |= 1 << 15;
+                    // brick width: 16 voxels for thin boxes, 512 (one full tile row per load instruction: the longest
+                    // contiguous runs, 4.0 instead of 3.0 TB/s on the copy class) for wide copy-class boxes, else 128
+                    int lxb = (R.x1 - R.x0 <= 32) ? 1 : 4;
+                    if (nv == 1 && positive_full && R.x1 - R.x0 > 160) lxb = 6;
                     R.nviews = nv | (lxb << 8);
                     const int rid = (int)regions.size();
                     if (rid >= 65536) return MVS_OK;
@@ -740,14 +883,54 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
                     const int bxw = kRV << lxb;
                     const int nbz = (R.z1 - R.z0 + kRB - 1) / kRB, nby = (R.y1 - R.y0 + 31) / 32, nbx = (R.x1 - R.x0 + bxw - 1) / bxw;
                     if (nbz >= 65536 || nby >= 65536 || nbx >= 65536) return MVS_OK;
-                    // z fastest so that consecutive bricks reuse the upper plane of their neighbour
                     const bool copy_class = (nv == 1) && positive_full;   // one full view with positive weight everywhere
                     std::vector<Item>& dst = items_by_class[copy_class ? 4 : nv <= 1 ? 0 : nv == 2 ? 1 : nv <= 4 ? 2 : 3];
+                    // x fastest, then z, then y: bricks that are neighbours along x share the cache lines at their common
+                    // edge, neighbours along z share a whole plane when the offsets are fractional; both reuses then happen
+                    // within a few bricks, i.e. inside the L2 of the XCD that owns this stretch of the list
                     for (int by = 0; by < nby; ++by)
-                        for (int bx = 0; bx < nbx; ++bx)
-                            for (int bz = 0; bz < nbz; ++bz) dst.push_back({rid | (bx << 16), by | (bz << 16)});
+                        for (int bz = 0; bz < nbz; ++bz)
+                            for (int bx = 0; bx < nbx; ++bx) dst.push_back({rid | (bx << 16), by | (bz << 16)});
                 }
             }
+        }
+        if (getenv("MVS_PLAN_STATS")) {
+            double vox[6][2] = {{0}};
+            for (const Region& R : regions) {
+                const int nv = R.nviews & 0xff;
+                const bool au = (R.allone_mask & ((1 << nv) - 1)) == ((1 << nv) - 1);
+                const int cls = nv <= 1 ? nv : nv == 2 ? 2 : nv <= 4 ? 3 : 4;
+                vox[cls][au ? 1 : 0] += (double)(R.z1 - R.z0) * (R.y1 - R.y0) * (R.x1 - R.x0);
+            }
+            {   // brick-level emulation of the device-side refinement
+                double tot[3] = {0, 0, 0}, unitb[3] = {0, 0, 0};
+                for (const Region& R : regions) {
+                    const int nv = R.nviews & 0xff, lxb = (R.nviews >> 8) & 7;
+                    if (nv < 2 || nv > 4) continue;
+                    const int bxw = kRV << lxb, cls = nv == 2 ? 0 : 1;
+                    for (int z = R.z0; z < R.z1; z += kRB)
+                        for (int y = R.y0; y < R.y1; y += 32)
+                            for (int x = R.x0; x < R.x1; x += bxw) {
+                                bool all = true;
+                                for (int v = 0; v < nv && all; ++v) {
+                                    if ((R.allone_mask >> v) & 1) continue;
+                                    if ((R.allone_mask >> (16 + v)) & 1) { all = false; break; }
+                                    for (int k = 0; k < 8; ++k) {
+                                        const int zz = (k & 4) ? std::min(z + kRB, R.z1) - 1 : z, yy = (k & 2) ? std::min(y + 32, R.y1) - 1 : y,
+                                                  xx = (k & 1) ? std::min(x + bxw, R.x1) - 1 : x;
+                                        if (!(tr_weight_profile(htr[R.ids[v]], zz, yy, xx) >= 1.f)) { all = false; break; }
+                                    }
+                                }
+                                tot[cls] += 1; if (all) unitb[cls] += 1;
+                            }
+                }
+                fprintf(stderr, "[mvs plan] unit bricks: nv2 %.0f / %.0f, nv3-4 %.0f / %.0f\n", unitb[0], tot[0], unitb[1], tot[1]);
+            }
+            fprintf(stderr, "[mvs plan] regions %zu; Mvox (ramp / all-unit): nv0 %.1f/%.1f nv1 %.1f/%.1f nv2 %.1f/%.1f nv3-4 %.1f/%.1f nv5+ %.1f/%.1f; bricks",
+                    regions.size(), vox[0][0] / 1e6, vox[0][1] / 1e6, vox[1][0] / 1e6, vox[1][1] / 1e6, vox[2][0] / 1e6, vox[2][1] / 1e6,
+                    vox[3][0] / 1e6, vox[3][1] / 1e6, vox[4][0] / 1e6, vox[4][1] / 1e6);
+            for (int k = 0; k < 5; ++k) fprintf(stderr, " %zu", items_by_class[k].size());
+            fprintf(stderr, "\n");
         }
         std::vector<Item> items;
         for (int k = 0; k < 5; ++k) {
@@ -784,12 +967,12 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
     for (int k = 0; k < 5; ++k) {
         const int cnt = pc.class_count[k];
         if (cnt && k == 4) {
-            const dim3 grid((cnt + 3) / 4), block(256);
+            const dim3 grid(((cnt + 3) / 4 + 7) / 8 * 8), block(256);   // multiple of 8: see the XCD mapping in the kernels
             if (dtype == MVS_U8) hipLaunchKernelGGL((copy_region_kernel<unsigned char, unsigned char>), grid, block, 0, c->stream, P, item0, cnt);
             else if (dtype == MVS_U16) hipLaunchKernelGGL((copy_region_kernel<unsigned short, unsigned short>), grid, block, 0, c->stream, P, item0, cnt);
             else hipLaunchKernelGGL((copy_region_kernel<float, float>), grid, block, 0, c->stream, P, item0, cnt);
         } else if (cnt) {
-            const dim3 grid((cnt + 3) / 4), block(256);
+            const dim3 grid(((cnt + 3) / 4 + 7) / 8 * 8), block(256);   // multiple of 8: see the XCD mapping in the kernels
 #define MVS_RK(T, NVC) hipLaunchKernelGGL((fuse_region_kernel<T, T, NVC>), grid, block, 0, c->stream, P, item0, cnt)
 #define MVS_RKD(NVC) do { if (dtype == MVS_U8) MVS_RK(unsigned char, NVC); else if (dtype == MVS_U16) MVS_RK(unsigned short, NVC); else MVS_RK(float, NVC); } while (0)
             if (k == 0) MVS_RKD(1); else if (k == 1) MVS_RKD(2); else if (k == 2) MVS_RKD(4); else MVS_RKD(8);
