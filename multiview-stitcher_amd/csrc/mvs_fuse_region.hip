@@ -123,6 +123,7 @@ __device__ __forceinline__ int rli(int x, int l) { return __builtin_amdgcn_readl
 // Lane layout of a brick: 2^lxb lanes side by side along x (8 voxels each), the rest of the 64 lanes stacked along y.
 //   lxb = 4: 4 rows x 128 voxels per group, 8 groups per brick   (regular regions)
 //   lxb = 1: 32 rows x 16 voxels, one group                      (thin ramp zones next to a view border)
+//   lxb = 3: 8 rows x 64 voxels, 4 groups (overlap zones along x); lxb = 6: 1 row x 512 voxels, 32 groups (copy class)
 struct LaneMap {
     int r, c, RG, NG, BXW;
     __device__ __forceinline__ LaneMap(int lane, int lxb)
@@ -876,6 +877,9 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
                     // contiguous runs, 4.0 instead of 3.0 TB/s on the copy class) for wide copy-class boxes, else 128
                     int lxb = (R.x1 - R.x0 <= 32) ? 1 : 4;
                     if (nv == 1 && positive_full && R.x1 - R.x0 > 160) lxb = 6;
+                    // overlap zones along x (about 100 voxels wide): 64-voxel bricks, so that each brick holds only ONE of the
+                    // zone's two ramp ends and the other view classifies as "unit" (measured best of 16/32/64/128)
+                    if (nv >= 2 && R.x1 - R.x0 > 32 && R.x1 - R.x0 <= 136) lxb = 3;
                     R.nviews = nv | (lxb << 8);
                     const int rid = (int)regions.size();
                     if (rid >= 65536) return MVS_OK;
