@@ -267,7 +267,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fuse_tr_kernel<u16,u16,weighted_average>",
+                "kernel": "fuse launch = copy_region_kernel + fuse_region_kernel<1|2|4|8> (u16), timed as one unit",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -866,7 +866,9 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
                             wmin = fminf(wmin, tr_weight_profile(htr[v], z, y, x));
                         }
                         const bool unit = full && wmin >= 1.f;          // weight exactly 1 everywhere
-                        if (full && wmin >= 1e-3f) positive_full = true;   // weight > 0 everywhere (ramp(1e-3) = 2.5e-6 > 2^-26)
+                        // weight > 0 everywhere: the float32 ramp (cos(pi (1 - W)) + 1) / 2 only vanishes when the cosine
+                        // rounds to -1, i.e. W < 7.8e-5; at W = 3e-4 the cosine is 7 ulp away from -1
+                        if (full && wmin >= 3e-4f) positive_full = true;
                         else all_positive = false;
                         if (unit) R.allone_mask |= 1 << nv;
                         if (!full) R.allone_mask |= 1 << (16 + nv);

@@ -46,7 +46,7 @@ class DevicePairExecutor:
 
         def work(d):
             dev = self.devices[d]
-            cache = {}
+            cache = registration._BinCache()
             for k in buckets[d]:
                 i, j = edges[k]
                 a, b = msims[i], msims[j]

@@ -347,12 +347,9 @@ def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=Non
         if max(registration_binning.values()) <= 1:
             return sim
         key = (id(sim.data), tuple(sorted(registration_binning.items())))
-        if _bin_cache is not None and key in _bin_cache:
-            return _bin_cache[key]
-        b = _bin_sim(sim, registration_binning, device)
-        if _bin_cache is not None:
-            _bin_cache[key] = b
-        return b
+        if _bin_cache is None:
+            return _bin_sim(sim, registration_binning, device)
+        return _bin_cache.get_or_compute(key, lambda: _bin_sim(sim, registration_binning, device))
 
     reg_sims_b = [binned(sim1), binned(sim2)]
     ov = _get_overlap_bboxes(reg_sims_b[0], reg_sims_b[1], transform_key, None, overlap_tolerance)
@@ -381,7 +378,7 @@ def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=Non
 
 def compute_pairwise_registrations(msims, edges, transform_key, registration_binning=None, overlap_tolerance=0.0,
                                    pairwise_reg_func=phase_correlation_registration, pairwise_reg_func_kwargs=None,
-                                   pairwise_executor=None, device=0):
+                                   pairwise_executor=None, device=0, host_threads=1):
     """registration.compute_pairwise_registrations (registration.py:2622-2714): either hand all edges to a
     user ``pairwise_executor(msims, edges, register_kwargs)`` or loop over them on one device."""
     register_kwargs = dict(transform_key=transform_key, registration_binning=registration_binning,
@@ -392,8 +389,52 @@ def compute_pairwise_registrations(msims, edges, transform_key, registration_bin
         if len(results) != len(edges):
             raise ValueError("pairwise_executor must return one result per edge")
         return results
-    cache = {}
-    return [register_pair_of_msims(msims[i], msims[j], device=device, _bin_cache=cache, **register_kwargs) for i, j in edges]
+    cache = _BinCache()
+    edges = list(edges)
+    n_threads = max(1, min(int(host_threads), len(edges)))
+    if n_threads == 1:
+        return [register_pair_of_msims(msims[i], msims[j], device=device, _bin_cache=cache, **register_kwargs) for i, j in edges]
+    # Pairs are independent.  Every call into libmvs_hip.so releases the GIL and is serialised per device by the
+    # context lock, so with a few host threads the Python glue of one pair runs while the GPU works on another.
+    # Measured on the north-star mosaic this does not pay (the idle time sits inside the calls, at their host
+    # synchronisations), hence the default of one thread; results keep the order of `edges` either way.
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=n_threads) as pool:
+        futs = [pool.submit(register_pair_of_msims, msims[i], msims[j], device=device, _bin_cache=cache, **register_kwargs)
+                for i, j in edges]
+        return [f.result() for f in futs]
+
+
+class _BinCache:
+    """Binned tiles shared by the pairs of one compute_pairwise_registrations call (each tile is binned once).
+    Thread safe: the first thread asking for a key computes it, the others wait for that result."""
+
+    def __init__(self):
+        import threading
+
+        self._lock = threading.Lock()
+        self._items = {}
+
+    def get_or_compute(self, key, fn):
+        import threading
+
+        with self._lock:
+            slot = self._items.get(key)
+            owner = slot is None
+            if owner:
+                slot = self._items[key] = {"event": threading.Event(), "value": None, "error": None}
+        if owner:
+            try:
+                slot["value"] = fn()
+            except BaseException as e:   # noqa: BLE001 - re-raised in every waiter
+                slot["error"] = e
+            slot["event"].set()
+        else:
+            slot["event"].wait()
+        if slot["error"] is not None:
+            raise slot["error"]
+        return slot["value"]
 
 
 def resolve_translations(n_views, edges, pair_results, reference_view=0, weights=None):
