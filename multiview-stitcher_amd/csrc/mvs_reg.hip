@@ -3,7 +3,7 @@
 // mvs_phasecorr == skimage.registration.phase_cross_correlation(a, b, normalization=None|"phase",
 // upsample_factor=u, disambiguate=False)[0] as called from the reference's
 // registration.phase_correlation_registration (src/multiview_stitcher/registration.py:422-431):
-//   F = fftn(a), G = fftn(b)                         (complex64, mvs_fft.hip)
+//   F = fftn(a), G = fftn(b)                         (complex64, mvs_fft.hip; both from ONE transform of a + i b)
 //   P = F * conj(G);  "phase": P /= max(|P|, 100 eps)
 //   cc = ifftn(P);  integer peak = argmax |cc|  (lowest flat index wins ties, like np.argmax)
 //   wrap to signed shift, then the matrix-multiply upsampled DFT around round(shift*u)/u
@@ -17,39 +17,55 @@
 
 namespace {
 
-__global__ void to_complex_kernel(const float* __restrict__ src, float2* __restrict__ dst, long long n) {
+// Both images are real, so ONE complex transform carries both spectra: Z = fft(a + i b), and with Zm = Z(-k)
+//   A(k) = (Z + conj Zm) / 2,   B(k) = (Z - conj Zm) / (2 i).
+__global__ void pack_pair_kernel(const float* __restrict__ a, const float* __restrict__ b, float2* __restrict__ dst, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        float v = src[i];
-        if (v != v) v = 0.f;   // np.nan_to_num (registration.py:403-408)
-        dst[i] = make_float2(v, 0.f);
+        float va = a[i], vb = b[i];
+        if (va != va) va = 0.f;   // np.nan_to_num (registration.py:403-408)
+        if (vb != vb) vb = 0.f;
+        dst[i] = make_float2(va, vb);
     }
 }
 
-// P = F * conj(G), optionally divided by max(|P|, 100 eps); written to P and (a copy) to C
-__global__ void xpower_kernel(const float2* __restrict__ F, const float2* __restrict__ G, float2* __restrict__ P,
-                              float2* __restrict__ C, long long n, int normalize) {
+// Cross power spectra from the packed transform: p = A conj(B); P1 = p / max(|p|, 100 eps) ("phase"), P2 = p (None).
+// The spectra are Hermitian, so their inverse transforms are real and again share one complex transform:
+// C = Pa + i Pb  ->  ifft(C) = cc_a + i cc_b.  sel_a / sel_b pick which of {P1 (1), P2 (0)} go where (sel_b < 0: C = Pa).
+__global__ void xpower_packed_kernel(const float2* __restrict__ Z, float2* __restrict__ P1, float2* __restrict__ P2,
+                                     float2* __restrict__ C, int nz, int ny, int nx, int sel_a, int sel_b) {
+    const long long n = (long long)nz * ny * nx;
     const float floor_ = 100.f * FLT_EPSILON;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const float2 f = F[i], g = G[i];
-        float2 p = make_float2(f.x * g.x + f.y * g.y, f.y * g.x - f.x * g.y);
-        if (normalize) {
-            const float a = fmaxf(hypotf(p.x, p.y), floor_);
-            p.x /= a;
-            p.y /= a;
+        const int kx = (int)(i % nx);
+        const long long t = i / nx;
+        const int ky = (int)(t % ny), kz = (int)(t / ny);
+        const int mx = kx ? nx - kx : 0, my = ky ? ny - ky : 0, mz = kz ? nz - kz : 0;
+        const float2 z = Z[i], m = Z[((long long)mz * ny + my) * nx + mx];
+        const float2 f = make_float2(0.5f * (z.x + m.x), 0.5f * (z.y - m.y));
+        const float2 g = make_float2(0.5f * (z.y + m.y), -0.5f * (z.x - m.x));
+        const float2 p = make_float2(f.x * g.x + f.y * g.y, f.y * g.x - f.x * g.y);   // f * conj(g)
+        const float a = fmaxf(hypotf(p.x, p.y), floor_);
+        const float2 p1 = make_float2(p.x / a, p.y / a);
+        P1[i] = p1;
+        P2[i] = p;
+        const float2 pa = sel_a ? p1 : p;
+        if (sel_b < 0) C[i] = pa;
+        else {
+            const float2 pb = sel_b ? p1 : p;
+            C[i] = make_float2(pa.x - pb.y, pa.y + pb.x);
         }
-        P[i] = p;
-        C[i] = p;
     }
 }
 
 // argmax |c| with np.argmax's tie-break (lowest flat index): per-block partial results
-__global__ __launch_bounds__(256) void argmax_abs_kernel(const float2* __restrict__ c, long long n, float* __restrict__ pval,
+// comp 0: |c| (one correlation per transform); 1 / 2: |Re c| / |Im c| (two real correlations packed in one transform)
+__global__ __launch_bounds__(256) void argmax_abs_kernel(const float2* __restrict__ c, long long n, int comp, float* __restrict__ pval,
                                                          long long* __restrict__ pidx) {
     float best = -1.f;
     long long bi = 0x7fffffffffffffffLL;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float2 v = c[i];
-        const float a = hypotf(v.x, v.y);
+        const float a = comp == 0 ? hypotf(v.x, v.y) : comp == 1 ? fabsf(v.x) : fabsf(v.y);
         if (a > best || (a == best && i < bi)) { best = a; bi = i; }
     }
     // wavefront shuffle reduction, then across the 4 wavefronts through LDS
@@ -258,34 +274,35 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     if (rc) return rc;
     rc = mvs_stage_float_volume(c, moving, mem, n, 5, &db);
     if (rc) return rc;
-    // complex work volumes: F, G (the two forward transforms, shared by every normalisation), P, CC
-    float2* F = (float2*)mvs_scratch(c, 6, (size_t)n * 8 * 4);
-    if (!F) return MVS_ERR_HIP;
-    float2* G = F + n;
-    float2* P = G + n;
-    float2* CC = P + n;
+    // complex work volumes: Z (ONE forward transform of a + i b carries both spectra), P1 / P2 (cross power with and
+    // without phase normalisation, kept for the upsampled DFT), CC (inverse transform; two correlations per transform)
+    float2* Z = (float2*)mvs_scratch(c, 6, (size_t)n * 8 * 4);
+    if (!Z) return MVS_ERR_HIP;
+    float2* P1 = Z + n;
+    float2* P2 = P1 + n;
+    float2* CC = P2 + n;
 
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     const int gb = grid_for(n);
-    hipLaunchKernelGGL(to_complex_kernel, dim3(gb), dim3(256), 0, c->stream, da, F, n);
-    hipLaunchKernelGGL(to_complex_kernel, dim3(gb), dim3(256), 0, c->stream, db, G, n);
-    rc = mvs_fft3_c2c(c, F, shape, false);
-    if (rc) return rc;
-    rc = mvs_fft3_c2c(c, G, shape, false);
+    hipLaunchKernelGGL(pack_pair_kernel, dim3(gb), dim3(256), 0, c->stream, da, db, Z, n);
+    rc = mvs_fft3_c2c(c, Z, shape, false);
     if (rc) return rc;
   for (int inorm = 0; inorm < n_norm; ++inorm) {
     const int normalization = normalizations[inorm];
     double* shift_out = shifts_out + 3 * inorm;
     int64_t* peak_index_out = peak_indices_out ? peak_indices_out + 3 * inorm : nullptr;
     float* peak_abs_out = peak_abs_out_all ? peak_abs_out_all + inorm : nullptr;
-    hipLaunchKernelGGL(xpower_kernel, dim3(gb), dim3(256), 0, c->stream, F, G, P, CC, n, normalization ? 1 : 0);
+    // (the inverse transforms stay separate: one complex transform per normalisation)
+    hipLaunchKernelGGL(xpower_packed_kernel, dim3(gb), dim3(256), 0, c->stream, Z, P1, P2, CC, nz, ny, nx, normalization ? 1 : 0, -1);
     rc = mvs_fft3_c2c(c, CC, shape, true);   // cc (unnormalised inverse: argmax is scale invariant)
     if (rc) return rc;
+    const int comp = 0;
+    const float2* P = normalization ? P1 : P2;
     char* red = (char*)mvs_scratch(c, 3, (size_t)gb * 16);
     if (!red) return MVS_ERR_HIP;
     float* pval = (float*)red;
     long long* pidx = (long long*)(red + (size_t)gb * 8);
-    hipLaunchKernelGGL(argmax_abs_kernel, dim3(gb), dim3(256), 0, c->stream, CC, n, pval, pidx);
+    hipLaunchKernelGGL(argmax_abs_kernel, dim3(gb), dim3(256), 0, c->stream, CC, n, comp, pval, pidx);
     MVS_HIP_TRY(c, hipGetLastError());
     std::vector<char> h((size_t)gb * 16);
     MVS_HIP_TRY(c, hipMemcpyAsync(h.data(), red, h.size(), hipMemcpyDeviceToHost, c->stream));
