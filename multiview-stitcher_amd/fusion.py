@@ -57,6 +57,28 @@ _FUSION_CODES = {
 }
 
 
+# The reference's own function objects (multiview_stitcher.fusion.weighted_average_fusion, ...) select the kernel
+# mode of the same name: `builtin(reference_func)` is what a backend="hip" branch inside the reference would pass on
+# (INTEGRATION.md section 1).
+BUILTIN = {
+    "weighted_average_fusion": weighted_average_fusion,
+    "max_fusion": max_fusion,
+    "simple_average_fusion": simple_average_fusion,
+    "content_based": content_based,
+}
+
+
+def builtin(func):
+    """Map one of the reference's built-in fusion / weight functions (callable or name; None stays None) onto the
+    kernel mode of the same name; anything else raises, custom callables cannot run inside mvs_fuse_chunk."""
+    if func is None:
+        return None
+    name = func if isinstance(func, str) else getattr(func, "__name__", None)
+    if name not in BUILTIN:
+        raise NotImplementedError(f"{func!r} is not a built-in fusion/weights function of the hip backend")
+    return BUILTIN[name]
+
+
 def _fusion_code(fusion_func):
     try:
         return _FUSION_CODES[fusion_func]

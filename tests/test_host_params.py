@@ -59,3 +59,17 @@ def test_embed3_2d():
     m, o = transformation.embed3(np.array([[1.0, 0.1], [0.2, 0.9]]), np.array([3.0, 4.0]))
     np.testing.assert_array_equal(m, [[1, 0, 0], [0, 1.0, 0.1], [0, 0.2, 0.9]])
     np.testing.assert_array_equal(o, [0, 3, 4])
+
+
+def test_builtin_maps_reference_function_objects_by_name():
+    """the reference's own function objects select the kernel mode of the same name."""
+    from multiview_stitcher_amd import fusion
+
+    def weighted_average_fusion(transformed_views, blending_weights, fusion_weights=None):   # stand-in for the reference's object
+        raise AssertionError
+
+    assert fusion.builtin(weighted_average_fusion) is fusion.weighted_average_fusion
+    assert fusion.builtin("max_fusion") is fusion.max_fusion
+    assert fusion.builtin(None) is None
+    with pytest.raises(NotImplementedError):
+        fusion.builtin(lambda x: x)
