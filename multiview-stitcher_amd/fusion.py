@@ -147,6 +147,13 @@ def fuse_np(
     input_dtype = np.dtype(sims[0].dtype)
     if input_dtype not in _lib.DTYPE_CODES:
         raise TypeError(f"unsupported dtype {input_dtype} (uint8/uint16/float32)")
+    if fusion_func not in _FUSION_CODES or (weights_func is not None and weights_func is not content_based):
+        # user callables (docs/extension_api_fusion.md): they run after the resample, so the chunk cannot be fused in one
+        # kernel; the voxel work that is ours (resample, blending weights) still runs on the device
+        return _fuse_np_with_callables(
+            sims, params, output_properties, fusion_func, fusion_func_kwargs, weights_func, weights_func_kwargs,
+            trim_overlap_in_pixels, interpolation_order, full_view_bbs, spacings, blending_widths, shrink_distance,
+            output_on_backend, device)
     fusion_code = _fusion_code(fusion_func)
     weights_code = _weights_code(weights_func)
 
@@ -213,6 +220,93 @@ def fuse_np(
     rc = lib.mvs_fuse_chunk(device, views, n, C.byref(opts), result.ctypes.data)
     _lib.check(rc, device, "mvs_fuse_chunk")
     return result
+
+
+def has_keyword(func, keyword):
+    """misc_utils.has_keyword (misc_utils.py:69-80): does ``func`` accept ``keyword``?"""
+    import inspect
+
+    try:
+        return keyword in inspect.signature(func).parameters
+    except (TypeError, ValueError):
+        return False
+
+
+def _fuse_np_with_callables(sims, params, output_properties, fusion_func, fusion_func_kwargs, weights_func,
+                            weights_func_kwargs, trim_overlap_in_pixels, interpolation_order, full_view_bbs, spacings,
+                            blending_widths, shrink_distance, output_on_backend, device):
+    """fuse_np for user-supplied ``fusion_func`` / ``weights_func`` callables (_core.py:1608-1733): every view is
+    resampled with mvs_resample (float32, NaN outside), blending weights come from mvs_blend_weights and are
+    normalised like weights.normalize_weights (weights.py:325-345); the callables then receive host float32
+    arrays exactly as in the reference (``transformed_views`` (V, *S), ``blending_weights``, ``fusion_weights``,
+    ``params``, ``output_spacing`` / ``output_chunksize`` when they ask for them)."""
+    from .transformation import transform_sim
+
+    fusion_func_kwargs = dict(fusion_func_kwargs or {})
+    weights_func_kwargs = dict(weights_func_kwargs or {})
+    sdims = si_utils.get_spatial_dims_from_sim(sims[0])
+    input_dtype = np.dtype(sims[0].dtype)
+    if spacings is None:
+        spacings = [fvb["spacing"] for fvb in full_view_bbs] if full_view_bbs is not None else [None] * len(sims)
+    if full_view_bbs is None:
+        full_view_bbs = [si_utils.get_stack_properties_from_sim(s) for s in sims]
+    out_bb = _bb_dicts(output_properties, sdims)
+
+    def host(a):
+        return a.get() if is_device_array(a) else np.asarray(a)
+
+    views_t = np.stack([
+        host(transform_sim(sim, np.linalg.inv(np.asarray(param, dtype=np.float64)), output_stack_properties=out_bb,
+                           input_spacing=spacing, order=interpolation_order, cval=np.nan, device=device,
+                           allow_noop=False).data).astype(np.float32, copy=False)
+        for sim, param, spacing in zip(sims, params, spacings)
+    ])
+    needs_blending = has_keyword(fusion_func, "blending_weights") or (
+        weights_func is not None and has_keyword(weights_func, "blending_weights"))
+    blend = None
+    if needs_blending:
+        blend = np.stack([
+            weights.get_blending_weights(out_bb, _bb_dicts(full_view_bbs[i], sdims), params[i], blending_widths,
+                                         shrink_distance, device)
+            for i in range(len(sims))
+        ])
+        blend = blend * ~np.isnan(views_t)
+        wsum = np.nansum(blend, axis=0)
+        wsum[wsum == 0] = 1
+        blend = blend / wsum
+    fusion_func_kwargs["transformed_views"] = views_t
+    if has_keyword(fusion_func, "params"):
+        fusion_func_kwargs["params"] = params
+    if has_keyword(fusion_func, "blending_weights"):
+        fusion_func_kwargs["blending_weights"] = blend
+    if has_keyword(fusion_func, "output_spacing") and "output_spacing" not in fusion_func_kwargs:
+        fusion_func_kwargs["output_spacing"] = out_bb["spacing"]
+    if weights_func is not None and has_keyword(fusion_func, "fusion_weights"):
+        if weights_func is content_based:
+            raise NotImplementedError("content_based weights with a custom fusion_func: pass a callable weights_func")
+        weights_func_kwargs["transformed_views"] = views_t
+        if has_keyword(weights_func, "params"):
+            weights_func_kwargs["params"] = params
+        if has_keyword(weights_func, "blending_weights"):
+            weights_func_kwargs["blending_weights"] = blend
+        if has_keyword(weights_func, "output_chunksize") and "output_chunksize" not in weights_func_kwargs:
+            weights_func_kwargs["output_chunksize"] = out_bb["shape"]
+        fusion_func_kwargs["fusion_weights"] = weights_func(**weights_func_kwargs)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", category=RuntimeWarning)   # func_ignore_nan_warning (_core.py:1684-1687)
+        fused = np.asarray(fusion_func(**fusion_func_kwargs))
+    if not isinstance(trim_overlap_in_pixels, dict):
+        trim = {d: int(trim_overlap_in_pixels) for d in sdims}
+    else:
+        trim = {d: int(trim_overlap_in_pixels.get(d, 0)) for d in sdims}
+    if any(trim[d] > 0 for d in sdims):
+        fused = fused[tuple(slice(trim[d], -trim[d]) if trim[d] > 0 else slice(None) for d in sdims)]
+    fused = np.nan_to_num(fused).astype(input_dtype)
+    if output_on_backend:
+        return DeviceArray.from_host(np.ascontiguousarray(fused), device)
+    return fused
 
 
 # --- output stack properties (_core.py:1736-1992) ---------------------------------------------

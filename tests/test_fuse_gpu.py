@@ -226,3 +226,36 @@ def test_more_than_64_views_on_one_column_falls_back(hip_device, kernel_path):
     out_bb = union_bb(bbs, params, np.ones(2))
     got, want, want_f = _run_both(sims, params, out_bb)
     assert_fused_close(got, want, want_f[0], noise_floor=want_f[1])
+
+
+def test_user_callables_get_device_resampled_views(hip_device):
+    """docs/extension_api_fusion.md: a custom fusion_func / weights_func receives the resampled float32 views, the
+    normalised blending weights and its own fusion weights; written like the built-in weighted average it must give
+    what mvs_fuse_chunk gives for the same chunk (the built-ins run fused, the callables on device-resampled arrays)."""
+    from multiview_stitcher_amd import fusion, spatial_image_utils as si
+
+    sims, params = _grid_case(2, np.float32, (2, 2), (50, 61), 9, True)
+    sdims = si.get_spatial_dims_from_sim(sims[0])
+    _, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(2))
+    seen = {}
+
+    def my_weights(transformed_views, blending_weights, params, gain=1.0):
+        seen["weights_args"] = (transformed_views.shape, blending_weights.shape, len(params), gain)
+        return np.full(transformed_views.shape, gain, np.float32)
+
+    def my_fusion(transformed_views, blending_weights, fusion_weights, output_spacing, params):
+        seen["fusion_args"] = (transformed_views.dtype, sorted(output_spacing), len(params))
+        additive = blending_weights * fusion_weights
+        wsum = np.nansum(additive, axis=0)
+        wsum[wsum == 0] = 1
+        return np.nansum(transformed_views * (additive / wsum), axis=0).astype(np.float32)
+
+    kw = dict(full_view_bbs=[bb_to_dicts(b, sdims) for b in bbs], trim_overlap_in_pixels=2)
+    got = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), fusion_func=my_fusion, weights_func=my_weights,
+                         weights_func_kwargs={"gain": 2.0}, **kw)
+    want = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), fusion_func=fusion.weighted_average_fusion, **kw)
+    assert got.dtype == want.dtype and got.shape == want.shape
+    assert seen["weights_args"][0] == (4,) + tuple(int(v) for v in out_bb["shape"]) and seen["weights_args"][2:] == (4, 2.0)
+    assert seen["fusion_args"] == (np.dtype(np.float32), sorted(sdims), 4)
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4 * float(np.max(want)))
