@@ -200,6 +200,17 @@ __device__ __forceinline__ void row_nodes(const RecRegs& R, int v, int zc, int y
     dG = G2 - G1;
 }
 
+// Buffer resource of view v's slab and the byte offset of the 8-voxel window of row (zc, yl) starting at chunk x = xl.
+template <typename TIn>
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t view_window(const RecRegs& R, int v, int zc, int yl, int xl, int& vo, int& nbytes) {
+    constexpr int ES = (int)sizeof(TIn);
+    const int sy = rec_field<F_ST_Y>(R, v), sz = rec_field<F_ST_Z>(R, v);
+    const unsigned long long dptr = ((unsigned long long)(unsigned)rec_field<F_DATA_HI>(R, v) << 32) | (unsigned)rec_field<F_DATA_LO>(R, v);
+    nbytes = rec_field<F_SPAN_LO>(R, v) * ES;
+    vo = (((zc + rec_field<F_IO_Z>(R, v)) * sz + (yl + rec_field<F_IO_Y>(R, v)) * sy) + (xl + rec_field<F_IO_X>(R, v))) * ES;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)dptr, 0, nbytes, 0x00020000);
+}
+
 // Values of view v at the lane's 8 voxels of row (zc, yl) starting at chunk x = xl: all stencil rows of the view are
 // fetched back-to-back with bounds-checked buffer loads, then interpolated (x, then z, then y).
 template <typename TIn>
@@ -362,15 +373,13 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
     }
     const bool all_unit = (allone_mask & ((1 << nv) - 1)) == ((1 << nv) - 1);
     TOut* out = (TOut*)P.out;
-    if (all_unit && !partial_mask && !ISF) {
-        bool allint = true;
+    bool allint = true;   // every view has an integer offset: one tap row per view
 #pragma unroll
-        for (int v = 0; v < NV; ++v)
-            if (v < nv) allint = allint && !(rec_fieldf<F_FW_Z>(R, v) > 0.f || rec_fieldf<F_FW_Y>(R, v) > 0.f || rec_fieldf<F_FW_X>(R, v) > 0.f);
-        if (allint) {
-            region_brick_avg<TIn, TOut, NV>(P, R, nv, z0b, z1, y0b, y1, x0b, x1, lane, lxb, strip);
-            return;
-        }
+    for (int v = 0; v < NV; ++v)
+        if (v < nv) allint = allint && !(rec_fieldf<F_FW_Z>(R, v) > 0.f || rec_fieldf<F_FW_Y>(R, v) > 0.f || rec_fieldf<F_FW_X>(R, v) > 0.f);
+    if (all_unit && !partial_mask && !ISF && allint) {
+        region_brick_avg<TIn, TOut, NV>(P, R, nv, z0b, z1, y0b, y1, x0b, x1, lane, lxb, strip);
+        return;
     }
 
     for (int p = 0; p < kRB; ++p) {
@@ -402,11 +411,36 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
 #pragma unroll
             for (int j = 0; j < kRV; ++j) { num[j] = 0.f; den[j] = 0.f; last[j] = 0.f; wlast[j] = 0.f; }
 
+            // integer offsets: the tap rows of ALL views are requested before the first one is consumed (one memory
+            // round trip per row group instead of one per view -- these kernels run at 2-3 wavefronts per SIMD)
+            // (measured: pays for NV = 4, costs 9 % for NV = 2, whose two loads already overlap well enough)
+            constexpr bool kBatch = NV >= 4;
+            unsigned int raw[NV][9];
+            if (kBatch && allint) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+                    if (v < nv) {
+                        int vo, nb;
+                        const __amdgpu_buffer_rsrc_t rs = view_window<TIn>(R, v, zc, yl, xl, vo, nb);
+                        Row8<TIn, false>::load(rs, vo, raw[v]);
+                    }
+            }
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
                 if (v >= nv) break;
                 float val[kRV];
-                fetch_val<TIn>(R, v, zc, yl, xl, strip, val);
+                if (kBatch && allint) {
+                    constexpr int WB = 9 * (int)sizeof(TIn);
+                    int vo, nb;
+                    const __amdgpu_buffer_rsrc_t rs = view_window<TIn>(R, v, zc, yl, xl, vo, nb);
+                    float e[9];
+                    Row8<TIn, false>::decode(raw[v], e);
+                    if (__any((vo < 0 && vo + WB > 0) || (vo < nb && vo + WB > nb))) row8_refetch<TIn>(rs, vo, e, strip);
+#pragma unroll
+                    for (int j = 0; j < kRV; ++j) val[j] = e[j];
+                } else {
+                    fetch_val<TIn>(R, v, zc, yl, xl, strip, val);
+                }
 
                 // views that cover the box only partly: per-voxel in-bounds test against the view's valid box
                 const bool partial = (partial_mask >> v) & 1;
@@ -436,8 +470,15 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
                     const float W0 = (u0 >= 0.f && inside) ? row_profile(u0, G1, dG) : 0.f;
                     const float W7 = (u7 >= 0.f && inside) ? row_profile(u7, G1, dG) : 0.f;
                     const bool lane_unit = fminf(W0, W7) >= 1.f;
+                    // Beyond the first support cell (u >= 1) a row whose nodes do not grow any more (dG == 0: the row lies in
+                    // the ramp of ANOTHER axis) has the same profile value G1 at all 8 voxels: one ramp evaluation per lane.
+                    const bool lane_flat = (fminf(u0, u7) >= 1.f) && (dG == 0.f);
                     if (!__any(!lane_unit)) unit = true;
-                    else {
+                    else if (!__any(!(lane_unit || lane_flat))) {
+                        const float w0 = blend_ramp_nb(W0);
+#pragma unroll
+                        for (int j = 0; j < kRV; ++j) w[j] = w0;
+                    } else {
 #pragma unroll
                         for (int j = 0; j < kRV; ++j) {
                             const float u = fminf(dl0 + (float)j, dh0 - (float)j) * kx;
