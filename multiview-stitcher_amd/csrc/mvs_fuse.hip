@@ -881,7 +881,7 @@ static void exact_valid_range(double off, int n, int n_out, int* lo_out, int* hi
 }
 
 // Decide whether a view qualifies for the translation fast path and derive its constants.
-static void prepare_translation_view(DevView* d, int order, int fusion, const int64_t chunk_shape[3]) {
+static void prepare_translation_view(DevView* d, int order, int fusion, const int64_t chunk_shape[3], size_t elem_size) {
     d->tr_ok = 0;
     static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     for (int k = 0; k < 9; ++k)
@@ -934,7 +934,8 @@ static void prepare_translation_view(DevView* d, int order, int fusion, const in
     }
     d->span = (long long)(d->nz - 1) * d->stride_z + (long long)(d->ny - 1) * d->stride_y + d->nx;
     if (d->stride_z > 0x7fffffffLL || d->stride_y > 0x7fffffffLL || d->stride_z < 0 || d->stride_y < 0) return;
-    if (d->span * 4 >= (1ll << 30)) return;   // 32-bit byte offsets in the buffer loads (any dtype <= 4 B)
+    // 32-bit signed byte offsets in the buffer loads; windows may start up to a few rows before / after the slab
+    if ((long long)d->span * (long long)elem_size >= (1ll << 31) - (1ll << 27) || (long long)d->stride_z * (long long)elem_size >= (1ll << 26)) return;
     for (int k = 0; k < 3; ++k) {
         const double off = d->off[k];
         if (order == 0) {
@@ -1135,7 +1136,7 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
         }
         rc = fill_dev_view(c, views[i], opts->ndim, dptr, &hviews[i]);
         if (rc) return rc;
-        prepare_translation_view(&hviews[i], opts->order, opts->fusion, opts->out_shape);
+        prepare_translation_view(&hviews[i], opts->order, opts->fusion, opts->out_shape, es);
     }
     bool use_tr = !c->force_generic;
     for (int i = 0; i < n_views && use_tr; ++i) use_tr = hviews[i].tr_ok != 0;
