@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--grid", type=str, default="4,4,4", help="tiles in z,y,x")
     ap.add_argument("--tile", type=str, default="512,512,512", help="tile shape z,y,x")
     ap.add_argument("--overlap-frac", type=float, default=0.2)
+    ap.add_argument("--reg-threads", type=int, default=None, help="host threads / context lanes for the pairwise registrations (library default: 6)")
     ap.add_argument("--no-register", action="store_true", help="time fusion only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=str, default="96,256,256", help="output region of the CPU baseline sample")
@@ -200,7 +201,8 @@ def main():
         key = key_in
         if do_register:
             registration.register(sims, transform_key=key_in, new_transform_key=key_out, device=local_rank,
-                                  pre_registration_pruning_method="keep_axis_aligned")
+                                  pre_registration_pruning_method="keep_axis_aligned",
+                                  n_parallel_pairwise_regs=args.reg_threads)
             key = key_out
         t_reg1 = time.perf_counter()
         fused = fusion.fuse(sims, transform_key=key, output_chunksize={d: 1 << 30 for d in "zyx"},

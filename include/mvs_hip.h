@@ -20,6 +20,12 @@
  *   - Threading: one context per device; calls on the same device serialise on
  *     an internal mutex and run on that context's HIP stream; calls on
  *     different devices are fully concurrent.
+ *   - Context lanes: a device argument may carry a lane number in bits 8..10
+ *     (`device | lane << 8`, lane < 8): every lane is an independent context on the
+ *     same GPU (own stream, scratch buffers, allocation pool and lock), so host
+ *     threads that work on independent units (image pairs) overlap on the device
+ *     instead of serialising on one lock.  Memory allocated through one lane can be
+ *     read by the others once the producing call has returned.
  *   - Ownership: the caller owns every pointer it passes for the duration of
  *     the call.  Device allocations made by mvs_malloc / mvs_upload_tile belong
  *     to the library until mvs_free.

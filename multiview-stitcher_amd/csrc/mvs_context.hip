@@ -4,11 +4,11 @@
 #include <algorithm>
 #include <cstring>
 
-static MvsContext g_ctx[MVS_MAX_DEVICES];
+static MvsContext g_ctx[MVS_MAX_DEVICES * MVS_MAX_LANES];
 
 MvsContext* mvs_ctx(int device) {
-    if (device < 0 || device >= MVS_MAX_DEVICES) return nullptr;
-    return &g_ctx[device];
+    if (device < 0 || (device & 0xff) >= MVS_MAX_DEVICES || (device >> 8) >= MVS_MAX_LANES) return nullptr;
+    return &g_ctx[mvs_ctx_index(device)];
 }
 
 int mvs_fail(MvsContext* c, int code, const char* fmt, ...) {
@@ -107,10 +107,10 @@ int mvs_init(int device) {
     if (c->ready) return MVS_OK;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || device >= n)
-        return mvs_fail(c, MVS_ERR_HIP, "no HIP device %d (count=%d, %s)", device, n,
+    if (e != hipSuccess || mvs_hip_device(device) >= n)
+        return mvs_fail(c, MVS_ERR_HIP, "no HIP device %d (count=%d, %s)", mvs_hip_device(device), n,
                         hipGetErrorString(e));
-    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     MVS_HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     MVS_HIP_TRY(c, hipEventCreate(&c->ev_start));
     MVS_HIP_TRY(c, hipEventCreate(&c->ev_stop));
@@ -125,7 +125,7 @@ void mvs_shutdown(int device) {
     MvsContext* c = mvs_ctx(device);
     if (!c || !c->ready) return;
     std::lock_guard<std::mutex> lock(c->mu);
-    hipSetDevice(device);
+    hipSetDevice(mvs_hip_device(device));
     hipStreamSynchronize(c->stream);
     {
         std::lock_guard<std::mutex> plock(c->pool_mu);
@@ -164,7 +164,7 @@ int mvs_set_stream(int device, void* hip_stream) {
     hipStream_t next = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     if (next != c->stream) {
         // recycled allocations and scratch are only ordered within one stream: drain the old one first
-        MVS_HIP_TRY(c, hipSetDevice(device));
+        MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
         MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     c->stream = next;
@@ -202,7 +202,7 @@ int mvs_synchronize(int device) {
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
-    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MVS_OK;
 }
@@ -211,7 +211,7 @@ double mvs_last_kernel_ms(int device) {
     MvsContext* c = mvs_ctx(device);
     if (!c || !c->ready || !c->timing_valid) return -1.0;
     std::lock_guard<std::mutex> lock(c->mu);
-    hipSetDevice(device);
+    hipSetDevice(mvs_hip_device(device));
     if (hipEventSynchronize(c->ev_stop) != hipSuccess) return -1.0;
     float ms = -1.f;
     if (hipEventElapsedTime(&ms, c->ev_start, c->ev_stop) != hipSuccess) return -1.0;
@@ -223,7 +223,7 @@ int mvs_malloc(int device, uint64_t nbytes, void** dev_ptr) {
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
     if (!dev_ptr) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_malloc: dev_ptr is NULL");
-    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     const size_t want = pool_round(nbytes);
     std::lock_guard<std::mutex> lock(c->pool_mu);
     auto it = c->pool_free.lower_bound(want);
@@ -249,7 +249,7 @@ int mvs_free(int device, void* dev_ptr) {
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
     if (!dev_ptr) return MVS_OK;
-    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     std::lock_guard<std::mutex> lock(c->pool_mu);
     auto it = c->pool_live.find(dev_ptr);
     if (it == c->pool_live.end()) {   // not ours (or freed twice): behave like hipFree
@@ -273,7 +273,7 @@ int mvs_memcpy_h2d(int device, void* dst_dev, const void* src_host, uint64_t nby
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
-    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     MVS_HIP_TRY(c, hipMemcpyAsync(dst_dev, src_host, nbytes, hipMemcpyHostToDevice, c->stream));
     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MVS_OK;
@@ -283,7 +283,7 @@ int mvs_memcpy_d2h(int device, void* dst_host, const void* src_dev, uint64_t nby
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
-    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     MVS_HIP_TRY(c, hipMemcpyAsync(dst_host, src_dev, nbytes, hipMemcpyDeviceToHost, c->stream));
     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MVS_OK;

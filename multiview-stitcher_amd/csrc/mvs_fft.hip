@@ -153,7 +153,7 @@ void host_fft_pow2(std::vector<double>& re, std::vector<double>& im) {
 
 int get_plan(MvsContext* c, int n, FftPlan* out) {
     std::lock_guard<std::mutex> lock(g_plan_mu);
-    const long long key = ((long long)c->device << 32) | (unsigned)n;
+    const long long key = ((long long)mvs_hip_device(c->device) << 32) | (unsigned)n;   // plans live on the GPU, whichever lane made them
     auto it = g_plans.find(key);
     if (it != g_plans.end()) { *out = it->second; return MVS_OK; }
     FftPlan p;

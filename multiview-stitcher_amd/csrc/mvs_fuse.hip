@@ -1093,7 +1093,7 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
     }
     if (opts->ndim == 2 && opts->out_shape[0] != 1)
         return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_fuse_chunk: 2D chunks need out_shape[0] == 1");
-    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
 
     if (opts->weights == MVS_WEIGHTS_CONTENT_BASED) {
         if (opts->fusion != MVS_FUSE_WEIGHTED_AVERAGE)
@@ -1295,7 +1295,7 @@ extern "C" int mvs_resample(int device, const mvs_view_t* view, const int64_t ou
     for (int k = 0; k < 3; ++k)
         if (out_shape[k] < 1 || out_shape[k] > 0x7fffffffLL)
             return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_resample: bad out_shape");
-    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     DevView d;
     rc = stage_single_view(c, view, 3, true, &d);
     if (rc) return rc;
@@ -1332,7 +1332,7 @@ extern "C" int mvs_blend_weights(int device, const mvs_view_t* view, int32_t ndi
     std::lock_guard<std::mutex> lock(c->mu);
     if (!view || !out_shape || !out) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_blend_weights: NULL argument");
     if (ndim != 2 && ndim != 3) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_blend_weights: ndim must be 2 or 3");
-    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     DevView d;
     rc = stage_single_view(c, view, ndim, false, &d);
     if (rc) return rc;

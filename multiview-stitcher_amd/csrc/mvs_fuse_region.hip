@@ -778,7 +778,7 @@ struct PlanCache {
     size_t rbytes = 0;
     bool valid = false;
 };
-PlanCache g_plan[MVS_MAX_DEVICES];
+PlanCache g_plan[MVS_MAX_DEVICES * MVS_MAX_LANES];
 
 unsigned long long fnv1a(const void* p, size_t n, unsigned long long h) {
     const unsigned char* b = (const unsigned char*)p;
@@ -862,7 +862,7 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
     unsigned long long h = fnv1a(htr, sizeof(TrView) * (size_t)n_views, 1469598103934665603ull);
     h = fnv1a(t, sizeof(t), h);
     h = fnv1a(o, sizeof(o), h);
-    PlanCache& pc = g_plan[c->device];
+    PlanCache& pc = g_plan[mvs_ctx_index(c->device)];
     char* dbuf = nullptr;
     int nitems = 0;
     size_t rbytes = 0;

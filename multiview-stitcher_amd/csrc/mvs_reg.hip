@@ -220,7 +220,7 @@ extern "C" int mvs_rescale_intensity(int device, const float* in, int32_t mem, i
     if (rc) return rc;
     std::lock_guard<std::mutex> lock(c->mu);
     if (!in || !out || n < 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_rescale_intensity: bad argument");
-    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     float* din;
     rc = mvs_stage_float_volume(c, in, mem, n, 4, &din);
     if (rc) return rc;
@@ -265,7 +265,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     for (int k = 0; k < 3; ++k)
         if (shape[k] < 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_phasecorr: bad shape");
     if (ndim == 2 && shape[0] != 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_phasecorr: 2D needs shape[0]==1");
-    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     const long long n = (long long)shape[0] * shape[1] * shape[2];
     const int nz = (int)shape[0], ny = (int)shape[1], nx = (int)shape[2];
 
@@ -437,7 +437,7 @@ extern "C" int mvs_bin_mean(int device, const void* in, int32_t dtype, int32_t m
         if (bin[k] < 1 || shape[k] < bin[k]) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_bin_mean: bad bin/shape on axis %d", k);
         o[k] = (int)(shape[k] / bin[k]);
     }
-    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     const void* din = in;
     long long sz = stride[0], sy = stride[1];
     if (mem == MVS_MEM_HOST) {

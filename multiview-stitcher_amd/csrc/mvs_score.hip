@@ -491,7 +491,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_score_candidates: bad argument");
     if (ndim != 2 && ndim != 3) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_score_candidates: ndim must be 2 or 3");
     if (ndim == 2 && shape[0] != 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_score_candidates: 2D needs shape[0]==1");
-    MVS_HIP_TRY(c, hipSetDevice(device));
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     const Shape3 S = {(int)shape[0], (int)shape[1], (int)shape[2]};
     const long long n = (long long)S.nz * S.ny * S.nx;
     if (n >= (1ll << 31) - 8) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_score_candidates: volume too large");

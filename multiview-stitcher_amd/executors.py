@@ -53,7 +53,7 @@ class DevicePairExecutor:
 
                 def local(m):
                     data = m.data if not hasattr(m, "scales") else None
-                    if data is not None and is_device_array(data) and data.device != dev:
+                    if data is not None and is_device_array(data) and (data.device & 0xff) != (dev & 0xff):   # another GPU (the high bits are a context lane)
                         return m.copy(data=DeviceArray.from_host(data.get(), dev))   # peer copy via host
                     return m
 

@@ -378,7 +378,7 @@ def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=Non
 
 def compute_pairwise_registrations(msims, edges, transform_key, registration_binning=None, overlap_tolerance=0.0,
                                    pairwise_reg_func=phase_correlation_registration, pairwise_reg_func_kwargs=None,
-                                   pairwise_executor=None, device=0, host_threads=1):
+                                   pairwise_executor=None, device=0, host_threads=6):
     """registration.compute_pairwise_registrations (registration.py:2622-2714): either hand all edges to a
     user ``pairwise_executor(msims, edges, register_kwargs)`` or loop over them on one device."""
     register_kwargs = dict(transform_key=transform_key, registration_binning=registration_binning,
@@ -391,18 +391,27 @@ def compute_pairwise_registrations(msims, edges, transform_key, registration_bin
         return results
     cache = _BinCache()
     edges = list(edges)
-    n_threads = max(1, min(int(host_threads), len(edges)))
+    n_threads = max(1, min(int(host_threads), len(edges), 8))   # 8 = context lanes per GPU (MVS_MAX_LANES)
     if n_threads == 1:
         return [register_pair_of_msims(msims[i], msims[j], device=device, _bin_cache=cache, **register_kwargs) for i, j in edges]
-    # Pairs are independent.  Every call into libmvs_hip.so releases the GIL and is serialised per device by the
-    # context lock, so with a few host threads the Python glue of one pair runs while the GPU works on another.
-    # Measured on the north-star mosaic this does not pay (the idle time sits inside the calls, at their host
-    # synchronisations), hence the default of one thread; results keep the order of `edges` either way.
+    # Pairs are independent.  Every call into libmvs_hip.so releases the GIL; each worker thread drives its own
+    # context lane (stream + scratch + lock) of the GPU, so the kernels of one pair fill the host round trips and
+    # the Python glue of another.  Results keep the order of `edges`.
+    import threading
     from concurrent.futures import ThreadPoolExecutor
 
+    lanes = {}
+    lane_lock = threading.Lock()
+
+    def work(i, j):
+        # each worker thread owns one context lane of the GPU (`device | lane << 8`: own stream, scratch and lock)
+        tid = threading.get_ident()
+        with lane_lock:
+            lane = lanes.setdefault(tid, len(lanes))
+        return register_pair_of_msims(msims[i], msims[j], device=(device & 0xff) | (lane << 8), _bin_cache=cache, **register_kwargs)
+
     with ThreadPoolExecutor(max_workers=n_threads) as pool:
-        futs = [pool.submit(register_pair_of_msims, msims[i], msims[j], device=device, _bin_cache=cache, **register_kwargs)
-                for i, j in edges]
+        futs = [pool.submit(work, i, j) for i, j in edges]
         return [f.result() for f in futs]
 
 
@@ -542,6 +551,7 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
         results = compute_pairwise_registrations(
             fields, edges, transform_key, registration_binning, overlap_tolerance, pairwise_reg_func,
             pairwise_reg_func_kwargs, pairwise_executor, device,
+            host_threads=(6 if n_parallel_pairwise_regs is None else n_parallel_pairwise_regs),
         )
         keep = list(range(len(edges)))
         if post_registration_do_quality_filter:

@@ -188,3 +188,19 @@ def test_constant_overlap_gives_identity_with_warning(hip_device):
         np.testing.assert_array_equal(s, s1)
         np.testing.assert_array_equal(dbg["peak_index"], dbg1["peak_index"])
         assert dbg["peak_abs"] == dbg1["peak_abs"]
+
+
+def test_context_lanes_give_identical_results(hip_device):
+    """`device | lane << 8` addresses an independent context on the same GPU: same numbers, and a buffer
+    produced through one lane is readable through another."""
+    from multiview_stitcher_amd import _reg_ops
+    from multiview_stitcher_amd.device import DeviceArray
+
+    a, b = _pair((24, 40, 36), (2, -3, 4))
+    a, b = np.nan_to_num(ro.rescale_intensity_01(a)), np.nan_to_num(ro.rescale_intensity_01(b))
+    want = _reg_ops.phase_cross_correlation(a, b, 2, "phase", device=0, return_debug=True)
+    da, db = DeviceArray.from_host(a, 0), DeviceArray.from_host(b, 1 << 8)      # lane 0 and lane 1 allocations
+    for dev in (1 << 8, 3 << 8):
+        got = _reg_ops.phase_cross_correlation(da, db, 2, "phase", device=dev, return_debug=True)
+        np.testing.assert_array_equal(got[0], want[0])
+        assert got[1]["peak_abs"] == want[1]["peak_abs"]
