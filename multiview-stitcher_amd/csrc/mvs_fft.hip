@@ -37,13 +37,48 @@ struct FftArgs {
     const float2* bfft;       // Bluestein: FFT_M of the wrapped conj chirp, scaled by 1/M
 };
 
-// radix-2 Stockham stages on `lpb` lines of length M held in LDS; returns the buffer holding the result
+// Stockham autosort stages on `lpb` lines of length M held in LDS: radix-4 passes (half the LDS round trips and
+// barriers of radix 2) plus one radix-2 pass when log2 M is odd.  `tw` = exp(-2 pi i m / M), m < M/2, also in LDS.
+// Returns the buffer holding the result.
+__device__ __forceinline__ float2 tw_at(const float2* tw, int m, int half) {   // exp(-2 pi i m / M) for m < M
+    const float2 w = tw[m & (half - 1)];
+    return (m & half) ? make_float2(-w.x, -w.y) : w;
+}
+
 __device__ __forceinline__ float2* stockham(float2* a, float2* b, int lpb, int M, int log2M, const float2* tw, bool inv) {
-    const int half = M >> 1;
-    for (int s = 0; s < log2M; ++s) {
+    const int half = M >> 1, quarter = M >> 2;
+    const int log2q = log2M - 2;
+    int s = 0;           // log2 of the current sub-transform length p
+    for (; s + 2 <= log2M; s += 2) {
         const int p = 1 << s;
-        for (int t = threadIdx.x; t < lpb * half; t += blockDim.x) {
-            const int line = t / half, i = t - line * half;
+        const int tstep = M >> (s + 2);                    // twiddle index step: w = exp(-2 pi i k / (4 p))
+        for (int t = threadIdx.x; t < (lpb << log2q); t += blockDim.x) {
+            const int line = t >> log2q, i = t & (quarter - 1);
+            const int k = i & (p - 1);
+            const int j = ((i - k) << 2) + k;
+            const float2* al = a + line * M;
+            float2 w1 = tw_at(tw, k * tstep, half), w2 = tw_at(tw, 2 * k * tstep, half), w3 = tw_at(tw, 3 * k * tstep, half);
+            if (inv) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+            const float2 a0 = al[i];
+            const float2 u1 = cmul(w1, al[i + quarter]), u2 = cmul(w2, al[i + 2 * quarter]), u3 = cmul(w3, al[i + 3 * quarter]);
+            const float2 s02 = make_float2(a0.x + u2.x, a0.y + u2.y), d02 = make_float2(a0.x - u2.x, a0.y - u2.y);
+            const float2 s13 = make_float2(u1.x + u3.x, u1.y + u3.y), d13 = make_float2(u1.x - u3.x, u1.y - u3.y);
+            // forward: -i * d13 = (d13.y, -d13.x); inverse: +i * d13 = (-d13.y, d13.x)
+            const float2 r13 = inv ? make_float2(-d13.y, d13.x) : make_float2(d13.y, -d13.x);
+            float2* bl = b + line * M;
+            bl[j] = make_float2(s02.x + s13.x, s02.y + s13.y);
+            bl[j + p] = make_float2(d02.x + r13.x, d02.y + r13.y);
+            bl[j + 2 * p] = make_float2(s02.x - s13.x, s02.y - s13.y);
+            bl[j + 3 * p] = make_float2(d02.x - r13.x, d02.y - r13.y);
+        }
+        __syncthreads();
+        float2* tmp = a; a = b; b = tmp;
+    }
+    if (s < log2M) {     // one radix-2 pass left
+        const int p = 1 << s;
+        const int log2h = log2M - 1;
+        for (int t = threadIdx.x; t < (lpb << log2h); t += blockDim.x) {
+            const int line = t >> log2h, i = t & (half - 1);
             const int k = i & (p - 1);
             const int j = ((i - k) << 1) + k;
             float2 w = tw[k * (half >> s)];
@@ -59,62 +94,98 @@ __device__ __forceinline__ float2* stockham(float2* a, float2* b, int lpb, int M
     return a;
 }
 
+// element offset of line l of this pass
+__device__ __forceinline__ long long line_base(const FftArgs& A, int l) {
+    const int inner = (int)A.inner;
+    return (long long)(l / inner) * A.outer_stride + (l % inner);
+}
+
 template <bool BLUESTEIN>
 __global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs A) {
     extern __shared__ float2 lds[];
     float2* buf0 = lds;
     float2* buf1 = lds + (size_t)A.lpb * A.M;
-    const long long l0 = (long long)blockIdx.x * A.lpb;
-    const int nl = (int)min((long long)A.lpb, A.n_lines - l0);
+    float2* tw = buf1 + (size_t)A.lpb * A.M;          // M/2 twiddles
+    const int l0 = blockIdx.x * A.lpb;
+    const int nl = min(A.lpb, (int)A.n_lines - l0);
     const bool inv = A.inverse != 0;
+    const int M = A.M, log2M = A.log2M, n = A.n, lpb = A.lpb;
+    for (int t = threadIdx.x; t < (M >> 1); t += blockDim.x) tw[t] = A.tw[t];
 
-    // ---- load: thread -> (k, line) with line fastest so adjacent x positions coalesce ----
-    for (int t = threadIdx.x; t < A.lpb * A.M; t += blockDim.x) {
-        int line, k;
-        if (A.stride == 1) { line = t / A.M; k = t - line * A.M; }
-        else { k = t / A.lpb; line = t - k * A.lpb; }
-        float2 v = make_float2(0.f, 0.f);
-        if (line < nl && k < A.n) {
-            const long long l = l0 + line;
-            const long long base = (l / A.inner) * A.outer_stride + (l % A.inner);
-            v = A.data[base + (long long)k * A.stride];
-            if (BLUESTEIN) {
-                if (inv) v.y = -v.y;              // IDFT(x) = conj(DFT(conj x))
-                v = cmul(v, A.chirp[k]);
+    // ---- load.  Along x (stride 1) a line is contiguous: threads run along k.  Along y / z the `lpb` lines of a
+    // workgroup are adjacent x positions: threads run along the lines first so that global accesses coalesce; a
+    // thread's line (and its base offset) is then the same in every iteration (lpb is a power of two <= 16). ----
+    if (A.stride == 1) {
+        for (int line = 0; line < lpb; ++line) {
+            const long long base = (line < nl) ? line_base(A, l0 + line) : 0;
+            for (int k = threadIdx.x; k < M; k += blockDim.x) {
+                float2 v = make_float2(0.f, 0.f);
+                if (line < nl && k < n) {
+                    v = A.data[base + k];
+                    if (BLUESTEIN) {
+                        if (inv) v.y = -v.y;              // IDFT(x) = conj(DFT(conj x))
+                        v = cmul(v, A.chirp[k]);
+                    }
+                }
+                buf0[line * M + k] = v;
             }
         }
-        buf0[line * A.M + k] = v;
+    } else {
+        const int line = threadIdx.x & (lpb - 1), kstep = blockDim.x / lpb;
+        const long long base = (line < nl) ? line_base(A, l0 + line) : 0;
+        for (int k = threadIdx.x / lpb; k < M; k += kstep) {
+            float2 v = make_float2(0.f, 0.f);
+            if (line < nl && k < n) {
+                v = A.data[base + (long long)k * A.stride];
+                if (BLUESTEIN) {
+                    if (inv) v.y = -v.y;
+                    v = cmul(v, A.chirp[k]);
+                }
+            }
+            buf0[line * M + k] = v;
+        }
     }
     __syncthreads();
 
     float2* r;
     if (!BLUESTEIN) {
-        r = stockham(buf0, buf1, A.lpb, A.M, A.log2M, A.tw, inv);
+        r = stockham(buf0, buf1, lpb, M, log2M, tw, inv);
     } else {
-        r = stockham(buf0, buf1, A.lpb, A.M, A.log2M, A.tw, false);
+        r = stockham(buf0, buf1, lpb, M, log2M, tw, false);
         float2* o = (r == buf0) ? buf1 : buf0;
-        for (int t = threadIdx.x; t < A.lpb * A.M; t += blockDim.x) {
-            const int k = t % A.M;
+        for (int t = threadIdx.x; t < (lpb << log2M); t += blockDim.x) {
+            const int k = t & (M - 1);
             r[t] = cmul(r[t], A.bfft[k]);
         }
         __syncthreads();
-        r = stockham(r, o, A.lpb, A.M, A.log2M, A.tw, true);
+        r = stockham(r, o, lpb, M, log2M, tw, true);
     }
 
     // ---- store ----
-    for (int t = threadIdx.x; t < A.lpb * A.n; t += blockDim.x) {
-        int line, k;
-        if (A.stride == 1) { line = t / A.n; k = t - line * A.n; }
-        else { k = t / A.lpb; line = t - k * A.lpb; }
-        if (line < nl) {
-            float2 v = r[line * A.M + k];
-            if (BLUESTEIN) {
-                v = cmul(v, A.chirp[k]);
-                if (inv) v.y = -v.y;
+    if (A.stride == 1) {
+        for (int line = 0; line < nl; ++line) {
+            const long long base = line_base(A, l0 + line);
+            for (int k = threadIdx.x; k < n; k += blockDim.x) {
+                float2 v = r[line * M + k];
+                if (BLUESTEIN) {
+                    v = cmul(v, A.chirp[k]);
+                    if (inv) v.y = -v.y;
+                }
+                A.data[base + k] = v;
             }
-            const long long l = l0 + line;
-            const long long base = (l / A.inner) * A.outer_stride + (l % A.inner);
-            A.data[base + (long long)k * A.stride] = v;
+        }
+    } else {
+        const int line = threadIdx.x & (lpb - 1), kstep = blockDim.x / lpb;
+        if (line < nl) {
+            const long long base = line_base(A, l0 + line);
+            for (int k = threadIdx.x / lpb; k < n; k += kstep) {
+                float2 v = r[line * M + k];
+                if (BLUESTEIN) {
+                    v = cmul(v, A.chirp[k]);
+                    if (inv) v.y = -v.y;
+                }
+                A.data[base + (long long)k * A.stride] = v;
+            }
         }
     }
 }
@@ -225,7 +296,7 @@ int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inver
         int lpb = std::max(1, std::min(16, 4096 / p.M));
         if (axis == 2) lpb = std::max(1, std::min(4, 2048 / p.M));
         A.lpb = lpb;
-        const size_t lds = 2ull * lpb * p.M * sizeof(float2);
+        const size_t lds = (2ull * lpb * p.M + p.M / 2 + 1) * sizeof(float2);   // two line buffers + the twiddles
         const long long nblocks = (A.n_lines + lpb - 1) / lpb;
         if (p.bluestein) {
             MVS_HIP_TRY(c, hipFuncSetAttribute((const void*)fft_lines_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

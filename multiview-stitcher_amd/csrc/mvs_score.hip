@@ -330,6 +330,87 @@ __global__ __launch_bounds__(256) void ssim_last_pass_kernel(Five P, Shape3 R, i
     if (threadIdx.x == 0) partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
+// 3D: the y pass and the x pass + SSIM of one candidate in ONE kernel.  A workgroup takes a 32 x 64 tile of the cropped
+// interior of one plane: the y-filtered values of the tile and its x halo (5 quantities) go to LDS (float32, the
+// rounding point of the separate passes), the x filter and the SSIM formula read them from there -- the y-filtered
+// arrays never touch memory, which removes 45 % of the HBM traffic of the three-pass version.
+template <int WIN>
+__global__ __launch_bounds__(256) void ssim_yx_fused_kernel(Five P, Shape3 R, float cov_norm, float C1, float C2, double* __restrict__ partial) {
+    constexpr int H = WIN / 2, pad = (WIN - 1) / 2, TY = 32, TX = 64, LX = TX + 2 * H, NL = kChunk + 2 * H;
+    __shared__ float s[5][TY][LX + 1];
+    const int cz = R.nz - 2 * pad, cy = R.ny - 2 * pad, cx = R.nx - 2 * pad;
+    double acc = 0.0;
+    if (cz > 0 && cy > 0 && cx > 0) {
+        const int nty = (cy + TY - 1) / TY, ntx = (cx + TX - 1) / TX;
+        const int ntiles = cz * nty * ntx;
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const int tx = tile % ntx, ty = (tile / ntx) % nty, z = pad + tile / (ntx * nty);
+            const int y0 = pad + ty * TY, x0 = pad + tx * TX;
+            // ---- y pass: column c of the tile (+ halo), 8 rows per item ----
+            for (int item = threadIdx.x; item < LX * (TY / kChunk); item += 256) {
+                const int c = item % LX, rc = item / LX;
+                const int base = z * R.ny * R.nx + reflect_index(x0 - H + c, R.nx);
+                const int r0 = y0 + rc * kChunk;
+                int off[NL];
+#pragma unroll
+                for (int k = 0; k < NL; ++k) off[k] = base + reflect_index(r0 - H + k, R.ny) * R.nx;
+#pragma unroll
+                for (int a = 0; a < 5; ++a) {
+                    float v[NL];
+#pragma unroll
+                    for (int k = 0; k < NL; ++k) v[k] = P.src[a][off[k]];
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) {
+                        double sum = 0.0;
+#pragma unroll
+                        for (int j = 0; j < WIN; ++j) sum += (double)v[k + j];
+                        s[a][rc * kChunk + k][c] = (float)(sum / (double)WIN);
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- x pass + SSIM: row `row` of the tile, 8 voxels per thread ----
+            {
+                const int row = threadIdx.x >> 3, ch = threadIdx.x & 7;
+                const int y = y0 + row;
+                if (y < R.ny - pad) {
+                    float f[5][kChunk];
+#pragma unroll
+                    for (int a = 0; a < 5; ++a) {
+                        float v[NL];
+#pragma unroll
+                        for (int k = 0; k < NL; ++k) v[k] = s[a][row][ch * kChunk + k];
+#pragma unroll
+                        for (int k = 0; k < kChunk; ++k) {
+                            double sum = 0.0;
+#pragma unroll
+                            for (int j = 0; j < WIN; ++j) sum += (double)v[k + j];
+                            f[a][k] = (float)(sum / (double)WIN);
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < kChunk; ++k) {
+                        if (x0 + ch * kChunk + k >= R.nx - pad) continue;
+                        const float a = f[0][k], b = f[1][k];
+                        const float vx = cov_norm * (f[2][k] - a * a);
+                        const float vy = cov_norm * (f[3][k] - b * b);
+                        const float vxy = cov_norm * (f[4][k] - a * b);
+                        const float A1 = 2.f * a * b + C1, A2 = 2.f * vxy + C2;
+                        const float B1 = a * a + b * b + C1, B2 = vx + vy + C2;
+                        acc += (double)((A1 * A2) / (B1 * B2));
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    __shared__ double sred[4];
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sred[0] + sred[1] + sred[2] + sred[3];
+}
+
 // folds the per-workgroup partials of one candidate's SSIM passes
 __global__ __launch_bounds__(256) void finish_region_kernel(const float* __restrict__ pmax, const int* __restrict__ phasnan,
                                                             const double* __restrict__ psum, RegionStats* __restrict__ out) {
@@ -468,10 +549,9 @@ void launch_ssim_passes(hipStream_t stream, const float* im0, const float* im1t,
                        ndim == 3 ? 0 : 1, P1, pmax, phasnan);
     float* const* last_src = setA;
     if (ndim == 3) {
-        for (int a = 0; a < 5; ++a) { P2.src[a] = setA[a]; P2.dst[a] = setB[a]; }
-        const long long items = (long long)((R.ny + kChunk - 1) / kChunk) * R.nz * R.nx;
-        hipLaunchKernelGGL(ssim_mid_pass_kernel<WIN>, dim3(grid_for(items)), dim3(256), 0, stream, P2, R);
-        last_src = setB;
+        for (int a = 0; a < 5; ++a) { P2.src[a] = setA[a]; P2.dst[a] = nullptr; }
+        hipLaunchKernelGGL(ssim_yx_fused_kernel<WIN>, dim3(kStatBlocks), dim3(256), 0, stream, P2, R, cov_norm, C1, C2, psum);
+        return;
     }
     for (int a = 0; a < 5; ++a) { P3.src[a] = last_src[a]; P3.dst[a] = nullptr; }
     hipLaunchKernelGGL(ssim_last_pass_kernel<WIN>, dim3(kStatBlocks), dim3(256), 0, stream, P3, R, ndim, cov_norm, C1, C2, psum);
