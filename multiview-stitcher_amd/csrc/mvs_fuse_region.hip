@@ -338,7 +338,7 @@ __device__ __forceinline__ void region_brick_avg(const RegionParams& P, const Re
 // registers and the row nodes of ramp-weighted views in per-view vector registers.
 template <typename TIn, typename TOut, int NV>
 __device__ __forceinline__ void region_brick(const RegionParams& P, const RecRegs& R, int nviews, int masks, int z0b, int z1,
-                                             int y0b, int y1, int x0b, int x1, int lane, int lxb, float* strip) {
+                                             int y0b, int y1, int x0b, int x1, int lane, int lxb, float* strip, float* nodes) {
     constexpr bool ISF = std::is_floating_point<TIn>::value;
     const int nv = nviews;   // <= NV
     const LaneMap L(lane, lxb);
@@ -382,30 +382,37 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
         return;
     }
 
-    for (int p = 0; p < kRB; ++p) {
-        const int zc = z0b + p;
-        if (zc >= z1) break;
-        // ---- row nodes of the views with ramp weights, for the 32 rows of this brick plane (lane = row) ----
-        float nG1[NV], ndG[NV];
-        int nin[NV];
+    // ---- row nodes (G1, dG, inside) of the views with ramp weights for the 32 rows x 4 planes of the brick: lane
+    // (row, plane pair) evaluates them once into a wavefront-private LDS table [view][plane][row][3] ----
+    if (!all_unit) {
+        const int row = lane & 31, pp = (lane >> 5) * 2;
 #pragma unroll
-        for (int v = 0; v < NV; ++v) { nG1[v] = 0.f; ndG[v] = 0.f; nin[v] = 0; }
-        if (!all_unit) {
+        for (int v = 0; v < NV; ++v) {
+            if (v < nv && !((allone_mask >> v) & 1)) {
 #pragma unroll
-            for (int v = 0; v < NV; ++v) {
-                if (v < nv && !((allone_mask >> v) & 1)) {
+                for (int q = 0; q < 2; ++q) {
+                    float G1, dG;
                     bool inside;
-                    row_nodes(R, v, zc, min(y0b + (lane & 31), y1 - 1), nG1[v], ndG[v], inside);
-                    nin[v] = inside ? 1 : 0;
+                    row_nodes(R, v, min(z0b + pp + q, z1 - 1), min(y0b + row, y1 - 1), G1, dG, inside);
+                    float* nd = nodes + ((v * kRB + pp + q) * 32 + row) * 3;
+                    nd[0] = G1; nd[1] = dG; nd[2] = inside ? 1.f : 0.f;
                 }
             }
         }
-        for (int g = 0; g < L.NG; ++g) {
-            const int yg = y0b + L.RG * g;
-            if (yg >= y1) break;
-            const int yc = yg + r;
-            const bool row_ok = yc < y1;
-            const int yl = row_ok ? yc : y1 - 1;
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // Row groups outside, planes inside: with fractional offsets consecutive planes share a tap plane, and this order
+    // re-reads it right away (L1 / L2 hit) instead of one whole brick plane later.
+    for (int g = 0; g < L.NG; ++g) {
+        const int yg = y0b + L.RG * g;
+        if (yg >= y1) break;
+        const int yc = yg + r;
+        const bool row_ok = yc < y1;
+        const int yl = row_ok ? yc : y1 - 1;
+        for (int p = 0; p < kRB; ++p) {
+            const int zc = z0b + p;
+            if (zc >= z1) break;
 
             float num[kRV], den[kRV], last[kRV], wlast[kRV];
 #pragma unroll
@@ -457,10 +464,9 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
                 bool unit = (allone_mask >> v) & 1;
                 float w[kRV];
                 if (!unit) {
-                    // nodes of my row come from lane (RG g + r) of the per-view node registers
-                    const int src = L.RG * g + r;
-                    const float G1 = __shfl(nG1[v], src), dG = __shfl(ndG[v], src);
-                    const int inside = __shfl(nin[v], src);
+                    const float* nd = nodes + ((v * kRB + p) * 32 + L.RG * g + r) * 3;
+                    const float G1 = nd[0], dG = nd[1];
+                    const int inside = nd[2] != 0.f;
                     const float kx = rec_fieldf<F_SK_X>(R, v);
                     const float dl0 = (float)(xl - rec_field<F_SILO_X>(R, v)) - rec_fieldf<F_SFLO_X>(R, v);
                     const float dh0 = (float)(rec_field<F_SIHI_X>(R, v) - xl) - rec_fieldf<F_SFHI_X>(R, v);
@@ -648,6 +654,62 @@ __global__ __launch_bounds__(256) void copy_region_kernel(RegionParams P, int it
     constexpr int WB = 9 * ES;
     TOut* out = (TOut*)P.out;
 
+    if (anyfrac) {
+        // Fractional offset: an output plane needs the tap planes z and z + 1, so the 4 planes of the brick share 3 of
+        // their 5 tap planes.  Per row group the 5 x 2 tap rows (y, y + 1) are requested once, back-to-back, interpolated
+        // along x once, and every plane pair is then combined in registers (2.5 instead of 4 row loads per output row).
+        const float ux = 1.f - wx, uy = 1.f - wy, uz = 1.f - wz;
+        const int np = min(z1 - z0b, kRB);                     // planes of this brick
+        for (int g = 0; g < L.NG; ++g) {
+            if (y0b + L.RG * g >= y1) break;
+            const int yc = y0b + L.RG * g + r;
+            const int yl = min(yc, y1 - 1);
+            unsigned int raw[kRB + 1][2][9];
+            int vo[kRB + 1];
+#pragma unroll
+            for (int q = 0; q <= kRB; ++q) {
+                const int zq = z0b + min(q, np);               // planes past the brick repeat the last needed one
+                vo[q] = ((zq + ioz) * sz + (yl + ioy) * sy + (xl + iox)) * ES;
+                Row8<TIn, true>::load(rsrc, vo[q], raw[q][0]);
+                Row8<TIn, true>::load(rsrc, vo[q] + sy * ES, raw[q][1]);
+            }
+            float lo0[kRV], lo1[kRV];
+#pragma unroll
+            for (int q = 0; q <= kRB; ++q) {
+                if (q > np) break;
+                float e0[9], e1[9];
+                Row8<TIn, true>::decode(raw[q][0], e0);
+                Row8<TIn, true>::decode(raw[q][1], e1);
+                const int o0 = vo[q], o1 = vo[q] + sy * ES;
+                if (__any(o0 < 0 || o1 + WB > nbytes)) {
+                    if (__any((o0 < 0 && o0 + WB > 0) || (o0 < nbytes && o0 + WB > nbytes))) row8_refetch<TIn>(rsrc, o0, e0, strip);
+                    if (__any((o1 < 0 && o1 + WB > 0) || (o1 < nbytes && o1 + WB > nbytes))) row8_refetch<TIn>(rsrc, o1, e1, strip);
+                }
+                float hi0[kRV], hi1[kRV];
+#pragma unroll
+                for (int j = 0; j < kRV; ++j) {
+                    hi0[j] = fmaf(e0[j + 1], wx, e0[j] * ux);
+                    hi1[j] = fmaf(e1[j + 1], wx, e1[j] * ux);
+                }
+                if (q > 0) {
+                    const int zc = z0b + q - 1;
+                    float o[kRV];
+#pragma unroll
+                    for (int j = 0; j < kRV; ++j) {
+                        const float s0 = fmaf(hi0[j], wz, lo0[j] * uz), s1 = fmaf(hi1[j], wz, lo1[j] * uz);
+                        const float vv = fmaf(s1, wy, s0 * uy);
+                        o[j] = (vv == vv) ? vv : 0.f;
+                    }
+                    if (yc < y1 && nvalid_x > 0)
+                        store8<TOut>(out + ((long long)(zc - P.tz) * P.oy + (yc - P.ty)) * (long long)P.ox + (xq - P.tx), o, nvalid_x);
+                }
+#pragma unroll
+                for (int j = 0; j < kRV; ++j) { lo0[j] = hi0[j]; lo1[j] = hi1[j]; }
+            }
+        }
+        return;
+    }
+
     for (int p = 0; p < kRB; ++p) {
         const int zc = z0b + p;
         if (zc >= z1) break;
@@ -723,6 +785,7 @@ __global__ __launch_bounds__(256) void copy_region_kernel(RegionParams P, int it
 template <typename TIn, typename TOut, int NVC>
 __global__ __launch_bounds__(256) void fuse_region_kernel(RegionParams P, int item0, int nitems) {
     __shared__ float s_strip[4][9 * 64];
+    __shared__ float s_nodes[4][(NVC ? NVC : 1) * kRB * 32 * 3];
     const int lane = threadIdx.x & 63;
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD k takes the k-th
     // contiguous eighth of the brick list -- neighbouring bricks, which share the cache lines at their edges and (with
@@ -764,7 +827,7 @@ __global__ __launch_bounds__(256) void fuse_region_kernel(RegionParams P, int it
         if ((NVC == 0 || NVC > 6) && nviews > 6 && va < nviews - 6) R.b = reinterpret_cast<const float4*>(P.views + idb)[qa];
     }
     if (NVC == 0) region_brick_generic<TIn, TOut>(P, R, rw, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane, lxb, strip);
-    else region_brick<TIn, TOut, (NVC ? NVC : 1)>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane, lxb, strip);
+    else region_brick<TIn, TOut, (NVC ? NVC : 1)>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane, lxb, strip, s_nodes[threadIdx.x >> 6]);
 }
 
 }  // namespace
