@@ -44,7 +44,7 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_mosaic_on_device(torch, dev, grid, tile, overlap, seed, max_jitter=3):
+def make_mosaic_on_device(torch, dev, grid, tile, overlap, seed, max_jitter=3, return_ground_truth=False):
     """Seeded synthetic mosaic generated in HBM: smoothed uniform noise ground truth (uint16, 0..4095)
     cut into overlapping tiles with an integer jitter the metadata does not know."""
     grid, tile, overlap = np.asarray(grid), np.asarray(tile), np.asarray(overlap)
@@ -83,6 +83,8 @@ def make_mosaic_on_device(torch, dev, grid, tile, overlap, seed, max_jitter=3):
         tiles.append(gt[sl].contiguous())
         jitters.append(jit)
         origins.append((idx * step).astype(float))
+    if return_ground_truth:      # (tests) ground-truth volume; world coordinate w of the mosaic sits at index w + pad
+        return tiles, np.array(jitters), np.array(origins), gt, pad
     del gt
     return tiles, np.array(jitters), np.array(origins)
 

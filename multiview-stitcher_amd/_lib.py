@@ -153,6 +153,11 @@ def i64x3(vals):
     return (C.c_int64 * 3)(*[int(v) for v in vals])
 
 
+def synchronize(device=0):
+    """Block until all work queued on the context's stream has finished (mvs_synchronize)."""
+    check(init(device).mvs_synchronize(int(device)), device, "mvs_synchronize")
+
+
 def last_kernel_ms(device=0):
     return float(load().mvs_last_kernel_ms(int(device)))
 

@@ -51,6 +51,14 @@ class DeviceArray:
         strides = [int(np.prod(shape[i + 1:])) for i in range(len(shape))]
         return cls(owner, ptr, shape, strides, dtype, device)
 
+    @property
+    def __cuda_array_interface__(self):
+        """Zero-copy hand-over to torch / cupy-style consumers (``torch.as_tensor(arr, device="cuda")``); the array must
+        stay alive while the consumer uses the memory, and the producing call must have been synchronised."""
+        item = self.dtype.itemsize
+        return {"shape": self.shape, "typestr": self.dtype.str, "data": (self.ptr, False), "version": 3,
+                "strides": None if self.is_contiguous() else tuple(s * item for s in self.strides)}
+
     def is_contiguous(self):
         expect = [int(np.prod(self.shape[i + 1:])) for i in range(self.ndim)]
         return all(s == e or n == 1 for s, e, n in zip(self.strides, expect, self.shape))
