@@ -82,6 +82,60 @@ __global__ __launch_bounds__(256) void gauss1d_kernel(const float* __restrict__ 
     }
 }
 
+// The same filter with the lines staged in LDS: a workgroup takes T adjacent lines, copies them (+ the reflected halo
+// of `radius` samples on both sides) into LDS once and every output reads its 2 * radius + 1 taps from there -- no
+// index arithmetic, no reflection and no global load per tap (the tap-by-tap kernel above spends its time there: the
+// sigma = 11 filter has 89 taps).  Same accumulation order, same rounding.  LDS layout [pos + radius][line], line
+// pitch T + 1 (odd) so that both access directions are bank-conflict free.
+struct GaussLines { long long n_lines; int len; long long stride; long long inner; long long outer_stride; int T; };
+
+__global__ __launch_bounds__(256) void gauss1d_lds_kernel(const float* __restrict__ src, float* __restrict__ dst, GaussLines L, int radius,
+                                                          const double* __restrict__ fw, int pos_fastest) {
+    extern __shared__ float sl[];
+    const int T = L.T, TP = T + 1, len = L.len;
+    const long long l0 = (long long)blockIdx.x * T;
+    const int nl = (int)min((long long)T, L.n_lines - l0);
+    const int total = T * len;
+    // ---- stage the lines ----
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        int line, pos;
+        if (pos_fastest) { line = idx / len; pos = idx - line * len; }
+        else { pos = idx / T; line = idx - pos * T; }
+        float v = 0.f;
+        if (line < nl) {
+            const long long l = l0 + line;
+            v = src[(l / L.inner) * L.outer_stride + (l % L.inner) + (long long)pos * L.stride];
+        }
+        sl[(pos + radius) * TP + line] = v;
+    }
+    __syncthreads();
+    // ---- reflected halo: d c b a | a b c d | d c b a (period 2 len) ----
+    for (int idx = threadIdx.x; idx < 2 * radius * T; idx += blockDim.x) {
+        const int h = idx / T, line = idx - h * T;
+        const int p = (h < radius) ? (h - radius) : (len + h - radius);      // position outside [0, len)
+        int q = p;
+        if (len == 1) q = 0;
+        else {
+            const int period = 2 * len;
+            q %= period; if (q < 0) q += period; if (q >= len) q = period - 1 - q;
+        }
+        sl[(p + radius) * TP + line] = sl[(q + radius) * TP + line];
+    }
+    __syncthreads();
+    // ---- filter ----
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        int line, pos;
+        if (pos_fastest) { line = idx / len; pos = idx - line * len; }
+        else { pos = idx / T; line = idx - pos * T; }
+        if (line >= nl) continue;
+        const float* c = sl + (pos + radius) * TP + line;
+        double acc = (double)c[0] * fw[radius];
+        for (int j = radius; j >= 1; --j) acc += ((double)c[-j * TP] + (double)c[j * TP]) * fw[radius - j];
+        const long long l = l0 + line;
+        dst[(l / L.inner) * L.outer_stride + (l % L.inner) + (long long)pos * L.stride] = (float)acc;
+    }
+}
+
 // Z = VV / WW with WW[nan] = 1, Z[nan] = NaN (weights.py:314-320); then D = (A - Z)^2, V1 = D with NaN -> 0
 __global__ void ng_finish_sq_kernel(const float* __restrict__ VV, const float* __restrict__ WW, const float* __restrict__ A,
                                     long long n, float* __restrict__ V1) {
@@ -236,7 +290,23 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
         int pass = 0;
         for (int axis = 3 - ndim; axis < 3; ++axis, ++pass) {
             float* d = (axis == 2) ? dst : tmp[pass & 1];
-            hipLaunchKernelGGL(gauss1d_kernel, dim3(gb), dim3(256), 0, c->stream, cur, d, S, axis, radius, fw);
+            // LDS-staged lines when a useful tile of them fits into 64 KiB; else the tap-by-tap kernel
+            GaussLines L;
+            const long long nz = S.nz, ny = S.ny, nx = S.nx;
+            if (axis == 2) { L.len = S.nx; L.stride = 1; L.n_lines = nz * ny; L.inner = 1; L.outer_stride = nx; }
+            else if (axis == 1) { L.len = S.ny; L.stride = nx; L.n_lines = nz * nx; L.inner = nx; L.outer_stride = ny * nx; }
+            else { L.len = S.nz; L.stride = ny * nx; L.n_lines = ny * nx; L.inner = ny * nx; L.outer_stride = 0; }
+            const int span = L.len + 2 * radius;
+            int T = (axis == 2) ? 8 : 32;
+            while (T > 1 && (size_t)span * (T + 1) * 4 > 60 * 1024) T >>= 1;
+            if ((size_t)span * (T + 1) * 4 <= 60 * 1024 && (axis == 2 || T >= 8)) {
+                L.T = T;
+                const size_t lds = (size_t)span * (T + 1) * 4;
+                const long long nb = (L.n_lines + T - 1) / T;
+                hipLaunchKernelGGL(gauss1d_lds_kernel, dim3((unsigned)nb), dim3(256), lds, c->stream, cur, d, L, radius, fw, axis == 2 ? 1 : 0);
+            } else {
+                hipLaunchKernelGGL(gauss1d_kernel, dim3(gb), dim3(256), 0, c->stream, cur, d, S, axis, radius, fw);
+            }
             cur = d;
         }
     };

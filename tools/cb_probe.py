@@ -1,0 +1,20 @@
+"""Content-based fusion (weights.content_based, C3-like): 2x2x2 grid of 256^3 u16 tiles, 256^3 output chunks (+ 22 px halo)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+from multiview_stitcher_amd import _lib, fusion
+from multiview_stitcher_amd import spatial_image_utils as si
+dev = torch.device("cuda", 0); _lib.init(0)
+grid, tile = np.array([2, 2, 2]), np.array([256, 256, 256])
+overlap = np.round(tile * 0.2).astype(int)
+tiles, jit, org = bench.make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=5, max_jitter=0)
+sims = bench.build_sims(tiles, org, 0)
+for rep in range(3):
+    t0 = time.perf_counter()
+    out = fusion.fuse(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, weights_func=fusion.content_based, output_chunksize={d: 256 for d in "zyx"},
+                      output_on_backend=True, device=0)
+    _lib.synchronize(0)
+    dt = time.perf_counter() - t0
+    print("content-based fuse %s: %.1f ms, %.1f Mvoxels/s" % (out.shape, dt * 1e3, np.prod(out.shape) / dt / 1e6), flush=True)
