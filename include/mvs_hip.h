@@ -116,6 +116,13 @@ int mvs_free(int device, void* dev_ptr);
 int mvs_memcpy_h2d(int device, void* dst_dev, const void* src_host, uint64_t nbytes);
 int mvs_memcpy_d2h(int device, void* dst_host, const void* src_dev, uint64_t nbytes);
 int mvs_upload_tile(int device, const void* host, int32_t dtype, const int64_t shape[3], void** dev_ptr);
+/* Stream-ordered byte fill of device memory (returns without waiting). */
+int mvs_memset(int device, void* dst_dev, int32_t byte_value, uint64_t nbytes);
+/* Device-to-device copy of a contiguous (z,y,x) box into a window of a larger contiguous array (both on this
+ * device; stream-ordered, returns without waiting): how the chunks of a chunked fuse() are assembled into one
+ * device-resident mosaic (the reference's chunks each go to their own zarr region, fusion/_core.py:1123-1141). */
+int mvs_copy_into(int device, const void* src_dev, int32_t dtype, const int64_t shape[3],
+                  void* dst_dev, const int64_t dst_shape[3], const int64_t dst_offset[3]);
 
 /* ---- fusion ------------------------------------------------------------------ *
  * mvs_fuse_chunk == the body of fusion.fuse_np (fusion/_core.py:1608-1713) for

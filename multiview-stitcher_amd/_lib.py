@@ -72,6 +72,9 @@ SIGNATURES = {
     "mvs_memcpy_h2d": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]),
     "mvs_memcpy_d2h": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]),
     "mvs_upload_tile": (C.c_int, [C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]),
+    "mvs_memset": (C.c_int, [C.c_int, C.c_void_p, C.c_int32, C.c_uint64]),
+    "mvs_copy_into": (C.c_int, [C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64),
+                                C.POINTER(C.c_int64)]),
     "mvs_fuse_chunk": (C.c_int, [C.c_int, C.POINTER(mvs_view_t), C.c_int32, C.POINTER(mvs_fuse_opts_t), C.c_void_p]),
     "mvs_resample": (C.c_int, [C.c_int, C.POINTER(mvs_view_t), C.POINTER(C.c_int64), C.c_int32, C.c_float, C.c_void_p, C.c_int32]),
     "mvs_blend_weights": (C.c_int, [C.c_int, C.POINTER(mvs_view_t), C.c_int32, C.POINTER(C.c_int64), C.c_void_p, C.c_int32]),

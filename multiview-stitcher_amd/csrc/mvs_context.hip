@@ -55,6 +55,10 @@ void* mvs_scratch(MvsContext* c, int slot, size_t nbytes) {
 void* mvs_pinned_slot(MvsContext* c, int slot, size_t nbytes) {
     void*& p = slot ? c->pinned2 : c->pinned;
     size_t& pc = slot ? c->pinned2_cap : c->pinned_cap;
+    if (c->pinned_pending[slot ? 1 : 0]) {
+        hipEventSynchronize(c->pinned_ev[slot ? 1 : 0]);
+        c->pinned_pending[slot ? 1 : 0] = false;
+    }
     if (nbytes <= pc && p) return p;
     if (p) {
         hipStreamSynchronize(c->stream);
@@ -74,6 +78,12 @@ void* mvs_pinned_slot(MvsContext* c, int slot, size_t nbytes) {
 }
 
 void* mvs_pinned(MvsContext* c, size_t nbytes) { return mvs_pinned_slot(c, 0, nbytes); }
+
+void mvs_pinned_mark(MvsContext* c, int slot) {
+    const int k = slot ? 1 : 0;
+    if (hipEventRecord(c->pinned_ev[k], c->stream) == hipSuccess) c->pinned_pending[k] = true;
+    else hipStreamSynchronize(c->stream);
+}
 
 static size_t pool_round(uint64_t nbytes) {
     if (nbytes == 0) nbytes = 1;
@@ -114,6 +124,9 @@ int mvs_init(int device) {
     MVS_HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     MVS_HIP_TRY(c, hipEventCreate(&c->ev_start));
     MVS_HIP_TRY(c, hipEventCreate(&c->ev_stop));
+    MVS_HIP_TRY(c, hipEventCreateWithFlags(&c->pinned_ev[0], hipEventDisableTiming));
+    MVS_HIP_TRY(c, hipEventCreateWithFlags(&c->pinned_ev[1], hipEventDisableTiming));
+    c->pinned_pending[0] = c->pinned_pending[1] = false;
     c->stream = c->own_stream;
     c->device = device;
     c->ready = true;
@@ -145,6 +158,9 @@ void mvs_shutdown(int device) {
     c->pinned_cap = c->pinned2_cap = 0;
     hipEventDestroy(c->ev_start);
     hipEventDestroy(c->ev_stop);
+    hipEventDestroy(c->pinned_ev[0]);
+    hipEventDestroy(c->pinned_ev[1]);
+    c->pinned_pending[0] = c->pinned_pending[1] = false;
     hipStreamDestroy(c->own_stream);
     c->own_stream = c->stream = nullptr;
     c->ready = false;
@@ -301,6 +317,60 @@ int mvs_upload_tile(int device, const void* host, int32_t dtype, const int64_t s
     rc = mvs_malloc(device, n, dev_ptr);
     if (rc) return rc;
     return mvs_memcpy_h2d(device, *dev_ptr, host, n);
+}
+
+// rows of `nbytes_row` bytes: src is contiguous (row r at r * nbytes_row), dst rows sit at (z * dst_pitch_z + y * dst_pitch_y)
+__global__ __launch_bounds__(256) void copy_box_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int nz, int ny,
+                                                       long long nbytes_row, long long dst_pitch_y, long long dst_pitch_z) {
+    const int rows = nz * ny;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int z = r / ny, y = r - z * ny;
+        const unsigned char* s = src + (long long)r * nbytes_row;
+        unsigned char* d = dst + (long long)z * dst_pitch_z + (long long)y * dst_pitch_y;
+        // 4-byte words when both ends allow it (element sizes are 1, 2, 4: the tails are at most 3 bytes)
+        const bool w4 = (((unsigned long long)s | (unsigned long long)d | (unsigned long long)nbytes_row) & 3ull) == 0;
+        if (w4) {
+            const long long nw = nbytes_row >> 2;
+            for (long long i = threadIdx.x; i < nw; i += blockDim.x) reinterpret_cast<unsigned int*>(d)[i] = reinterpret_cast<const unsigned int*>(s)[i];
+        } else {
+            for (long long i = threadIdx.x; i < nbytes_row; i += blockDim.x) d[i] = s[i];
+        }
+    }
+}
+
+int mvs_memset(int device, void* dst_dev, int32_t byte_value, uint64_t nbytes) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    if (!dst_dev && nbytes) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_memset: NULL pointer");
+    std::lock_guard<std::mutex> lock(c->mu);
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
+    if (nbytes) MVS_HIP_TRY(c, hipMemsetAsync(dst_dev, byte_value, nbytes, c->stream));
+    return MVS_OK;
+}
+
+int mvs_copy_into(int device, const void* src_dev, int32_t dtype, const int64_t shape[3], void* dst_dev, const int64_t dst_shape[3],
+                  const int64_t dst_offset[3]) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    const size_t es = mvs_dtype_size(dtype);
+    if (!es || !src_dev || !dst_dev || !shape || !dst_shape || !dst_offset)
+        return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_copy_into: bad argument");
+    for (int k = 0; k < 3; ++k)
+        if (shape[k] < 0 || dst_offset[k] < 0 || dst_offset[k] + shape[k] > dst_shape[k])
+            return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_copy_into: box does not fit into the destination");
+    if (shape[0] * shape[1] * shape[2] == 0) return MVS_OK;
+    if (shape[0] * shape[1] >= (1ll << 31)) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_copy_into: too many rows");
+    std::lock_guard<std::mutex> lock(c->mu);
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
+    const long long py = dst_shape[2] * (long long)es, pz = dst_shape[1] * py;
+    unsigned char* d0 = (unsigned char*)dst_dev + dst_offset[0] * pz + dst_offset[1] * py + dst_offset[2] * (long long)es;
+    const int rows = (int)(shape[0] * shape[1]);
+    hipLaunchKernelGGL(copy_box_kernel, dim3(std::min(rows, 65536)), dim3(256), 0, c->stream, (const unsigned char*)src_dev, d0, (int)shape[0],
+                       (int)shape[1], (long long)shape[2] * (long long)es, py, pz);
+    MVS_HIP_TRY(c, hipGetLastError());
+    return MVS_OK;
 }
 
 }  // extern "C"

@@ -1154,6 +1154,7 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
             xtab_total += (size_t)std::max(hviews[i].hi[2] - hviews[i].lo[2] + 1, 0) + 2 * kXTabMargin;
         }
     MVS_HIP_TRY(c, hipMemcpyAsync(dviews, hviews, params_bytes, hipMemcpyHostToDevice, c->stream));
+    mvs_pinned_mark(c, 0);
 
     const size_t out_bytes = (size_t)os[0] * os[1] * os[2] * es;
     void* dout = out;

@@ -327,7 +327,7 @@ __device__ __forceinline__ void region_brick_avg(const RegionParams& P, const Re
                 float q[kRV];
 #pragma unroll
                 for (int j = 0; j < kRV; ++j) q[j] = num[j] * rn;
-                if (yc < y1 && nvalid_x > 0)
+                if (gb + g < L.NG && yc < y1 && nvalid_x > 0)      // (thin bricks have fewer row groups than one batch)
                     store8<TOut>(out + ((long long)(zc - P.tz) * P.oy + (yc - P.ty)) * (long long)P.ox + (xq - P.tx), q, nvalid_x);
             }
         }
@@ -1058,6 +1058,7 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
         memcpy(hbuf, regions.data(), regions.size() * sizeof(Region));
         memcpy(hbuf + rbytes, items.data(), ibytes);
         MVS_HIP_TRY(c, hipMemcpyAsync(dbuf, hbuf, rbytes + ibytes, hipMemcpyHostToDevice, c->stream));
+        mvs_pinned_mark(c, 1);
         nitems = (int)items.size();
         pc.hash = h;
         pc.nitems = nitems;

@@ -43,6 +43,10 @@ struct MvsContext {
     size_t pinned_cap = 0;
     void* pinned2 = nullptr;
     size_t pinned2_cap = 0;
+    // an async upload out of a pinned staging buffer may still be in flight when the next call wants to refill it
+    // (calls that leave their result on the device return without synchronising): one event per staging slot
+    hipEvent_t pinned_ev[2] = {nullptr, nullptr};
+    bool pinned_pending[2] = {false, false};
     bool no_regions = false;      // test switch: skip the region kernel (use the column kernel)
     // caching device allocator behind mvs_malloc / mvs_free: freed blocks are kept (size-keyed) and handed out
     // again, because hipMalloc / hipFree cost ~0.4 ms each and the registration path allocates per pair.
@@ -59,7 +63,8 @@ int mvs_fail(MvsContext* c, int code, const char* fmt, ...);
 int mvs_check_ready(int device, MvsContext** out);     // locks nothing; returns code
 void* mvs_scratch(MvsContext* c, int slot, size_t nbytes);   // nullptr on failure (error set)
 void* mvs_pinned(MvsContext* c, size_t nbytes);
-void* mvs_pinned_slot(MvsContext* c, int slot, size_t nbytes);   // slot 0 == mvs_pinned
+void* mvs_pinned_slot(MvsContext* c, int slot, size_t nbytes);   // slot 0 == mvs_pinned; waits for the slot's last upload
+void mvs_pinned_mark(MvsContext* c, int slot);                    // call after enqueueing the copies that read the slot
 
 #define MVS_HIP_TRY(c, expr)                                                         \
     do {                                                                             \

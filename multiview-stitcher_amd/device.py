@@ -9,6 +9,8 @@ to ``mvs_fuse_chunk``.
 
 from __future__ import annotations
 
+import ctypes as C
+
 import numpy as np
 
 from . import _lib
@@ -50,6 +52,26 @@ class DeviceArray:
         shape = tuple(int(s) for s in shape)
         strides = [int(np.prod(shape[i + 1:])) for i in range(len(shape))]
         return cls(owner, ptr, shape, strides, dtype, device)
+
+    def fill_zero(self):
+        """Stream-ordered zero fill (contiguous arrays)."""
+        if not self.is_contiguous():
+            raise ValueError("fill_zero needs a contiguous array")
+        _lib.check(_lib.init(self.device).mvs_memset(self.device, C.c_void_p(self.ptr), 0, self.nbytes), self.device, "mvs_memset")
+
+    def copy_into(self, dst, offset):
+        """Copy this (contiguous) array into the window of the contiguous DeviceArray ``dst`` that starts at ``offset``
+        (device to device, stream-ordered: mvs_copy_into)."""
+        if not (self.is_contiguous() and dst.is_contiguous()) or self.dtype != dst.dtype or self.ndim > dst.ndim or dst.ndim > 3:
+            raise ValueError("copy_into needs contiguous arrays of one dtype, the source rank <= the destination rank <= 3")
+        if len(offset) != dst.ndim:
+            raise ValueError("one offset per destination axis")
+        s3 = (1,) * (3 - self.ndim) + tuple(self.shape)          # a lower-rank source is a box with leading extent 1
+        d3 = (1,) * (3 - dst.ndim) + tuple(dst.shape)
+        o3 = (0,) * (3 - dst.ndim) + tuple(int(v) for v in offset)
+        rc = _lib.init(dst.device).mvs_copy_into(dst.device, C.c_void_p(self.ptr), _lib.DTYPE_CODES[self.dtype], _lib.i64x3(s3),
+                                                 C.c_void_p(dst.ptr), _lib.i64x3(d3), _lib.i64x3(o3))
+        _lib.check(rc, dst.device, "mvs_copy_into")
 
     @property
     def __cuda_array_interface__(self):

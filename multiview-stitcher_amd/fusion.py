@@ -702,6 +702,7 @@ def fuse(
         if on_device:
             dev_out = DeviceArray.empty(out_shape_sp, dtype, device)
             single = len(plan["per_chunk_entries"]) == 1
+            zeroed = False
         for entry in plan["per_chunk_entries"]:
             bi = entry["block_index"]
             if chunk_filter is not None and not chunk_filter(bi):
@@ -734,20 +735,20 @@ def fuse(
             )
             if on_device and single:
                 fuse_np(out=dev_out, **kwargs)
+            elif on_device:
+                # chunked workflow with a device-resident mosaic: every chunk is fused on the device and copied into
+                # its window of the mosaic device-to-device (stream-ordered, no host round trip)
+                if not zeroed:
+                    dev_out.fill_zero()      # chunks without contributing views stay 0, like the host result
+                    zeroed = True
+                chunk = fuse_np(output_on_backend=True, **kwargs)
+                chunk.copy_into(dev_out, [s_.start for s_ in sl])
             else:
                 chunk = np.asarray(fuse_np(**kwargs))
                 if entry["fuse_planewise"]:
                     chunk = chunk[np.newaxis]
-                if on_device:
-                    # multi-chunk device output: stage through host (rare path)
-                    if result is None:
-                        result = np.zeros(ns_shape + out_shape_sp, dtype=dtype)
-                    result[tuple(ns_index) + sl] = chunk
-                else:
-                    result[tuple(ns_index) + sl] = chunk
+                result[tuple(ns_index) + sl] = chunk
         if on_device:
-            if not single:
-                dev_out = DeviceArray.from_host(result[tuple(ns_index)], device)
             result_data = dev_out
     if on_device:
         data = result_data

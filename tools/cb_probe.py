@@ -11,6 +11,7 @@ grid, tile = np.array([2, 2, 2]), np.array([256, 256, 256])
 overlap = np.round(tile * 0.2).astype(int)
 tiles, jit, org = bench.make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=5, max_jitter=0)
 sims = bench.build_sims(tiles, org, 0)
+torch.cuda.synchronize()   # the tiles are produced on torch's stream, the library runs on its own
 for rep in range(3):
     t0 = time.perf_counter()
     out = fusion.fuse(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, weights_func=fusion.content_based, output_chunksize={d: 256 for d in "zyx"},
