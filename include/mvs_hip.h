@@ -162,6 +162,11 @@ int mvs_phasecorr(int device, const float* fixed, const float* moving, int32_t m
                   int32_t ndim, const int64_t shape[3], int32_t normalization,
                   int32_t upsample_factor, double shift_out[3],
                   int64_t peak_index_out[3], float* peak_abs_out);
+/* In-place complex64 (interleaved re, im) transform of one C-contiguous (z,y,x) array == numpy.fft.fftn /
+ * ifftn (inverse != 0: conjugate transform WITHOUT the 1/N).  Any axis length up to 4096 (powers of two:
+ * Stockham; others: Bluestein).  The building block of mvs_phasecorr, exposed for tests and custom
+ * pairwise registration functions. */
+int mvs_fft_c2c(int device, void* data, int32_t mem, int32_t ndim, const int64_t shape[3], int32_t inverse);
 /* The same for n_norm normalisations of ONE image pair (the reference calls phase_cross_correlation
  * with "phase" and None on the same inputs, registration.py:413-431): the two forward transforms
  * are computed once.  shifts_out: n_norm x 3, peak_indices_out: n_norm x 3 (may be NULL),

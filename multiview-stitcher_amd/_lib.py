@@ -83,6 +83,7 @@ SIGNATURES = {
         [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.c_int32,
          C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_float)],
     ),
+    "mvs_fft_c2c": (C.c_int, [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int32]),
     "mvs_phasecorr_multi": (
         C.c_int,
         [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int32,

@@ -65,6 +65,15 @@ def phase_cross_correlation(reference_image, moving_image, upsample_factor=1, no
     return s
 
 
+def fftn(a, inverse=False, device=0):
+    """numpy.fft.fftn / ifftn (the inverse WITHOUT its 1/N) of a 2D / 3D complex64 host array on the GPU (mvs_fft_c2c)."""
+    lib = _lib.init(device)
+    out = np.ascontiguousarray(a, dtype=np.complex64).copy()
+    rc = lib.mvs_fft_c2c(device, out.ctypes.data, _lib.MVS_MEM_HOST, out.ndim, _lib.i64x3(shape3(out.shape)), 1 if inverse else 0)
+    _lib.check(rc, device, "mvs_fft_c2c")
+    return out
+
+
 def phase_cross_correlation_multi(reference_image, moving_image, upsample_factor=1, normalizations=("phase", None), device=0):
     """``phase_cross_correlation`` for several normalisations of one image pair; the forward transforms are
     shared (mvs_phasecorr_multi).  Returns a list of (shift, debug) like ``phase_cross_correlation(return_debug=True)``."""

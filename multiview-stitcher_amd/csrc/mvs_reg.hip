@@ -243,6 +243,32 @@ extern "C" int mvs_rescale_intensity(int device, const float* in, int32_t mem, i
     return MVS_OK;
 }
 
+// In-place complex64 (interleaved re, im) n-D transform of one C-contiguous (z,y,x) array: numpy.fft.fftn / ifftn
+// without the 1/N of the inverse.  The building block of mvs_phasecorr, exposed so that it can be checked on its own.
+extern "C" int mvs_fft_c2c(int device, void* data, int32_t mem, int32_t ndim, const int64_t shape[3], int32_t inverse) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (!data || !shape || (ndim != 2 && ndim != 3)) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_fft_c2c: bad argument");
+    for (int k = 0; k < 3; ++k)
+        if (shape[k] < 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_fft_c2c: bad shape");
+    if (ndim == 2 && shape[0] != 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_fft_c2c: 2D needs shape[0]==1");
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
+    const size_t bytes = (size_t)shape[0] * shape[1] * shape[2] * sizeof(float2);
+    float2* d = (float2*)data;
+    if (mem == MVS_MEM_HOST) {
+        d = (float2*)mvs_scratch(c, 6, bytes);
+        if (!d) return MVS_ERR_HIP;
+        MVS_HIP_TRY(c, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    rc = mvs_fft3_c2c(c, d, shape, inverse != 0);
+    if (rc) return rc;
+    if (mem == MVS_MEM_HOST) MVS_HIP_TRY(c, hipMemcpyAsync(data, d, bytes, hipMemcpyDeviceToHost, c->stream));
+    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MVS_OK;
+}
+
 extern "C" int mvs_phasecorr(int device, const float* fixed, const float* moving, int32_t mem, int32_t ndim,
                              const int64_t shape[3], int32_t normalization, int32_t upsample_factor,
                              double shift_out[3], int64_t peak_index_out[3], float* peak_abs_out) {

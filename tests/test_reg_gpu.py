@@ -204,3 +204,17 @@ def test_context_lanes_give_identical_results(hip_device):
         got = _reg_ops.phase_cross_correlation(da, db, 2, "phase", device=dev, return_debug=True)
         np.testing.assert_array_equal(got[0], want[0])
         assert got[1]["peak_abs"] == want[1]["peak_abs"]
+
+
+@pytest.mark.parametrize("shape", [(8, 8), (64, 128), (6, 10), (60, 104), (16, 32, 64), (5, 12, 27), (51, 64, 30)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fft_c2c_matches_numpy(hip_device, shape, inverse):
+    """mvs_fft_c2c against numpy.fft on general complex input (Stockham radix-4/2 for powers of two, Bluestein otherwise)."""
+    from multiview_stitcher_amd import _reg_ops
+
+    rng = np.random.default_rng(1)
+    a = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    want = np.fft.ifftn(a.astype(np.complex128)) * a.size if inverse else np.fft.fftn(a.astype(np.complex128))
+    got = _reg_ops.fftn(a, inverse=inverse)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 3e-6 * scale * np.log2(a.size)
