@@ -23,7 +23,7 @@ int mvs_device_nanminmax(MvsContext* c, const float* d_in, long long n, float* m
 
 namespace {
 
-constexpr int kStatBlocks = 512;     // workgroups (= partial results per candidate) of the statistics kernels
+constexpr int kStatBlocks = 1024;    // workgroups (= partial results per candidate) of the statistics kernels
 constexpr int kMaxResident = 16;     // shifted copies of the moving image kept per batch of candidates
 constexpr int kChunk = 8;            // outputs one thread produces along the filtered axis
 
