@@ -160,8 +160,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # one process per GPU; "nccl" is RCCL.  (MVS_BENCH_BACKEND=gloo and more ranks than GPUs are only for exercising
+    # this launch path on a box with fewer GPUs: ranks then share devices.)
+    backend = os.environ.get("MVS_BENCH_BACKEND", "nccl")
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and backend == "nccl":
+        raise SystemExit(f"{world} ranks but {n_dev} GPUs visible")
+    local_rank = local_rank % max(n_dev, 1)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -229,7 +239,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
