@@ -129,6 +129,8 @@ int mvs_init(int device) {
     c->pinned_pending[0] = c->pinned_pending[1] = false;
     c->stream = c->own_stream;
     c->device = device;
+    // extra lanes serve pair-sized work: keep their allocation caches small (lane 0 may hold whole mosaics)
+    c->pool_cache_limit = ((device >> 8) ? (size_t)4 : (size_t)32) << 30;
     c->ready = true;
     c->last_error.clear();
     return MVS_OK;
