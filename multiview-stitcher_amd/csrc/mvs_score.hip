@@ -330,13 +330,14 @@ __global__ __launch_bounds__(256) void ssim_last_pass_kernel(Five P, Shape3 R, i
     if (threadIdx.x == 0) partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 
-// 3D: the y pass and the x pass + SSIM of one candidate in ONE kernel.  A workgroup takes a 32 x 64 tile of the cropped
+// 3D: the y pass and the x pass + SSIM of one candidate in ONE kernel.  A workgroup takes a 32 x 56 tile of the cropped
 // interior of one plane: the y-filtered values of the tile and its x halo (5 quantities) go to LDS (float32, the
 // rounding point of the separate passes), the x filter and the SSIM formula read them from there -- the y-filtered
 // arrays never touch memory, which removes 45 % of the HBM traffic of the three-pass version.
 template <int WIN>
 __global__ __launch_bounds__(256) void ssim_yx_fused_kernel(Five P, Shape3 R, float cov_norm, float C1, float C2, double* __restrict__ partial) {
-    constexpr int H = WIN / 2, pad = (WIN - 1) / 2, TY = 32, TX = 64, LX = TX + 2 * H, NL = kChunk + 2 * H;
+    // tile: 32 rows x 56 voxels -> 62 (WIN = 7) halo columns x 4 row chunks = 248 y-pass items: one round of the 256 threads
+    constexpr int H = WIN / 2, pad = (WIN - 1) / 2, TY = 32, TX = 56, LX = TX + 2 * H, NL = kChunk + 2 * H;
     __shared__ float s[5][TY][LX + 1];
     const int cz = R.nz - 2 * pad, cy = R.ny - 2 * pad, cx = R.nx - 2 * pad;
     double acc = 0.0;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void ssim_yx_fused_kernel(Five P, Shape3 R, fl
             {
                 const int row = threadIdx.x >> 3, ch = threadIdx.x & 7;
                 const int y = y0 + row;
-                if (y < R.ny - pad) {
+                if (y < R.ny - pad && ch * kChunk < TX) {
                     float f[5][kChunk];
 #pragma unroll
                     for (int a = 0; a < 5; ++a) {
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256) void ssim_yx_fused_kernel(Five P, Shape3 R, fl
                     }
 #pragma unroll
                     for (int k = 0; k < kChunk; ++k) {
-                        if (x0 + ch * kChunk + k >= R.nx - pad) continue;
+                        if (x0 + ch * kChunk + k >= R.nx - pad || ch * kChunk + k >= TX) continue;
                         const float a = f[0][k], b = f[1][k];
                         const float vx = cov_norm * (f[2][k] - a * a);
                         const float vy = cov_norm * (f[3][k] - b * b);
