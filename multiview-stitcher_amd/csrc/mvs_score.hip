@@ -87,7 +87,7 @@ __device__ __forceinline__ int tap2(int i0, int n) {
 // consecutive voxels (one index decode, one 16-byte store).
 __global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im1, const float* __restrict__ im0,
                                                     float* __restrict__ out, Shape3 S, double tz, double ty, double tx,
-                                                    VoxStats* __restrict__ partial) {
+                                                    int skip_zero_taps, VoxStats* __restrict__ partial) {
     const unsigned int n = (unsigned int)S.nz * S.ny * S.nx;
     const unsigned int ngroups = (n + 3) / 4;
     unsigned long long cnt = 0;
@@ -111,7 +111,18 @@ __global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im
                     const double wz = cz - fz, wy = cy - fy, wx = cx - fx;
                     const int iz1 = tap2(iz, S.nz), iy1 = tap2(iy, S.ny), ix1 = tap2(ix, S.nx);
                     double acc = 0.0;
-                    // scipy accumulates coeff * wz * wy * wx over the taps in z-major order
+                    // scipy accumulates coeff * wz * wy * wx over the taps in z-major order.  A tap with weight 0 only matters
+                    // when it can be NaN or inf (0 * NaN = NaN): for an all-finite moving image the taps of axes with an
+                    // integer shift are skipped -- adding their +0.0 would not change the sum (1 / 2 / 4 taps instead of 8).
+                    if (skip_zero_taps) {
+                        const bool nz2 = wz != 0.0, ny2 = wy != 0.0, nx2 = wx != 0.0;
+                        for (int a = 0; a <= (nz2 ? 1 : 0); ++a)
+                            for (int b = 0; b <= (ny2 ? 1 : 0); ++b)
+                                for (int cidx = 0; cidx <= (nx2 ? 1 : 0); ++cidx)
+                                    acc += (double)im1[(a ? iz1 : iz) * sz + (b ? iy1 : iy) * sy + (cidx ? ix1 : ix)] * (a ? wz : 1.0 - wz) *
+                                           (b ? wy : 1.0 - wy) * (cidx ? wx : 1.0 - wx);
+                        r = (float)acc;
+                    } else {
                     acc += (double)im1[iz * sz + iy * sy + ix] * (1.0 - wz) * (1.0 - wy) * (1.0 - wx);
                     acc += (double)im1[iz * sz + iy * sy + ix1] * (1.0 - wz) * (1.0 - wy) * wx;
                     acc += (double)im1[iz * sz + iy1 * sy + ix] * (1.0 - wz) * wy * (1.0 - wx);
@@ -121,6 +132,7 @@ __global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im
                     acc += (double)im1[iz1 * sz + iy1 * sy + ix] * wz * wy * (1.0 - wx);
                     acc += (double)im1[iz1 * sz + iy1 * sy + ix1] * wz * wy * wx;
                     r = (float)acc;
+                    }
                 }
                 if (r == r) {
                     mnz = min(mnz, z); mny = min(mny, y); mnx = min(mnx, x);
@@ -154,6 +166,7 @@ __global__ __launch_bounds__(256) void image_stats_kernel(const float* __restric
             const float v = im[i0 + k];
             if (v == v) {
                 ++cnt;
+                if (fabsf(v) == INFINITY) cnt += 1ull << 32;   // #inf rides in the upper half (both counts stay < 2^31)
                 mnz = min(mnz, z); mny = min(mny, y); mnx = min(mnx, x);
                 mxz = max(mxz, z); mxy = max(mxy, y); mxx = max(mxx, x);
             }
@@ -623,7 +636,9 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     const int* bb0 = h_im[0].bb;
     const int* bbm = h_im[1].bb;
-    const unsigned int valid1 = (unsigned int)h_im[1].cnt;
+    const unsigned int valid1 = (unsigned int)(h_im[1].cnt & 0xffffffffull);
+    // every voxel of the moving image finite?  (lower half: #non-NaN, upper half: #inf, see image_stats_kernel)
+    const int im1_all_finite = ((long long)valid1 == n && (h_im[1].cnt >> 32) == 0) ? 1 : 0;
 
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     // analytic pre-test: upper bound of the mask count from the valid bounding boxes -- im1t can only be valid
@@ -684,7 +699,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             double t[3] = {0.0, 0.0, 0.0};
             for (int k = 0; k < ndim; ++k) t[k0 + k] = t_candidates[ic * ndim + k];
             hipLaunchKernelGGL(shift_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im1, im0, im1t_buf[j], S, t[0], t[1], t[2],
-                               vox_partial + (size_t)j * kStatBlocks);
+                               im1_all_finite, vox_partial + (size_t)j * kStatBlocks);
             resident[ic] = j;
         }
         hipLaunchKernelGGL(finish_voxstats_kernel, dim3(nb), dim3(256), 0, c->stream, vox_partial, vox_out);
@@ -793,7 +808,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             else {
                 double t[3] = {0.0, 0.0, 0.0};
                 for (int k = 0; k < ndim; ++k) t[k0 + k] = t_candidates[ic * ndim + k];
-                hipLaunchKernelGGL(shift_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im1, im0, im1t, S, t[0], t[1], t[2], vox_partial);
+                hipLaunchKernelGGL(shift_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im1, im0, im1t, S, t[0], t[1], t[2], im1_all_finite, vox_partial);
                 std::fill(resident.begin(), resident.end(), -1);
                 resident[ic] = 0;
             }
