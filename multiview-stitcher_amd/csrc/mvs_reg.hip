@@ -112,22 +112,28 @@ __global__ __launch_bounds__(256) void updft_x_kernel(const float2* __restrict__
 }
 
 // Generic later stage: in has shape (n_outer, n_red, n_inner) -> out (n_outer, U, n_inner):
-// out[o][b][i] = sum_r K[b][r] * in[o][r][i]; one thread per output element (sizes are tiny here).
-__global__ void updft_mid_kernel(const float2* __restrict__ in, const float2* __restrict__ K, float2* __restrict__ out,
-                                 int n_outer, int n_red, int n_inner, int U) {
+// out[o][b][i] = sum_r K[b][r] * in[o][r][i]; one wavefront per output element, lanes stride over r (the outputs are
+// few -- U^2 nz or U^3 -- and the reduction long, so a thread per output would leave the GPU idle behind a serial loop).
+__global__ __launch_bounds__(256) void updft_mid_kernel(const float2* __restrict__ in, const float2* __restrict__ K, float2* __restrict__ out,
+                                                        int n_outer, int n_red, int n_inner, int U) {
     const long long total = (long long)n_outer * U * n_inner;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    for (long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); t < total; t += (long long)gridDim.x * 4) {
         const int i = (int)(t % n_inner);
         const int b = (int)((t / n_inner) % U);
         const int o = (int)(t / ((long long)n_inner * U));
         float2 acc = make_float2(0.f, 0.f);
-        for (int r = 0; r < n_red; ++r) {
+        for (int r = lane; r < n_red; r += 64) {
             const float2 v = in[((long long)o * n_red + r) * n_inner + i];
             const float2 k = K[b * n_red + r];
             acc.x += k.x * v.x - k.y * v.y;
             acc.y += k.x * v.y + k.y * v.x;
         }
-        out[t] = acc;
+        for (int off = 32; off > 0; off >>= 1) {
+            acc.x += __shfl_down(acc.x, off);
+            acc.y += __shfl_down(acc.y, off);
+        }
+        if (lane == 0) out[t] = acc;
     }
 }
 
@@ -387,12 +393,12 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
         // stage 1: x  -> (z, y, ux)
         hipLaunchKernelGGL(updft_x_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, P, dk + koff[2], o1, nrows, nx, U);
         // stage 2: y  -> (z, uy, ux)
-        hipLaunchKernelGGL(updft_mid_kernel, dim3(grid_for((long long)s2)), dim3(256), 0, c->stream, o1, dk + koff[1], o2, nz, ny, U, U);
+        hipLaunchKernelGGL(updft_mid_kernel, dim3((unsigned)std::min<long long>(((long long)s2 + 3) / 4, 4096)), dim3(256), 0, c->stream, o1, dk + koff[1], o2, nz, ny, U, U);
         size_t nout = s2;
         float2* res = o2;
         if (ndim == 3) {
             // stage 3: z -> (uz, uy, ux)
-            hipLaunchKernelGGL(updft_mid_kernel, dim3(grid_for((long long)s3)), dim3(256), 0, c->stream, o2, dk + koff[0], o3, 1, nz, U * U, U);
+            hipLaunchKernelGGL(updft_mid_kernel, dim3((unsigned)std::min<long long>(((long long)s3 + 3) / 4, 4096)), dim3(256), 0, c->stream, o2, dk + koff[0], o3, 1, nz, U * U, U);
             nout = s3;
             res = o3;
         }
