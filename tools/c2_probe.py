@@ -19,3 +19,10 @@ for rep in range(3):
     rec = np.array([param_utils.select_time(si.get_affine_from_sim(s, "reg"), 0)[:2, 2] for s in sims])
     print("C2 %s: register %.1f ms, fuse %.1f ms, %.0f Mvoxels/s; max |recovered - jitter| = %.3g px" % (
         out.shape, (t1 - t0) * 1e3, (t2 - t1) * 1e3, np.prod(out.shape) / (t2 - t0) / 1e6, np.abs(rec - (jit - jit[0])).max()), flush=True)
+if os.environ.get("MVS_PROFILE"):
+    import cProfile, pstats
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(3):
+        out = fusion.fuse(sims, transform_key="reg", output_chunksize={d: 2048 for d in "yx"}, output_on_backend=True, device=0)
+    _lib.synchronize(0)
+    pr.disable(); pstats.Stats(pr).sort_stats("tottime").print_stats(14)
