@@ -62,11 +62,14 @@ def get_chunk_bbs(array_bb, chunksizes):
     return chunk_bbs, block_indices
 
 
+_UNIT_CORNERS = {n: np.array(list(np.ndindex(tuple([2] * n)))) for n in (2, 3)}   # corners of the unit cube, last axis fastest
+
+
 def get_vertices_from_stack_props(stack_props):
     """mv_graph.get_vertices_from_stack_props (mv_graph.py:423-444)."""
     ndim = len(stack_props["origin"])
     sdims = SPATIAL_DIMS[-ndim:]
-    gv = np.array(list(np.ndindex(tuple([2] * ndim))))
+    gv = _UNIT_CORNERS[ndim]
     vertices = gv * (np.array([stack_props["shape"][d] for d in sdims]) - 1) * np.array(
         [stack_props["spacing"][d] for d in sdims]
     ) + np.array([stack_props["origin"][d] for d in sdims])

@@ -25,23 +25,24 @@ def _as_array(x):
 
 def _enumerate_candidates(shift_candidates, shape, ndim):
     """registration.py:453-477: per shift estimate and per axis with a non-zero shift the four variants
-    {s, -s, -(s - N), -s - N}; keep |t| < max over ALL dims of the image shape."""
-    max_shift_per_dim = np.max([shape, shape])
+    {s, -s, -(s - N), -s - N}; keep |t| < max over ALL dims of the image shape.  Same order as the reference's
+    nested loops (itertools.product over the axes, last axis fastest); plain Python floats, no per-element numpy calls."""
+    import itertools
+
+    max_shift_per_dim = float(max(shape))
     t_candidates = []
     for shift_candidate in shift_candidates:
-        for s in np.ndindex(tuple([1 if shift_candidate[d] == 0 else 4 for d in range(ndim)])):
-            t = []
-            for d in range(ndim):
-                if s[d] == 0:
-                    t.append(shift_candidate[d])
-                elif s[d] == 1:
-                    t.append(-shift_candidate[d])
-                elif s[d] == 2:
-                    t.append(-(shift_candidate[d] - shape[d]))
-                elif s[d] == 3:
-                    t.append(-shift_candidate[d] - shape[d])
-            if np.max(np.abs(t)) < max_shift_per_dim:
-                t_candidates.append(t)
+        per_axis = []
+        for d in range(ndim):
+            sc = shift_candidate[d]
+            if sc == 0:
+                per_axis.append((sc,))
+            else:
+                n = shape[d]
+                per_axis.append((sc, -sc, -(sc - n), -sc - n))
+        for t in itertools.product(*per_axis):
+            if max(abs(v) for v in t) < max_shift_per_dim:
+                t_candidates.append(list(t))
     return t_candidates
 
 

@@ -29,4 +29,4 @@ if os.environ.get("MVS_PROFILE"):
         registration.register(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, new_transform_key="reg", device=0,
                               pre_registration_pruning_method="keep_axis_aligned")
     pr.disable()
-    pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+    pstats.Stats(pr).sort_stats("tottime").print_stats(40)
