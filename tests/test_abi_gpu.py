@@ -1,0 +1,49 @@
+"""GPU: error behaviour and memory helpers of the C ABI (include/mvs_hip.h): 0 = ok, negative = error with a message in
+mvs_last_error(device); the Python shim turns that into RuntimeError."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_invalid_arguments_return_codes_and_messages(hip_device):
+    from multiview_stitcher_amd import _lib
+
+    lib = _lib.init(0)
+    a = np.zeros((4, 4), np.float32)
+    shape = _lib.i64x3((1, 4, 4))
+    shift, peak, pabs = (C.c_double * 3)(), (C.c_int64 * 3)(), C.c_float()
+    rc = lib.mvs_phasecorr(0, a.ctypes.data, a.ctypes.data, _lib.MVS_MEM_HOST, 4, shape, 1, 1, shift, peak, C.byref(pabs))   # ndim 4
+    assert rc < 0 and b"ndim" in lib.mvs_last_error(0)
+    rc = lib.mvs_phasecorr(0, None, a.ctypes.data, _lib.MVS_MEM_HOST, 2, shape, 1, 1, shift, peak, C.byref(pabs))
+    assert rc < 0 and lib.mvs_last_error(0)
+    with pytest.raises(RuntimeError, match="mvs_phasecorr"):
+        _lib.check(rc, 0, "mvs_phasecorr")
+    # transform lengths above 4096 are refused, not silently mishandled
+    big = np.zeros((1, 2, 4100), np.complex64)
+    rc = lib.mvs_fft_c2c(0, big.ctypes.data, _lib.MVS_MEM_HOST, 2, _lib.i64x3((1, 2, 4100)), 0)
+    assert rc < 0 and b"4096" in lib.mvs_last_error(0)
+
+
+def test_pool_recycles_blocks_and_copy_into_checks_bounds(hip_device):
+    from multiview_stitcher_amd import _lib
+    from multiview_stitcher_amd.device import DeviceArray
+
+    lib = _lib.init(0)
+    p1, p2 = C.c_void_p(), C.c_void_p()
+    assert lib.mvs_malloc(0, 3 << 20, C.byref(p1)) == 0
+    assert lib.mvs_free(0, p1) == 0
+    assert lib.mvs_malloc(0, 3 << 20, C.byref(p2)) == 0          # same size class: the cached block comes back
+    assert p2.value == p1.value
+    assert lib.mvs_free(0, p2) == 0
+    small = DeviceArray.from_host(np.ones((4, 4), np.uint16), 0)
+    dst = DeviceArray.empty((6, 6), np.uint16, 0)
+    with pytest.raises(RuntimeError, match="does not fit"):
+        small.copy_into(dst, (3, 0))
+    dst.fill_zero()
+    small.copy_into(dst, (2, 1))
+    want = np.zeros((6, 6), np.uint16)
+    want[2:6, 1:5] = 1
+    np.testing.assert_array_equal(dst.get(), want)
