@@ -415,11 +415,20 @@ def process_output_chunksize(sims, output_chunksize):
 
 
 # --- chunk -> view-slab planner (_core.py:354-722) ---------------------------------------------
+def _isclose(a, b, atol):
+    """np.isclose(a, b, atol=atol) (rtol 1e-5) for Python scalars -- the planner calls it thousands of times per plan
+    and numpy's array machinery costs ~5 us per call."""
+    a, b = float(a), float(b)
+    if a == b:
+        return True
+    return abs(a - b) <= atol + 1e-5 * abs(b)       # False for NaN, like numpy
+
+
 def _is_grid_aligned(offset, spacing, tol=1e-6):
     if spacing == 0:
         return False
-    po = offset / spacing
-    return bool(np.isclose(po, np.round(po), atol=tol))
+    po = float(offset) / float(spacing)
+    return _isclose(po, round(po), tol) if np.isfinite(po) else False
 
 
 def _param_entry(param, sdims, din, dout):
@@ -434,13 +443,13 @@ def _get_axis_aligned_translation_dims(sparams, sdims, tol=1e-6):
         others = [d for d in sdims if d != dim]
         ok = True
         for p in sparams:
-            if not np.isclose(_param_entry(p, sdims, dim, dim), 1, atol=tol):
+            if not _isclose(_param_entry(p, sdims, dim, dim), 1, tol):
                 ok = False
                 break
-            if any(not np.isclose(_param_entry(p, sdims, dim, o), 0, atol=tol) for o in others):
+            if any(not _isclose(_param_entry(p, sdims, dim, o), 0, tol) for o in others):
                 ok = False
                 break
-            if any(not np.isclose(_param_entry(p, sdims, o, dim), 0, atol=tol) for o in others):
+            if any(not _isclose(_param_entry(p, sdims, o, dim), 0, tol) for o in others):
                 ok = False
                 break
         if ok:
@@ -455,7 +464,7 @@ def _get_grid_aligned_translation_dims(sparams, views_bb, output_stack_propertie
     for dim in sdims:
         if dim not in axis_aligned:
             continue
-        if any(not np.isclose(output_stack_properties["spacing"][dim], vbb["spacing"][dim], atol=tol) for vbb in views_bb):
+        if any(not _isclose(output_stack_properties["spacing"][dim], vbb["spacing"][dim], tol) for vbb in views_bb):
             continue
         ok = True
         for iview, p in enumerate(sparams):
