@@ -204,6 +204,20 @@ int mvs_score_candidates(int device, const float* fixed, const float* moving, in
                          int32_t quality_for_all,
                          double* ssim_out, double* spearman_out, int32_t* code_out);
 
+/* The whole of registration.phase_correlation_registration (registration.py:353-565) for two same-shape
+ * float32 overlap crops (NaN = outside the view) in one call: intensity normalisation, the two phase
+ * correlations, the zero-shift candidate when a crop holds NaNs (quirk Q1), candidate enumeration, scoring and
+ * the nanargmax selection with the reference's list bookkeeping (quirk Q3).  upsample_factor: the reference uses
+ * 10 in 2D and 2 in 3D; region_mode -1 = the reference's choice ("intersection" with NaNs, else "union");
+ * constant_check != 0 adds dispatch_pairwise_reg_func's guard (registration.py:1500-1520).
+ * t_out: translation (z,y,x; fixed px -> moving px), quality_out: Spearman coefficient of the selected candidate.
+ * status_out: 0 = ok, 1 = no admissible candidate (the reference returns [zeros(ndim)], quirk Q2),
+ * 2 = constant crop (identity, quality NaN), 3 = no finite SSIM (np.nanargmax raises in the reference). */
+int mvs_register_crops(int device, const float* fixed, const float* moving, int32_t mem, int32_t ndim,
+                       const int64_t shape[3], int32_t upsample_factor, int32_t region_mode,
+                       int32_t constant_check, double t_out[3], double* quality_out,
+                       int32_t* status_out, int32_t* n_candidates_out);
+
 #ifdef __cplusplus
 }
 #endif

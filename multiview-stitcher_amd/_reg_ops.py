@@ -104,6 +104,27 @@ def phase_cross_correlation_multi(reference_image, moving_image, upsample_factor
     return out
 
 
+def register_crops(im0, im1, upsample_factor, region_mode=None, constant_check=False, device=0):
+    """registration.phase_correlation_registration in one library call (mvs_register_crops).  Returns
+    (t (ndim,) float64, quality, status, n_candidates); status as documented in include/mvs_hip.h."""
+    lib = _lib.init(device)
+    shape = tuple(int(s) for s in im0.shape)
+    ndim = len(shape)
+    p0, m0, k0 = _ptr_mem(im0)
+    p1, m1, k1 = _ptr_mem(im1)
+    if m0 != m1:
+        raise TypeError("both images must live on the same side (host or device)")
+    t = (C.c_double * 3)()
+    q = C.c_double()
+    status = C.c_int32()
+    ncand = C.c_int32()
+    mode = -1 if region_mode is None else {"union": 0, "intersection": 1}[region_mode]
+    rc = lib.mvs_register_crops(device, p0, p1, m0, ndim, _lib.i64x3(shape3(shape)), int(upsample_factor), mode, int(bool(constant_check)),
+                                t, C.byref(q), C.byref(status), C.byref(ncand))
+    _lib.check(rc, device, "mvs_register_crops")
+    return np.array(list(t)[3 - ndim:], dtype=np.float64), float(q.value), int(status.value), int(ncand.value)
+
+
 def score_candidates(im0, im1, t_candidates, region_mode, data_range, im1_min, device=0, quality_for_all=True):
     """The candidate loop of registration.py:493-556 on the GPU.  im0 / im1: rescaled float32 images
     (NaN = outside).  Returns (ssim, spearman, code) arrays; code 1 = (-1,-1) appended, 2 = `continue`.

@@ -113,7 +113,7 @@ int mvs_device_count(void) {
 int mvs_init(int device) {
     MvsContext* c = mvs_ctx(device);
     if (!c) return MVS_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     if (c->ready) return MVS_OK;
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -139,7 +139,7 @@ int mvs_init(int device) {
 void mvs_shutdown(int device) {
     MvsContext* c = mvs_ctx(device);
     if (!c || !c->ready) return;
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     hipSetDevice(mvs_hip_device(device));
     hipStreamSynchronize(c->stream);
     {
@@ -178,7 +178,7 @@ int mvs_set_stream(int device, void* hip_stream) {
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     hipStream_t next = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     if (next != c->stream) {
         // recycled allocations and scratch are only ordered within one stream: drain the old one first
@@ -194,7 +194,7 @@ int mvs_set_option(int device, const char* key, int64_t value) {
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
     if (!key) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_set_option: NULL key");
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     if (!strcmp(key, "force_generic")) {
         c->force_generic = value != 0;
         return MVS_OK;
@@ -228,7 +228,7 @@ int mvs_synchronize(int device) {
 double mvs_last_kernel_ms(int device) {
     MvsContext* c = mvs_ctx(device);
     if (!c || !c->ready || !c->timing_valid) return -1.0;
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     hipSetDevice(mvs_hip_device(device));
     if (hipEventSynchronize(c->ev_stop) != hipSuccess) return -1.0;
     float ms = -1.f;
@@ -345,7 +345,7 @@ int mvs_memset(int device, void* dst_dev, int32_t byte_value, uint64_t nbytes) {
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
     if (!dst_dev && nbytes) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_memset: NULL pointer");
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     if (nbytes) MVS_HIP_TRY(c, hipMemsetAsync(dst_dev, byte_value, nbytes, c->stream));
     return MVS_OK;
@@ -364,7 +364,7 @@ int mvs_copy_into(int device, const void* src_dev, int32_t dtype, const int64_t 
             return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_copy_into: box does not fit into the destination");
     if (shape[0] * shape[1] * shape[2] == 0) return MVS_OK;
     if (shape[0] * shape[1] >= (1ll << 31)) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_copy_into: too many rows");
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     const long long py = dst_shape[2] * (long long)es, pz = dst_shape[1] * py;
     unsigned char* d0 = (unsigned char*)dst_dev + dst_offset[0] * pz + dst_offset[1] * py + dst_offset[2] * (long long)es;

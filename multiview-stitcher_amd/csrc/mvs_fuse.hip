@@ -1069,7 +1069,7 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     if (!views || n_views < 1 || !opts || !out)
         return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_fuse_chunk: NULL/empty argument");
     if (opts->ndim != 2 && opts->ndim != 3)
@@ -1290,7 +1290,7 @@ extern "C" int mvs_resample(int device, const mvs_view_t* view, const int64_t ou
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     if (!view || !out_shape || !out) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_resample: NULL argument");
     if (order != 0 && order != 1) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_resample: order %d (only 0|1)", order);
     for (int k = 0; k < 3; ++k)
@@ -1330,7 +1330,7 @@ extern "C" int mvs_blend_weights(int device, const mvs_view_t* view, int32_t ndi
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     if (!view || !out_shape || !out) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_blend_weights: NULL argument");
     if (ndim != 2 && ndim != 3) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_blend_weights: ndim must be 2 or 3");
     MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));

@@ -35,7 +35,7 @@ struct MvsContext {
     bool timing_valid = false;
     int ablate = 0;               // profiling only (see FuseParams)
     bool force_generic = false;   // debug/test switch: never take the translation fast path
-    std::mutex mu;
+    std::recursive_mutex mu;      // recursive: composite entry points (mvs_pair.hip) call the public ones under the lock
     std::string last_error;
     // grow-only device scratch buffers (slot-indexed) and one pinned host staging buffer
     MvsScratch dev[12];

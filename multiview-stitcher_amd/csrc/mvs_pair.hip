@@ -1,0 +1,149 @@
+// mvs_pair.hip -- one call for the reference's phase_correlation_registration (gfx950 host side).
+//
+// mvs_register_crops == registration.phase_correlation_registration
+// (src/multiview_stitcher/registration.py:353-565) for two same-shape float32 overlap crops (NaN = outside the view):
+// intensity normalisation (:381-389), phase correlation with and without phase normalisation (:413-431), the zero-shift
+// candidate of the masked variant when a crop holds NaNs (:433-443, quirk Q1), candidate enumeration (:453-477), candidate
+// scoring (:493-556) and the selection by nanargmax with the reference's list bookkeeping (quirk Q3: the `continue` of
+// :530-533 appends nothing, the arg-max index then addresses the UNFILTERED candidate list).  Every voxel-sized step is one
+// of the library's own entry points; what this file adds is the control flow between them, which otherwise costs ~0.5 ms of
+// interpreter time per image pair (with the GIL held) in the Python mirror -- multiview_stitcher_amd.registration keeps
+// that mirror for the debug outputs and for custom keyword arguments.
+#include "mvs_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+extern "C" int mvs_register_crops(int device, const float* fixed, const float* moving, int32_t mem, int32_t ndim, const int64_t shape[3],
+                                  int32_t upsample_factor, int32_t region_mode, int32_t constant_check, double t_out[3], double* quality_out,
+                                  int32_t* status_out, int32_t* n_candidates_out) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    if (!fixed || !moving || !shape || !t_out || !quality_out || !status_out)
+        return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_register_crops: NULL argument");
+    if (ndim != 2 && ndim != 3) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_register_crops: ndim must be 2 or 3");
+    if (ndim == 2 && shape[0] != 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_register_crops: 2D needs shape[0]==1");
+    if (region_mode < -1 || region_mode > 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_register_crops: region_mode must be -1, 0 or 1");
+    const int64_t n = shape[0] * shape[1] * shape[2];
+    if (n < 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_register_crops: empty shape");
+    const int k0 = 3 - ndim;
+    t_out[0] = t_out[1] = t_out[2] = 0.0;
+    *quality_out = NAN;
+    *status_out = 0;
+    if (n_candidates_out) *n_candidates_out = 0;
+
+    // ---- normalise (registration.py:381-389); also nanmin / nanmax / #valid of the inputs ----
+    float* r0 = (float*)mvs_scratch(c, 9, (size_t)n * 4);
+    float* r1 = (float*)mvs_scratch(c, 10, (size_t)n * 4);
+    if (!r0 || !r1) return MVS_ERR_HIP;
+    float min0, max0, min1, max1;
+    int64_t nv0, nv1;
+    rc = mvs_rescale_intensity(device, fixed, mem, n, r0, MVS_MEM_DEVICE, &min0, &max0, &nv0);
+    if (rc) return rc;
+    rc = mvs_rescale_intensity(device, moving, mem, n, r1, MVS_MEM_DEVICE, &min1, &max1, &nv1);
+    if (rc) return rc;
+    if (constant_check && (min0 == max0 || min1 == max1)) {   // dispatch_pairwise_reg_func's guard (registration.py:1500-1520)
+        *status_out = 2;
+        return MVS_OK;
+    }
+    const bool has_nan = (nv0 < n) || (nv1 < n);
+    if (region_mode < 0) region_mode = has_nan ? 1 : 0;       // "intersection" with NaNs, else "union"
+
+    // ---- the two phase correlations (registration.py:413-431); shifts come back as float32 values ----
+    const int32_t norms[2] = {1, 0};
+    double shifts[6];
+    rc = mvs_phasecorr_multi(device, r0, r1, MVS_MEM_DEVICE, ndim, shape, norms, 2, upsample_factor, shifts, nullptr, nullptr);
+    if (rc) return rc;
+    std::vector<std::vector<float>> estimates;
+    for (int e = 0; e < 2; ++e) {
+        std::vector<float> s(ndim);
+        for (int k = 0; k < ndim; ++k) s[k] = (float)shifts[3 * e + k0 + k];
+        estimates.push_back(s);
+    }
+    if (has_nan) estimates.push_back(std::vector<float>(ndim, 0.f));   // the masked variant's zero shift (Q1)
+
+    // ---- data_range / im1_min after rescaling: the values present are min -> 0 and max -> 1 per image ----
+    auto rescaled_range = [](float mn, float mx, int64_t nv, float& lo, float& hi) {
+        if (nv == 0) { lo = hi = NAN; return; }
+        if (mx != mn) { lo = 0.f; hi = 1.f; } else { lo = hi = mn; }
+    };
+    float lo0, hi0, lo1, hi1;
+    rescaled_range(min0, max0, nv0, lo0, hi0);
+    rescaled_range(min1, max1, nv1, lo1, hi1);
+    auto nanmaxf = [](float a, float b) { return (a != a) ? b : (b != b) ? a : std::max(a, b); };
+    auto nanminf = [](float a, float b) { return (a != a) ? b : (b != b) ? a : std::min(a, b); };
+    const float data_range = nanmaxf(hi0, hi1) - nanminf(lo0, lo1);    // float32 arithmetic like numpy
+    const double im1_min = (double)lo1;
+
+    // ---- candidate enumeration (registration.py:453-477): float32 arithmetic, itertools.product order ----
+    float max_shift = 0.f;
+    for (int k = 0; k < ndim; ++k) max_shift = std::max(max_shift, (float)shape[k0 + k]);
+    std::vector<double> cand;    // n_cand x ndim
+    for (const std::vector<float>& sc : estimates) {
+        int nvar[3], idx[3] = {0, 0, 0};
+        float var[3][4];
+        for (int d = 0; d < ndim; ++d) {
+            const float nn = (float)shape[k0 + d];
+            if (sc[d] == 0.f) { nvar[d] = 1; var[d][0] = sc[d]; }
+            else { nvar[d] = 4; var[d][0] = sc[d]; var[d][1] = -sc[d]; var[d][2] = -(sc[d] - nn); var[d][3] = -sc[d] - nn; }
+        }
+        for (;;) {
+            float amax = 0.f;
+            for (int d = 0; d < ndim; ++d) amax = std::max(amax, std::fabs(var[d][idx[d]]));
+            if (amax < max_shift)
+                for (int d = 0; d < ndim; ++d) cand.push_back((double)var[d][idx[d]]);
+            int d = ndim - 1;                                    // last axis fastest
+            while (d >= 0 && ++idx[d] == nvar[d]) { idx[d] = 0; --d; }
+            if (d < 0) break;
+        }
+    }
+    const int n_all = (int)(cand.size() / (size_t)ndim);
+    if (n_candidates_out) *n_candidates_out = n_all;
+    if (n_all == 0) {            // Q2: the reference returns `[zeros(ndim)]`
+        *status_out = 1;
+        return MVS_OK;
+    }
+
+    // ---- score every distinct candidate once (the two estimates usually agree), scatter back ----
+    std::vector<int> uniq_of(n_all, -1);
+    std::vector<double> uniq;
+    for (int i = 0; i < n_all; ++i) {
+        const int nu = (int)(uniq.size() / (size_t)ndim);
+        for (int u = 0; u < nu && uniq_of[i] < 0; ++u) {
+            bool same = true;
+            for (int d = 0; d < ndim; ++d) same = same && (uniq[(size_t)u * ndim + d] == cand[(size_t)i * ndim + d]);
+            if (same) uniq_of[i] = u;
+        }
+        if (uniq_of[i] < 0) {
+            uniq_of[i] = nu;
+            for (int d = 0; d < ndim; ++d) uniq.push_back(cand[(size_t)i * ndim + d]);
+        }
+    }
+    const int n_uniq = (int)(uniq.size() / (size_t)ndim);
+    std::vector<double> ssim_u(n_uniq), spear_u(n_uniq);
+    std::vector<int32_t> code_u(n_uniq);
+    rc = mvs_score_candidates(device, r0, r1, MVS_MEM_DEVICE, ndim, shape, uniq.data(), n_uniq, region_mode, (double)data_range, im1_min, 0,
+                              ssim_u.data(), spear_u.data(), code_u.data());
+    if (rc) return rc;
+
+    // ---- metric lists as the reference builds them (code 2 appends nothing), nanargmax, Q3 indexing ----
+    int best_pos = -1, pos = 0;
+    double best = 0.0, best_quality = NAN;
+    for (int i = 0; i < n_all; ++i) {
+        const int u = uniq_of[i];
+        if (code_u[u] == 2) continue;
+        const double sv = ssim_u[u];
+        if (sv == sv && (best_pos < 0 || sv > best)) { best = sv; best_pos = pos; best_quality = spear_u[u]; }
+        ++pos;
+    }
+    if (best_pos < 0) {          // np.nanargmax of an empty / all-NaN list raises in the reference
+        *status_out = 3;
+        return MVS_OK;
+    }
+    for (int d = 0; d < ndim; ++d) t_out[k0 + d] = cand[(size_t)best_pos * ndim + d];   // index into the UNFILTERED list (Q3)
+    *quality_out = best_quality;
+    return MVS_OK;
+}

@@ -224,7 +224,7 @@ extern "C" int mvs_rescale_intensity(int device, const float* in, int32_t mem, i
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     if (!in || !out || n < 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_rescale_intensity: bad argument");
     MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     float* din;
@@ -255,7 +255,7 @@ extern "C" int mvs_fft_c2c(int device, void* data, int32_t mem, int32_t ndim, co
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     if (!data || !shape || (ndim != 2 && ndim != 3)) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_fft_c2c: bad argument");
     for (int k = 0; k < 3; ++k)
         if (shape[k] < 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_fft_c2c: bad shape");
@@ -289,7 +289,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     if (!fixed || !moving || !shape || !shifts_out || !normalizations || n_norm < 1)
         return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_phasecorr: NULL argument");
     if (ndim != 2 && ndim != 3) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_phasecorr: ndim must be 2 or 3");
@@ -459,7 +459,7 @@ extern "C" int mvs_bin_mean(int device, const void* in, int32_t dtype, int32_t m
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     if (!in || !out || !shape || !stride || !bin) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_bin_mean: NULL argument");
     const size_t es = mvs_dtype_size(dtype);
     if (!es) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_bin_mean: bad dtype");

@@ -580,7 +580,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
-    std::lock_guard<std::mutex> lock(c->mu);
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
     if (!fixed || !moving || !shape || !t_candidates || !ssim_out || !spearman_out || !code_out || n_candidates < 0)
         return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_score_candidates: bad argument");
     if (ndim != 2 && ndim != 3) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_score_candidates: ndim must be 2 or 3");

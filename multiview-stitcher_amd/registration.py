@@ -61,6 +61,23 @@ def phase_correlation_registration(fixed_data, moving_data, disambiguate_region_
     ndim = len(shape)
     on_dev = is_device_array(im0)
 
+    if not return_debug and set(skimage_phase_corr_kwargs) <= {"upsample_factor"}:
+        # the whole function as one library call (same steps, same quirks); the Python flow below stays for the debug
+        # outputs and for callers that pass other phase_cross_correlation keywords
+        uf = skimage_phase_corr_kwargs.get("upsample_factor", 10 if ndim == 2 else 2)
+        t, quality, status, _ = _reg_ops.register_crops(im0, im1, uf, disambiguate_region_mode, _constant_check, device)
+        if status == 2:
+            warnings.warn(
+                "An overlap region between tiles/views is all zero or constant. Assuming identity transform.",
+                UserWarning, stacklevel=3,
+            )
+            return {"affine_matrix": param_utils.identity_transform(ndim), "quality": np.nan}
+        if status == 1:
+            return [np.zeros(ndim)]
+        if status == 3:
+            raise ValueError("All-NaN slice encountered")     # what np.nanargmax raises in the reference (registration.py:558-559)
+        return {"affine_matrix": param_utils.affine_from_translation([float(v) for v in t]), "quality": quality}
+
     # normalise (registration.py:381-389); the kernel also reports nanmin/nanmax/#valid of the INPUT
     im0, min0, max0, nvalid0 = _reg_ops.rescale_intensity(im0, device, out_on_device=on_dev)
     im1, min1, max1, nvalid1 = _reg_ops.rescale_intensity(im1, device, out_on_device=on_dev)
