@@ -1,5 +1,5 @@
 """Minimal driver for profiling the fuse kernel alone (few other kernels, so PMC passes stay short).
-usage: python tools/fuse_probe.py [reps] [frac]   (frac=1: fractional registered-like offsets)"""
+usage: python tools/fuse_probe.py [reps] [frac]   (frac=1: fractional offsets, 2: integer jitter of +-3 px)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -23,8 +23,10 @@ for idx in np.ndindex(*grid):
     o = np.asarray(idx) * step
     sim = si.to_spatial_image(da, dims=["z", "y", "x"], scale=dict(zip("zyx", [1.0] * 3)), translation=dict(zip("zyx", o.astype(float))))
     p = np.eye(4)
-    if frac:
+    if frac == 1:
         p[:3, 3] = np.round(rng.uniform(-2, 2, 3), 3)
+    elif frac == 2:                                     # integer jitter, like a registered mosaic
+        p[:3, 3] = rng.integers(-3, 4, 3).astype(float)
     si.set_sim_affine(sim, p, "k")
     sims.append(sim)
 torch.cuda.synchronize()
