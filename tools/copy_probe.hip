@@ -105,13 +105,38 @@ int main() {
         const int w = 410, x0 = 102, onx = 1742;
         unsigned short* big;
         const size_t orows = (size_t)nz * ny;   // as many destination rows
-        CHECK(hipMalloc(&big, orows * onx * 2 + (1 << 20)));
+        CHECK(hipMalloc(&big, orows * 1792 * 2 + (1 << 20)));
         auto run = [&](const char* name, int ostride, int ox0) {
             rep(name, time_ms([&] { hipLaunchKernelGGL((v2_sub<8>), dim3(nbricks / 4), dim3(256), 0, 0, src, big, nz, ny, nx, x0, w, ostride, ox0, nby); }) * (512.0 / w));
         };
         run("v2 410/512 -> stride 410 (scaled)", 410, 0);
         run("v2 410/512 -> stride 512 (scaled)", 512, 0);
         run("v2 410/512 -> stride 1742 (scaled)", onx, 512);
+        // which part of the loss is alignment?  (w, x0, destination pitch and start varied; time scaled to full rows)
+        auto run2 = [&](const char* name, int w2, int x02, int ostride, int ox0) {
+            rep(name, time_ms([&] { hipLaunchKernelGGL((v2_sub<8>), dim3(nbricks / 4), dim3(256), 0, 0, src, big, nz, ny, nx, x02, w2, ostride, ox0, nby); }) * (512.0 / w2));
+        };
+        run2("v2 410/512 -> pitch 1792 @512", 410, 102, 1792, 512);
+        run2("v2 384/512 (x0=128) -> pitch 1742 @512", 384, 128, 1742, 512);
+        run2("v2 384/512 (x0=128) -> pitch 1792 @512", 384, 128, 1792, 512);
+        run2("v2 384/512 (x0=128) -> pitch 384", 384, 128, 384, 0);
+        run2("v2 512/512 -> pitch 1742 @512", 512, 0, 1742, 512);
+        run2("v2 512/512 -> pitch 1792 @512", 512, 0, 1792, 512);
+        // two writers of the boundary lines: piece A = px [0,410) and piece B = px [410,512) of every row, written by
+        // two launches one after the other, by two launches on two streams, and the alignment-friendly split 384 | 128
+        hipStream_t s1, s2; CHECK(hipStreamCreate(&s1)); CHECK(hipStreamCreate(&s2));
+        auto two = [&](const char* name, int wa, int ostride, hipStream_t sa, hipStream_t sb) {
+            rep(name, time_ms([&] {
+                hipLaunchKernelGGL((v2_sub<8>), dim3(nbricks / 4), dim3(256), 0, sa, src, big, nz, ny, nx, 0, wa, ostride, 512, nby);
+                hipLaunchKernelGGL((v2_sub<8>), dim3(nbricks / 4), dim3(256), 0, sb, src, big, nz, ny, nx, wa, 512 - wa, ostride, 512 + wa, nby);
+                if (sa != sb) { hipStreamSynchronize(sa); hipStreamSynchronize(sb); }
+            }));
+        };
+        two("410|102 pitch 1742, sequential", 410, 1742, 0, 0);
+        two("410|102 pitch 1742, two streams", 410, 1742, s1, s2);
+        two("384|128 pitch 1792, sequential", 384, 1792, 0, 0);
+        two("384|128 pitch 1792, two streams", 384, 1792, s1, s2);
+        two("410|102 pitch 1792, sequential", 410, 1792, 0, 0);
     }
     return 0;
 }
