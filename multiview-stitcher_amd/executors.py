@@ -67,7 +67,8 @@ class DevicePairExecutor:
 def fuse_on_devices(sims, devices=(0,), **fuse_kwargs):
     """Fuse with the output chunks farmed over several GPUs of one process: chunk b goes to device
     ``devices[b % n]`` (z-major block order keeps a device's chunks adjacent); the host array is assembled
-    from the per-device partial results.  Equivalent to fusion.fuse on one device."""
+    from the per-device partial results -- or, with ``output_zarr_url``, every device streams its chunks into the one
+    Zarr store and there is nothing to assemble.  Equivalent to fusion.fuse on one device."""
     from . import fusion
 
     n = len(devices)
@@ -81,7 +82,14 @@ def fuse_on_devices(sims, devices=(0,), **fuse_kwargs):
             return counter[key] % n == d
         return f
 
-    # enumerate blocks deterministically first (single pass with a rejecting filter)
+    zarr_url = fuse_kwargs.get("output_zarr_url")
+    if zarr_url is not None:
+        import os
+        import shutil
+
+        if (fuse_kwargs.get("zarr_options") or {}).get("overwrite", True) and os.path.exists(zarr_url):
+            shutil.rmtree(zarr_url)
+    # enumerate blocks deterministically first (single pass with a rejecting filter; creates the output store, if any)
     fusion.fuse(sims, chunk_filter=lambda bi: counter.setdefault(tuple(bi), len(counter)) < 0, device=devices[0], **fuse_kwargs)
     parts = [None] * n
 
@@ -91,6 +99,15 @@ def fuse_on_devices(sims, devices=(0,), **fuse_kwargs):
     with ThreadPoolExecutor(max_workers=n) as ex:
         list(ex.map(work, range(n)))
     out = parts[0]
+    if zarr_url is not None:
+        # every worker wrote its own chunk files into the one store: nothing to merge; the pyramid is built once
+        zopt = fuse_kwargs.get("zarr_options") or {}
+        if zopt.get("ome_zarr", False):
+            from . import ngff_utils
+
+            out = ngff_utils.write_sim_to_ome_zarr(out, zarr_url, overwrite=False, ngff_version=zopt.get("ngff_version", "0.4"),
+                                                   zarr_array_creation_kwargs=zopt.get("zarr_array_creation_kwargs"), device=devices[0])
+        return out
     data = np.asarray(out.data).copy()
     for p in parts[1:]:
         data += np.asarray(p.data)   # disjoint chunks, untouched ones are zero

@@ -14,6 +14,9 @@ from __future__ import annotations
 import ctypes as C
 from itertools import product
 
+import os
+import shutil
+
 import numpy as np
 
 from . import _lib, mv_graph, param_utils, weights
@@ -621,9 +624,12 @@ def fuse(
     """Fuse input views (fusion.fuse, _core.py:782-1501), eagerly, on the HIP backend.
 
     Same arguments as the reference.  Differences forced by the environment:
-    evaluation is eager (there is no dask), ``output_zarr_url`` is not
-    supported here, and ``images`` are numpy- or DeviceArray-backed
-    SpatialImages.  Output chunks are fused one ``mvs_fuse_chunk`` call each,
+    evaluation is eager (there is no dask) and ``images`` are numpy-,
+    DeviceArray- or zarr-backed SpatialImages (``ngff_utils.read_sim_from_ome_zarr``;
+    only the slab a chunk needs is read).  With ``output_zarr_url`` every
+    fused chunk is written into a Zarr v2 array (``zarr_options``: ``ome_zarr``,
+    ``ngff_version`` "0.4", ``overwrite``, ``zarr_array_creation_kwargs``) and
+    the returned image is backed by that array.  Output chunks are fused one ``mvs_fuse_chunk`` call each,
     following the reference's chunk grid, halo and slab windows; the result is
     a SpatialImage with identity affine under ``transform_key``.
     ``chunk_filter(block_index) -> bool`` restricts the work to a subset of
@@ -637,8 +643,8 @@ def fuse(
         raise TypeError("fuse() got both 'images' and deprecated 'sims'. Use only 'images'.")
     if not images:
         raise ValueError("images must contain at least one image.")
-    if output_zarr_url is not None:
-        raise NotImplementedError("zarr streaming output is outside the HIP hot path (SURVEY 8f-1)")
+    if output_zarr_url is not None and output_on_backend:
+        raise ValueError("output_zarr_url streams chunks to disk; it cannot be combined with output_on_backend")
     if backend not in ("hip", None):
         raise ValueError("multiview_stitcher_amd.fusion.fuse only implements backend='hip'")
     from . import msi_utils
@@ -687,7 +693,29 @@ def fuse(
     ns_shape = tuple(sims_[0].sizes[d] for d in nsdims)
     dtype = np.dtype(sims_[0].dtype)
     on_device = output_on_backend
-    result = None if on_device else np.zeros(ns_shape + out_shape_sp, dtype=dtype)
+    zarr_out = None
+    if output_zarr_url is not None:
+        # streaming output (_core.py:1068-1171, 2044-2156): every fused chunk goes straight into its region of a Zarr v2
+        # array, the mosaic never exists in host memory; with ome_zarr=True the array is level "0" of an NGFF image
+        from . import ngff_utils, zarr_io
+
+        zarr_options = dict(zarr_options or {})
+        ome_zarr = bool(zarr_options.get("ome_zarr", False))
+        ngff_version = zarr_options.get("ngff_version", "0.4")
+        create_kw = dict(zarr_options.get("zarr_array_creation_kwargs") or {})
+        if zarr_options.get("overwrite", True) and os.path.exists(output_zarr_url) and chunk_filter is None:
+            shutil.rmtree(output_zarr_url)
+        if ome_zarr:
+            create_kw = ngff_utils.update_zarr_array_creation_kwargs_for_ngff_version(ngff_version, create_kw)
+            zarr_io.create_group(output_zarr_url)
+        store_url = os.path.join(output_zarr_url, "0") if ome_zarr else output_zarr_url
+        if os.path.exists(os.path.join(store_url, ".zarray")):
+            zarr_out = zarr_io.ZarrArray.open(store_url)      # a farm worker joining an array another worker created
+        else:
+            zarr_out = zarr_io.ZarrArray.create(
+                store_url, ns_shape + out_shape_sp, (1,) * len(ns_shape) + tuple(output_chunksize[d] for d in sdims), dtype,
+                **create_kw)
+    result = None if (on_device or zarr_out is not None) else np.zeros(ns_shape + out_shape_sp, dtype=dtype)
     if on_device and ns_shape and int(np.prod(ns_shape)) != 1:
         raise NotImplementedError("output_on_backend with several (c,t) fields")
 
@@ -756,14 +784,17 @@ def fuse(
                 chunk = np.asarray(fuse_np(**kwargs))
                 if entry["fuse_planewise"]:
                     chunk = chunk[np.newaxis]
-                result[tuple(ns_index) + sl] = chunk
+                if zarr_out is not None:
+                    zarr_out.write(list(ns_index) + [s_.start for s_ in sl], chunk.reshape((1,) * len(ns_index) + chunk.shape))
+                else:
+                    result[tuple(ns_index) + sl] = chunk
         if on_device:
             result_data = dev_out
     if on_device:
         data = result_data
         dims = sdims
     else:
-        data = result
+        data = result if zarr_out is None else zarr_out[...]
         dims = list(nsdims) + list(sdims)
     res = si_utils.to_spatial_image(
         data, dims=dims, scale=output_stack_properties["spacing"], translation=output_stack_properties["origin"],
@@ -771,4 +802,9 @@ def fuse(
         t_coords=sims_[0].coords.get("t") if "t" in dims else None,
     )
     si_utils.set_sim_affine(res, param_utils.identity_transform(len(sdims)), transform_key)
+    if zarr_out is not None and ome_zarr and chunk_filter is None:
+        # pyramid levels + multiscales metadata around the level-0 array written above (_core.py:1160-1171)
+        res = ngff_utils.write_sim_to_ome_zarr(res, output_zarr_url, overwrite=False, ngff_version=ngff_version,
+                                               zarr_array_creation_kwargs=zarr_options.get("zarr_array_creation_kwargs"),
+                                               device=device)
     return res

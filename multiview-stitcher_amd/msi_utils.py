@@ -71,6 +71,23 @@ def _downsample_sim(sim, factors):
     return res
 
 
+def calc_resolution_levels(spatial_shape, downscale_factors_per_spatial_dim=None, min_shape=100):
+    """Shapes, relative and absolute factors of the pyramid levels, level 0 included (msi_utils.py:279-325): a dim is
+    halved (or divided by its factor) as long as the result stays above ``min_shape``."""
+    sdims = list(spatial_shape.keys())
+    if downscale_factors_per_spatial_dim is None:
+        downscale_factors_per_spatial_dim = {d: 2 for d in sdims}
+    shapes, rel, ab = [dict(spatial_shape)], [{d: 1 for d in sdims}], [{d: 1 for d in sdims}]
+    while True:
+        f = {d: downscale_factors_per_spatial_dim[d] if shapes[-1][d] // downscale_factors_per_spatial_dim[d] > min_shape else 1
+             for d in sdims}
+        if not any(v > 1 for v in f.values()):
+            return shapes, rel, ab
+        ab.append({d: ab[-1][d] * f[d] for d in sdims})
+        shapes.append({d: shapes[-1][d] // f[d] for d in sdims})
+        rel.append(f)
+
+
 def get_msim_from_sim(sim, scale_factors=None, chunks=None):
     """msi_utils.get_msim_from_sim (msi_utils.py:373-430); default: scale0 only."""
     sims = [sim]

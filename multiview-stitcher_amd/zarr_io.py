@@ -1,0 +1,309 @@
+"""Zarr-v2 directory-store arrays for the two ends of the fuse path, without the zarr package.
+
+The reference streams tiles out of and fused chunks into Zarr arrays through zarr-python / dask
+(src/multiview_stitcher/fusion/_core.py:134-199 reads only the raw region a chunk needs, :2044-2156 writes each
+fused chunk into its own region of the output array; src/multiview_stitcher/ngff_utils.py:1564-1760 writes the
+NGFF pyramid).  Neither package exists on the MI355X box, so this module restates the part of the Zarr v2
+storage specification those call sites rely on:
+
+* ``<array>/.zarray``: JSON with ``zarr_format`` 2, ``shape``, ``chunks``, ``dtype`` (numpy typestr), ``order``
+  "C", ``fill_value``, ``compressor`` (null | zlib | gzip here -- blosc / zstd need codecs this image lacks and raise),
+  ``filters`` null, optional ``dimension_separator`` ("." default, "/" for NGFF 0.4,
+  ngff_utils.py:1258-1281);
+* one file per chunk, named by the chunk's grid index joined with the separator; every stored chunk has the
+  full chunk shape (edge chunks are padded with the fill value); a missing file means "all fill value";
+* ``.zgroup`` / ``.zattrs`` JSON for groups and attributes.
+
+``ZarrArray[...]`` is lazy: indexing returns a ``ZarrView`` that reads only the chunks its window touches when
+it is converted with ``np.asarray`` -- which is what ``fusion.fuse`` does per output chunk and view slab, so a
+mosaic larger than host memory streams through one slab at a time.  Chunk files are written to a temporary
+name and renamed, so writers that own disjoint chunks (the multi-GPU farm) never see partial files.
+"""
+
+from __future__ import annotations
+
+import gzip
+import itertools
+import json
+import os
+import shutil
+import threading
+import zlib
+
+import numpy as np
+
+
+def _decode_fill(value, dtype):
+    if value is None:
+        return np.zeros((), dtype)[()]
+    if isinstance(value, str):
+        value = {"NaN": np.nan, "Infinity": np.inf, "-Infinity": -np.inf}[value]
+    return np.asarray(value).astype(dtype)[()]
+
+
+def _encode_fill(value, dtype):
+    value = np.asarray(value).astype(dtype)[()]
+    if np.issubdtype(dtype, np.floating):
+        if np.isnan(value):
+            return "NaN"
+        if np.isinf(value):
+            return "Infinity" if value > 0 else "-Infinity"
+        return float(value)
+    if np.issubdtype(dtype, np.bool_):
+        return bool(value)
+    return int(value)
+
+
+_tmp_counter = itertools.count()
+
+
+def _tmp_name(path):
+    """Unique per process, thread and call: writers of the same key (metadata written by every farm worker) never share
+    a temporary file; the rename is atomic."""
+    return f"{path}.tmp{os.getpid()}_{threading.get_ident()}_{next(_tmp_counter)}"
+
+
+def _write_json(path, obj):
+    tmp = _tmp_name(path)
+    with open(tmp, "w") as f:
+        json.dump(obj, f, indent=4, sort_keys=True)
+    os.replace(tmp, path)
+
+
+class _Codec:
+    """compressor entry of .zarray -> (decode, encode); only what the standard library offers."""
+
+    def __init__(self, config):
+        self.config = config
+        cid = None if config is None else config.get("id")
+        level = 1 if config is None else int(config.get("level", 1))
+        if cid is None:
+            self.decode, self.encode = (lambda b: b), (lambda b: b)
+        elif cid == "zlib":
+            self.decode, self.encode = zlib.decompress, (lambda b: zlib.compress(b, level))
+        elif cid == "gzip":
+            self.decode, self.encode = gzip.decompress, (lambda b: gzip.compress(b, compresslevel=level))
+        else:
+            raise NotImplementedError(
+                f"zarr compressor {cid!r} needs a codec that is not available here (supported: null, zlib, gzip)")
+
+
+class ZarrArray:
+    """One Zarr v2 array in a directory store."""
+
+    def __init__(self, path, meta):
+        self.path = str(path)
+        if int(meta.get("zarr_format", 2)) != 2:
+            raise NotImplementedError("only zarr_format 2 is supported")
+        if meta.get("order", "C") != "C":
+            raise NotImplementedError("only C-order chunks are supported")
+        if meta.get("filters"):
+            raise NotImplementedError("zarr filters are not supported")
+        self.shape = tuple(int(s) for s in meta["shape"])
+        self.chunks = tuple(int(c) for c in meta["chunks"])
+        self.dtype = np.dtype(meta["dtype"])
+        self.fill_value = _decode_fill(meta.get("fill_value"), self.dtype)
+        self.separator = meta.get("dimension_separator", ".")
+        self.codec = _Codec(meta.get("compressor"))
+        self.meta = meta
+        self.ndim = len(self.shape)
+        self.grid = tuple(-(-s // c) for s, c in zip(self.shape, self.chunks))
+
+    # ---- construction -------------------------------------------------------------------------
+    @classmethod
+    def open(cls, path):
+        with open(os.path.join(path, ".zarray")) as f:
+            return cls(path, json.load(f))
+
+    @classmethod
+    def create(cls, path, shape, chunks, dtype, fill_value=0, dimension_separator=".", compressor=None,
+               overwrite=False):
+        if os.path.exists(path):
+            if not overwrite:
+                raise FileExistsError(path)
+            shutil.rmtree(path)
+        os.makedirs(path)
+        dtype = np.dtype(dtype)
+        shape = [int(s) for s in shape]
+        chunks = [max(1, min(int(c), s)) if s else int(c) for c, s in zip(chunks, shape)]
+        meta = {
+            "zarr_format": 2, "shape": shape, "chunks": chunks, "dtype": dtype.str, "order": "C",
+            "fill_value": _encode_fill(fill_value, dtype), "compressor": compressor, "filters": None,
+        }
+        if dimension_separator != ".":
+            meta["dimension_separator"] = dimension_separator
+        _Codec(compressor)   # fail before anything is written
+        _write_json(os.path.join(path, ".zarray"), meta)
+        return cls(path, meta)
+
+    # ---- chunks -------------------------------------------------------------------------------
+    def chunk_path(self, idx):
+        return os.path.join(self.path, *self.separator.join(str(int(i)) for i in idx).split("/"))
+
+    def read_chunk(self, idx):
+        """Full-shape chunk ``idx`` or None when it was never written."""
+        try:
+            with open(self.chunk_path(idx), "rb") as f:
+                raw = f.read()
+        except FileNotFoundError:
+            return None
+        arr = np.frombuffer(self.codec.decode(raw), dtype=self.dtype)
+        if arr.size != int(np.prod(self.chunks)):
+            raise ValueError(f"chunk {idx} of {self.path} holds {arr.size} elements, expected {np.prod(self.chunks)}")
+        return arr.reshape(self.chunks)
+
+    def write_chunk(self, idx, data):
+        data = np.ascontiguousarray(data, dtype=self.dtype)
+        assert data.shape == self.chunks, (data.shape, self.chunks)
+        path = self.chunk_path(idx)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = _tmp_name(path)
+        with open(tmp, "wb") as f:
+            f.write(self.codec.encode(data.tobytes()))
+        os.replace(tmp, path)
+
+    def _touched(self, starts, stops):
+        return itertools.product(*[range(a // c, -(-b // c)) for a, b, c in zip(starts, stops, self.chunks) if True])
+
+    # ---- regions ------------------------------------------------------------------------------
+    def read(self, starts, stops):
+        """The window [starts, stops) as one C-contiguous array; only the chunks it touches are opened."""
+        starts, stops = [int(a) for a in starts], [int(b) for b in stops]
+        shape = [max(b - a, 0) for a, b in zip(starts, stops)]
+        out = np.empty(shape, dtype=self.dtype)
+        if 0 in shape:
+            return out
+        for idx in self._touched(starts, stops):
+            lo = [max(a, i * c) for a, i, c in zip(starts, idx, self.chunks)]
+            hi = [min(b, (i + 1) * c) for b, i, c in zip(stops, idx, self.chunks)]
+            dst = tuple(slice(l - a, h - a) for l, h, a in zip(lo, hi, starts))
+            chunk = self.read_chunk(idx)
+            if chunk is None:
+                out[dst] = self.fill_value
+            else:
+                out[dst] = chunk[tuple(slice(l - i * c, h - i * c) for l, h, i, c in zip(lo, hi, idx, self.chunks))]
+        return out
+
+    def write(self, starts, data):
+        """Store ``data`` at offset ``starts``.  Chunks covered entirely (up to the array border) are written without
+        reading; partially covered ones are read, patched and rewritten."""
+        data = np.asarray(data)
+        starts = [int(a) for a in starts]
+        stops = [a + n for a, n in zip(starts, data.shape)]
+        if len(starts) != self.ndim or any(a < 0 or b > s for a, b, s in zip(starts, stops, self.shape)):
+            raise IndexError(f"region {starts}..{stops} outside array of shape {self.shape}")
+        if data.size == 0:
+            return
+        for idx in self._touched(starts, stops):
+            c0 = [i * c for i, c in zip(idx, self.chunks)]
+            lo = [max(a, o) for a, o in zip(starts, c0)]
+            hi = [min(b, o + c) for b, o, c in zip(stops, c0, self.chunks)]
+            valid_hi = [min(o + c, s) for o, c, s in zip(c0, self.chunks, self.shape)]
+            src = data[tuple(slice(l - a, h - a) for l, h, a in zip(lo, hi, starts))]
+            full = all(l == o and h == v for l, h, o, v in zip(lo, hi, c0, valid_hi))
+            chunk = None if full else self.read_chunk(idx)
+            if chunk is None:
+                chunk = np.full(self.chunks, self.fill_value, dtype=self.dtype)
+            else:
+                chunk = chunk.copy()
+            chunk[tuple(slice(l - o, h - o) for l, h, o in zip(lo, hi, c0))] = src
+            self.write_chunk(idx, chunk)
+
+    # ---- numpy-like face ----------------------------------------------------------------------
+    def __getitem__(self, key):
+        return ZarrView(self, [(0, s) for s in self.shape])[key]
+
+    def __setitem__(self, key, value):
+        view = self[key]
+        value = np.asarray(value, dtype=self.dtype)
+        value = np.broadcast_to(value, view.shape).reshape([b - a for a, b in view._window()])
+        self.write([a for a, _ in view._window()], value)
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self[...], dtype=dtype)
+
+    def __repr__(self):
+        return f"<ZarrArray {self.path} shape={self.shape} chunks={self.chunks} {self.dtype}>"
+
+
+class ZarrView:
+    """Lazy window of a ZarrArray: per source axis either an int (axis dropped) or a (start, stop) range."""
+
+    def __init__(self, array, sel):
+        self.array = array
+        self._sel = list(sel)
+
+    dtype = property(lambda self: self.array.dtype)
+    shape = property(lambda self: tuple(s[1] - s[0] for s in self._sel if isinstance(s, tuple)))
+    ndim = property(lambda self: len(self.shape))
+    size = property(lambda self: int(np.prod(self.shape)))
+
+    def _window(self):
+        return [(s, s + 1) if not isinstance(s, tuple) else s for s in self._sel]
+
+    def __getitem__(self, key):
+        if not isinstance(key, tuple):
+            key = (key,)
+        if any(k is Ellipsis for k in key):
+            i = [k is Ellipsis for k in key].index(True)
+            key = key[:i] + (slice(None),) * (self.ndim - (len(key) - 1)) + key[i + 1:]
+        key = key + (slice(None),) * (self.ndim - len(key))
+        if len(key) != self.ndim:
+            raise IndexError(f"too many indices for a {self.ndim}-d window")
+        sel, it = [], iter(key)
+        for s in self._sel:
+            if not isinstance(s, tuple):
+                sel.append(s)
+                continue
+            k, n = next(it), s[1] - s[0]
+            if isinstance(k, (int, np.integer)):
+                k = int(k) + (n if k < 0 else 0)
+                if not 0 <= k < n:
+                    raise IndexError(f"index {k} out of range for axis of length {n}")
+                sel.append(s[0] + k)
+            elif isinstance(k, slice):
+                a, b, step = k.indices(n)
+                if step != 1:
+                    raise NotImplementedError("strided selection of a zarr window")
+                sel.append((s[0] + a, s[0] + max(a, b)))
+            else:
+                raise TypeError(f"unsupported index {k!r}")
+        return ZarrView(self.array, sel)
+
+    def __array__(self, dtype=None, copy=None):
+        win = self._window()
+        out = self.array.read([a for a, _ in win], [b for _, b in win]).reshape(self.shape)
+        return out if dtype is None else out.astype(dtype, copy=False)
+
+    def astype(self, dtype):
+        return np.asarray(self).astype(dtype)
+
+    def __repr__(self):
+        return f"<ZarrView {self._sel} of {self.array.path}>"
+
+
+def is_zarr_backed(data):
+    return isinstance(data, (ZarrArray, ZarrView))
+
+
+# ---- groups and attributes ---------------------------------------------------------------------
+def create_group(path, attrs=None, overwrite=False):
+    if overwrite and os.path.exists(path):
+        shutil.rmtree(path)
+    os.makedirs(path, exist_ok=True)
+    _write_json(os.path.join(path, ".zgroup"), {"zarr_format": 2})
+    if attrs is not None:
+        write_attrs(path, attrs)
+    return path
+
+
+def read_attrs(path):
+    try:
+        with open(os.path.join(path, ".zattrs")) as f:
+            return json.load(f)
+    except FileNotFoundError:
+        return {}
+
+
+def write_attrs(path, attrs):
+    _write_json(os.path.join(path, ".zattrs"), attrs)

@@ -1,0 +1,128 @@
+"""GPU tests of the streaming ends of the fuse path: zarr-backed tiles in, Zarr v2 / NGFF 0.4 out,
+pyramid levels by the device block-mean kernel.  Everything is compared with the in-memory workflow on the same tiles."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _dataset(ndim):
+    from multiview_stitcher_amd import sample_data
+
+    if ndim == 2:
+        return sample_data.generate_tiled_dataset(ndim=2, tile_shape=(256, 224), tiles=(2, 2), overlap=(48, 40), dtype=np.uint16,
+                                                  max_jitter=2, seed=4, jitter_in_metadata=True)[0]
+    return sample_data.generate_tiled_dataset(ndim=3, tile_shape=(40, 128, 144), tiles=(1, 2, 2), overlap=(0, 24, 32), dtype=np.uint16,
+                                              max_jitter=2, seed=6, jitter_in_metadata=True)[0]
+
+
+def _block_mean(a, f):
+    """np.mean over blocks, trimmed, cast back (ngff_utils.py:1284-1330)."""
+    sl = tuple(slice(0, (n // k) * k) for n, k in zip(a.shape, f))
+    a = a[sl]
+    shp = []
+    for n, k in zip(a.shape, f):
+        shp += [n // k, k]
+    return a.reshape(shp).mean(axis=tuple(range(1, 2 * a.ndim, 2))).astype(a.dtype)
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_fuse_streams_zarr_in_and_out(hip_device, tmp_path, ndim):
+    from multiview_stitcher_amd import fusion, ngff_utils, sample_data, zarr_io, spatial_image_utils as si
+
+    key = sample_data.METADATA_TRANSFORM_KEY
+    sims = _dataset(ndim)
+    chunks = {"y": 128, "x": 96} if ndim == 2 else {"z": 32, "y": 96, "x": 128}
+    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks).data)
+
+    # tiles -> OME-Zarr stores -> lazy sims carrying the stage transform
+    lazy = []
+    for i, s in enumerate(sims):
+        z = ngff_utils.write_sim_to_ome_zarr(s, str(tmp_path / f"tile{i}.zarr"))
+        assert zarr_io.is_zarr_backed(z.data)
+        si.set_sim_affine(z, si.get_affine_from_sim(s, key), key)
+        lazy.append(z)
+    out_url = str(tmp_path / "fused.zarr")
+    fused = fusion.fuse(lazy, transform_key=key, output_chunksize=chunks, output_zarr_url=out_url,
+                        zarr_options={"ome_zarr": True})
+    assert zarr_io.is_zarr_backed(fused.data)
+    np.testing.assert_array_equal(np.asarray(fused.data), want)
+    assert si.get_origin_from_sim(fused) == pytest.approx(si.get_origin_from_sim(fusion.fuse(sims, transform_key=key, output_chunksize=chunks)))
+
+    # store layout: group, level arrays with '/' keys and the fuse chunk grid, multiscales document
+    meta0 = json.load(open(os.path.join(out_url, "0", ".zarray")))
+    sd = ["z", "y", "x"][-ndim:]
+    assert meta0["chunks"] == [1, 1] + [chunks[d] for d in sd] and meta0["dimension_separator"] == "/"
+    ms = json.load(open(os.path.join(out_url, ".zattrs")))["multiscales"][0]
+    assert [a["name"] for a in ms["axes"]] == ["c", "t"] + sd
+    nlev = len(ms["datasets"])
+    assert nlev >= 2
+    # pyramid: every level is the block mean of the previous one (device kernel vs numpy)
+    msim = ngff_utils.read_msim_from_ome_zarr(out_url)
+    prev = want
+    for lev in range(1, nlev):
+        cur = np.asarray(msim[f"scale{lev}"].data)
+        f = [1, 1] + [p // c for p, c in zip(prev.shape[2:], cur.shape[2:])]
+        np.testing.assert_array_equal(cur, _block_mean(prev, f))
+        s0, s1 = ms["datasets"][lev - 1]["coordinateTransformations"], ms["datasets"][lev]["coordinateTransformations"]
+        for ax in range(2, 2 + ndim):
+            assert s1[0]["scale"][ax] == pytest.approx(s0[0]["scale"][ax] * f[ax])
+            assert s1[1]["translation"][ax] == pytest.approx(s0[1]["translation"][ax] + (f[ax] - 1) * s0[0]["scale"][ax] / 2)
+        prev = cur
+
+
+def test_plain_zarr_output_and_chunk_farm(hip_device, tmp_path):
+    """Without ome_zarr the array sits directly under the url; two workers with complementary chunk filters fill one
+    store (the multi-GPU farm's pattern: disjoint chunk files, no merge step)."""
+    from multiview_stitcher_amd import fusion, sample_data, zarr_io
+
+    key = sample_data.METADATA_TRANSFORM_KEY
+    sims = _dataset(2)
+    chunks = {"y": 128, "x": 96}
+    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks).data)
+    url = str(tmp_path / "plain.zarr")
+    for part in (0, 1):
+        fusion.fuse(sims, transform_key=key, output_chunksize=chunks, output_zarr_url=url,
+                    chunk_filter=lambda bi, part=part: (bi[-1] + bi[-2]) % 2 == part)
+    z = zarr_io.ZarrArray.open(url)
+    assert "dimension_separator" not in z.meta
+    np.testing.assert_array_equal(np.asarray(z), want)
+
+
+def test_register_reads_zarr_backed_tiles(hip_device, tmp_path):
+    from multiview_stitcher_amd import msi_utils, ngff_utils, param_utils, registration, sample_data, spatial_image_utils as si
+
+    key = sample_data.METADATA_TRANSFORM_KEY
+    sims, jit, _ = sample_data.generate_tiled_dataset(ndim=2, tile_shape=(128, 160), tiles=(2, 2), overlap=(40, 48), dtype=np.uint16,
+                                                      max_jitter=3, seed=2)
+    want = registration.register([msi_utils.get_msim_from_sim(s) for s in sims], transform_key=key, new_transform_key="reg", reg_channel_index=0)
+    lazy = []
+    for i, s in enumerate(sims):
+        z = ngff_utils.write_sim_to_ome_zarr(s, str(tmp_path / f"t{i}.zarr"))
+        si.set_sim_affine(z, si.get_affine_from_sim(s, key), key)
+        lazy.append(msi_utils.get_msim_from_sim(z))
+    got = registration.register(lazy, transform_key=key, new_transform_key="reg", reg_channel_index=0)
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(param_utils.select_time(a, 0), param_utils.select_time(b, 0))
+
+
+def test_device_farm_streams_into_one_store(hip_device, tmp_path):
+    """executors.fuse_on_devices with output_zarr_url: the workers' chunk files add up to the single-device result and the
+    pyramid is completed once at the end."""
+    from multiview_stitcher_amd import executors, fusion, ngff_utils, sample_data
+
+    key = sample_data.METADATA_TRANSFORM_KEY
+    sims = _dataset(2)
+    chunks = {"y": 128, "x": 96}
+    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks).data)
+    url = str(tmp_path / "farm.zarr")
+    os.makedirs(url)
+    open(os.path.join(url, "stale"), "w").write("x")      # overwrite=True (default) clears what was there
+    out = executors.fuse_on_devices(sims, devices=(0, 0 | 1 << 8), transform_key=key, output_chunksize=chunks, output_zarr_url=url,
+                                    zarr_options={"ome_zarr": True})
+    assert not os.path.exists(os.path.join(url, "stale"))
+    np.testing.assert_array_equal(np.asarray(out.data), want)
+    assert len(ngff_utils.read_msim_from_ome_zarr(url).keys()) >= 2

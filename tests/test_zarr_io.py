@@ -1,0 +1,137 @@
+"""CPU tests of the Zarr-v2 / NGFF-0.4 restatement: byte layout against the storage specification
+(known-answer files written by hand), windowed reads / writes against numpy, and the multiscales document against the
+reference's conventions (ngff_utils.py:1185-1230, 1493-1561; msi_utils.py:279-325)."""
+import gzip
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from multiview_stitcher_amd import msi_utils, ngff_utils, zarr_io
+from multiview_stitcher_amd import spatial_image_utils as si
+
+
+def test_known_answer_store_layout(tmp_path):
+    # a 5x7 uint16 array in 2x4 chunks, "." separator: 3x2 chunk files, edge chunks padded to the full chunk shape
+    a = np.arange(35, dtype="<u2").reshape(5, 7)
+    z = zarr_io.ZarrArray.create(tmp_path / "a.zarr", a.shape, (2, 4), a.dtype, fill_value=9)
+    z[...] = a
+    meta = json.load(open(tmp_path / "a.zarr" / ".zarray"))
+    assert meta == {"zarr_format": 2, "shape": [5, 7], "chunks": [2, 4], "dtype": "<u2", "order": "C", "fill_value": 9,
+                    "compressor": None, "filters": None}
+    assert sorted(f for f in os.listdir(tmp_path / "a.zarr") if not f.startswith(".")) == ["0.0", "0.1", "1.0", "1.1", "2.0", "2.1"]
+    raw = np.frombuffer(open(tmp_path / "a.zarr" / "2.1", "rb").read(), dtype="<u2").reshape(2, 4)
+    np.testing.assert_array_equal(raw, [[32, 33, 34, 9], [9, 9, 9, 9]])   # row 4, cols 4..6, then fill
+    raw = np.frombuffer(open(tmp_path / "a.zarr" / "0.1", "rb").read(), dtype="<u2").reshape(2, 4)
+    np.testing.assert_array_equal(raw, [[4, 5, 6, 9], [11, 12, 13, 9]])
+
+
+def test_reads_a_store_written_by_hand(tmp_path):
+    # what zarr-python 2 writes for zarr.open(..., shape=(3, 4), chunks=(2, 2), dtype="f4", compressor=Zlib(1),
+    # dimension_separator="/"): nested chunk keys, zlib streams, NaN fill as the string "NaN"; chunk 1/0 missing
+    root = tmp_path / "h.zarr"
+    os.makedirs(root / "0")
+    os.makedirs(root / "1")
+    json.dump({"zarr_format": 2, "shape": [3, 4], "chunks": [2, 2], "dtype": "<f4", "order": "C", "fill_value": "NaN",
+               "compressor": {"id": "zlib", "level": 1}, "filters": None, "dimension_separator": "/"}, open(root / ".zarray", "w"))
+    full = np.arange(12, dtype="<f4").reshape(3, 4)
+    pad = np.full((4, 4), np.nan, "<f4")
+    pad[:3] = full
+    for i, j in [(0, 0), (0, 1), (1, 1)]:
+        open(root / str(i) / str(j), "wb").write(zlib.compress(np.ascontiguousarray(pad[2 * i:2 * i + 2, 2 * j:2 * j + 2]).tobytes(), 1))
+    z = zarr_io.ZarrArray.open(root)
+    got = np.asarray(z)
+    want = full.copy()
+    want[2, 0:2] = np.nan
+    np.testing.assert_array_equal(got, want)
+    assert np.asarray(z[1:, 1:3]).shape == (2, 2)
+    np.testing.assert_array_equal(np.asarray(z[1, 2:]), [6, 7])
+
+
+@pytest.mark.parametrize("compressor", [None, {"id": "zlib", "level": 1}, {"id": "gzip", "level": 1}])
+@pytest.mark.parametrize("sep", [".", "/"])
+def test_windows_against_numpy(tmp_path, compressor, sep):
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 60000, (3, 37, 29, 41)).astype(np.uint16)
+    z = zarr_io.ZarrArray.create(tmp_path / "w.zarr", a.shape, (1, 16, 8, 16), a.dtype, compressor=compressor, dimension_separator=sep)
+    ref = np.zeros_like(a)
+    for _ in range(20):    # random, mostly unaligned writes: exercises the read-patch-write path
+        lo = [int(rng.integers(0, s)) for s in a.shape]
+        hi = [int(rng.integers(l + 1, s + 1)) for l, s in zip(lo, a.shape)]
+        sl = tuple(slice(l, h) for l, h in zip(lo, hi))
+        z[sl] = a[sl]
+        ref[sl] = a[sl]
+    np.testing.assert_array_equal(np.asarray(z), ref)
+    z[...] = a
+    for _ in range(20):
+        lo = [int(rng.integers(0, s)) for s in a.shape]
+        hi = [int(rng.integers(l, s + 1)) for l, s in zip(lo, a.shape)]
+        sl = tuple(slice(l, h) for l, h in zip(lo, hi))
+        np.testing.assert_array_equal(np.asarray(z[sl]), a[sl])
+    # composed lazy views, ints drop axes, negative indices, ellipsis
+    v = z[1][5:30, :, 3:]
+    assert v.shape == (25, 29, 38) and v.dtype == np.uint16
+    np.testing.assert_array_equal(np.asarray(v[2:4, -1, ...]), a[1, 7:9, -1, 3:])
+    if compressor and compressor["id"] == "gzip":
+        assert gzip.decompress(open(z.chunk_path((0, 0, 0, 0)), "rb").read())[:2] == a[0, 0, 0, :1].tobytes()
+
+
+def test_unknown_codec_and_format_fail_loudly(tmp_path):
+    with pytest.raises(NotImplementedError, match="blosc"):
+        zarr_io.ZarrArray.create(tmp_path / "b.zarr", (4,), (2,), "u1", compressor={"id": "blosc", "cname": "lz4"})
+    os.makedirs(tmp_path / "v3.zarr")
+    json.dump({"zarr_format": 3, "shape": [1], "chunks": [1], "dtype": "|u1"}, open(tmp_path / "v3.zarr" / ".zarray", "w"))
+    with pytest.raises(NotImplementedError):
+        zarr_io.ZarrArray.open(tmp_path / "v3.zarr")
+    z = zarr_io.ZarrArray.create(tmp_path / "c.zarr", (4, 4), (2, 2), "u1")
+    with pytest.raises(IndexError):
+        z.write([3, 3], np.zeros((2, 2), "u1"))
+
+
+def test_resolution_levels_kat():
+    # msi_utils.py:279-325: halve while shape // 2 > 100
+    shapes, rel, ab = msi_utils.calc_resolution_levels({"z": 120, "y": 1000, "x": 450})
+    assert shapes == [{"z": 120, "y": 1000, "x": 450}, {"z": 120, "y": 500, "x": 225}, {"z": 120, "y": 250, "x": 112}, {"z": 120, "y": 125, "x": 112}]
+    assert rel[1:] == [{"z": 1, "y": 2, "x": 2}, {"z": 1, "y": 2, "x": 2}, {"z": 1, "y": 2, "x": 1}]
+    assert ab[-1] == {"z": 1, "y": 8, "x": 4}
+    assert msi_utils.calc_resolution_levels({"y": 150, "x": 150})[0] == [{"y": 150, "x": 150}]
+
+
+def test_multiscales_document(tmp_path):
+    sp, o = {"z": 2.0, "y": 0.5, "x": 0.5}, {"z": 10.0, "y": -3.0, "x": 4.0}
+    _, _, ab = msi_utils.calc_resolution_levels({"z": 50, "y": 420, "x": 420})
+    tfs, axes = ngff_utils.calc_ngff_coordinate_transformations_and_axes({"spacing": sp, "origin": o}, ab, nsdims=["t", "c"])
+    assert axes == [{"name": "t", "type": "time"}, {"name": "c", "type": "channel"},
+                    {"name": "z", "type": "space", "unit": "micrometer"}, {"name": "y", "type": "space", "unit": "micrometer"},
+                    {"name": "x", "type": "space", "unit": "micrometer"}]
+    assert tfs[0] == [{"type": "scale", "scale": [1.0, 1.0, 2.0, 0.5, 0.5]}, {"type": "translation", "translation": [0.0, 0, 10.0, -3.0, 4.0]}]
+    # level 2: y, x factor 4 -> spacing 2.0, origin shifted by (4 - 1) * 0.5 / 2
+    assert tfs[2] == [{"type": "scale", "scale": [1.0, 1.0, 2.0, 2.0, 2.0]}, {"type": "translation", "translation": [0.0, 0, 10.0, -2.25, 4.75]}]
+    g = zarr_io.create_group(str(tmp_path / "g.zarr"))
+    ngff_utils.write_multiscales_metadata(g, axes, [{"path": str(i), "coordinateTransformations": t} for i, t in enumerate(tfs)])
+    doc = json.load(open(tmp_path / "g.zarr" / ".zattrs"))
+    assert list(doc) == ["multiscales"] and len(doc["multiscales"]) == 1
+    ms = doc["multiscales"][0]
+    assert sorted(ms) == ["axes", "datasets", "name", "version"] and ms["version"] == "0.4"
+    assert [d["path"] for d in ms["datasets"]] == ["0", "1", "2"]
+    assert json.load(open(tmp_path / "g.zarr" / ".zgroup")) == {"zarr_format": 2}
+
+
+def test_lazy_sim_round_trip_without_gpu(tmp_path):
+    # level 0 only (shape too small for a pyramid -> no kernel needed): write, read back lazily, select like fuse does
+    a = np.random.default_rng(1).integers(0, 4000, (1, 1, 20, 90, 80)).astype(np.uint16)
+    sim = si.to_spatial_image(a, dims=["c", "t", "z", "y", "x"], scale={"z": 2.0, "y": 1.0, "x": 1.0}, translation={"z": 5.0, "y": 7.0, "x": -2.0})
+    back = ngff_utils.write_sim_to_ome_zarr(sim, str(tmp_path / "s.zarr"))
+    assert zarr_io.is_zarr_backed(back.data) and back.dims == ("c", "t", "z", "y", "x")
+    assert si.get_spacing_from_sim(back) == {"z": 2.0, "y": 1.0, "x": 1.0}
+    assert si.get_origin_from_sim(back) == {"z": 5.0, "y": 7.0, "x": -2.0}
+    assert json.load(open(tmp_path / "s.zarr" / "0" / ".zarray"))["dimension_separator"] == "/"
+    assert os.path.exists(tmp_path / "s.zarr" / "0" / "0" / "0" / "0" / "0" / "0")
+    field = back.isel({"c": 0, "t": 0})
+    slab = field.sel({"z": slice(9.0, 21.0), "y": slice(None, 20.0), "x": slice(0.0, None)})
+    assert zarr_io.is_zarr_backed(slab.data)
+    np.testing.assert_array_equal(np.asarray(slab.data), a[0, 0, 2:9, :14, 2:])
+    ms = ngff_utils.read_msim_from_ome_zarr(str(tmp_path / "s.zarr"))
+    assert ms.keys() == ["scale0"]
