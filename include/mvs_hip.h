@@ -218,6 +218,20 @@ int mvs_register_crops(int device, const float* fixed, const float* moving, int3
                        int32_t constant_check, double t_out[3], double* quality_out,
                        int32_t* status_out, int32_t* n_candidates_out);
 
+/* Host-only (no device, no mvs_init needed): the inner loop of the reference's global optimisation for the translation
+ * model -- optimize_bead_subgraph, param_resolution/global_optimization.py:313-417 with transforms.py:45-53 as estimator.
+ * Edge e joins nodes edge_nodes[2e], edge_nodes[2e+1] and carries n_beads virtual beads in each node's frame
+ * (beads_a / beads_b: n_edges x n_beads x ndim doubles, param_resolution/utils.py:42-78).  Sweep: the nodes in `order`
+ * (ref_node and nodes without edges are skipped) each add mean(adjacent bead - own bead), taken in world coordinates over
+ * all their beads, to their translation.  After each sweep the bead residuals |a + t_a - b - t_b| are stored
+ * (edge_residuals: n_edges x n_beads), their mean of edge means and maximum are appended to mean_hist / max_hist
+ * (max_iter doubles each); from the 7th sweep on the loop stops when max |r - r_previous| / max r < rel_tol.
+ * translations (n_nodes x ndim) is in/out; n_iter_out = sweeps done. */
+int mvs_beads_translation_sweeps(int32_t ndim, int32_t n_nodes, int32_t n_edges, const int32_t* edge_nodes,
+                                 const double* beads_a, const double* beads_b, int32_t n_beads, const int32_t* order,
+                                 int32_t ref_node, int32_t max_iter, double rel_tol, double* translations,
+                                 double* edge_residuals, double* mean_hist, double* max_hist, int32_t* n_iter_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,82 @@
+// Host-side inner loop of the groupwise resolution (no device work): the node sweeps of the virtual-bead optimisation for the
+// translation model.  See include/mvs_hip.h (mvs_beads_translation_sweeps) for the contract; the edge-removal outer loop and
+// the models with a linear part live in multiview_stitcher_amd/param_resolution.py.
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "mvs_hip.h"
+
+extern "C" int mvs_beads_translation_sweeps(int32_t ndim, int32_t n_nodes, int32_t n_edges, const int32_t* edge_nodes,
+                                            const double* beads_a, const double* beads_b, int32_t n_beads, const int32_t* order,
+                                            int32_t ref_node, int32_t max_iter, double rel_tol, double* translations,
+                                            double* edge_residuals, double* mean_hist, double* max_hist, int32_t* n_iter_out) {
+    if (ndim < 1 || ndim > 3 || n_nodes < 1 || n_edges < 0 || n_beads < 1 || max_iter < 0 || !edge_nodes || !order ||
+        !translations || !edge_residuals || !mean_hist || !max_hist || !n_iter_out || (n_edges > 0 && (!beads_a || !beads_b)))
+        return MVS_ERR_INVALID_ARG;
+    for (int e = 0; e < n_edges; ++e)
+        for (int k = 0; k < 2; ++k)
+            if (edge_nodes[2 * e + k] < 0 || edge_nodes[2 * e + k] >= n_nodes) return MVS_ERR_INVALID_ARG;
+    // incident edges per node, in edge order (the order the reference concatenates a node's beads in)
+    std::vector<std::vector<int>> inc((size_t)n_nodes);
+    for (int e = 0; e < n_edges; ++e) {
+        inc[(size_t)edge_nodes[2 * e]].push_back(e);
+        inc[(size_t)edge_nodes[2 * e + 1]].push_back(e);
+    }
+    const size_t per_edge = (size_t)n_beads * (size_t)ndim;
+    std::vector<double> prev((size_t)n_edges * (size_t)n_beads, 0.0);
+    int it = 0;
+    for (; it < max_iter; ++it) {
+        for (int s = 0; s < n_nodes; ++s) {
+            const int c = order[s];
+            if (c < 0 || c >= n_nodes) return MVS_ERR_INVALID_ARG;
+            if (inc[(size_t)c].empty() || c == ref_node) continue;
+            // TranslationTransform.estimate: mean over all bead pairs of (adjacent bead - own bead), both in world coordinates
+            double sum[3] = {0.0, 0.0, 0.0};
+            for (int e : inc[(size_t)c]) {
+                const bool c_is_a = edge_nodes[2 * e] == c;
+                const int other = c_is_a ? edge_nodes[2 * e + 1] : edge_nodes[2 * e];
+                const double* own = (c_is_a ? beads_a : beads_b) + (size_t)e * per_edge;
+                const double* adj = (c_is_a ? beads_b : beads_a) + (size_t)e * per_edge;
+                for (int b = 0; b < n_beads; ++b)
+                    for (int d = 0; d < ndim; ++d)
+                        sum[d] += (adj[b * ndim + d] + translations[(size_t)other * ndim + d]) -
+                                  (own[b * ndim + d] + translations[(size_t)c * ndim + d]);
+            }
+            const double cnt = (double)(inc[(size_t)c].size() * (size_t)n_beads);
+            for (int d = 0; d < ndim; ++d) translations[(size_t)c * ndim + d] += sum[d] / cnt;
+        }
+        // bead residuals of every edge, their mean of means and overall maximum
+        double mean_acc = 0.0, mx = 0.0;
+        for (int e = 0; e < n_edges; ++e) {
+            const int a = edge_nodes[2 * e], b2 = edge_nodes[2 * e + 1];
+            double esum = 0.0;
+            for (int b = 0; b < n_beads; ++b) {
+                double q = 0.0;
+                for (int d = 0; d < ndim; ++d) {
+                    const double v = (beads_a[(size_t)e * per_edge + b * ndim + d] + translations[(size_t)a * ndim + d]) -
+                                     (beads_b[(size_t)e * per_edge + b * ndim + d] + translations[(size_t)b2 * ndim + d]);
+                    q += v * v;
+                }
+                const double r = std::sqrt(q);
+                edge_residuals[(size_t)e * n_beads + b] = r;
+                esum += r;
+                mx = std::fmax(mx, r);
+            }
+            mean_acc += esum / (double)n_beads;
+        }
+        mean_hist[it] = n_edges ? mean_acc / (double)n_edges : 0.0;
+        max_hist[it] = mx;
+        bool converged = false;
+        if (it > 5) {   // global_optimization.py:399-417: largest relative change of any bead residual
+            double rel = 0.0;
+            if (mx > 0.0)
+                for (size_t i = 0; i < prev.size(); ++i) rel = std::fmax(rel, std::fabs((edge_residuals[i] - prev[i]) / mx));
+            converged = rel < rel_tol;
+        }
+        for (size_t i = 0; i < prev.size(); ++i) prev[i] = edge_residuals[i];
+        if (converged) { ++it; break; }
+    }
+    *n_iter_out = it;
+    return MVS_OK;
+}

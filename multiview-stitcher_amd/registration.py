@@ -468,9 +468,9 @@ def resolve_translations(n_views, edges, pair_results, reference_view=0, weights
     """Minimal groupwise resolution for translation-only pairwise results: least squares on
     tau_j - tau_i = -d_ij with tau_ref = 0 (each connected component gets its own reference).
 
-    Stand-in for param_resolution.groupwise_resolution(method="global_optimization")
-    (src/multiview_stitcher/param_resolution/__init__.py:44-150): the reference iterates virtual-bead fits and
-    prunes inconsistent edges; for consistent translation graphs both reduce to this linear system."""
+    Not the reference's method (that is ``param_resolution.groupwise_resolution``); kept as
+    ``groupwise_resolution_method="linear"``: the fixed point of the reference's bead sweeps on a translation graph
+    when no edge is pruned, in one solve."""
     ndim = np.asarray(pair_results[0]["transform"]).shape[0] - 1 if pair_results else 0
     params = [np.eye(ndim + 1) for _ in range(n_views)]
     if not edges:
@@ -532,9 +532,11 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
     (3) groupwise resolution, (4) write ``new_transform_key`` (rebased on ``transform_key``).
     Accepts MultiscaleSpatialImages or SpatialImages (numpy- or DeviceArray-backed).  Host-side
     stand-ins, documented in DESIGN.md: the overlap graph is built from world AABBs (axis-aligned
-    views) and every pruning method keeps the face-sharing neighbours; the groupwise resolution is
-    the linear translation solve of ``resolve_translations``."""
-    from . import msi_utils, mv_graph
+    views) and every pruning method keeps the face-sharing neighbours.  The groupwise resolution is
+    ``param_resolution.groupwise_resolution`` (``groupwise_resolution_method``: "global_optimization" (default),
+    "shortest_paths", a callable, or "linear" for the plain least-squares solve of ``resolve_translations``;
+    ``groupwise_resolution_kwargs`` e.g. ``{"transform": "rigid", "reference_view": 0}``)."""
+    from . import msi_utils, mv_graph, param_resolution
     from . import spatial_image_utils as si_utils
 
     if transform_key is None:
@@ -561,7 +563,7 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
         edges = [tuple(p) for p in pairs]
 
     # (2) pairwise registrations per time point
-    params_t, all_results = [], []
+    params_t, all_results, resolution_info = [], [], []
     for it in range(nt):
         fields = [s.isel({"t": it}) if "t" in s.dims else s for s in sims_reg]
         for f, s in zip(fields, sims_reg):
@@ -574,8 +576,17 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
         keep = list(range(len(edges)))
         if post_registration_do_quality_filter:
             keep = [k for k in keep if results[k]["quality"] >= post_registration_quality_threshold]
-        # (3) groupwise resolution
-        params_t.append(resolve_translations(len(sims), [edges[k] for k in keep], [results[k] for k in keep]))
+        # (3) groupwise resolution (registration.py:2560-2580 -> param_resolution.groupwise_resolution)
+        if groupwise_resolution_method == "linear":
+            params_t.append(resolve_translations(len(sims), [edges[k] for k in keep], [results[k] for k in keep]))
+            resolution_info.append(None)
+        else:
+            g = param_resolution.RegGraph(range(len(sims)), {v: sps[v] for v in range(len(sims))})
+            for k in keep:
+                g.add_edge(edges[k][0], edges[k][1], results[k]["transform"], quality=results[k]["quality"], bbox=results[k]["bbox"])
+            p_nodes, info = param_resolution.groupwise_resolution(g, groupwise_resolution_method, **dict(groupwise_resolution_kwargs or {}))
+            params_t.append([p_nodes[v] for v in range(len(sims))])
+            resolution_info.append(info)
         all_results.append(results)
     params = [np.stack([params_t[it][v] for it in range(nt)], axis=0) if "t" in sims_reg[0].dims else params_t[0][v]
               for v in range(len(sims))]
@@ -589,6 +600,7 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
                 si_utils.set_sim_affine(m, p, new_transform_key, base_transform_key=transform_key)
     if return_dict:
         return {"params": params,
+                "groupwise_resolution": {"info": resolution_info},
                 "pairwise_registration": {"edges": edges, "results": all_results,
                                           "metrics": {"qualities": {e: r["quality"] for e, r in zip(edges, all_results[0])}}}}
     return params

@@ -42,13 +42,16 @@ def test_north_star_register_and_fuse_properties(hip_device):
     registration.register(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, new_transform_key="reg", device=0,
                           pre_registration_pruning_method="keep_axis_aligned")
     rec = np.array([param_utils.select_time(si.get_affine_from_sim(s, "reg"), 0)[:3, 3] for s in sims])
-    np.testing.assert_allclose(rec, jitters - jitters[0], atol=1e-6)
+    # (the global optimisation keeps its best-connected view fixed, not tile 0, and its 500 bead sweeps -- the reference's
+    # max_iter -- leave ~3e-7 px on this consistent graph; fuse snaps offsets within 1e-6 of the grid, transformation.py:72-83)
+    np.testing.assert_allclose(rec - rec[0], jitters - jitters[0], atol=1e-6)
+    ref_shift = np.round(rec[0]).astype(int)      # = -jitter of the fixed view: world x shows ground truth x + pad - ref_shift
 
     # (2) idempotence: registering the registered mosaic finds no further shift
     registration.register(sims, transform_key="reg", new_transform_key="reg2", device=0,
                           pre_registration_pruning_method="keep_axis_aligned")
     rec2 = np.array([param_utils.select_time(si.get_affine_from_sim(s, "reg2"), 0)[:3, 3] for s in sims])
-    np.testing.assert_allclose(rec2, rec, atol=1e-6)
+    np.testing.assert_allclose(rec2 - rec2[0], rec - rec[0], atol=2e-6)
 
     # (3) the fused mosaic reproduces the ground truth: all tiles were cut from one volume, so every weighted mean is a
     # mean of identical values -- exact where one view or unit weights contribute, and at most one count low where the
@@ -58,8 +61,8 @@ def test_north_star_register_and_fuse_properties(hip_device):
     _lib.synchronize(0)
     f = _as_torch(torch, fused.data)
     fo = np.round(si.get_origin_from_sim(fused, asarray=True)).astype(int)
-    assert np.allclose(si.get_origin_from_sim(fused, asarray=True), fo)
-    sl = tuple(slice(int(o + pad), int(o + pad + n)) for o, n in zip(fo, f.shape))
+    assert np.allclose(si.get_origin_from_sim(fused, asarray=True), fo, atol=1e-5)
+    sl = tuple(slice(int(o + pad - r), int(o + pad - r + n)) for o, r, n in zip(fo, ref_shift, f.shape))
     want = gt.view(torch.int16)[sl]
     assert want.shape == f.shape
     # (the outermost voxels of the mosaic are excluded: next to the edges of a tile its blend weight rounds to 0 and the
@@ -71,7 +74,7 @@ def test_north_star_register_and_fuse_properties(hip_device):
     frac_low = float((diff != 0).float().mean())
     assert frac_low < 0.05, frac_low
     # single-cover interior of tile (1, 1, 1): exact copy
-    c = (origins[21] + rec[21] - fo).astype(int) + 110 - m
+    c = np.round(origins[21] + rec[21] - fo).astype(int) + 110 - m
     box = tuple(slice(int(a), int(a + 290)) for a in c)
     assert bool((diff[box] == 0).all())
     del diff, want

@@ -1,0 +1,156 @@
+"""CPU tests of the groupwise resolution restatement.  The reference's package cannot be imported here
+(xarray / pandas / dask absent), so the restatement is pinned by: skimage-0.18.3 golden vectors for the Umeyama fit,
+networkx itself for the iteration orders the tie breaks depend on, closed-form answers on consistent graphs, and the
+properties the reference's own tests assert (T/test_param_resolution.py:329-352, 360-406, 417-464)."""
+import os
+
+import numpy as np
+import pytest
+
+from multiview_stitcher_amd import param_resolution as pr
+from multiview_stitcher_amd import param_utils
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "skimage018_transforms.npz")
+
+
+def test_umeyama_matches_skimage_golden():
+    z = np.load(GOLD)
+    for k in range(int(z["n_cases"])):
+        src, dst = z[f"c{k}_src"], z[f"c{k}_dst"]
+        np.testing.assert_allclose(pr._umeyama(src, dst, False), z[f"c{k}_rigid"], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(pr._umeyama(src, dst, True), z[f"c{k}_similarity"], rtol=1e-12, atol=1e-12)
+
+
+def test_edge_and_component_order_match_networkx():
+    nx = pytest.importorskip("networkx")
+    rng = np.random.default_rng(0)
+    for _ in range(30):
+        n = int(rng.integers(3, 12))
+        nodes = list(rng.permutation(n))
+        pairs = [(a, b) for a in range(n) for b in range(a + 1, n)]
+        ins = [pairs[i] for i in rng.permutation(len(pairs))[: int(rng.integers(1, len(pairs) + 1))]]
+        g = nx.Graph()
+        g.add_nodes_from(nodes)
+        g.add_edges_from(ins)
+        want = [tuple(sorted(e)) for e in g.edges]
+        assert pr._nx_edge_order(nodes, ins) == want
+        rg = pr.RegGraph(nodes)
+        for a, b in ins:
+            rg.add_edge(a, b, np.eye(3), bbox=[[0, 0], [1, 1]])
+        assert rg.connected_components() == list(nx.connected_components(g))
+
+
+def _grid_graph(nx_, ny_, ndim=2, noise=0.0, seed=0, quality=1.0):
+    """Views on a grid with hidden true offsets tau; edge (i, j) transform = translate(tau_i - tau_j) (+ noise), i.e. the
+    pairwise result that P = translate(tau) resolves exactly."""
+    rng = np.random.default_rng(seed)
+    n = nx_ * ny_
+    tau = rng.normal(0, 3, (n, ndim))
+    g = pr.RegGraph(range(n), {v: {"spacing": dict(zip("zyx"[-ndim:], [1.0] * ndim))} for v in range(n)})
+    for a in range(n):
+        ya, xa = divmod(a, nx_)
+        for b in [a + 1 if xa + 1 < nx_ else None, a + nx_ if ya + 1 < ny_ else None]:
+            if b is None:
+                continue
+            t = tau[a] - tau[b] + (rng.normal(0, noise, ndim) if noise else 0)
+            lo = rng.normal(0, 50, ndim)
+            g.add_edge(a, b, param_utils.affine_from_translation(t), quality=quality, bbox=[lo, lo + rng.uniform(20, 60, ndim)])
+    return g, tau
+
+
+@pytest.mark.parametrize("transform", ["translation", "rigid", "similarity", "affine"])
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_consistent_graph_is_resolved_exactly(transform, ndim):
+    g, tau = _grid_graph(3, 3, ndim)
+    params, info = pr.groupwise_resolution(g, "global_optimization", transform=transform, reference_view=0)
+    for v in range(9):
+        want = param_utils.affine_from_translation(tau[v] - tau[0])
+        # the sweeps stop at a relative change of 1e-4 (rel_tol): models with a linear part keep a ~1e-4 residue there, which
+        # the lever arm of the beads (|x| ~ 100) turns into a few 1e-2 of translation
+        np.testing.assert_allclose(params[v][:ndim, :ndim], want[:ndim, :ndim], atol=1e-3)
+        np.testing.assert_allclose(params[v][:ndim, ndim], want[:ndim, ndim], atol=1e-2 if transform == "translation" else 0.15)
+        if transform == "translation":      # T/test_param_resolution.py:349: the linear part stays the identity
+            np.testing.assert_array_equal(params[v][:ndim, :ndim], np.eye(ndim))
+    assert sorted(info["used_edges"][0]) == sorted(g.edges)
+    assert max(info["edge_residuals"][0].values()) < 0.05
+    m = info["metrics"][0]
+    assert m["max_residual"][-1] <= m["max_residual"][0] and len(m["iteration"]) == len(m["mean_residual"])
+
+
+def test_noisy_graph_close_to_least_squares():
+    from multiview_stitcher_amd import registration
+
+    g, tau = _grid_graph(4, 3, 2, noise=0.2, seed=3)
+    params, info = pr.groupwise_resolution(g, "global_optimization", reference_view=0, abs_tol=100.0)
+    edges = list(g.edges)
+    ls = registration.resolve_translations(12, edges, [{"transform": g.edges[e]["transform"]} for e in edges])
+    got = np.array([params[v][:2, 2] for v in range(12)])
+    want = np.array([p[:2, 2] for p in ls])
+    # the bead iteration is a Jacobi / Gauss-Seidel sweep of the same quadratic problem: same fixed point up to rel_tol
+    np.testing.assert_allclose(got, want, atol=0.05)
+    assert all(r > 0 for r in info["edge_residuals"][0].values())      # T/test_param_resolution.py:406
+
+
+@pytest.mark.parametrize("method", ["global_optimization", "shortest_paths"])
+def test_bad_edge_is_not_used(method):
+    """T/test_param_resolution.py:417-464: one grossly wrong, low-quality edge on a cycle must not survive."""
+    g, tau = _grid_graph(3, 3, 2, noise=0.05, seed=1)
+    bad = (4, 5)
+    g.edges[bad]["quality"] = 0.01
+    g.edges[bad]["transform"] = param_utils.affine_from_translation([100.0, 100.0])
+    params, info = pr.groupwise_resolution(g, method, reference_view=0)
+    assert bad not in info["used_edges"][0]
+    got = np.array([params[v][:2, 2] for v in range(9)])
+    np.testing.assert_allclose(got, tau - tau[0], atol=0.5)
+    assert info["edge_residuals"][0][bad] > 50
+
+
+def test_shortest_paths_residuals():
+    """T/test_param_resolution.py:360-404: ~0 on used edges, > 0 on the others."""
+    g, _ = _grid_graph(3, 3, 2, noise=0.3, seed=5)
+    _, info = pr.groupwise_resolution(g, "shortest_paths", reference_view=0)
+    used = set(info["used_edges"][0])
+    assert len(used) == 8
+    for e, r in info["edge_residuals"][0].items():
+        assert (r < 1e-6) if e in used else (r > 1e-5)
+
+
+def test_components_two_views_and_errors():
+    g, tau = _grid_graph(2, 1, 2)
+    g.nodes += [7, 8, 9]
+    g.add_edge(8, 7, param_utils.affine_from_translation([1.0, 2.0]), bbox=[[0, 0], [5, 5]])     # stored as (7, 8), inverted
+    g.stack_props.update({v: {"spacing": {"y": 1.0, "x": 1.0}} for v in (7, 8, 9)})
+    params, info = pr.groupwise_resolution(g, "global_optimization")
+    assert set(params) == {0, 1, 7, 8, 9}
+    np.testing.assert_array_equal(params[9], np.eye(3))            # isolated view
+    np.testing.assert_array_equal(params[0], np.eye(3))            # default reference of a 2-view graph is min(nodes) ...
+    np.testing.assert_allclose(params[1][:2, 2], tau[1] - tau[0], atol=1e-9)
+    np.testing.assert_allclose(params[8][:2, 2] - params[7][:2, 2], [1.0, 2.0], atol=1e-9)
+    with pytest.raises(pr.NotEnoughOverlapError):
+        pr.groupwise_resolution(pr.RegGraph([0, 1]), "global_optimization")
+    with pytest.raises(ValueError):
+        pr.groupwise_resolution(g, "no_such_method")
+    with pytest.raises(ValueError):
+        pr.groupwise_resolution(g, "global_optimization", transform="projective")
+    pr.register_groupwise_resolution_method("ident", lambda sub, **kw: ({n: np.eye(3) for n in sub.nodes}, {"metrics": None, "used_edges": []}))
+    p2, _ = pr.groupwise_resolution(g, "ident")
+    assert all(np.array_equal(v, np.eye(3)) for v in p2.values())
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_native_translation_sweeps_equal_numpy_sweeps(ndim, monkeypatch):
+    """mvs_beads_translation_sweeps (host C++ in libmvs_hip.so) against the generic numpy loop on a graph with a bad edge
+    (several outer iterations, edge removal): same parameters, same per-sweep history, same surviving edges."""
+    g, _ = _grid_graph(4, 3, ndim, noise=0.3, seed=11, quality=0.8)
+    g.edges[(5, 6)]["transform"] = param_utils.affine_from_translation([40.0] * ndim)
+    g.edges[(5, 6)]["quality"] = 0.1
+    p_nat, i_nat = pr.groupwise_resolution(g, "global_optimization", reference_view=2)
+    monkeypatch.setattr(pr, "_FORCE_NUMPY", True)
+    p_np, i_np = pr.groupwise_resolution(g, "global_optimization", reference_view=2)
+    assert i_nat["used_edges"] == i_np["used_edges"] and (5, 6) not in i_nat["used_edges"][0]
+    for v in p_np:
+        np.testing.assert_allclose(p_nat[v], p_np[v], rtol=0, atol=1e-10)
+    m_nat, m_np = i_nat["metrics"][0], i_np["metrics"][0]
+    assert m_nat["iteration"] == m_np["iteration"]
+    np.testing.assert_allclose(m_nat["max_residual"], m_np["max_residual"], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(m_nat["mean_residual"], m_np["mean_residual"], rtol=1e-9, atol=1e-12)

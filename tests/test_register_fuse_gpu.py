@@ -15,7 +15,7 @@ def test_register_recovers_hidden_jitter_2d(hip_device):
                                    reg_channel_index=0)
     from multiview_stitcher_amd import param_utils
     got = np.array([param_utils.select_time(p, 0)[:-1, -1] for p in params])   # params are t-stacked like the reference's
-    np.testing.assert_allclose(got, jit - jit[0], atol=0.5)
+    np.testing.assert_allclose(got - got[0], jit - jit[0], atol=0.5)      # relative to tile 0 (the resolver picks its own reference view)
     # new key = params rebased on the metadata transform (msi_utils.set_affine_transform, base_transform_key)
     t_new = msi_utils.get_transform_from_msim(msims[3], "reg")
     t_old = msi_utils.get_transform_from_msim(msims[3], sample_data.METADATA_TRANSFORM_KEY)
@@ -32,7 +32,7 @@ def test_register_3d_with_binning_and_device_tiles(hip_device):
                                 registration_binning={"z": 1, "y": 2, "x": 2}, return_dict=True)
     got = np.array([p[:-1, -1] for p in res["params"]])
     want = jit - jit[0]
-    np.testing.assert_allclose(got, want, atol=1.01)      # binning 2 -> half-resolution shifts
+    np.testing.assert_allclose(got - got[0], want, atol=1.01)      # binning 2 -> half-resolution shifts
     assert all(q > 0.5 for q in res["pairwise_registration"]["metrics"]["qualities"].values())
 
 
@@ -42,7 +42,8 @@ def test_register_then_fuse_end_to_end(hip_device):
 
     sims, jit, gt = sample_data.generate_tiled_dataset(ndim=2, tile_shape=(96, 96), tiles=(2, 2), overlap=(32, 32),
                                                        dtype=np.uint16, max_jitter=2, seed=9)
-    registration.register(sims, transform_key=sample_data.METADATA_TRANSFORM_KEY, new_transform_key="reg", reg_channel_index=0)
+    registration.register(sims, transform_key=sample_data.METADATA_TRANSFORM_KEY, new_transform_key="reg", reg_channel_index=0,
+                          groupwise_resolution_kwargs={"reference_view": 0})     # tile 0 keeps its stage position
     fused = fusion.fuse(sims, transform_key="reg", output_chunksize={"y": 64, "x": 64})
     data = np.asarray(fused.data)[0, 0]
     o = np.array([fused.coords["y"][0], fused.coords["x"][0]])
