@@ -3,9 +3,9 @@
 Mirror of the parts of the reference's ``mv_graph`` that feed kernel arguments:
 ``get_chunk_bbs`` (mv_graph.py:934-986), ``get_vertices_from_stack_props``
 (mv_graph.py:423-444), ``get_overlap_for_bbs`` (mv_graph.py:989-1117),
-``project_bb_along_dim`` (mv_graph.py:1120-1145), plus a closed-form AABB
-neighbour graph for axis-aligned tile grids standing in for the Qhull-based
-``build_view_adjacency_graph_from_msims`` (mv_graph.py:35-180).
+``project_bb_along_dim`` (mv_graph.py:1120-1145), and the view adjacency graph
+with its pruning methods (mv_graph.py:35-338, 636-881, 1148-1196; second half
+of this file).
 
 Bounding boxes are the reference's dict-of-dicts:
 ``{"origin": {dim: float}, "spacing": {dim: float}, "shape": {dim: int}}``.
@@ -17,7 +17,7 @@ from itertools import product
 
 import numpy as np
 
-from . import transformation
+from . import param_utils, transformation
 
 SPATIAL_DIMS = ["z", "y", "x"]
 
@@ -175,3 +175,416 @@ def prune_to_axis_aligned(pairs, stack_props_list, affines):
         if np.sum(far) == 1:
             kept.append((i, j, vol))
     return kept
+
+
+# ---- view adjacency graph and its pruning ---------------------------------------------------------------
+# Restatement of mv_graph.py:35-180 (graph construction), :183-338 (overlap of two views as the volume of the
+# intersection of their halfspaces), :636-881 and :1148-1196 (pruning methods) without networkx / dask / skimage.
+# The geometric kernels are the reference's own scipy call sites (cKDTree, linprog, HalfspaceIntersection, ConvexHull:
+# scipy is present here and on the GPU box); axis-aligned pairs -- the regular-grid case -- take a closed form instead
+# of the three Qhull / LP calls per pair.
+class NotEnoughOverlapError(Exception):
+    pass
+
+
+class Graph:
+    """Undirected graph with networkx's iteration orders (nodes in insertion order, a node's neighbours in the order
+    its edges were added, ``edges()`` node by node with every edge once): the reference's tie breaks depend on them."""
+
+    def __init__(self, nodes=()):
+        self.adj = {}
+        self.node_attrs = {}
+        for n in nodes:
+            self.add_node(n)
+
+    nodes = property(lambda self: list(self.adj))
+
+    def add_node(self, n, **attrs):
+        self.adj.setdefault(n, {})
+        self.node_attrs.setdefault(n, {}).update(attrs)
+
+    def add_edge(self, u, v, **attrs):
+        self.add_node(u)
+        self.add_node(v)
+        d = self.adj[u].get(v, {})
+        d.update(attrs)
+        self.adj[u][v] = d
+        self.adj[v][u] = d
+
+    def remove_edge(self, u, v):
+        del self.adj[u][v]
+        if u != v:
+            del self.adj[v][u]
+
+    def has_edge(self, u, v):
+        return v in self.adj.get(u, {})
+
+    def edges(self, data=False):
+        seen, out = set(), []
+        for n, nbrs in self.adj.items():
+            for m, d in nbrs.items():
+                if m not in seen:
+                    out.append((n, m, d) if data else (n, m))
+            seen.add(n)
+        return out
+
+    def degree(self, n):
+        return len(self.adj[n])
+
+    def copy(self):
+        g = Graph()
+        for n in self.adj:
+            g.add_node(n, **self.node_attrs[n])
+        for u, v, d in self.edges(data=True):
+            g.add_edge(u, v, **dict(d))
+        # keep every node's neighbour order (add_edge above inserts in edge order, which can differ for the far endpoint)
+        g.adj = {n: {m: g.adj[n][m] for m in self.adj[n]} for n in self.adj}
+        return g
+
+    def connected_components(self):
+        seen, comps = set(), []
+        for s in self.adj:
+            if s in seen:
+                continue
+            comp, queue = {s}, [s]
+            while queue:
+                v = queue.pop()
+                for w in self.adj[v]:
+                    if w not in comp:
+                        comp.add(w)
+                        queue.append(w)
+            seen |= comp
+            comps.append(comp)
+        return comps
+
+
+def get_faces_from_stack_props(stack_props):
+    """Corner points of the 2 * ndim faces in world coordinates (mv_graph.py:386-420)."""
+    sdims = [d for d in ["z", "y", "x"] if d in stack_props["spacing"]]
+    ndim = len(sdims)
+    gv = np.array(list(np.ndindex(*([2] * ndim))))
+    faces = np.array([gv[gv[:, ax] == side] for ax in range(ndim) for side in (0, 1)], dtype=np.float64)
+    faces = faces * (np.array([stack_props["shape"][d] for d in sdims]) - 1) * np.array([stack_props["spacing"][d] for d in sdims]) \
+        + np.array([stack_props["origin"][d] for d in sdims])
+    if "transform" in stack_props:
+        shp = faces.shape
+        faces = transformation.transform_pts(faces.reshape(-1, ndim), param_utils.select_time(np.asarray(stack_props["transform"]), 0)).reshape(shp)
+    return faces
+
+
+def get_center_from_stack_props(stack_props):
+    """World coordinates of the stack centre (mv_graph.py:475-493)."""
+    sdims = [d for d in SPATIAL_DIMS if d in stack_props["origin"]]
+    c = np.array([stack_props["origin"][d] + stack_props["spacing"][d] * (stack_props["shape"][d] - 1) / 2 for d in sdims])
+    if "transform" in stack_props:
+        c = transformation.transform_pts(c[None], param_utils.select_time(np.asarray(stack_props["transform"]), 0))[0]
+    return c
+
+
+def get_halfspace_equations_from_stack_props(stack_props):
+    """Rows [n, c] with n . x + c <= 0 inside the stack (mv_graph.py:183-218)."""
+    faces = get_faces_from_stack_props(stack_props)
+    ndim = faces.shape[-1]
+    center = get_center_from_stack_props(stack_props)
+    eqs = []
+    for face in faces:
+        if ndim == 2:
+            normal = np.array([-(face[1][1] - face[0][1]), face[1][0] - face[0][0]])
+        else:
+            normal = np.cross(face[1] - face[0], face[2] - face[0])
+        normal = normal / np.linalg.norm(normal)
+        if np.dot(normal, center) - np.dot(normal, face[0]) > 0:
+            normal = -normal
+        eqs.append(np.concatenate([normal, [-np.dot(normal, face[0])]]))
+    return np.array(eqs)
+
+
+def _axis_aligned_box(stack_props, tol=1e-12):
+    """(lo, hi) if the stack's world frame is axis-aligned without permutation (transform = diag scale + shift), else None."""
+    sdims = [d for d in ["z", "y", "x"] if d in stack_props["spacing"]]
+    n = len(sdims)
+    lo = np.array([stack_props["origin"][d] for d in sdims], dtype=np.float64)
+    hi = lo + (np.array([stack_props["shape"][d] for d in sdims]) - 1) * np.array([stack_props["spacing"][d] for d in sdims])
+    if "transform" in stack_props:
+        a = param_utils.select_time(np.asarray(stack_props["transform"], dtype=np.float64), 0)
+        lin = a[:n, :n]
+        if np.any(np.abs(lin - np.diag(np.diag(lin))) > tol) or np.any(np.diag(lin) <= 0):
+            return None
+        lo, hi = np.diag(lin) * lo + a[:n, n], np.diag(lin) * hi + a[:n, n]
+    return lo, hi
+
+
+def get_overlap_between_pair_of_stack_props(stack_props1, stack_props2):
+    """Volume (area in 2D) of the intersection of two views in world coordinates (mv_graph.py:301-338); -1 when the
+    intersection is degenerate / empty.  Axis-aligned pairs: product of the interval overlaps, the value Qhull returns
+    for a box; general pairs: the reference's linprog + HalfspaceIntersection + ConvexHull sequence."""
+    b1, b2 = _axis_aligned_box(stack_props1), _axis_aligned_box(stack_props2)
+    if b1 is not None and b2 is not None:
+        ext = np.minimum(b1[1], b2[1]) - np.maximum(b1[0], b2[0])
+        return (float(np.prod(ext)), None) if np.all(ext > 0) else (-1, None)
+    from scipy.optimize import linprog
+    from scipy.spatial import ConvexHull, HalfspaceIntersection
+    from scipy.spatial import QhullError
+
+    eqs = np.concatenate([get_halfspace_equations_from_stack_props(stack_props1), get_halfspace_equations_from_stack_props(stack_props2)])
+    norm = np.linalg.norm(eqs[:, :-1], axis=1).reshape(-1, 1)
+    c = np.zeros(eqs.shape[1])
+    c[-1] = -1
+    res = linprog(c, A_ub=np.hstack((eqs[:, :-1], norm)), b_ub=-eqs[:, -1:], bounds=(None, None))
+    if res.x is None:
+        return -1, None
+    try:
+        hs = HalfspaceIntersection(eqs, res.x[:-1])
+        return float(ConvexHull(hs.intersections).volume), hs
+    except QhullError:
+        return -1, None
+
+
+def extend_stack_props(stack_props, extend_by):
+    """spatial_image_utils.extend_stack_props (spatial_image_utils.py:889-913); returns a new dict."""
+    sp = {k: (dict(v) if isinstance(v, dict) else v) for k, v in stack_props.items()}
+    if not isinstance(extend_by, dict):
+        extend_by = {d: extend_by for d in sp["spacing"]}
+    for d, val in extend_by.items():
+        sp["shape"][d] = sp["shape"][d] + int(np.ceil(2 * val / sp["spacing"][d]))
+        sp["origin"][d] = sp["origin"][d] - val
+    return sp
+
+
+def build_view_adjacency_graph(stack_props_list, overlap_tolerance=None, pairs=None):
+    """Views as nodes (attribute ``stack_props``, incl. ``transform``), an edge with ``overlap`` = intersection volume
+    between every pair of views that overlap (mv_graph.py:35-180).  Candidate pairs: views whose centres are closer than
+    the largest view diagonal + 1 (cKDTree ball query, as in the reference), unless ``pairs`` is given."""
+    from scipy.spatial import cKDTree
+
+    sps = [extend_stack_props(sp, overlap_tolerance) if overlap_tolerance is not None else sp for sp in stack_props_list]
+    g = Graph(range(len(sps)))
+    for i, sp in enumerate(sps):
+        g.node_attrs[i]["stack_props"] = sp
+    if pairs is None:
+        centers = np.array([get_center_from_stack_props(sp) for sp in sps])
+        diam = max(np.linalg.norm([sp["shape"][d] * sp["spacing"][d] for d in sp["spacing"]]) for sp in sps)
+        tree = cKDTree(centers)
+        pairs = [(i, j) for i in range(len(sps)) for j in tree.query_ball_point(centers[i], diam + 1) if i != j]
+    # overlap volume per unordered pair (the reference evaluates (i, j) and (j, i); the volume is symmetric): all pairs of
+    # axis-aligned views in one vectorised closed form, the others one by one through the halfspace intersection
+    keys = list(dict.fromkeys((min(i, j), max(i, j)) for i, j in pairs))
+    boxes = [_axis_aligned_box(sp) for sp in sps]
+    cache = {}
+    aa = [k for k in keys if boxes[k[0]] is not None and boxes[k[1]] is not None]
+    if aa:
+        lo = np.array([b[0] if b is not None else np.zeros(len(sps[0]["spacing"])) for b in boxes])
+        hi = np.array([b[1] if b is not None else np.zeros(len(sps[0]["spacing"])) for b in boxes])
+        ia, ib = np.array([k[0] for k in aa]), np.array([k[1] for k in aa])
+        ext = np.minimum(hi[ia], hi[ib]) - np.maximum(lo[ia], lo[ib])
+        vol = np.where(np.all(ext > 0, axis=1), np.prod(ext, axis=1), -1.0)
+        cache.update({k: float(v) for k, v in zip(aa, vol)})
+    for k in keys:
+        if k not in cache:
+            cache[k] = get_overlap_between_pair_of_stack_props(sps[k[0]], sps[k[1]])[0]
+    for i, j in pairs:
+        if cache[(min(i, j), max(i, j))] > 0:        # "overlap 0 means one pixel overlap" is not an edge
+            g.add_edge(i, j, overlap=cache[(min(i, j), max(i, j))])
+    return g
+
+
+def edge_betweenness_centrality(g):
+    """Brandes' algorithm for unweighted graphs, normalised by n (n - 1) -- networkx.edge_betweenness_centrality with its
+    defaults, same traversal and accumulation order (the values are compared with <=, so rounding matters)."""
+    nodes = g.nodes
+    bet = {e: 0.0 for e in g.edges()}
+    for s in nodes:
+        S, P, sigma, D = [], {v: [] for v in nodes}, dict.fromkeys(nodes, 0.0), {s: 0}
+        sigma[s] = 1.0
+        queue, head = [s], 0
+        while head < len(queue):
+            v = queue[head]
+            head += 1
+            S.append(v)
+            for w in g.adj[v]:
+                if w not in D:
+                    queue.append(w)
+                    D[w] = D[v] + 1
+                if D[w] == D[v] + 1:
+                    sigma[w] += sigma[v]
+                    P[w].append(v)
+        delta = dict.fromkeys(S, 0)
+        while S:
+            w = S.pop()
+            coeff = (1 + delta[w]) / sigma[w]
+            for v in P[w]:
+                c = sigma[v] * coeff
+                bet[(v, w) if (v, w) in bet else (w, v)] += c
+                delta[v] += c
+    n = len(nodes)
+    if n > 1:
+        for e in bet:
+            bet[e] *= 1 / (n * (n - 1))
+    return bet
+
+
+def greedy_color(g):
+    """networkx.coloring.greedy_color, strategy largest_first: nodes by descending degree (stable), smallest free colour."""
+    colors = {}
+    for u in sorted(g.nodes, key=g.degree, reverse=True):
+        used = {colors[v] for v in g.adj[u] if v in colors}
+        c = 0
+        while c in used:
+            c += 1
+        colors[u] = c
+    return colors
+
+
+def prune_graph_to_alternating_colors(g, n_colors=2, return_colors=True):
+    """Remove the weakest edges (overlap + a betweenness bonus of at most half the smallest overlap) in rising order until
+    the graph can be coloured greedily with ``n_colors`` colours (mv_graph.py:664-741); edges whose removal would isolate
+    a view stay.  On a regular grid this removes the diagonal neighbours."""
+    if not g.edges():
+        return (g, {n: 0 for n in g.nodes}) if return_colors else g
+    gp = g.copy()
+    cent = edge_betweenness_centrality(g)
+    cmax, cmin = max(cent.values()), min(cent.values())
+    min_overlap = min(d["overlap"] for _, _, d in gp.edges(data=True))
+    if cmax > cmin:
+        cent = {e: (c - cmin) / (cmax - cmin) * 0.5 * min_overlap for e, c in cent.items()}
+    vals = {(a, b): cent[(a, b)] + d["overlap"] for a, b, d in gp.edges(data=True)}
+    levels = sorted(np.unique(list(vals.values())))
+    k = 0
+    while True:
+        colors = greedy_color(gp)
+        if len(set(colors.values())) <= n_colors:
+            break
+        drop = [(a, b) for a, b in gp.edges() if vals[(a, b)] <= levels[k] and min(gp.degree(a), gp.degree(b)) > 1]
+        for a, b in drop:
+            gp.remove_edge(a, b)
+        k += 1
+    return (gp, colors) if return_colors else gp
+
+
+def _dijkstra_paths(g, source, weight):
+    """Shortest paths from ``source`` by edge attribute ``weight``; among equal-length paths the first one found in
+    adjacency order wins (networkx's bidirectional search may pick another one -- same total weight)."""
+    import heapq
+
+    dist, prev, done = {source: 0.0}, {}, set()
+    heap, count = [(0.0, 0, source)], 1
+    while heap:
+        d, _, v = heapq.heappop(heap)
+        if v in done:
+            continue
+        done.add(v)
+        for w, attrs in g.adj[v].items():
+            nd = d + attrs[weight]
+            if w not in done and nd < dist.get(w, np.inf):
+                dist[w], prev[w] = nd, v
+                heapq.heappush(heap, (nd, count, w))
+                count += 1
+    paths = {}
+    for n in dist:
+        p = [n]
+        while p[-1] != source:
+            p.append(prev[p[-1]])
+        paths[n] = p[::-1]
+    return paths
+
+
+def prune_to_shortest_weighted_paths(g):
+    """Keep the edges on the overlap-weighted shortest paths from each component's best-connected view
+    (mv_graph.py:744-805)."""
+    import warnings
+
+    ccs = g.connected_components()
+    if max(len(c) for c in ccs) < 2:
+        raise NotEnoughOverlapError("No overlap between views/tiles.")
+    lonely = [n for c in ccs if len(c) == 1 for n in c]
+    if lonely:
+        warnings.warn("The following views/tiles have no links with other views:\n%s" % lonely, UserWarning, stacklevel=1)
+    out = Graph()
+    for n in g.nodes:
+        out.add_node(n, **g.node_attrs[n])
+    for a, b, d in g.edges(data=True):
+        d["overlap_inv"] = 1 / (d["overlap"] + 1)
+    for cc in ccs:
+        totals = {n: sum(d["overlap"] for d in g.adj[n].values()) for n in g.nodes if n in cc}
+        ref = max(totals, key=totals.get)
+        for n, path in _dijkstra_paths(g, ref, "overlap_inv").items():
+            for a, b in zip(path[:-1], path[1:]):
+                out.add_edge(a, b, overlap=g.adj[a][b]["overlap"])
+    return out
+
+
+def prune_to_axis_aligned_edges(g, max_angle=0.05):
+    """Keep the edges whose centre-to-centre direction lies within ``max_angle`` rad of one of the first view's axes
+    (mv_graph.py:808-855).  Evaluated for all edges at once."""
+    out = Graph()
+    for n in g.nodes:
+        out.add_node(n, **g.node_attrs[n])
+    edges = g.edges(data=True)
+    if not edges:
+        return out
+    idx = {n: k for k, n in enumerate(g.nodes)}
+    verts = np.array([get_vertices_from_stack_props(g.node_attrs[n]["stack_props"]) for n in g.nodes])    # (N, 2^n, n)
+    ndim = verts.shape[2]
+    centers = verts.mean(axis=1)
+    grid = np.array(list(np.ndindex(*([2] * ndim))))
+    ax = verts[:, np.sum(grid, axis=1) == 1, :] - verts[:, :1, :]                                              # (N, n, n) axis vectors
+    ax = ax / np.linalg.norm(ax, axis=2, keepdims=True)
+    ia, ib = np.array([idx[a] for a, _, _ in edges]), np.array([idx[b] for _, b, _ in edges])
+    vec = centers[ib] - centers[ia]
+    vec = vec / np.linalg.norm(vec, axis=1, keepdims=True)
+    with np.errstate(invalid="ignore"):
+        angle = np.arccos(np.abs(np.einsum("ed,ekd->ek", vec, ax[ia])))
+    keep = np.any(angle < max_angle, axis=1)
+    for (a, b, d), k in zip(edges, keep):
+        if k:
+            out.add_edge(a, b, **d)
+    return out
+
+
+def threshold_otsu(values, nbins=256):
+    """skimage.filters.threshold_otsu on a 1-D sample (the call of mv_graph.py:858-881): 256-bin histogram over the value
+    range, threshold = centre of the bin that maximises the between-class variance."""
+    values = np.asarray(values, dtype=np.float64).ravel()
+    if values.min() == values.max():
+        return values[0]
+    counts, edges = np.histogram(values, bins=nbins, range=(values.min(), values.max()))
+    centers = (edges[:-1] + edges[1:]) / 2.0
+    counts = counts.astype(np.float64)
+    w1 = np.cumsum(counts)
+    w2 = np.cumsum(counts[::-1])[::-1]
+    m1 = np.cumsum(counts * centers) / w1
+    m2 = (np.cumsum((counts * centers)[::-1]) / w2[::-1])[::-1]
+    var12 = w1[:-1] * w2[1:] * (m1[:-1] - m2[1:]) ** 2
+    return centers[np.argmax(var12)]
+
+
+def filter_edges(g, weight_key="overlap", threshold=None):
+    """Drop the edges whose weight lies below the (Otsu) threshold (mv_graph.py:858-881)."""
+    edges = g.edges(data=True)
+    if not edges:
+        return g
+    if threshold is None:
+        threshold = threshold_otsu([d[weight_key] for _, _, d in edges])
+    out = g.copy()
+    for a, b, d in edges:
+        if np.min(d[weight_key]) < threshold:
+            out.remove_edge(a, b)
+    return out
+
+
+def prune_view_adjacency_graph(g, method=None, pruning_method_kwargs=None):
+    """Dispatcher of mv_graph.py:1148-1196."""
+    if not g.edges():
+        raise NotEnoughOverlapError("Not enough overlap between views for stitching.")
+    kw = dict(pruning_method_kwargs or {})
+    if method is None:
+        return g
+    if method == "alternating_pattern":
+        return prune_graph_to_alternating_colors(g, return_colors=False, **kw)
+    if method == "shortest_paths_overlap_weighted":
+        return prune_to_shortest_weighted_paths(g, **kw)
+    if method == "otsu_threshold_on_overlap":
+        return filter_edges(g, **kw)
+    if method == "keep_axis_aligned":
+        return prune_to_axis_aligned_edges(g, **kw)
+    raise ValueError(f"Unknown graph pruning method: {method}")

@@ -524,6 +524,7 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
              registration_binning=None, overlap_tolerance=0.0, pairwise_reg_func=phase_correlation_registration,
              pairwise_reg_func_kwargs=None, groupwise_resolution_method="global_optimization",
              groupwise_resolution_kwargs=None, pre_registration_pruning_method="alternating_pattern",
+             pre_reg_pruning_method_kwargs=None,
              post_registration_do_quality_filter=False, post_registration_quality_threshold=0.2, pairs=None,
              n_parallel_pairwise_regs=None, pairwise_executor=None, return_dict=False, device=0):
     """Register views to a common coordinate system (registration.register, registration.py:2227-2620).
@@ -531,8 +532,10 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
     Flow as in the reference: (1) overlap graph, (2) pairwise registrations of the selected edges,
     (3) groupwise resolution, (4) write ``new_transform_key`` (rebased on ``transform_key``).
     Accepts MultiscaleSpatialImages or SpatialImages (numpy- or DeviceArray-backed).  Host-side
-    stand-ins, documented in DESIGN.md: the overlap graph is built from world AABBs (axis-aligned
-    views) and every pruning method keeps the face-sharing neighbours.  The groupwise resolution is
+    logic as in the reference: the overlap graph holds the intersection volume of every pair of nearby views (closed
+    form for axis-aligned pairs, scipy's halfspace intersection otherwise) and is pruned by
+    ``pre_registration_pruning_method`` (None, "alternating_pattern" (default), "shortest_paths_overlap_weighted",
+    "otsu_threshold_on_overlap", "keep_axis_aligned").  The groupwise resolution is
     ``param_resolution.groupwise_resolution`` (``groupwise_resolution_method``: "global_optimization" (default),
     "shortest_paths", a callable, or "linear" for the plain least-squares solve of ``resolve_translations``;
     ``groupwise_resolution_kwargs`` e.g. ``{"transform": "rigid", "reference_view": 0}``)."""
@@ -554,13 +557,13 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
     # (1) graph
     sps = [si_utils.get_stack_properties_from_sim(s) for s in sims_reg]
     affs = [param_utils.select_time(si_utils.get_affine_from_sim(s, transform_key), 0) for s in sims_reg]
-    if pairs is None:
-        cand = mv_graph.build_view_adjacency_pairs(sps, affs)
-        if pre_registration_pruning_method is not None:
-            cand = mv_graph.prune_to_axis_aligned(cand, sps, affs)
-        edges = [(i, j) for i, j, _ in cand]
-    else:
-        edges = [tuple(p) for p in pairs]
+    # overlap graph of the views (mv_graph.py:35-180) and its pruning to the pairs that get registered (registration.py:2467-2491)
+    tol = overlap_tolerance
+    if tol is not None and not isinstance(tol, dict):
+        tol = {d: float(tol) for d in sps[0]["spacing"]}
+    g_views = mv_graph.build_view_adjacency_graph([dict(sp, transform=a) for sp, a in zip(sps, affs)], overlap_tolerance=tol, pairs=pairs)
+    g_views = mv_graph.prune_view_adjacency_graph(g_views, pre_registration_pruning_method, pre_reg_pruning_method_kwargs)
+    edges = [tuple(sorted(e)) for e in g_views.edges()]
 
     # (2) pairwise registrations per time point
     params_t, all_results, resolution_info = [], [], []

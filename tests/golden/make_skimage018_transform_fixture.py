@@ -31,6 +31,12 @@ for k, (ndim, npts) in enumerate([(2, 4), (2, 12), (3, 8), (3, 24), (2, 8), (3, 
             assert t.estimate(src, dst)
             assert np.array_equal(np.asarray(t.params), params)
         out[f"c{k}_{name}"] = np.asarray(params, dtype=np.float64)
+# Otsu threshold of 1-D samples (mv_graph.py:858-881 calls skimage.filters.threshold_otsu on the edge overlaps)
+from skimage.filters import threshold_otsu
+for k, vals in enumerate([np.r_[np.full(12, 5120.0), np.full(8, 100.0)], rng.gamma(2.0, 50.0, 40), np.r_[rng.normal(10, 1, 30), rng.normal(50, 5, 9)],
+                          np.array([3.0, 3.0, 3.0, 7.0]), np.array([1.0, 2.0])]):
+    out[f"otsu{k}_vals"], out[f"otsu{k}_thr"] = vals, np.array(threshold_otsu(vals))
+out["n_otsu"] = np.array(5)
 out["n_cases"] = np.array(6)
 np.savez_compressed(__file__.replace("make_skimage018_transform_fixture.py", "skimage018_transforms.npz"), **out)
 print("wrote", len(out), "arrays")
