@@ -192,6 +192,28 @@ __device__ __forceinline__ int reflect_index(int p, int len) {
     return p;
 }
 
+// WIN-tap box means of NOUT consecutive positions of a line, inputs v[0 .. NOUT + WIN - 2]: the running sum of scipy's
+// uniform_filter1d (ni_filters.c: tmp += line[l + size - 1] - line[l - 1]; out = tmp / size, double accumulator), restarted
+// per thread.  2 double operations and one float->double conversion per output instead of WIN of each, and no double
+// division (x * (1 / WIN) rounds to the same float32 as x / WIN except on exact ties of the final rounding): these
+// kernels were bound by exactly that arithmetic, not by memory.
+template <int WIN, int NOUT>
+__device__ __forceinline__ void box_means(const float (&v)[NOUT + WIN - 1], float (&out)[NOUT]) {
+    constexpr double inv = 1.0 / (double)WIN;
+    double d[NOUT + WIN - 1];
+#pragma unroll
+    for (int k = 0; k < NOUT + WIN - 1; ++k) d[k] = (double)v[k];
+    double run = 0.0;
+#pragma unroll
+    for (int j = 0; j < WIN; ++j) run += d[j];
+    out[0] = (float)(run * inv);
+#pragma unroll
+    for (int k = 1; k < NOUT; ++k) {
+        run += d[k + WIN - 1] - d[k - 1];
+        out[k] = (float)(run * inv);
+    }
+}
+
 struct Five { const float* src[5]; float* dst[5]; };
 
 // pass 1: filter along `axis` (0 = z, 1 = y) of the region [lo, lo + R) of im0 / im1t
@@ -227,19 +249,27 @@ __global__ __launch_bounds__(256) void ssim_first_pass_kernel(const float* __res
             vb[k] = (b != b) ? 0.f : b;
         }
         const int dst_base = (z * R.ny + y) * R.nx + x;
+        float f[5][kChunk];
+        box_means<WIN, kChunk>(va, f[0]);
+        box_means<WIN, kChunk>(vb, f[1]);
+        {
+            float prod[NL];   // products in float32 like the reference's `im * im` on float32 arrays
+#pragma unroll
+            for (int k = 0; k < NL; ++k) prod[k] = va[k] * va[k];
+            box_means<WIN, kChunk>(prod, f[2]);
+#pragma unroll
+            for (int k = 0; k < NL; ++k) prod[k] = vb[k] * vb[k];
+            box_means<WIN, kChunk>(prod, f[3]);
+#pragma unroll
+            for (int k = 0; k < NL; ++k) prod[k] = va[k] * vb[k];
+            box_means<WIN, kChunk>(prod, f[4]);
+        }
 #pragma unroll
         for (int k = 0; k < kChunk; ++k) {
             if (p0 + k >= len) break;
-            double sa = 0.0, sb = 0.0, saa = 0.0, sbb = 0.0, sab = 0.0;
-#pragma unroll
-            for (int j = 0; j < WIN; ++j) {
-                const float a = va[k + j], b = vb[k + j];
-                sa += (double)a; sb += (double)b; saa += (double)(a * a); sbb += (double)(b * b); sab += (double)(a * b);
-            }
             const int o = dst_base + (p0 + k) * dst_stride;
-            P.dst[0][o] = (float)(sa / (double)WIN); P.dst[1][o] = (float)(sb / (double)WIN);
-            P.dst[2][o] = (float)(saa / (double)WIN); P.dst[3][o] = (float)(sbb / (double)WIN);
-            P.dst[4][o] = (float)(sab / (double)WIN);
+#pragma unroll
+            for (int a = 0; a < 5; ++a) P.dst[a][o] = f[a][k];
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -277,13 +307,12 @@ __global__ __launch_bounds__(256) void ssim_mid_pass_kernel(Five P, Shape3 R) {
             float v[NL];
 #pragma unroll
             for (int k = 0; k < NL; ++k) v[k] = P.src[a][off[k]];
+            float f[kChunk];
+            box_means<WIN, kChunk>(v, f);
 #pragma unroll
             for (int k = 0; k < kChunk; ++k) {
                 if (p0 + k >= len) break;
-                double s = 0.0;
-#pragma unroll
-                for (int j = 0; j < WIN; ++j) s += (double)v[k + j];
-                P.dst[a][base + (p0 + k) * R.nx] = (float)(s / (double)WIN);
+                P.dst[a][base + (p0 + k) * R.nx] = f[k];
             }
         }
     }
@@ -315,13 +344,7 @@ __global__ __launch_bounds__(256) void ssim_last_pass_kernel(Five P, Shape3 R, i
             float v[NL];
 #pragma unroll
             for (int k = 0; k < NL; ++k) v[k] = P.src[a][off[k]];
-#pragma unroll
-            for (int k = 0; k < kChunk; ++k) {
-                double s = 0.0;
-#pragma unroll
-                for (int j = 0; j < WIN; ++j) s += (double)v[k + j];
-                f[a][k] = (float)(s / (double)WIN);
-            }
+            box_means<WIN, kChunk>(v, f[a]);
         }
 #pragma unroll
         for (int k = 0; k < kChunk; ++k) {
@@ -373,13 +396,10 @@ __global__ __launch_bounds__(256) void ssim_yx_fused_kernel(Five P, Shape3 R, fl
                     float v[NL];
 #pragma unroll
                     for (int k = 0; k < NL; ++k) v[k] = P.src[a][off[k]];
+                    float f[kChunk];
+                    box_means<WIN, kChunk>(v, f);
 #pragma unroll
-                    for (int k = 0; k < kChunk; ++k) {
-                        double sum = 0.0;
-#pragma unroll
-                        for (int j = 0; j < WIN; ++j) sum += (double)v[k + j];
-                        s[a][rc * kChunk + k][c] = (float)(sum / (double)WIN);
-                    }
+                    for (int k = 0; k < kChunk; ++k) s[a][rc * kChunk + k][c] = f[k];
                 }
             }
             __syncthreads();
@@ -394,13 +414,7 @@ __global__ __launch_bounds__(256) void ssim_yx_fused_kernel(Five P, Shape3 R, fl
                         float v[NL];
 #pragma unroll
                         for (int k = 0; k < NL; ++k) v[k] = s[a][row][ch * kChunk + k];
-#pragma unroll
-                        for (int k = 0; k < kChunk; ++k) {
-                            double sum = 0.0;
-#pragma unroll
-                            for (int j = 0; j < WIN; ++j) sum += (double)v[k + j];
-                            f[a][k] = (float)(sum / (double)WIN);
-                        }
+                        box_means<WIN, kChunk>(v, f[a]);
                     }
 #pragma unroll
                     for (int k = 0; k < kChunk; ++k) {
