@@ -99,29 +99,48 @@ __global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im
         const unsigned int t = i0 / (unsigned int)S.nx;
         int y = (int)(t % (unsigned int)S.ny), z = (int)(t / (unsigned int)S.ny);
         float r4[4];
+        // the z and y parts of the coordinate (validity, base tap, weight) only change when the 4-voxel group wraps to the
+        // next row: they are evaluated per row, the x part per voxel -- same double arithmetic as before, a third of it
+        int row_z = -1, row_y = -1;
+        bool zy_ok = false;
+        int iz = 0, iy = 0, iz1 = 0, iy1 = 0;
+        double wz = 0.0, wy = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float r = NAN;
             if (i0 + k < n) {
-                // identity matrix rows: ((z*1 + y*0) + x*0) + t  -- same rounding as scipy's loop
-                const double cz = (double)z + tz, cy = (double)y + ty, cx = (double)x + tx;
-                if (!(cz < 0.0 || cz > (double)(S.nz - 1) || cy < 0.0 || cy > (double)(S.ny - 1) || cx < 0.0 || cx > (double)(S.nx - 1))) {
-                    const double fz = floor(cz), fy = floor(cy), fx = floor(cx);
-                    const int iz = (int)fz, iy = (int)fy, ix = (int)fx;
-                    const double wz = cz - fz, wy = cy - fy, wx = cx - fx;
-                    const int iz1 = tap2(iz, S.nz), iy1 = tap2(iy, S.ny), ix1 = tap2(ix, S.nx);
+                if (z != row_z || y != row_y) {
+                    row_z = z; row_y = y;
+                    // identity matrix rows: ((z*1 + y*0) + x*0) + t  -- same rounding as scipy's loop
+                    const double cz = (double)z + tz, cy = (double)y + ty;
+                    zy_ok = !(cz < 0.0 || cz > (double)(S.nz - 1) || cy < 0.0 || cy > (double)(S.ny - 1));
+                    const double fz = floor(cz), fy = floor(cy);
+                    iz = (int)fz; iy = (int)fy;
+                    wz = cz - fz; wy = cy - fy;
+                    if (zy_ok) { iz1 = tap2(iz, S.nz); iy1 = tap2(iy, S.ny); }
+                }
+                const double cx = (double)x + tx;
+                if (zy_ok && !(cx < 0.0 || cx > (double)(S.nx - 1))) {
+                    const double fx = floor(cx);
+                    const int ix = (int)fx;
+                    const double wx = cx - fx;
+                    const int ix1 = tap2(ix, S.nx);
                     double acc = 0.0;
                     // scipy accumulates coeff * wz * wy * wx over the taps in z-major order.  A tap with weight 0 only matters
                     // when it can be NaN or inf (0 * NaN = NaN): for an all-finite moving image the taps of axes with an
                     // integer shift are skipped -- adding their +0.0 would not change the sum (1 / 2 / 4 taps instead of 8).
                     if (skip_zero_taps) {
                         const bool nz2 = wz != 0.0, ny2 = wy != 0.0, nx2 = wx != 0.0;
-                        for (int a = 0; a <= (nz2 ? 1 : 0); ++a)
-                            for (int b = 0; b <= (ny2 ? 1 : 0); ++b)
-                                for (int cidx = 0; cidx <= (nx2 ? 1 : 0); ++cidx)
-                                    acc += (double)im1[(a ? iz1 : iz) * sz + (b ? iy1 : iy) * sy + (cidx ? ix1 : ix)] * (a ? wz : 1.0 - wz) *
-                                           (b ? wy : 1.0 - wy) * (cidx ? wx : 1.0 - wx);
-                        r = (float)acc;
+                        if (!nz2 && !ny2 && !nx2) {
+                            r = im1[iz * sz + iy * sy + ix];      // one tap of weight 1 * 1 * 1: (float)((double)v * 1.0) == v
+                        } else {
+                            for (int a = 0; a <= (nz2 ? 1 : 0); ++a)
+                                for (int b = 0; b <= (ny2 ? 1 : 0); ++b)
+                                    for (int cidx = 0; cidx <= (nx2 ? 1 : 0); ++cidx)
+                                        acc += (double)im1[(a ? iz1 : iz) * sz + (b ? iy1 : iy) * sy + (cidx ? ix1 : ix)] * (a ? wz : 1.0 - wz) *
+                                               (b ? wy : 1.0 - wy) * (cidx ? wx : 1.0 - wx);
+                            r = (float)acc;
+                        }
                     } else {
                     acc += (double)im1[iz * sz + iy * sy + ix] * (1.0 - wz) * (1.0 - wy) * (1.0 - wx);
                     acc += (double)im1[iz * sz + iy * sy + ix1] * (1.0 - wz) * (1.0 - wy) * wx;
@@ -507,34 +526,118 @@ __global__ __launch_bounds__(256) void compact_kernel(const float* __restrict__ 
     }
 }
 
-// average rank (scipy.stats.rankdata method="average") of sorted position i: (first + last + 1) / 2 where
-// [first, last) is the run of equal keys around i.  Galloping search outwards from i: runs are short compared
-// with n and the probes stay in the cache lines around i.
-__device__ __forceinline__ double average_rank(const float* __restrict__ sorted, unsigned int i, unsigned int n) {
-    const float k = sorted[i];
-    unsigned int first = i, last = i + 1, lo, hi;
-    if (i > 0 && sorted[i - 1] == k) {
-        unsigned int pos = i, step = 1;
-        while (pos >= step && sorted[pos - step] == k) { pos -= step; step <<= 1; }
-        lo = pos >= step ? pos - step + 1 : 0; hi = pos;          // first index with key == k in [lo, hi]
-        while (lo < hi) { const unsigned int m = (lo + hi) >> 1; if (sorted[m] < k) lo = m + 1; else hi = m; }
-        first = lo;
+// average rank (scipy.stats.rankdata method="average") of sorted position i: (first + last + 1) / 2 where [first, last) is the
+// run of equal keys around i.
+// Average ranks of one chunk of kRankChunk consecutive sorted keys, 8 per thread (thread t owns positions
+// base + 8 t .. + 7): run starts / ends are flagged against the neighbouring key, the start (end) of the run a position
+// belongs to is a forward max-scan (backward min-scan) of the flagged positions -- in registers within a thread, by
+// shuffles within a wavefront, through LDS across the four wavefronts.  Only the run that enters the chunk from the left
+// and the one that leaves it on the right need a search outside the chunk (galloping, one thread each).  Replaces a
+// galloping search per element (~20 dependent loads each on the long runs of quantised image data).
+constexpr int kRankItems = 8, kRankChunk = 256 * kRankItems;
+
+__device__ __forceinline__ void chunk_average_ranks(const float* __restrict__ sorted, unsigned int n, unsigned int chunk0,
+                                                    float (&rank)[kRankItems], bool (&valid)[kRankItems]) {
+    __shared__ unsigned int s_first[4], s_last[4], s_edge[2];
+    const unsigned int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned int base = chunk0 + tid * kRankItems;
+    const unsigned int chunk_end = min(chunk0 + (unsigned int)kRankChunk, n);   // exclusive
+    float k[kRankItems + 2];                                                      // k[0] = left neighbour, k[9] = right neighbour
+#pragma unroll
+    for (int j = 0; j < kRankItems + 2; ++j) {
+        const long long idx = (long long)base + j - 1;
+        k[j] = (idx >= 0 && idx < (long long)n) ? sorted[idx] : 0.f;
     }
-    if (i + 1 < n && sorted[i + 1] == k) {
-        unsigned int pos = i, step = 1;
-        while (pos + step < n && sorted[pos + step] == k) { pos += step; step <<= 1; }
-        lo = pos + 1; hi = min(pos + step, n);                    // first index with key > k in [lo, hi]
-        while (lo < hi) { const unsigned int m = (lo + hi) >> 1; if (sorted[m] <= k) lo = m + 1; else hi = m; }
-        last = lo;
+    if (tid == 0) {   // run entering the chunk from the left: its first index (galloping backwards), else the chunk start
+        unsigned int first = chunk0;
+        if (chunk0 > 0 && chunk0 < n && sorted[chunk0 - 1] == sorted[chunk0]) {
+            const float key = sorted[chunk0];
+            unsigned int pos = chunk0, step = 1;
+            while (pos >= step && sorted[pos - step] == key) { pos -= step; step <<= 1; }
+            unsigned int lo = pos >= step ? pos - step + 1 : 0, hi = pos;
+            while (lo < hi) { const unsigned int m = (lo + hi) >> 1; if (sorted[m] < key) lo = m + 1; else hi = m; }
+            first = lo;
+        }
+        s_edge[0] = first;
     }
-    return 0.5 * ((double)first + (double)last + 1.0);
+    if (tid == 64) {  // run leaving the chunk on the right: its exclusive end (galloping forwards)
+        unsigned int last = chunk_end;
+        if (chunk_end < n && chunk_end > 0 && sorted[chunk_end] == sorted[chunk_end - 1]) {
+            const float key = sorted[chunk_end - 1];
+            unsigned int pos = chunk_end - 1, step = 1;
+            while (pos + step < n && sorted[pos + step] == key) { pos += step; step <<= 1; }
+            unsigned int lo = pos + 1, hi = min(pos + step, n);
+            while (lo < hi) { const unsigned int m = (lo + hi) >> 1; if (sorted[m] <= key) lo = m + 1; else hi = m; }
+            last = lo;
+        }
+        s_edge[1] = last;
+    }
+    // ---- forward: index of the last run start at or before each position (0 = none seen yet; stored as index + 1) ----
+    unsigned int first[kRankItems], cur = 0;
+#pragma unroll
+    for (int j = 0; j < kRankItems; ++j) {
+        const unsigned int idx = base + j;
+        valid[j] = idx < n;
+        if (valid[j] && (idx == 0 || k[j] != k[j + 1])) cur = idx + 1;
+        first[j] = cur;
+    }
+    unsigned int incl = cur;   // inclusive max-scan of the per-thread carries over the wavefront
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_up(incl, off);
+        if (lane >= (unsigned int)off) incl = max(incl, o);
+    }
+    unsigned int carry_f = __shfl_up(incl, 1);
+    if (lane == 0) carry_f = 0;
+    if (lane == 63) s_first[wave] = incl;
+    // ---- backward: exclusive end of the run each position belongs to (0xffffffff = not seen yet) ----
+    unsigned int last[kRankItems], curl = 0xffffffffu;
+#pragma unroll
+    for (int j = kRankItems - 1; j >= 0; --j) {
+        const unsigned int idx = base + j;
+        if (idx < n && (idx == n - 1 || k[j + 1] != k[j + 2])) curl = idx + 1;
+        last[j] = curl;
+    }
+    unsigned int incl_l = curl;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned int o = __shfl_down(incl_l, off);
+        if (lane + (unsigned int)off < 64) incl_l = min(incl_l, o);
+    }
+    unsigned int carry_l = __shfl_down(incl_l, 1);
+    if (lane == 63) carry_l = 0xffffffffu;
+    if (lane == 0) s_last[wave] = incl_l;
+    __syncthreads();
+    for (unsigned int w = 0; w < wave; ++w) carry_f = max(carry_f, s_first[w]);
+    for (unsigned int w = wave + 1; w < 4; ++w) carry_l = min(carry_l, s_last[w]);
+    const unsigned int edge_first = s_edge[0], edge_last = s_edge[1];
+#pragma unroll
+    for (int j = 0; j < kRankItems; ++j) {
+        unsigned int f = max(first[j], carry_f), l = min(last[j], carry_l);
+        f = f ? f - 1 : edge_first;
+        if (l == 0xffffffffu) l = edge_last;
+        rank[j] = (float)(0.5 * ((double)f + (double)l + 1.0));
+    }
+    __syncthreads();   // the LDS cells are reused by the next chunk
 }
 
 // ranks of the x keys in x-sorted order (they then ride along the second sort as its payload, so nothing is
 // ever scattered back to voxel order).  Stored as float like scipy's float64 ranks rounded: exact for n < 2^24.
 __global__ __launch_bounds__(256) void ranks_sorted_kernel(const float* __restrict__ sorted, unsigned int n, float* __restrict__ rank_out) {
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-        rank_out[i] = (float)average_rank(sorted, i, n);
+    const unsigned int nchunks = (n + kRankChunk - 1) / kRankChunk;
+    for (unsigned int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        float rank[kRankItems];
+        bool valid[kRankItems];
+        chunk_average_ranks(sorted, n, c * kRankChunk, rank, valid);
+        const unsigned int base = c * kRankChunk + threadIdx.x * kRankItems;
+        if (base + kRankItems <= n) {
+            *reinterpret_cast<float4*>(rank_out + base) = make_float4(rank[0], rank[1], rank[2], rank[3]);
+            *reinterpret_cast<float4*>(rank_out + base + 4) = make_float4(rank[4], rank[5], rank[6], rank[7]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < kRankItems; ++j) if (valid[j]) rank_out[base + j] = rank[j];
+        }
+    }
 }
 
 // in y-sorted order: rank of y computed on the fly, rank of x from the payload; sums for the Pearson
@@ -542,9 +645,18 @@ __global__ __launch_bounds__(256) void ranks_sorted_kernel(const float* __restri
 __global__ __launch_bounds__(256) void rankcorr_kernel(const float* __restrict__ ysorted, const float* __restrict__ rx, unsigned int n,
                                                        double mean, double* __restrict__ partial) {
     double sxy = 0.0, sxx = 0.0, syy = 0.0;
-    for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const double a = (double)rx[i] - mean, b = (double)(float)average_rank(ysorted, i, n) - mean;
-        sxy += a * b; sxx += a * a; syy += b * b;
+    const unsigned int nchunks = (n + kRankChunk - 1) / kRankChunk;
+    for (unsigned int c = blockIdx.x; c < nchunks; c += gridDim.x) {
+        float rank[kRankItems];
+        bool valid[kRankItems];
+        chunk_average_ranks(ysorted, n, c * kRankChunk, rank, valid);
+        const unsigned int base = c * kRankChunk + threadIdx.x * kRankItems;
+#pragma unroll
+        for (int j = 0; j < kRankItems; ++j)
+            if (valid[j]) {
+                const double a = (double)rx[base + j] - mean, b = (double)rank[j] - mean;
+                sxy += a * b; sxx += a * a; syy += b * b;
+            }
     }
     for (int off = 32; off > 0; off >>= 1) {
         sxy += __shfl_down(sxy, off); sxx += __shfl_down(sxx, off); syy += __shfl_down(syy, off);
@@ -691,9 +803,9 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, c->stream, im0, im1t, n, setA[0], setA[1], d_counter);
         const unsigned int m = (unsigned int)cnts[ic];
         MVS_HIP_TRY(c, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, setA[0], setA[2], setA[1], setA[3], (size_t)m, 0, 32, c->stream));
-        hipLaunchKernelGGL(ranks_sorted_kernel, dim3(grid_for(m)), dim3(256), 0, c->stream, setA[2], m, setA[4]);
+        const int mgb = (int)std::min<long long>(((long long)m + kRankChunk - 1) / kRankChunk, 2048);   // one chunk of sorted keys per workgroup turn
+        hipLaunchKernelGGL(ranks_sorted_kernel, dim3(mgb), dim3(256), 0, c->stream, setA[2], m, setA[4]);
         MVS_HIP_TRY(c, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, setA[3], setB[0], setA[4], setB[1], (size_t)m, 0, 32, c->stream));
-        const int mgb = grid_for(m);
         hipLaunchKernelGGL(rankcorr_kernel, dim3(mgb), dim3(256), 0, c->stream, setB[0], setB[1], m, 0.5 * ((double)m + 1.0), partial);
         std::vector<double> hp((size_t)mgb * 3);
         MVS_HIP_TRY(c, hipMemcpyAsync(hp.data(), partial, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, c->stream));
