@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument("--tile", type=str, default="512,512,512", help="tile shape z,y,x")
     ap.add_argument("--overlap-frac", type=float, default=0.2)
     ap.add_argument("--cpu-tile", type=int, default=192, help="edge of the small tiles of the cpu_baseline sample")
-    ap.add_argument("--reg-threads", type=int, default=None, help="host threads / context lanes for the pairwise registrations (library default: 6)")
+    ap.add_argument("--reg-threads", type=int, default=None, help="host threads / context lanes for the pairwise registrations (library default: 8)")
     ap.add_argument("--no-register", action="store_true", help="time fusion only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()

@@ -20,8 +20,8 @@
  *   - Threading: one context per device; calls on the same device serialise on
  *     an internal mutex and run on that context's HIP stream; calls on
  *     different devices are fully concurrent.
- *   - Context lanes: a device argument may carry a lane number in bits 8..10
- *     (`device | lane << 8`, lane < 8): every lane is an independent context on the
+ *   - Context lanes: a device argument may carry a lane number in bits 8..11
+ *     (`device | lane << 8`, lane < 16): every lane is an independent context on the
  *     same GPU (own stream, scratch buffers, allocation pool and lock), so host
  *     threads that work on independent units (image pairs) overlap on the device
  *     instead of serialising on one lock.  Memory allocated through one lane can be

@@ -17,7 +17,7 @@
 #define MVS_MAX_DEVICES 16
 // A context id is `device | lane << 8`: up to MVS_MAX_LANES independent contexts (stream, scratch, pool, lock) on one
 // GPU, so that host threads working on independent units (pairs) overlap on the device instead of queueing on one lock.
-#define MVS_MAX_LANES 8
+#define MVS_MAX_LANES 16
 static inline int mvs_hip_device(int id) { return id & 0xff; }
 static inline int mvs_ctx_index(int id) { return ((id >> 8) & 0xff) * MVS_MAX_DEVICES + (id & 0xff); }
 

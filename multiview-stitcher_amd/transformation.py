@@ -33,17 +33,19 @@ def get_pixel_affine(p, input_origin, input_spacing, output_origin, output_spaci
     p = np.asarray(p, dtype=np.float64)
     ndim = p.shape[0] - 1
     M, t = p[:ndim, :ndim], p[:ndim, ndim]
-    Sx = np.diag(np.asarray(output_spacing, dtype=np.float64))
-    Sy = np.diag(np.asarray(input_spacing, dtype=np.float64))
+    sx = np.asarray(output_spacing, dtype=np.float64)
+    sy = np.asarray(input_spacing, dtype=np.float64)
     Ox = np.asarray(output_origin, dtype=np.float64)
     Oy = np.asarray(input_origin, dtype=np.float64)
-    matrix_prime = np.linalg.solve(Sy, np.dot(M, Sx))
+    # np.linalg.solve(diag(sy), X) is a row-wise division (LU of a diagonal matrix: one exact division per element), and
+    # M @ diag(sx) a column-wise product (the other terms of each dot product are exact zeros): same bits, no LAPACK call
+    matrix_prime = (M * sx[None, :]) / sy[:, None]
     local_offset = t + np.dot(M - np.eye(ndim), Ox)
-    offset_prime = np.linalg.solve(Sy, local_offset - (Oy - Ox))
+    offset_prime = (local_offset - (Oy - Ox)) / sy
     matrix_prime = np.around(matrix_prime, decimals=10)
     offset_prime = np.around(offset_prime, decimals=10)
     nearest = np.round(offset_prime)
-    snap = np.isclose(offset_prime, nearest, rtol=0, atol=1e-6)
+    snap = np.abs(offset_prime - nearest) <= 1e-6      # np.isclose(offset', nearest, rtol=0, atol=1e-6)
     offset_prime[snap] = nearest[snap]
     return matrix_prime, offset_prime
 

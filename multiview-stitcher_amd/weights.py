@@ -31,6 +31,9 @@ def _shrink_source_bb(origin, spacing, shape, shrink_distance, sdims):
     return origin + sd, spacing, shape - 2 * sd / spacing
 
 
+_TABLE_CACHE = {}
+
+
 def blending_support(source_bb, blending_widths=None, shrink_distance=0):
     """The EDT support image of get_blending_weights (weights.py:430-470).
 
@@ -56,15 +59,21 @@ def blending_support(source_bb, blending_widths=None, shrink_distance=0):
     edt_support_spacing = support_spacing * (shape - 1 + 2 * 1) / (shape - 1)
     edt_support_origin = origin - 1 * spacing
     sampling = edt_support_spacing / bw
-    tent = np.minimum(np.arange(5), 4 - np.arange(5)).astype(np.float64)
-    per_axis = [tent * sampling[d] for d in range(ndim)]
-    grids = np.meshgrid(*per_axis, indexing="ij")
-    table = np.minimum.reduce(grids)
+    key = tuple(sampling.tolist())
+    table = _TABLE_CACHE.get(key)
+    if table is None:      # all tiles of a mosaic share one table
+        tent = np.minimum(np.arange(5), 4 - np.arange(5)).astype(np.float64)
+        per_axis = [tent * sampling[d] for d in range(ndim)]
+        grids = np.meshgrid(*per_axis, indexing="ij")
+        table = np.minimum.reduce(grids).astype(np.float32)
+        if len(_TABLE_CACHE) > 64:
+            _TABLE_CACHE.clear()
+        _TABLE_CACHE[key] = table
     # origin/spacing as the reference reads them back from the coordinate arrays
     # (spatial_image_utils.py:316-317, 554-589): coords = o + s*arange(5)
     c0 = edt_support_origin + edt_support_spacing * 0.0
     c1 = edt_support_origin + edt_support_spacing * 1.0
-    return table.astype(np.float32), c0, c1 - c0
+    return table, c0, c1 - c0
 
 
 def fill_view_weights(view, source_bb, affine, target_origin, target_spacing, blending_widths=None, shrink_distance=0):
