@@ -97,7 +97,9 @@ int mvs_synchronize(int device);
 /* Tuning / test switches. "force_generic" = 1: mvs_fuse_chunk never takes the translation fast
  * path (both paths must agree; tests compare them).  "no_regions" = 1: skip the region kernels.
  * "pool_cache_limit_mb": bytes (MiB) mvs_free may keep cached for later mvs_malloc calls
- * (default 32768; 0 = release immediately). */
+ * (default 32768; 0 = release immediately).  "materialize_shifts" = 1: mvs_score_candidates / mvs_register_crops
+ * always write the shifted copies of the moving image (by default finite-only crops evaluate them inside the SSIM z
+ * pass; both ways must agree bit for bit; tests compare them). */
 int mvs_set_option(int device, const char* key, int64_t value);
 /* Device time (ms, hipEvent) spent in the kernels of the most recent compute
  * call on this device; blocks until that work has finished. */

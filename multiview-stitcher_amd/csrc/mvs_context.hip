@@ -209,6 +209,10 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         c->no_regions = value != 0;
         return MVS_OK;
     }
+    if (!strcmp(key, "materialize_shifts")) {
+        c->materialize_shifts = value != 0;
+        return MVS_OK;
+    }
     if (!strcmp(key, "ablate")) {
         c->ablate = (int)value;
         return MVS_OK;

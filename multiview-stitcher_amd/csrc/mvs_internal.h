@@ -35,6 +35,7 @@ struct MvsContext {
     bool timing_valid = false;
     int ablate = 0;               // profiling only (see FuseParams)
     bool force_generic = false;   // debug/test switch: never take the translation fast path
+    bool materialize_shifts = false;   // test switch: candidate scoring always writes the shifted copies (no on-the-fly SSIM z pass)
     std::recursive_mutex mu;      // recursive: composite entry points (mvs_pair.hip) call the public ones under the lock
     std::string last_error;
     // grow-only device scratch buffers (slot-indexed) and one pinned host staging buffer

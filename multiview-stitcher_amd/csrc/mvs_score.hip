@@ -83,8 +83,54 @@ __device__ __forceinline__ int tap2(int i0, int n) {
     return i1;
 }
 
+// One axis of scipy's order-1 coordinate: c = pos + t (the identity-matrix row, same rounding as scipy's loop), valid iff
+// 0 <= c <= n - 1, taps floor(c) and its neighbour (mirrored at the edge, weight 0 there), weight w = c - floor(c).
+struct AxisTap { int ok, i0, i1; double w; };
+__device__ __forceinline__ AxisTap axis_tap(int pos, double t, int n) {
+    AxisTap a;
+    const double c = (double)pos + t;
+    a.ok = !(c < 0.0 || c > (double)(n - 1));
+    const double f = floor(c);
+    a.i0 = (int)f;
+    a.w = c - f;
+    a.i1 = a.ok ? tap2(a.i0, n) : 0;
+    return a;
+}
+
+// Value of the shifted moving image at a voxel whose three axis parts are given (NaN outside).  scipy accumulates
+// coeff * wz * wy * wx over the taps in z-major order.  A tap with weight 0 only matters when it can be NaN or inf
+// (0 * NaN = NaN): for an all-finite moving image (skip_zero_taps) the taps of axes with an integer shift are skipped --
+// adding their +0.0 would not change the sum (1 / 2 / 4 taps instead of 8).
+__device__ __forceinline__ float shifted_value(const float* __restrict__ im1, int sy, int sz, const AxisTap& Z, const AxisTap& Y,
+                                               const AxisTap& X, int skip_zero_taps) {
+    if (!(Z.ok && Y.ok && X.ok)) return NAN;
+    const double wz = Z.w, wy = Y.w, wx = X.w;
+    const int iz = Z.i0, iy = Y.i0, ix = X.i0, iz1 = Z.i1, iy1 = Y.i1, ix1 = X.i1;
+    double acc = 0.0;
+    if (skip_zero_taps) {
+        const bool nz2 = wz != 0.0, ny2 = wy != 0.0, nx2 = wx != 0.0;
+        if (!nz2 && !ny2 && !nx2) return im1[iz * sz + iy * sy + ix];      // one tap of weight 1 * 1 * 1: (float)((double)v * 1.0) == v
+        for (int a = 0; a <= (nz2 ? 1 : 0); ++a)
+            for (int b = 0; b <= (ny2 ? 1 : 0); ++b)
+                for (int cidx = 0; cidx <= (nx2 ? 1 : 0); ++cidx)
+                    acc += (double)im1[(a ? iz1 : iz) * sz + (b ? iy1 : iy) * sy + (cidx ? ix1 : ix)] * (a ? wz : 1.0 - wz) *
+                           (b ? wy : 1.0 - wy) * (cidx ? wx : 1.0 - wx);
+        return (float)acc;
+    }
+    acc += (double)im1[iz * sz + iy * sy + ix] * (1.0 - wz) * (1.0 - wy) * (1.0 - wx);
+    acc += (double)im1[iz * sz + iy * sy + ix1] * (1.0 - wz) * (1.0 - wy) * wx;
+    acc += (double)im1[iz * sz + iy1 * sy + ix] * (1.0 - wz) * wy * (1.0 - wx);
+    acc += (double)im1[iz * sz + iy1 * sy + ix1] * (1.0 - wz) * wy * wx;
+    acc += (double)im1[iz1 * sz + iy * sy + ix] * wz * (1.0 - wy) * (1.0 - wx);
+    acc += (double)im1[iz1 * sz + iy * sy + ix1] * wz * (1.0 - wy) * wx;
+    acc += (double)im1[iz1 * sz + iy1 * sy + ix] * wz * wy * (1.0 - wx);
+    acc += (double)im1[iz1 * sz + iy1 * sy + ix1] * wz * wy * wx;
+    return (float)acc;
+}
+
 // Stats gathered while shifting: #(valid im1t & valid im0) and the bbox of valid im1t.  Each thread takes 4
-// consecutive voxels (one index decode, one 16-byte store).
+// consecutive voxels (one index decode, one 16-byte store); the z and y parts of the coordinate only change when the
+// group wraps to the next row, so they are evaluated per row, the x part per voxel.
 __global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im1, const float* __restrict__ im0,
                                                     float* __restrict__ out, Shape3 S, double tz, double ty, double tx,
                                                     int skip_zero_taps, VoxStats* __restrict__ partial) {
@@ -99,60 +145,18 @@ __global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im
         const unsigned int t = i0 / (unsigned int)S.nx;
         int y = (int)(t % (unsigned int)S.ny), z = (int)(t / (unsigned int)S.ny);
         float r4[4];
-        // the z and y parts of the coordinate (validity, base tap, weight) only change when the 4-voxel group wraps to the
-        // next row: they are evaluated per row, the x part per voxel -- same double arithmetic as before, a third of it
         int row_z = -1, row_y = -1;
-        bool zy_ok = false;
-        int iz = 0, iy = 0, iz1 = 0, iy1 = 0;
-        double wz = 0.0, wy = 0.0;
+        AxisTap Z = {0, 0, 0, 0.0}, Y = {0, 0, 0, 0.0};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float r = NAN;
             if (i0 + k < n) {
                 if (z != row_z || y != row_y) {
                     row_z = z; row_y = y;
-                    // identity matrix rows: ((z*1 + y*0) + x*0) + t  -- same rounding as scipy's loop
-                    const double cz = (double)z + tz, cy = (double)y + ty;
-                    zy_ok = !(cz < 0.0 || cz > (double)(S.nz - 1) || cy < 0.0 || cy > (double)(S.ny - 1));
-                    const double fz = floor(cz), fy = floor(cy);
-                    iz = (int)fz; iy = (int)fy;
-                    wz = cz - fz; wy = cy - fy;
-                    if (zy_ok) { iz1 = tap2(iz, S.nz); iy1 = tap2(iy, S.ny); }
+                    Z = axis_tap(z, tz, S.nz);
+                    Y = axis_tap(y, ty, S.ny);
                 }
-                const double cx = (double)x + tx;
-                if (zy_ok && !(cx < 0.0 || cx > (double)(S.nx - 1))) {
-                    const double fx = floor(cx);
-                    const int ix = (int)fx;
-                    const double wx = cx - fx;
-                    const int ix1 = tap2(ix, S.nx);
-                    double acc = 0.0;
-                    // scipy accumulates coeff * wz * wy * wx over the taps in z-major order.  A tap with weight 0 only matters
-                    // when it can be NaN or inf (0 * NaN = NaN): for an all-finite moving image the taps of axes with an
-                    // integer shift are skipped -- adding their +0.0 would not change the sum (1 / 2 / 4 taps instead of 8).
-                    if (skip_zero_taps) {
-                        const bool nz2 = wz != 0.0, ny2 = wy != 0.0, nx2 = wx != 0.0;
-                        if (!nz2 && !ny2 && !nx2) {
-                            r = im1[iz * sz + iy * sy + ix];      // one tap of weight 1 * 1 * 1: (float)((double)v * 1.0) == v
-                        } else {
-                            for (int a = 0; a <= (nz2 ? 1 : 0); ++a)
-                                for (int b = 0; b <= (ny2 ? 1 : 0); ++b)
-                                    for (int cidx = 0; cidx <= (nx2 ? 1 : 0); ++cidx)
-                                        acc += (double)im1[(a ? iz1 : iz) * sz + (b ? iy1 : iy) * sy + (cidx ? ix1 : ix)] * (a ? wz : 1.0 - wz) *
-                                               (b ? wy : 1.0 - wy) * (cidx ? wx : 1.0 - wx);
-                            r = (float)acc;
-                        }
-                    } else {
-                    acc += (double)im1[iz * sz + iy * sy + ix] * (1.0 - wz) * (1.0 - wy) * (1.0 - wx);
-                    acc += (double)im1[iz * sz + iy * sy + ix1] * (1.0 - wz) * (1.0 - wy) * wx;
-                    acc += (double)im1[iz * sz + iy1 * sy + ix] * (1.0 - wz) * wy * (1.0 - wx);
-                    acc += (double)im1[iz * sz + iy1 * sy + ix1] * (1.0 - wz) * wy * wx;
-                    acc += (double)im1[iz1 * sz + iy * sy + ix] * wz * (1.0 - wy) * (1.0 - wx);
-                    acc += (double)im1[iz1 * sz + iy * sy + ix1] * wz * (1.0 - wy) * wx;
-                    acc += (double)im1[iz1 * sz + iy1 * sy + ix] * wz * wy * (1.0 - wx);
-                    acc += (double)im1[iz1 * sz + iy1 * sy + ix1] * wz * wy * wx;
-                    r = (float)acc;
-                    }
-                }
+                r = shifted_value(im1, sy, sz, Z, Y, axis_tap(x, tx, S.nx), skip_zero_taps);
                 if (r == r) {
                     mnz = min(mnz, z); mny = min(mny, y); mnx = min(mnx, x);
                     mxz = max(mxz, z); mxy = max(mxy, y); mxx = max(mxx, x);
@@ -236,10 +240,13 @@ __device__ __forceinline__ void box_means(const float (&v)[NOUT + WIN - 1], floa
 struct Five { const float* src[5]; float* dst[5]; };
 
 // pass 1: filter along `axis` (0 = z, 1 = y) of the region [lo, lo + R) of im0 / im1t
-template <int WIN>
+// SHIFTED: `im1t` is the unshifted moving image and its shifted value is evaluated on the fly (same arithmetic as
+// shift_kernel), so the candidates of an all-finite pair never materialise their shifted copy.
+struct ShiftArg { double tz, ty, tx; int skip_zero_taps; };
+template <int WIN, bool SHIFTED>
 __global__ __launch_bounds__(256) void ssim_first_pass_kernel(const float* __restrict__ im0, const float* __restrict__ im1t, Shape3 S,
                                                               int lz, int ly, int lx, Shape3 R, int axis, Five P,
-                                                              float* __restrict__ pmax, int* __restrict__ phasnan) {
+                                                              float* __restrict__ pmax, int* __restrict__ phasnan, ShiftArg T) {
     constexpr int H = WIN / 2, NL = kChunk + 2 * H;
     const int len = axis == 0 ? R.nz : R.ny;
     const int nchunks = (len + kChunk - 1) / kChunk;
@@ -257,10 +264,22 @@ __global__ __launch_bounds__(256) void ssim_first_pass_kernel(const float* __res
         else { p0 = (int)(t % (unsigned int)nchunks) * kChunk; z = (int)(t / (unsigned int)nchunks); y = 0; }
         const int src_base = ((z + lz) * S.ny + (y + ly)) * S.nx + (x + lx);
         float va[NL], vb[NL];
+        // SHIFTED: the axis parts that do not move along the filtered axis are fixed for this thread
+        AxisTap TX = {0, 0, 0, 0.0}, TO = {0, 0, 0, 0.0};
+        if (SHIFTED) {
+            TX = axis_tap(x + lx, T.tx, S.nx);
+            TO = axis == 0 ? axis_tap(y + ly, T.ty, S.ny) : axis_tap(z + lz, T.tz, S.nz);
+        }
 #pragma unroll
         for (int k = 0; k < NL; ++k) {
             const int p = reflect_index(p0 - H + k, len);
-            float a = im0[src_base + p * src_stride], b = im1t[src_base + p * src_stride];
+            float a = im0[src_base + p * src_stride], b;
+            if (SHIFTED) {
+                if (axis == 0) b = shifted_value(im1t, S.nx, S.ny * S.nx, axis_tap(lz + p, T.tz, S.nz), TO, TX, T.skip_zero_taps);
+                else b = shifted_value(im1t, S.nx, S.ny * S.nx, TO, axis_tap(ly + p, T.ty, S.ny), TX, T.skip_zero_taps);
+            } else {
+                b = im1t[src_base + p * src_stride];
+            }
             if (k >= H && k < H + kChunk && p0 + (k - H) < len) {   // this voxel is the centre of one output
                 if (b == b) mx = fmaxf(mx, b); else hn = 1;
             }
@@ -682,11 +701,15 @@ struct DeviceBump {   // bump allocator over one scratch slot
 template <int WIN>
 void launch_ssim_passes(hipStream_t stream, const float* im0, const float* im1t, Shape3 S, const int lo[3], Shape3 R, int ndim,
                         float* const setA[5], float* const setB[5], float cov_norm, float C1, float C2, float* pmax, int* phasnan,
-                        double* psum) {
+                        double* psum, const ShiftArg* on_the_fly = nullptr) {
     Five P1, P2, P3;
     for (int a = 0; a < 5; ++a) { P1.src[a] = nullptr; P1.dst[a] = setA[a]; }
-    hipLaunchKernelGGL(ssim_first_pass_kernel<WIN>, dim3(kStatBlocks), dim3(256), 0, stream, im0, im1t, S, lo[0], lo[1], lo[2], R,
-                       ndim == 3 ? 0 : 1, P1, pmax, phasnan);
+    if (on_the_fly)      // im1t is the UNSHIFTED moving image
+        hipLaunchKernelGGL((ssim_first_pass_kernel<WIN, true>), dim3(kStatBlocks), dim3(256), 0, stream, im0, im1t, S, lo[0], lo[1], lo[2], R,
+                           ndim == 3 ? 0 : 1, P1, pmax, phasnan, *on_the_fly);
+    else
+        hipLaunchKernelGGL((ssim_first_pass_kernel<WIN, false>), dim3(kStatBlocks), dim3(256), 0, stream, im0, im1t, S, lo[0], lo[1], lo[2], R,
+                           ndim == 3 ? 0 : 1, P1, pmax, phasnan, ShiftArg{0.0, 0.0, 0.0, 0});
     float* const* last_src = setA;
     if (ndim == 3) {
         for (int a = 0; a < 5; ++a) { P2.src[a] = setA[a]; P2.dst[a] = nullptr; }
@@ -765,6 +788,12 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     const unsigned int valid1 = (unsigned int)(h_im[1].cnt & 0xffffffffull);
     // every voxel of the moving image finite?  (lower half: #non-NaN, upper half: #inf, see image_stats_kernel)
     const int im1_all_finite = ((long long)valid1 == n && (h_im[1].cnt >> 32) == 0) ? 1 : 0;
+    const int im0_all_finite = ((long long)(h_im[0].cnt & 0xffffffffull) == n && (h_im[0].cnt >> 32) == 0) ? 1 : 0;
+    // Both crops finite (tiles on a common grid): the valid box of a shifted copy and with it the mask count are known
+    // without touching the volume -- x is valid iff 0 <= fl(x + t) <= n - 1 per axis -- so the reduction of phase A and its
+    // host round trip are skipped, and candidates with integer shifts are never materialised: the SSIM z pass reads the
+    // moving image at the shifted position (the winner's copy is written afterwards, for the rank correlation).
+    const bool on_the_fly = !quality_for_all && im0_all_finite && im1_all_finite && !c->materialize_shifts;
 
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     // analytic pre-test: upper bound of the mask count from the valid bounding boxes -- im1t can only be valid
@@ -820,18 +849,47 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         const int nb = (int)std::min<size_t>((size_t)nres, todo.size() - b0);
         std::fill(resident.begin(), resident.end(), -1);
         // ---- phase A: shifted copies + mask counts / bboxes of the whole batch ----
+        VoxStats h_vs[kMaxResident];
+        ShiftArg shifts[kMaxResident];
+        bool otf[kMaxResident] = {};
         for (int j = 0; j < nb; ++j) {
             const int ic = todo[b0 + j];
             double t[3] = {0.0, 0.0, 0.0};
             for (int k = 0; k < ndim; ++k) t[k0 + k] = t_candidates[ic * ndim + k];
+            shifts[j] = ShiftArg{t[0], t[1], t[2], im1_all_finite};
+            if (on_the_fly) {
+                // the predicate of axis_tap, evaluated on the host in the same double arithmetic: first and last valid index
+                const int dims[3] = {S.nz, S.ny, S.nx};
+                unsigned long long cnt = 1;
+                for (int k = 0; k < 3; ++k) {
+                    auto ok = [&](long long x) { const double cc = (double)x + t[k]; return !(cc < 0.0 || cc > (double)(dims[k] - 1)); };
+                    long long lo = (long long)std::ceil(-t[k]), hi = (long long)std::floor((double)(dims[k] - 1) - t[k]);
+                    lo = std::min<long long>(std::max<long long>(lo, 0), dims[k]);
+                    hi = std::max<long long>(std::min<long long>(hi, dims[k] - 1), -1);
+                    while (lo > 0 && ok(lo - 1)) --lo;
+                    while (lo < dims[k] && !ok(lo)) ++lo;
+                    while (hi < dims[k] - 1 && ok(hi + 1)) ++hi;
+                    while (hi >= 0 && !ok(hi)) --hi;
+                    h_vs[j].bb[k] = (int)lo;
+                    h_vs[j].bb[3 + k] = (int)hi;
+                    cnt *= (unsigned long long)std::max<long long>(hi - lo + 1, 0);
+                }
+                h_vs[j].cnt = cnt;
+                // integer shifts: one tap of weight 1 per voxel -- the z pass reads the moving image directly.  Fractional
+                // shifts keep their shifted copy (its 2-8 double-precision taps per voxel would be re-evaluated 1.75 times
+                // by the windowed z pass), but nobody waits for its statistics.
+                otf[j] = t[0] == std::floor(t[0]) && t[1] == std::floor(t[1]) && t[2] == std::floor(t[2]);
+                if (otf[j]) continue;
+            }
             hipLaunchKernelGGL(shift_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im1, im0, im1t_buf[j], S, t[0], t[1], t[2],
                                im1_all_finite, vox_partial + (size_t)j * kStatBlocks);
             resident[ic] = j;
         }
-        hipLaunchKernelGGL(finish_voxstats_kernel, dim3(nb), dim3(256), 0, c->stream, vox_partial, vox_out);
-        VoxStats h_vs[kMaxResident];
-        MVS_HIP_TRY(c, hipMemcpyAsync(h_vs, vox_out, sizeof(VoxStats) * nb, hipMemcpyDeviceToHost, c->stream));
-        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!on_the_fly) {
+            hipLaunchKernelGGL(finish_voxstats_kernel, dim3(nb), dim3(256), 0, c->stream, vox_partial, vox_out);
+            MVS_HIP_TRY(c, hipMemcpyAsync(h_vs, vox_out, sizeof(VoxStats) * nb, hipMemcpyDeviceToHost, c->stream));
+            MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
 
         // ---- phase B: SSIM passes of every candidate that keeps enough jointly valid voxels ----
         Shape3 Rs[kMaxResident];
@@ -870,9 +928,11 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             float* pm = pmax + (size_t)j * kStatBlocks;
             int* ph = phasnan + (size_t)j * kStatBlocks;
             double* ps = psum + (size_t)j * kStatBlocks;
-            if (win == 7) launch_ssim_passes<7>(c->stream, im0, im1t_buf[j], S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps);
-            else if (win == 5) launch_ssim_passes<5>(c->stream, im0, im1t_buf[j], S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps);
-            else launch_ssim_passes<3>(c->stream, im0, im1t_buf[j], S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps);
+            const float* second = otf[j] ? im1 : im1t_buf[j];
+            const ShiftArg* sa = otf[j] ? &shifts[j] : nullptr;
+            if (win == 7) launch_ssim_passes<7>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa);
+            else if (win == 5) launch_ssim_passes<5>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa);
+            else launch_ssim_passes<3>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa);
             scored[j] = true;
         }
         RegionStats h_rs[kMaxResident];

@@ -248,3 +248,27 @@ def test_register_crops_equals_the_stepwise_flow(hip_device, case):
     got = registration.phase_correlation_registration(a, b, **kw)                          # one library call
     np.testing.assert_array_equal(got["affine_matrix"], want["affine_matrix"])
     assert got["quality"] == want["quality"] or (np.isnan(got["quality"]) and np.isnan(want["quality"]))
+
+
+def test_on_the_fly_shifted_ssim_equals_materialised_copies(hip_device):
+    """Finite-only crops: the candidates' shifted values are evaluated inside the SSIM z pass (no shifted copies, no mask
+    reduction, analytic valid boxes).  Must give the same bits as the path that writes the copies (option
+    "materialize_shifts"), for integer, half-integer and tenth-pixel shifts, in 2D and 3D, incl. rejected candidates."""
+    from multiview_stitcher_amd import _lib, _reg_ops
+
+    rng = np.random.default_rng(5)
+    for shape, cands in [((20, 48, 40), [(0, 0, 0), (1.5, -2, 0.5), (-3, 4, 2), (19, 0, 0), (0.5, 0.5, 0.5), (-18.5, 47, 39), (25, 0, 0)]),
+                         ((64, 72), [(0, 0), (2.3, -1.7), (-4, 5), (0.1, 63.9), (70, 1)])]:
+        a = rng.random(shape).astype(np.float32)
+        b = rng.random(shape).astype(np.float32)
+        dr = float(max(a.max(), b.max()) - min(a.min(), b.min()))
+        res = []
+        for flag in (1, 0):
+            _lib.set_option("materialize_shifts", flag)
+            try:
+                res.append(_reg_ops.score_candidates(a, b, np.array(cands, dtype=np.float64), "union", dr, float(b.min()), quality_for_all=False))
+            finally:
+                _lib.set_option("materialize_shifts", 0)
+        for x, y in zip(res[0], res[1]):
+            np.testing.assert_array_equal(x, y)
+        assert (res[0][2] == 0).sum() >= 3 and (res[0][2] == 1).sum() >= 1
