@@ -77,6 +77,42 @@ __global__ __launch_bounds__(256) void v2_sub(const unsigned short* __restrict__
         }
     }
 }
+// one wavefront writes BOTH pieces of its rows (A = px [0, wa), B = px [wa, 512)), piece after piece per row group: the lines
+// shared by the two pieces are completed by the same wavefront within a few hundred cycles (row-owning design)
+template <int G>
+__global__ __launch_bounds__(256) void v3_both(const unsigned short* __restrict__ src, unsigned short* __restrict__ dst, int nz, int ny, int nx,
+                                               int wa, int ostride, int ox0, int nbricks_y) {
+    const int lane = threadIdx.x & 63;
+    const int brick = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int by = brick % nbricks_y, bz = brick / nbricks_y;
+    if (bz * 4 >= nz) return;
+    typedef unsigned int v4 __attribute__((ext_vector_type(4), aligned(2)));
+    for (int p = 0; p < 4; ++p) {
+        const int z = bz * 4 + p;
+        for (int gb = 0; gb < 32; gb += G) {
+            for (int piece = 0; piece < 2; ++piece) {
+                const int x0 = piece ? wa : 0, w = piece ? 512 - wa : wa;
+                const bool act = lane * 8 < w;
+                const int nvalid = min(8, w - lane * 8);
+                v4 raw[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int y = by * 32 + gb + g;
+                    raw[g] = *reinterpret_cast<const v4*>(src + ((size_t)z * ny + y) * nx + x0 + (act ? lane * 8 : 0));
+                }
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int y = by * 32 + gb + g;
+                    unsigned short* q = dst + ((size_t)z * ny + y) * ostride + ox0 + x0 + lane * 8;
+                    if (act) {
+                        if (nvalid == 8) { v4 t = raw[g]; *reinterpret_cast<v4*>(q) = t; }
+                        else for (int j = 0; j < nvalid; ++j) q[j] = (unsigned short)((raw[g][j >> 1] >> (16 * (j & 1))) & 0xffff);
+                    }
+                }
+            }
+        }
+    }
+}
 template <typename F> float time_ms(F f) {
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     f(); f();
@@ -137,6 +173,8 @@ int main() {
         two("384|128 pitch 1792, sequential", 384, 1792, 0, 0);
         two("384|128 pitch 1792, two streams", 384, 1792, s1, s2);
         two("410|102 pitch 1792, sequential", 410, 1792, 0, 0);
+        rep("410|102 pitch 1742, same wavefront", time_ms([&] { hipLaunchKernelGGL((v3_both<8>), dim3(nbricks / 4), dim3(256), 0, 0, src, big, nz, ny, nx, 410, 1742, 512, nby); }));
+        rep("384|128 pitch 1792, same wavefront", time_ms([&] { hipLaunchKernelGGL((v3_both<8>), dim3(nbricks / 4), dim3(256), 0, 0, src, big, nz, ny, nx, 384, 1792, 512, nby); }));
     }
     return 0;
 }
