@@ -30,11 +30,19 @@ __global__ void pack_pair_kernel(const float* __restrict__ a, const float* __res
 
 // Cross power spectra from the packed transform: p = A conj(B); P1 = p / max(|p|, 100 eps) ("phase"), P2 = p (None).
 // The spectra are Hermitian, so their inverse transforms are real and again share one complex transform:
-// C = Pa + i Pb  ->  ifft(C) = cc_a + i cc_b.  sel_a / sel_b pick which of {P1 (1), P2 (0)} go where (sel_b < 0: C = Pa).
+// C = sa Pa + i sb Pb  ->  ifft(C) = sa cc_a + i sb cc_b.  sel_a / sel_b pick which of {P1 (1), P2 (0)} go where
+// (sel_b < 0: C = Pa, one correlation per transform).
 __global__ void xpower_packed_kernel(const float2* __restrict__ Z, float2* __restrict__ P1, float2* __restrict__ P2,
                                      float2* __restrict__ C, int nz, int ny, int nx, int sel_a, int sel_b) {
     const long long n = (long long)nz * ny * nx;
     const float floor_ = 100.f * FLT_EPSILON;
+    float scale_phase = 1.f, scale_plain = 1.f;
+    if (sel_b >= 0) {
+        const float2 z0 = Z[0];                                    // sum(a) + i sum(b): the DC term of the plain cross power is their product
+        const float dc = fabsf(z0.x * z0.y);
+        scale_plain = (dc > 0.f && dc < INFINITY) ? ldexpf(1.f, -ilogbf(dc)) : 1.f;
+        scale_phase = ldexpf(1.f, -ilogbf((float)n));
+    }
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int kx = (int)(i % nx);
         const long long t = i / nx;
@@ -51,21 +59,33 @@ __global__ void xpower_packed_kernel(const float2* __restrict__ Z, float2* __res
         const float2 pa = sel_a ? p1 : p;
         if (sel_b < 0) C[i] = pa;
         else {
+            // Two correlations in one transform only work if both have the same order of magnitude: float32 rounding of the
+            // larger one leaks into the other channel.  The phase-normalised correlation is <= N, the plain one about
+            // N * sum(a) * sum(b) for non-negative images (its DC term dominates): both are brought to O(1) by exact
+            // powers of two (scale_phase, scale_plain), which commute with every operation of the transform, so each
+            // channel holds the bits of its separate transform times its scale, plus ~1e-7 of the other channel.
             const float2 pb = sel_b ? p1 : p;
-            C[i] = make_float2(pa.x - pb.y, pa.y + pb.x);
+            const float sa = sel_a ? scale_phase : scale_plain, sb = sel_b ? scale_phase : scale_plain;
+            C[i] = make_float2(pa.x * sa - pb.y * sb, pa.y * sa + pb.x * sb);
         }
     }
 }
 
 // argmax |c| with np.argmax's tie-break (lowest flat index): per-block partial results
-// comp 0: |c| (one correlation per transform); 1 / 2: |Re c| / |Im c| (two real correlations packed in one transform)
-__global__ __launch_bounds__(256) void argmax_abs_kernel(const float2* __restrict__ c, long long n, int comp, float* __restrict__ pval,
+// COMP 0: |c| (one correlation per transform); 1 / 2: |Re c| / |Im c| (two real correlations packed in one transform).
+// (A template parameter: the variant that selected the component at run time returned wrong maxima for the imaginary part.)
+template <int COMP>
+__global__ __launch_bounds__(256) void argmax_abs_kernel(const float2* __restrict__ c, long long n, float* __restrict__ pval,
                                                          long long* __restrict__ pidx) {
+    constexpr int comp = COMP;
     float best = -1.f;
     long long bi = 0x7fffffffffffffffLL;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float2 v = c[i];
-        const float a = comp == 0 ? hypotf(v.x, v.y) : comp == 1 ? fabsf(v.x) : fabsf(v.y);
+        float a;
+        if (comp == 0) a = hypotf(v.x, v.y);
+        else if (comp == 1) a = fabsf(v.x);
+        else a = fabsf(v.y);
         if (a > best || (a == best && i < bi)) { best = a; bi = i; }
     }
     // wavefront shuffle reduction, then across the 4 wavefronts through LDS
@@ -307,7 +327,8 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     rc = mvs_stage_float_volume(c, moving, mem, n, 5, &db);
     if (rc) return rc;
     // complex work volumes: Z (ONE forward transform of a + i b carries both spectra), P1 / P2 (cross power with and
-    // without phase normalisation, kept for the upsampled DFT), CC (inverse transform; two correlations per transform)
+    // without phase normalisation, kept for the upsampled DFT), CC (inverse transform; both correlations in one transform
+    // when two normalisations are asked for)
     float2* Z = (float2*)mvs_scratch(c, 6, (size_t)n * 8 * 4);
     if (!Z) return MVS_ERR_HIP;
     float2* P1 = Z + n;
@@ -319,34 +340,56 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     hipLaunchKernelGGL(pack_pair_kernel, dim3(gb), dim3(256), 0, c->stream, da, db, Z, n);
     rc = mvs_fft3_c2c(c, Z, shape, false);
     if (rc) return rc;
+  // Two different normalisations: both correlations come out of ONE inverse transform (real and imaginary channel, see
+  // xpower_packed_kernel) and one host round trip; otherwise one complex transform per normalisation.
+  const bool packed = n_norm == 2 && (normalizations[0] != 0) != (normalizations[1] != 0) && !c->materialize_shifts;
+  char* red = (char*)mvs_scratch(c, 3, (size_t)gb * 32);
+  if (!red) return MVS_ERR_HIP;
+  std::vector<char> h((size_t)gb * 32);
+  float packed_scale[2] = {1.f, 1.f};
+  if (packed) {
+    hipLaunchKernelGGL(xpower_packed_kernel, dim3(gb), dim3(256), 0, c->stream, Z, P1, P2, CC, nz, ny, nx, normalizations[0] ? 1 : 0,
+                       normalizations[1] ? 1 : 0);
+    rc = mvs_fft3_c2c(c, CC, shape, true);
+    if (rc) return rc;
+    hipLaunchKernelGGL(argmax_abs_kernel<1>, dim3(gb), dim3(256), 0, c->stream, CC, n, (float*)red, (long long*)(red + (size_t)gb * 8));
+    hipLaunchKernelGGL(argmax_abs_kernel<2>, dim3(gb), dim3(256), 0, c->stream, CC, n, (float*)(red + (size_t)gb * 16), (long long*)(red + (size_t)gb * 24));
+    MVS_HIP_TRY(c, hipGetLastError());
+    float2 z0;
+    MVS_HIP_TRY(c, hipMemcpyAsync(h.data(), red, h.size(), hipMemcpyDeviceToHost, c->stream));
+    MVS_HIP_TRY(c, hipMemcpyAsync(&z0, Z, sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // the channel scales of xpower_packed_kernel (exact powers of two), to report the peak height unscaled
+    const float dc = std::fabs(z0.x * z0.y);
+    const float s_plain = (dc > 0.f && dc < INFINITY) ? std::ldexp(1.f, -std::ilogb(dc)) : 1.f;
+    const float s_phase = std::ldexp(1.f, -std::ilogb((float)n));
+    for (int ch = 0; ch < 2; ++ch) packed_scale[ch] = normalizations[ch] ? s_phase : s_plain;
+  }
   for (int inorm = 0; inorm < n_norm; ++inorm) {
     const int normalization = normalizations[inorm];
     double* shift_out = shifts_out + 3 * inorm;
     int64_t* peak_index_out = peak_indices_out ? peak_indices_out + 3 * inorm : nullptr;
     float* peak_abs_out = peak_abs_out_all ? peak_abs_out_all + inorm : nullptr;
-    // (the inverse transforms stay separate: one complex transform per normalisation)
-    hipLaunchKernelGGL(xpower_packed_kernel, dim3(gb), dim3(256), 0, c->stream, Z, P1, P2, CC, nz, ny, nx, normalization ? 1 : 0, -1);
-    rc = mvs_fft3_c2c(c, CC, shape, true);   // cc (unnormalised inverse: argmax is scale invariant)
-    if (rc) return rc;
-    const int comp = 0;
     const float2* P = normalization ? P1 : P2;
-    char* red = (char*)mvs_scratch(c, 3, (size_t)gb * 16);
-    if (!red) return MVS_ERR_HIP;
-    float* pval = (float*)red;
-    long long* pidx = (long long*)(red + (size_t)gb * 8);
-    hipLaunchKernelGGL(argmax_abs_kernel, dim3(gb), dim3(256), 0, c->stream, CC, n, comp, pval, pidx);
-    MVS_HIP_TRY(c, hipGetLastError());
-    std::vector<char> h((size_t)gb * 16);
-    MVS_HIP_TRY(c, hipMemcpyAsync(h.data(), red, h.size(), hipMemcpyDeviceToHost, c->stream));
-    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const char* hpart = h.data() + (packed ? (size_t)inorm * gb * 16 : 0);
+    if (!packed) {
+        hipLaunchKernelGGL(xpower_packed_kernel, dim3(gb), dim3(256), 0, c->stream, Z, P1, P2, CC, nz, ny, nx, normalization ? 1 : 0, -1);
+        rc = mvs_fft3_c2c(c, CC, shape, true);   // cc (unnormalised inverse: argmax is scale invariant)
+        if (rc) return rc;
+        hipLaunchKernelGGL(argmax_abs_kernel<0>, dim3(gb), dim3(256), 0, c->stream, CC, n, (float*)red, (long long*)(red + (size_t)gb * 8));
+        MVS_HIP_TRY(c, hipGetLastError());
+        MVS_HIP_TRY(c, hipMemcpyAsync(h.data(), red, (size_t)gb * 16, hipMemcpyDeviceToHost, c->stream));
+        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     float best = -1.f;
     long long bi = 0;
     {
-        const float* hv = (const float*)h.data();
-        const long long* hi = (const long long*)(h.data() + (size_t)gb * 8);
+        const float* hv = (const float*)hpart;
+        const long long* hi = (const long long*)(hpart + (size_t)gb * 8);
         for (int i = 0; i < gb; ++i)
             if (hv[i] > best || (hv[i] == best && hi[i] < bi)) { best = hv[i]; bi = hi[i]; }
     }
+    if (packed) best /= packed_scale[inorm];
     const long long pz = bi / ((long long)ny * nx), py = (bi / nx) % ny, px = bi % nx;
     const long long peak[3] = {pz, py, px};
     if (peak_index_out) { peak_index_out[0] = pz; peak_index_out[1] = py; peak_index_out[2] = px; }

@@ -187,7 +187,8 @@ def test_constant_overlap_gives_identity_with_warning(hip_device):
         s1, dbg1 = _reg_ops.phase_cross_correlation(a2, b2, 2, norm, return_debug=True)
         np.testing.assert_array_equal(s, s1)
         np.testing.assert_array_equal(dbg["peak_index"], dbg1["peak_index"])
-        assert dbg["peak_abs"] == dbg1["peak_abs"]
+        # both correlations share one inverse transform (|Re| / |Im| channel, power-of-two scaled): same peak, height to ~1e-6
+        assert dbg["peak_abs"] == pytest.approx(dbg1["peak_abs"], rel=1e-5)
 
 
 def test_context_lanes_give_identical_results(hip_device):
@@ -272,3 +273,26 @@ def test_on_the_fly_shifted_ssim_equals_materialised_copies(hip_device):
         for x, y in zip(res[0], res[1]):
             np.testing.assert_array_equal(x, y)
         assert (res[0][2] == 0).sum() >= 3 and (res[0][2] == 1).sum() >= 1
+
+
+def test_packed_inverse_transform_finds_the_same_peaks(hip_device):
+    """mvs_phasecorr_multi with ("phase", None): one inverse transform carries both correlations.  Against one transform per
+    normalisation (option "materialize_shifts" = the plain paths): identical integer peaks and sub-pixel shifts on smooth
+    images (broad plain-correlation peaks: the hard case for cross-channel rounding noise), 2D and 3D, odd sizes."""
+    from multiview_stitcher_amd import _lib, _reg_ops
+
+    for shape, shift in [((51, 128, 96), (2, -3, 5)), ((40, 45, 53), (-1, 4, 0)), ((1, 200, 104), (0, 7, -6)), ((64, 64, 27), (3, 0, -2))]:
+        a, b = _pair(shape, shift)
+        a, b = np.nan_to_num(ro.rescale_intensity_01(a)), np.nan_to_num(ro.rescale_intensity_01(b))
+        a2, b2 = (a[0], b[0]) if shape[0] == 1 else (a, b)
+        res = []
+        for flag in (1, 0):
+            _lib.set_option("materialize_shifts", flag)
+            try:
+                res.append(_reg_ops.phase_cross_correlation_multi(a2, b2, 2 if a2.ndim == 3 else 10, ("phase", None)))
+            finally:
+                _lib.set_option("materialize_shifts", 0)
+        for (s0, d0), (s1, d1) in zip(*res):
+            np.testing.assert_array_equal(s0, s1)
+            np.testing.assert_array_equal(d0["peak_index"], d1["peak_index"])
+            assert d0["peak_abs"] == pytest.approx(d1["peak_abs"], rel=1e-5)
