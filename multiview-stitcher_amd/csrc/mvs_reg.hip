@@ -365,9 +365,21 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     const float s_phase = std::ldexp(1.f, -std::ilogb((float)n));
     for (int ch = 0; ch < 2; ++ch) packed_scale[ch] = normalizations[ch] ? s_phase : s_plain;
   }
+  // Per normalisation: integer peak -> upsampled DFT around it.  The refinements of all normalisations are queued before
+  // the host waits once for their results (phase 2 below).
+  struct NormState { float shift[3]; std::vector<float2> hk, hres; size_t nout = 0; };   // hk stays alive until the wait (async upload)
+  std::vector<NormState> state((size_t)n_norm);
+  const int up_U = (int)ceilf((float)upsample_factor * 1.5f);
+  const size_t up_kbytes = ((size_t)up_U * (size_t)(nz + ny + nx) * sizeof(float2) + 255) / 256 * 256;
+  const size_t up_s1 = (size_t)nz * ny * up_U, up_s2 = (size_t)nz * up_U * up_U, up_s3 = (size_t)up_U * up_U * up_U;
+  const size_t up_bytes = up_kbytes + (up_s1 + up_s2 + up_s3) * sizeof(float2) + 1024;
+  char* up_base = nullptr;
+  if (upsample_factor > 1) {
+      up_base = (char*)mvs_scratch(c, 7, up_bytes * (size_t)n_norm);
+      if (!up_base) return MVS_ERR_HIP;
+  }
   for (int inorm = 0; inorm < n_norm; ++inorm) {
     const int normalization = normalizations[inorm];
-    double* shift_out = shifts_out + 3 * inorm;
     int64_t* peak_index_out = peak_indices_out ? peak_indices_out + 3 * inorm : nullptr;
     float* peak_abs_out = peak_abs_out_all ? peak_abs_out_all + inorm : nullptr;
     const float2* P = normalization ? P1 : P2;
@@ -396,7 +408,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     if (peak_abs_out) *peak_abs_out = best / (float)n;   // ifftn's 1/N
 
     // ---- signed shift, float32 arithmetic like skimage ----
-    float shift[3];
+    float (&shift)[3] = state[inorm].shift;
     for (int k = 0; k < 3; ++k) {
         shift[k] = (float)peak[k];
         const float mid = truncf((float)shape[k] / 2.f);   // np.fix(axis_size / 2)
@@ -413,7 +425,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
         }
         // kernels exp(-2 pi i (a - off) * fftfreq(n, uf)[x]) computed in double, cast to complex64
         const int k0 = (ndim == 3) ? 0 : 1;
-        std::vector<float2> hk;
+        std::vector<float2>& hk = state[inorm].hk;
         size_t koff[3] = {0, 0, 0};
         for (int k = k0; k < 3; ++k) {
             koff[k] = hk.size();
@@ -427,9 +439,8 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
         const size_t kbytes = hk.size() * sizeof(float2);
         const long long nrows = (long long)nz * ny;
         const size_t s1 = (size_t)nrows * U, s2 = (size_t)nz * U * U, s3 = (size_t)U * U * U;
-        float2* dk = (float2*)mvs_scratch(c, 7, kbytes + (s1 + s2 + s3) * sizeof(float2) + 1024);
-        if (!dk) return MVS_ERR_HIP;
-        float2* o1 = (float2*)((char*)dk + ((kbytes + 255) / 256) * 256);
+        float2* dk = (float2*)(up_base + (size_t)inorm * up_bytes);
+        float2* o1 = (float2*)((char*)dk + up_kbytes);
         float2* o2 = o1 + s1;
         float2* o3 = o2 + s2;
         MVS_HIP_TRY(c, hipMemcpyAsync(dk, hk.data(), kbytes, hipMemcpyHostToDevice, c->stream));
@@ -446,14 +457,27 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
             res = o3;
         }
         MVS_HIP_TRY(c, hipGetLastError());
-        std::vector<float2> hres(nout);
-        MVS_HIP_TRY(c, hipMemcpyAsync(hres.data(), res, nout * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
-        MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
-        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        state[inorm].nout = nout;
+        state[inorm].hres.resize(nout);
+        MVS_HIP_TRY(c, hipMemcpyAsync(state[inorm].hres.data(), res, nout * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    }
+  }
+  MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+  c->timing_valid = true;
+  if (upsample_factor > 1) MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+  // ---- phase 2: sub-pixel maximum of every refinement ----
+  for (int inorm = 0; inorm < n_norm; ++inorm) {
+    float (&shift)[3] = state[inorm].shift;
+    if (upsample_factor > 1) {
+        const float uf = (float)upsample_factor;
+        const int U = up_U;
+        const float dftshift = truncf((float)U / 2.f);
+        const int k0 = (ndim == 3) ? 0 : 1;
+        const std::vector<float2>& hres = state[inorm].hres;
         // argmax |.| (conj does not change the modulus), lowest flat index
         float bu = -1.f;
         size_t iu = 0;
-        for (size_t i = 0; i < nout; ++i) {
+        for (size_t i = 0; i < state[inorm].nout; ++i) {
             const float a = hypotf(hres[i].x, hres[i].y);
             if (a > bu) { bu = a; iu = i; }
         }
@@ -462,10 +486,8 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
         m[1] = (int)((iu / U) % U);
         if (ndim == 3) m[0] = (int)(iu / ((size_t)U * U));
         for (int k = k0; k < 3; ++k) shift[k] += ((float)m[k] - dftshift) / uf;
-    } else {
-        MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
     }
-    c->timing_valid = true;
+    double* shift_out = shifts_out + 3 * inorm;
     for (int k = 0; k < 3; ++k) {
         if (shape[k] == 1) shift[k] = 0.f;
         shift_out[k] = (double)shift[k];
