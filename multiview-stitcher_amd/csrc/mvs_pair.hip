@@ -11,6 +11,9 @@
 // that mirror for the debug outputs and for custom keyword arguments.
 #include "mvs_internal.h"
 
+int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, long long n, float* out0, float* out1,
+                            float mn[2], float mx[2], long long nvalid[2]);   // mvs_reg.hip
+
 #include <algorithm>
 #include <cmath>
 #include <vector>
@@ -41,10 +44,20 @@ extern "C" int mvs_register_crops(int device, const float* fixed, const float* m
     if (!r0 || !r1) return MVS_ERR_HIP;
     float min0, max0, min1, max1;
     int64_t nv0, nv1;
-    rc = mvs_rescale_intensity(device, fixed, mem, n, r0, MVS_MEM_DEVICE, &min0, &max0, &nv0);
-    if (rc) return rc;
-    rc = mvs_rescale_intensity(device, moving, mem, n, r1, MVS_MEM_DEVICE, &min1, &max1, &nv1);
-    if (rc) return rc;
+    if (mem == MVS_MEM_DEVICE) {      // one host round trip for both crops
+        MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
+        float mn[2], mx[2];
+        long long nv[2];
+        rc = mvs_rescale_pair_device(c, fixed, moving, n, r0, r1, mn, mx, nv);
+        if (rc) return rc;
+        min0 = mn[0]; max0 = mx[0]; nv0 = nv[0];
+        min1 = mn[1]; max1 = mx[1]; nv1 = nv[1];
+    } else {
+        rc = mvs_rescale_intensity(device, fixed, mem, n, r0, MVS_MEM_DEVICE, &min0, &max0, &nv0);
+        if (rc) return rc;
+        rc = mvs_rescale_intensity(device, moving, mem, n, r1, MVS_MEM_DEVICE, &min1, &max1, &nv1);
+        if (rc) return rc;
+    }
     if (constant_check && (min0 == max0 || min1 == max1)) {   // dispatch_pairwise_reg_func's guard (registration.py:1500-1520)
         *status_out = 2;
         return MVS_OK;

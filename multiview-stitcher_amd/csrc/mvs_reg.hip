@@ -229,6 +229,41 @@ int mvs_device_nanminmax(MvsContext* c, const float* d_in, long long n, float* m
     return MVS_OK;
 }
 
+// Intensity normalisation of BOTH crops of a pair (device resident) with one host round trip: the two reductions are
+// queued together, their partials come back in one copy, then the two rescale kernels follow.  Same kernels and
+// arithmetic as two mvs_rescale_intensity calls.
+int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, long long n, float* out0, float* out1,
+                            float mn[2], float mx[2], long long nvalid[2]) {
+    const int nb = grid_for(n);
+    char* scratch = (char*)mvs_scratch(c, 3, (size_t)nb * 32);
+    if (!scratch) return MVS_ERR_HIP;
+    const float* ins[2] = {in0, in1};
+    for (int k = 0; k < 2; ++k) {
+        char* part = scratch + (size_t)k * nb * 16;
+        hipLaunchKernelGGL(nanminmax_kernel, dim3(nb), dim3(256), 0, c->stream, ins[k], n, (float*)part, (float*)part + nb,
+                           (long long*)(part + (size_t)nb * 8));
+    }
+    MVS_HIP_TRY(c, hipGetLastError());
+    std::vector<char> h((size_t)nb * 32);
+    MVS_HIP_TRY(c, hipMemcpyAsync(h.data(), scratch, h.size(), hipMemcpyDeviceToHost, c->stream));
+    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    float* outs[2] = {out0, out1};
+    for (int k = 0; k < 2; ++k) {
+        const char* part = h.data() + (size_t)k * nb * 16;
+        const float* hmin = (const float*)part;
+        const float* hmax = hmin + nb;
+        const long long* hval = (const long long*)(part + (size_t)nb * 8);
+        float a = INFINITY, b = -INFINITY;
+        long long v = 0;
+        for (int i = 0; i < nb; ++i) { a = std::min(a, hmin[i]); b = std::max(b, hmax[i]); v += hval[i]; }
+        if (v == 0) { a = NAN; b = NAN; }
+        mn[k] = a; mx[k] = b; nvalid[k] = v;
+        hipLaunchKernelGGL(rescale_kernel, dim3(nb), dim3(256), 0, c->stream, ins[k], outs[k], n, a, b, a == b ? 1 : 0);
+    }
+    MVS_HIP_TRY(c, hipGetLastError());
+    return MVS_OK;
+}
+
 // device-resident building blocks (used by mvs_phasecorr and mvs_score.hip)
 int mvs_stage_float_volume(MvsContext* c, const float* src, int32_t mem, long long n, int slot, float** dptr) {
     if (mem == MVS_MEM_DEVICE) { *dptr = (float*)src; return MVS_OK; }
