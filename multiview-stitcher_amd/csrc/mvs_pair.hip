@@ -138,8 +138,12 @@ extern "C" int mvs_register_crops(int device, const float* fixed, const float* m
     const int n_uniq = (int)(uniq.size() / (size_t)ndim);
     std::vector<double> ssim_u(n_uniq), spear_u(n_uniq);
     std::vector<int32_t> code_u(n_uniq);
+    // rescaled crops are finite iff the inputs were: no NaN (all voxels counted) and finite extrema (no inf)
+    c->both_crops_finite = !has_nan && std::isfinite(min0) && std::isfinite(max0) && std::isfinite(min1) && std::isfinite(max1) &&
+                           !c->materialize_shifts;
     rc = mvs_score_candidates(device, r0, r1, MVS_MEM_DEVICE, ndim, shape, uniq.data(), n_uniq, region_mode, (double)data_range, im1_min, 0,
                               ssim_u.data(), spear_u.data(), code_u.data());
+    c->both_crops_finite = false;
     if (rc) return rc;
 
     // ---- metric lists as the reference builds them (code 2 appends nothing), nanargmax, Q3 indexing ----

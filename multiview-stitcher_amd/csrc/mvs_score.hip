@@ -777,12 +777,22 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     if (!d_counter) return mvs_fail(c, MVS_ERR_HIP, "mvs_score_candidates: scratch layout");
 
     // valid voxels of im1 and the bboxes of both images (registration.py:400, 491)
-    hipLaunchKernelGGL(image_stats_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im0, S, vox_partial);
-    hipLaunchKernelGGL(image_stats_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im1, S, vox_partial + kStatBlocks);
-    hipLaunchKernelGGL(finish_voxstats_kernel, dim3(2), dim3(256), 0, c->stream, vox_partial, vox_out);
     VoxStats h_im[2];
-    MVS_HIP_TRY(c, hipMemcpyAsync(h_im, vox_out, sizeof(h_im), hipMemcpyDeviceToHost, c->stream));
-    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->both_crops_finite) {
+        // the caller (mvs_register_crops) has just reduced both images and found neither NaN nor inf: every voxel is valid,
+        // the boxes are the whole volume -- no reduction, no host round trip
+        for (int k = 0; k < 2; ++k) {
+            h_im[k].cnt = (unsigned long long)n;
+            h_im[k].bb[0] = h_im[k].bb[1] = h_im[k].bb[2] = 0;
+            h_im[k].bb[3] = S.nz - 1; h_im[k].bb[4] = S.ny - 1; h_im[k].bb[5] = S.nx - 1;
+        }
+    } else {
+        hipLaunchKernelGGL(image_stats_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im0, S, vox_partial);
+        hipLaunchKernelGGL(image_stats_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im1, S, vox_partial + kStatBlocks);
+        hipLaunchKernelGGL(finish_voxstats_kernel, dim3(2), dim3(256), 0, c->stream, vox_partial, vox_out);
+        MVS_HIP_TRY(c, hipMemcpyAsync(h_im, vox_out, sizeof(h_im), hipMemcpyDeviceToHost, c->stream));
+        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
     const int* bb0 = h_im[0].bb;
     const int* bbm = h_im[1].bb;
     const unsigned int valid1 = (unsigned int)(h_im[1].cnt & 0xffffffffull);

@@ -296,3 +296,23 @@ def test_packed_inverse_transform_finds_the_same_peaks(hip_device):
             np.testing.assert_array_equal(s0, s1)
             np.testing.assert_array_equal(d0["peak_index"], d1["peak_index"])
             assert d0["peak_abs"] == pytest.approx(d1["peak_abs"], rel=1e-5)
+
+
+def test_register_crops_shortcuts_for_finite_crops_change_nothing(hip_device):
+    """Finite crops take every shortcut of mvs_register_crops (packed inverse transform, no image statistics pass, analytic
+    valid boxes, on-the-fly integer shifts); "materialize_shifts" switches all of them off.  Same translation, same quality."""
+    from multiview_stitcher_amd import _lib, _reg_ops
+
+    for shape, shift, up in [((24, 40, 36), (2, -3, 4), 2), ((51, 64, 48), (-1, 2, 3), 2), ((96, 80), (5, -7), 10)]:
+        a, b = _pair(shape, shift, noise=0.002)
+        res = []
+        for flag in (1, 0):
+            _lib.set_option("materialize_shifts", flag)
+            try:
+                res.append(_reg_ops.register_crops(a, b, up))
+            finally:
+                _lib.set_option("materialize_shifts", 0)
+        (t0, q0, st0, nc0), (t1, q1, st1, nc1) = res
+        assert st0 == st1 == 0 and nc0 == nc1
+        np.testing.assert_array_equal(t0, t1)
+        assert q0 == q1
