@@ -16,6 +16,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 int mvs_stage_float_volume(MvsContext* c, const float* src, int32_t mem, long long n, int slot, float** dptr);   // mvs_reg.hip
@@ -243,7 +244,10 @@ struct Five { const float* src[5]; float* dst[5]; };
 // SHIFTED: `im1t` is the unshifted moving image and its shifted value is evaluated on the fly (same arithmetic as
 // shift_kernel), so the candidates of an all-finite pair never materialise their shifted copy.
 struct ShiftArg { double tz, ty, tx; int skip_zero_taps; };
-template <int WIN, bool SHIFTED>
+// QSET: which of the five quantities are filtered and written -- 0: all (x, y, xx, yy, xy); 1: only x, xx (the fixed
+// image's own terms: the same for every candidate whose region is the whole volume, computed once per pair); 2: only
+// y, yy, xy (the candidate's terms when x, xx are shared).
+template <int WIN, bool SHIFTED, int QSET = 0>
 __global__ __launch_bounds__(256) void ssim_first_pass_kernel(const float* __restrict__ im0, const float* __restrict__ im1t, Shape3 S,
                                                               int lz, int ly, int lx, Shape3 R, int axis, Five P,
                                                               float* __restrict__ pmax, int* __restrict__ phasnan, ShiftArg T) {
@@ -288,26 +292,31 @@ __global__ __launch_bounds__(256) void ssim_first_pass_kernel(const float* __res
         }
         const int dst_base = (z * R.ny + y) * R.nx + x;
         float f[5][kChunk];
-        box_means<WIN, kChunk>(va, f[0]);
-        box_means<WIN, kChunk>(vb, f[1]);
+        constexpr bool kX = QSET != 2, kY = QSET != 1;
+        if (kX) box_means<WIN, kChunk>(va, f[0]);
+        if (kY) box_means<WIN, kChunk>(vb, f[1]);
         {
             float prod[NL];   // products in float32 like the reference's `im * im` on float32 arrays
+            if (kX) {
 #pragma unroll
-            for (int k = 0; k < NL; ++k) prod[k] = va[k] * va[k];
-            box_means<WIN, kChunk>(prod, f[2]);
+                for (int k = 0; k < NL; ++k) prod[k] = va[k] * va[k];
+                box_means<WIN, kChunk>(prod, f[2]);
+            }
+            if (kY) {
 #pragma unroll
-            for (int k = 0; k < NL; ++k) prod[k] = vb[k] * vb[k];
-            box_means<WIN, kChunk>(prod, f[3]);
+                for (int k = 0; k < NL; ++k) prod[k] = vb[k] * vb[k];
+                box_means<WIN, kChunk>(prod, f[3]);
 #pragma unroll
-            for (int k = 0; k < NL; ++k) prod[k] = va[k] * vb[k];
-            box_means<WIN, kChunk>(prod, f[4]);
+                for (int k = 0; k < NL; ++k) prod[k] = va[k] * vb[k];
+                box_means<WIN, kChunk>(prod, f[4]);
+            }
         }
 #pragma unroll
         for (int k = 0; k < kChunk; ++k) {
             if (p0 + k >= len) break;
             const int o = dst_base + (p0 + k) * dst_stride;
-#pragma unroll
-            for (int a = 0; a < 5; ++a) P.dst[a][o] = f[a][k];
+            if (kX) { P.dst[0][o] = f[0][k]; P.dst[2][o] = f[2][k]; }
+            if (kY) { P.dst[1][o] = f[1][k]; P.dst[3][o] = f[3][k]; P.dst[4][o] = f[4][k]; }
         }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -408,11 +417,16 @@ __global__ __launch_bounds__(256) void ssim_last_pass_kernel(Five P, Shape3 R, i
 // interior of one plane: the y-filtered values of the tile and its x halo (5 quantities) go to LDS (float32, the
 // rounding point of the separate passes), the x filter and the SSIM formula read them from there -- the y-filtered
 // arrays never touch memory, which removes 45 % of the HBM traffic of the three-pass version.
-template <int WIN>
+// MODE 0: all five quantities -> SSIM.  MODE 1: only x, xx (P.src[0], P.src[2]): their fully filtered values are WRITTEN to
+// P.dst[0], P.dst[2] (no SSIM) -- once per pair.  MODE 2: y, yy, xy are filtered here, x and xx are read, already filtered, from
+// P.dst[0], P.dst[2] (written by MODE 1) -> SSIM.  Same arithmetic per quantity in every mode.
+template <int WIN, int MODE = 0>
 __global__ __launch_bounds__(256) void ssim_yx_fused_kernel(Five P, Shape3 R, float cov_norm, float C1, float C2, double* __restrict__ partial) {
     // tile: 32 rows x 56 voxels -> 62 (WIN = 7) halo columns x 4 row chunks = 248 y-pass items: one round of the 256 threads
     constexpr int H = WIN / 2, pad = (WIN - 1) / 2, TY = 32, TX = 56, LX = TX + 2 * H, NL = kChunk + 2 * H;
-    __shared__ float s[5][TY][LX + 1];
+    constexpr int NF = MODE == 0 ? 5 : MODE == 1 ? 2 : 3;                       // quantities filtered by this instantiation
+    constexpr int QM[5] = {MODE == 2 ? 1 : 0, MODE == 0 ? 1 : MODE == 1 ? 2 : 3, MODE == 0 ? 2 : 4, 3, 4};   // slot -> quantity
+    __shared__ float s[NF][TY][LX + 1];
     const int cz = R.nz - 2 * pad, cy = R.ny - 2 * pad, cx = R.nx - 2 * pad;
     double acc = 0.0;
     if (cz > 0 && cy > 0 && cx > 0) {
@@ -430,10 +444,10 @@ __global__ __launch_bounds__(256) void ssim_yx_fused_kernel(Five P, Shape3 R, fl
 #pragma unroll
                 for (int k = 0; k < NL; ++k) off[k] = base + reflect_index(r0 - H + k, R.ny) * R.nx;
 #pragma unroll
-                for (int a = 0; a < 5; ++a) {
+                for (int a = 0; a < NF; ++a) {
                     float v[NL];
 #pragma unroll
-                    for (int k = 0; k < NL; ++k) v[k] = P.src[a][off[k]];
+                    for (int k = 0; k < NL; ++k) v[k] = P.src[QM[a]][off[k]];
                     float f[kChunk];
                     box_means<WIN, kChunk>(v, f);
 #pragma unroll
@@ -448,15 +462,18 @@ __global__ __launch_bounds__(256) void ssim_yx_fused_kernel(Five P, Shape3 R, fl
                 if (y < R.ny - pad && ch * kChunk < TX) {
                     float f[5][kChunk];
 #pragma unroll
-                    for (int a = 0; a < 5; ++a) {
+                    for (int a = 0; a < NF; ++a) {
                         float v[NL];
 #pragma unroll
                         for (int k = 0; k < NL; ++k) v[k] = s[a][row][ch * kChunk + k];
-                        box_means<WIN, kChunk>(v, f[a]);
+                        box_means<WIN, kChunk>(v, f[QM[a]]);
                     }
+                    const int obase = (z * R.ny + y) * R.nx + x0 + ch * kChunk;
 #pragma unroll
                     for (int k = 0; k < kChunk; ++k) {
                         if (x0 + ch * kChunk + k >= R.nx - pad || ch * kChunk + k >= TX) continue;
+                        if (MODE == 1) { P.dst[0][obase + k] = f[0][k]; P.dst[2][obase + k] = f[2][k]; continue; }
+                        if (MODE == 2) { f[0][k] = P.dst[0][obase + k]; f[2][k] = P.dst[2][obase + k]; }
                         const float a = f[0][k], b = f[1][k];
                         const float vx = cov_norm * (f[2][k] - a * a);
                         const float vy = cov_norm * (f[3][k] - b * b);
@@ -474,7 +491,7 @@ __global__ __launch_bounds__(256) void ssim_yx_fused_kernel(Five P, Shape3 R, fl
     __shared__ double sred[4];
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partial[blockIdx.x] = sred[0] + sred[1] + sred[2] + sred[3];
+    if (MODE != 1 && threadIdx.x == 0) partial[blockIdx.x] = sred[0] + sred[1] + sred[2] + sred[3];
 }
 
 // folds the per-workgroup partials of one candidate's SSIM passes
@@ -698,12 +715,39 @@ struct DeviceBump {   // bump allocator over one scratch slot
     }
 };
 
+// The fixed image's own terms (mean of x and of x * x over the window) of a 3D pair whose SSIM region is the whole volume for
+// every candidate: z pass + y/x pass once, results in setB[2], setB[3] (shared_x of launch_ssim_passes).
+template <int WIN>
+void launch_ssim_shared_x(hipStream_t stream, const float* im0, Shape3 S, Shape3 R, float* const setA[5], float* const setB[5],
+                          float* pmax, int* phasnan) {
+    Five P1, P2;
+    for (int a = 0; a < 5; ++a) { P1.src[a] = nullptr; P1.dst[a] = setA[a]; P2.src[a] = setA[a]; P2.dst[a] = nullptr; }
+    P2.dst[0] = setB[2];
+    P2.dst[2] = setB[3];
+    hipLaunchKernelGGL((ssim_first_pass_kernel<WIN, false, 1>), dim3(kStatBlocks), dim3(256), 0, stream, im0, im0, S, 0, 0, 0, R, 0, P1, pmax, phasnan,
+                       ShiftArg{0.0, 0.0, 0.0, 0});
+    hipLaunchKernelGGL((ssim_yx_fused_kernel<WIN, 1>), dim3(kStatBlocks), dim3(256), 0, stream, P2, R, 0.f, 0.f, 0.f, (double*)nullptr);
+}
+
 template <int WIN>
 void launch_ssim_passes(hipStream_t stream, const float* im0, const float* im1t, Shape3 S, const int lo[3], Shape3 R, int ndim,
                         float* const setA[5], float* const setB[5], float cov_norm, float C1, float C2, float* pmax, int* phasnan,
-                        double* psum, const ShiftArg* on_the_fly = nullptr) {
+                        double* psum, const ShiftArg* on_the_fly = nullptr, bool shared_x = false) {
     Five P1, P2, P3;
     for (int a = 0; a < 5; ++a) { P1.src[a] = nullptr; P1.dst[a] = setA[a]; }
+    if (shared_x) {      // 3D, region = whole volume: only the candidate's terms are filtered, x / xx come from setB[2], setB[3]
+        if (on_the_fly)
+            hipLaunchKernelGGL((ssim_first_pass_kernel<WIN, true, 2>), dim3(kStatBlocks), dim3(256), 0, stream, im0, im1t, S, lo[0], lo[1], lo[2], R,
+                               0, P1, pmax, phasnan, *on_the_fly);
+        else
+            hipLaunchKernelGGL((ssim_first_pass_kernel<WIN, false, 2>), dim3(kStatBlocks), dim3(256), 0, stream, im0, im1t, S, lo[0], lo[1], lo[2], R,
+                               0, P1, pmax, phasnan, ShiftArg{0.0, 0.0, 0.0, 0});
+        for (int a = 0; a < 5; ++a) { P2.src[a] = setA[a]; P2.dst[a] = nullptr; }
+        P2.dst[0] = setB[2];
+        P2.dst[2] = setB[3];
+        hipLaunchKernelGGL((ssim_yx_fused_kernel<WIN, 2>), dim3(kStatBlocks), dim3(256), 0, stream, P2, R, cov_norm, C1, C2, psum);
+        return;
+    }
     if (on_the_fly)      // im1t is the UNSHIFTED moving image
         hipLaunchKernelGGL((ssim_first_pass_kernel<WIN, true>), dim3(kStatBlocks), dim3(256), 0, stream, im0, im1t, S, lo[0], lo[1], lo[2], R,
                            ndim == 3 ? 0 : 1, P1, pmax, phasnan, *on_the_fly);
@@ -855,6 +899,14 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         return MVS_OK;
     };
 
+    // 3D, fixed image finite, "union" regions: the SSIM region of every candidate is the whole volume, so the fixed image's own
+    // window means (x, xx: 2 of the 5 filtered quantities) are computed once for the pair instead of once per candidate
+    bool shared_x = false;
+    if (ndim == 3 && region_mode == 0 && im0_all_finite && todo.size() >= 2 && std::min(S.nz, std::min(S.ny, S.nx)) >= 7 &&
+        !c->materialize_shifts) {
+        shared_x = true;
+        launch_ssim_shared_x<7>(c->stream, im0, S, S, setA, setB, pmax, phasnan);
+    }
     for (size_t b0 = 0; b0 < todo.size(); b0 += (size_t)nres) {
         const int nb = (int)std::min<size_t>((size_t)nres, todo.size() - b0);
         std::fill(resident.begin(), resident.end(), -1);
@@ -940,7 +992,9 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             double* ps = psum + (size_t)j * kStatBlocks;
             const float* second = otf[j] ? im1 : im1t_buf[j];
             const ShiftArg* sa = otf[j] ? &shifts[j] : nullptr;
-            if (win == 7) launch_ssim_passes<7>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa);
+            const bool full = R.nz == S.nz && R.ny == S.ny && R.nx == S.nx;
+            if (win == 7 && shared_x && full) launch_ssim_passes<7>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa, true);
+            else if (win == 7) launch_ssim_passes<7>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa);
             else if (win == 5) launch_ssim_passes<5>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa);
             else launch_ssim_passes<3>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa);
             scored[j] = true;
