@@ -132,7 +132,8 @@ __device__ __forceinline__ float shifted_value(const float* __restrict__ im1, in
 // Stats gathered while shifting: #(valid im1t & valid im0) and the bbox of valid im1t.  Each thread takes 4
 // consecutive voxels (one index decode, one 16-byte store); the z and y parts of the coordinate only change when the
 // group wraps to the next row, so they are evaluated per row, the x part per voxel.
-__global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im1, const float* __restrict__ im0,
+template <bool STATS>
+__device__ __forceinline__ void shift_body(const float* __restrict__ im1, const float* __restrict__ im0,
                                                     float* __restrict__ out, Shape3 S, double tz, double ty, double tx,
                                                     int skip_zero_taps, VoxStats* __restrict__ partial) {
     const unsigned int n = (unsigned int)S.nz * S.ny * S.nx;
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im
                     Y = axis_tap(y, ty, S.ny);
                 }
                 r = shifted_value(im1, sy, sz, Z, Y, axis_tap(x, tx, S.nx), skip_zero_taps);
-                if (r == r) {
+                if (STATS && r == r) {
                     mnz = min(mnz, z); mny = min(mny, y); mnx = min(mnx, x);
                     mxz = max(mxz, z); mxy = max(mxy, y); mxx = max(mxx, x);
                     const float a = im0[i0 + k];
@@ -172,7 +173,22 @@ __global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im
         else
             for (int k = 0; k < 4; ++k) if (i0 + k < n) out[i0 + k] = r4[k];
     }
-    block_reduce_voxstats(cnt, mnz, mny, mnx, mxz, mxy, mxx, partial + blockIdx.x);
+    if (STATS) block_reduce_voxstats(cnt, mnz, mny, mnx, mxz, mxy, mxx, partial + blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im1, const float* __restrict__ im0,
+                                                    float* __restrict__ out, Shape3 S, double tz, double ty, double tx,
+                                                    int skip_zero_taps, VoxStats* __restrict__ partial) {
+    shift_body<true>(im1, im0, out, S, tz, ty, tx, skip_zero_taps, partial);
+}
+
+// shifted copies of several candidates in one launch (blockIdx.y = candidate); no statistics (the caller knows the valid boxes)
+struct ShiftCand { float* out; double tz, ty, tx; };
+struct ShiftBatch { ShiftCand c[kMaxResident]; };
+__global__ __launch_bounds__(256) void shift_batch_kernel(const float* __restrict__ im1, const float* __restrict__ im0, Shape3 S, ShiftBatch B,
+                                                          int skip_zero_taps) {
+    const ShiftCand& C = B.c[blockIdx.y];
+    shift_body<false>(im1, im0, C.out, S, C.tz, C.ty, C.tx, skip_zero_taps, nullptr);
 }
 
 // #valid voxels and their bbox for one image (get_bb_from_nanmask, registration.py:482-489; valid_pixels1 :400)
@@ -248,7 +264,7 @@ struct ShiftArg { double tz, ty, tx; int skip_zero_taps; };
 // image's own terms: the same for every candidate whose region is the whole volume, computed once per pair); 2: only
 // y, yy, xy (the candidate's terms when x, xx are shared).
 template <int WIN, bool SHIFTED, int QSET = 0>
-__global__ __launch_bounds__(256) void ssim_first_pass_kernel(const float* __restrict__ im0, const float* __restrict__ im1t, Shape3 S,
+__device__ __forceinline__ void ssim_first_pass_body(const float* __restrict__ im0, const float* __restrict__ im1t, Shape3 S,
                                                               int lz, int ly, int lx, Shape3 R, int axis, Five P,
                                                               float* __restrict__ pmax, int* __restrict__ phasnan, ShiftArg T) {
     constexpr int H = WIN / 2, NL = kChunk + 2 * H;
@@ -332,6 +348,31 @@ __global__ __launch_bounds__(256) void ssim_first_pass_kernel(const float* __res
         pmax[blockIdx.x] = mx;
         phasnan[blockIdx.x] = hn;
     }
+}
+
+template <int WIN, bool SHIFTED, int QSET = 0>
+__global__ __launch_bounds__(256) void ssim_first_pass_kernel(const float* __restrict__ im0, const float* __restrict__ im1t, Shape3 S,
+                                                              int lz, int ly, int lx, Shape3 R, int axis, Five P,
+                                                              float* __restrict__ pmax, int* __restrict__ phasnan, ShiftArg T) {
+    ssim_first_pass_body<WIN, SHIFTED, QSET>(im0, im1t, S, lz, ly, lx, R, axis, P, pmax, phasnan, T);
+}
+
+// All candidates of a batch in ONE launch (blockIdx.y = candidate): the z pass of the candidate's terms (QSET 2) over the
+// whole volume.  A step of the north-star mosaic issues ~13 500 kernels; the GPU is busy but every launch has its cost.
+struct FirstCand { const float* src; float* dst1; float* dst3; float* dst4; ShiftArg T; int shifted; };
+struct FirstBatch { FirstCand c[kMaxResident]; };
+template <int WIN>
+__global__ __launch_bounds__(256) void ssim_first_pass_batch_kernel(const float* __restrict__ im0, Shape3 S, FirstBatch B,
+                                                                    float* __restrict__ pmax, int* __restrict__ phasnan) {
+    const FirstCand& C = B.c[blockIdx.y];
+    if (!C.src) return;       // slot of a rejected candidate or of one scored by its own launches
+    Five P;
+    for (int a = 0; a < 5; ++a) { P.src[a] = nullptr; P.dst[a] = nullptr; }
+    P.dst[1] = C.dst1; P.dst[3] = C.dst3; P.dst[4] = C.dst4;
+    float* pm = pmax + (size_t)blockIdx.y * kStatBlocks;
+    int* ph = phasnan + (size_t)blockIdx.y * kStatBlocks;
+    if (C.shifted) ssim_first_pass_body<WIN, true, 2>(im0, C.src, S, 0, 0, 0, S, 0, P, pm, ph, C.T);
+    else ssim_first_pass_body<WIN, false, 2>(im0, C.src, S, 0, 0, 0, S, 0, P, pm, ph, C.T);
 }
 
 // middle pass (3D only): the five arrays filtered along y
@@ -421,7 +462,7 @@ __global__ __launch_bounds__(256) void ssim_last_pass_kernel(Five P, Shape3 R, i
 // P.dst[0], P.dst[2] (no SSIM) -- once per pair.  MODE 2: y, yy, xy are filtered here, x and xx are read, already filtered, from
 // P.dst[0], P.dst[2] (written by MODE 1) -> SSIM.  Same arithmetic per quantity in every mode.
 template <int WIN, int MODE = 0>
-__global__ __launch_bounds__(256) void ssim_yx_fused_kernel(Five P, Shape3 R, float cov_norm, float C1, float C2, double* __restrict__ partial) {
+__device__ __forceinline__ void ssim_yx_fused_body(Five P, Shape3 R, float cov_norm, float C1, float C2, double* __restrict__ partial) {
     // tile: 32 rows x 56 voxels -> 62 (WIN = 7) halo columns x 4 row chunks = 248 y-pass items: one round of the 256 threads
     constexpr int H = WIN / 2, pad = (WIN - 1) / 2, TY = 32, TX = 56, LX = TX + 2 * H, NL = kChunk + 2 * H;
     constexpr int NF = MODE == 0 ? 5 : MODE == 1 ? 2 : 3;                       // quantities filtered by this instantiation
@@ -492,6 +533,26 @@ __global__ __launch_bounds__(256) void ssim_yx_fused_kernel(Five P, Shape3 R, fl
     if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (MODE != 1 && threadIdx.x == 0) partial[blockIdx.x] = sred[0] + sred[1] + sred[2] + sred[3];
+}
+
+template <int WIN, int MODE = 0>
+__global__ __launch_bounds__(256) void ssim_yx_fused_kernel(Five P, Shape3 R, float cov_norm, float C1, float C2, double* __restrict__ partial) {
+    ssim_yx_fused_body<WIN, MODE>(P, R, cov_norm, C1, C2, partial);
+}
+
+// y / x pass + SSIM of all candidates of a batch in one launch (MODE 2: the fixed image's terms come from ux / uxx)
+struct YxCand { const float* src1; const float* src3; const float* src4; };
+struct YxBatch { YxCand c[kMaxResident]; };
+template <int WIN>
+__global__ __launch_bounds__(256) void ssim_yx_batch_kernel(YxBatch B, float* __restrict__ ux, float* __restrict__ uxx, Shape3 R,
+                                                            float cov_norm, float C1, float C2, double* __restrict__ partial) {
+    const YxCand& C = B.c[blockIdx.y];
+    if (!C.src1) return;
+    Five P;
+    for (int a = 0; a < 5; ++a) { P.src[a] = nullptr; P.dst[a] = nullptr; }
+    P.src[1] = C.src1; P.src[3] = C.src3; P.src[4] = C.src4;
+    P.dst[0] = ux; P.dst[2] = uxx;
+    ssim_yx_fused_body<WIN, 2>(P, R, cov_norm, C1, C2, partial + (size_t)blockIdx.y * kStatBlocks);
 }
 
 // folds the per-workgroup partials of one candidate's SSIM passes
@@ -800,7 +861,9 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                                             (float*)nullptr, (size_t)n, 0, 32, c->stream));
     const int gb = grid_for(n);
     const size_t stat_bytes = (size_t)(kMaxResident + 2) * kStatBlocks * (sizeof(VoxStats) + 4 + 4 + 8) + (kMaxResident + 2) * 64;
-    const size_t need = (size_t)n * 4 * (10 + nres) + 256 * (12 + nres) + sort_temp_bytes + (size_t)gb * 32 + stat_bytes + 64 * 1024;
+    // batched launches (one z pass / one y-x pass for all candidates of a batch) keep three z-filtered arrays per candidate
+    const bool may_batch = ndim == 3 && region_mode == 0 && !quality_for_all && !c->materialize_shifts && (long long)n * 12 * nres <= (3ll << 30);
+    const size_t need = (size_t)n * 4 * (10 + nres + (may_batch ? 3 * nres : 0)) + 256 * (12 + 4 * nres) + sort_temp_bytes + (size_t)gb * 32 + stat_bytes + 64 * 1024;
     char* base = (char*)mvs_scratch(c, 6, need);
     if (!base) return MVS_ERR_HIP;
     DeviceBump B{base, need, 0};
@@ -809,6 +872,8 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     float* setA[5]; float* setB[5];
     for (int a = 0; a < 5; ++a) setA[a] = B.take<float>(n);
     for (int a = 0; a < 5; ++a) setB[a] = B.take<float>(n);
+    std::vector<float*> cand3((size_t)(may_batch ? 3 * nres : 0));
+    for (float*& q : cand3) q = B.take<float>(n);
     void* sort_temp = B.take<char>(sort_temp_bytes);
     double* partial = B.take<double>((size_t)gb * 4);
     VoxStats* vox_partial = B.take<VoxStats>((size_t)(kMaxResident + 2) * kStatBlocks);
@@ -914,6 +979,9 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         VoxStats h_vs[kMaxResident];
         ShiftArg shifts[kMaxResident];
         bool otf[kMaxResident] = {};
+        const bool batched = on_the_fly && shared_x && may_batch;
+        ShiftBatch shift_batch;
+        int n_shift_batch = 0;
         for (int j = 0; j < nb; ++j) {
             const int ic = todo[b0 + j];
             double t[3] = {0.0, 0.0, 0.0};
@@ -942,11 +1010,18 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 // by the windowed z pass), but nobody waits for its statistics.
                 otf[j] = t[0] == std::floor(t[0]) && t[1] == std::floor(t[1]) && t[2] == std::floor(t[2]);
                 if (otf[j]) continue;
+                if (batched) {      // all fractional shifts of the batch in one launch, after this loop
+                    shift_batch.c[n_shift_batch++] = ShiftCand{im1t_buf[j], t[0], t[1], t[2]};
+                    resident[ic] = j;
+                    continue;
+                }
             }
             hipLaunchKernelGGL(shift_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im1, im0, im1t_buf[j], S, t[0], t[1], t[2],
                                im1_all_finite, vox_partial + (size_t)j * kStatBlocks);
             resident[ic] = j;
         }
+        if (n_shift_batch)
+            hipLaunchKernelGGL(shift_batch_kernel, dim3(kStatBlocks, n_shift_batch), dim3(256), 0, c->stream, im1, im0, S, shift_batch, im1_all_finite);
         if (!on_the_fly) {
             hipLaunchKernelGGL(finish_voxstats_kernel, dim3(nb), dim3(256), 0, c->stream, vox_partial, vox_out);
             MVS_HIP_TRY(c, hipMemcpyAsync(h_vs, vox_out, sizeof(VoxStats) * nb, hipMemcpyDeviceToHost, c->stream));
@@ -957,6 +1032,14 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         Shape3 Rs[kMaxResident];
         int wins[kMaxResident];
         bool scored[kMaxResident];
+        FirstBatch first_batch;
+        YxBatch yx_batch;
+        bool any_batched = false;
+        float batch_cov_norm = 0.f;
+        for (int j = 0; j < nb; ++j) {
+            first_batch.c[j] = FirstCand{nullptr, nullptr, nullptr, nullptr, ShiftArg{0.0, 0.0, 0.0, 0}, 0};
+            yx_batch.c[j] = YxCand{nullptr, nullptr, nullptr};
+        }
         for (int j = 0; j < nb; ++j) {
             const int ic = todo[b0 + j];
             const unsigned long long cnt = h_vs[j].cnt;
@@ -993,11 +1076,22 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             const float* second = otf[j] ? im1 : im1t_buf[j];
             const ShiftArg* sa = otf[j] ? &shifts[j] : nullptr;
             const bool full = R.nz == S.nz && R.ny == S.ny && R.nx == S.nx;
-            if (win == 7 && shared_x && full) launch_ssim_passes<7>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa, true);
+            if (batched && win == 7 && full) {     // joins the two batched launches below
+                float* d1 = cand3[(size_t)3 * j], *d3 = cand3[(size_t)3 * j + 1], *d4 = cand3[(size_t)3 * j + 2];
+                first_batch.c[j] = FirstCand{second, d1, d3, d4, shifts[j], otf[j] ? 1 : 0};
+                yx_batch.c[j] = YxCand{d1, d3, d4};
+                any_batched = true;
+                batch_cov_norm = cov_norm;
+            }
+            else if (win == 7 && shared_x && full) launch_ssim_passes<7>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa, true);
             else if (win == 7) launch_ssim_passes<7>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa);
             else if (win == 5) launch_ssim_passes<5>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa);
             else launch_ssim_passes<3>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa);
             scored[j] = true;
+        }
+        if (any_batched) {
+            hipLaunchKernelGGL(ssim_first_pass_batch_kernel<7>, dim3(kStatBlocks, nb), dim3(256), 0, c->stream, im0, S, first_batch, pmax, phasnan);
+            hipLaunchKernelGGL(ssim_yx_batch_kernel<7>, dim3(kStatBlocks, nb), dim3(256), 0, c->stream, yx_batch, setB[2], setB[3], S, batch_cov_norm, C1, C2, psum);
         }
         RegionStats h_rs[kMaxResident];
         bool any = false;
