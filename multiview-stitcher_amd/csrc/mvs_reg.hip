@@ -552,6 +552,33 @@ __global__ void bin_mean_kernel(const T* __restrict__ in, long long sz, long lon
         out[i] = (T)m;   // astype: truncation for integer dtypes
     }
 }
+// uint16, bin 2 along x, rows 16-byte aligned: a thread produces 4 consecutive outputs of a row from one 16-byte load per
+// input row (the generic kernel reads element by element: 1.3 TB/s on a 512^3 tile).  Integer sums are exact in double,
+// so the order of the additions does not matter and the result equals the generic kernel's.
+__global__ __launch_bounds__(256) void bin_mean_u16x2_kernel(const unsigned short* __restrict__ in, long long sz, long long sy,
+                                                             unsigned short* __restrict__ out, int oz, int oy, int ox, int bz, int by) {
+    const int gx = ox >> 2;                                   // groups of 4 outputs per row (ox % 4 == 0)
+    const long long ngroups = (long long)oz * oy * gx;
+    const double inv = 1.0 / ((double)bz * by * 2);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (long long)gridDim.x * blockDim.x) {
+        const int xg = (int)(g % gx);
+        const long long t = g / gx;
+        const int y = (int)(t % oy), z = (int)(t / oy);
+        unsigned int acc[4] = {0u, 0u, 0u, 0u};               // at most 2 * by * bz * 65535: fits for by * bz <= 32767
+        for (int dz = 0; dz < bz; ++dz)
+            for (int dy = 0; dy < by; ++dy) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(in + (long long)(z * bz + dz) * sz + (long long)(y * by + dy) * sy + (long long)xg * 8);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] += (v[k] & 0xffffu) + (v[k] >> 16);
+            }
+        unsigned short r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = (unsigned short)((double)acc[k] * inv);   // astype: truncation
+        *reinterpret_cast<uint2*>(out + ((long long)z * oy + y) * ox + (long long)xg * 4) =
+            make_uint2((unsigned int)r[0] | ((unsigned int)r[1] << 16), (unsigned int)r[2] | ((unsigned int)r[3] << 16));
+    }
+}
 }  // namespace
 
 extern "C" int mvs_bin_mean(int device, const void* in, int32_t dtype, int32_t mem, const int64_t shape[3],
@@ -590,6 +617,12 @@ extern "C" int mvs_bin_mean(int device, const void* in, int32_t dtype, int32_t m
     const int gb = grid_for(n);
 #define MVS_BIN(T) hipLaunchKernelGGL(bin_mean_kernel<T>, dim3(gb), dim3(256), 0, c->stream, (const T*)din, sz, sy, (T*)dout, \
                                       o[0], o[1], o[2], (int)bin[0], (int)bin[1], (int)bin[2])
+    const bool vec_u16 = dtype == MVS_U16 && bin[2] == 2 && o[2] % 4 == 0 && sy % 8 == 0 && sz % 8 == 0 && ((uintptr_t)din % 16) == 0 &&
+                         ((uintptr_t)dout % 8) == 0 && bin[0] * bin[1] <= 16384;
+    if (vec_u16) {
+        hipLaunchKernelGGL(bin_mean_u16x2_kernel, dim3(grid_for(n / 4)), dim3(256), 0, c->stream, (const unsigned short*)din, sz, sy,
+                           (unsigned short*)dout, o[0], o[1], o[2], (int)bin[0], (int)bin[1]);
+    } else
     switch (dtype) {
         case MVS_U8: MVS_BIN(unsigned char); break;
         case MVS_U16: MVS_BIN(unsigned short); break;

@@ -316,3 +316,28 @@ def test_register_crops_shortcuts_for_finite_crops_change_nothing(hip_device):
         assert st0 == st1 == 0 and nc0 == nc1
         np.testing.assert_array_equal(t0, t1)
         assert q0 == q1
+
+
+@pytest.mark.parametrize("shape,bins", [((16, 64, 128), (2, 2, 2)), ((9, 33, 64), (1, 2, 2)), ((12, 20, 72), (3, 1, 2)), ((8, 30, 50), (2, 2, 2)),
+                                        ((6, 24, 40), (2, 2, 1)), ((64, 96), (2, 2)), ((10, 16, 24), (2, 3, 4))])
+def test_bin_mean_matches_numpy(hip_device, shape, bins):
+    """coarsen(bins, boundary="trim").mean().astype(dtype) (registration.py:1732-1741): the vectorised uint16 kernel (bin 2 along x,
+    aligned rows) and the generic one against numpy, host and device (strided window) inputs."""
+    from multiview_stitcher_amd import _reg_ops
+    from multiview_stitcher_amd.device import DeviceArray
+
+    rng = np.random.default_rng(4)
+    for dtype in (np.uint16, np.uint8, np.float32):
+        a = (rng.random(shape) * (60000 if dtype == np.uint16 else 250)).astype(dtype)
+        sl = tuple(slice(0, (n // b) * b) for n, b in zip(shape, bins))
+        shp = []
+        for n, b in zip(shape, bins):
+            shp += [n // b, b]
+        want = a[sl].reshape(shp).mean(axis=tuple(range(1, 2 * len(shape), 2))).astype(dtype)
+        got = _reg_ops.bin_mean(a, list(bins))
+        if dtype == np.float32:
+            np.testing.assert_allclose(got, want, rtol=1e-6)
+        else:
+            np.testing.assert_array_equal(got, want)
+        d = DeviceArray.from_host(a, 0)
+        np.testing.assert_array_equal(_reg_ops.bin_mean(d, list(bins)).get(), got)
