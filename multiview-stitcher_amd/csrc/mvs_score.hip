@@ -375,37 +375,6 @@ __global__ __launch_bounds__(256) void ssim_first_pass_batch_kernel(const float*
     else ssim_first_pass_body<WIN, false, 2>(im0, C.src, S, 0, 0, 0, S, 0, P, pm, ph, C.T);
 }
 
-// middle pass (3D only): the five arrays filtered along y
-template <int WIN>
-__global__ __launch_bounds__(256) void ssim_mid_pass_kernel(Five P, Shape3 R) {
-    constexpr int H = WIN / 2, NL = kChunk + 2 * H;
-    const int len = R.ny;
-    const int nchunks = (len + kChunk - 1) / kChunk;
-    const unsigned int items = (unsigned int)nchunks * (unsigned int)R.nz * (unsigned int)R.nx;
-    for (unsigned int w = blockIdx.x * blockDim.x + threadIdx.x; w < items; w += gridDim.x * blockDim.x) {
-        const int x = (int)(w % (unsigned int)R.nx);
-        const unsigned int t = w / (unsigned int)R.nx;
-        const int p0 = (int)(t % (unsigned int)nchunks) * kChunk, z = (int)(t / (unsigned int)nchunks);
-        const int base = z * R.ny * R.nx + x;
-        int off[NL];
-#pragma unroll
-        for (int k = 0; k < NL; ++k) off[k] = base + reflect_index(p0 - H + k, len) * R.nx;
-#pragma unroll
-        for (int a = 0; a < 5; ++a) {
-            float v[NL];
-#pragma unroll
-            for (int k = 0; k < NL; ++k) v[k] = P.src[a][off[k]];
-            float f[kChunk];
-            box_means<WIN, kChunk>(v, f);
-#pragma unroll
-            for (int k = 0; k < kChunk; ++k) {
-                if (p0 + k >= len) break;
-                P.dst[a][base + (p0 + k) * R.nx] = f[k];
-            }
-        }
-    }
-}
-
 // last pass (x axis) + SSIM map + sum over the cropped interior (float32 map, float64 mean like skimage)
 template <int WIN>
 __global__ __launch_bounds__(256) void ssim_last_pass_kernel(Five P, Shape3 R, int ndim, float cov_norm, float C1, float C2,
