@@ -341,3 +341,29 @@ def test_bin_mean_matches_numpy(hip_device, shape, bins):
             np.testing.assert_array_equal(got, want)
         d = DeviceArray.from_host(a, 0)
         np.testing.assert_array_equal(_reg_ops.bin_mean(d, list(bins)).get(), got)
+
+
+def test_many_candidates_span_several_batches(hip_device):
+    """More candidates than one batch holds (16): the fixed image's shared SSIM terms are computed once, the batched z / y-x
+    launches run per batch, the winner of a later batch is re-shifted for the rank correlation.  Same bits as the plain path."""
+    from multiview_stitcher_amd import _lib, _reg_ops
+
+    rng = np.random.default_rng(9)
+    shape = (18, 40, 44)
+    a = rng.random(shape).astype(np.float32)
+    b = np.roll(a, (1, -2, 3), axis=(0, 1, 2)) + 0.01 * rng.random(shape).astype(np.float32)
+    cands = [(dz, dy, dx) for dz in (-1, 0, 1.5) for dy in (-2, 0, 2) for dx in (-3, 0.5, 3)] + [(-1, 2, -3), (1, -2, 3)]
+    assert len(cands) > 16
+    dr = float(max(a.max(), b.max()) - min(a.min(), b.min()))
+    res = []
+    for flag in (1, 0):
+        _lib.set_option("materialize_shifts", flag)
+        try:
+            res.append(_reg_ops.score_candidates(a, b, np.array(cands, dtype=np.float64), "union", dr, float(b.min()), quality_for_all=False))
+        finally:
+            _lib.set_option("materialize_shifts", 0)
+    for x, y in zip(res[0], res[1]):
+        np.testing.assert_array_equal(x, y)
+    ssim, spear, codes = res[1]
+    best = int(np.nanargmax(np.where(codes == 0, ssim, -np.inf)))
+    assert tuple(cands[best]) == (1, -2, 3) and np.isfinite(spear[best]) and np.isnan(spear).sum() == (codes == 0).sum() - 1
