@@ -35,6 +35,7 @@ struct MvsContext {
     bool timing_valid = false;
     int ablate = 0;               // profiling only (see FuseParams)
     bool force_generic = false;   // debug/test switch: never take the translation fast path
+    const float* raw_u16_keys[2] = {nullptr, nullptr};   // set by mvs_register_crops: integer-valued originals of the two crops (16-bit rank keys)
     bool both_crops_finite = false;    // set by mvs_register_crops around its mvs_score_candidates call (under the context lock)
     bool materialize_shifts = false;   // test switch: candidate scoring always writes the shifted copies (no on-the-fly SSIM z pass)
     std::recursive_mutex mu;      // recursive: composite entry points (mvs_pair.hip) call the public ones under the lock

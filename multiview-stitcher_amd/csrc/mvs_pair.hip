@@ -12,7 +12,7 @@
 #include "mvs_internal.h"
 
 int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, long long n, float* out0, float* out1,
-                            float mn[2], float mx[2], long long nvalid[2]);   // mvs_reg.hip
+                            float mn[2], float mx[2], long long nvalid[2], long long n_not_u16[2]);   // mvs_reg.hip
 
 #include <algorithm>
 #include <cmath>
@@ -44,12 +44,18 @@ extern "C" int mvs_register_crops(int device, const float* fixed, const float* m
     if (!r0 || !r1) return MVS_ERR_HIP;
     float min0, max0, min1, max1;
     int64_t nv0, nv1;
+    const float* raw_keys0 = nullptr;
+    const float* raw_keys1 = nullptr;
     if (mem == MVS_MEM_DEVICE) {      // one host round trip for both crops
         MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
         float mn[2], mx[2];
-        long long nv[2];
-        rc = mvs_rescale_pair_device(c, fixed, moving, n, r0, r1, mn, mx, nv);
+        long long nv[2], not_u16[2];
+        rc = mvs_rescale_pair_device(c, fixed, moving, n, r0, r1, mn, mx, nv, not_u16);
         if (rc) return rc;
+        // crops of integer tiles on the fixed grid hold 16-bit integers: rescaling is strictly increasing and one-to-one on them,
+        // so the rank order (and every tie) of the rescaled image equals that of the raw integers -> 16-bit sort keys
+        raw_keys0 = (not_u16[0] == 0) ? fixed : nullptr;
+        raw_keys1 = (not_u16[1] == 0) ? moving : nullptr;
         min0 = mn[0]; max0 = mx[0]; nv0 = nv[0];
         min1 = mn[1]; max1 = mx[1]; nv1 = nv[1];
     } else {
@@ -141,9 +147,12 @@ extern "C" int mvs_register_crops(int device, const float* fixed, const float* m
     // rescaled crops are finite iff the inputs were: no NaN (all voxels counted) and finite extrema (no inf)
     c->both_crops_finite = !has_nan && std::isfinite(min0) && std::isfinite(max0) && std::isfinite(min1) && std::isfinite(max1) &&
                            !c->materialize_shifts;
+    c->raw_u16_keys[0] = c->materialize_shifts ? nullptr : raw_keys0;
+    c->raw_u16_keys[1] = c->materialize_shifts ? nullptr : raw_keys1;
     rc = mvs_score_candidates(device, r0, r1, MVS_MEM_DEVICE, ndim, shape, uniq.data(), n_uniq, region_mode, (double)data_range, im1_min, 0,
                               ssim_u.data(), spear_u.data(), code_u.data());
     c->both_crops_finite = false;
+    c->raw_u16_keys[0] = c->raw_u16_keys[1] = nullptr;
     if (rc) return rc;
 
     // ---- metric lists as the reference builds them (code 2 appends nothing), nanargmax, Q3 indexing ----

@@ -164,7 +164,12 @@ __global__ __launch_bounds__(256) void nanminmax_kernel(const float* __restrict_
     long long nv = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float v = a[i];
-        if (v == v) { mn = fminf(mn, v); mx = fmaxf(mx, v); ++nv; }
+        if (v == v) {
+            mn = fminf(mn, v); mx = fmaxf(mx, v); ++nv;
+            // upper half of the count: valid voxels that are NOT integers in [0, 65535] (an image of such integers can be rank-
+            // ordered by 16-bit keys, see mvs_score.hip)
+            if (!(v >= 0.f && v <= 65535.f && v == floorf(v))) nv += 1ll << 32;
+        }
     }
     for (int off = 32; off > 0; off >>= 1) {
         mn = fminf(mn, __shfl_down(mn, off));
@@ -224,6 +229,7 @@ int mvs_device_nanminmax(MvsContext* c, const float* d_in, long long n, float* m
     float a = INFINITY, b = -INFINITY;
     long long v = 0;
     for (int i = 0; i < nb; ++i) { a = std::min(a, hmin[i]); b = std::max(b, hmax[i]); v += hval[i]; }
+    v &= 0xffffffffll;      // the upper half counts voxels that are not 16-bit integers (used by mvs_rescale_pair_device only)
     if (v == 0) { a = NAN; b = NAN; }
     *mn = a; *mx = b; *nvalid = v;
     return MVS_OK;
@@ -233,7 +239,7 @@ int mvs_device_nanminmax(MvsContext* c, const float* d_in, long long n, float* m
 // queued together, their partials come back in one copy, then the two rescale kernels follow.  Same kernels and
 // arithmetic as two mvs_rescale_intensity calls.
 int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, long long n, float* out0, float* out1,
-                            float mn[2], float mx[2], long long nvalid[2]) {
+                            float mn[2], float mx[2], long long nvalid[2], long long n_not_u16[2]) {
     const int nb = grid_for(n);
     char* scratch = (char*)mvs_scratch(c, 3, (size_t)nb * 32);
     if (!scratch) return MVS_ERR_HIP;
@@ -256,6 +262,8 @@ int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, l
         float a = INFINITY, b = -INFINITY;
         long long v = 0;
         for (int i = 0; i < nb; ++i) { a = std::min(a, hmin[i]); b = std::max(b, hmax[i]); v += hval[i]; }
+        n_not_u16[k] = v >> 32;
+        v &= 0xffffffffll;
         if (v == 0) { a = NAN; b = NAN; }
         mn[k] = a; mx[k] = b; nvalid[k] = v;
         hipLaunchKernelGGL(rescale_kernel, dim3(nb), dim3(256), 0, c->stream, ins[k], outs[k], n, a, b, a == b ? 1 : 0);

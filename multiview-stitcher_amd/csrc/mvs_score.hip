@@ -549,9 +549,11 @@ __global__ __launch_bounds__(256) void finish_region_kernel(const float* __restr
 // ---- Spearman: compaction of the jointly valid voxels, two chained radix sorts, rank correlation ------------
 // kx = im0[mask], ky = im1t[mask] - 1 (float32, like the reference).  Each thread takes 8 consecutive voxels; a
 // workgroup reserves its output range with ONE atomic (the order of the pairs is irrelevant to a rank correlation).
+// raw0 != nullptr: the fixed image's sort key is its integer-valued original (< 65536) stored as uint32 -- same order and
+// ties as the rescaled value (the rescaling is strictly increasing and one-to-one on integers), a 2-pass radix sort instead of 4.
 __global__ __launch_bounds__(256) void compact_kernel(const float* __restrict__ im0, const float* __restrict__ im1t, long long n,
                                                       float* __restrict__ kx, float* __restrict__ ky,
-                                                      unsigned int* __restrict__ counter) {
+                                                      unsigned int* __restrict__ counter, const float* __restrict__ raw0) {
     constexpr int K = 8;
     __shared__ unsigned int s_wave[4];
     __shared__ unsigned int s_base;
@@ -584,7 +586,8 @@ __global__ __launch_bounds__(256) void compact_kernel(const float* __restrict__ 
 #pragma unroll
         for (int k = 0; k < K; ++k)
             if (a[k] == a[k] && b[k] == b[k]) {
-                kx[p] = a[k];
+                if (raw0) reinterpret_cast<unsigned int*>(kx)[p] = (unsigned int)raw0[i0 + k];
+                else kx[p] = a[k];
                 ky[p] = b[k] - 1.0f;
                 ++p;
             }
@@ -602,22 +605,23 @@ __global__ __launch_bounds__(256) void compact_kernel(const float* __restrict__ 
 // galloping search per element (~20 dependent loads each on the long runs of quantised image data).
 constexpr int kRankItems = 8, kRankChunk = 256 * kRankItems;
 
-__device__ __forceinline__ void chunk_average_ranks(const float* __restrict__ sorted, unsigned int n, unsigned int chunk0,
+template <typename K>
+__device__ __forceinline__ void chunk_average_ranks(const K* __restrict__ sorted, unsigned int n, unsigned int chunk0,
                                                     float (&rank)[kRankItems], bool (&valid)[kRankItems]) {
     __shared__ unsigned int s_first[4], s_last[4], s_edge[2];
     const unsigned int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned int base = chunk0 + tid * kRankItems;
     const unsigned int chunk_end = min(chunk0 + (unsigned int)kRankChunk, n);   // exclusive
-    float k[kRankItems + 2];                                                      // k[0] = left neighbour, k[9] = right neighbour
+    K k[kRankItems + 2];                                                      // k[0] = left neighbour, k[9] = right neighbour
 #pragma unroll
     for (int j = 0; j < kRankItems + 2; ++j) {
         const long long idx = (long long)base + j - 1;
-        k[j] = (idx >= 0 && idx < (long long)n) ? sorted[idx] : 0.f;
+        k[j] = (idx >= 0 && idx < (long long)n) ? sorted[idx] : (K)0;
     }
     if (tid == 0) {   // run entering the chunk from the left: its first index (galloping backwards), else the chunk start
         unsigned int first = chunk0;
         if (chunk0 > 0 && chunk0 < n && sorted[chunk0 - 1] == sorted[chunk0]) {
-            const float key = sorted[chunk0];
+            const K key = sorted[chunk0];
             unsigned int pos = chunk0, step = 1;
             while (pos >= step && sorted[pos - step] == key) { pos -= step; step <<= 1; }
             unsigned int lo = pos >= step ? pos - step + 1 : 0, hi = pos;
@@ -629,7 +633,7 @@ __device__ __forceinline__ void chunk_average_ranks(const float* __restrict__ so
     if (tid == 64) {  // run leaving the chunk on the right: its exclusive end (galloping forwards)
         unsigned int last = chunk_end;
         if (chunk_end < n && chunk_end > 0 && sorted[chunk_end] == sorted[chunk_end - 1]) {
-            const float key = sorted[chunk_end - 1];
+            const K key = sorted[chunk_end - 1];
             unsigned int pos = chunk_end - 1, step = 1;
             while (pos + step < n && sorted[pos + step] == key) { pos += step; step <<= 1; }
             unsigned int lo = pos + 1, hi = min(pos + step, n);
@@ -689,7 +693,8 @@ __device__ __forceinline__ void chunk_average_ranks(const float* __restrict__ so
 
 // ranks of the x keys in x-sorted order (they then ride along the second sort as its payload, so nothing is
 // ever scattered back to voxel order).  Stored as float like scipy's float64 ranks rounded: exact for n < 2^24.
-__global__ __launch_bounds__(256) void ranks_sorted_kernel(const float* __restrict__ sorted, unsigned int n, float* __restrict__ rank_out) {
+template <typename K>
+__global__ __launch_bounds__(256) void ranks_sorted_kernel(const K* __restrict__ sorted, unsigned int n, float* __restrict__ rank_out) {
     const unsigned int nchunks = (n + kRankChunk - 1) / kRankChunk;
     for (unsigned int c = blockIdx.x; c < nchunks; c += gridDim.x) {
         float rank[kRankItems];
@@ -828,6 +833,12 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     size_t sort_temp_bytes = 0;
     MVS_HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, sort_temp_bytes, (float*)nullptr, (float*)nullptr, (float*)nullptr,
                                             (float*)nullptr, (size_t)n, 0, 32, c->stream));
+    {
+        size_t tb16 = 0;
+        MVS_HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tb16, (unsigned int*)nullptr, (unsigned int*)nullptr, (float*)nullptr,
+                                                (float*)nullptr, (size_t)n, 0, 16, c->stream));
+        sort_temp_bytes = std::max(sort_temp_bytes, tb16);
+    }
     const int gb = grid_for(n);
     const size_t stat_bytes = (size_t)(kMaxResident + 2) * kStatBlocks * (sizeof(VoxStats) + 4 + 4 + 8) + (kMaxResident + 2) * 64;
     // batched launches (one z pass / one y-x pass for all candidates of a batch) keep three z-filtered arrays per candidate
@@ -917,11 +928,18 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     // carrying y, ranks of x in sorted order, sort by y carrying rank(x), correlation sums in y-sorted order
     auto spearman_from = [&](int ic, const float* im1t) -> int {
         MVS_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 4, c->stream));
-        hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, c->stream, im0, im1t, n, setA[0], setA[1], d_counter);
+        const float* raw0 = c->raw_u16_keys[0];      // 16-bit integer keys for the fixed image when the caller vouches for them
+        hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, c->stream, im0, im1t, n, setA[0], setA[1], d_counter, raw0);
         const unsigned int m = (unsigned int)cnts[ic];
-        MVS_HIP_TRY(c, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, setA[0], setA[2], setA[1], setA[3], (size_t)m, 0, 32, c->stream));
         const int mgb = (int)std::min<long long>(((long long)m + kRankChunk - 1) / kRankChunk, 2048);   // one chunk of sorted keys per workgroup turn
-        hipLaunchKernelGGL(ranks_sorted_kernel, dim3(mgb), dim3(256), 0, c->stream, setA[2], m, setA[4]);
+        if (raw0) {
+            MVS_HIP_TRY(c, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, (unsigned int*)setA[0], (unsigned int*)setA[2], setA[1], setA[3], (size_t)m,
+                                                    0, 16, c->stream));
+            hipLaunchKernelGGL(ranks_sorted_kernel<unsigned int>, dim3(mgb), dim3(256), 0, c->stream, (const unsigned int*)setA[2], m, setA[4]);
+        } else {
+            MVS_HIP_TRY(c, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, setA[0], setA[2], setA[1], setA[3], (size_t)m, 0, 32, c->stream));
+            hipLaunchKernelGGL(ranks_sorted_kernel<float>, dim3(mgb), dim3(256), 0, c->stream, setA[2], m, setA[4]);
+        }
         MVS_HIP_TRY(c, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, setA[3], setB[0], setA[4], setB[1], (size_t)m, 0, 32, c->stream));
         hipLaunchKernelGGL(rankcorr_kernel, dim3(mgb), dim3(256), 0, c->stream, setB[0], setB[1], m, 0.5 * ((double)m + 1.0), partial);
         std::vector<double> hp((size_t)mgb * 3);

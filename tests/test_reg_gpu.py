@@ -303,8 +303,16 @@ def test_register_crops_shortcuts_for_finite_crops_change_nothing(hip_device):
     valid boxes, on-the-fly integer shifts); "materialize_shifts" switches all of them off.  Same translation, same quality."""
     from multiview_stitcher_amd import _lib, _reg_ops
 
-    for shape, shift, up in [((24, 40, 36), (2, -3, 4), 2), ((51, 64, 48), (-1, 2, 3), 2), ((96, 80), (5, -7), 10)]:
+    cases = [((24, 40, 36), (2, -3, 4), 2, False), ((51, 64, 48), (-1, 2, 3), 2, False), ((96, 80), (5, -7), 10, False),
+             # integer-valued crops (uint16 tiles on the fixed grid): 16-bit rank keys for the fixed image; the last one with NaNs
+             ((24, 40, 36), (2, -3, 4), 2, True), ((40, 72, 30), (0, 1, -2), 2, True), ((20, 48, 40), (1, 2, 0), 2, "nan")]
+    for shape, shift, up, integer in cases:
         a, b = _pair(shape, shift, noise=0.002)
+        if integer:
+            a, b = np.round(a * 3000).astype(np.float32), np.round(b * 3000).astype(np.float32)
+            if integer == "nan":
+                a[:, :3] = np.nan
+                b[..., -2:] = np.nan
         res = []
         for flag in (1, 0):
             _lib.set_option("materialize_shifts", flag)
