@@ -100,7 +100,9 @@ int mvs_synchronize(int device);
  * (default 32768; 0 = release immediately).  "materialize_shifts" = 1: mvs_score_candidates / mvs_register_crops
  * always write the shifted copies of the moving image (by default finite-only crops evaluate them inside the SSIM z
  * pass; both ways must agree bit for bit) and mvs_phasecorr_multi runs one inverse transform per normalisation (by default
- * two normalisations share one); tests compare the plain and the default paths. */
+ * two normalisations share one); tests compare the plain and the default paths.  "serial_classes" = 1: the class kernels of
+ * the translation fast path of mvs_fuse_chunk run one after the other on the context's stream (default: side by side on
+ * side streams, joined before the call's work is considered done). */
 int mvs_set_option(int device, const char* key, int64_t value);
 /* Device time (ms, hipEvent) spent in the kernels of the most recent compute
  * call on this device; blocks until that work has finished. */

@@ -160,6 +160,8 @@ void mvs_shutdown(int device) {
     c->pinned_cap = c->pinned2_cap = 0;
     hipEventDestroy(c->ev_start);
     hipEventDestroy(c->ev_stop);
+    for (int a = 0; a < 4; ++a) { if (c->aux_stream[a]) hipStreamDestroy(c->aux_stream[a]); if (c->ev_join[a]) hipEventDestroy(c->ev_join[a]); c->aux_stream[a] = nullptr; c->ev_join[a] = nullptr; }
+    if (c->ev_fork) { hipEventDestroy(c->ev_fork); c->ev_fork = nullptr; }
     hipEventDestroy(c->pinned_ev[0]);
     hipEventDestroy(c->pinned_ev[1]);
     c->pinned_pending[0] = c->pinned_pending[1] = false;
@@ -207,6 +209,10 @@ int mvs_set_option(int device, const char* key, int64_t value) {
     }
     if (!strcmp(key, "no_regions")) {
         c->no_regions = value != 0;
+        return MVS_OK;
+    }
+    if (!strcmp(key, "serial_classes")) {
+        c->serial_classes = value != 0;
         return MVS_OK;
     }
     if (!strcmp(key, "materialize_shifts")) {

@@ -1076,17 +1076,37 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
     P.oz = o[0]; P.oy = o[1]; P.ox = o[2];
     P.tz = t[0]; P.ty = t[1]; P.tx = t[2];
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));   // kernel time only (the plan is host work, cached per geometry)
+    // The five class kernels write disjoint voxels and have different bottlenecks (the copy class is bound by memory, the
+    // NV = 4 / 8 classes by their weight arithmetic): they run side by side -- NV = 2, the largest, on the main stream, the
+    // others on side streams that start after everything queued so far (fork event) and are waited for at the end (join).
+    const bool fork = !c->serial_classes;
+    if (fork && !c->ev_fork) {
+        MVS_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for (int a = 0; a < 4; ++a) {
+            MVS_HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream[a], hipStreamNonBlocking));
+            MVS_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming));
+        }
+    }
+    if (fork) MVS_HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+    const int side_of_class[5] = {0, -1, 1, 2, 3};          // class -> side stream (-1: main)
+    bool side_used[4] = {false, false, false, false};
     int item0 = 0;
     for (int k = 0; k < 5; ++k) {
         const int cnt = pc.class_count[k];
+        hipStream_t kstream = c->stream;
+        if (fork && cnt && side_of_class[k] >= 0) {
+            kstream = c->aux_stream[side_of_class[k]];
+            side_used[side_of_class[k]] = true;
+            MVS_HIP_TRY(c, hipStreamWaitEvent(kstream, c->ev_fork, 0));
+        }
         if (cnt && k == 4) {
             const dim3 grid(((cnt + 3) / 4 + 7) / 8 * 8), block(256);   // multiple of 8: see the XCD mapping in the kernels
-            if (dtype == MVS_U8) hipLaunchKernelGGL((copy_region_kernel<unsigned char, unsigned char>), grid, block, 0, c->stream, P, item0, cnt);
-            else if (dtype == MVS_U16) hipLaunchKernelGGL((copy_region_kernel<unsigned short, unsigned short>), grid, block, 0, c->stream, P, item0, cnt);
-            else hipLaunchKernelGGL((copy_region_kernel<float, float>), grid, block, 0, c->stream, P, item0, cnt);
+            if (dtype == MVS_U8) hipLaunchKernelGGL((copy_region_kernel<unsigned char, unsigned char>), grid, block, 0, kstream, P, item0, cnt);
+            else if (dtype == MVS_U16) hipLaunchKernelGGL((copy_region_kernel<unsigned short, unsigned short>), grid, block, 0, kstream, P, item0, cnt);
+            else hipLaunchKernelGGL((copy_region_kernel<float, float>), grid, block, 0, kstream, P, item0, cnt);
         } else if (cnt) {
             const dim3 grid(((cnt + 3) / 4 + 7) / 8 * 8), block(256);   // multiple of 8: see the XCD mapping in the kernels
-#define MVS_RK(T, NVC) hipLaunchKernelGGL((fuse_region_kernel<T, T, NVC>), grid, block, 0, c->stream, P, item0, cnt)
+#define MVS_RK(T, NVC) hipLaunchKernelGGL((fuse_region_kernel<T, T, NVC>), grid, block, 0, kstream, P, item0, cnt)
 #define MVS_RKD(NVC) do { if (dtype == MVS_U8) MVS_RK(unsigned char, NVC); else if (dtype == MVS_U16) MVS_RK(unsigned short, NVC); else MVS_RK(float, NVC); } while (0)
             if (k == 0) MVS_RKD(1); else if (k == 1) MVS_RKD(2); else if (k == 2) MVS_RKD(4); else MVS_RKD(8);
 #undef MVS_RKD
@@ -1095,6 +1115,11 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
         item0 += cnt;
     }
     MVS_HIP_TRY(c, hipGetLastError());
+    for (int a = 0; a < 4; ++a)
+        if (side_used[a]) {
+            MVS_HIP_TRY(c, hipEventRecord(c->ev_join[a], c->aux_stream[a]));
+            MVS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join[a], 0));
+        }
     *done = true;
     return MVS_OK;
 }

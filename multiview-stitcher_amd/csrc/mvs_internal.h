@@ -36,6 +36,10 @@ struct MvsContext {
     int ablate = 0;               // profiling only (see FuseParams)
     bool force_generic = false;   // debug/test switch: never take the translation fast path
     const float* raw_u16_keys[2] = {nullptr, nullptr};   // set by mvs_register_crops: integer-valued originals of the two crops (16-bit rank keys)
+    // the class kernels of one fuse launch run on side streams next to the main one (fork / join by events)
+    hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool serial_classes = false;       // option "serial_classes": launch them one after the other on the main stream instead
     bool both_crops_finite = false;    // set by mvs_register_crops around its mvs_score_candidates call (under the context lock)
     bool materialize_shifts = false;   // test switch: candidate scoring always writes the shifted copies (no on-the-fly SSIM z pass)
     std::recursive_mutex mu;      // recursive: composite entry points (mvs_pair.hip) call the public ones under the lock

@@ -31,6 +31,7 @@ for idx in np.ndindex(*grid):
     sims.append(sim)
 torch.cuda.synchronize()
 _lib.set_option("ablate", int(os.environ.get("MVS_ABLATE", "0")))
+_lib.set_option("serial_classes", int(os.environ.get("MVS_SERIAL", "0")))   # 1: class kernels one after the other (A/B of the side streams)
 ms = []
 for _ in range(reps):
     out = fusion.fuse(sims, transform_key="k", output_chunksize={d: 1 << 30 for d in "zyx"}, output_on_backend=True, device=0)
