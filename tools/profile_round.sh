@@ -8,7 +8,8 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 rm -rf $O/prof_bench $O/pmc_*
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/prof_bench.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_bench.log 2>&1
+python $R/tools/fuse_window.py $(find $O/prof_bench -name "*kernel_trace.csv") > $O/prof_bench/fuse_launch_windows.csv
 find $O/prof_bench -name "*kernel_trace.csv" -delete; find $O/prof_bench -name "*.db" -delete
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-include-regex "fuse|copy_region" --pmc $c --output-format csv -d $O/pmc_int_$c -- python $R/tools/fuse_probe.py 2 0 > $O/pmc_int_$c.log 2>&1
@@ -18,3 +19,4 @@ done
 for d in int frac cal; do for c in FETCH_SIZE WRITE_SIZE; do echo "== $d $c"; grep -h "kernel ms" $O/pmc_${d}_$c.log; python $R/tools/pmc_summary.py $(find $O/pmc_${d}_$c -name "*counter_collection.csv"); done; done
 tail -1 $O/prof_bench.log
 python $R/tools/kstats.py $(find $O/prof_bench -name "*kernel_stats.csv") 30
+cat $O/prof_bench/fuse_launch_windows.csv
