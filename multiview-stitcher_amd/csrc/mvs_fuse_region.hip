@@ -1075,18 +1075,18 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
     P.out = dout;
     P.oz = o[0]; P.oy = o[1]; P.ox = o[2];
     P.tz = t[0]; P.ty = t[1]; P.tx = t[2];
-    MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));   // kernel time only (the plan is host work, cached per geometry)
     // The five class kernels write disjoint voxels and have different bottlenecks (the copy class is bound by memory, the
     // NV = 4 / 8 classes by their weight arithmetic): they run side by side -- NV = 2, the largest, on the main stream, the
     // others on side streams that start after everything queued so far (fork event) and are waited for at the end (join).
     const bool fork = !c->serial_classes;
-    if (fork && !c->ev_fork) {
+    if (fork && !c->ev_fork) {      // once per context (tens of ms: outside the timed section)
         MVS_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         for (int a = 0; a < 4; ++a) {
             MVS_HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream[a], hipStreamNonBlocking));
             MVS_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming));
         }
     }
+    MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));   // kernel time only (the plan is host work, cached per geometry)
     if (fork) MVS_HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
     const int side_of_class[5] = {0, -1, 1, 2, 3};          // class -> side stream (-1: main)
     bool side_used[4] = {false, false, false, false};
