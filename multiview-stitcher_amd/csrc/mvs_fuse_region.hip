@@ -1081,8 +1081,12 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
     const bool fork = !c->serial_classes;
     if (fork && !c->ev_fork) {      // once per context (tens of ms: outside the timed section)
         MVS_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        int prio_lo = 0, prio_hi = 0;
+        hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         for (int a = 0; a < 4; ++a) {
-            MVS_HIP_TRY(c, hipStreamCreateWithFlags(&c->aux_stream[a], hipStreamNonBlocking));
+            // lowest priority: the NV = 2 class on the main stream is the longest of the five and ends the launch, the others
+            // fill in around it (11.7 -> 11.3 ms on the jittered mosaic against equal priorities)
+            MVS_HIP_TRY(c, hipStreamCreateWithPriority(&c->aux_stream[a], hipStreamNonBlocking, prio_lo));
             MVS_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming));
         }
     }
