@@ -287,7 +287,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fuse launch = copy_region_kernel + fuse_region_kernel<1|2|4|8> (u16), timed as one unit",
+                "kernel": "fuse launch = copy_region_kernel + fuse_region_kernel<1|2|4|8> (u16) side by side on forked streams, timed as one unit (first start to last end)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
