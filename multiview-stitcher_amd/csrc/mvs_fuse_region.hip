@@ -1078,7 +1078,7 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
     // The five class kernels write disjoint voxels and have different bottlenecks (the copy class is bound by memory, the
     // NV = 4 / 8 classes by their weight arithmetic): they run side by side -- NV = 2, the largest, on the main stream, the
     // others on side streams that start after everything queued so far (fork event) and are waited for at the end (join).
-    const bool fork = !c->serial_classes;
+    const bool fork = !c->serial_classes && nitems >= 4096;   // small chunks: five event round trips cost more than the overlap gains
     if (fork && !c->ev_fork) {      // once per context (tens of ms: outside the timed section)
         MVS_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         int prio_lo = 0, prio_hi = 0;
