@@ -339,6 +339,163 @@ def dispatch_pairwise_reg_func(pairwise_reg_func, fixed_data=None, moving_data=N
         return pairwise_reg_func(**pairwise_reg_func_kwargs)
 
 
+# ---- lean per-pair host path ----------------------------------------------------------------------------------------
+# The generic functions above spend ~0.45 ms of interpreter time per pair in small numpy calls, and every worker thread
+# needs the GIL for them: on the north-star mosaic that serial share (144 x 0.45 ms) is a third of the registration time
+# (adding 0.3 ms of Python per pair adds 40 ms per step).  For the common case -- views whose transform is a pure
+# translation, the built-in phase correlation -- the same steps are done here with plain Python floats, in the same
+# order of IEEE operations as the numpy expressions they replace (equality with the generic path is tested on the CPU
+# for the plan and on the GPU for the result).
+class _TileGeom:
+    """What the pair plans need of one (binned) view: its coordinate arrays as lists, origin / spacing / shape as the
+    spatial_image_utils getters derive them, and the translation of its transform."""
+
+    __slots__ = ("sim", "sdims", "coords", "origin", "spacing", "shape", "t", "affine")
+
+    def __init__(self, sim, transform_key):
+        from . import spatial_image_utils as si_utils
+
+        self.sim = sim
+        self.sdims = si_utils.get_spatial_dims_from_sim(sim)
+        self.coords = [np.asarray(sim.coords[d], dtype=np.float64).tolist() for d in self.sdims]
+        self.origin = [c[0] for c in self.coords]
+        self.spacing = [c[1] - c[0] if len(c) > 1 else 1.0 for c in self.coords]
+        self.shape = [len(c) for c in self.coords]
+        a = param_utils.select_time(np.asarray(sim.attrs["transforms"][transform_key], dtype=np.float64), 0)
+        n = len(self.sdims)
+        pure = a.shape == (n + 1, n + 1) and np.array_equal(a[:n, :n], np.eye(n)) and np.array_equal(a[n], np.eye(n + 1)[n])
+        self.t = [float(v) for v in a[:n, n]] if pure else None
+        self.affine = a
+
+
+def _lean_world_box(g, tol):
+    """world_aabb of stack props extended by ``tol`` (si_utils_extend) under a pure translation: per axis
+    (fl(o + t), fl(fl(fl((n - 1) s) + o) + t)) with o, n the extended origin / shape."""
+    lo, hi = [], []
+    for k in range(len(g.sdims)):
+        n, o, s = g.shape[k], g.origin[k], g.spacing[k]
+        if tol is not None:
+            n = n + int(np.ceil(2 * tol[k] / s))
+            o = o - tol[k]
+        lo.append(o + g.t[k])
+        hi.append(((n - 1) * 1.0 * s + o) + g.t[k])
+    return lo, hi
+
+
+def _lean_overlap(g1, g2, tol, to_intrinsic):
+    """_get_overlap_bboxes for two translated views: (lowers, uppers) per view, in each view's own frame
+    (``to_intrinsic``) or in world coordinates."""
+    lo1, hi1 = _lean_world_box(g1, tol)
+    lo2, hi2 = _lean_world_box(g2, tol)
+    lo = [max(a, b) for a, b in zip(lo1, lo2)]
+    hi = [min(a, b) for a, b in zip(hi1, hi2)]
+    if any(h < l for l, h in zip(lo, hi)):
+        return None
+    up = [1.0 * (h - l) + l for l, h in zip(lo, hi)]            # the far corner as the generic path builds it: gv * (hi - lo) + lo
+    if not to_intrinsic:
+        return [lo, lo], [up, up]
+    lowers = [[l + (-t) for l, t in zip(lo, g.t)] for g in (g1, g2)]
+    uppers = [[u + (-t) for u, t in zip(up, g.t)] for g in (g1, g2)]
+    return lowers, uppers
+
+
+def _around10(x):
+    """np.around(x, 10) for a Python float: rint(x * 1e10) / 1e10 (round() is half-to-even like rint)."""
+    return round(x * 1e10) / 1e10
+
+
+def _lean_pair_plan(g1, g2, tol):
+    """Crop windows, output grid and pixel affines of one pair (steps of register_pair_of_msims /
+    sims_to_intrinsic_coord_system / get_pixel_affine for translated views).  None when the views do not overlap."""
+    import bisect
+
+    ov = _lean_overlap(g1, g2, tol, True)
+    if ov is None:
+        return None
+    lowers, uppers = ov
+    n = len(g1.sdims)
+    windows, origins, spacings = [], [], []
+    for i, g in enumerate((g1, g2)):
+        win, o, sp = [], [], []
+        for k in range(n):
+            c = g.coords[k]
+            start = lowers[i][k] - 1e-6 - g.spacing[k]
+            stop = uppers[i][k] + 1e-6 + g.spacing[k]
+            a, b = bisect.bisect_left(c, start), bisect.bisect_right(c, stop)
+            if b <= a:
+                return None
+            win.append((a, b))
+            o.append(c[a])
+            sp.append(c[a + 1] - c[a] if b - a > 1 else 1.0)
+        windows.append(win)
+        origins.append(o)
+        spacings.append(sp)
+    out_spacing = [max(a, b) for a, b in zip(spacings[0], spacings[1])]
+    out_origin = list(lowers[0])
+    out_shape = [int(np.floor((uppers[0][k] - lowers[0][k]) / out_spacing[k] + 1)) for k in range(n)]
+    t_rel = [a + (-b) for a, b in zip(g1.t, g2.t)]              # inv(A2) @ A1 for translations
+    mats, offs = [], []
+    for i in range(2):
+        tt = [0.0] * n if i == 0 else t_rel
+        m, o = [], []
+        for k in range(n):
+            m.append(_around10((1.0 * out_spacing[k]) / spacings[i][k]))
+            v = _around10(((tt[k] + 0.0) - (origins[i][k] - out_origin[k])) / spacings[i][k])
+            r = float(round(v))
+            o.append(r if abs(v - r) <= 1e-6 else v)
+        mats.append(m)
+        offs.append(o)
+    return {"windows": windows, "out_origin": out_origin, "out_spacing": out_spacing, "out_shape": out_shape,
+            "matrix_diag": mats, "offset": offs}
+
+
+def _lean_register_pair(g1b, g2b, g1, g2, sdims, tol, upsample_factor, transform_key, device):
+    """register_pair_of_msims for translated views and the built-in phase correlation, on plans made of floats."""
+    from . import spatial_image_utils as si_utils
+    from .transformation import resample_array
+
+    plan = _lean_pair_plan(g1b, g2b, tol)
+    if plan is None:
+        raise ValueError("views do not overlap")
+    n = len(sdims)
+    crops = []
+    for i, g in enumerate((g1b, g2b)):
+        data = g.sim.data[tuple(slice(a, b) for a, b in plan["windows"][i])]
+        crops.append(resample_array(data, np.diag(plan["matrix_diag"][i]), np.array(plan["offset"][i]), plan["out_shape"], 1, np.nan, device))
+    uf = (10 if n == 2 else 2) if upsample_factor is None else upsample_factor
+    t, quality, status, _ = _reg_ops.register_crops(crops[0], crops[1], uf, None, True, device)
+    if status == 2:
+        warnings.warn("An overlap region between tiles/views is all zero or constant. Assuming identity transform.", UserWarning, stacklevel=3)
+        affine, quality = param_utils.identity_transform(n), np.nan
+    elif status == 1:
+        raise RuntimeError("phase correlation produced no admissible shift candidate (registration.py:479-480)")
+    elif status == 3:
+        raise ValueError("All-NaN slice encountered")
+    else:
+        affine = param_utils.affine_from_translation([float(v) for v in t])
+    # physical affine (get_affine_from_intrinsic_affine with both transformed crops on the output grid and carrying view 1's
+    # transform): kept in numpy, its matmul / inverse chain is part of the result's rounding
+    # origin / spacing as the getters read them back from the crops' coordinate arrays (o + s * arange): c[0] and c[1] - c[0]
+    eff_spacing = [((o + sp * 1.0) - (o + sp * 0.0)) if nn > 1 else 1.0 for o, sp, nn in zip(plan["out_origin"], plan["out_spacing"], plan["out_shape"])]
+    eff_origin = [o + sp * 0.0 for o, sp in zip(plan["out_origin"], plan["out_spacing"])]
+    d_to_p = np.matmul(param_utils.affine_from_translation(np.array(eff_origin)), np.diag(eff_spacing + [1]))
+    D = np.matmul(g1b.affine, d_to_p)
+    affine_phys = np.matmul(D, np.matmul(affine, np.linalg.inv(D)))
+    lo, up = _lean_overlap(g1, g2, tol, False)
+    return {"transform": affine_phys, "quality": float(quality) if quality is not None else np.nan,
+            "bbox": np.array([lo[0], up[0]])}
+
+
+_lean_enabled = [True]      # tests switch the lean path off to compare it with the generic one
+
+
+def _geom_of(sim, transform_key, cache):
+    """_TileGeom of a view, shared by the pairs of one compute_pairwise_registrations call."""
+    if cache is None:
+        return _TileGeom(sim, transform_key)
+    return cache.get_or_compute(("geom", id(sim), transform_key), lambda: _TileGeom(sim, transform_key))
+
+
 def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=None, overlap_tolerance=None,
                            pairwise_reg_func=phase_correlation_registration, pairwise_reg_func_kwargs=None, device=0,
                            _bin_cache=None):
@@ -370,6 +527,12 @@ def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=Non
         return _bin_cache.get_or_compute(key, lambda: _bin_sim(sim, registration_binning, device))
 
     reg_sims_b = [binned(sim1), binned(sim2)]
+    if pairwise_reg_func is phase_correlation_registration and set(pairwise_reg_func_kwargs) <= {"upsample_factor"} and _lean_enabled[0] \
+            and all(list(s_.dims) == list(sdims) for s_ in (sim1, sim2)):
+        geoms = [_geom_of(s_, transform_key, _bin_cache) for s_ in (reg_sims_b[0], reg_sims_b[1], sim1, sim2)]
+        if all(g.t is not None for g in geoms):
+            return _lean_register_pair(geoms[0], geoms[1], geoms[2], geoms[3], sdims, [overlap_tolerance[d] for d in sdims],
+                                       pairwise_reg_func_kwargs.get("upsample_factor"), transform_key, device)
     ov = _get_overlap_bboxes(reg_sims_b[0], reg_sims_b[1], transform_key, None, overlap_tolerance)
     if ov is None:
         raise ValueError("views do not overlap")
