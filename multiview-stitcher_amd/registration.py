@@ -162,6 +162,11 @@ def get_optimal_registration_binning(sim1, sim2, max_total_pixels_per_stack=400*
     ndim = len(sdims)
     input_spacings = [si_utils.get_spacing_from_sim(s) for s in [sim1, sim2]]
     sh1, sh2 = si_utils.get_shape_from_sim(sim1), si_utils.get_shape_from_sim(sim2)
+    # a pure function of shapes and spacings: the pairs of a regular mosaic all share one answer
+    memo_key = (tuple(sdims), tuple(sh1[d] for d in sdims), tuple(sh2[d] for d in sdims),
+                tuple(input_spacings[0][d] for d in sdims), tuple(input_spacings[1][d] for d in sdims), max_total_pixels_per_stack)
+    if memo_key in _BINNING_MEMO:
+        return dict(_BINNING_MEMO[memo_key])
     overlap = {d: max(sh1[d], sh2[d]) for d in sdims}
     binning = {d: 1 for d in sdims}
     spacings = input_spacings
@@ -173,7 +178,13 @@ def get_optimal_registration_binning(sim1, sim2, max_total_pixels_per_stack=400*
             for d in ["x", "y"]:
                 binning[d] += 1
         spacings = [{d: input_spacings[i][d] * binning[d] for d in sdims} for i in range(2)]
+    if len(_BINNING_MEMO) > 256:
+        _BINNING_MEMO.clear()
+    _BINNING_MEMO[memo_key] = dict(binning)
     return binning
+
+
+_BINNING_MEMO = {}
 
 
 def _smoke(device=0):
