@@ -223,6 +223,15 @@ int mvs_register_crops(int device, const float* fixed, const float* moving, int3
                        int32_t constant_check, double t_out[3], double* quality_out,
                        int32_t* status_out, int32_t* n_candidates_out);
 
+/* One call per image pair == sims_to_intrinsic_coord_system + dispatch_pairwise_reg_func(phase_correlation_registration)
+ * (registration.py:280-350, 1477-1544, 353-565): both views (mvs_view_t geometry as for mvs_resample: matrix / offset map
+ * pixels of the fixed view's overlap grid to pixels of the view's slab) are resampled with order 1 and NaN outside onto
+ * out_shape (float32, library scratch) and handed to mvs_register_crops without a host round trip in between.  Outputs as
+ * mvs_register_crops. */
+int mvs_register_views(int device, const mvs_view_t* fixed_view, const mvs_view_t* moving_view, int32_t ndim,
+                       const int64_t out_shape[3], int32_t upsample_factor, int32_t region_mode, int32_t constant_check,
+                       double t_out[3], double* quality_out, int32_t* status_out, int32_t* n_candidates_out);
+
 /* Host-only (no device, no mvs_init needed): the inner loop of the reference's global optimisation for the translation
  * model -- optimize_bead_subgraph, param_resolution/global_optimization.py:313-417 with transforms.py:45-53 as estimator.
  * Edge e joins nodes edge_nodes[2e], edge_nodes[2e+1] and carries n_beads virtual beads in each node's frame

@@ -99,6 +99,11 @@ SIGNATURES = {
         [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
          C.c_void_p, C.c_int32],
     ),
+    "mvs_register_views": (
+        C.c_int,
+        [C.c_int, C.POINTER(mvs_view_t), C.POINTER(mvs_view_t), C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32,
+         C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    ),
     "mvs_beads_translation_sweeps": (
         C.c_int,
         [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,

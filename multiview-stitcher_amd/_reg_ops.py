@@ -125,6 +125,46 @@ def register_crops(im0, im1, upsample_factor, region_mode=None, constant_check=F
     return np.array(list(t)[3 - ndim:], dtype=np.float64), float(q.value), int(status.value), int(ncand.value)
 
 
+def register_views(data0, matrix0, offset0, data1, matrix1, offset1, out_shape, upsample_factor, region_mode=None, constant_check=False,
+                   device=0):
+    """Resample both overlap crops and register them in one library call (mvs_register_views).  ``data*``: DeviceArray slabs
+    (strided windows allowed), ``matrix*`` (diagonal given as a list) / ``offset*``: the pixel affines of
+    transformation.get_pixel_affine, ``out_shape``: the fixed view's overlap grid.  Returns like ``register_crops``."""
+    from .transformation import shape3
+
+    lib = _lib.init(device)
+    ndim = len(out_shape)
+    views = (_lib.mvs_view_t * 2)()
+    for v, data, mdiag, off in ((views[0], data0, matrix0, offset0), (views[1], data1, matrix1, offset1)):
+        if not is_device_array(data) or data.dtype not in _lib.DTYPE_CODES:
+            raise TypeError("register_views needs DeviceArray slabs of a supported dtype")
+        k = 3 - ndim
+        m = [1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0]
+        o = [0.0, 0.0, 0.0]
+        for a in range(ndim):
+            m[(k + a) * 4] = float(mdiag[a])
+            o[k + a] = float(off[a])
+        shp, st = [int(x) for x in data.shape], [int(x) for x in data.strides]
+        if ndim == 2:
+            shp, st = [1] + shp, [st[0] * shp[0]] + st
+        v.data = data.ptr
+        v.dtype = _lib.DTYPE_CODES[data.dtype]
+        v.mem = _lib.MVS_MEM_DEVICE
+        v.shape[:] = shp
+        v.stride[:] = st
+        v.matrix[:] = m
+        v.offset[:] = o
+    t = (C.c_double * 3)()
+    q = C.c_double()
+    status = C.c_int32()
+    ncand = C.c_int32()
+    mode = -1 if region_mode is None else {"union": 0, "intersection": 1}[region_mode]
+    rc = lib.mvs_register_views(device, C.byref(views[0]), C.byref(views[1]), ndim, _lib.i64x3(shape3(out_shape)), int(upsample_factor), mode,
+                                int(bool(constant_check)), t, C.byref(q), C.byref(status), C.byref(ncand))
+    _lib.check(rc, device, "mvs_register_views")
+    return np.array(list(t)[3 - ndim:], dtype=np.float64), float(q.value), int(status.value), int(ncand.value)
+
+
 def score_candidates(im0, im1, t_candidates, region_mode, data_range, im1_min, device=0, quality_for_all=True):
     """The candidate loop of registration.py:493-556 on the GPU.  im0 / im1: rescaled float32 images
     (NaN = outside).  Returns (ssim, spearman, code) arrays; code 1 = (-1,-1) appended, 2 = `continue`.

@@ -1321,7 +1321,7 @@ extern "C" int mvs_resample(int device, const mvs_view_t* view, const int64_t ou
     c->timing_valid = true;
     if (out_mem == MVS_MEM_HOST)
         MVS_HIP_TRY(c, hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!(c->defer_sync && out_mem == MVS_MEM_DEVICE)) MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MVS_OK;
 }
 

@@ -40,12 +40,13 @@ struct MvsContext {
     hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool serial_classes = false;       // option "serial_classes": launch them one after the other on the main stream instead
+    bool defer_sync = false;           // set by composite entry points: mvs_resample to device memory returns without waiting
     bool both_crops_finite = false;    // set by mvs_register_crops around its mvs_score_candidates call (under the context lock)
     bool materialize_shifts = false;   // test switch: candidate scoring always writes the shifted copies (no on-the-fly SSIM z pass)
     std::recursive_mutex mu;      // recursive: composite entry points (mvs_pair.hip) call the public ones under the lock
     std::string last_error;
     // grow-only device scratch buffers (slot-indexed) and one pinned host staging buffer
-    MvsScratch dev[12];
+    MvsScratch dev[14];
     void* pinned = nullptr;
     size_t pinned_cap = 0;
     void* pinned2 = nullptr;

@@ -173,3 +173,30 @@ extern "C" int mvs_register_crops(int device, const float* fixed, const float* m
     *quality_out = best_quality;
     return MVS_OK;
 }
+
+
+// One call per image pair: both overlap crops are resampled onto the fixed view's grid (sims_to_intrinsic_coord_system,
+// registration.py:280-350: order 1, NaN outside) into library scratch and registered (mvs_register_crops), without a host
+// round trip in between.  Replaces three calls, two crop allocations and two waits of the Python flow.
+extern "C" int mvs_register_views(int device, const mvs_view_t* fixed_view, const mvs_view_t* moving_view, int32_t ndim,
+                                  const int64_t out_shape[3], int32_t upsample_factor, int32_t region_mode, int32_t constant_check,
+                                  double t_out[3], double* quality_out, int32_t* status_out, int32_t* n_candidates_out) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    if (!fixed_view || !moving_view || !out_shape) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_register_views: NULL argument");
+    for (int k = 0; k < 3; ++k)
+        if (out_shape[k] < 1) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_register_views: bad out_shape");
+    const int64_t n = out_shape[0] * out_shape[1] * out_shape[2];
+    float* crop0 = (float*)mvs_scratch(c, 11, (size_t)n * 4);
+    float* crop1 = (float*)mvs_scratch(c, 12, (size_t)n * 4);
+    if (!crop0 || !crop1) return MVS_ERR_HIP;
+    c->defer_sync = true;
+    rc = mvs_resample(device, fixed_view, out_shape, 1, NAN, crop0, MVS_MEM_DEVICE);
+    if (!rc) rc = mvs_resample(device, moving_view, out_shape, 1, NAN, crop1, MVS_MEM_DEVICE);
+    c->defer_sync = false;
+    if (rc) return rc;
+    return mvs_register_crops(device, crop0, crop1, MVS_MEM_DEVICE, ndim, out_shape, upsample_factor, region_mode, constant_check, t_out,
+                              quality_out, status_out, n_candidates_out);
+}

@@ -13,7 +13,7 @@ import warnings
 
 import numpy as np
 
-from . import _reg_ops, param_utils
+from . import _lib, _reg_ops, param_utils
 from .device import is_device_array
 
 logger = logging.getLogger(__name__)
@@ -469,12 +469,16 @@ def _lean_register_pair(g1b, g2b, g1, g2, sdims, tol, upsample_factor, transform
     if plan is None:
         raise ValueError("views do not overlap")
     n = len(sdims)
-    crops = []
-    for i, g in enumerate((g1b, g2b)):
-        data = g.sim.data[tuple(slice(a, b) for a, b in plan["windows"][i])]
-        crops.append(resample_array(data, np.diag(plan["matrix_diag"][i]), np.array(plan["offset"][i]), plan["out_shape"], 1, np.nan, device))
+    slabs = [g.sim.data[tuple(slice(a, b) for a, b in plan["windows"][i])] for i, g in enumerate((g1b, g2b))]
     uf = (10 if n == 2 else 2) if upsample_factor is None else upsample_factor
-    t, quality, status, _ = _reg_ops.register_crops(crops[0], crops[1], uf, None, True, device)
+    if all(is_device_array(d) and d.dtype in _lib.DTYPE_CODES for d in slabs):
+        # resample both crops + register them: one library call, no crop allocation, no wait in between
+        t, quality, status, _ = _reg_ops.register_views(slabs[0], plan["matrix_diag"][0], plan["offset"][0], slabs[1], plan["matrix_diag"][1],
+                                                        plan["offset"][1], plan["out_shape"], uf, None, True, device)
+    else:
+        crops = [resample_array(d, np.diag(plan["matrix_diag"][i]), np.array(plan["offset"][i]), plan["out_shape"], 1, np.nan, device)
+                 for i, d in enumerate(slabs)]
+        t, quality, status, _ = _reg_ops.register_crops(crops[0], crops[1], uf, None, True, device)
     if status == 2:
         warnings.warn("An overlap region between tiles/views is all zero or constant. Assuming identity transform.", UserWarning, stacklevel=3)
         affine, quality = param_utils.identity_transform(n), np.nan

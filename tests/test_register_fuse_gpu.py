@@ -183,3 +183,37 @@ def test_chunked_fuse_with_device_resident_mosaic(hip_device):
     diff = host.astype(np.int64) - whole.astype(np.int64)
     assert np.abs(diff).max() <= 1
     assert (diff != 0).mean() < 0.02
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_lean_pair_path_equals_generic_on_device(hip_device, ndim):
+    """register() through the lean per-pair host path (plain-float plans + mvs_register_views: resample both crops and register
+    them in one call) and through the generic numpy path (transform_sim x 2 + mvs_register_crops): identical transforms,
+    qualities and bounding boxes, with device-resident tiles, binning and non-integer stage positions."""
+    from multiview_stitcher_amd import device, registration, sample_data, spatial_image_utils as si
+
+    if ndim == 2:
+        sims, _, _ = sample_data.generate_tiled_dataset(ndim=2, tile_shape=(160, 144), tiles=(2, 3), overlap=(40, 36), dtype=np.uint16, max_jitter=3, seed=3,
+                                                        spacing=(0.7, 0.7))
+        binning = {"y": 1, "x": 1}
+    else:
+        sims, _, _ = sample_data.generate_tiled_dataset(ndim=3, tile_shape=(40, 96, 80), tiles=(2, 2, 2), overlap=(12, 24, 20), dtype=np.uint16, max_jitter=2,
+                                                        seed=8, spacing=(2.0, 0.5, 0.5))
+        binning = {"z": 1, "y": 2, "x": 2}
+    sims = [device.to_device(s.isel({d: 0 for d in si.get_nonspatial_dims_from_sim(s)}), 0) for s in sims]
+    out = []
+    for lean in (True, False):
+        registration._lean_enabled[0] = lean
+        try:
+            out.append(registration.register(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, registration_binning=binning, return_dict=True,
+                                             n_parallel_pairwise_regs=3))
+        finally:
+            registration._lean_enabled[0] = True
+    a, b = out
+    assert a["pairwise_registration"]["edges"] == b["pairwise_registration"]["edges"] and len(a["pairwise_registration"]["edges"]) >= 4
+    for ra, rb in zip(a["pairwise_registration"]["results"][0], b["pairwise_registration"]["results"][0]):
+        np.testing.assert_array_equal(ra["transform"], rb["transform"])
+        np.testing.assert_array_equal(ra["bbox"], rb["bbox"])
+        assert ra["quality"] == rb["quality"]
+    for pa, pb in zip(a["params"], b["params"]):
+        np.testing.assert_array_equal(pa, pb)
