@@ -102,7 +102,11 @@ int mvs_synchronize(int device);
  * pass; both ways must agree bit for bit) and mvs_phasecorr_multi runs one inverse transform per normalisation (by default
  * two normalisations share one); tests compare the plain and the default paths.  "serial_classes" = 1: the class kernels of
  * the translation fast path of mvs_fuse_chunk run one after the other on the context's stream (default: side by side on
- * side streams, joined before the call's work is considered done). */
+ * side streams, joined before the call's work is considered done).  "rows_v1" = 1: the direct-load row-owning kernels
+ * (whole output rows per workgroup, mvs_fuse_rows.hip) are tried before the region kernels for every dtype (default: for
+ * float32 tiles only, where they reproduce scipy's NaN propagation through zero-weight taps).  "rowlds" = 1: the LDS-staged
+ * row-owning kernel (uint16, one tap per view; mvs_fuse_rowlds.hip) is tried first.  Both opt-in paths must agree with
+ * the default ones (tests compare all of them with the oracle). */
 int mvs_set_option(int device, const char* key, int64_t value);
 /* Device time (ms, hipEvent) spent in the kernels of the most recent compute
  * call on this device; blocks until that work has finished. */

@@ -211,6 +211,14 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         c->no_regions = value != 0;
         return MVS_OK;
     }
+    if (!strcmp(key, "rowlds")) {
+        c->rowlds = value != 0;
+        return MVS_OK;
+    }
+    if (!strcmp(key, "rows_v1")) {
+        c->rows_v1 = value != 0;
+        return MVS_OK;
+    }
     if (!strcmp(key, "serial_classes")) {
         c->serial_classes = value != 0;
         return MVS_OK;

@@ -948,6 +948,7 @@ static void prepare_translation_view(DevView* d, int order, int fusion, const in
         }
         exact_valid_range(off, n[k], (int)chunk_shape[k], &d->lo[k], &d->hi[k]);
     }
+    d->pad[0] = (order == 0) ? 0.f : 1.f;   // carried into TrView.linear
     d->tr_ok = 1;
 }
 
@@ -1037,6 +1038,8 @@ static void fill_tr_view(const DevView& d, TrView* t) {
         t->ws[k] = d.ws[k];
     }
     t->wnz = d.wnz;
+    t->n[0] = d.nz; t->n[1] = d.ny; t->n[2] = d.nx;
+    t->linear = d.pad[0] != 0.f ? 1 : 0;
     t->data = (unsigned long long)d.data;
     t->span = d.span;
     t->stride_y = (int)d.stride_y;
@@ -1060,6 +1063,11 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_views, int dtype, void* dout, const int64_t os[3],
                      const int64_t trim[3], bool* done);   // mvs_fuse_region.hip
+
+int mvs_fuse_rows(MvsContext* c, const TrView* htr, const TrView* dtr, int n_views, int dtype, void* dout, const int64_t os[3],
+                  const int64_t trim[3], bool* done);      // mvs_fuse_rows.hip
+int mvs_fuse_rowlds(MvsContext* c, const TrView* htr, const TrView* dtr, int n_views, int dtype, void* dout, const int64_t os[3],
+                    const int64_t trim[3], bool* done);    // mvs_fuse_rowlds.hip
 
 int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_views,
                            const mvs_fuse_opts_t* opts, void* out);   // mvs_gauss.hip
@@ -1140,6 +1148,11 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
     }
     bool use_tr = !c->force_generic;
     for (int i = 0; i < n_views && use_tr; ++i) use_tr = hviews[i].tr_ok != 0;
+    // Float tiles with linear interpolation: scipy multiplies the second tap of every axis by its (possibly zero) weight,
+    // so a NaN there poisons the sample.  Only the row kernels (weighted average) and the generic kernel read all taps;
+    // the column / region kernels read one tap at integer offsets, so they are not used for such tiles.
+    const bool nan_exact = (dtype == MVS_F32 && opts->order == 1);
+    if (nan_exact && opts->fusion != MVS_FUSE_WEIGHTED_AVERAGE) use_tr = false;
     size_t xtab_total = 0;
     int* hcull = (int*)((char*)hviews + views_bytes);
     TrView* htr = (TrView*)((char*)hviews + views_bytes + cull_bytes);
@@ -1171,24 +1184,47 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
     P.tz = (int)opts->trim[0]; P.ty = (int)opts->trim[1]; P.tx = (int)opts->trim[2];
     P.cull = (const int*)((const char*)dviews + views_bytes);
     P.ablate = c->ablate;
-    if (use_tr) {
-        P.bz = (os[0] > 1) ? kTrPlanes : 1;
-        P.by = (os[0] > 1) ? kTrRows * kTrGroups : 4 * kTrRows * kTrGroups;
-    } else {
-        P.bz = (os[0] > 1) ? 4 : 1;
-        P.by = (os[0] > 1) ? 4 : 16;
-    }
-    const int brick_x = use_tr ? kTrBrickX : kBrickX;
-    P.nbz = (P.oz + P.bz - 1) / P.bz;
-    P.nby = (P.oy + P.by - 1) / P.by;
-    P.nbx = (P.ox + brick_x - 1) / brick_x;
-    const long long nblocks = (long long)P.nbz * P.nby * P.nbx;
+    long long nblocks = 0;
+    auto set_brick_grid = [&](bool tr) {
+        if (tr) {
+            P.bz = (os[0] > 1) ? kTrPlanes : 1;
+            P.by = (os[0] > 1) ? kTrRows * kTrGroups : 4 * kTrRows * kTrGroups;
+        } else {
+            P.bz = (os[0] > 1) ? 4 : 1;
+            P.by = (os[0] > 1) ? 4 : 16;
+        }
+        const int brick_x = tr ? kTrBrickX : kBrickX;
+        P.nbz = (P.oz + P.bz - 1) / P.bz;
+        P.nby = (P.oy + P.by - 1) / P.by;
+        P.nbx = (P.ox + brick_x - 1) / brick_x;
+        nblocks = (long long)P.nbz * P.nby * P.nbx;
+    };
+    set_brick_grid(use_tr);
     if (nblocks > 0x7fffffffLL) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "chunk too large for one launch");
 
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     int* tr_overflow_ptr = nullptr;
     bool regions_done = false;
-    if (use_tr && opts->fusion == MVS_FUSE_WEIGHTED_AVERAGE && !c->no_regions) {
+    if (use_tr && opts->fusion == MVS_FUSE_WEIGHTED_AVERAGE && c->rowlds) {
+        // LDS-staged row-owning kernel (uint16, one tap per view); falls through otherwise
+        rc = mvs_fuse_rowlds(c, htr, (const TrView*)((const char*)dviews + views_bytes + cull_bytes), n_views, dtype, dout, os,
+                             opts->trim, &regions_done);
+        if (rc) return rc;
+    }
+    if (!regions_done && use_tr && opts->fusion == MVS_FUSE_WEIGHTED_AVERAGE && (c->rows_v1 || (dtype == MVS_F32 && opts->order == 1))) {
+        // direct-load row-owning kernels.  Float tiles take them by default: they read both taps of every axis even at
+        // integer offsets, so a NaN next to a tap poisons the sample exactly as scipy's zero-weight multiply does
+        // (the region kernels read one tap there).  Other dtypes: opt-in ("rows_v1"), the region kernels are faster so far.
+        rc = mvs_fuse_rows(c, htr, (const TrView*)((const char*)dviews + views_bytes + cull_bytes), n_views, dtype, dout, os,
+                           opts->trim, &regions_done);
+        if (rc) return rc;
+    }
+    if (!regions_done && nan_exact && use_tr) {   // float tiles the row kernels could not take: generic kernel
+        use_tr = false;
+        set_brick_grid(false);
+        if (nblocks > 0x7fffffffLL) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "chunk too large for one launch");
+    }
+    if (!regions_done && use_tr && opts->fusion == MVS_FUSE_WEIGHTED_AVERAGE && !c->no_regions) {
         rc = mvs_fuse_regions(c, htr, (const TrView*)((const char*)dviews + views_bytes + cull_bytes), n_views, dtype, dout, os,
                               opts->trim, &regions_done);
         if (rc) return rc;

@@ -25,7 +25,7 @@ struct DevView {
     int sup_ilo[3], sup_ihi[3];
     float sup_flo[3], sup_fhi[3];
     long long span;   // elements from data[0] to the last voxel of the slab, + 1
-    float pad[3];
+    float pad[3];     // pad[0]: 1 = linear interpolation (set with tr_ok)
 };
 
 

@@ -8,7 +8,8 @@
 
 constexpr float kPiHalf = 1.57079632679489661923f;
 
-// Compact per-view record of the fast path (160 bytes = 10 x 16-byte loads per lane).
+// Compact per-view record of the fast path (176 bytes; the region / column kernels read the first 160 = 10 x 16-byte
+// loads per lane, the row kernels (mvs_fuse_rows*) read the fields with scalar loads).
 struct alignas(16) TrView {
     int lo[3], hi[3];            // valid chunk-index box (inclusive), exact per scipy's in-bounds test
     int io[3];                   // input index = chunk index + io
@@ -23,8 +24,10 @@ struct alignas(16) TrView {
     float sup_k[3];              // support nodes per output pixel
     float ws[3];                 // tent scales of the closed-form support table
     int pad1[2];
+    int n[3];                    // slab shape z, y, x (second-tap mirroring at the upper border, float tiles)
+    int linear;                  // 1: interpolation order 1 (two taps per axis), 0: order 0 (one tap)
 };
-static_assert(sizeof(TrView) == 160, "TrView layout");
+static_assert(sizeof(TrView) == 176, "TrView layout");
 
 // ---- blend weight in "distance" form -----------------------------------------------------------
 // Along one axis the support grid has nodes 0..4 at chunk indices sup_lo .. sup_hi.  With

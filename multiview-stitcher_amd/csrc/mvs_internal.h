@@ -46,7 +46,7 @@ struct MvsContext {
     std::recursive_mutex mu;      // recursive: composite entry points (mvs_pair.hip) call the public ones under the lock
     std::string last_error;
     // grow-only device scratch buffers (slot-indexed) and one pinned host staging buffer
-    MvsScratch dev[14];
+    MvsScratch dev[16];
     void* pinned = nullptr;
     size_t pinned_cap = 0;
     void* pinned2 = nullptr;
@@ -56,6 +56,8 @@ struct MvsContext {
     hipEvent_t pinned_ev[2] = {nullptr, nullptr};
     bool pinned_pending[2] = {false, false};
     bool no_regions = false;      // test switch: skip the region kernel (use the column kernel)
+    bool rowlds = false;          // opt-in: LDS-staged row kernel (mvs_fuse_rowlds.hip) before the other fast paths
+    bool rows_v1 = false;         // opt-in: direct-load row kernels (mvs_fuse_rows.hip) for every dtype (default: float tiles only)
     // caching device allocator behind mvs_malloc / mvs_free: freed blocks are kept (size-keyed) and handed out
     // again, because hipMalloc / hipFree cost ~0.4 ms each and the registration path allocates per pair.
     // Work of this library is stream-ordered on `stream`, so a recycled block is never touched out of order.

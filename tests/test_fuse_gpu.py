@@ -9,15 +9,20 @@ from tests.helpers import (assert_fused_close, bb_to_dicts, reference_noise_floo
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["fast", "generic"], autouse=True)
+@pytest.fixture(params=["fast", "generic", "rows", "rowlds"], autouse=True)
 def kernel_path(request, hip_device):
-    """Every parity case runs twice: through the translation fast path (when the views qualify) and
-    with the generic affine kernel forced -- both must match the oracle."""
+    """Every parity case runs through each kernel family: the default translation fast path (region kernels; float
+    tiles: row kernels), the generic affine kernel forced, and the two opt-in row-owning paths (direct-load rows for
+    every dtype; LDS-staged rows for uint16 single-tap views) -- all must match the oracle."""
     from multiview_stitcher_amd import _lib
 
     _lib.set_option("force_generic", 1 if request.param == "generic" else 0)
+    _lib.set_option("rows_v1", 1 if request.param == "rows" else 0)
+    _lib.set_option("rowlds", 1 if request.param == "rowlds" else 0)
     yield request.param
     _lib.set_option("force_generic", 0)
+    _lib.set_option("rows_v1", 0)
+    _lib.set_option("rowlds", 0)
 
 
 def _grid_case(ndim, dtype, tiles, tile_shape, overlap, frac_shift, seed=0, spacing=None):
@@ -78,6 +83,30 @@ def test_fuse_3d_grid(hip_device, dtype, frac_shift):
     _, bbs = zip(*[sim_to_view(s) for s in sims])
     out_bb = union_bb(bbs, params, np.ones(3))
     got, want, want_f = _run_both(sims, params, out_bb)
+    assert_fused_close(got, want, want_f[0], noise_floor=want_f[1])
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_float_tiles_holding_nan_are_poisoned_like_scipy(hip_device, ndim):
+    """scipy's linear interpolation reads both taps of every axis even at an integer offset (weights 1 and 0), so a NaN
+    right of / below / behind a voxel makes the resampled value NaN (transformation.py:136-139), the view drops out
+    of that voxel (weights.py:325-345) and a voxel seen by no other view becomes 0.  At the upper border the second
+    tap is the mirrored index n - 2.  Integer offsets, default options."""
+    tiles, shape, ov = ((2, 2), (40, 56), 11) if ndim == 2 else ((1, 2, 2), (10, 30, 44), (0, 8, 12))
+    sims, params = _grid_case(ndim, np.float32, tiles, shape, ov, False, seed=3)
+    rng = np.random.default_rng(5)
+    new = []
+    for s in sims:
+        d = np.asarray(s.data).copy()
+        idx = tuple(rng.integers(0, n, 60) for n in d.shape)
+        d[idx] = np.nan
+        d[tuple(n - 2 for n in d.shape)] = np.nan          # mirrored second tap of the last voxel
+        d[(0,) * (d.ndim - 1) + (d.shape[-1] - 2,)] = np.nan
+        new.append(s.copy(data=d))
+    _, bbs = zip(*[sim_to_view(s) for s in new])
+    out_bb = union_bb(bbs, params, np.ones(ndim))
+    got, want, want_f = _run_both(new, params, out_bb)
+    assert np.isfinite(got).all()
     assert_fused_close(got, want, want_f[0], noise_floor=want_f[1])
 
 

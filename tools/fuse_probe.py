@@ -31,6 +31,8 @@ for idx in np.ndindex(*grid):
     sims.append(sim)
 torch.cuda.synchronize()
 _lib.set_option("ablate", int(os.environ.get("MVS_ABLATE", "0")))
+_lib.set_option("rowlds", int(os.environ.get("MVS_ROWLDS", "0")))                 # 1: LDS-staged row kernel first
+_lib.set_option("rows_v1", int(os.environ.get("MVS_ROWS_V1", "0")))               # 1: direct-load row kernels before the region kernels
 _lib.set_option("serial_classes", int(os.environ.get("MVS_SERIAL", "0")))   # 1: class kernels one after the other (A/B of the side streams)
 ms = []
 for _ in range(reps):
