@@ -117,6 +117,14 @@ def write_sim_to_ome_zarr(sim, output_zarr_url, downscale_factors_per_spatial_di
     coordtfs, axes = calc_ngff_coordinate_transformations_and_axes(
         {"spacing": spacing, "origin": origin, "shape": spatial_shape}, res_abs, nsdims=nsdims)
     chunks = _chunk_shape_from_sim(sim)
+    if kw.get("chunks") is not None:      # zarr_array_creation_kwargs={"chunks": ...}: full-rank, or spatial dims only
+        req = [int(v) for v in kw["chunks"]]
+        if len(req) == len(sdims):
+            req = [1] * len(nsdims) + req
+        if len(req) != len(dims):
+            raise ValueError(f"chunks {kw['chunks']} do not match dims {dims}")
+        chunks = req
+    kw = {k: v for k, v in kw.items() if k != "chunks"}
     ns_shape = [int(sim.sizes[d]) for d in nsdims]
 
     zarr_io.create_group(output_zarr_url, overwrite=overwrite)

@@ -187,22 +187,6 @@ def get_optimal_registration_binning(sim1, sim2, max_total_pixels_per_stack=400*
 _BINNING_MEMO = {}
 
 
-def _smoke(device=0):
-    """Used by __graft_entry__.smoke(): one small pairwise registration checked against the oracle."""
-    from oracle import reg_oracle as ro
-    from scipy import ndimage
-
-    rng = np.random.default_rng(0)
-    big = ndimage.gaussian_filter(rng.random((40, 84, 76)), 1.0).astype(np.float32)
-    a = np.ascontiguousarray(big[8:32, 10:74, 10:66])
-    b = np.ascontiguousarray(big[9:33, 8:72, 13:69])
-    want = ro.phase_correlation_registration(a, b)
-    got = phase_correlation_registration(a, b, device=device)
-    assert np.array_equal(got["affine_matrix"], want["affine_matrix"]), (got, want)
-    assert abs(got["quality"] - want["quality"]) < 1e-5
-    print("smoke: pairwise registration shift", got["affine_matrix"][:-1, -1], "quality", got["quality"], "matches oracle")
-
-
 # =====================================================================================================
 # Pair preparation and the register() workflow (host glue around the kernels)
 # =====================================================================================================

@@ -17,11 +17,19 @@ Rules (see DESIGN.md "Oracle"):
   functions the reference calls (``scipy.ndimage.affine_transform``,
   ``distance_transform_edt``, ``gaussian_filter``), so that half is pinned by
   the library itself plus the reference's own constant-tile known-answer
-  tests (``tests/test_oracle_reference_kats.py``).
+  tests (``tests/test_fuse_oracle.py``) and by non-constant blending-weight
+  vectors derived by hand (``tests/test_weights_oracle.py``).
   The registration half depends on scikit-image 0.26 (not installed, not in
   the reference tree): its published algorithm (Guizar-Sicairos upsampled-DFT
-  phase correlation, Wang SSIM) is restated in ``reg_oracle.py``;
-  exact peak indices / sub-pixel shifts are **parity unpinned** by any golden
-  vector of the reference (its tests are tolerance tests only) and are pinned
-  here by those tolerance tests + cross-checks against skimage 0.18.3.
+  phase correlation, Wang SSIM) is restated in ``reg_oracle.py``.  The
+  reference's own tests hold no golden vectors for it (tolerance tests only),
+  so it is pinned by vectors EXECUTED with scikit-image 0.18.3
+  (``tests/golden/skimage018_pcc.npz``, ``skimage018_round2.npz``; generator
+  ``tests/golden/make_skimage018_fixture.py`` under /opt/conda/bin/python3.9):
+  unnormalised phase correlation and its upsampled-DFT refinement, the
+  "phase"-normalised variant through 0.18.3's own machinery around the one
+  published normalisation line, the masked variant with inverted masks on
+  NaN-holding images (quirk Q1 -> zero shift), ``rescale_intensity`` values
+  (Q5) and SSIM for float64 and float32 inputs (Q4), plus the reference's
+  tolerance tests (``tests/test_reg_oracle.py``).
 """

@@ -89,3 +89,142 @@ def test_north_star_register_and_fuse_properties(hip_device):
     d2 = f.to(torch.int32) - _as_torch(torch, fused_g.data).to(torch.int32)
     assert int(d2.abs().max()) <= 1
     assert float((d2 != 0).float().mean()) < 0.05
+
+
+# ---- BASELINE.json configs C2, C3, C5 at (near) full size: size-independent properties --------------------------------
+def _mosaic_2d_f32(torch, dev, grid, tile, overlap, seed, max_jitter=3):
+    grid, tile, overlap = np.asarray(grid), np.asarray(tile), np.asarray(overlap)
+    step, pad = tile - overlap, max_jitter + 1
+    gt_shape = step * (grid - 1) + tile + 2 * pad
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    noise = torch.rand((1, 1, int(gt_shape[0]), int(gt_shape[1])), generator=g, device=dev)
+    for _ in range(3):
+        noise = torch.nn.functional.avg_pool2d(noise, 5, stride=1, padding=2, count_include_pad=False)
+    gt = ((noise[0, 0] - 0.4) / 0.2).clamp_(0, 1).contiguous()
+    rng = np.random.default_rng(seed + 1)
+    tiles, jitters, origins = [], [], []
+    for idx in np.ndindex(*grid):
+        idx = np.asarray(idx)
+        jit = rng.integers(-max_jitter, max_jitter + 1, size=2)
+        if not idx.any():
+            jit[:] = 0
+        start = idx * step + pad + jit
+        tiles.append(gt[tuple(slice(int(s), int(s + n)) for s, n in zip(start, tile))].contiguous())
+        jitters.append(jit)
+        origins.append((idx * step).astype(float))
+    return tiles, np.array(jitters), np.array(origins), gt, pad
+
+
+def test_c2_config_register_and_fuse_2d_float32(hip_device):
+    """C2: 3x3 grid of 2D 2048 x 2048 float32 tiles, 20 % overlap (410 px): phase-correlation registration of the 12
+    face pairs (transform lengths 2048 and 410/411: Bluestein lines) + cosine-blend fuse in 2048^2 chunks."""
+    if torch is None or not torch.cuda.is_available():
+        pytest.skip("needs torch on the GPU for the on-device mosaic")
+    from multiview_stitcher_amd import _lib, fusion, param_utils, registration
+    from multiview_stitcher_amd import spatial_image_utils as si
+    from multiview_stitcher_amd.device import DeviceArray
+
+    dev = torch.device("cuda", 0)
+    tiles, jitters, origins, gt, pad = _mosaic_2d_f32(torch, dev, (3, 3), (2048, 2048), (410, 410), seed=77)
+    torch.cuda.synchronize()
+    sims = []
+    for t, o in zip(tiles, origins):
+        da = DeviceArray.from_pointer(t.data_ptr(), tuple(t.shape), np.float32, 0, owner=t)
+        s = si.to_spatial_image(da, dims=["y", "x"], scale={"y": 1.0, "x": 1.0}, translation=dict(zip("yx", o)))
+        si.set_sim_affine(s, np.eye(3), si.DEFAULT_TRANSFORM_KEY)
+        sims.append(s)
+    registration.register(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, new_transform_key="reg", device=0)
+    rec = np.array([param_utils.select_time(si.get_affine_from_sim(s, "reg"), 0)[:2, 2] for s in sims])
+    np.testing.assert_allclose(rec - rec[0], jitters - jitters[0], atol=1e-6)
+    fused = fusion.fuse(sims, transform_key="reg", output_chunksize={"y": 2048, "x": 2048}, output_on_backend=True, device=0)
+    _lib.synchronize(0)
+    f = torch.as_tensor(fused.data, device="cuda")
+    fo = np.round(si.get_origin_from_sim(fused, asarray=True)).astype(int)
+    ref_shift = np.round(rec[0]).astype(int)
+    sl = tuple(slice(int(o + pad - r), int(o + pad - r + n)) for o, r, n in zip(fo, ref_shift, f.shape))
+    want = gt[sl]
+    assert want.shape == f.shape
+    m = 16
+    d = (f[m:-m, m:-m] - want[m:-m, m:-m]).abs()
+    # every contribution to a voxel is the same ground-truth value: the weighted mean differs by float32 rounding only
+    assert float(d.max()) <= 2e-6, float(d.max())
+
+
+def test_c3_config_content_based_fuse_properties(hip_device):
+    """C3: 4 x 4 x 2 (x, y, z) grid of 3D 256 x 512 x 512 uint16 tiles, content-based weights at the reference's default
+    sigma_1 = 5 / sigma_2 = 11 (halo 22 px), 256^3 output chunks.  All tiles are cut from one volume, so every
+    normalised weighted mean is a mean of identical values: the ground truth, at most one count low (truncation)."""
+    if torch is None or not torch.cuda.is_available():
+        pytest.skip("needs torch on the GPU for the on-device mosaic")
+    import bench
+    from multiview_stitcher_amd import _lib, fusion
+    from multiview_stitcher_amd import spatial_image_utils as si
+
+    dev = torch.device("cuda", 0)
+    grid, tile = np.array([2, 4, 4]), np.array([256, 512, 512])
+    overlap = np.round(tile * 0.2).astype(int)
+    tiles, jitters, origins, gt, pad = bench.make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=99, max_jitter=0,
+                                                                   return_ground_truth=True)
+    sims = bench.build_sims(tiles, origins, 0)
+    torch.cuda.synchronize()
+    fused = fusion.fuse(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, weights_func=fusion.content_based,
+                        output_chunksize={d: 256 for d in "zyx"}, output_on_backend=True, device=0)
+    _lib.synchronize(0)
+    f = _as_torch(torch, fused.data)
+    assert tuple(f.shape) == tuple(int(v) for v in (tile - overlap) * (grid - 1) + tile)
+    want = gt.view(torch.int16)[tuple(slice(pad, pad + n) for n in f.shape)]
+    m = 24     # rim: blend weights round to 0 next to tile edges facing the border (weights.py:502-507)
+    inner = tuple(slice(m, n - m) for n in f.shape)
+    diff = f[inner].to(torch.int32) - want[inner].to(torch.int32)
+    assert int(diff.max()) <= 0 and int(diff.min()) >= -1
+    assert float((diff != 0).float().mean()) < 0.05
+
+
+def test_c5_shape_streamed_chunked_fuse_on_two_device_contexts(hip_device, tmp_path):
+    """C5 at a reduced grid: 2 x 2 x 2 of the exaSPIM-style 512 x 1024 x 1024 uint16 tiles, written as Zarr (128^3
+    chunks), fused chunk by chunk (256^3) with the chunks farmed over two device contexts into one OME-Zarr store.
+    Known-answer: the stage metadata holds the true positions, so the fused mosaic is the ground truth."""
+    if torch is None or not torch.cuda.is_available():
+        pytest.skip("needs torch on the GPU for the on-device mosaic")
+    import bench
+    from multiview_stitcher_amd import executors, ngff_utils, zarr_io
+    from multiview_stitcher_amd import spatial_image_utils as si
+
+    dev = torch.device("cuda", 0)
+    grid, tile = np.array([2, 2, 2]), np.array([512, 1024, 1024])
+    overlap = np.round(tile * 0.2).astype(int)
+    tiles, jitters, origins, gt, pad = bench.make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=5, max_jitter=0,
+                                                                   return_ground_truth=True)
+    torch.cuda.synchronize()
+    lazy = []
+    for i, (t, o) in enumerate(zip(tiles, origins)):
+        host = t.view(torch.int16).cpu().numpy().view(np.uint16)
+        s = si.to_spatial_image(host, dims=["z", "y", "x"], scale={d: 1.0 for d in "zyx"}, translation=dict(zip("zyx", o)))
+        z = ngff_utils.write_sim_to_ome_zarr(s, str(tmp_path / f"tile{i}.zarr"), zarr_array_creation_kwargs={"chunks": (128, 128, 128)})
+        assert zarr_io.is_zarr_backed(z.data)
+        si.set_sim_affine(z, np.eye(4), si.DEFAULT_TRANSFORM_KEY)
+        lazy.append(z)
+        del host
+    del tiles
+    out_url = str(tmp_path / "fused.zarr")
+    fused = executors.fuse_on_devices(lazy, devices=(0, 0), transform_key=si.DEFAULT_TRANSFORM_KEY,
+                                      output_chunksize={d: 256 for d in "zyx"}, output_zarr_url=out_url,
+                                      zarr_options={"ome_zarr": True})
+    assert zarr_io.is_zarr_backed(fused.data)
+    shape = tuple(int(v) for v in (tile - overlap) * (grid - 1) + tile)
+    assert tuple(fused.data.shape[-3:]) == shape
+    rng = np.random.default_rng(0)
+    gtv = gt.view(torch.int16)
+    low, tot = 0, 0
+    for _ in range(12):          # random 96^3 windows away from the rim, straddling chunk borders
+        lo = [int(rng.integers(24, n - 24 - 96)) for n in shape]
+        win = np.asarray(fused.data[(0, 0) + tuple(slice(a, a + 96) for a in lo)]) if fused.data.ndim == 5 else \
+            np.asarray(fused.data[tuple(slice(a, a + 96) for a in lo)])
+        want = gtv[tuple(slice(a + pad, a + pad + 96) for a in lo)].cpu().numpy().view(np.uint16)
+        d = win.astype(np.int32).reshape(want.shape) - want.astype(np.int32)
+        # one count low only where the float32 weighted mean of identical values lands just under the integer (overlap zones)
+        assert d.max() <= 0 and d.min() >= -1 and (d != 0).mean() < 0.25
+        low += int((d != 0).sum())
+        tot += d.size
+    assert low / tot < 0.05

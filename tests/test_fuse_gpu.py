@@ -200,7 +200,7 @@ def test_fuse_content_based_weights(hip_device, ndim, dtype, kernel_path):
     """weights_func=content_based (weights.py:22-74) with its halo (2*sigma_2) trimmed: chunk-level parity."""
     from multiview_stitcher_amd import fusion, spatial_image_utils as si
 
-    if kernel_path == "generic":
+    if kernel_path != "fast":
         pytest.skip("content-based weights have a single implementation")
     if ndim == 3:
         sims, params = _grid_case(3, dtype, (1, 2, 2), (20, 40, 44), (0, 12, 14), True, seed=4)
@@ -225,11 +225,42 @@ def test_fuse_content_based_weights(hip_device, ndim, dtype, kernel_path):
         np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
 
 
+@pytest.mark.parametrize("dtype", [np.uint16, np.float32])
+def test_fuse_content_based_default_sigmas_3d(hip_device, dtype, kernel_path):
+    """The reference's DEFAULT content-based parameters sigma_1 = 5, sigma_2 = 11 (weights.py:26-27; Gaussian radii 20
+    and 44, halo 2 * sigma_2 = 22 px: the C3 configuration) on a 3D chunk of (64 + 44)^3-class extent, so that lines
+    both shorter and longer than the LDS-staged filter's tile take part.  Fractional offsets."""
+    from multiview_stitcher_amd import fusion, spatial_image_utils as si
+
+    if kernel_path != "fast":
+        pytest.skip("content-based weights have a single implementation")
+    sims, params = _grid_case(3, dtype, (1, 2, 2), (108, 84, 90), (0, 40, 44), True, seed=11)
+    sig = {"sigma_1": 5.0, "sigma_2": 11.0}
+    sdims = si.get_spatial_dims_from_sim(sims[0])
+    views, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(3))
+    halo = 22
+    want, want_f, dbg = fo.fuse_np(list(views), params, out_bb, full_view_bbs=list(bbs), weights="content_based",
+                                   weights_kwargs=sig, trim_overlap_in_pixels=halo, return_debug=True)
+    got = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), weights_func=fusion.content_based,
+                         weights_func_kwargs=sig, full_view_bbs=[bb_to_dicts(b, sdims) for b in bbs],
+                         trim_overlap_in_pixels=halo)
+    assert got.shape == want.shape and min(got.shape) >= 64
+    if np.issubdtype(dtype, np.integer):
+        d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+        assert d.max() <= 1 and (d > 0).mean() < 0.02
+        # the +-1 LSB flips must sit at truncation boundaries of the reference's own float result
+        frac = want_f - np.floor(want_f)
+        assert np.all(np.minimum(frac, 1 - frac)[d == 1] < 2e-3 * np.maximum(np.abs(want_f[d == 1]), 1.0))
+    else:
+        np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-5)
+
+
 def test_fuse_content_based_chunked_workflow(hip_device, kernel_path):
     """fusion.fuse(weights_func=content_based): halo = 2*sigma_2 from required_overlap, chunks trimmed (T/test_fusion.py:845-896)."""
     from multiview_stitcher_amd import fusion, sample_data
 
-    if kernel_path == "generic":
+    if kernel_path != "fast":
         pytest.skip("content-based weights have a single implementation")
     sims, _, _ = sample_data.generate_tiled_dataset(ndim=3, tile_shape=(12, 40, 40), tiles=(1, 2, 2), overlap=(0, 10, 10), max_jitter=0)
     fused = fusion.fuse(sims, transform_key=sample_data.METADATA_TRANSFORM_KEY, weights_func=fusion.content_based,

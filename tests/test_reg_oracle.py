@@ -66,3 +66,64 @@ def test_binning_heuristic_matches_survey_cases():
     # 256x512x512 isotropic -> {z:2,y:1,x:1}; 512^3 -> all 2
     assert ro.get_optimal_registration_binning((256, 512, 512), (256, 512, 512), (1, 1, 1), (1, 1, 1)) == {"z": 2, "y": 1, "x": 1}
     assert ro.get_optimal_registration_binning((512,) * 3, (512,) * 3, (1, 1, 1), (1, 1, 1)) == {"z": 2, "y": 2, "x": 2}
+
+
+# ---- round 2: pins for quirks Q1 / Q4 / Q5 and the "phase" normalisation (tests/golden/skimage018_round2.npz) ----------
+GOLD2 = np.load(os.path.join(os.path.dirname(__file__), "golden", "skimage018_round2.npz"))
+
+
+@pytest.mark.parametrize("name", ["q1_2d", "q1_3d", "q1_2d_fixed"])
+def test_q1_masked_variant_with_inverted_masks_is_the_zero_shift(name):
+    """registration.py:433-443 hands NaN-holding images and INVERTED masks to the masked phase correlation.  Executed
+    with scikit-image 0.18.3: the normalised correlation is identically zero, every position is a maximum, the mean
+    position is the zero shift.  (0.18.3 itself correlates axes (0, 1) only, so for 3D input its third component is the
+    centre of the untouched axis; its correlation routine run over all axes -- what the n-D releases do -- gives 0.)"""
+    a = GOLD2[name + "_a"]
+    assert float(GOLD2[name + "_xcorr_absmax"]) == 0.0
+    np.testing.assert_array_equal(np.abs(GOLD2[name + "_shift_allaxes"]), np.zeros(a.ndim))
+    if a.ndim == 2:
+        np.testing.assert_array_equal(GOLD2[name + "_shift"], np.zeros(2))
+    else:
+        np.testing.assert_array_equal(GOLD2[name + "_shift"], [0.0, 0.0, (a.shape[2] - 1) / 2])
+    # ... and that is the candidate the oracle (and the product) append
+    res = ro.phase_correlation_registration(a, GOLD2[name + "_b"], return_debug=True)
+    cands = res["debug"]["shift_candidates"]
+    assert len(cands) == 3
+    np.testing.assert_array_equal(cands[2], np.zeros(a.ndim))
+
+
+@pytest.mark.parametrize("name", ["rs_f32", "rs_u16like"])
+def test_q5_rescale_intensity_values_match_skimage018(name):
+    """0.18.3 returns float64 that holds the float32 arithmetic's values ((im - min) / (max - min) with the range as
+    Python floats); releases >= 0.19 keep float32.  The oracle's float32 result must be those values exactly."""
+    want = GOLD2[name + "_out"]
+    assert str(GOLD2[name + "_out_dtype"]) == "float64"
+    got = ro.rescale_intensity_01(GOLD2[name + "_in"])
+    assert got.dtype == np.float32
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    m = ~np.isnan(want)
+    np.testing.assert_array_equal(got[m].astype(np.float64), want[m])
+
+
+@pytest.mark.parametrize("name", ["ssimf32_2d", "ssimf32_3d", "ssimf32_3d_w5"])
+def test_q4_float32_ssim_within_tolerance_of_the_float64_value(name):
+    """0.18.3 converts to float64 before filtering; >= 0.19 -- and the oracle -- filter float32 images in float32.
+    Stated tolerance of the float32 evaluation against the executed float64 value: 2e-5 absolute."""
+    x, y = GOLD2[name + "_x"], GOLD2[name + "_y"]
+    assert x.dtype == np.float32
+    v32 = ro.structural_similarity(x, y, data_range=float(GOLD2[name + "_dr"]), win_size=int(GOLD2[name + "_win"]))
+    v64 = ro.structural_similarity(x.astype(np.float64), y.astype(np.float64), data_range=float(GOLD2[name + "_dr"]),
+                                   win_size=int(GOLD2[name + "_win"]))
+    assert abs(v64 - float(GOLD2[name + "_val"])) < 1e-12
+    assert abs(v32 - float(GOLD2[name + "_val"])) < 2e-5
+
+
+@pytest.mark.parametrize("name", ["ph_2d", "ph_2d_odd", "ph_3d"])
+def test_phase_normalisation_matches_skimage018_machinery(name):
+    """normalization="phase" does not exist in 0.18.3; the fixture applies the one published line
+    (image_product /= max(|image_product|, 100 eps)) and runs everything else -- transforms, peak search, wrap-around,
+    _upsampled_dft refinement -- with 0.18.3's own code."""
+    a, b, up = GOLD2[name + "_a"], GOLD2[name + "_b"], int(GOLD2[name + "_up"])
+    s, dbg = ro.phase_cross_correlation(a, b, upsample_factor=up, normalization="phase", return_debug=True)
+    np.testing.assert_array_equal(dbg["peak_index"], GOLD2[name + "_peak"])
+    np.testing.assert_allclose(np.asarray(s, dtype=np.float64), GOLD2[name + "_shift"], atol=1e-6)
