@@ -125,6 +125,11 @@ int mvs_free(int device, void* dev_ptr);
 int mvs_memcpy_h2d(int device, void* dst_dev, const void* src_host, uint64_t nbytes);
 int mvs_memcpy_d2h(int device, void* dst_host, const void* src_dev, uint64_t nbytes);
 int mvs_upload_tile(int device, const void* host, int32_t dtype, const int64_t shape[3], void** dev_ptr);
+/* Copy between two GPUs of the node (peer access over xGMI when available): ordered after the work queued on the
+ * source context, returns when the bytes have arrived.  The multi-GPU farms fetch the halo tiles of a pair / chunk
+ * owner from the neighbour that holds them with this (reference precedent: browser/executors.py:166-194, 267-281,
+ * where every worker re-reads its inputs from storage). */
+int mvs_memcpy_peer(int dst_device, void* dst_dev, int src_device, const void* src_dev, uint64_t nbytes);
 /* Stream-ordered byte fill of device memory (returns without waiting). */
 int mvs_memset(int device, void* dst_dev, int32_t byte_value, uint64_t nbytes);
 /* Device-to-device copy of a contiguous (z,y,x) box into a window of a larger contiguous array (both on this

@@ -66,6 +66,7 @@ SIGNATURES = {
     "mvs_set_stream": (C.c_int, [C.c_int, C.c_void_p]),
     "mvs_synchronize": (C.c_int, [C.c_int]),
     "mvs_set_option": (C.c_int, [C.c_int, C.c_char_p, C.c_int64]),
+    "mvs_memcpy_peer": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]),
     "mvs_last_kernel_ms": (C.c_double, [C.c_int]),
     "mvs_malloc": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mvs_free": (C.c_int, [C.c_int, C.c_void_p]),

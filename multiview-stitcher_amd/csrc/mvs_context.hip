@@ -325,6 +325,42 @@ int mvs_memcpy_d2h(int device, void* dst_host, const void* src_dev, uint64_t nby
     return MVS_OK;
 }
 
+// Device-to-device copy between two GPUs of the node (xGMI peer access when the driver grants it, staged by the runtime
+// otherwise).  Ordered after everything queued on the SOURCE context's stream, issued on the destination's stream, returns
+// when the bytes have arrived: the one-tile halo a chunk or pair owner fetches from a neighbour's resident tiles.
+int mvs_memcpy_peer(int dst_device, void* dst_dev, int src_device, const void* src_dev, uint64_t nbytes) {
+    MvsContext *cd, *cs;
+    int rc = mvs_check_ready(dst_device, &cd);
+    if (rc) return rc;
+    rc = mvs_check_ready(src_device, &cs);
+    if (rc) return rc;
+    if (!dst_dev || !src_dev) return mvs_fail(cd, MVS_ERR_INVALID_ARG, "mvs_memcpy_peer: NULL pointer");
+    const int dd = mvs_hip_device(dst_device), sd = mvs_hip_device(src_device);
+    MVS_HIP_TRY(cs, hipSetDevice(sd));
+    MVS_HIP_TRY(cs, hipStreamSynchronize(cs->stream));
+    MVS_HIP_TRY(cd, hipSetDevice(dd));
+    if (dd == sd) {
+        MVS_HIP_TRY(cd, hipMemcpyAsync(dst_dev, src_dev, nbytes, hipMemcpyDeviceToDevice, cd->stream));
+    } else {
+        static std::mutex peer_mu;
+        static bool peer_tried[MVS_MAX_DEVICES][MVS_MAX_DEVICES] = {{false}};
+        {
+            std::lock_guard<std::mutex> lk(peer_mu);
+            if (!peer_tried[dd][sd]) {     // best effort: without peer access the runtime stages the copy
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, dd, sd) == hipSuccess && can) {
+                    hipError_t e = hipDeviceEnablePeerAccess(sd, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+                }
+                peer_tried[dd][sd] = true;
+            }
+        }
+        MVS_HIP_TRY(cd, hipMemcpyPeerAsync(dst_dev, dd, src_dev, sd, nbytes, cd->stream));
+    }
+    MVS_HIP_TRY(cd, hipStreamSynchronize(cd->stream));
+    return MVS_OK;
+}
+
 int mvs_upload_tile(int device, const void* host, int32_t dtype, const int64_t shape[3],
                     void** dev_ptr) {
     MvsContext* c;

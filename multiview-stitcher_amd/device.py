@@ -53,6 +53,29 @@ class DeviceArray:
         strides = [int(np.prod(shape[i + 1:])) for i in range(len(shape))]
         return cls(owner, ptr, shape, strides, dtype, device)
 
+    def on_device(self, device):
+        """This array on GPU ``device`` (the low byte of a context id; the high bits are a lane): itself when it already
+        lives there, otherwise a peer copy (mvs_memcpy_peer) of the spanned range with the same shape and strides.
+        Copies of whole library-owned allocations are cached on the owner, so a tile is fetched once per device."""
+        dev = int(device)
+        if (self.device & 0xff) == (dev & 0xff):
+            return self
+        item = self.dtype.itemsize
+        owner = self._buf
+        lib = _lib.init(dev)
+        if isinstance(owner, _lib.DeviceBuffer) and owner.ptr:
+            cache = owner.__dict__.setdefault("_peer_copies", {})
+            peer = cache.get(dev & 0xff)
+            if peer is None:
+                peer = _lib.DeviceBuffer(dev, owner.nbytes)
+                _lib.check(lib.mvs_memcpy_peer(dev, C.c_void_p(peer.ptr), self.device, C.c_void_p(owner.ptr), owner.nbytes), dev, "mvs_memcpy_peer")
+                cache[dev & 0xff] = peer
+            return DeviceArray(peer, peer.ptr + (self.ptr - owner.ptr), self.shape, self.strides, self.dtype, dev)
+        span = sum((n - 1) * st for n, st in zip(self.shape, self.strides)) + 1
+        buf = _lib.DeviceBuffer(dev, span * item)
+        _lib.check(lib.mvs_memcpy_peer(dev, C.c_void_p(buf.ptr), self.device, C.c_void_p(self.ptr), span * item), dev, "mvs_memcpy_peer")
+        return DeviceArray(buf, buf.ptr, self.shape, self.strides, self.dtype, dev)
+
     def fill_zero(self):
         """Stream-ordered zero fill (contiguous arrays)."""
         if not self.is_contiguous():

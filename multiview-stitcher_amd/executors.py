@@ -3,6 +3,8 @@ no collectives.
 
 ``DevicePairExecutor``  -> ``registration.register(..., pairwise_executor=...)``   (registration.py:2634-2655)
 ``fuse_on_devices``     -> the role of ``batch_options["batch_func"]``            (fusion/_core.py:1133-1141)
+``process_batch_using_gpus`` -> a ``batch_options["batch_func"]`` like the reference's process_batch_using_joblib / _ray /
+                           _dask (misc_utils.py:161-234): the blocks of a batch are fused on several GPUs of the node
 ``shard_units``         -> rank-local work list for one-process-per-GPU launches (torch.distributed ranks)
 """
 
@@ -54,7 +56,7 @@ class DevicePairExecutor:
                 def local(m):
                     data = m.data if not hasattr(m, "scales") else None
                     if data is not None and is_device_array(data) and (data.device & 0xff) != (dev & 0xff):   # another GPU (the high bits are a context lane)
-                        return m.copy(data=DeviceArray.from_host(data.get(), dev))   # peer copy via host
+                        return m.copy(data=data.on_device(dev))   # peer copy over xGMI, cached per (tile, device)
                     return m
 
                 results[k] = registration.register_pair_of_msims(local(a), local(b), device=dev, _bin_cache=cache, **register_kwargs)
@@ -62,6 +64,29 @@ class DevicePairExecutor:
         with ThreadPoolExecutor(max_workers=n) as ex:
             list(ex.map(work, range(n)))
         return results
+
+
+def process_batch_using_gpus(func, block_ids, devices=(0,)):
+    """batch_func for ``fusion.fuse(..., output_zarr_url=..., batch_options={"batch_func": process_batch_using_gpus,
+    "n_batch": k, "batch_func_kwargs": {"devices": (0, 1, ...)}})`` -- the GPU counterpart of the reference's
+    process_batch_using_joblib (misc_utils.py:184-209): ``func`` is fuse()'s ``fuse_chunk(block_id, device=...)``; the
+    blocks of the batch are dealt to the devices in contiguous runs (neighbouring blocks share tiles, so a device's
+    peer-copied tiles are reused) and fused from one host thread per device (the library releases the GIL inside calls;
+    every block writes its own region of the output store, so there is nothing to merge)."""
+    devices = list(devices)
+    n = len(devices)
+    block_ids = list(block_ids)
+    bounds = np.linspace(0, len(block_ids), n + 1).astype(int)
+
+    def work(d):
+        for b in block_ids[bounds[d]:bounds[d + 1]]:
+            func(b, device=devices[d])
+
+    if n == 1:
+        work(0)
+        return
+    with ThreadPoolExecutor(max_workers=n) as ex:
+        list(ex.map(work, range(n)))
 
 
 def fuse_on_devices(sims, devices=(0,), **fuse_kwargs):

@@ -178,6 +178,7 @@ def fuse_np(
         if is_device_array(data):
             if data.dtype != input_dtype:
                 raise TypeError("all views of a chunk must share one dtype")
+            data = data.on_device(device)     # a tile resident on another GPU: peer copy, cached per (tile, device)
             fill_view_geometry(views[i], data.ptr, _lib.DTYPE_CODES[input_dtype], _lib.MVS_MEM_DEVICE,
                                data.shape, data.strides, matrix, offset)
         else:
@@ -225,6 +226,34 @@ def fuse_np(
     return result
 
 
+def _host_weighted_average_fusion(transformed_views, blending_weights, fusion_weights=None):
+    """weighted_average_fusion on host arrays (_core.py:61-94) -- used when a custom weights_func supplies fusion_weights."""
+    if fusion_weights is None:
+        additive = blending_weights
+    else:
+        additive = blending_weights * fusion_weights
+        wsum = np.nansum(additive, axis=0)            # weights.normalize_weights (weights.py:325-345)
+        wsum[wsum == 0] = 1
+        additive = additive / wsum
+    return np.nansum(transformed_views * additive, axis=0).astype(transformed_views[0].dtype)
+
+
+def _host_max_fusion(transformed_views):
+    """max_fusion on host arrays (_core.py:42-58)."""
+    return np.nanmax(transformed_views, axis=0)
+
+
+def _host_simple_average_fusion(transformed_views):
+    """simple_average_fusion on host arrays (_core.py:97-131)."""
+    nvalid = np.sum(~np.isnan(transformed_views), axis=0).astype(np.float32)
+    nvalid[nvalid == 0] = np.nan
+    return (np.nansum(transformed_views, axis=0) / nvalid).astype(transformed_views[0].dtype)
+
+
+_HOST_FUSION = {weighted_average_fusion: _host_weighted_average_fusion, max_fusion: _host_max_fusion,
+                simple_average_fusion: _host_simple_average_fusion}
+
+
 def has_keyword(func, keyword):
     """misc_utils.has_keyword (misc_utils.py:69-80): does ``func`` accept ``keyword``?"""
     import inspect
@@ -245,6 +274,9 @@ def _fuse_np_with_callables(sims, params, output_properties, fusion_func, fusion
     ``params``, ``output_spacing`` / ``output_chunksize`` when they ask for them)."""
     from .transformation import transform_sim
 
+    # A custom weights_func with one of the built-in fusion functions (the documented extension case, _core.py:1663-1690):
+    # the built-ins are kernel modes here, so their host form takes over behind the user's weights.
+    fusion_func = _HOST_FUSION.get(fusion_func, fusion_func) if not isinstance(fusion_func, str) else _HOST_FUSION[BUILTIN[fusion_func + "_fusion"]]
     fusion_func_kwargs = dict(fusion_func_kwargs or {})
     weights_func_kwargs = dict(weights_func_kwargs or {})
     sdims = si_utils.get_spatial_dims_from_sim(sims[0])
@@ -719,65 +751,125 @@ def fuse(
     if on_device and ns_shape and int(np.prod(ns_shape)) != 1:
         raise NotImplementedError("output_on_backend with several (c,t) fields")
 
+    # batch_options (_core.py:1068-1141, 2044-2156): with a Zarr output the reference hands batches of block ids to
+    # batch_func(fuse_chunk, block_ids, **batch_func_kwargs); fuse_chunk(block_id) fuses one block and writes its region
+    batch_options = dict(batch_options or {})
+    unknown = set(batch_options) - {"batch_func", "n_batch", "batch_func_kwargs"}
+    if unknown:
+        raise TypeError(f"unknown batch_options keys {sorted(unknown)}")
+    if batch_options and output_zarr_url is None:
+        raise ValueError("batch_options drive the block-wise Zarr output of fuse(); pass output_zarr_url as well")
+    if batch_options and chunk_filter is not None:
+        raise ValueError("batch_options and chunk_filter both select blocks; use one of them")
+
     plan_cache = {}
-    for ns_index in np.ndindex(*ns_shape) if ns_shape else [()]:
-        ns_sel = {d: int(i) for d, i in zip(nsdims, ns_index)}
-        it = ns_sel.get("t", 0)
-        sparams = [param_utils.select_time(p, it) for p in params]
+
+    def plan_for(it):
         key = it if any(np.asarray(p).ndim == 3 for p in params) else 0
         if key not in plan_cache:
-            plan_cache[key] = _build_spatial_fusion_plan(
+            sparams = [param_utils.select_time(p, it) for p in params]
+            plan_cache[key] = (sparams, _build_spatial_fusion_plan(
                 sparams=sparams, views_bb=views_bb, output_stack_properties=output_stack_properties,
                 output_chunksize=output_chunksize, output_chunk_bbs=chunk_bbs,
                 output_chunk_bbs_with_overlap=chunk_bbs_ov, output_chunk_bbs_for_result=chunk_bbs_res,
                 block_indices=block_indices, overlap_in_pixels=overlap_in_pixels, trim_overlap=trim_overlap,
                 interpolation_order=interpolation_order, sdims=sdims,
-            )
-        plan = plan_cache[key]
-        fields = [s.isel(ns_sel) for s in sims_]
+            ))
+        return plan_cache[key]
+
+    def chunk_call(ns_index, entry, dev):
+        """fuse_np arguments of one (field, block) and its window in the result."""
+        ns_sel = {d: int(i) for d, i in zip(nsdims, ns_index)}
+        sparams, _ = plan_for(ns_sel.get("t", 0))
+        bi = entry["block_index"]
+        cbb_ov = entry["output_bb_overlap"]
+        slabs = [_select_slab(s.isel(ns_sel), obb, sdims) for s, obb in ((sims_[iv], obb) for iv, obb in entry["views"])]
+        idxs = [iv for iv, _ in entry["views"]]
+        if entry["fuse_planewise"]:
+            slabs = [s.isel({"z": 0}) for s in slabs]
+            tmp_params = [sparams[iv][1:, 1:] for iv in idxs]
+            cbb_use = mv_graph.project_bb_along_dim(cbb_ov, "z")
+            fvb = [mv_graph.project_bb_along_dim(views_bb[iv], "z") for iv in idxs]
+        else:
+            tmp_params = [sparams[iv] for iv in idxs]
+            cbb_use = cbb_ov
+            fvb = [views_bb[iv] for iv in idxs]
+        sl = tuple(
+            slice(int(block_offsets[i][bi[i]]), int(block_offsets[i][bi[i]]) + int(entry["output_bb"]["shape"][d]))
+            for i, d in enumerate(sdims)
+        )
+        kwargs = dict(
+            sims=slabs, params=tmp_params, output_properties=cbb_use, fusion_func=fusion_func,
+            fusion_func_kwargs=fusion_func_kwargs, weights_func=weights_func,
+            weights_func_kwargs=weights_func_kwargs,
+            trim_overlap_in_pixels=(overlap_in_pixels if trim_overlap else 0),
+            interpolation_order=interpolation_order, full_view_bbs=fvb, blending_widths=blending_widths,
+            shrink_distance=shrink_distance, backend="hip", device=dev,
+        )
+        return kwargs, sl
+
+    if batch_options:
+        # ---- block-wise Zarr output driven by batch_func ----
+        nblocks = tuple(ns_shape) + tuple(len(c) for c in norm_chunks)
+        by_block_cache = {}
+
+        def fuse_chunk(block_id, device=device):
+            """Fuse block ``block_id`` (index into the chunk grid of the output array, non-spatial axes first) and write
+            it into its region of the output store; ``device`` lets a batch function place blocks on several GPUs."""
+            block_id = tuple(int(b) for b in block_id)
+            ns_index, bi = block_id[: len(ns_shape)], block_id[len(ns_shape):]
+            _, plan_t = plan_for({d: i for d, i in zip(nsdims, ns_index)}.get("t", 0))
+            by_block = by_block_cache.setdefault(id(plan_t), {tuple(e["block_index"]): e for e in plan_t["per_chunk_entries"]})
+            entry = by_block[bi]
+            if not entry["views"]:
+                return None      # the store's fill value (0) stands for blocks without contributing views
+            kwargs, sl = chunk_call(ns_index, entry, device)
+            chunk = np.asarray(fuse_np(**kwargs))
+            if entry["fuse_planewise"]:
+                chunk = chunk[np.newaxis]
+            zarr_out.write(list(ns_index) + [s_.start for s_ in sl], chunk.reshape((1,) * len(ns_index) + chunk.shape))
+            return None
+
+        batch_func = batch_options.get("batch_func")
+        n_batch = int(batch_options.get("n_batch", 1))
+        batch_func_kwargs = dict(batch_options.get("batch_func_kwargs") or {})
+        block_iter = iter(np.ndindex(*nblocks))
+        while True:
+            batch = [b for _, b in zip(range(n_batch), block_iter)]
+            if not batch:
+                break
+            if batch_func is None:
+                for block_id in batch:
+                    fuse_chunk(block_id)
+            else:
+                batch_func(fuse_chunk, batch, **batch_func_kwargs)
+    else:
+      for ns_index in np.ndindex(*ns_shape) if ns_shape else [()]:
+        ns_sel = {d: int(i) for d, i in zip(nsdims, ns_index)}
+        _, plan = plan_for(ns_sel.get("t", 0))
         dev_out = None
         if on_device:
             dev_out = DeviceArray.empty(out_shape_sp, dtype, device)
-            single = len(plan["per_chunk_entries"]) == 1
-            zeroed = False
+            entries = plan["per_chunk_entries"]
+            # one chunk that is actually fused over the whole array writes every voxel; in every other case (several chunks,
+            # a chunk without views, a chunk the filter rejects) untouched voxels must read 0 like the host result
+            single = (len(entries) == 1 and bool(entries[0]["views"])
+                      and (chunk_filter is None or chunk_filter(entries[0]["block_index"])))
+            if not single:
+                dev_out.fill_zero()
         for entry in plan["per_chunk_entries"]:
             bi = entry["block_index"]
             if chunk_filter is not None and not chunk_filter(bi):
                 continue
             if not entry["views"]:
                 continue
-            cbb_ov = entry["output_bb_overlap"]
-            slabs = [_select_slab(fields[iv], obb, sdims) for iv, obb in entry["views"]]
-            idxs = [iv for iv, _ in entry["views"]]
-            if entry["fuse_planewise"]:
-                slabs = [s.isel({"z": 0}) for s in slabs]
-                tmp_params = [sparams[iv][1:, 1:] for iv in idxs]
-                cbb_use = mv_graph.project_bb_along_dim(cbb_ov, "z")
-                fvb = [mv_graph.project_bb_along_dim(views_bb[iv], "z") for iv in idxs]
-            else:
-                tmp_params = [sparams[iv] for iv in idxs]
-                cbb_use = cbb_ov
-                fvb = [views_bb[iv] for iv in idxs]
-            sl = tuple(
-                slice(int(block_offsets[i][bi[i]]), int(block_offsets[i][bi[i]]) + int(entry["output_bb"]["shape"][d]))
-                for i, d in enumerate(sdims)
-            )
-            kwargs = dict(
-                sims=slabs, params=tmp_params, output_properties=cbb_use, fusion_func=fusion_func,
-                fusion_func_kwargs=fusion_func_kwargs, weights_func=weights_func,
-                weights_func_kwargs=weights_func_kwargs,
-                trim_overlap_in_pixels=(overlap_in_pixels if trim_overlap else 0),
-                interpolation_order=interpolation_order, full_view_bbs=fvb, blending_widths=blending_widths,
-                shrink_distance=shrink_distance, backend="hip", device=device,
-            )
+            kwargs, sl = chunk_call(ns_index, entry, device)
             if on_device and single:
-                fuse_np(out=dev_out, **kwargs)
+                # (a plane-wise entry is fused with 2D parameters: hand it the one plane of the 3D result)
+                fuse_np(out=dev_out[0] if entry["fuse_planewise"] else dev_out, **kwargs)
             elif on_device:
                 # chunked workflow with a device-resident mosaic: every chunk is fused on the device and copied into
                 # its window of the mosaic device-to-device (stream-ordered, no host round trip)
-                if not zeroed:
-                    dev_out.fill_zero()      # chunks without contributing views stay 0, like the host result
-                    zeroed = True
                 chunk = fuse_np(output_on_backend=True, **kwargs)
                 chunk.copy_into(dev_out, [s_.start for s_ in sl])
             else:

@@ -319,3 +319,35 @@ def test_user_callables_get_device_resampled_views(hip_device):
     assert seen["weights_args"][0] == (4,) + tuple(int(v) for v in out_bb["shape"]) and seen["weights_args"][2:] == (4, 2.0)
     assert seen["fusion_args"] == (np.dtype(np.float32), sorted(sdims), 4)
     np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4 * float(np.max(want)))
+
+
+@pytest.mark.parametrize("fusion_name", ["weighted_average_fusion", "max_fusion", "simple_average_fusion"])
+def test_custom_weights_func_with_builtin_fusion_func(hip_device, fusion_name):
+    """The documented extension case (_core.py:1663-1690, docs/extension_api_fusion.md): a user weights_func together with
+    a BUILT-IN fusion function.  Constant fusion weights must reproduce the plain built-in result; view-selecting weights
+    must reproduce that view."""
+    from multiview_stitcher_amd import fusion, spatial_image_utils as si
+
+    sims, params = _grid_case(2, np.float32, (1, 2), (40, 52), (0, 20), True, seed=2)
+    sdims = si.get_spatial_dims_from_sim(sims[0])
+    _, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(2))
+    ffunc = getattr(fusion, fusion_name)
+    kw = dict(full_view_bbs=[bb_to_dicts(b, sdims) for b in bbs])
+
+    def flat_weights(transformed_views):
+        return np.ones(transformed_views.shape, np.float32)
+
+    got = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), fusion_func=ffunc, weights_func=flat_weights, **kw)
+    want = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), fusion_func=ffunc, **kw)
+    np.testing.assert_allclose(got, want, rtol=2e-4, atol=2e-4 * float(np.max(want)))
+
+    if fusion_name == "weighted_average_fusion":
+        def first_view_only(transformed_views):
+            w = np.zeros(transformed_views.shape, np.float32)
+            w[0] = 1
+            return w
+
+        got1 = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), fusion_func=ffunc, weights_func=first_view_only, **kw)
+        only = fusion.fuse_np([sims[0]], [params[0]], bb_to_dicts(out_bb, sdims), fusion_func=ffunc, full_view_bbs=[bb_to_dicts(bbs[0], sdims)])
+        np.testing.assert_allclose(got1, only, rtol=2e-4, atol=2e-4 * float(np.max(only)))

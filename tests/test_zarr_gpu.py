@@ -126,3 +126,42 @@ def test_device_farm_streams_into_one_store(hip_device, tmp_path):
     assert not os.path.exists(os.path.join(url, "stale"))
     np.testing.assert_array_equal(np.asarray(out.data), want)
     assert len(ngff_utils.read_msim_from_ome_zarr(url).keys()) >= 2
+
+
+def test_batch_options_drive_block_wise_zarr_output(hip_device, tmp_path):
+    """fuse(..., output_zarr_url=, batch_options={"batch_func": f, "n_batch": k}) calls f(fuse_chunk, block_ids, **kw)
+    with every block id of the output chunk grid exactly once, in batches of k (fusion/_core.py:1123-1141;
+    misc_utils.py:150-158), and fuse_chunk(block_id) writes that block's region.  The built-in GPU batch function gives
+    the same store."""
+    from multiview_stitcher_amd import executors, fusion, sample_data
+
+    key = sample_data.METADATA_TRANSFORM_KEY
+    sims = _dataset(3)
+    chunks = {"z": 32, "y": 96, "x": 128}
+    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks).data)
+    seen, batch_sizes = [], []
+
+    def spy(fuse_chunk, block_ids, tag=None):
+        assert tag == "t"
+        batch_sizes.append(len(block_ids))
+        for b in block_ids:
+            seen.append(tuple(b))
+            assert fuse_chunk(b) is None
+
+    fused = fusion.fuse(sims, transform_key=key, output_chunksize=chunks, output_zarr_url=str(tmp_path / "a.zarr"),
+                        batch_options={"batch_func": spy, "n_batch": 4, "batch_func_kwargs": {"tag": "t"}})
+    grid = tuple(-(-n // c) for n, c in zip(want.shape, [1, 1] + [chunks[d] for d in "zyx"]))
+    assert sorted(seen) == sorted(np.ndindex(*grid)) and len(seen) == len(set(seen))
+    assert all(b == 4 for b in batch_sizes[:-1]) and 1 <= batch_sizes[-1] <= 4
+    np.testing.assert_array_equal(np.asarray(fused.data), want)
+
+    fused2 = fusion.fuse(sims, transform_key=key, output_chunksize=chunks, output_zarr_url=str(tmp_path / "b.zarr"),
+                         zarr_options={"ome_zarr": True},
+                         batch_options={"batch_func": executors.process_batch_using_gpus, "n_batch": 6,
+                                        "batch_func_kwargs": {"devices": (0, 0 | (1 << 8))}})
+    np.testing.assert_array_equal(np.asarray(fused2.data), want)
+
+    with pytest.raises(ValueError):
+        fusion.fuse(sims, transform_key=key, batch_options={"n_batch": 2})           # needs output_zarr_url
+    with pytest.raises(TypeError):
+        fusion.fuse(sims, transform_key=key, output_zarr_url=str(tmp_path / "c.zarr"), batch_options={"nbatch": 2})
