@@ -5,14 +5,22 @@ Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE 
 rank 0.  For N>1 it is launched by ``python -m torch.distributed.run`` with one rank per GPU.
 
 Workload (BASELINE.json north_star): a 4x4x4 grid of 512^3 uint16 tiles, 20 % overlap, per-tile
-integer jitter unknown to the stage metadata; one "step" = pairwise phase-correlation registration
-of all face-neighbour pairs + fusion of the whole mosaic (cosine-blend weighted average), tiles
-resident in HBM.  Each rank owns one such mosaic (independent positions of a multi-position
-acquisition): units shard with no data-path collective -> "scaling": "weak".
+integer jitter unknown to the stage metadata; one "step" = registration.register (overlap graph,
+pruning, pairwise phase-correlation registration of the kept pairs, groupwise resolution) + fusion of
+the whole mosaic (cosine-blend weighted average), tiles resident in HBM.
 
-value   = fused output Mvoxels/s over all ranks (register + fuse time, max over ranks)
+N > 1, --mode shard (default): ONE mosaic over the N GPUs -- every rank owns a brick of tiles (+ a
+one-tile halo fetched once by point-to-point sends, RCCL), registers the pairs whose fixed view it
+owns, the pairwise results (kB) are all-gathered, the resolution runs replicated and every rank
+fuses its sub-box of the output: no data-path collective, "scaling": "strong".
+--mode replica: one mosaic per rank (independent positions), "scaling": "weak".
+
+value   = fused output Mvoxels/s of the whole job (register + fuse time, max over ranks)
 roofline = algorithmic HBM bytes of the dominant kernel (fuse: every input voxel once + every
            output voxel once) / its HIP-event duration, vs 8 TB/s
+roofline_register = algorithmic bytes of the pairwise registrations / their wall time
+value_incl_pcie = the same mosaic with tiles starting and the result ending in pinned host memory
+           (uploads overlapped with registration, downloads with fusion), N = 1 only
 cpu_baseline = the numpy/scipy oracle timed on this box on a bounded sample (rank 0, N=1 only)
 """
 import argparse
@@ -41,6 +49,12 @@ def parse_args():
     ap.add_argument("--reg-threads", type=int, default=None, help="host threads / context lanes for the pairwise registrations (library default: 8)")
     ap.add_argument("--no-register", action="store_true", help="time fusion only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["shard", "replica"], default=None,
+                    help="N > 1: 'shard' (default) = ONE mosaic, tiles / pairs / output sub-boxes partitioned over the ranks "
+                         "(strong scaling); 'replica' = one mosaic per rank (weak scaling)")
+    ap.add_argument("--pruning", default="alternating_pattern",
+                    help="pre_registration_pruning_method (reference default: alternating_pattern)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pipeline leg (N = 1 only)")
     return ap.parse_args()
 
 
@@ -89,13 +103,18 @@ def make_mosaic_on_device(torch, dev, grid, tile, overlap, seed, max_jitter=3, r
     return tiles, np.array(jitters), np.array(origins)
 
 
-def build_sims(tiles, origins, dev_index):
+def build_sims(tiles, origins, dev_index, tile_shape=None):
+    """SpatialImages over the device tiles; a tile this rank does not hold (None) becomes a metadata-only RemoteArray."""
     from multiview_stitcher_amd import spatial_image_utils as si
     from multiview_stitcher_amd.device import DeviceArray
+    from multiview_stitcher_amd.sharding import RemoteArray
 
     sims = []
     for t, o in zip(tiles, origins):
-        da = DeviceArray.from_pointer(t.data_ptr(), tuple(t.shape), np.uint16, dev_index, owner=t)
+        if t is None:
+            da = RemoteArray(tuple(int(v) for v in tile_shape), np.uint16)
+        else:
+            da = DeviceArray.from_pointer(t.data_ptr(), tuple(t.shape), np.uint16, dev_index, owner=t)
         sim = si.to_spatial_image(da, dims=["z", "y", "x"], scale={"z": 1.0, "y": 1.0, "x": 1.0},
                                   translation=dict(zip("zyx", o)))
         si.set_sim_affine(sim, np.eye(4), si.DEFAULT_TRANSFORM_KEY)
@@ -103,10 +122,26 @@ def build_sims(tiles, origins, dev_index):
     return sims
 
 
+def _cpu_fuse_task(views, params, bbs, sub_bb):
+    from oracle import fuse_oracle as fo
+
+    fo.fuse_np(list(views), params, sub_bb, full_view_bbs=list(bbs))
+    return float(np.prod(sub_bb["shape"]))
+
+
+def _cpu_pair_task(a, b):
+    from oracle import reg_oracle as ro
+
+    ro.phase_correlation_registration(a, b)
+    return 0.0
+
+
 def cpu_baseline(args, grid, tile, overlap):
-    """Time the numpy/scipy oracle (the reference's own scipy calls, 1 thread) on a bounded sample of the same
-    workload in the metric's unit: a 2x2x2 mosaic of small tiles with the same overlap fraction, fused whole, plus
-    its 12 face-neighbour registrations (one pair per axis orientation is timed, x4)."""
+    """Time the numpy/scipy oracle (the reference's own scipy calls) on a bounded sample of the same workload in the
+    metric's unit: a 2x2x2 mosaic of small tiles with the same overlap fraction, fused whole, plus its 12
+    face-neighbour registrations (one pair per axis orientation is timed, x4) -- once on ONE core and once farmed over
+    all host cores with joblib/loky, the reference's own recipe for parallel fusion (misc_utils.py:184-209,
+    docs/fusion_overview.md:185-203): the output is cut into chunks, every chunk and every pair is one task."""
     from multiview_stitcher_amd import sample_data
     from oracle import fuse_oracle as fo
     from oracle import reg_oracle as ro
@@ -123,20 +158,55 @@ def cpu_baseline(args, grid, tile, overlap):
     fused = fo.fuse_np(list(views), params, out_bb, full_view_bbs=list(bbs))
     t_fuse = time.perf_counter() - t0
     vox = float(np.prod(np.asarray(fused[0] if isinstance(fused, tuple) else fused).shape))
-    t_pairs = []
+    t_pairs, pairs = [], []
     for axis in range(3):                           # overlap crops of a z-, y- and x-face pair
         a, b = ro.make_pair_for_bench(ts, ov, seed=3 + axis)
         a, b = np.ascontiguousarray(np.moveaxis(a, -1, axis)), np.ascontiguousarray(np.moveaxis(b, -1, axis))
+        pairs.append((a, b))
         t0 = time.perf_counter()
         ro.phase_correlation_registration(a, b)
         t_pairs.append(time.perf_counter() - t0)
     t_reg = 4.0 * float(np.sum(t_pairs))            # 12 face pairs in a 2x2x2 grid, 4 per orientation
-    return {"value": vox / (t_reg + t_fuse) / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
-            "sample": f"oracle (numpy + scipy 1.15: the reference's own affine_transform / fft / uniform_filter / spearmanr calls), "
-                      f"1 thread, on a 2x2x2 mosaic of uint16 tiles {ts.tolist()}, overlap {ov.tolist()}: fuse of the whole "
-                      f"{int(vox)}-voxel mosaic {t_fuse:.1f} s + 12 pair registrations {t_reg:.1f} s (3 timed, one per axis "
-                      f"orientation, {np.round(t_pairs, 2).tolist()} s, x4)",
-            "fuse_only_mvoxels_s": vox / t_fuse / 1e6, "register_pair_s": float(np.mean(t_pairs))}
+    out = {"value": vox / (t_reg + t_fuse) / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
+           "sample": f"oracle (numpy + scipy 1.15: the reference's own affine_transform / fft / uniform_filter / spearmanr calls), "
+                     f"1 thread, on a 2x2x2 mosaic of uint16 tiles {ts.tolist()}, overlap {ov.tolist()}: fuse of the whole "
+                     f"{int(vox)}-voxel mosaic {t_fuse:.1f} s + 12 pair registrations {t_reg:.1f} s (3 timed, one per axis "
+                     f"orientation, {np.round(t_pairs, 2).tolist()} s, x4)",
+           "fuse_only_mvoxels_s": vox / t_fuse / 1e6, "register_pair_s": float(np.mean(t_pairs))}
+    # ---- all cores: chunk / pair farm with joblib (loky processes, BLAS / pocketfft threads pinned to 1 per worker) ----
+    try:
+        from joblib import Parallel, delayed
+
+        ncores = len(os.sched_getaffinity(0))
+        shp = np.asarray(out_bb["shape"])
+        cuts = [np.linspace(0, n, 3).astype(int) for n in shp]          # 2 x 2 x 2 output chunks
+        subs = []
+        for idx in np.ndindex(2, 2, 2):
+            lo = np.array([cuts[k][i] for k, i in enumerate(idx)])
+            hi = np.array([cuts[k][i + 1] for k, i in enumerate(idx)])
+            subs.append(fo.bb(out_bb["origin"] + lo * out_bb["spacing"], out_bb["spacing"], hi - lo))
+        tasks = [delayed(_cpu_fuse_task)(views, params, bbs, sb) for sb in subs]
+        tasks += [delayed(_cpu_pair_task)(*pairs[k % 3]) for k in range(12)]
+        env = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+        for k in env:
+            os.environ[k] = "1"
+        try:
+            with Parallel(n_jobs=min(ncores, len(tasks)), backend="loky") as par:
+                par([delayed(_cpu_pair_task)(*(x[:8, :8, :8] for x in pairs[0]))] * min(ncores, len(tasks)))   # spawn + import the workers, untimed
+                t0 = time.perf_counter()
+                par(tasks)
+                t_all = time.perf_counter() - t0
+        finally:
+            for k, v in env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        out["all_cores"] = {"value": vox / t_all / 1e6, "unit": "Mvoxels/s", "cores": ncores, "workers": min(ncores, len(tasks)),
+                            "wall_s": t_all, "sample": "the same mosaic as 8 output-chunk tasks + 12 pair tasks, joblib loky"}
+    except Exception as e:      # noqa: BLE001 - the baseline must not take the bench line down
+        out["all_cores"] = {"error": repr(e)[:200]}
+    return out
 
 
 def fuse_traffic_bytes(grid, tile):
@@ -150,6 +220,89 @@ def fuse_traffic_bytes(grid, tile):
     except (OSError, KeyError, ValueError):
         pass
     return None
+
+
+def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
+    """PCIe-inclusive run of one mosaic: the tiles start in pinned host memory and the fused mosaic ends
+    there.  Uploads run on a copy stream in tile order while the pairs whose two tiles have arrived are registered;
+    the mosaic is fused in z slabs and every finished slab is downloaded while the next one is fused."""
+    from multiview_stitcher_amd import _lib, fusion, registration, sharding
+    from multiview_stitcher_amd import spatial_image_utils as si
+
+    host_tiles = []
+    for t in tiles:
+        h = torch.empty(t.shape, dtype=torch.int16, pin_memory=True)
+        h.copy_(t.view(torch.int16))
+        host_tiles.append(h)
+    torch.cuda.synchronize()
+    copy_stream = torch.cuda.Stream(device=dev)
+    n_slabs = 4
+
+    def run():
+        events = []
+        t0 = time.perf_counter()
+        with torch.cuda.stream(copy_stream):
+            for t, h in zip(tiles, host_tiles):
+                t.view(torch.int16).copy_(h, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+                events.append(ev)
+
+        def executor(msims, edges, register_kwargs):
+            order = sorted(range(len(edges)), key=lambda k: max(edges[k]))
+            results = [None] * len(edges)
+            kw = dict(register_kwargs)
+            tk, rb, ot = kw.pop("transform_key"), kw.pop("registration_binning", None), kw.pop("overlap_tolerance", 0.0)
+            prf, prk = kw.pop("pairwise_reg_func"), kw.pop("pairwise_reg_func_kwargs", None)
+            wave = max(1, len(order) // 8)
+            for a in range(0, len(order), wave):
+                ks = order[a:a + wave]
+                events[max(max(edges[k]) for k in ks)].synchronize()      # both tiles of every pair of this wave are resident
+                part = registration.compute_pairwise_registrations(msims, [edges[k] for k in ks], tk, rb, ot, prf, prk, None,
+                                                                   local_rank, host_threads=8)
+                for k, r in zip(ks, part):
+                    results[k] = r
+            return results
+
+        registration.register(sims, transform_key=key_in, new_transform_key=key_out, device=local_rank,
+                              pre_registration_pruning_method=args.pruning, pairwise_executor=executor)
+        t_reg = time.perf_counter()
+        osp = fusion._bb_dicts(fusion.process_output_stack_properties(sims, None, None, None, None, "union", key_out), ["z", "y", "x"])
+        nz = int(osp["shape"]["z"])
+        cuts = np.linspace(0, nz, n_slabs + 1).round().astype(int)
+        host_slabs, keep = [], []
+        for k in range(n_slabs):
+            sub = {"origin": dict(osp["origin"], z=osp["origin"]["z"] + cuts[k] * osp["spacing"]["z"]), "spacing": osp["spacing"],
+                   "shape": dict(osp["shape"], z=int(cuts[k + 1] - cuts[k]))}
+            fused = fusion.fuse(sims, transform_key=key_out, output_stack_properties=sub, output_chunksize={d: 1 << 30 for d in "zyx"},
+                                output_on_backend=True, device=local_rank)
+            _lib.synchronize(local_rank)
+            d = torch.as_tensor(_SignedView(fused.data), device="cuda")
+            if len(host_slabs) <= k:
+                host_slabs.append(torch.empty(d.shape, dtype=torch.int16, pin_memory=True))
+            with torch.cuda.stream(copy_stream):
+                host_slabs[k].copy_(d, non_blocking=True)
+            keep.append((fused, d))
+        copy_stream.synchronize()
+        t1 = time.perf_counter()
+        vox = float(nz) * osp["shape"]["y"] * osp["shape"]["x"]
+        return t1 - t0, t_reg - t0, vox, host_slabs
+
+    run()                                  # warm-up (pinned result buffers, plans)
+    total, t_reg, vox, _ = run()
+    h2d_gb = sum(t.numel() * 2 for t in tiles) / 1e9
+    return {"value": vox / total / 1e6, "unit": "Mvoxels/s", "ms": total * 1e3, "register_phase_ms": t_reg * 1e3,
+            "h2d_gb": h2d_gb, "d2h_gb": vox * 2 / 1e9, "fuse_slabs": n_slabs,
+            "note": "tiles in pinned host memory -> async uploads in tile order overlapped with the registration of the pairs "
+                    "already resident -> resolution -> fuse in z slabs, each slab's download overlapped with the next slab's fuse"}
+
+
+class _SignedView:
+    """torch's __cuda_array_interface__ import has no uint16: hand the bytes over as int16."""
+
+    def __init__(self, arr):
+        self.__cuda_array_interface__ = dict(arr.__cuda_array_interface__, typestr="<i2")
+        self.owner = arr
 
 
 def main():
@@ -174,34 +327,64 @@ def main():
             dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    mode = args.mode or "shard"
+    shard = world > 1 and mode == "shard"
 
-    from multiview_stitcher_amd import _lib, fusion
+    from multiview_stitcher_amd import _lib, fusion, mv_graph, sharding
     from multiview_stitcher_amd import spatial_image_utils as si
+    from multiview_stitcher_amd.device import DeviceArray
 
     _lib.init(local_rank)
     grid = np.array([int(v) for v in args.grid.split(",")])
     tile = np.array([int(v) for v in args.tile.split(",")])
     overlap = np.round(tile * args.overlap_frac).astype(int)
 
-    tiles, jitters, origins = make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=1000 + rank)
-    sims = build_sims(tiles, origins, local_rank)
+    # shard: every rank cuts the SAME mosaic (same seed) and keeps only the tiles it owns; replica: one mosaic per rank
+    tiles, jitters, origins = make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=1000 + (0 if shard else rank))
+    key_in, key_out = si.DEFAULT_TRANSFORM_KEY, "registered"
+    executor, halo_ms, n_held = None, None, len(tiles)
+    if shard:
+        sps = [{"origin": dict(zip("zyx", o)), "spacing": dict(zip("zyx", [1.0] * 3)), "shape": dict(zip("zyx", [int(v) for v in tile]))} for o in origins]
+        affs = [np.eye(4) for _ in origins]
+        osp0 = _union_stack(sps)
+        boxes, counts = sharding.output_subboxes(osp0, world)
+        owners = sharding.tile_owners(sps, affs, boxes)
+        g = mv_graph.build_view_adjacency_graph([dict(sp, transform=a) for sp, a in zip(sps, affs)], overlap_tolerance=None)
+        g = mv_graph.prune_view_adjacency_graph(g, args.pruning, None)
+        edges = [tuple(sorted(e)) for e in g.edges()]
+        needs = [sharding.rank_tiles(sps, affs, boxes, edges, owners, r, margin=8.0) for r in range(world)]
+        held = [t if owners[v] == rank else None for v, t in enumerate(tiles)]
+        del tiles
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        held = sharding.exchange_halo(torch, dist, held, owners, needs, rank, world, dev, via_host=(backend != "nccl"))
+        torch.cuda.synchronize()
+        halo_ms = (time.perf_counter() - t0) * 1e3
+        tiles = held
+        n_held = sum(t is not None for t in tiles)
+        executor = sharding.ShardedPairExecutor(rank, world, owners, device=local_rank)
+    sims = build_sims(tiles, origins, local_rank, tile_shape=tile)
     torch.cuda.synchronize()
 
     do_register = not args.no_register
     registration = None
     if do_register:
-        try:
-            from multiview_stitcher_amd import registration  # noqa: F811
-            if not hasattr(registration, "register"):
-                raise ImportError("register() not available")
-        except ImportError:
-            registration, do_register = None, False
+        from multiview_stitcher_amd import registration  # noqa: F811
 
-    key_in, key_out = si.DEFAULT_TRANSFORM_KEY, "registered"
     out_holder = {}
-    kernel_ms = []
-    reg_ms = []
-    fuse_ms = []
+    kernel_ms, reg_ms, fuse_ms, pair_ms, plan_ms = [], [], [], [], []
+    if do_register:
+        inner = registration.compute_pairwise_registrations
+
+        def timed_pairs(*a, **k):
+            t0 = time.perf_counter()
+            try:
+                return inner(*a, **k)
+            finally:
+                pair_ms[-1] += (time.perf_counter() - t0) * 1e3
+        registration.compute_pairwise_registrations = timed_pairs
 
     def step():
         # the previous step's mosaic is released before the next one is fused (as a consumer would), so the 10 GB
@@ -209,25 +392,34 @@ def main():
         out_holder.clear()
         t_reg0 = time.perf_counter()
         key = key_in
+        pair_ms.append(0.0)
         if do_register:
             registration.register(sims, transform_key=key_in, new_transform_key=key_out, device=local_rank,
-                                  pre_registration_pruning_method="keep_axis_aligned",
+                                  pre_registration_pruning_method=args.pruning, pairwise_executor=executor,
                                   n_parallel_pairwise_regs=args.reg_threads)
             key = key_out
         t_reg1 = time.perf_counter()
-        fused = fusion.fuse(sims, transform_key=key, output_chunksize={d: 1 << 30 for d in "zyx"},
-                            output_on_backend=True, device=local_rank)
+        if shard:
+            fused, _ = sharding.fuse_shard(sims, rank, world, key, output_chunksize={d: 1 << 30 for d in "zyx"},
+                                           output_on_backend=True, device=local_rank)
+        else:
+            fused = fusion.fuse(sims, transform_key=key, output_chunksize={d: 1 << 30 for d in "zyx"},
+                                output_on_backend=True, device=local_rank)
         out_holder["fused"] = fused
         kernel_ms.append(_lib.last_kernel_ms(local_rank))   # blocks until the fuse kernels are done
+        plan_ms.append(_lib.get_counter("fuse_plan_ms", local_rank))
         reg_ms.append((t_reg1 - t_reg0) * 1e3)
         fuse_ms.append((time.perf_counter() - t_reg1) * 1e3)
         return fused
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 0)):
         step()
-    kernel_ms.clear()
-    reg_ms.clear()
-    fuse_ms.clear()
+    cold_plan_ms = plan_ms[0] if plan_ms else None      # the first call of a geometry builds (and caches) the decomposition
+    for lst in (kernel_ms, reg_ms, fuse_ms, pair_ms, plan_ms):
+        lst.clear()
+    for lane in range(16):
+        for key in ("reg_alg_bytes", "reg_pairs", "reg_candidates"):
+            _lib.get_counter(key, local_rank | (lane << 8), reset=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -242,23 +434,51 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    reg_bytes = sum(_lib.get_counter("reg_alg_bytes", local_rank | (lane << 8)) for lane in range(16))
+    reg_pairs = sum(_lib.get_counter("reg_pairs", local_rank | (lane << 8)) for lane in range(16))
+    reg_cands = sum(_lib.get_counter("reg_candidates", local_rank | (lane << 8)) for lane in range(16))
 
     fused = out_holder["fused"]
     out_shape = fused.shape
-    out_vox = float(np.prod(out_shape))
-    in_vox = float(len(tiles) * np.prod(tile))
+    out_vox_local = float(np.prod(out_shape))
     es = 2
-    alg_bytes = in_vox * es + out_vox * es
+    # algorithmic bytes of THIS rank's fuse launch: every input voxel that reaches into its output box once + every
+    # output voxel once (N = 1: all tiles + the whole mosaic)
+    fo_ = si.get_origin_from_sim(fused, asarray=True)
+    in_vox_local = 0.0
+    from multiview_stitcher_amd import param_utils
+    for s_, t_ in zip(sims, tiles):
+        if t_ is None:
+            continue
+        p = param_utils.select_time(si.get_affine_from_sim(s_, key_out if do_register else key_in), 0)
+        lo = si.get_origin_from_sim(s_, asarray=True) + p[:3, 3]
+        hi = lo + (tile - 1)
+        ilo, ihi = np.maximum(lo, fo_), np.minimum(hi, fo_ + np.asarray(out_shape) - 1)
+        if np.all(ihi >= ilo):
+            in_vox_local += float(np.prod(np.floor(ihi - ilo) + 1))
+    alg_bytes = in_vox_local * es + out_vox_local * es
     k_ms = float(np.mean(kernel_ms))
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     ms_per_step = elapsed / args.steps * 1e3
-    value = out_vox * world / (elapsed / args.steps) / 1e6
+    if world > 1:
+        tv = torch.tensor([out_vox_local], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tv, op=dist.ReduceOp.SUM)
+        out_vox_total = float(tv.item())
+    else:
+        out_vox_total = out_vox_local
+    value = out_vox_total / (elapsed / args.steps) / 1e6
 
     reg_err = None
     if do_register:
-        from multiview_stitcher_amd import param_utils
         rec = np.array([param_utils.select_time(si.get_affine_from_sim(s, key_out), 0)[:3, 3] for s in sims])
         reg_err = float(np.max(np.abs((rec - rec[0]) - (jitters - jitters[0]))))   # relative to tile 0: the resolver fixes its own reference view
+    pair_wall_ms = float(np.mean(pair_ms)) if do_register else None      # (before the PCIe leg, which registers again)
+    pcie = None
+    if world == 1 and do_register and not args.no_pcie:
+        try:
+            pcie = pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out)
+        except Exception as e:   # noqa: BLE001 - an optional leg must not take the bench line down
+            pcie = {"error": repr(e)[:300]}
     if rank == 0:
         result = {
             "metric": "Mvoxels/s register+fuse, 3D tile grid" if do_register else "Mvoxels/s fuse only, 3D tile grid",
@@ -269,31 +489,53 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if shard else "weak",
             "vs_baseline": None,
             "dtype": "u16 in/out, f32 accumulate, f64 coordinates",
             "data": "synthetic (seeded smoothed noise mosaic generated in HBM, integer jitter unknown to metadata)",
+            "value_incl_pcie": pcie,
             "config": {
                 "workload": f"{'x'.join(map(str, grid))} grid (z,y,x) of {'x'.join(map(str, tile))} uint16 tiles, "
                             f"{int(args.overlap_frac * 100)}% overlap, "
-                            + ("phase-correlation register of face-neighbour pairs + " if do_register else "")
-                            + "cosine-blend weighted-average fuse; one mosaic per GPU",
-                "output_shape": [int(s) for s in out_shape],
-                "tiles_per_gpu": len(tiles),
+                            + (f"register (overlap graph, pre_registration_pruning_method={args.pruning!r}, phase-correlation "
+                               f"registration of the kept pairs, global_optimization resolution) + " if do_register else "")
+                            + "cosine-blend weighted-average fuse; "
+                            + ("ONE mosaic sharded over the ranks (tile bricks + halo, pairs by owner of the fixed view, output sub-boxes)"
+                               if shard else "one mosaic per GPU"),
+                "mode": "shard" if shard else ("replica" if world > 1 else "single"),
+                "output_shape_rank0": [int(s) for s in out_shape],
+                "tiles_held_rank0": int(n_held),
+                "halo_exchange_ms": halo_ms,
                 "register_ms_per_step": float(np.mean(reg_ms)) if do_register else None,
+                "pairwise_ms_per_step": pair_wall_ms,
+                "pairs_per_step_rank0": reg_pairs / max(args.steps, 1) if do_register else None,
+                "scored_candidates_per_pair": (reg_cands / reg_pairs) if reg_pairs else None,
                 "fuse_ms_per_step": float(np.mean(fuse_ms)),
                 "fuse_kernel_ms": k_ms,
+                "fuse_plan_cold_ms": cold_plan_ms,
                 "registration_max_abs_error_px": reg_err,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fuse launch = copy_region_kernel + fuse_region_kernel<1|2|4|8> (u16) side by side on forked streams, timed as one unit (first start to last end)",
+                "kernel": "fuse launch of rank 0 = copy_region_kernel + fuse_region_kernel<1|2|4|8> (u16) side by side on forked streams, timed as one unit (first start to last end)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": fuse_traffic_bytes(grid, tile),
+                "traffic": fuse_traffic_bytes(grid, tile) if world == 1 else None,
                 "algorithmic_bytes_per_launch": alg_bytes,
+            },
+            "roofline_register": None if not (do_register and reg_pairs) else {
+                "bound": "hbm",
+                "kernel": "pairwise registrations of rank 0 (binning, crops, FFTs, cross power, argmax, upsampled DFT, shifts, SSIM, ranks)",
+                "algorithmic_bytes_per_step": reg_bytes / args.steps,
+                "model": "SURVEY 8d: per pair of n binned overlap voxels 2 x 28 n (phase correlation, two normalisations) + 20 n per scored candidate + 64 n (rank correlation)",
+                "duration_ms": pair_wall_ms,
+                "achieved": reg_bytes / args.steps / (pair_wall_ms * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": reg_bytes / args.steps / (pair_wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "duration = wall time of compute_pairwise_registrations (kernels of 8 context lanes overlap; includes host round trips)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -303,6 +545,14 @@ def main():
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _union_stack(sps):
+    """Output stack of axis-aligned unit-spacing views: the union box (fusion.calc_fusion_stack_properties on metadata)."""
+    lo = np.min([[sp["origin"][d] for d in "zyx"] for sp in sps], axis=0)
+    hi = np.max([[sp["origin"][d] + (sp["shape"][d] - 1) * sp["spacing"][d] for d in "zyx"] for sp in sps], axis=0)
+    shape = np.floor((hi - lo) + 1e-9).astype(int) + 1
+    return {"origin": dict(zip("zyx", lo.tolist())), "spacing": dict(zip("zyx", [1.0] * 3)), "shape": dict(zip("zyx", shape.tolist()))}
 
 
 if __name__ == "__main__":

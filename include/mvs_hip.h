@@ -108,6 +108,11 @@ int mvs_synchronize(int device);
  * row-owning kernel (uint16, one tap per view; mvs_fuse_rowlds.hip) is tried first.  Both opt-in paths must agree with
  * the default ones (tests compare all of them with the oracle). */
 int mvs_set_option(int device, const char* key, int64_t value);
+/* Measurement counters of one context (bench.py): "reg_alg_bytes" = algorithmic HBM bytes of the pairwise registrations
+ * since the last reset (28 n per phase-correlation variant + 20 n per scored candidate + 64 n for the rank correlation, n = crop
+ * voxels), "reg_pairs", "reg_candidates", "fuse_plan_ms" = host time the last mvs_fuse_chunk spent decomposing the chunk
+ * (0 when the plan cached for the same geometry was reused).  reset != 0 clears an accumulating counter after reading. */
+int mvs_get_counter(int device, const char* key, int32_t reset, double* value_out);
 /* Device time (ms, hipEvent) spent in the kernels of the most recent compute
  * call on this device; blocks until that work has finished. */
 double mvs_last_kernel_ms(int device);

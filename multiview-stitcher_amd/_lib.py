@@ -66,6 +66,7 @@ SIGNATURES = {
     "mvs_set_stream": (C.c_int, [C.c_int, C.c_void_p]),
     "mvs_synchronize": (C.c_int, [C.c_int]),
     "mvs_set_option": (C.c_int, [C.c_int, C.c_char_p, C.c_int64]),
+    "mvs_get_counter": (C.c_int, [C.c_int, C.c_char_p, C.c_int32, C.POINTER(C.c_double)]),
     "mvs_memcpy_peer": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]),
     "mvs_last_kernel_ms": (C.c_double, [C.c_int]),
     "mvs_malloc": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
@@ -216,6 +217,13 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def get_counter(key, device=0, reset=False):
+    """mvs_get_counter: a measurement counter of context ``device`` (see include/mvs_hip.h)."""
+    v = C.c_double()
+    check(init(device).mvs_get_counter(int(device), key.encode(), 1 if reset else 0, C.byref(v)), device, "mvs_get_counter")
+    return float(v.value)
 
 
 def set_option(key, value, device=0):

@@ -100,6 +100,10 @@ static void pool_flush(MvsContext* c) {
     c->pool_cached_bytes = 0;
 }
 
+double mvs_rows_last_plan_ms(MvsContext* c);       // mvs_fuse_rows.hip
+double mvs_rowlds_last_plan_ms(MvsContext* c);     // mvs_fuse_rowlds.hip
+double mvs_regions_last_plan_ms(MvsContext* c);    // mvs_fuse_region.hip
+
 extern "C" {
 
 const char* mvs_version(void) { return "mvs_hip 0.1 (gfx950)"; }
@@ -232,6 +236,25 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         return MVS_OK;
     }
     return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_set_option: unknown key '%s'", key);
+}
+
+// Measurement counters of one context: "reg_alg_bytes" (algorithmic HBM bytes of the pairwise registrations),
+// "reg_pairs", "reg_candidates" (scored candidates), "fuse_plan_ms" (host time of the last fuse decomposition; 0 when the
+// cached plan was reused).  reset != 0 clears the accumulating ones after reading.
+int mvs_get_counter(int device, const char* key, int32_t reset, double* value_out) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    if (!key || !value_out) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_get_counter: NULL argument");
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    if (!strcmp(key, "reg_alg_bytes")) { *value_out = c->reg_alg_bytes; if (reset) c->reg_alg_bytes = 0.0; return MVS_OK; }
+    if (!strcmp(key, "reg_pairs")) { *value_out = (double)c->reg_pairs; if (reset) c->reg_pairs = 0; return MVS_OK; }
+    if (!strcmp(key, "reg_candidates")) { *value_out = (double)c->reg_candidates; if (reset) c->reg_candidates = 0; return MVS_OK; }
+    if (!strcmp(key, "fuse_plan_ms")) {
+        *value_out = mvs_rows_last_plan_ms(c) + mvs_rowlds_last_plan_ms(c) + mvs_regions_last_plan_ms(c);
+        return MVS_OK;
+    }
+    return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_get_counter: unknown key '%s'", key);
 }
 
 int mvs_synchronize(int device) {

@@ -17,6 +17,7 @@
 #include "mvs_fuse_tr.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -844,6 +845,7 @@ struct PlanCache {
     bool valid = false;
 };
 PlanCache g_plan[MVS_MAX_DEVICES * MVS_MAX_LANES];
+double g_region_plan_ms[MVS_MAX_DEVICES * MVS_MAX_LANES];
 
 unsigned long long fnv1a(const void* p, size_t n, unsigned long long h) {
     const unsigned char* b = (const unsigned char*)p;
@@ -917,6 +919,8 @@ void axis_breakpoints(const TrView* htr, int n_views, int d, int t, int o, std::
 }
 }  // namespace
 
+double mvs_regions_last_plan_ms(MvsContext* c) { return g_region_plan_ms[mvs_ctx_index(c->device)]; }
+
 // Returns MVS_OK and sets *done = true when the chunk was fused by the region kernel; *done = false means the
 // caller must use the column kernel (more than kMaxRV views on one region, or too many regions/bricks).
 int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_views, int dtype, void* dout, const int64_t os[3],
@@ -928,6 +932,8 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
     h = fnv1a(t, sizeof(t), h);
     h = fnv1a(o, sizeof(o), h);
     PlanCache& pc = g_plan[mvs_ctx_index(c->device)];
+    g_region_plan_ms[mvs_ctx_index(c->device)] = 0.0;
+    const auto t_plan0 = std::chrono::steady_clock::now();
     char* dbuf = nullptr;
     int nitems = 0;
     size_t rbytes = 0;
@@ -1066,6 +1072,7 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
         pc.nitems = nitems;
         pc.rbytes = rbytes;
         pc.valid = true;
+        g_region_plan_ms[mvs_ctx_index(c->device)] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan0).count();
     }
     RegionParams P;
     P.views = dtr;

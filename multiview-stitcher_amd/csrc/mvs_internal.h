@@ -35,6 +35,10 @@ struct MvsContext {
     bool timing_valid = false;
     int ablate = 0;               // profiling only (see FuseParams)
     bool force_generic = false;   // debug/test switch: never take the translation fast path
+    // measurement: algorithmic HBM bytes of the pairwise registrations run on this context since the last reset (SURVEY 8d:
+    // 28 n per phase-correlation variant, 20 n per scored candidate, 64 n for the rank correlation; n = crop voxels)
+    double reg_alg_bytes = 0.0;
+    long long reg_pairs = 0, reg_candidates = 0;
     const float* raw_u16_keys[2] = {nullptr, nullptr};   // set by mvs_register_crops: integer-valued originals of the two crops (16-bit rank keys)
     // the class kernels of one fuse launch run on side streams next to the main one (fork / join by events)
     hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};

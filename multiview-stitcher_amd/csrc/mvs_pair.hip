@@ -154,6 +154,11 @@ extern "C" int mvs_register_crops(int device, const float* fixed, const float* m
     c->both_crops_finite = false;
     c->raw_u16_keys[0] = c->raw_u16_keys[1] = nullptr;
     if (rc) return rc;
+    int n_scored = 0;      // candidates that went through the shift + SSIM kernels (the others were rejected from their boxes)
+    for (int u = 0; u < n_uniq; ++u) n_scored += (code_u[u] == 0) ? 1 : 0;
+    c->reg_alg_bytes += (double)n * (2.0 * 28.0 + 20.0 * (double)n_scored + 64.0);
+    c->reg_pairs += 1;
+    c->reg_candidates += n_scored;
 
     // ---- metric lists as the reference builds them (code 2 appends nothing), nanargmax, Q3 indexing ----
     int best_pos = -1, pos = 0;

@@ -49,17 +49,20 @@ class DevicePairExecutor:
         def work(d):
             dev = self.devices[d]
             cache = registration._BinCache()
-            for k in buckets[d]:
-                i, j = edges[k]
-                a, b = msims[i], msims[j]
+            local_views = {}        # view index -> the view as this device sees it (one peer copy per tile and device)
 
-                def local(m):
+            def local(iv):
+                if iv not in local_views:
+                    m = msims[iv]
                     data = m.data if not hasattr(m, "scales") else None
                     if data is not None and is_device_array(data) and (data.device & 0xff) != (dev & 0xff):   # another GPU (the high bits are a context lane)
-                        return m.copy(data=data.on_device(dev))   # peer copy over xGMI, cached per (tile, device)
-                    return m
+                        m = m.copy(data=data.on_device(dev))   # peer copy over xGMI
+                    local_views[iv] = m
+                return local_views[iv]
 
-                results[k] = registration.register_pair_of_msims(local(a), local(b), device=dev, _bin_cache=cache, **register_kwargs)
+            for k in buckets[d]:
+                i, j = edges[k]
+                results[k] = registration.register_pair_of_msims(local(i), local(j), device=dev, _bin_cache=cache, **register_kwargs)
 
         with ThreadPoolExecutor(max_workers=n) as ex:
             list(ex.map(work, range(n)))

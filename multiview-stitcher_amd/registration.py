@@ -492,7 +492,7 @@ def _geom_of(sim, transform_key, cache):
     """_TileGeom of a view, shared by the pairs of one compute_pairwise_registrations call."""
     if cache is None:
         return _TileGeom(sim, transform_key)
-    return cache.get_or_compute(("geom", id(sim), transform_key), lambda: _TileGeom(sim, transform_key))
+    return cache.get_or_compute(("geom", id(sim), transform_key), lambda: _TileGeom(sim, transform_key), keep=sim)
 
 
 def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=None, overlap_tolerance=None,
@@ -523,7 +523,8 @@ def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=Non
         key = (id(sim.data), tuple(sorted(registration_binning.items())))
         if _bin_cache is None:
             return _bin_sim(sim, registration_binning, device)
-        return _bin_cache.get_or_compute(key, lambda: _bin_sim(sim, registration_binning, device))
+        # (the cache slot keeps sim.data alive, so its id() cannot be recycled for another tile while the cache lives)
+        return _bin_cache.get_or_compute(key, lambda: _bin_sim(sim, registration_binning, device), keep=sim.data)
 
     reg_sims_b = [binned(sim1), binned(sim2)]
     if pairwise_reg_func is phase_correlation_registration and set(pairwise_reg_func_kwargs) <= {"upsample_factor"} and _lean_enabled[0] \
@@ -605,14 +606,15 @@ class _BinCache:
         self._lock = threading.Lock()
         self._items = {}
 
-    def get_or_compute(self, key, fn):
+    def get_or_compute(self, key, fn, keep=None):
+        """``keep``: the object whose id() is part of ``key``; the slot holds a reference to it."""
         import threading
 
         with self._lock:
             slot = self._items.get(key)
             owner = slot is None
             if owner:
-                slot = self._items[key] = {"event": threading.Event(), "value": None, "error": None}
+                slot = self._items[key] = {"event": threading.Event(), "value": None, "error": None, "keep": keep}
         if owner:
             try:
                 slot["value"] = fn()
@@ -730,7 +732,9 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
     # (2) pairwise registrations per time point
     params_t, all_results, resolution_info = [], [], []
     for it in range(nt):
-        fields = [s.isel({"t": it}) if "t" in s.dims else s for s in sims_reg]
+        # per-time-point fields are shallow copies with their OWN transforms dict: the caller's images are never modified
+        # (t-stacked affines of an image without a t axis would otherwise collapse to one time point for good)
+        fields = [s.isel({"t": it}) if "t" in s.dims else s.copy() for s in sims_reg]
         for f, s in zip(fields, sims_reg):
             f.attrs["transforms"] = {k: param_utils.select_time(v, it) for k, v in s.attrs.get("transforms", {}).items()}
         results = compute_pairwise_registrations(
@@ -740,7 +744,9 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
         )
         keep = list(range(len(edges)))
         if post_registration_do_quality_filter:
-            keep = [k for k in keep if results[k]["quality"] >= post_registration_quality_threshold]
+            # mv_graph.filter_edges removes edges with quality < threshold only: a NaN quality (constant overlap ->
+            # identity transform) stays in the graph, as in the reference
+            keep = [k for k in keep if not (results[k]["quality"] < post_registration_quality_threshold)]
         # (3) groupwise resolution (registration.py:2560-2580 -> param_resolution.groupwise_resolution)
         if groupwise_resolution_method == "linear":
             params_t.append(resolve_translations(len(sims), [edges[k] for k in keep], [results[k] for k in keep]))

@@ -1,0 +1,246 @@
+"""One mosaic over the GPUs of a node: tile ownership, pair and chunk assignment.
+
+Units are independent -- one task per image pair (registration.py:2657-2664) and one per output chunk
+(fusion/_core.py:1133-1141; task shapes after browser/executors.py:166-194, 267-281) -- so the data path needs no
+collective.  What has to be decided is WHERE each tile lives, so that it is uploaded once and its neighbours fetch it
+once:
+
+* the output stack is cut into one sub-box per rank (z first, then y, then x: z-major slabs keep a rank's chunks on the
+  same tiles);
+* a tile is OWNED by the rank whose sub-box holds its centre: with 8 ranks and the 4 x 4 x 4 grid every rank owns a
+  2 x 2 x 2 brick of tiles;
+* a pair is registered by the owner of its fixed (first) view; an output chunk is fused by the rank whose sub-box it
+  lies in;
+* a rank therefore needs its own tiles plus a one-tile HALO: the partners of its pairs and every tile that reaches into
+  its sub-box.  In one process (threads, one context per GPU) the halo arrives by peer copies (`DeviceArray.on_device` ->
+  mvs_memcpy_peer, xGMI); with one process per GPU it is exchanged once by point-to-point sends (`exchange_halo`,
+  torch.distributed isend / irecv = RCCL over xGMI).  Neither is on the per-step path: tiles stay resident.
+* the pairwise results (a 4 x 4 matrix, a quality and a box per pair) are gathered on every rank
+  (`ShardedPairExecutor`, all_gather_object: a few kB of control data) and the groupwise resolution runs replicated.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def factor_ranks(world_size, extents):
+    """Split counts (one per axis, product == world_size): factors of 2 (then odd factors) go to the axis whose parts are
+    currently the longest, ties to the FIRST axis (z-major)."""
+    counts = [1] * len(extents)
+    n = int(world_size)
+    factors = []
+    p = 2
+    while n > 1:
+        while n % p == 0:
+            factors.append(p)
+            n //= p
+        p += 1
+    for f in sorted(factors, reverse=True):
+        part = [e / c for e, c in zip(extents, counts)]
+        k = int(np.argmax(part))      # argmax returns the first of equal maxima
+        counts[k] *= f
+    return counts
+
+
+def output_subboxes(output_stack_properties, world_size, sdims=None):
+    """Cut an output stack (dict-of-dicts origin / spacing / shape) into ``world_size`` voxel-aligned sub-boxes; returns the
+    list of sub stacks (rank order: first axis slowest) and the split counts."""
+    osp = output_stack_properties
+    sdims = list(sdims or [d for d in ("z", "y", "x") if d in osp["shape"]])
+    shape = [int(osp["shape"][d]) for d in sdims]
+    counts = factor_ranks(world_size, shape)
+    bounds = [np.linspace(0, n, c + 1).round().astype(int) for n, c in zip(shape, counts)]
+    boxes = []
+    for idx in np.ndindex(*counts):
+        lo = [int(bounds[k][i]) for k, i in enumerate(idx)]
+        hi = [int(bounds[k][i + 1]) for k, i in enumerate(idx)]
+        boxes.append({
+            "origin": {d: float(osp["origin"][d]) + lo[k] * float(osp["spacing"][d]) for k, d in enumerate(sdims)},
+            "spacing": {d: float(osp["spacing"][d]) for d in sdims},
+            "shape": {d: hi[k] - lo[k] for k, d in enumerate(sdims)},
+            "index_offset": {d: lo[k] for k, d in enumerate(sdims)},
+        })
+    return boxes, counts
+
+
+def _world_box(stack_props, affine, sdims):
+    """Axis-aligned world bounding box of a view (corners of its stack under its affine)."""
+    nd = len(sdims)
+    o = np.array([float(stack_props["origin"][d]) for d in sdims])
+    s = np.array([float(stack_props["spacing"][d]) for d in sdims])
+    n = np.array([float(stack_props["shape"][d]) for d in sdims])
+    corners = np.array(list(np.ndindex(*([2] * nd)))) * ((n - 1) * s) + o
+    A = np.asarray(affine, dtype=np.float64)
+    w = corners @ A[:nd, :nd].T + A[:nd, nd]
+    return w.min(0), w.max(0)
+
+
+def tile_owners(stack_props_list, affines, subboxes, sdims=None):
+    """Owner rank of every view: the rank whose sub-box holds the centre of the view's world bounding box (clamped into the
+    output stack)."""
+    sdims = list(sdims or [d for d in ("z", "y", "x") if d in subboxes[0]["shape"]])
+    los = np.array([[b["origin"][d] for d in sdims] for b in subboxes])
+    his = np.array([[b["origin"][d] + b["shape"][d] * b["spacing"][d] for d in sdims] for b in subboxes])
+    glo, ghi = los.min(0), his.max(0)
+    owners = []
+    for sp, a in zip(stack_props_list, affines):
+        lo, hi = _world_box(sp, a, sdims)
+        c = np.clip((lo + hi) / 2, glo, np.nextafter(ghi, glo))
+        inside = np.all((c >= los) & (c < his), axis=1)
+        owners.append(int(np.argmax(inside)))
+    return owners
+
+
+def edge_owners(edges, owners):
+    """A pair is registered where its fixed (first) view lives."""
+    return [owners[i] for i, _ in edges]
+
+
+def rank_tiles(stack_props_list, affines, subboxes, edges, owners, rank, margin=8.0, sdims=None):
+    """Views rank ``rank`` must hold: its own, the partners of the pairs it registers and every view whose world box (grown
+    by ``margin`` world units: registration may move a view by a few pixels) reaches into its sub-box."""
+    sdims = list(sdims or [d for d in ("z", "y", "x") if d in subboxes[0]["shape"]])
+    need = {v for v, o in enumerate(owners) if o == rank}
+    for (i, j), o in zip(edges, edge_owners(edges, owners)):
+        if o == rank:
+            need.update((i, j))
+    b = subboxes[rank]
+    blo = np.array([b["origin"][d] for d in sdims])
+    bhi = np.array([b["origin"][d] + (b["shape"][d] - 1) * b["spacing"][d] for d in sdims])
+    for v, (sp, a) in enumerate(zip(stack_props_list, affines)):
+        lo, hi = _world_box(sp, a, sdims)
+        if np.all(lo - margin <= bhi) and np.all(hi + margin >= blo):
+            need.add(v)
+    return sorted(need)
+
+
+class RemoteArray:
+    """Placeholder for the data of a view that lives on another rank: shape and dtype only.  Registration's graph
+    building and the fuse planner read metadata; any attempt to touch the voxels raises."""
+
+    def __init__(self, shape, dtype, owner=None):
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.owner = owner
+
+    ndim = property(lambda self: len(self.shape))
+    size = property(lambda self: int(np.prod(self.shape)))
+
+    def __getitem__(self, key):
+        if not isinstance(key, tuple):
+            key = (key,)
+        key = key + (slice(None),) * (self.ndim - len(key))
+        shape = []
+        for k, n in zip(key, self.shape):
+            if isinstance(k, slice):
+                lo, hi, _ = k.indices(n)
+                shape.append(max(hi - lo, 0))
+        return RemoteArray(shape, self.dtype, self.owner)
+
+    def _fail(self, *a, **k):
+        raise RuntimeError(f"this view's voxels live on rank {self.owner}: it is not part of this rank's tiles + halo")
+
+    __array__ = get = astype = _fail
+    ptr = property(_fail)
+
+
+class ShardedPairExecutor:
+    """``pairwise_executor`` for one-process-per-GPU runs (registration.register(..., pairwise_executor=...),
+    registration.py:2634-2655): this rank registers the pairs whose fixed view it owns, then every rank receives all
+    results (``gather(obj) -> list over ranks``; default torch.distributed.all_gather_object)."""
+
+    def __init__(self, rank, world_size, owners, device=0, gather=None, register_fn=None, host_threads=8):
+        self.rank, self.world_size, self.owners = int(rank), int(world_size), list(owners)
+        self.device, self.gather, self.register_fn, self.host_threads = device, gather, register_fn, host_threads
+        self.last_local_count = 0
+
+    def __call__(self, msims, edges, register_kwargs):
+        mine = [k for k, o in enumerate(edge_owners(edges, self.owners)) if o == self.rank]
+        self.last_local_count = len(mine)
+        if self.register_fn is not None:
+            local = [self.register_fn(msims[edges[k][0]], msims[edges[k][1]], **register_kwargs) for k in mine]
+        else:
+            from . import registration
+
+            kw = dict(register_kwargs)
+            local = registration.compute_pairwise_registrations(
+                msims, [edges[k] for k in mine], kw.pop("transform_key"), kw.pop("registration_binning", None),
+                kw.pop("overlap_tolerance", 0.0), kw.pop("pairwise_reg_func", registration.phase_correlation_registration),
+                kw.pop("pairwise_reg_func_kwargs", None), None, self.device, host_threads=self.host_threads) if mine else []
+        payload = {k: r for k, r in zip(mine, local)}
+        if self.world_size == 1:
+            parts = [payload]
+        elif self.gather is not None:
+            parts = self.gather(payload)
+        else:
+            import torch.distributed as dist
+
+            parts = [None] * self.world_size
+            dist.all_gather_object(parts, payload)
+        results = [None] * len(edges)
+        for part in parts:
+            for k, r in part.items():
+                results[int(k)] = r
+        missing = [k for k, r in enumerate(results) if r is None]
+        if missing:
+            raise RuntimeError(f"no rank registered edges {missing[:8]}")
+        return results
+
+
+def fuse_shard(sims, rank, world_size, transform_key, output_stack_properties=None, **fuse_kwargs):
+    """Fuse this rank's sub-box of the mosaic (fusion.fuse on ``output_stack_properties`` = the rank's part of the global
+    output stack).  Returns (fused sub-image, sub-box); the union over ranks is fusion.fuse of the whole mosaic."""
+    from . import fusion
+    from . import spatial_image_utils as si_utils
+
+    sdims = si_utils.get_spatial_dims_from_sim(sims[0])
+    if output_stack_properties is None:
+        output_stack_properties = fusion.process_output_stack_properties(
+            list(sims), fuse_kwargs.pop("output_spacing", None), fuse_kwargs.pop("output_origin", None),
+            fuse_kwargs.pop("output_shape", None), None, fuse_kwargs.pop("output_stack_mode", "union"), transform_key)
+    osp = fusion._bb_dicts(output_stack_properties, sdims)
+    boxes, _ = output_subboxes(osp, world_size, sdims)
+    box = boxes[rank]
+    sub = {k: box[k] for k in ("origin", "spacing", "shape")}
+    fused = fusion.fuse(list(sims), transform_key=transform_key, output_stack_properties=sub, **fuse_kwargs)
+    return fused, box
+
+
+def exchange_halo(torch, dist, tiles, owners, needs, rank, world_size, device, via_host=False):
+    """One-process-per-GPU halo exchange (setup, once): ``tiles[v]`` is a device tensor on the owner and None elsewhere;
+    afterwards it is a tensor for every v in ``needs[rank]``.  ``needs``: list over ranks of view-index lists (every rank
+    computes all of them from the metadata).  Point-to-point isend / irecv (RCCL over xGMI with the nccl backend;
+    ``via_host``: staged through host tensors for backends without device support, e.g. gloo in tests).  uint16 travels as
+    int16 (same bytes)."""
+    def wire(t):
+        t = t.view(torch.int16) if t.dtype == torch.uint16 else t
+        return t.cpu() if via_host else t
+
+    ops, recv = [], {}
+    shapes = {v: (tuple(t.shape), t.dtype) for v, t in enumerate(tiles) if t is not None}
+    meta = [None] * world_size
+    dist.all_gather_object(meta, shapes)
+    allshapes = {}
+    for m in meta:
+        allshapes.update(m)
+    for r in range(world_size):
+        for v in needs[r]:
+            o = owners[v]
+            if o == r:
+                continue
+            if rank == o:
+                ops.append(dist.P2POp(dist.isend, wire(tiles[v]).contiguous(), r))
+            elif rank == r:
+                shp, dt = allshapes[v]
+                wdt = torch.int16 if dt == torch.uint16 else dt
+                recv[v] = (torch.empty(shp, dtype=wdt, device="cpu" if via_host else device), dt)
+                ops.append(dist.P2POp(dist.irecv, recv[v][0], o))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    out = list(tiles)
+    for v, (t, dt) in recv.items():
+        t = t.to(device) if via_host else t
+        out[v] = t.view(dt) if t.dtype != dt else t
+    return out

@@ -97,3 +97,113 @@ def test_planner_axis_aligned_slabs_and_graph():
     p = registration.resolve_translations(3, edges, res)
     np.testing.assert_allclose(p[1][:2, 2], [-1.0, 2.0], atol=1e-9)
     np.testing.assert_allclose(p[2][:2, 2], [-1.5, 1.5], atol=1e-9)
+
+
+# ---- one mosaic over the GPUs of a node (sharding.py) -------------------------------------------------------
+def _grid_meta(grid=(4, 4, 4), tile=512, ov=102):
+    from multiview_stitcher_amd import sharding  # noqa: F401
+
+    sps, affs = [], []
+    for idx in np.ndindex(*grid):
+        o = np.asarray(idx) * (tile - ov)
+        sps.append({"origin": dict(zip("zyx", o.astype(float))), "spacing": dict(zip("zyx", [1.0] * 3)),
+                    "shape": dict(zip("zyx", [tile] * 3))})
+        affs.append(np.eye(4))
+    n = (tile - ov) * (np.asarray(grid) - 1) + tile
+    osp = {"origin": dict(zip("zyx", [0.0] * 3)), "spacing": dict(zip("zyx", [1.0] * 3)), "shape": dict(zip("zyx", n.tolist()))}
+    edges = []
+    lin = np.arange(np.prod(grid)).reshape(grid)
+    for idx in np.ndindex(*grid):
+        for ax in range(3):
+            if idx[ax] + 1 < grid[ax]:
+                j = list(idx)
+                j[ax] += 1
+                edges.append((int(lin[idx]), int(lin[tuple(j)])))
+    return sps, affs, osp, edges
+
+
+def test_brick_partition_of_the_north_star_grid():
+    from multiview_stitcher_amd import sharding
+
+    sps, affs, osp, edges = _grid_meta()
+    assert len(edges) == 144
+    for world, want_counts in [(1, [1, 1, 1]), (2, [2, 1, 1]), (4, [2, 2, 1]), (8, [2, 2, 2])]:
+        boxes, counts = sharding.output_subboxes(osp, world)
+        assert counts == want_counts
+        # the sub-boxes tile the output stack exactly
+        vox = sum(int(np.prod([b["shape"][d] for d in "zyx"])) for b in boxes)
+        assert vox == int(np.prod([osp["shape"][d] for d in "zyx"]))
+        owners = sharding.tile_owners(sps, affs, boxes)
+        per_rank = np.bincount(owners, minlength=world)
+        assert per_rank.tolist() == [64 // world] * world                    # 8 ranks: a 2 x 2 x 2 brick each
+        eo = sharding.edge_owners(edges, owners)
+        assert sorted(np.bincount(eo, minlength=world).tolist())[0] >= 144 // world - 144 // (2 * world) - 6
+        for r in range(world):
+            need = sharding.rank_tiles(sps, affs, boxes, edges, owners, r)
+            own = [v for v, o in enumerate(owners) if o == r]
+            assert set(own) <= set(need)
+            # own brick + a one-tile halo: never more than the (brick + 1 layer on the inner sides) box
+            if world == 8:
+                assert len(need) == 27, len(need)      # 2x2x2 brick + halo towards the inner neighbours = 3x3x3
+            for (i, j), o in zip(edges, eo):
+                if o == r:
+                    assert i in need and j in need
+
+
+def test_remote_array_is_metadata_only():
+    from multiview_stitcher_amd import sharding
+
+    ra = sharding.RemoteArray((4, 5, 6), np.uint16, owner=3)
+    assert ra[1:3, :, 2:].shape == (2, 5, 4) and ra.dtype == np.uint16
+    import pytest
+
+    with pytest.raises(RuntimeError, match="rank 3"):
+        np.asarray(ra)
+
+
+def test_gloo_two_ranks_sharded_pair_executor(tmp_path):
+    """world_size 2, gloo: every rank registers the pairs whose fixed view it owns (stub registration), the results are
+    all-gathered and both ranks end up with the complete, identical list in edge order."""
+    script = tmp_path / "w2.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        import numpy as np
+        import torch.distributed as dist
+        from multiview_stitcher_amd import sharding
+        sys.path.insert(0, os.path.join({ROOT!r}, "tests"))
+        from test_farm_cpu import _grid_meta
+        dist.init_process_group("gloo")
+        r, w = dist.get_rank(), dist.get_world_size()
+        sps, affs, osp, edges = _grid_meta((2, 2, 4), 64, 12)
+        boxes, counts = sharding.output_subboxes(osp, w)
+        owners = sharding.tile_owners(sps, affs, boxes)
+        calls = []
+        def fake_register(a, b, **kw):
+            calls.append((a, b))
+            return {{"transform": np.eye(4) * (a + 1), "quality": float(b), "bbox": np.zeros((2, 3))}}
+        ex = sharding.ShardedPairExecutor(r, w, owners, register_fn=fake_register)
+        res = ex(list(range(len(sps))), edges, {{}})
+        assert len(res) == len(edges)
+        for (i, j), q in zip(edges, res):
+            assert q["quality"] == float(j) and q["transform"][0, 0] == i + 1
+        mine = [e for e, o in zip(edges, sharding.edge_owners(edges, owners)) if o == r]
+        assert calls == mine and 0 < len(mine) < len(edges)
+        got = [None] * w
+        dist.all_gather_object(got, len(mine))
+        if r == 0:
+            assert sum(got) == len(edges)
+            print("OK", got)
+        dist.destroy_process_group()
+    """))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), str(script)],
+        capture_output=True, text=True, timeout=300,
+    )
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "OK [" in out.stdout, out.stdout
