@@ -196,37 +196,41 @@ def _is_axis_aligned(affine, tol=1e-9):
 
 
 def _get_overlap_bboxes(sim1, sim2, input_transform_key=None, output_transform_key=None, overlap_tolerance=None):
-    """registration._get_overlap_bboxes (registration.py:194-277) for axis-aligned views.
-
-    The reference intersects the two view boxes as halfspaces (Qhull, mv_graph.py:301-338); for
-    axis-aligned views that polytope is the intersection of the world AABBs, whose corners are mapped
-    back into each view's intrinsic frame.  Returns None when the views do not overlap."""
+    """registration._get_overlap_bboxes (registration.py:194-277): the two view boxes are intersected as halfspaces in the
+    coordinate system of ``input_transform_key`` (mv_graph.py:301-338) and the vertices of the intersection polytope are
+    projected into each view's intrinsic frame; lowers / uppers are their extrema.  Axis-aligned pairs (every tile grid)
+    take the closed form -- the polytope is the intersection of the world AABBs, whose 2^ndim corners are the vertices;
+    rotated / sheared / scaled views go through scipy's linprog + HalfspaceIntersection like the reference.
+    Returns None when the views do not overlap."""
     from . import mv_graph
     from . import spatial_image_utils as si_utils
+    from .transformation import transform_pts
 
     sims = [sim1, sim2]
     affines = [param_utils.select_time(si_utils.get_affine_from_sim(s, input_transform_key), 0) for s in sims]
-    if not all(_is_axis_aligned(a) for a in affines):
-        raise NotImplementedError("pairwise registration of rotated / sheared views is not part of this path yet")
     sps = [si_utils.get_stack_properties_from_sim(s) for s in sims]
     if overlap_tolerance is not None:
         sps = [si_utils_extend(sp, overlap_tolerance) for sp in sps]
-    res = mv_graph.get_overlap_aabb(sps[0], affines[0], sps[1], affines[1])
-    if res is None:
-        return None
-    lo, hi = res
-    ndim = len(lo)
-    corners = np.array(list(np.ndindex(*([2] * ndim)))) * (hi - lo) + lo
+    if all(_is_axis_aligned(a) for a in affines):
+        res = mv_graph.get_overlap_aabb(sps[0], affines[0], sps[1], affines[1])
+        if res is None:
+            return None
+        lo, hi = res
+        ndim = len(lo)
+        corners = np.array(list(np.ndindex(*([2] * ndim)))) * (hi - lo) + lo
+        vol = float(np.prod(hi - lo))
+    else:
+        vol, hs = mv_graph.get_overlap_between_pair_of_stack_props(dict(sps[0], transform=affines[0]), dict(sps[1], transform=affines[1]))
+        if hs is None:
+            return None
+        corners = np.asarray(hs.intersections)
     if output_transform_key is None:
-        from .transformation import transform_pts
-
         cts = [transform_pts(corners, np.linalg.inv(a)) for a in affines]
     elif output_transform_key == input_transform_key:
         cts = [corners, corners]
     else:
         raise NotImplementedError
-    return {"lowers": [np.min(c, axis=0) for c in cts], "uppers": [np.max(c, axis=0) for c in cts],
-            "vol": float(np.prod(hi - lo))}
+    return {"lowers": [np.min(c, axis=0) for c in cts], "uppers": [np.max(c, axis=0) for c in cts], "vol": float(vol)}
 
 
 def si_utils_extend(stack_props, extend_by):
