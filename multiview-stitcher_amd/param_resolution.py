@@ -391,9 +391,196 @@ def groupwise_resolution_shortest_paths(g, reference_view=None):
     return params, {"metrics": None, "used_edges": list(used)}
 
 
+# ---- linear two-pass resolver (param_resolution/linear_two_pass.py:216-544) ------------------------------------------
+def _polar_rotation(linear):
+    """Closest rotation of a linear map (polar decomposition through the SVD, determinant forced to +1)."""
+    u, _, vt = np.linalg.svd(linear)
+    if np.linalg.det(u @ vt) < 0:
+        u = u.copy()
+        u[:, -1] *= -1
+    return u @ vt
+
+
+def _rotvec(rmat, ndim):
+    if ndim == 2:
+        return np.array([np.arctan2(rmat[1, 0], rmat[0, 0])])
+    from scipy.spatial.transform import Rotation
+
+    return Rotation.from_matrix(rmat).as_rotvec()
+
+
+def _rotmat(vec, ndim):
+    if ndim == 2:
+        c, s_ = np.cos(float(vec[0])), np.sin(float(vec[0]))
+        return np.array([[c, -s_], [s_, c]])
+    from scipy.spatial.transform import Rotation
+
+    return Rotation.from_rotvec(vec).as_matrix()
+
+
+def _difference_lsq(edge_list, values, weights, nodes, ref, dim, prior_lambda, lsqr_kwargs):
+    """Weighted least squares of x_u - x_v = value over the edges with x_ref = 0 (a graph-Laplacian system, solved with
+    scipy's LSQR on the sparse incidence matrix like the reference), optional Tikhonov rows sqrt(lambda) x = 0."""
+    from scipy import sparse
+    from scipy.sparse.linalg import lsqr
+
+    free = [n for n in nodes if n != ref]
+    col = {n: i * dim for i, n in enumerate(free)}
+    npar = len(free) * dim
+    rows, cols, data, rhs = [], [], [], []
+    r = 0
+    for (u, v), val, w in zip(edge_list, values, weights):
+        sw = np.sqrt(w)
+        for k in range(dim):
+            rhs.append(sw * val[k])
+            if u != ref:
+                rows.append(r); cols.append(col[u] + k); data.append(sw)
+            if v != ref:
+                rows.append(r); cols.append(col[v] + k); data.append(-sw)
+            r += 1
+    if prior_lambda > 0 and npar > 0:
+        sl = float(np.sqrt(prior_lambda))
+        for n in free:
+            for k in range(dim):
+                rhs.append(0.0)
+                rows.append(r); cols.append(col[n] + k); data.append(sl)
+                r += 1
+    out = {n: np.zeros(dim) for n in nodes}
+    if r == 0 or npar == 0:
+        return out
+    mat = sparse.coo_matrix((data, (rows, cols)), shape=(r, npar)).tocsr()
+    sol = lsqr(mat, np.asarray(rhs, dtype=np.float64), **lsqr_kwargs)[0]
+    for n in free:
+        out[n] = sol[col[n]:col[n] + dim]
+    return out
+
+
+def _kruskal_mst(nodes, edge_list, weights):
+    """Minimum spanning forest, edges taken in ascending weight with ties in the given order (Kruskal with a stable sort,
+    what networkx.minimum_spanning_tree does)."""
+    parent = {n: n for n in nodes}
+
+    def find(a):
+        while parent[a] != a:
+            parent[a] = parent[parent[a]]
+            a = parent[a]
+        return a
+
+    keep = set()
+    for k in sorted(range(len(edge_list)), key=lambda i: weights[i]):
+        a, b = find(edge_list[k][0]), find(edge_list[k][1])
+        if a != b:
+            parent[a] = b
+            keep.add(tuple(sorted(edge_list[k])))
+    return keep
+
+
+def groupwise_resolution_linear_two_pass(g, reference_view=None, transform="rigid", residual_threshold=None, mad_k=2.0,
+                                         keep_mst=True, weight_mode="quality_overlap", prior_lambda=0.0, **kwargs):
+    """One global linearisation with two-pass outlier pruning (linear_two_pass.py:216-544).
+
+    Every pairwise transform A_uv is reduced to a rotation R_uv (polar part, "rigid" only) and a displacement measured at
+    the centre p of the pair's overlap box, d = A p - p ("translation") or A p - R p ("rigid").  Rotation vectors then
+    translations are solved as weighted difference systems x_u - x_v = measurement with the reference view pinned
+    (translations of "rigid": t_u - t_v = R_v d).  Pass 1 uses all edges; edges whose RMS bead residual exceeds
+    ``residual_threshold`` (default: median + mad_k * MAD) are dropped unless a minimum spanning tree over the residuals
+    needs them (``keep_mst``); pass 2 solves again on the kept edges.  Weights: quality * overlap | quality | overlap |
+    uniform."""
+    if "mode" in kwargs:
+        transform = kwargs.pop("mode")
+    if "prune_quantile" in kwargs:
+        raise TypeError("prune_quantile is not supported; use residual_threshold or mad_k.")
+    ndim = g.ndim
+    if not g.edges:
+        return {n: param_utils.identity_transform(ndim) for n in g.nodes}, {"metrics": None, "used_edges": []}
+    if transform not in ("translation", "rigid"):
+        raise ValueError(f"Unknown transform: {transform}")
+    if ndim not in (2, 3):
+        raise ValueError("Only 2D and 3D supported.")
+    rigid = transform == "rigid"
+    rdim = 1 if ndim == 2 else 3
+    ref = reference_view if (reference_view is not None and reference_view in g.nodes) else \
+        get_node_with_maximal_edge_weight_sum_from_graph(g, "quality")
+    nodes = list(g.nodes)
+    lsqr_kwargs = {k: v for k, v in kwargs.items() if k in {"damp", "atol", "btol", "conlim", "iter_lim", "show", "calc_var"}}
+
+    def weight_of(e):
+        q, o = float(np.mean(e.get("quality", 1.0))), float(np.mean(e.get("overlap", 1.0)))
+        w = {"quality_overlap": q * o, "quality": q, "overlap": o, "uniform": 1.0}.get(weight_mode)
+        if w is None:
+            raise ValueError(f"Unknown weight_mode: {weight_mode}")
+        return w if (np.isfinite(w) and w >= 0) else 0.0
+
+    order = _nx_edge_order(nodes, list(g.edges))          # the order networkx iterates g.edges in
+    keys, rots, trans, wts = [], [], [], []
+    for key in order:
+        e = g.edges[key]
+        A = np.asarray(e["transform"], dtype=np.float64)
+        lin, t = A[:ndim, :ndim], A[:ndim, ndim]
+        center = np.zeros(ndim) if e.get("bbox") is None else np.mean(np.asarray(e["bbox"], dtype=np.float64)[:2], axis=0)
+        if rigid:
+            R = _polar_rotation(lin)
+            rots.append(_rotvec(R, ndim))
+            trans.append((lin @ center + t) - R @ center)
+        else:
+            rots.append(None)
+            trans.append((lin @ center + t) - center)
+        keys.append(key)
+        wts.append(weight_of(e))
+
+    def solve(idx):
+        ek = [keys[i] for i in idx]
+        w = [wts[i] for i in idx]
+        if rigid:
+            rv = _difference_lsq(ek, [rots[i] for i in idx], w, nodes, ref, rdim, prior_lambda, lsqr_kwargs)
+            rhs = [_rotmat(rv[keys[i][1]], ndim) @ trans[i] for i in idx]
+        else:
+            rv = {n: np.zeros(rdim) for n in nodes}
+            rhs = [trans[i] for i in idx]
+        tv = _difference_lsq(ek, rhs, w, nodes, ref, ndim, prior_lambda, lsqr_kwargs)
+        params = {}
+        for n in nodes:
+            M = np.eye(ndim + 1)
+            if rigid:
+                M[:ndim, :ndim] = _rotmat(rv[n], ndim)
+            M[:ndim, ndim] = tv[n]
+            params[n] = M
+        return params
+
+    all_idx = list(range(len(keys)))
+    p1 = solve(all_idx)
+    res_by_edge = compute_edge_residuals(g, p1)
+    residuals = np.array([res_by_edge.get(tuple(sorted(k)), np.nan) for k in keys], dtype=np.float64)
+    finite = residuals[np.isfinite(residuals)]
+    if residual_threshold is not None:
+        thr = float(residual_threshold)
+    elif finite.size:
+        med = float(np.median(finite))
+        thr = med + float(mad_k) * float(np.median(np.abs(finite - med)))
+    else:
+        thr = np.inf
+    r_keep = np.where(np.isfinite(residuals), residuals, np.inf)
+    keep = r_keep <= thr
+    forced = _kruskal_mst(nodes, keys, r_keep.tolist()) if keep_mst else set()
+    metrics, final = [], []
+    for i, k in enumerate(keys):
+        kept = bool(keep[i]) or tuple(sorted(k)) in forced
+        metrics.append({"u": k[0], "v": k[1], "weight": wts[i], "residual": float(residuals[i]), "kept_pass2": kept})
+        if kept:
+            final.append(i)
+    if not final:
+        final = all_idx
+        for m in metrics:
+            m["kept_pass2"] = True
+    params = solve(final)
+    return params, {"metrics": {"edges": metrics}, "used_edges": [tuple(sorted(keys[i])) for i in final]}
+
+
+
 _METHODS = {
     "global_optimization": groupwise_resolution_global_optimization,
     "shortest_paths": groupwise_resolution_shortest_paths,
+    "linear_two_pass": groupwise_resolution_linear_two_pass,
 }
 
 

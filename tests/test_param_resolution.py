@@ -154,3 +154,82 @@ def test_native_translation_sweeps_equal_numpy_sweeps(ndim, monkeypatch):
     assert m_nat["iteration"] == m_np["iteration"]
     np.testing.assert_allclose(m_nat["max_residual"], m_np["max_residual"], rtol=1e-9, atol=1e-12)
     np.testing.assert_allclose(m_nat["mean_residual"], m_np["mean_residual"], rtol=1e-9, atol=1e-12)
+
+
+# ---- linear two-pass resolver (param_resolution/linear_two_pass.py) ------------------------------------------------------
+def test_linear_two_pass_translation_solves_a_consistent_grid_exactly():
+    g, tau = _grid_graph(4, 3, ndim=3, seed=3)
+    params, info = pr.groupwise_resolution(g, "linear_two_pass", transform="translation", reference_view=0)
+    got = np.array([params[v][:3, 3] for v in range(12)])
+    np.testing.assert_allclose(got - got[0], tau - tau[0], atol=1e-6)
+    for v in range(12):
+        np.testing.assert_array_equal(params[v][:3, :3], np.eye(3))          # identity linear part (T/test_param_resolution.py)
+    # (residuals of a consistent graph are solver noise, so the median + 2 MAD rule may still drop a few edges: the
+    # spanning tree always stays)
+    assert 11 <= len(info["used_edges"][0]) <= len(g.edges)
+    assert max(info["edge_residuals"][0].values()) < 1e-5
+
+
+def test_linear_two_pass_prunes_a_bad_edge_but_keeps_the_spanning_tree():
+    g, tau = _grid_graph(4, 4, ndim=2, noise=0.01, seed=5)
+    bad = (5, 6)
+    g.edges[bad]["transform"] = param_utils.affine_from_translation(tau[5] - tau[6] + np.array([25.0, -30.0]))
+    params, info = pr.groupwise_resolution(g, "linear_two_pass", transform="translation", reference_view=0)
+    assert bad not in info["used_edges"][0]                                   # outlier removed in pass 2
+    got = np.array([params[v][:2, 2] for v in range(16)])
+    np.testing.assert_allclose(got - got[0], tau - tau[0], atol=0.1)
+    # a bridge survives pruning even with a large residual (keep_mst)
+    g2, tau2 = _grid_graph(3, 1, ndim=2, seed=1)
+    g2.edges[(1, 2)]["transform"] = param_utils.affine_from_translation(tau2[1] - tau2[2] + 40.0)
+    _, info2 = pr.groupwise_resolution(g2, "linear_two_pass", transform="translation", reference_view=0)
+    assert (1, 2) in info2["used_edges"][0]
+
+
+def test_linear_two_pass_rigid_recovers_small_rotations():
+    rng = np.random.default_rng(2)
+    n = 6
+    ang = rng.normal(0, 0.02, n)
+    ang[0] = 0
+    tt = rng.normal(0, 2, (n, 2))
+    tt[0] = 0
+
+    def C(i):
+        c, s = np.cos(ang[i]), np.sin(ang[i])
+        M = np.eye(3)
+        M[:2, :2] = [[c, -s], [s, c]]
+        M[:2, 2] = tt[i]
+        return M
+
+    g = pr.RegGraph(range(n), {v: {"spacing": {"y": 1.0, "x": 1.0}} for v in range(n)})
+    for a in range(n):
+        for b in (a + 1, a + 2):
+            if b < n:
+                lo = rng.normal(0, 5, 2)
+                g.add_edge(a, b, np.linalg.inv(C(b)) @ C(a), bbox=[lo, lo + 30.0])    # A_uv = C_v^-1 C_u
+    params, info = pr.groupwise_resolution(g, "linear_two_pass", transform="rigid", reference_view=0)
+    for v in range(n):
+        got_ang = np.arctan2(params[v][1, 0], params[v][0, 0])
+        assert abs(got_ang - ang[v]) < 2e-3                                   # first-order linearisation: small angles
+        np.testing.assert_allclose(params[v][:2, 2], tt[v], atol=0.2)
+    with pytest.raises(ValueError):
+        pr.groupwise_resolution(g, "linear_two_pass", transform="affine")
+    with pytest.raises(TypeError):
+        pr.groupwise_resolution(g, "linear_two_pass", prune_quantile=0.9)
+
+
+def test_kruskal_matches_networkx_minimum_spanning_tree():
+    nx = pytest.importorskip("networkx")
+    rng = np.random.default_rng(4)
+    for _ in range(20):
+        n = int(rng.integers(4, 10))
+        pairs = [(a, b) for a in range(n) for b in range(a + 1, n)]
+        ins = [pairs[i] for i in rng.permutation(len(pairs))[: int(rng.integers(n, len(pairs) + 1))]]
+        w = rng.integers(0, 4, len(ins)).astype(float).tolist()              # many ties
+        G = nx.Graph()
+        for (a, b), ww in zip(ins, w):
+            G.add_edge(a, b, weight=ww)
+        want = {tuple(sorted(e)) for e in nx.minimum_spanning_tree(G, weight="weight").edges}
+        order = pr._nx_edge_order(list(G.nodes), ins)
+        wmap = {tuple(sorted(e)): ww for e, ww in zip(ins, w)}
+        got = pr._kruskal_mst(list(G.nodes), order, [wmap[tuple(sorted(e))] for e in order])
+        assert sum(wmap[e] for e in got) == sum(wmap[e] for e in want) and len(got) == len(want)
