@@ -7,7 +7,7 @@ NGFF pyramid).  Neither package exists on the MI355X box, so this module restate
 storage specification those call sites rely on:
 
 * ``<array>/.zarray``: JSON with ``zarr_format`` 2, ``shape``, ``chunks``, ``dtype`` (numpy typestr), ``order``
-  "C", ``fill_value``, ``compressor`` (null | zlib | gzip here -- blosc / zstd need codecs this image lacks and raise),
+  "C", ``fill_value``, ``compressor`` (null | zlib | gzip | zstd | lz4 | blosc: zarr_codecs.py),
   ``filters`` null, optional ``dimension_separator`` ("." default, "/" for NGFF 0.4,
   ngff_utils.py:1258-1281);
 * one file per chunk, named by the chunk's grid index joined with the separator; every stored chunk has the
@@ -71,21 +71,39 @@ def _write_json(path, obj):
 
 
 class _Codec:
-    """compressor entry of .zarray -> (decode, encode); only what the standard library offers."""
+    """compressor entry of .zarray -> (decode(bytes, nbytes), encode(bytes)): zlib / gzip from the standard library, zstd /
+    lz4 / blosc through zarr_codecs (pyarrow's bundled entropy coders)."""
 
-    def __init__(self, config):
+    def __init__(self, config, itemsize=1):
         self.config = config
         cid = None if config is None else config.get("id")
         level = 1 if config is None else int(config.get("level", 1))
         if cid is None:
-            self.decode, self.encode = (lambda b: b), (lambda b: b)
+            self.decode, self.encode = (lambda b, n=None: b), (lambda b: b)
         elif cid == "zlib":
-            self.decode, self.encode = zlib.decompress, (lambda b: zlib.compress(b, level))
+            self.decode, self.encode = (lambda b, n=None: zlib.decompress(b)), (lambda b: zlib.compress(b, level))
         elif cid == "gzip":
-            self.decode, self.encode = gzip.decompress, (lambda b: gzip.compress(b, compresslevel=level))
+            self.decode, self.encode = (lambda b, n=None: gzip.decompress(b)), (lambda b: gzip.compress(b, compresslevel=level))
+        elif cid == "zstd":
+            from . import zarr_codecs
+
+            self.decode, self.encode = zarr_codecs.zstd_decode, (lambda b: zarr_codecs.zstd_encode(b, level))
+        elif cid == "lz4":
+            from . import zarr_codecs
+
+            self.decode, self.encode = zarr_codecs.lz4_decode, zarr_codecs.lz4_encode
+        elif cid == "blosc":
+            from . import zarr_codecs
+
+            cname, clevel = config.get("cname", "lz4"), int(config.get("clevel", 5))
+            shuffle, bs = int(config.get("shuffle", 1)), int(config.get("blocksize", 0))
+            if shuffle == -1:       # numcodecs AUTOSHUFFLE: bit shuffle for single-byte items, byte shuffle otherwise
+                shuffle = 2 if itemsize == 1 else 1
+            self.decode = zarr_codecs.blosc_decode
+            self.encode = lambda b: zarr_codecs.blosc_encode(b, itemsize, cname, clevel, shuffle, bs)
         else:
             raise NotImplementedError(
-                f"zarr compressor {cid!r} needs a codec that is not available here (supported: null, zlib, gzip)")
+                f"zarr compressor {cid!r} is not supported (null, zlib, gzip, zstd, lz4, blosc)")
 
 
 class ZarrArray:
@@ -104,7 +122,7 @@ class ZarrArray:
         self.dtype = np.dtype(meta["dtype"])
         self.fill_value = _decode_fill(meta.get("fill_value"), self.dtype)
         self.separator = meta.get("dimension_separator", ".")
-        self.codec = _Codec(meta.get("compressor"))
+        self.codec = _Codec(meta.get("compressor"), self.dtype.itemsize)
         self.meta = meta
         self.ndim = len(self.shape)
         self.grid = tuple(-(-s // c) for s, c in zip(self.shape, self.chunks))
@@ -132,7 +150,7 @@ class ZarrArray:
         }
         if dimension_separator != ".":
             meta["dimension_separator"] = dimension_separator
-        _Codec(compressor)   # fail before anything is written
+        _Codec(compressor, np.dtype(dtype).itemsize)   # fail before anything is written
         _write_json(os.path.join(path, ".zarray"), meta)
         return cls(path, meta)
 
@@ -147,7 +165,7 @@ class ZarrArray:
                 raw = f.read()
         except FileNotFoundError:
             return None
-        arr = np.frombuffer(self.codec.decode(raw), dtype=self.dtype)
+        arr = np.frombuffer(self.codec.decode(raw, int(np.prod(self.chunks)) * self.dtype.itemsize), dtype=self.dtype)
         if arr.size != int(np.prod(self.chunks)):
             raise ValueError(f"chunk {idx} of {self.path} holds {arr.size} elements, expected {np.prod(self.chunks)}")
         return arr.reshape(self.chunks)
