@@ -13,7 +13,8 @@ grid = np.array([int(v) for v in (sys.argv[3] if len(sys.argv) > 3 else "4,4,4")
 tile = np.array([int(v) for v in (sys.argv[4] if len(sys.argv) > 4 else "512,512,512").split(",")])
 dev = torch.device("cuda", 0)
 _lib.init(0)
-step = tile - np.round(tile * 0.2).astype(int)
+ov = int(sys.argv[5]) if len(sys.argv) > 5 else None      # overlap in voxels (default 20 %); 104 makes every cell boundary of 512-wide tiles a multiple of 8
+step = tile - (np.round(tile * 0.2).astype(int) if ov is None else ov)
 rng = np.random.default_rng(0)
 sims, keep = [], []
 for idx in np.ndindex(*grid):
