@@ -39,6 +39,7 @@ struct MvsContext {
     // 28 n per phase-correlation variant, 20 n per scored candidate, 64 n for the rank correlation; n = crop voxels)
     double reg_alg_bytes = 0.0;
     long long reg_pairs = 0, reg_candidates = 0;
+    float raw_range[4] = {0.f, 0.f, 0.f, 0.f};            // with raw_u16_keys: min, max of the fixed crop, min, max of the moving crop
     const float* raw_u16_keys[2] = {nullptr, nullptr};   // set by mvs_register_crops: integer-valued originals of the two crops (16-bit rank keys)
     // the class kernels of one fuse launch run on side streams next to the main one (fork / join by events)
     hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};

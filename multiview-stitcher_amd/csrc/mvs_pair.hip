@@ -149,6 +149,7 @@ extern "C" int mvs_register_crops(int device, const float* fixed, const float* m
                            !c->materialize_shifts;
     c->raw_u16_keys[0] = c->materialize_shifts ? nullptr : raw_keys0;
     c->raw_u16_keys[1] = c->materialize_shifts ? nullptr : raw_keys1;
+    c->raw_range[0] = min0; c->raw_range[1] = max0; c->raw_range[2] = min1; c->raw_range[3] = max1;
     rc = mvs_score_candidates(device, r0, r1, MVS_MEM_DEVICE, ndim, shape, uniq.data(), n_uniq, region_mode, (double)data_range, im1_min, 0,
                               ssim_u.data(), spear_u.data(), code_u.data());
     c->both_crops_finite = false;

@@ -739,6 +739,142 @@ __global__ __launch_bounds__(256) void rankcorr_kernel(const float* __restrict__
         for (int k = 0; k < 3; ++k) partial[blockIdx.x * 3 + k] = s[k][0] + s[k][1] + s[k][2] + s[k][3];
 }
 
+// ---- Spearman by histogram ranks (integer-valued crops, shifts that are multiples of 1/2) -------------------------------
+// When both crops hold 16-bit integers (uint8 / uint16 tiles on the fixed grid, binned or not) the rescaled fixed image is
+// a strictly increasing function of the raw integer, and the shifted moving image -- linear interpolation with weights 0,
+// 1/2 or 1 per axis when every shift component is a multiple of 1/2 -- is a strictly increasing function of
+// KEY = 8 x (sum of the taps with a non-zero weight) / 2^(#fractional axes), an integer below 2^19.  The average rank of a
+// voxel is then a function of its key alone: rank(v) = #keys < v + (#keys == v + 1) / 2, read from the prefix sums of a
+// histogram.  Two passes over the voxels (histogram; correlation of the centred ranks) and one scan of the bins replace the
+// compaction, two multi-pass radix sorts and the run-length rank kernels.  Ties and order are those of the exact
+// interpolated values; the float32 values scipy ranks are those values rounded once, distinct wherever the exact ones are
+// (spacing >= 2^-3 / range against 2^-24 relative), so the rank vectors coincide.
+constexpr int kHistBinsMax = 48 * 1024;      // x + y bins a workgroup's private histogram can hold (16-bit counters in 96 KiB of LDS)
+__device__ __forceinline__ int shifted_keysum(const float* __restrict__ raw1, int sy, int sz, const AxisTap& Z, const AxisTap& Y,
+                                              const AxisTap& X) {
+    // sum of the taps with a non-zero weight (2^#fractional-axes of them: the same number for every voxel of a candidate,
+    // so the sum orders the voxels like the interpolated value); -1 outside the moving image
+    if (!(Z.ok && Y.ok && X.ok)) return -1;
+    const bool fz = Z.w != 0.0, fy = Y.w != 0.0, fx = X.w != 0.0;
+    float acc = 0.f;
+    for (int a = 0; a <= (fz ? 1 : 0); ++a)
+        for (int b = 0; b <= (fy ? 1 : 0); ++b)
+            for (int q = 0; q <= (fx ? 1 : 0); ++q)
+                acc += raw1[(a ? Z.i1 : Z.i0) * sz + (b ? Y.i1 : Y.i0) * sy + (q ? X.i1 : X.i0)];
+    return (int)acc;
+}
+// CORR = false: key histograms (hx: nbx bins from key kx0, hy: nby bins from key ky0).  Every workgroup counts its voxels
+// (fewer than 65536) in a private LDS histogram of 16-bit counters -- neighbouring voxels of a smooth image share their
+// keys, global atomics on them serialise -- and adds its non-empty bins to the global tables.
+// CORR = true: sum of rx[kx] * ry[ky] over the jointly valid voxels.
+template <bool CORR>
+__global__ __launch_bounds__(256) void hist_rank_kernel(const float* __restrict__ raw0, const float* __restrict__ raw1, Shape3 S, double tz,
+                                                        double ty, double tx, int kx0, int nbx, int ky0, int nby,
+                                                        unsigned int* __restrict__ hx, unsigned int* __restrict__ hy,
+                                                        const float* __restrict__ rx, const float* __restrict__ ry,
+                                                        double* __restrict__ partial) {
+    extern __shared__ unsigned int s_hist[];          // (nbx + nby + 1) / 2 words of two 16-bit counters
+    const unsigned int n = (unsigned int)S.nz * S.ny * S.nx;
+    const int sy = S.nx, sz = S.ny * S.nx;
+    const int nwords = (nbx + nby + 1) / 2;
+    if (!CORR) {
+        for (int i = threadIdx.x; i < nwords; i += blockDim.x) s_hist[i] = 0u;
+        __syncthreads();
+    }
+    double sxy = 0.0;
+    // contiguous range of 4-voxel groups per workgroup (at most 16383 groups = 65532 voxels: the counters cannot overflow)
+    const unsigned int ngroups = (n + 3) / 4;
+    const unsigned int per = (ngroups + gridDim.x - 1) / gridDim.x;
+    const unsigned int g0 = blockIdx.x * per, g1 = min(g0 + per, ngroups);
+    for (unsigned int g = g0 + threadIdx.x; g < g1; g += blockDim.x) {
+        const unsigned int i0 = g * 4;
+        int x = (int)(i0 % (unsigned int)S.nx);
+        const unsigned int t = i0 / (unsigned int)S.nx;
+        int y = (int)(t % (unsigned int)S.ny), z = (int)(t / (unsigned int)S.ny);
+        int row_z = -1, row_y = -1;
+        AxisTap Z = {0, 0, 0, 0.0}, Y = {0, 0, 0, 0.0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < n) {
+                if (z != row_z || y != row_y) {
+                    row_z = z; row_y = y;
+                    Z = axis_tap(z, tz, S.nz);
+                    Y = axis_tap(y, ty, S.ny);
+                }
+                const int ks = shifted_keysum(raw1, sy, sz, Z, Y, axis_tap(x, tx, S.nx));
+                if (ks >= 0) {
+                    const int kx = (int)raw0[i0 + k] - kx0, ky = ks - ky0;
+                    if (CORR) sxy += (double)rx[kx] * (double)ry[ky];
+                    else {
+                        atomicAdd(&s_hist[kx >> 1], 1u << (16 * (kx & 1)));
+                        const int q = nbx + ky;
+                        atomicAdd(&s_hist[q >> 1], 1u << (16 * (q & 1)));
+                    }
+                }
+                if (++x == S.nx) { x = 0; if (++y == S.ny) { y = 0; ++z; } }
+            }
+        }
+    }
+    if (CORR) {
+        for (int off = 32; off > 0; off >>= 1) sxy += __shfl_down(sxy, off);
+        __shared__ double s[4];
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = sxy;
+        __syncthreads();
+        if (threadIdx.x == 0) partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    } else {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nwords; i += blockDim.x) {
+            const unsigned int w = s_hist[i];
+            if (w) {
+                const int b0 = 2 * i, b1 = 2 * i + 1;
+                const unsigned int c0 = w & 0xffffu, c1 = w >> 16;
+                if (c0) atomicAdd((b0 < nbx) ? hx + b0 : hy + (b0 - nbx), c0);
+                if (c1) atomicAdd((b1 < nbx) ? hx + b1 : hy + (b1 - nbx), c1);
+            }
+        }
+    }
+}
+// One workgroup per table: centred average ranks of the bins, rc[v] = #(keys < v) + (h[v] + 1) / 2 - (m + 1) / 2, and
+// out[0] = sum_v h[v] rc[v]^2, out[1] = m (the number of keys).  1024 threads, contiguous bin ranges, two passes.
+__global__ __launch_bounds__(1024) void rank_table_kernel(const unsigned int* __restrict__ hx, int nx, float* __restrict__ rx,
+                                                          const unsigned int* __restrict__ hy, int ny, float* __restrict__ ry,
+                                                          double* __restrict__ out) {
+    const unsigned int* h = blockIdx.x ? hy : hx;
+    const int nb = blockIdx.x ? ny : nx;
+    float* r = blockIdx.x ? ry : rx;
+    __shared__ unsigned long long s_part[1024];
+    __shared__ double s_var[1024];
+    const int per = (nb + 1023) / 1024, b0 = threadIdx.x * per, b1 = min(b0 + per, nb);
+    unsigned long long loc = 0;
+    for (int b = b0; b < b1; ++b) loc += h[b];
+    s_part[threadIdx.x] = loc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long run = 0;
+        for (int i = 0; i < 1024; ++i) { const unsigned long long v = s_part[i]; s_part[i] = run; run += v; }
+        s_var[0] = (double)run;       // m
+    }
+    __syncthreads();
+    const double m = s_var[0];
+    __syncthreads();
+    unsigned long long before = s_part[threadIdx.x];
+    double var = 0.0;
+    for (int b = b0; b < b1; ++b) {
+        const unsigned int c = h[b];
+        const double rc = (double)before + ((double)c + 1.0) * 0.5 - (m + 1.0) * 0.5;
+        r[b] = (float)rc;
+        var += (double)c * rc * rc;
+        before += c;
+    }
+    s_var[threadIdx.x] = var;
+    __syncthreads();
+    for (int off = 512; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s_var[threadIdx.x] += s_var[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[2 * blockIdx.x] = s_var[0]; out[2 * blockIdx.x + 1] = m; }
+}
+
 struct DeviceBump {   // bump allocator over one scratch slot
     char* base; size_t cap, used;
     template <typename T> T* take(size_t count) {
@@ -843,7 +979,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     const size_t stat_bytes = (size_t)(kMaxResident + 2) * kStatBlocks * (sizeof(VoxStats) + 4 + 4 + 8) + (kMaxResident + 2) * 64;
     // batched launches (one z pass / one y-x pass for all candidates of a batch) keep three z-filtered arrays per candidate
     const bool may_batch = ndim == 3 && region_mode == 0 && !quality_for_all && !c->materialize_shifts && (long long)n * 12 * nres <= (3ll << 30);
-    const size_t need = (size_t)n * 4 * (10 + nres + (may_batch ? 3 * nres : 0)) + 256 * (12 + 4 * nres) + sort_temp_bytes + (size_t)gb * 32 + stat_bytes + 64 * 1024;
+    const size_t need = (size_t)n * 4 * (10 + nres + (may_batch ? 3 * nres : 0)) + 256 * (12 + 4 * nres) + sort_temp_bytes + (size_t)gb * 32 + stat_bytes + 64 * 1024 + (size_t)(kHistBinsMax + 64) * 8 + 1024;
     char* base = (char*)mvs_scratch(c, 6, need);
     if (!base) return MVS_ERR_HIP;
     DeviceBump B{base, need, 0};
@@ -862,6 +998,8 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     int* phasnan = B.take<int>((size_t)kMaxResident * kStatBlocks);
     double* psum = B.take<double>((size_t)kMaxResident * kStatBlocks);
     RegionStats* reg_out = B.take<RegionStats>(kMaxResident);
+    unsigned int* d_hist = B.take<unsigned int>((size_t)kHistBinsMax + 64);     // key histograms of the rank correlation
+    float* d_rank = B.take<float>((size_t)kHistBinsMax + 64);
     unsigned int* d_counter = B.take<unsigned int>(64);
     if (!d_counter) return mvs_fail(c, MVS_ERR_HIP, "mvs_score_candidates: scratch layout");
 
@@ -927,6 +1065,46 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     // Spearman over the jointly valid voxels of candidate ic, whose shifted image is `im1t`: compaction, sort by x
     // carrying y, ranks of x in sorted order, sort by y carrying rank(x), correlation sums in y-sorted order
     auto spearman_from = [&](int ic, const float* im1t) -> int {
+        {
+            // histogram ranks: both crops hold 16-bit integers (the caller vouches: raw_u16_keys) and are finite, every
+            // component of this candidate's shift is a multiple of 1/2
+            double t[3] = {0.0, 0.0, 0.0};
+            bool halves = true;
+            for (int k = 0; k < ndim; ++k) {
+                t[k0 + k] = t_candidates[ic * ndim + k];
+                halves = halves && (std::floor(t[k0 + k] * 2.0) == t[k0 + k] * 2.0);
+            }
+            int nf = 0;
+            for (int k = 0; k < 3; ++k) nf += (std::floor(t[k]) != t[k]) ? 1 : 0;
+            // key ranges from the raw extrema of the crops (c->raw_range: min / max of the fixed and of the moving crop)
+            const long long kx0 = (long long)c->raw_range[0], nbx = (long long)c->raw_range[1] - kx0 + 1;
+            const long long ky0 = (long long)c->raw_range[2] * (1 << nf), nby = ((long long)c->raw_range[3] - (long long)c->raw_range[2]) * (1 << nf) + 1;
+            const long long hgb = std::max<long long>(gb, ((long long)n / 4 + 16382) / 16383);      // < 65536 voxels per workgroup
+            if (halves && c->raw_u16_keys[0] && c->raw_u16_keys[1] && c->both_crops_finite && !c->materialize_shifts && nbx > 0 && nby > 0 &&
+                nbx + nby <= kHistBinsMax && hgb <= 65535) {
+                static bool lds_attr[MVS_MAX_DEVICES] = {false};
+                if (!lds_attr[mvs_hip_device(device)]) {
+                    MVS_HIP_TRY(c, hipFuncSetAttribute((const void*)hist_rank_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+                    lds_attr[mvs_hip_device(device)] = true;
+                }
+                const size_t lds_bytes = (size_t)((nbx + nby + 1) / 2) * 4;
+                MVS_HIP_TRY(c, hipMemsetAsync(d_hist, 0, sizeof(unsigned int) * (size_t)(nbx + nby), c->stream));
+                hipLaunchKernelGGL(hist_rank_kernel<false>, dim3((unsigned)hgb), dim3(256), lds_bytes, c->stream, c->raw_u16_keys[0], c->raw_u16_keys[1],
+                                   S, t[0], t[1], t[2], (int)kx0, (int)nbx, (int)ky0, (int)nby, d_hist, d_hist + nbx, (const float*)nullptr,
+                                   (const float*)nullptr, (double*)nullptr);
+                hipLaunchKernelGGL(rank_table_kernel, dim3(2), dim3(1024), 0, c->stream, d_hist, (int)nbx, d_rank, d_hist + nbx, (int)nby,
+                                   d_rank + nbx, partial);
+                hipLaunchKernelGGL(hist_rank_kernel<true>, dim3(gb), dim3(256), 0, c->stream, c->raw_u16_keys[0], c->raw_u16_keys[1], S, t[0], t[1],
+                                   t[2], (int)kx0, (int)nbx, (int)ky0, (int)nby, d_hist, d_hist + nbx, d_rank, d_rank + nbx, partial + 4);
+                std::vector<double> hp((size_t)gb + 4);
+                MVS_HIP_TRY(c, hipMemcpyAsync(hp.data(), partial, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, c->stream));
+                MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+                double sxy = 0;
+                for (int i = 0; i < gb; ++i) sxy += hp[4 + i];
+                spearman_out[ic] = sxy / std::sqrt(hp[0] * hp[2]);
+                return MVS_OK;
+            }
+        }
         MVS_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 4, c->stream));
         const float* raw0 = c->raw_u16_keys[0];      // 16-bit integer keys for the fixed image when the caller vouches for them
         hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, c->stream, im0, im1t, n, setA[0], setA[1], d_counter, raw0);

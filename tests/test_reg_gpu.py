@@ -323,7 +323,44 @@ def test_register_crops_shortcuts_for_finite_crops_change_nothing(hip_device):
         (t0, q0, st0, nc0), (t1, q1, st1, nc1) = res
         assert st0 == st1 == 0 and nc0 == nc1
         np.testing.assert_array_equal(t0, t1)
-        assert q0 == q1
+        if integer is True:
+            # finite integer-valued crops + a shift in multiples of 1/2: the default path ranks by key histograms, the plain
+            # one by radix sorts -- the same rank vectors, sums taken in a different order
+            assert q0 == pytest.approx(q1, rel=1e-10)
+            want = ro.phase_correlation_registration(a, b)
+            np.testing.assert_array_equal(want["affine_matrix"][:-1, -1], t1)
+            assert abs(q1 - want["quality"]) < 1e-6
+        else:
+            assert q0 == q1
+
+
+@pytest.mark.parametrize("shape,bins,jit", [((48, 80, 64), (2, 2, 2), (1, -3, 2)), ((40, 64, 96), (2, 2, 2), (3, 1, -1)), ((64, 96), (1, 1), (2, -5))])
+def test_histogram_ranks_on_binned_integer_tiles_match_oracle(hip_device, shape, bins, jit):
+    """uint16 tiles binned by 2 (registration.py:1732-1741: block mean cast back to uint16) and shifted by odd pixel counts:
+    the true shift is a half-integer on the binned grid, the winning candidate's moving crop is interpolated with weights
+    1/2, and the Spearman coefficient comes from key histograms.  Translation equal to the oracle's, quality within 1e-6."""
+    from multiview_stitcher_amd import _reg_ops
+
+    rng = np.random.default_rng(7)
+    ndim = len(shape)
+    pad = 8
+    big = ndimage.gaussian_filter(rng.random(tuple(s * b + 2 * pad for s, b in zip(shape, bins))), 2.0)
+    big = np.round((big - big.min()) / (big.max() - big.min()) * 4000).astype(np.uint16)
+
+    def binned(off):
+        sl = tuple(slice(pad + o, pad + o + s * b) for o, s, b in zip(off, shape, bins))
+        v = big[sl].astype(np.float64)
+        v = v.reshape([q for s, b in zip(shape, bins) for q in (s, b)]).mean(axis=tuple(range(1, 2 * ndim, 2)))
+        return v.astype(np.uint16).astype(np.float32)
+
+    a, b = binned((0,) * ndim), binned(jit)
+    t, q, st, nc = _reg_ops.register_crops(a, b, 2 if ndim == 3 else 10)
+    want = ro.phase_correlation_registration(a, b)
+    assert st == 0
+    np.testing.assert_array_equal(t, want["affine_matrix"][:-1, -1])
+    if ndim == 3:
+        assert np.any(np.abs(t * 2 % 2) == 1)          # a genuinely half-integer component
+    assert abs(q - want["quality"]) < 1e-6
 
 
 @pytest.mark.parametrize("shape,bins", [((16, 64, 128), (2, 2, 2)), ((9, 33, 64), (1, 2, 2)), ((12, 20, 72), (3, 1, 2)), ((8, 30, 50), (2, 2, 2)),
