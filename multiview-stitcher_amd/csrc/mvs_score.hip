@@ -524,6 +524,166 @@ __global__ __launch_bounds__(256) void ssim_yx_batch_kernel(YxBatch B, float* __
     ssim_yx_fused_body<WIN, 2>(P, R, cov_norm, C1, C2, partial + (size_t)blockIdx.y * kStatBlocks);
 }
 
+// ---- all three passes + SSIM of every candidate of a batch in ONE launch (3D, WIN-wide window, whole-volume region, finite
+// crops; the fixed image's own window means come, fully filtered, from ux / uxx).  A workgroup owns a TY x TX tile of the
+// cropped interior and WALKS z: every thread keeps the running double sums of scipy's uniform_filter1d (tmp += new - old)
+// for its pixels of the tile + halo patch, so a plane of z-filtered values (float32, the rounding point of the separate
+// passes) goes to LDS, is filtered along y into a second LDS array and along x straight into the SSIM formula.  Nothing
+// but the two crops is read -- they are shared by all candidates and stay in L2 / MALL -- and nothing is written: the
+// separate passes moved 50 bytes per voxel and candidate through HBM (14 read + 12 written by the z pass, 24 read by the
+// y / x pass).  Interior outputs (crop = window / 2) never reach a reflected sample, so no boundary handling is needed;
+// the region statistics (nanmax / has-NaN of the candidate image, idempotent) are gathered from every sample loaded.
+// A candidate is its shifted copy (dz = dy = dx = 0) or, for an integer shift, the moving crop itself read in place.
+struct FusedCand { const float* src; int dz, dy, dx; };
+struct FusedBatch { FusedCand c[kMaxResident]; };
+template <int WIN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
+void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch B,
+                                                               const float* __restrict__ ux, const float* __restrict__ uxx, int zseg,
+                                                               float cov_norm, float C1, float C2, float* __restrict__ pmax,
+                                                               int* __restrict__ phasnan, double* __restrict__ psum) {
+    constexpr int H = WIN / 2, pad = (WIN - 1) / 2, TY = 16, TX = 56, LY = TY + 2 * H, LX = TX + 2 * H;
+    constexpr int NO = 4, NI = NO + 2 * H;           // outputs / inputs of one y- or x-pass item
+    constexpr int NR = (LY + 3) / 4;                 // patch rows per thread: row = (tid >> 6) + 4 k, column = tid & 63
+    constexpr double inv = 1.0 / (double)WIN;
+    static_assert(LX <= 64 && TY % NO == 0 && TX % NO == 0 && (TY * TX) / NO <= 256 && LX * (TY / NO) <= 256, "tile layout");
+    __shared__ float sz_[3][LY][LX + 1];             // z-filtered y, yy, xy of the current plane (tile + halo)
+    __shared__ float sy_[3][TY][LX + 1];             // ... filtered along y as well
+    const FusedCand C = B.c[blockIdx.y];
+    if (!C.src) return;
+    const int tid = threadIdx.x, col = tid & 63, wrow = tid >> 6;
+    const int cz = S.nz - 2 * pad, cy = S.ny - 2 * pad, cx = S.nx - 2 * pad;
+    float mx = -INFINITY;
+    int hn = 0;
+    double acc = 0.0;
+    if (cz > 0 && cy > 0 && cx > 0) {
+        const int nty = (cy + TY - 1) / TY, ntx = (cx + TX - 1) / TX, nzs = (cz + zseg - 1) / zseg;
+        const int nitems = nty * ntx * nzs;
+        const int sy = S.nx, sz = S.ny * S.nx;
+        for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+            const int tx = item % ntx, ty = (item / ntx) % nty, zs = item / (ntx * nty);
+            const int z0 = pad + zs * zseg, z1 = min(z0 + zseg, S.nz - pad);
+            const int y0 = pad + ty * TY, x0 = pad + tx * TX;
+            const int gx = min(x0 - H + col, S.nx - 1);          // (clamped duplicates feed outputs that are never used)
+            const bool xin = (unsigned)(gx + C.dx) < (unsigned)S.nx;
+            int o0[NR], o1[NR];                                    // plane offsets of this thread's pixels in im0 / the candidate (-1: outside)
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                const int gy = min(y0 - H + min(wrow + 4 * k, LY - 1), S.ny - 1);
+                o0[k] = gy * sy + gx;
+                o1[k] = (xin && (unsigned)(gy + C.dy) < (unsigned)S.ny) ? (gy + C.dy) * sy + gx + C.dx : -1;
+            }
+            double s1[NR], s3[NR], s4[NR];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) { s1[k] = 0.0; s3[k] = 0.0; s4[k] = 0.0; }
+            // plane p's samples are loaded one iteration ahead (new: plane p, old: plane p - WIN) so that their latency hides
+            // behind the LDS phases of plane p - 1
+            float an[NR], bn[NR], ao[NR], bo[NR];
+            auto load_plane = [&](int p) __attribute__((always_inline)) {
+                const bool zin = (unsigned)(p + C.dz) < (unsigned)S.nz;
+                const bool have_old = p - (z0 - H) >= WIN;
+                const bool zin_o = have_old && (unsigned)(p - WIN + C.dz) < (unsigned)S.nz;
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    an[k] = im0[p * sz + o0[k]];
+                    bn[k] = (zin && o1[k] >= 0) ? C.src[(p + C.dz) * sz + o1[k]] : NAN;
+                    ao[k] = have_old ? im0[(p - WIN) * sz + o0[k]] : 0.f;
+                    bo[k] = have_old ? ((zin_o && o1[k] >= 0) ? C.src[(p - WIN + C.dz) * sz + o1[k]] : NAN) : 0.f;
+                }
+            };
+            if (col < LX) load_plane(z0 - H);
+            for (int p = z0 - H; p < z1 + H; ++p) {
+                if (col < LX) {
+                    float a_[NR], b_[NR], ao_[NR], bo_[NR];
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) { a_[k] = an[k]; b_[k] = bn[k]; ao_[k] = ao[k]; bo_[k] = bo[k]; }
+                    if (p + 1 < z1 + H) load_plane(p + 1);
+#pragma unroll
+                    for (int k = 0; k < NR; ++k) {
+                        const int row = wrow + 4 * k;
+                        if (row >= LY) break;
+                        float a = a_[k], b = b_[k], a2 = ao_[k], b2 = bo_[k];
+                        if (b == b) mx = fmaxf(mx, b); else hn = 1;
+                        a = (a != a) ? 0.f : a;
+                        b = (b != b) ? 0.f : b;
+                        a2 = (a2 != a2) ? 0.f : a2;
+                        b2 = (b2 != b2) ? 0.f : b2;
+                        // products in float32 like `im * im`; tmp += new - old like uniform_filter1d
+                        s1[k] += (double)b - (double)b2;
+                        s3[k] += (double)(b * b) - (double)(b2 * b2);
+                        s4[k] += (double)(a * b) - (double)(a2 * b2);
+                        if (p >= z0 + H) {
+                            sz_[0][row][col] = (float)(s1[k] * inv);
+                            sz_[1][row][col] = (float)(s3[k] * inv);
+                            sz_[2][row][col] = (float)(s4[k] * inv);
+                        }
+                    }
+                }
+                if (p < z0 + H) continue;
+                const int zc = p - H;
+                __syncthreads();
+                // ---- y pass: column c of the patch, NO rows per item ----
+                if (tid < LX * (TY / NO)) {
+                    const int c = tid % LX, rc = tid / LX;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        float v[NI], f[NO];
+#pragma unroll
+                        for (int k = 0; k < NI; ++k) v[k] = sz_[a][rc * NO + k][c];
+                        box_means<WIN, NO>(v, f);
+#pragma unroll
+                        for (int k = 0; k < NO; ++k) sy_[a][rc * NO + k][c] = f[k];
+                    }
+                }
+                __syncthreads();
+                // ---- x pass + SSIM: row `row` of the tile, NO voxels per thread ----
+                if (tid < TY * (TX / NO)) {
+                    const int row = tid / (TX / NO), ch = tid % (TX / NO);
+                    const int y = y0 + row;
+                    if (y < S.ny - pad) {
+                        float f[3][NO];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            float v[NI];
+#pragma unroll
+                            for (int k = 0; k < NI; ++k) v[k] = sy_[a][row][ch * NO + k];
+                            box_means<WIN, NO>(v, f[a]);
+                        }
+                        const int obase = (zc * S.ny + y) * S.nx + x0 + ch * NO;
+#pragma unroll
+                        for (int k = 0; k < NO; ++k) {
+                            if (x0 + ch * NO + k >= S.nx - pad) continue;
+                            const float a = ux[obase + k], axx = uxx[obase + k], b = f[0][k];
+                            const float vx = cov_norm * (axx - a * a);
+                            const float vy = cov_norm * (f[1][k] - b * b);
+                            const float vxy = cov_norm * (f[2][k] - a * b);
+                            const float A1 = 2.f * a * b + C1, A2 = 2.f * vxy + C2;
+                            const float B1 = a * a + b * b + C1, B2 = vx + vy + C2;
+                            acc += (double)((A1 * A2) / (B1 * B2));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mx = fmaxf(mx, __shfl_down(mx, off));
+        hn |= __shfl_down(hn, off);
+        acc += __shfl_down(acc, off);
+    }
+    __shared__ float r_mx[4];
+    __shared__ int r_hn[4];
+    __shared__ double r_acc[4];
+    if ((tid & 63) == 0) { r_mx[tid >> 6] = mx; r_hn[tid >> 6] = hn; r_acc[tid >> 6] = acc; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) { mx = fmaxf(mx, r_mx[w]); hn |= r_hn[w]; acc += r_acc[w]; }
+        const size_t o = (size_t)blockIdx.y * kStatBlocks + blockIdx.x;
+        pmax[o] = mx; phasnan[o] = hn; psum[o] = acc;
+    }
+}
+
 // folds the per-workgroup partials of one candidate's SSIM passes
 __global__ __launch_bounds__(256) void finish_region_kernel(const float* __restrict__ pmax, const int* __restrict__ phasnan,
                                                             const double* __restrict__ psum, RegionStats* __restrict__ out) {
@@ -1199,11 +1359,13 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         bool scored[kMaxResident];
         FirstBatch first_batch;
         YxBatch yx_batch;
+        FusedBatch fused_batch;
         bool any_batched = false;
         float batch_cov_norm = 0.f;
         for (int j = 0; j < nb; ++j) {
             first_batch.c[j] = FirstCand{nullptr, nullptr, nullptr, nullptr, ShiftArg{0.0, 0.0, 0.0, 0}, 0};
             yx_batch.c[j] = YxCand{nullptr, nullptr, nullptr};
+            fused_batch.c[j] = FusedCand{nullptr, 0, 0, 0};
         }
         for (int j = 0; j < nb; ++j) {
             const int ic = todo[b0 + j];
@@ -1245,6 +1407,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 float* d1 = cand3[(size_t)3 * j], *d3 = cand3[(size_t)3 * j + 1], *d4 = cand3[(size_t)3 * j + 2];
                 first_batch.c[j] = FirstCand{second, d1, d3, d4, shifts[j], otf[j] ? 1 : 0};
                 yx_batch.c[j] = YxCand{d1, d3, d4};
+                fused_batch.c[j] = otf[j] ? FusedCand{im1, (int)shifts[j].tz, (int)shifts[j].ty, (int)shifts[j].tx} : FusedCand{im1t_buf[j], 0, 0, 0};
                 any_batched = true;
                 batch_cov_norm = cov_norm;
             }
@@ -1254,7 +1417,13 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             else launch_ssim_passes<3>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa);
             scored[j] = true;
         }
-        if (any_batched) {
+        if (any_batched && !c->ssim_two_pass) {
+            // one resident round of workgroups (3 per CU); z segments only when the tiles alone do not fill the GPU
+            const int tiles = ((S.ny - 6 + 15) / 16) * ((S.nx - 6 + 55) / 56), cz = S.nz - 6;
+            const int nzs = std::max(1, std::min(768 / std::max(tiles * nb, 1), (cz + 7) / 8));
+            hipLaunchKernelGGL(ssim_fused_batch_kernel<7>, dim3(kStatBlocks, nb), dim3(256), 0, c->stream, im0, S, fused_batch, setB[2], setB[3],
+                               (cz + nzs - 1) / nzs, batch_cov_norm, C1, C2, pmax, phasnan, psum);
+        } else if (any_batched) {
             hipLaunchKernelGGL(ssim_first_pass_batch_kernel<7>, dim3(kStatBlocks, nb), dim3(256), 0, c->stream, im0, S, first_batch, pmax, phasnan);
             hipLaunchKernelGGL(ssim_yx_batch_kernel<7>, dim3(kStatBlocks, nb), dim3(256), 0, c->stream, yx_batch, setB[2], setB[3], S, batch_cov_norm, C1, C2, psum);
         }

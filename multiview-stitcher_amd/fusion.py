@@ -449,6 +449,30 @@ def process_output_chunksize(sims, output_chunksize):
     return output_chunksize
 
 
+MAX_LAUNCH_BYTES = int(os.environ.get("MVS_MAX_LAUNCH_BYTES", 32 << 30))
+
+
+def _merged_chunksize(chunksize, shape, sdims, itemsize, max_bytes=None):
+    """Launch-block size for fuse(merge_chunks=True): whole multiples of the requested chunk size, as large as fits
+    ``max_bytes`` of output -- the whole stack if possible, otherwise the block count is doubled along the axis with
+    the longest blocks (first axis on ties) until a block fits."""
+    max_bytes = MAX_LAUNCH_BYTES if max_bytes is None else int(max_bytes)
+    cs = {d: max(int(chunksize[d]), 1) for d in sdims}
+    nchunks = {d: -(-int(shape[d]) // cs[d]) for d in sdims}
+    parts = {d: 1 for d in sdims}
+
+    def block(d):
+        return min(-(-nchunks[d] // parts[d]) * cs[d], int(shape[d]))
+
+    while int(np.prod([block(d) for d in sdims])) * itemsize > max_bytes:
+        cand = [d for d in sdims if parts[d] < nchunks[d]]
+        if not cand:
+            break
+        d = max(cand, key=lambda d_: block(d_))
+        parts[d] = min(parts[d] * 2, nchunks[d])
+    return {d: block(d) for d in sdims}
+
+
 # --- chunk -> view-slab planner (_core.py:354-722) ---------------------------------------------
 def _isclose(a, b, atol):
     """np.isclose(a, b, atol=atol) (rtol 1e-5) for Python scalars -- the planner calls it thousands of times per plan
@@ -652,6 +676,7 @@ def fuse(
     sims=None,
     device=0,
     chunk_filter=None,
+    merge_chunks=True,
 ):
     """Fuse input views (fusion.fuse, _core.py:782-1501), eagerly, on the HIP backend.
 
@@ -666,6 +691,10 @@ def fuse(
     a SpatialImage with identity affine under ``transform_key``.
     ``chunk_filter(block_index) -> bool`` restricts the work to a subset of
     chunks (used by the multi-GPU farm); untouched chunks stay zero.
+    ``merge_chunks``: with an in-memory (host or device) result, the built-in fusion functions and no halo, the chunk
+    grid is only the reference's unit of dask scheduling -- every output voxel is the same function of the views
+    whichever chunk it falls in -- so the requested chunks are merged into launch blocks of up to
+    ``MAX_LAUNCH_BYTES`` of output (the whole mosaic when it fits: one ``mvs_fuse_chunk`` launch instead of hundreds).
     """
     if images is None:
         if sims is None:
@@ -706,6 +735,13 @@ def fuse(
             if not isinstance(cur, dict):
                 cur = {d: cur for d in sdims}
             overlap_in_pixels = {d: max(overlap_in_pixels[d], cur[d]) for d in sdims}
+
+    if (merge_chunks and output_zarr_url is None and not batch_options and chunk_filter is None
+            and weights_func is None and fusion_func in _FUSION_CODES and not any(overlap_in_pixels[d] for d in sdims)
+            and not any(type(s_.data).__name__ in ("ZarrArray", "ZarrView") for s_ in sims_)      # stores are read slab by slab
+            and not ("z" in sdims and int(output_chunksize["z"]) == 1 and output_stack_properties["shape"]["z"] > 1)):
+        output_chunksize = _merged_chunksize(output_chunksize, output_stack_properties["shape"], sdims,
+                                             np.dtype(sims_[0].dtype).itemsize)
 
     chunk_bbs, block_indices = mv_graph.get_chunk_bbs(output_stack_properties, output_chunksize)
     chunk_bbs_ov = [
@@ -878,6 +914,8 @@ def fuse(
                     chunk = chunk[np.newaxis]
                 if zarr_out is not None:
                     zarr_out.write(list(ns_index) + [s_.start for s_ in sl], chunk.reshape((1,) * len(ns_index) + chunk.shape))
+                elif chunk.shape == result.shape:
+                    result = chunk           # one launch block and one field: the fused array is the result
                 else:
                     result[tuple(ns_index) + sl] = chunk
         if on_device:

@@ -73,3 +73,19 @@ def test_builtin_maps_reference_function_objects_by_name():
     assert fusion.builtin(None) is None
     with pytest.raises(NotImplementedError):
         fusion.builtin(lambda x: x)
+
+
+def test_merged_chunksize_is_whole_multiples_within_budget():
+    """fuse(merge_chunks=True): launch blocks are multiples of the requested chunks, the whole stack when it fits."""
+    from multiview_stitcher_amd import fusion
+
+    shape = {"z": 1742, "y": 1742, "x": 1742}
+    cs = {d: 256 for d in "zyx"}
+    assert fusion._merged_chunksize(cs, shape, "zyx", 2) == shape                    # 10.6 GB: one block
+    m = fusion._merged_chunksize(cs, shape, "zyx", 2, max_bytes=3 << 30)
+    assert all(m[d] % 256 == 0 or m[d] == shape[d] for d in "zyx")
+    assert m["z"] * m["y"] * m["x"] * 2 <= 3 << 30
+    assert m["z"] <= m["y"] <= m["x"]                                                # z is cut first
+    tiny = fusion._merged_chunksize(cs, shape, "zyx", 2, max_bytes=1)
+    assert tiny == cs                                                                 # never below the request
+    assert fusion._merged_chunksize({"y": 5, "x": 5}, {"y": 18, "x": 18}, "yx", 2) == {"y": 18, "x": 18}

@@ -412,3 +412,39 @@ def test_many_candidates_span_several_batches(hip_device):
     ssim, spear, codes = res[1]
     best = int(np.nanargmax(np.where(codes == 0, ssim, -np.inf)))
     assert tuple(cands[best]) == (1, -2, 3) and np.isfinite(spear[best]) and np.isnan(spear).sum() == (codes == 0).sum() - 1
+
+
+@pytest.mark.parametrize("shape", [(51, 128, 120), (96, 51, 70), (40, 90, 29), (9, 30, 64)])
+def test_fused_ssim_walk_equals_separate_passes_and_oracle(hip_device, shape):
+    """Finite 3D crops, several candidates: one launch walks z per (y, x) tile and keeps the z- and y-filtered planes in LDS
+    (ssim_fused_batch_kernel) instead of the z launch + y/x launch of option "ssim_two_pass".  Same codes and region
+    decisions, SSIM equal up to the summation order of the float64 running sums (1e-9), and within the oracle bar."""
+    from multiview_stitcher_amd import _lib, _reg_ops
+
+    rng = np.random.default_rng(11)
+    a, b = _pair(shape, (2, -3, 4), noise=0.01)
+    a, b = np.nan_to_num(ro.rescale_intensity_01(a)), np.nan_to_num(ro.rescale_intensity_01(b))
+    cands = np.array([(0, 0, 0), (-2, 3, -4), (-2.5, 3, -4), (-1.5, 2.5, -3.5), (3, -5, 7), (-2, 3, -3), (0, 0, 1), (shape[0] - 2, 0, 0),
+                      (-1, -1, -1), (2 * shape[0], 0, 0)], dtype=np.float64)
+    dr = float(max(a.max(), b.max()) - min(a.min(), b.min()))
+    res = []
+    for flag in (1, 0):
+        _lib.set_option("ssim_two_pass", flag)
+        try:
+            res.append(_reg_ops.score_candidates(a, b, cands, "union", dr, float(b.min()), quality_for_all=False))
+        finally:
+            _lib.set_option("ssim_two_pass", 0)
+    (s0, q0, c0), (s1, q1, c1) = res
+    np.testing.assert_array_equal(c0, c1)
+    np.testing.assert_allclose(s1, s0, rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(np.isnan(q0), np.isnan(q1))
+    np.testing.assert_allclose(q1[~np.isnan(q1)], q0[~np.isnan(q0)], rtol=1e-12)
+    assert (c1 == 0).sum() >= 6 and (c1 == 1).sum() >= 1
+    im0nm = np.isnan(a)
+    valid1 = int(np.sum(~np.isnan(b)))
+    bb0 = ro.get_bb_from_nanmask(~im0nm)
+    for i in (0, 1, 3, 7):
+        code, s, _ = ro.score_candidate(a, b, im0nm, cands[i], valid1, "union", dr, float(b.min()), bb0)
+        assert code == c1[i]
+        if code == 0:
+            assert abs(s1[i] - s) <= 2e-5 * max(abs(s), 1e-3)

@@ -71,7 +71,7 @@ def test_kat_axis_aligned_translation_max_fusion(hip_device):
 
     sims = [_sim(np.ones((1, 1, 8, 8)) .astype(np.float32) * v, ["c", "t", "y", "x"], {"y": 1.0, "x": 1.0}, {"y": 0.0, "x": xo})
             for v, xo in [(1, 0.0), (2, 6.0)]]
-    fused = fusion.fuse(sims, transform_key="k", fusion_func=fusion.max_fusion, output_chunksize={"y": 4, "x": 4})
+    fused = fusion.fuse(sims, transform_key="k", fusion_func=fusion.max_fusion, output_chunksize={"y": 4, "x": 4}, merge_chunks=False)
     d = np.asarray(fused.data)
     assert d.shape == (1, 1, 8, 14)
     np.testing.assert_array_equal(d[..., :, :6], 1)
@@ -85,7 +85,7 @@ def test_kat_singleton_view_slice_preserves_spacing(hip_device):
     sim = _sim(np.ones((2, 20), dtype=np.uint16), ["y", "x"], {"y": 0.3, "x": 0.3}, {"y": 0.0, "x": 0.0})
     props = {"origin": {"y": 0.0, "x": -2.7}, "spacing": {"y": 0.3, "x": 0.3}, "shape": {"y": 2, "x": 29}}
     fused = fusion.fuse([sim], transform_key="k", fusion_func=fusion.max_fusion, interpolation_order=0,
-                        output_stack_properties=props, output_chunksize={"y": 2, "x": 10})
+                        output_stack_properties=props, output_chunksize={"y": 2, "x": 10}, merge_chunks=False)
     want = np.tile(np.concatenate([np.zeros(9, np.uint16), np.ones(20, np.uint16)]), (2, 1))
     np.testing.assert_array_equal(np.squeeze(np.asarray(fused.data)), want)
 
@@ -99,7 +99,7 @@ def test_kat_large_origin_roundoff(hip_device):
     s = si.get_spacing_from_sim(sim)["x"]
     props = {"origin": {"y": 0.0, "x": origin - 9 * s}, "spacing": {"y": s, "x": s}, "shape": {"y": 2, "x": 4093}}
     fused = fusion.fuse([sim], transform_key="k", fusion_func=fusion.max_fusion, interpolation_order=0,
-                        output_stack_properties=props, output_chunksize={"y": 2, "x": 4084})
+                        output_stack_properties=props, output_chunksize={"y": 2, "x": 4084}, merge_chunks=False)
     want = np.tile(np.concatenate([np.zeros(9, np.uint16), np.ones(4084, np.uint16)]), (2, 1))
     np.testing.assert_array_equal(np.squeeze(np.asarray(fused.data)), want)
 
@@ -113,7 +113,7 @@ def test_kat_fractional_translation_grid(hip_device):
     for iv, tr in enumerate([{"y": 0, "x": 0}, {"y": a, "x": 0}, {"y": 0, "x": a}, {"y": a, "x": a}]):
         sim = _sim(np.full((2, 10, 10), iv + 1, dtype=np.uint16), ["c", "y", "x"], {"y": 1, "x": 1}, tr)
         msims.append(msi_utils.get_msim_from_sim(sim, scale_factors=[]))
-    fused = fusion.fuse(images=msims, transform_key="k", output_chunksize={"y": 5, "x": 5})
+    fused = fusion.fuse(images=msims, transform_key="k", output_chunksize={"y": 5, "x": 5}, merge_chunks=False)
     d = np.asarray(fused.data)
     assert fused.sizes["y"] == 18 and fused.sizes["x"] == 18
     assert d.max() == 4 and d.min() > 0
@@ -175,7 +175,7 @@ def test_chunked_fuse_with_device_resident_mosaic(hip_device):
 
     fields = [squeeze_field(s) for s in sims]
     dsims = [f.copy(data=DeviceArray.from_host(np.ascontiguousarray(f.data), 0)) for f in fields]
-    kw = dict(transform_key=key, output_chunksize={"z": 32, "y": 32, "x": 32})
+    kw = dict(transform_key=key, output_chunksize={"z": 32, "y": 32, "x": 32}, merge_chunks=False)
     host = np.asarray(fusion.fuse(fields, **kw).data)
     dev = fusion.fuse(dsims, output_on_backend=True, **kw)       # slabs are strided windows of the device tiles
     np.testing.assert_array_equal(dev.data.get().reshape(host.shape), host)
@@ -183,6 +183,10 @@ def test_chunked_fuse_with_device_resident_mosaic(hip_device):
     diff = host.astype(np.int64) - whole.astype(np.int64)
     assert np.abs(diff).max() <= 1
     assert (diff != 0).mean() < 0.02
+    # merge_chunks (the default): the 32^3 request becomes one launch block = the unchunked result, host or device
+    kw["merge_chunks"] = True
+    np.testing.assert_array_equal(np.asarray(fusion.fuse(fields, **kw).data), whole)
+    np.testing.assert_array_equal(fusion.fuse(dsims, output_on_backend=True, **kw).data.get().reshape(whole.shape), whole)
 
 
 @pytest.mark.parametrize("ndim", [2, 3])

@@ -21,7 +21,7 @@ def test_two_rank_shard_equals_single_device(hip_device):
     # reference: everything on one device
     full = [s.copy(data=DeviceArray.from_host(np.ascontiguousarray(s.data), 0)) for s in sims]
     ref = registration.register(full, transform_key=key, new_transform_key="reg", device=0, return_dict=True)
-    want = np.asarray(fusion.fuse(full, transform_key="reg", output_chunksize={d: 64 for d in "zyx"}).data)
+    want = np.asarray(fusion.fuse(full, transform_key="reg", output_chunksize={d: 64 for d in "zyx"}, merge_chunks=False).data)
 
     # partition from the stage metadata
     sps = [si.get_stack_properties_from_sim(s) for s in sims]
@@ -71,10 +71,18 @@ def test_two_rank_shard_equals_single_device(hip_device):
     got = np.zeros_like(want)
     covered = np.zeros(want.shape[-3:], dtype=bool)
     for r in range(world):
-        fused, box = sharding.fuse_shard(rank_sims[r], r, world, "reg", output_chunksize={d: 64 for d in "zyx"}, device=0 | (r << 8))
+        fused, box = sharding.fuse_shard(rank_sims[r], r, world, "reg", output_chunksize={d: 64 for d in "zyx"}, device=0 | (r << 8),
+                                         merge_chunks=False)
         sl = tuple(slice(box["index_offset"][d], box["index_offset"][d] + box["shape"][d]) for d in "zyx")
         got[(Ellipsis,) + sl] = np.asarray(fused.data)
         assert not covered[sl].any()
         covered[sl] = True
     assert covered.all()
     np.testing.assert_array_equal(got, want)
+    # one launch block per sub-box (merge_chunks, the default): equal up to the float32 rounding of block-relative
+    # coordinates (the registered offsets are fractional)
+    for r in range(world):
+        fused, box = sharding.fuse_shard(rank_sims[r], r, world, "reg", device=0 | (r << 8))
+        sl = tuple(slice(box["index_offset"][d], box["index_offset"][d] + box["shape"][d]) for d in "zyx")
+        diff = np.asarray(fused.data).astype(np.int64) - want[(Ellipsis,) + sl].astype(np.int64)
+        assert np.abs(diff).max() <= 1 and (diff != 0).mean() < 0.02
