@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--tile", type=str, default="512,512,512", help="tile shape z,y,x")
     ap.add_argument("--overlap-frac", type=float, default=0.2)
     ap.add_argument("--cpu-tile", type=int, default=192, help="edge of the small tiles of the cpu_baseline sample")
-    ap.add_argument("--reg-threads", type=int, default=None, help="host threads / context lanes for the pairwise registrations (library default: 8)")
+    ap.add_argument("--reg-threads", type=int, default=None, help="host threads / context lanes for the pairwise registrations (library default: 16)")
     ap.add_argument("--no-register", action="store_true", help="time fusion only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["shard", "replica"], default=None,
@@ -545,7 +545,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": reg_bytes / args.steps / (pair_wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "duration = wall time of compute_pairwise_registrations (kernels of 8 context lanes overlap; includes host round trips)",
+                "note": "duration = wall time of compute_pairwise_registrations (kernels of the context lanes (default 16) overlap; includes host round trips)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -909,6 +909,7 @@ __global__ __launch_bounds__(256) void rankcorr_kernel(const float* __restrict__
 // compaction, two multi-pass radix sorts and the run-length rank kernels.  Ties and order are those of the exact
 // interpolated values; the float32 values scipy ranks are those values rounded once, distinct wherever the exact ones are
 // (spacing >= 2^-3 / range against 2^-24 relative), so the rank vectors coincide.
+constexpr int kHistParts = 256;           // workgroups whose private histograms are written out and folded (more: atomic flush)
 constexpr int kHistBinsMax = 48 * 1024;      // x + y bins a workgroup's private histogram can hold (16-bit counters in 96 KiB of LDS)
 __device__ __forceinline__ int shifted_keysum(const float* __restrict__ raw1, int sy, int sz, const AxisTap& Z, const AxisTap& Y,
                                               const AxisTap& X) {
@@ -928,11 +929,11 @@ __device__ __forceinline__ int shifted_keysum(const float* __restrict__ raw1, in
 // keys, global atomics on them serialise -- and adds its non-empty bins to the global tables.
 // CORR = true: sum of rx[kx] * ry[ky] over the jointly valid voxels.
 template <bool CORR>
-__global__ __launch_bounds__(256) void hist_rank_kernel(const float* __restrict__ raw0, const float* __restrict__ raw1, Shape3 S, double tz,
+__global__ __launch_bounds__(CORR ? 256 : 1024) void hist_rank_kernel(const float* __restrict__ raw0, const float* __restrict__ raw1, Shape3 S, double tz,
                                                         double ty, double tx, int kx0, int nbx, int ky0, int nby,
                                                         unsigned int* __restrict__ hx, unsigned int* __restrict__ hy,
                                                         const float* __restrict__ rx, const float* __restrict__ ry,
-                                                        double* __restrict__ partial) {
+                                                        double* __restrict__ partial, unsigned int* __restrict__ parts) {
     extern __shared__ unsigned int s_hist[];          // (nbx + nby + 1) / 2 words of two 16-bit counters
     const unsigned int n = (unsigned int)S.nz * S.ny * S.nx;
     const int sy = S.nx, sz = S.ny * S.nx;
@@ -981,6 +982,11 @@ __global__ __launch_bounds__(256) void hist_rank_kernel(const float* __restrict_
         if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = sxy;
         __syncthreads();
         if (threadIdx.x == 0) partial[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+    } else if (parts) {
+        // the private histogram goes out whole (coalesced, no atomics); hist_fold_kernel adds the workgroups' parts
+        __syncthreads();
+        unsigned int* mine = parts + (size_t)blockIdx.x * nwords;
+        for (int i = threadIdx.x; i < nwords; i += blockDim.x) mine[i] = s_hist[i];
     } else {
         __syncthreads();
         for (int i = threadIdx.x; i < nwords; i += blockDim.x) {
@@ -996,6 +1002,31 @@ __global__ __launch_bounds__(256) void hist_rank_kernel(const float* __restrict_
 }
 // One workgroup per table: centred average ranks of the bins, rc[v] = #(keys < v) + (h[v] + 1) / 2 - (m + 1) / 2, and
 // out[0] = sum_v h[v] rc[v]^2, out[1] = m (the number of keys).  1024 threads, contiguous bin ranges, two passes.
+// sums the packed 16-bit histograms of `nparts` workgroups into the 32-bit histograms hx (bins < nbx) and hy: a workgroup
+// takes 64 words, its four wavefronts a quarter of the parts each
+__global__ __launch_bounds__(256) void hist_fold_kernel(const unsigned int* __restrict__ parts, int nparts, int nwords, int nbx, int nby,
+                                                        unsigned int* __restrict__ hx, unsigned int* __restrict__ hy) {
+    __shared__ unsigned int s0[4][64], s1[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    unsigned int c0 = 0, c1 = 0;
+    if (i < nwords)
+        for (int w = q; w < nparts; w += 4) {
+            const unsigned int v = parts[(size_t)w * nwords + i];
+            c0 += v & 0xffffu;
+            c1 += v >> 16;
+        }
+    s0[q][lane] = c0; s1[q][lane] = c1;
+    __syncthreads();
+    if (q == 0 && i < nwords) {
+        c0 = s0[0][lane] + s0[1][lane] + s0[2][lane] + s0[3][lane];
+        c1 = s1[0][lane] + s1[1][lane] + s1[2][lane] + s1[3][lane];
+        const int b0 = 2 * i, b1 = 2 * i + 1;
+        if (b0 < nbx) hx[b0] = c0; else if (b0 - nbx < nby) hy[b0 - nbx] = c0;
+        if (b1 < nbx) hx[b1] = c1; else if (b1 - nbx < nby) hy[b1 - nbx] = c1;
+    }
+}
+
 __global__ __launch_bounds__(1024) void rank_table_kernel(const unsigned int* __restrict__ hx, int nx, float* __restrict__ rx,
                                                           const unsigned int* __restrict__ hy, int ny, float* __restrict__ ry,
                                                           double* __restrict__ out) {
@@ -1139,7 +1170,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     const size_t stat_bytes = (size_t)(kMaxResident + 2) * kStatBlocks * (sizeof(VoxStats) + 4 + 4 + 8) + (kMaxResident + 2) * 64;
     // batched launches (one z pass / one y-x pass for all candidates of a batch) keep three z-filtered arrays per candidate
     const bool may_batch = ndim == 3 && region_mode == 0 && !quality_for_all && !c->materialize_shifts && (long long)n * 12 * nres <= (3ll << 30);
-    const size_t need = (size_t)n * 4 * (10 + nres + (may_batch ? 3 * nres : 0)) + 256 * (12 + 4 * nres) + sort_temp_bytes + (size_t)gb * 32 + stat_bytes + 64 * 1024 + (size_t)(kHistBinsMax + 64) * 8 + 1024;
+    const size_t need = (size_t)n * 4 * (10 + nres + (may_batch ? 3 * nres : 0)) + 256 * (12 + 4 * nres) + sort_temp_bytes + (size_t)gb * 32 + stat_bytes + 64 * 1024 + (size_t)(kHistBinsMax + 64) * 8 + (size_t)kHistParts * (kHistBinsMax / 2 + 1) * 4 + 2048;
     char* base = (char*)mvs_scratch(c, 6, need);
     if (!base) return MVS_ERR_HIP;
     DeviceBump B{base, need, 0};
@@ -1160,6 +1191,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     RegionStats* reg_out = B.take<RegionStats>(kMaxResident);
     unsigned int* d_hist = B.take<unsigned int>((size_t)kHistBinsMax + 64);     // key histograms of the rank correlation
     float* d_rank = B.take<float>((size_t)kHistBinsMax + 64);
+    unsigned int* d_parts = B.take<unsigned int>((size_t)kHistParts * (kHistBinsMax / 2 + 1));   // per-workgroup packed histograms
     unsigned int* d_counter = B.take<unsigned int>(64);
     if (!d_counter) return mvs_fail(c, MVS_ERR_HIP, "mvs_score_candidates: scratch layout");
 
@@ -1239,7 +1271,11 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             // key ranges from the raw extrema of the crops (c->raw_range: min / max of the fixed and of the moving crop)
             const long long kx0 = (long long)c->raw_range[0], nbx = (long long)c->raw_range[1] - kx0 + 1;
             const long long ky0 = (long long)c->raw_range[2] * (1 << nf), nby = ((long long)c->raw_range[3] - (long long)c->raw_range[2]) * (1 << nf) + 1;
-            const long long hgb = std::max<long long>(gb, ((long long)n / 4 + 16382) / 16383);      // < 65536 voxels per workgroup
+            // < 65536 voxels per workgroup; up to kHistParts workgroups write their histograms out whole (folded by a
+            // second kernel), beyond that the non-zero counters are flushed with atomics
+            const long long hneed = ((long long)n / 4 + 16382) / 16383;
+            const bool fold = hneed <= kHistParts;
+            const long long hgb = fold ? std::max<long long>(hneed, std::min<long long>(kHistParts, ((long long)n + 8191) / 8192)) : std::max<long long>(gb, hneed);
             if (halves && c->raw_u16_keys[0] && c->raw_u16_keys[1] && c->both_crops_finite && !c->materialize_shifts && nbx > 0 && nby > 0 &&
                 nbx + nby <= kHistBinsMax && hgb <= 65535) {
                 static bool lds_attr[MVS_MAX_DEVICES] = {false};
@@ -1248,14 +1284,19 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                     lds_attr[mvs_hip_device(device)] = true;
                 }
                 const size_t lds_bytes = (size_t)((nbx + nby + 1) / 2) * 4;
-                MVS_HIP_TRY(c, hipMemsetAsync(d_hist, 0, sizeof(unsigned int) * (size_t)(nbx + nby), c->stream));
-                hipLaunchKernelGGL(hist_rank_kernel<false>, dim3((unsigned)hgb), dim3(256), lds_bytes, c->stream, c->raw_u16_keys[0], c->raw_u16_keys[1],
+                if (!fold) MVS_HIP_TRY(c, hipMemsetAsync(d_hist, 0, sizeof(unsigned int) * (size_t)(nbx + nby), c->stream));
+                hipLaunchKernelGGL(hist_rank_kernel<false>, dim3((unsigned)hgb), dim3(1024), lds_bytes, c->stream, c->raw_u16_keys[0], c->raw_u16_keys[1],
                                    S, t[0], t[1], t[2], (int)kx0, (int)nbx, (int)ky0, (int)nby, d_hist, d_hist + nbx, (const float*)nullptr,
-                                   (const float*)nullptr, (double*)nullptr);
+                                   (const float*)nullptr, (double*)nullptr, fold ? d_parts : (unsigned int*)nullptr);
+                if (fold) {
+                    const int nwords = (int)((nbx + nby + 1) / 2);
+                    hipLaunchKernelGGL(hist_fold_kernel, dim3((nwords + 63) / 64), dim3(256), 0, c->stream, d_parts, (int)hgb, nwords, (int)nbx, (int)nby,
+                                       d_hist, d_hist + nbx);
+                }
                 hipLaunchKernelGGL(rank_table_kernel, dim3(2), dim3(1024), 0, c->stream, d_hist, (int)nbx, d_rank, d_hist + nbx, (int)nby,
                                    d_rank + nbx, partial);
                 hipLaunchKernelGGL(hist_rank_kernel<true>, dim3(gb), dim3(256), 0, c->stream, c->raw_u16_keys[0], c->raw_u16_keys[1], S, t[0], t[1],
-                                   t[2], (int)kx0, (int)nbx, (int)ky0, (int)nby, d_hist, d_hist + nbx, d_rank, d_rank + nbx, partial + 4);
+                                   t[2], (int)kx0, (int)nbx, (int)ky0, (int)nby, d_hist, d_hist + nbx, d_rank, d_rank + nbx, partial + 4, (unsigned int*)nullptr);
                 std::vector<double> hp((size_t)gb + 4);
                 MVS_HIP_TRY(c, hipMemcpyAsync(hp.data(), partial, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, c->stream));
                 MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));

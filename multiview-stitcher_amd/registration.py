@@ -563,7 +563,7 @@ def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=Non
 
 def compute_pairwise_registrations(msims, edges, transform_key, registration_binning=None, overlap_tolerance=0.0,
                                    pairwise_reg_func=phase_correlation_registration, pairwise_reg_func_kwargs=None,
-                                   pairwise_executor=None, device=0, host_threads=8):
+                                   pairwise_executor=None, device=0, host_threads=16):
     """registration.compute_pairwise_registrations (registration.py:2622-2714): either hand all edges to a
     user ``pairwise_executor(msims, edges, register_kwargs)`` or loop over them on one device."""
     register_kwargs = dict(transform_key=transform_key, registration_binning=registration_binning,
@@ -744,7 +744,7 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
         results = compute_pairwise_registrations(
             fields, edges, transform_key, registration_binning, overlap_tolerance, pairwise_reg_func,
             pairwise_reg_func_kwargs, pairwise_executor, device,
-            host_threads=(8 if n_parallel_pairwise_regs is None else n_parallel_pairwise_regs),
+            host_threads=(16 if n_parallel_pairwise_regs is None else n_parallel_pairwise_regs),
         )
         keep = list(range(len(edges)))
         if post_registration_do_quality_filter:
