@@ -96,7 +96,9 @@ __global__ __launch_bounds__(256) void gauss1d_lds_kernel(const float* __restric
     const long long l0 = (long long)blockIdx.x * T;
     const int nl = (int)min((long long)T, L.n_lines - l0);
     const int total = T * len;
-    // ---- stage the lines ----
+    // ---- stage the lines; note whether every sample of the tile has the same bits as its first one ----
+    const float first = src[(l0 / L.inner) * L.outer_stride + (l0 % L.inner)];
+    int same = 1;
     for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
         int line, pos;
         if (pos_fastest) { line = idx / len; pos = idx - line * len; }
@@ -105,10 +107,26 @@ __global__ __launch_bounds__(256) void gauss1d_lds_kernel(const float* __restric
         if (line < nl) {
             const long long l = l0 + line;
             v = src[(l / L.inner) * L.outer_stride + (l % L.inner) + (long long)pos * L.stride];
+            same &= (__float_as_uint(v) == __float_as_uint(first)) ? 1 : 0;
         }
         sl[(pos + radius) * TP + line] = v;
     }
-    __syncthreads();
+    if (__syncthreads_and(same)) {
+        // a constant tile (outside a view's footprint: value and mask 0; deep inside it: mask 1, and the constants the
+        // earlier axes made of those): every output is the same sum, evaluated once in the order of the general path
+        double acc = (double)first * fw[radius];
+        for (int j = radius; j >= 1; --j) acc = fma((double)first + (double)first, fw[radius - j], acc);
+        const float r = (float)acc;
+        for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+            int line, pos;
+            if (pos_fastest) { line = idx / len; pos = idx - line * len; }
+            else { pos = idx / T; line = idx - pos * T; }
+            if (line >= nl) continue;
+            const long long l = l0 + line;
+            dst[(l / L.inner) * L.outer_stride + (l % L.inner) + (long long)pos * L.stride] = r;
+        }
+        return;
+    }
     // ---- reflected halo: d c b a | a b c d | d c b a (period 2 len) ----
     for (int idx = threadIdx.x; idx < 2 * radius * T; idx += blockDim.x) {
         const int h = idx / T, line = idx - h * T;
@@ -122,17 +140,51 @@ __global__ __launch_bounds__(256) void gauss1d_lds_kernel(const float* __restric
         sl[(p + radius) * TP + line] = sl[(q + radius) * TP + line];
     }
     __syncthreads();
-    // ---- filter ----
-    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-        int line, pos;
-        if (pos_fastest) { line = idx / len; pos = idx - line * len; }
-        else { pos = idx / T; line = idx - pos * T; }
+    // ---- filter: a thread produces K consecutive outputs of one line.  Pair j of output k needs the samples k - j and
+    // k + j: over the K outputs these are two windows of K samples that slide by one (in opposite directions) when j
+    // drops by one, so every step costs two LDS reads and two conversions for K (add, multiply, add) triples -- the
+    // tap-by-tap form read and converted 2 (2 r + 1) samples per output and was bound by exactly that.  The windows
+    // rotate through fixed registers (the j loop is unrolled K-fold); per output the order of operations is scipy's, with
+    // the multiply-add fused (one rounding less in float64, 1e-16 relative: invisible after the float32 store). ----
+    constexpr int K = 8;
+    const int nblk = (len + K - 1) / K;
+    const int qmax = len - 1 + 2 * radius;                        // last staged row of the LDS array
+    for (int idx = threadIdx.x; idx < T * nblk; idx += blockDim.x) {
+        const int blk = idx / T, line = idx - blk * T;
         if (line >= nl) continue;
-        const float* c = sl + (pos + radius) * TP + line;
-        double acc = (double)c[0] * fw[radius];
-        for (int j = radius; j >= 1; --j) acc += ((double)c[-j * TP] + (double)c[j * TP]) * fw[radius - j];
+        const int p0 = blk * K;
+        const float* c = sl + line;                                // sample at position q: c[(q + radius) * TP]
+        double PA[K], PB[K], acc[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            PA[k] = (double)c[min(p0 + k, qmax) * TP];                                  // position p0 + k - radius
+            PB[k] = (double)c[min(p0 + k + 2 * radius, qmax) * TP];                     // position p0 + k + radius
+            acc[k] = (double)c[min(p0 + k + radius, qmax) * TP] * fw[radius];
+        }
+        for (int jb = radius; jb >= 1; jb -= K) {
+#pragma unroll
+            for (int s = 0; s < K; ++s) {
+                const int j = jb - s;
+                if (j < 1) break;
+                const double w = fw[radius - j];
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc[k] = fma(PA[(k + s) % K] + PB[(k - s + K) % K], w, acc[k]);
+                // windows of pair j - 1: one new sample each (positions p0 + K - 1 - (j - 1) and p0 + (j - 1))
+                PA[s % K] = (double)c[min(p0 + K - j + radius, qmax) * TP];
+                PB[(K - 1 - s) % K] = (double)c[(p0 + j - 1 + radius) * TP];
+            }
+        }
         const long long l = l0 + line;
-        dst[(l / L.inner) * L.outer_stride + (l % L.inner) + (long long)pos * L.stride] = (float)acc;
+        const long long obase = (l / L.inner) * L.outer_stride + (l % L.inner) + (long long)p0 * L.stride;
+        if (L.stride == 1 && p0 + K <= len && ((obase & 3) == 0)) {
+            float4* o4 = reinterpret_cast<float4*>(dst + obase);
+            o4[0] = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+            o4[1] = make_float4((float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                if (p0 + k < len) dst[obase + (long long)k * L.stride] = (float)acc[k];
+        }
     }
 }
 
