@@ -210,15 +210,16 @@ def cpu_baseline(args, grid, tile, overlap):
 
 
 def fuse_traffic_bytes(grid, tile):
-    """HBM bytes per fuse launch from the committed PMC pass (FETCH_SIZE x2 per the calibration + WRITE_SIZE,
-    profiles/round1_summary.md); only valid for the workload it was measured on."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "round1_fuse_traffic.json")) as f:
-            t = json.load(f)
-        if list(grid) == [4, 4, 4] and list(tile) == [512, 512, 512]:
-            return t["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    """HBM bytes per fuse launch from the committed PMC passes (FETCH_SIZE x2 per the calibration + WRITE_SIZE,
+    profiles/round2_summary.md, tools/profile_round2.sh); only valid for the workload it was measured on."""
+    for name in ("round2_fuse_traffic.json", "round1_fuse_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                t = json.load(f)
+            if list(grid) == [4, 4, 4] and list(tile) == [512, 512, 512]:
+                return t["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
     return None
 
 
@@ -412,6 +413,21 @@ def main():
         fuse_ms.append((time.perf_counter() - t_reg1) * 1e3)
         return fused
 
+    # Everything alive now (torch, numpy, scipy, the tiles' metadata) is long-lived: move it to the permanent generation so
+    # that the cyclic collector's occasional full passes do not walk the import graph of torch inside a step (60-70 ms each,
+    # twice in 20 steps without this).  Collection itself stays enabled.
+    import gc
+    gc.collect()
+    gc.freeze()
+    if os.environ.get("MVS_BENCH_TRACE"):
+        gc_t = {}
+
+        def gc_cb(phase, info):
+            if phase == "start":
+                gc_t["t"] = time.perf_counter()
+            else:
+                print(f"gc gen{info['generation']} {1e3 * (time.perf_counter() - gc_t['t']):.1f} ms collected {info['collected']}", file=sys.stderr)
+        gc.callbacks.append(gc_cb)
     for _ in range(max(args.warmup, 0)):
         step()
     cold_plan_ms = plan_ms[0] if plan_ms else None      # the first call of a geometry builds (and caches) the decomposition
@@ -430,6 +446,8 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    if os.environ.get("MVS_BENCH_TRACE"):
+        print("per-step ms: register", [round(v, 1) for v in reg_ms], "fuse", [round(v, 1) for v in fuse_ms], file=sys.stderr)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -502,6 +520,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u16 in/out, f32 accumulate, f64 coordinates",
             "data": "synthetic (seeded smoothed noise mosaic generated in HBM, integer jitter unknown to metadata)",
+            "host": "python gc.freeze() after setup (garbage collection stays enabled)",
             "value_incl_pcie": pcie,
             "config": {
                 "workload": f"{'x'.join(map(str, grid))} grid (z,y,x) of {'x'.join(map(str, tile))} uint16 tiles, "
