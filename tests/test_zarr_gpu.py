@@ -36,7 +36,7 @@ def test_fuse_streams_zarr_in_and_out(hip_device, tmp_path, ndim):
     key = sample_data.METADATA_TRANSFORM_KEY
     sims = _dataset(ndim)
     chunks = {"y": 128, "x": 96} if ndim == 2 else {"z": 32, "y": 96, "x": 128}
-    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks).data)
+    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks, merge_chunks=False).data)
 
     # tiles -> OME-Zarr stores -> lazy sims carrying the stage transform
     lazy = []
@@ -82,7 +82,7 @@ def test_plain_zarr_output_and_chunk_farm(hip_device, tmp_path):
     key = sample_data.METADATA_TRANSFORM_KEY
     sims = _dataset(2)
     chunks = {"y": 128, "x": 96}
-    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks).data)
+    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks, merge_chunks=False).data)
     url = str(tmp_path / "plain.zarr")
     for part in (0, 1):
         fusion.fuse(sims, transform_key=key, output_chunksize=chunks, output_zarr_url=url,
@@ -117,7 +117,7 @@ def test_device_farm_streams_into_one_store(hip_device, tmp_path):
     key = sample_data.METADATA_TRANSFORM_KEY
     sims = _dataset(2)
     chunks = {"y": 128, "x": 96}
-    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks).data)
+    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks, merge_chunks=False).data)
     url = str(tmp_path / "farm.zarr")
     os.makedirs(url)
     open(os.path.join(url, "stale"), "w").write("x")      # overwrite=True (default) clears what was there
@@ -138,7 +138,7 @@ def test_batch_options_drive_block_wise_zarr_output(hip_device, tmp_path):
     key = sample_data.METADATA_TRANSFORM_KEY
     sims = _dataset(3)
     chunks = {"z": 32, "y": 96, "x": 128}
-    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks).data)
+    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks, merge_chunks=False).data)
     seen, batch_sizes = [], []
 
     def spy(fuse_chunk, block_ids, tag=None):
