@@ -141,6 +141,46 @@ template <> struct Out8<unsigned short> { typedef unsigned short v8 __attribute_
 template <> struct Out8<unsigned char> { typedef unsigned char v8 __attribute__((ext_vector_type(8), aligned(1))); };
 template <> struct Out8<float> { typedef float v8 __attribute__((ext_vector_type(8), aligned(4))); };
 
+// Integer tiles copied into an output of the same type (copy class, integer offsets): the loaded dwords go out as they are
+// -- no decode to float, no cast back, no packing.  A tail of nvalid < 8 elements leaves as 4 + 2 + 1 elements.
+typedef unsigned int u32x4_a2 __attribute__((ext_vector_type(4), aligned(2)));
+typedef unsigned int u32x2_a2 __attribute__((ext_vector_type(2), aligned(2)));
+typedef unsigned int u32_a2 __attribute__((aligned(2)));
+typedef unsigned int u32x2_a1 __attribute__((ext_vector_type(2), aligned(1)));
+__device__ __forceinline__ void store8_bits(unsigned short* p, const unsigned int (&w)[9], int nvalid) {
+    const unsigned int w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    if (nvalid >= kRV) {
+        u32x4_a2 o;
+        o.x = w0; o.y = w1; o.z = w2; o.w = w3;
+        *reinterpret_cast<u32x4_a2*>(p) = o;
+        return;
+    }
+    const bool has4 = (nvalid & 4) != 0;
+    if (has4) {
+        u32x2_a2 o;
+        o.x = w0; o.y = w1;
+        *reinterpret_cast<u32x2_a2*>(p) = o;
+    }
+    if (nvalid & 2) *reinterpret_cast<u32_a2*>(p + (has4 ? 4 : 0)) = has4 ? w2 : w0;
+    if (nvalid & 1) {                  // the last element has the even index nvalid - 1: low half of dword (nvalid - 1) / 2
+        const int d = (nvalid - 1) >> 1;
+        const unsigned int v = (d == 0) ? w0 : (d == 1) ? w1 : (d == 2) ? w2 : w3;
+        p[nvalid - 1] = (unsigned short)(v & 0xffffu);
+    }
+}
+__device__ __forceinline__ void store8_bits(unsigned char* p, const unsigned int (&w)[9], int nvalid) {
+    if (nvalid >= kRV) {
+        u32x2_a1 o;
+        o.x = w[0]; o.y = w[1];
+        *reinterpret_cast<u32x2_a1*>(p) = o;
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < kRV; ++j)
+        if (j < nvalid) p[j] = (unsigned char)((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+}
+__device__ __forceinline__ void store8_bits(float*, const unsigned int (&)[9], int) {}     // (never taken: float tiles need nan_to_num)
+
 template <typename TOut>
 __device__ __forceinline__ void store8(TOut* p, const float (&q)[kRV], int nvalid) {
     if (nvalid >= kRV) {
@@ -153,6 +193,15 @@ __device__ __forceinline__ void store8(TOut* p, const float (&q)[kRV], int nvali
         for (int j = 0; j < kRV; ++j)
             if (j < nvalid) p[j] = cast_r<TOut>(q[j]);
     }
+}
+
+// uint16 output: pack first, then the same 1 (full) / <= 3 (tail) stores as the raw copy
+template <>
+__device__ __forceinline__ void store8<unsigned short>(unsigned short* p, const float (&q)[kRV], int nvalid) {
+    unsigned int w[9];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = (unsigned int)(int)q[2 * k] | ((unsigned int)(int)q[2 * k + 1] << 16);
+    store8_bits(p, w, nvalid);
 }
 
 // The per-view record fields live in lanes: lane (v * 10 + q) of set A (views 0..5) / set B (views 6, 7) holds
@@ -728,17 +777,30 @@ __global__ __launch_bounds__(256) void copy_region_kernel(RegionParams P, int it
                 vo[g] = vo_p + yl * sy * ES;
                 Row8<TIn, false>::load(rsrc, vo[g], raw[g]);
             }
+            int ends = 0;
 #pragma unroll
-            for (int g = 0; g < kRG; ++g) {
-                const int yc = y0b + L.RG * (gb + g) + r;
-                float e[9];
-                Row8<TIn, false>::decode(raw[g], e);
-                if (__any((vo[g] < 0 && vo[g] + WB > 0) || (vo[g] < nbytes && vo[g] + WB > nbytes))) row8_refetch<TIn>(rsrc, vo[g], e, strip);
-                float q[kRV];
+            for (int g = 0; g < kRG; ++g) ends |= (int)(vo[g] < 0) & (int)(vo[g] + WB > 0) | (int)(vo[g] < nbytes) & (int)(vo[g] + WB > nbytes);
+            if (std::is_same<TIn, TOut>::value && !std::is_floating_point<TIn>::value && !__any(ends != 0)) {
+                // same integer type in and out: the loaded dwords are the result
 #pragma unroll
-                for (int j = 0; j < kRV; ++j) q[j] = (e[j] == e[j]) ? e[j] : 0.f;   // nan_to_num (float tiles)
-                if (yc < y1 && nvalid_x > 0)
-                    store8<TOut>(out + ((long long)(zc - P.tz) * P.oy + (yc - P.ty)) * (long long)P.ox + (xq - P.tx), q, nvalid_x);
+                for (int g = 0; g < kRG; ++g) {
+                    const int yc = y0b + L.RG * (gb + g) + r;
+                    if (yc < y1 && nvalid_x > 0)
+                        store8_bits(out + ((long long)(zc - P.tz) * P.oy + (yc - P.ty)) * (long long)P.ox + (xq - P.tx), raw[g], nvalid_x);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < kRG; ++g) {
+                    const int yc = y0b + L.RG * (gb + g) + r;
+                    float e[9];
+                    Row8<TIn, false>::decode(raw[g], e);
+                    if (__any((vo[g] < 0 && vo[g] + WB > 0) || (vo[g] < nbytes && vo[g] + WB > nbytes))) row8_refetch<TIn>(rsrc, vo[g], e, strip);
+                    float q[kRV];
+#pragma unroll
+                    for (int j = 0; j < kRV; ++j) q[j] = (e[j] == e[j]) ? e[j] : 0.f;   // nan_to_num (float tiles)
+                    if (yc < y1 && nvalid_x > 0)
+                        store8<TOut>(out + ((long long)(zc - P.tz) * P.oy + (yc - P.ty)) * (long long)P.ox + (xq - P.tx), q, nvalid_x);
+                }
             }
           }
         } else {
