@@ -260,6 +260,14 @@ int mvs_beads_translation_sweeps(int32_t ndim, int32_t n_nodes, int32_t n_edges,
                                  int32_t ref_node, int32_t max_iter, double rel_tol, double* translations,
                                  double* edge_residuals, double* mean_hist, double* max_hist, int32_t* n_iter_out);
 
+/* Host-only: edge betweenness centrality of the view adjacency graph -- networkx.edge_betweenness_centrality(g) as
+ * prune_graph_to_alternating_colors calls it (mv_graph.py:664-741; Brandes, unweighted, normalised by n (n - 1)).  Nodes are
+ * 0 .. n_nodes - 1 in the graph's node order, node v's neighbours adj_nodes[adj_offsets[v] .. adj_offsets[v + 1]) in
+ * adjacency order, adj_edge[a] = index of the edge adjacency entry a belongs to; bet_out: n_edges doubles.  Traversal and
+ * accumulation order are networkx's (the reference compares the derived edge values with <=). */
+int mvs_edge_betweenness(int32_t n_nodes, int32_t n_edges, const int32_t* adj_offsets, const int32_t* adj_nodes,
+                         const int32_t* adj_edge, double* bet_out);
+
 #ifdef __cplusplus
 }
 #endif

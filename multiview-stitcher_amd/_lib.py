@@ -112,6 +112,10 @@ SIGNATURES = {
          C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
          C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)],
     ),
+    "mvs_edge_betweenness": (
+        C.c_int,
+        [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)],
+    ),
     "mvs_register_crops": (
         C.c_int,
         [C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32,

@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256) void copy_region_kernel(RegionParams P, int it
             }
             int ends = 0;
 #pragma unroll
-            for (int g = 0; g < kRG; ++g) ends |= (int)(vo[g] < 0) & (int)(vo[g] + WB > 0) | (int)(vo[g] < nbytes) & (int)(vo[g] + WB > nbytes);
+            for (int g = 0; g < kRG; ++g) ends |= ((int)(vo[g] < 0) & (int)(vo[g] + WB > 0)) | ((int)(vo[g] < nbytes) & (int)(vo[g] + WB > nbytes));
             if (std::is_same<TIn, TOut>::value && !std::is_floating_point<TIn>::value && !__any(ends != 0)) {
                 // same integer type in and out: the loaded dwords are the result
 #pragma unroll

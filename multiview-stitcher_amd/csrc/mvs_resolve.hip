@@ -1,6 +1,7 @@
 // Host-side inner loop of the groupwise resolution (no device work): the node sweeps of the virtual-bead optimisation for the
 // translation model.  See include/mvs_hip.h (mvs_beads_translation_sweeps) for the contract; the edge-removal outer loop and
 // the models with a linear part live in multiview_stitcher_amd/param_resolution.py.
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -78,5 +79,66 @@ extern "C" int mvs_beads_translation_sweeps(int32_t ndim, int32_t n_nodes, int32
         if (converged) { ++it; break; }
     }
     *n_iter_out = it;
+    return MVS_OK;
+}
+
+// Brandes' edge betweenness of an unweighted, undirected graph, normalised by n (n - 1): the values
+// networkx.edge_betweenness_centrality(g) returns with its defaults (the reference calls it in
+// prune_graph_to_alternating_colors, mv_graph.py:664-741, and compares the derived edge values with <=, so the order of the
+// floating-point accumulation is part of the contract).  Nodes are 0 .. n_nodes - 1 in the graph's node order; node v's
+// neighbours are adj_nodes[adj_offsets[v] .. adj_offsets[v + 1]) in adjacency (insertion) order, adj_edge gives the index
+// of the edge each adjacency entry belongs to.  Same traversal (BFS in adjacency order), same operations in the same
+// order as the Python form in mv_graph.edge_betweenness_centrality, which tests pin against networkx itself.
+extern "C" int mvs_edge_betweenness(int32_t n_nodes, int32_t n_edges, const int32_t* adj_offsets, const int32_t* adj_nodes,
+                                    const int32_t* adj_edge, double* bet_out) {
+    if (n_nodes < 0 || n_edges < 0 || (n_nodes > 0 && (!adj_offsets || !bet_out))) return MVS_ERR_INVALID_ARG;
+    for (int e = 0; e < n_edges; ++e) bet_out[e] = 0.0;
+    std::vector<int> S, queue, dist((size_t)n_nodes), pred_off((size_t)n_nodes + 1), pred_cnt((size_t)n_nodes);
+    std::vector<double> sigma((size_t)n_nodes), delta((size_t)n_nodes);
+    // predecessor lists: node w has at most deg(w) predecessors -> slots [adj_offsets[w], adj_offsets[w + 1])
+    const int nadj = n_nodes ? adj_offsets[n_nodes] : 0;
+    std::vector<int> pred((size_t)std::max(nadj, 1)), pred_e((size_t)std::max(nadj, 1));
+    S.reserve((size_t)n_nodes);
+    queue.reserve((size_t)n_nodes);
+    for (int s = 0; s < n_nodes; ++s) {
+        S.clear();
+        queue.clear();
+        for (int v = 0; v < n_nodes; ++v) { dist[v] = -1; sigma[v] = 0.0; pred_cnt[v] = 0; delta[v] = 0.0; }
+        sigma[s] = 1.0;
+        dist[s] = 0;
+        queue.push_back(s);
+        for (size_t head = 0; head < queue.size(); ++head) {
+            const int v = queue[head];
+            S.push_back(v);
+            for (int a = adj_offsets[v]; a < adj_offsets[v + 1]; ++a) {
+                const int w = adj_nodes[a];
+                if (dist[w] < 0) {
+                    queue.push_back(w);
+                    dist[w] = dist[v] + 1;
+                }
+                if (dist[w] == dist[v] + 1) {
+                    sigma[w] += sigma[v];
+                    pred[(size_t)adj_offsets[w] + pred_cnt[w]] = v;
+                    pred_e[(size_t)adj_offsets[w] + pred_cnt[w]] = adj_edge[a];
+                    ++pred_cnt[w];
+                }
+            }
+        }
+        while (!S.empty()) {
+            const int w = S.back();
+            S.pop_back();
+            const double coeff = (1.0 + delta[w]) / sigma[w];
+            for (int k = 0; k < pred_cnt[w]; ++k) {
+                const int v = pred[(size_t)adj_offsets[w] + k];
+                const double c = sigma[v] * coeff;
+                bet_out[pred_e[(size_t)adj_offsets[w] + k]] += c;
+                delta[v] += c;
+            }
+        }
+    }
+    if (n_nodes > 1) {
+        const double scale = 1.0 / ((double)n_nodes * (double)(n_nodes - 1));
+        for (int e = 0; e < n_edges; ++e) bet_out[e] *= scale;
+    }
     return MVS_OK;
 }

@@ -35,6 +35,7 @@ def test_graph_orders_and_algorithms_match_networkx():
         want = nx.edge_betweenness_centrality(h)
         got = mv_graph.edge_betweenness_centrality(g)
         assert list(got) == list(want) and all(got[e] == want[e] for e in want)       # bit for bit: the values feed <= tests
+        assert mv_graph._edge_betweenness_centrality_python(g) == got                  # library (host C++) == Python form
         assert mv_graph.greedy_color(g) == nx.coloring.greedy_color(h)
         # removal keeps the orders; copy keeps them too
         a, b = ins[0]

@@ -25,4 +25,4 @@ for name, fn in (("register", lambda: registration.register(sims, transform_key=
                  ("fuse", lambda: (fusion.fuse(sims, transform_key="reg", output_on_backend=True, device=0), _lib.synchronize(0)))):
     t0 = time.perf_counter(); fn(); print(name, "ms", (time.perf_counter() - t0) * 1e3)
     pr = cProfile.Profile(); pr.enable(); fn(); pr.disable()
-    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(35); print(s.getvalue()[:6000])
+    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
