@@ -260,6 +260,30 @@ int mvs_beads_translation_sweeps(int32_t ndim, int32_t n_nodes, int32_t n_edges,
                                  int32_t ref_node, int32_t max_iter, double rel_tol, double* translations,
                                  double* edge_residuals, double* mean_hist, double* max_hist, int32_t* n_iter_out);
 
+/* Host-only: the chunk -> view-slab plan of fusion.fuse (fusion/_core.py:354-722 with mv_graph.py:934-1117 and the label
+ * selection of _core.py:1371-1386).  All per-axis arrays hold `ndim` entries per item in (z,) y, x order: views as
+ * origin / spacing / shape of their stacks and (ndim + 1)^2 row-major affines `params` (view -> world; `inv_params` = their
+ * inverses, needed -- and only read -- when some view is not a pure translation), the output stack, the chunk size and the
+ * halo (overlap_in_pixels).  Decides which axes are pure translations for every view (dim_masks_out[0], bit d = axis d) and on
+ * which of those the output samples fall on every view's sampling grid (dim_masks_out[1]: no interpolation taps there,
+ * _core.py:354-459), then lists, in block order (first axis slowest) and ascending view index, one entry per (output chunk,
+ * contributing view): the integer window lo[d] .. lo[d] + n[d] - 1 of the view that the chunk (grown by the halo and by
+ * `interpolation_order` taps on the axes that interpolate) needs (_core.py:462-533 for translations, mv_graph.py:989-1117
+ * for general affines), exactly the samples the reference's `sims[iview].sel(...)` selects.  planewise = 1 when the chunk is a
+ * single z plane on the views' z grid (fused with the 2D parameters, _core.py:694-703).  Call with entries = NULL to get
+ * the count in n_entries_out, then with capacity >= that count. */
+typedef struct mvs_plan_entry {
+    int64_t block[3];
+    int32_t view;
+    int32_t planewise;
+    int64_t lo[3];
+    int64_t n[3];
+} mvs_plan_entry_t;
+int mvs_fuse_plan(int32_t ndim, int32_t n_views, const double* view_origin, const double* view_spacing, const int64_t* view_shape,
+                  const double* params, const double* inv_params, const double* out_origin, const double* out_spacing,
+                  const int64_t* out_shape, const int64_t* chunk_size, const int64_t* halo, int32_t interpolation_order,
+                  mvs_plan_entry_t* entries, int64_t capacity, int64_t* n_entries_out, int32_t* dim_masks_out);
+
 /* Host-only: edge betweenness centrality of the view adjacency graph -- networkx.edge_betweenness_centrality(g) as
  * prune_graph_to_alternating_colors calls it (mv_graph.py:664-741; Brandes, unweighted, normalised by n (n - 1)).  Nodes are
  * 0 .. n_nodes - 1 in the graph's node order, node v's neighbours adj_nodes[adj_offsets[v] .. adj_offsets[v + 1]) in

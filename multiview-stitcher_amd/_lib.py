@@ -112,6 +112,12 @@ SIGNATURES = {
          C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double),
          C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)],
     ),
+    "mvs_fuse_plan": (
+        C.c_int,
+        [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+         C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+         C.POINTER(C.c_int64), C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)],
+    ),
     "mvs_edge_betweenness": (
         C.c_int,
         [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)],

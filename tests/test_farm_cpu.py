@@ -79,17 +79,13 @@ def test_planner_axis_aligned_slabs_and_graph():
     osp = fusion.calc_fusion_stack_properties(sims, affs, {"z": 1.0, "y": 1.0, "x": 1.0})
     assert osp["shape"] == {"z": 16, "y": 70, "x": 100}
     cs = {"z": 16, "y": 32, "x": 32}
-    cbb, bidx = mv_graph.get_chunk_bbs(osp, cs)
-    plan = fusion._build_spatial_fusion_plan(
-        sparams=affs, views_bb=sps, output_stack_properties=osp, output_chunksize=cs, output_chunk_bbs=cbb,
-        output_chunk_bbs_with_overlap=cbb, output_chunk_bbs_for_result=cbb, block_indices=bidx,
-        overlap_in_pixels={d: 0 for d in "zyx"}, trim_overlap=True, interpolation_order=1, sdims=["z", "y", "x"],
-    )
-    assert plan["uses_axis_aligned_translation"] and plan["grid_aligned_translation_dims"] == ["z", "y", "x"]
-    first = plan["per_chunk_entries"][0]
-    assert [iv for iv, _ in first["views"]] == [0, 1, 3, 4]      # chunk (0,0,0) = y 0..31, x 0..31 touches the 2x2 corner tiles
-    assert first["views"][0][1]["shape"] == {"z": 16, "y": 32, "x": 32}
-    assert first["views"][1][1]["shape"]["x"] == 2                # tile 1 starts at x=30: two columns reach into the chunk
+    by_block, info = fusion._plan_chunks(affs, sps, osp, cs, {d: 0 for d in "zyx"}, 1, ["z", "y", "x"])
+    assert info["axis_aligned_translation_dims"] == ["z", "y", "x"] and info["grid_aligned_translation_dims"] == ["z", "y", "x"]
+    planewise, first = by_block[(0, 0, 0)]
+    assert not planewise
+    assert [iv for iv, _, _ in first] == [0, 1, 3, 4]      # chunk (0,0,0) = y 0..31, x 0..31 touches the 2x2 corner tiles
+    assert first[0][1:] == ((0, 0, 0), (16, 32, 32))
+    assert first[1][1][2] == 0 and first[1][2][2] == 2           # tile 1 starts at x=30: two columns reach into the chunk
     # translation least squares: a consistent loop is solved exactly
     edges = [(0, 1), (1, 2), (0, 2)]
     d = {(0, 1): [1.0, -2.0], (1, 2): [0.5, 0.5], (0, 2): [1.5, -1.5]}

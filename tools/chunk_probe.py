@@ -10,10 +10,12 @@ grid, tile = np.array([4, 4, 4]), np.array([512] * 3)
 tiles, jit, org = bench.make_mosaic_on_device(torch, dev, grid, tile, np.round(tile * 0.2).astype(int), seed=1000)
 sims = bench.build_sims(tiles, org, 0)
 torch.cuda.synchronize()   # the tiles are produced on torch's stream, the library runs on its own
-for cs in (1 << 30, 1024, 512, 256):
-    for rep in range(2):
-        t0 = time.perf_counter()
-        out = fusion.fuse(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, output_chunksize={d: cs for d in "zyx"}, output_on_backend=True, device=0)
-        _lib.synchronize(0)
-        dt = time.perf_counter() - t0
-    print("chunksize %d: %.1f ms (%.0f Mvoxels/s)" % (cs, dt * 1e3, np.prod(out.shape) / dt / 1e6), flush=True)
+for merge in (True, False):
+    for cs in (1 << 30, 1024, 512, 256):
+        for rep in range(2):
+            t0 = time.perf_counter()
+            out = fusion.fuse(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, output_chunksize={d: cs for d in "zyx"}, output_on_backend=True, device=0,
+                              merge_chunks=merge)
+            _lib.synchronize(0)
+            dt = time.perf_counter() - t0
+        print("merge_chunks=%s chunksize %d: %.1f ms (%.0f Mvoxels/s)" % (merge, cs, dt * 1e3, np.prod(out.shape) / dt / 1e6), flush=True)
