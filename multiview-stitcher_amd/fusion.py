@@ -450,6 +450,7 @@ def process_output_chunksize(sims, output_chunksize):
 
 
 MAX_LAUNCH_BYTES = int(os.environ.get("MVS_MAX_LAUNCH_BYTES", 32 << 30))
+MAX_STREAM_BYTES = int(os.environ.get("MVS_MAX_STREAM_BYTES", 1 << 30))      # launch block of a fuse() that reads or writes Zarr stores
 
 
 def _merged_chunksize(chunksize, shape, sdims, itemsize, max_bytes=None):
@@ -564,10 +565,12 @@ def fuse(
     a SpatialImage with identity affine under ``transform_key``.
     ``chunk_filter(block_index) -> bool`` restricts the work to a subset of
     chunks (used by the multi-GPU farm); untouched chunks stay zero.
-    ``merge_chunks``: with an in-memory (host or device) result, the built-in fusion functions and no halo, the chunk
-    grid is only the reference's unit of dask scheduling -- every output voxel is the same function of the views
-    whichever chunk it falls in -- so the requested chunks are merged into launch blocks of up to
-    ``MAX_LAUNCH_BYTES`` of output (the whole mosaic when it fits: one ``mvs_fuse_chunk`` launch instead of hundreds).
+    ``merge_chunks``: with the built-in fusion functions and no halo the chunk grid is only the reference's unit of dask
+    scheduling (and the chunk grid of a Zarr output) -- every output voxel is the same function of the views whichever
+    chunk it falls in -- so the requested chunks are merged into launch blocks of whole chunks: up to ``MAX_LAUNCH_BYTES``
+    of output for in-memory results (the whole mosaic when it fits: one ``mvs_fuse_chunk`` launch instead of hundreds), up to
+    ``MAX_STREAM_BYTES`` when tiles are read from or the result is written to a Zarr store (a block is fused in one launch
+    and written into its chunk files).  ``batch_options`` and ``chunk_filter`` address single chunks and switch this off.
     """
     if images is None:
         if sims is None:
@@ -609,12 +612,14 @@ def fuse(
                 cur = {d: cur for d in sdims}
             overlap_in_pixels = {d: max(overlap_in_pixels[d], cur[d]) for d in sdims}
 
-    if (merge_chunks and output_zarr_url is None and not batch_options and chunk_filter is None
+    store_chunksize = dict(output_chunksize)          # the chunk grid of a Zarr output stays the requested one
+    if (merge_chunks and not batch_options and chunk_filter is None
             and weights_func is None and fusion_func in _FUSION_CODES and not any(overlap_in_pixels[d] for d in sdims)
-            and not any(type(s_.data).__name__ in ("ZarrArray", "ZarrView") for s_ in sims_)      # stores are read slab by slab
             and not ("z" in sdims and int(output_chunksize["z"]) == 1 and output_stack_properties["shape"]["z"] > 1)):
+        # streamed inputs / outputs pass through host memory block by block: a smaller budget per launch block
+        streamed = output_zarr_url is not None or any(type(s_.data).__name__ in ("ZarrArray", "ZarrView") for s_ in sims_)
         output_chunksize = _merged_chunksize(output_chunksize, output_stack_properties["shape"], sdims,
-                                             np.dtype(sims_[0].dtype).itemsize)
+                                             np.dtype(sims_[0].dtype).itemsize, MAX_STREAM_BYTES if streamed else None)
 
     chunk_bbs, block_indices = mv_graph.get_chunk_bbs(output_stack_properties, output_chunksize)
     chunk_bbs_ov = [
@@ -654,7 +659,7 @@ def fuse(
             zarr_out = zarr_io.ZarrArray.open(store_url)      # a farm worker joining an array another worker created
         else:
             zarr_out = zarr_io.ZarrArray.create(
-                store_url, ns_shape + out_shape_sp, (1,) * len(ns_shape) + tuple(output_chunksize[d] for d in sdims), dtype,
+                store_url, ns_shape + out_shape_sp, (1,) * len(ns_shape) + tuple(store_chunksize[d] for d in sdims), dtype,
                 **create_kw)
     result = None if (on_device or zarr_out is not None) else np.zeros(ns_shape + out_shape_sp, dtype=dtype)
     if on_device and ns_shape and int(np.prod(ns_shape)) != 1:

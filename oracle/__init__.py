@@ -32,4 +32,6 @@ Rules (see DESIGN.md "Oracle"):
   NaN-holding images (quirk Q1 -> zero shift), ``rescale_intensity`` values
   (Q5) and SSIM for float64 and float32 inputs (Q4), plus the reference's
   tolerance tests (``tests/test_reg_oracle.py``).
+* ``plan_oracle.py``: literal restatement of the reference's chunk -> view-slab planner (fusion/_core.py:354-722); the
+  product plans with the library (``mvs_fuse_plan``) and ``tests/test_plan_oracle.py`` compares window for window.
 """

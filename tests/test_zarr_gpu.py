@@ -36,7 +36,7 @@ def test_fuse_streams_zarr_in_and_out(hip_device, tmp_path, ndim):
     key = sample_data.METADATA_TRANSFORM_KEY
     sims = _dataset(ndim)
     chunks = {"y": 128, "x": 96} if ndim == 2 else {"z": 32, "y": 96, "x": 128}
-    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks, merge_chunks=False).data)
+    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks).data)      # (chunks merged into one launch block)
 
     # tiles -> OME-Zarr stores -> lazy sims carrying the stage transform
     lazy = []
@@ -50,6 +50,10 @@ def test_fuse_streams_zarr_in_and_out(hip_device, tmp_path, ndim):
                         zarr_options={"ome_zarr": True})
     assert zarr_io.is_zarr_backed(fused.data)
     np.testing.assert_array_equal(np.asarray(fused.data), want)
+    # chunk by chunk (merge_chunks=False): the streamed result equals the chunk-by-chunk in-memory result
+    fused_c = fusion.fuse(lazy, transform_key=key, output_chunksize=chunks, output_zarr_url=str(tmp_path / "fused_c.zarr"), merge_chunks=False)
+    np.testing.assert_array_equal(np.asarray(fused_c.data),
+                                  np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks, merge_chunks=False).data))
     assert si.get_origin_from_sim(fused) == pytest.approx(si.get_origin_from_sim(fusion.fuse(sims, transform_key=key, output_chunksize=chunks)))
 
     # store layout: group, level arrays with '/' keys and the fuse chunk grid, multiscales document
