@@ -152,7 +152,7 @@ __device__ __forceinline__ void store8_bits(unsigned short* p, const unsigned in
     if (nvalid >= kRV) {
         u32x4_a2 o;
         o.x = w0; o.y = w1; o.z = w2; o.w = w3;
-        *reinterpret_cast<u32x4_a2*>(p) = o;
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x4_a2*>(p));      // the mosaic is written once and not read again
         return;
     }
     const bool has4 = (nvalid & 4) != 0;
@@ -172,7 +172,7 @@ __device__ __forceinline__ void store8_bits(unsigned char* p, const unsigned int
     if (nvalid >= kRV) {
         u32x2_a1 o;
         o.x = w[0]; o.y = w[1];
-        *reinterpret_cast<u32x2_a1*>(p) = o;
+        __builtin_nontemporal_store(o, reinterpret_cast<u32x2_a1*>(p));
         return;
     }
 #pragma unroll
@@ -187,7 +187,7 @@ __device__ __forceinline__ void store8(TOut* p, const float (&q)[kRV], int nvali
         typename Out8<TOut>::v8 v;
 #pragma unroll
         for (int j = 0; j < kRV; ++j) v[j] = cast_r<TOut>(q[j]);
-        *reinterpret_cast<typename Out8<TOut>::v8*>(p) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<typename Out8<TOut>::v8*>(p));
     } else {
 #pragma unroll
         for (int j = 0; j < kRV; ++j)
