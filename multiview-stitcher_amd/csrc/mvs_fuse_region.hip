@@ -64,6 +64,10 @@ template <bool NINE> struct Row8<unsigned short, NINE> {
         w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
         if (NINE) w[4] = __builtin_amdgcn_raw_buffer_load_b16(r, vo + 16, 0, 0);
     }
+    static __device__ __forceinline__ void load_nt(__amdgpu_buffer_rsrc_t r, int vo, unsigned int (&w)[9]) {   // streaming hint
+        const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(r, vo, 0, 2);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+    }
     static __device__ __forceinline__ void decode(const unsigned int (&w)[9], float (&v)[9]) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) { v[2 * k] = (float)(w[k] & 0xffffu); v[2 * k + 1] = (float)(w[k] >> 16); }
@@ -775,7 +779,8 @@ __global__ __launch_bounds__(256) void copy_region_kernel(RegionParams P, int it
             for (int g = 0; g < kRG; ++g) {
                 const int yl = min(y0b + L.RG * (gb + g) + r, y1 - 1);
                 vo[g] = vo_p + yl * sy * ES;
-                Row8<TIn, false>::load(rsrc, vo[g], raw[g]);
+                if (std::is_same<TIn, unsigned short>::value) Row8<unsigned short, false>::load_nt(rsrc, vo[g], raw[g]);
+                else Row8<TIn, false>::load(rsrc, vo[g], raw[g]);
             }
             int ends = 0;
 #pragma unroll
