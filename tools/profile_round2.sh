@@ -32,6 +32,7 @@ cd $R
   echo "== rows_v1 exact grid"; MVS_ROWS_V1=1 python tools/fuse_probe.py 5 0 2>&1 | grep "kernel ms" | tail -1
   echo "== serial classes"; MVS_SERIAL=1 python tools/fuse_probe.py 5 0 2>&1 | grep "kernel ms" | tail -1
 } > $O/fuse_variants.txt 2>&1
+[ -x tools/dma_probe ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/dma_probe tools/dma_probe.hip
 ./tools/dma_probe > $O/dma_probe.txt 2>&1
 python tools/cb_probe.py > $O/cb_probe.txt 2>&1
 python tools/pair_overhead.py > $O/pair_overhead.txt 2>&1
