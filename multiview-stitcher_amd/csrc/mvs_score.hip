@@ -182,13 +182,81 @@ __global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ im
     shift_body<true>(im1, im0, out, S, tz, ty, tx, skip_zero_taps, partial);
 }
 
+// The same shifted copy for a finite moving image and a shift whose components are all multiples of 1/2 (3D phase
+// correlation refines to 1/upsample_factor = 1/2 pixel): c = pos + t is exact, so floor(c) = pos + floor(t), the weight is 0
+// or exactly 1/2 on every axis, every tap product is an exact scaling by a power of two and the validity test is an integer
+// comparison -- the same taps in the same (z-major) order as shifted_value, without its per-voxel double-precision
+// coordinate arithmetic.  fz / fy / fx = floor(t), hz / hy / hx = 1 where the component has the fraction 1/2.
+struct HalfShift { int fz, fy, fx, hz, hy, hx; };
+__device__ __forceinline__ void shift_half_body(const float* __restrict__ im1, float* __restrict__ out, Shape3 S, HalfShift T) {
+    const unsigned int n = (unsigned int)S.nz * S.ny * S.nx;
+    const unsigned int ngroups = (n + 3) / 4;
+    const int sy = S.nx, sz = S.ny * S.nx;
+    // valid iff 0 <= pos + t <= n - 1: pos + f >= 0 and pos + f + h/2 <= n - 1
+    const double scale = 1.0 / (double)(1 << (T.hz + T.hy + T.hx));          // product of the tap weights: 1, 1/2, 1/4 or 1/8
+    for (unsigned int g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x) {
+        const unsigned int i0 = g * 4;
+        int x = (int)(i0 % (unsigned int)S.nx);
+        const unsigned int t = i0 / (unsigned int)S.nx;
+        int y = (int)(t % (unsigned int)S.ny), z = (int)(t / (unsigned int)S.ny);
+        float r4[4];
+        {
+            // the common case -- the 4 voxels lie in one row and all their taps inside the image: every tap row is one
+            // 16-byte load (+ 1 element for a half-pixel x shift) instead of 4 x 2 scalar loads
+            const int iz = z + T.fz, iy = y + T.fy, ix = x + T.fx;
+            if (x + 3 < S.nx && iz >= 0 && iz + T.hz <= S.nz - 1 && iy >= 0 && iy + T.hy <= S.ny - 1 && ix >= 0 && ix + 3 + T.hx <= S.nx - 1 &&
+                (T.hz | T.hy | T.hx)) {
+                const float* p = im1 + iz * sz + iy * sy + ix;
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int a = 0; a <= T.hz; ++a)
+                    for (int b = 0; b <= T.hy; ++b) {
+                        const float* q = p + a * sz + b * sy;
+                        float v[5];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = q[j];
+                        v[4] = T.hx ? q[4] : 0.f;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc[j] += (double)v[j] * scale;
+                            if (T.hx) acc[j] += (double)v[j + 1] * scale;
+                        }
+                    }
+                *reinterpret_cast<float4*>(out + i0) = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+                continue;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float r = NAN;
+            if (i0 + k < n) {
+                const int iz = z + T.fz, iy = y + T.fy, ix = x + T.fx;
+                const bool ok = iz >= 0 && iz + T.hz <= S.nz - 1 && iy >= 0 && iy + T.hy <= S.ny - 1 && ix >= 0 && ix + T.hx <= S.nx - 1;
+                if (ok) {
+                    const float* p = im1 + iz * sz + iy * sy + ix;
+                    double acc = 0.0;
+                    for (int a = 0; a <= T.hz; ++a)
+                        for (int b = 0; b <= T.hy; ++b)
+                            for (int c = 0; c <= T.hx; ++c) acc += (double)p[a * sz + b * sy + c] * scale;
+                    r = (T.hz | T.hy | T.hx) ? (float)acc : p[0];
+                }
+                if (++x == S.nx) { x = 0; if (++y == S.ny) { y = 0; ++z; } }
+            }
+            r4[k] = r;
+        }
+        if (i0 + 3 < n) *reinterpret_cast<float4*>(out + i0) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+        else
+            for (int k = 0; k < 4; ++k) if (i0 + k < n) out[i0 + k] = r4[k];
+    }
+}
+
 // shifted copies of several candidates in one launch (blockIdx.y = candidate); no statistics (the caller knows the valid boxes)
-struct ShiftCand { float* out; double tz, ty, tx; };
+struct ShiftCand { float* out; double tz, ty, tx; int half; HalfShift H; };
 struct ShiftBatch { ShiftCand c[kMaxResident]; };
 __global__ __launch_bounds__(256) void shift_batch_kernel(const float* __restrict__ im1, const float* __restrict__ im0, Shape3 S, ShiftBatch B,
                                                           int skip_zero_taps) {
     const ShiftCand& C = B.c[blockIdx.y];
-    shift_body<false>(im1, im0, C.out, S, C.tz, C.ty, C.tx, skip_zero_taps, nullptr);
+    if (C.half && skip_zero_taps) shift_half_body(im1, C.out, S, C.H);
+    else shift_body<false>(im1, im0, C.out, S, C.tz, C.ty, C.tx, skip_zero_taps, nullptr);
 }
 
 // #valid voxels and their bbox for one image (get_bb_from_nanmask, registration.py:482-489; valid_pixels1 :400)
@@ -1377,7 +1445,19 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 otf[j] = t[0] == std::floor(t[0]) && t[1] == std::floor(t[1]) && t[2] == std::floor(t[2]);
                 if (otf[j]) continue;
                 if (batched) {      // all fractional shifts of the batch in one launch, after this loop
-                    shift_batch.c[n_shift_batch++] = ShiftCand{im1t_buf[j], t[0], t[1], t[2]};
+                    ShiftCand sc{im1t_buf[j], t[0], t[1], t[2], 0, HalfShift{0, 0, 0, 0, 0, 0}};
+                    if (!c->materialize_shifts) {
+                        bool half = true;
+                        int f[3], h[3];
+                        for (int k = 0; k < 3; ++k) {
+                            const double t2 = t[k] * 2.0;
+                            half = half && std::floor(t2) == t2 && std::fabs(t[k]) < 1e6;
+                            f[k] = (int)std::floor(t[k]);
+                            h[k] = (t[k] != std::floor(t[k])) ? 1 : 0;
+                        }
+                        if (half) { sc.half = 1; sc.H = HalfShift{f[0], f[1], f[2], h[0], h[1], h[2]}; }
+                    }
+                    shift_batch.c[n_shift_batch++] = sc;
                     resident[ic] = j;
                     continue;
                 }
