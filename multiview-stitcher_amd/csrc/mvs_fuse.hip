@@ -971,6 +971,52 @@ __global__ __launch_bounds__(256) void resample_kernel(DevView V, float* out, in
     }
 }
 
+// The same for an integer tile under a whole-pixel translation (identity matrix, integer offset: the registration crops of a
+// tile grid): scipy's order-0 / order-1 value at an integer coordinate of finite data is the sample itself (second tap weight
+// 0), so the resample is a crop + conversion -- 8 outputs per thread, one 16-byte (8-byte for uint8) load where the whole group
+// lies inside the tile.
+template <typename TIn>
+__global__ __launch_bounds__(256) void crop_int_kernel(const TIn* __restrict__ data, long long stride_z, long long stride_y, int nz, int ny,
+                                                       int nx, int tz, int ty, int tx, float* __restrict__ out, int oz, int oy, int ox,
+                                                       float cval) {
+    typedef TIn in8_t __attribute__((ext_vector_type(8), aligned(sizeof(TIn))));
+    typedef float f4_t __attribute__((ext_vector_type(4), aligned(4)));
+    const int gpr = (ox + 7) / 8;                                   // groups of 8 outputs per row
+    const long long ngroups = (long long)oz * oy * gpr;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (long long)gridDim.x * blockDim.x) {
+        const int xg = (int)(g % gpr) * 8;
+        const long long row = g / gpr;
+        const int y = (int)(row % oy), z = (int)(row / oy);
+        const int iz = z + tz, iy = y + ty, ix = xg + tx;
+        float* o = out + row * ox + xg;
+        const bool zy = iz >= 0 && iz < nz && iy >= 0 && iy < ny;
+        const TIn* p = data + (long long)iz * stride_z + (long long)iy * stride_y + ix;
+        if (zy && xg + 8 <= ox && ix >= 0 && ix + 8 <= nx) {
+            const in8_t v = *reinterpret_cast<const in8_t*>(p);
+            f4_t a, b;
+            a.x = (float)v[0]; a.y = (float)v[1]; a.z = (float)v[2]; a.w = (float)v[3];
+            b.x = (float)v[4]; b.y = (float)v[5]; b.z = (float)v[6]; b.w = (float)v[7];
+            *reinterpret_cast<f4_t*>(o) = a;
+            *reinterpret_cast<f4_t*>(o + 4) = b;
+        } else {
+            for (int j = 0; j < 8 && xg + j < ox; ++j) o[j] = (zy && ix + j >= 0 && ix + j < nx) ? (float)p[j] : cval;
+        }
+    }
+}
+
+// true when `V` is a whole-pixel translation of an integer tile (see crop_int_kernel); t = the integer offsets
+static bool is_integer_crop(const DevView& V, int dtype, int t[3]) {
+    if (dtype != MVS_U8 && dtype != MVS_U16) return false;
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 9; ++k)
+        if (V.m[k] != I[k]) return false;
+    for (int k = 0; k < 3; ++k) {
+        if (!(V.off[k] == std::floor(V.off[k])) || std::fabs(V.off[k]) > 1e9) return false;
+        t[k] = (int)V.off[k];
+    }
+    return true;
+}
+
 // Blend-weight volume of one view (weights.py:391-511), float32.
 __global__ __launch_bounds__(256) void blend_kernel(DevView V, float* out, int oz, int oy, int ox) {
     const long long n = (long long)oz * oy * ox;
@@ -1342,16 +1388,8 @@ extern "C" int mvs_resample(int device, const mvs_view_t* view, const int64_t ou
         dout = (float*)mvs_scratch(c, 1, (size_t)n * 4);
         if (!dout) return MVS_ERR_HIP;
     }
-    int nblocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
-#define MVS_RS(T, O) hipLaunchKernelGGL((resample_kernel<T, O>), dim3(nblocks), dim3(256), 0, c->stream, d, dout, \
-                                        (int)out_shape[0], (int)out_shape[1], (int)out_shape[2], cval)
-    switch (view->dtype) {
-        case MVS_U8: if (order) MVS_RS(unsigned char, 1); else MVS_RS(unsigned char, 0); break;
-        case MVS_U16: if (order) MVS_RS(unsigned short, 1); else MVS_RS(unsigned short, 0); break;
-        default: if (order) MVS_RS(float, 1); else MVS_RS(float, 0); break;
-    }
-#undef MVS_RS
+    mvs_launch_resample(c, d, view->dtype, order, cval, dout, out_shape);
     MVS_HIP_TRY(c, hipGetLastError());
     MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
     c->timing_valid = true;
@@ -1400,6 +1438,18 @@ int mvs_fill_dev_view(MvsContext* c, const mvs_view_t& v, int ndim, const void* 
 
 void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, float cval, float* out, const int64_t shape[3]) {
     const long long n = (long long)shape[0] * shape[1] * shape[2];
+    int t[3];
+    if (!c->force_generic && is_integer_crop(d, dtype, t)) {
+        const long long ng = (long long)shape[0] * shape[1] * ((shape[2] + 7) / 8);
+        const int nb = (int)std::min<long long>((ng + 255) / 256, 256 * 16);
+        if (dtype == MVS_U8)
+            hipLaunchKernelGGL(crop_int_kernel<unsigned char>, dim3(nb), dim3(256), 0, c->stream, (const unsigned char*)d.data, d.stride_z, d.stride_y,
+                               d.nz, d.ny, d.nx, t[0], t[1], t[2], out, (int)shape[0], (int)shape[1], (int)shape[2], cval);
+        else
+            hipLaunchKernelGGL(crop_int_kernel<unsigned short>, dim3(nb), dim3(256), 0, c->stream, (const unsigned short*)d.data, d.stride_z, d.stride_y,
+                               d.nz, d.ny, d.nx, t[0], t[1], t[2], out, (int)shape[0], (int)shape[1], (int)shape[2], cval);
+        return;
+    }
     const int nblocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
 #define MVS_RS(T, O) hipLaunchKernelGGL((resample_kernel<T, O>), dim3(nblocks), dim3(256), 0, c->stream, d, out, \
                                         (int)shape[0], (int)shape[1], (int)shape[2], cval)
