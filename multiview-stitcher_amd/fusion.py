@@ -653,9 +653,11 @@ def fuse(
             shutil.rmtree(output_zarr_url)
         if ome_zarr:
             create_kw = ngff_utils.update_zarr_array_creation_kwargs_for_ngff_version(ngff_version, create_kw)
-            zarr_io.create_group(output_zarr_url)
+            zarr_io.create_group(output_zarr_url, **ngff_utils.zarr_group_creation_kwargs_for_ngff_version(ngff_version))
+            if create_kw.get("zarr_format") == 3:
+                create_kw.setdefault("dimension_names", list(nsdims) + list(sdims))
         store_url = os.path.join(output_zarr_url, "0") if ome_zarr else output_zarr_url
-        if os.path.exists(os.path.join(store_url, ".zarray")):
+        if zarr_io.array_exists(store_url):
             zarr_out = zarr_io.ZarrArray.open(store_url)      # a farm worker joining an array another worker created
         else:
             zarr_out = zarr_io.ZarrArray.create(

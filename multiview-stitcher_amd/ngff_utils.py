@@ -1,11 +1,12 @@
-"""OME-Zarr (NGFF 0.4) reading and writing around the fuse path.
+"""OME-Zarr (NGFF 0.4 on Zarr v2, NGFF 0.5 on Zarr v3) reading and writing around the fuse path.
 
 Mirror of the call shapes of src/multiview_stitcher/ngff_utils.py for the part the hot path touches:
 ``write_sim_to_ome_zarr`` (ngff_utils.py:1564-1760: resolution levels by block means, one Zarr array per level,
 ``multiscales`` metadata), ``calc_ngff_coordinate_transformations_and_axes`` (ngff_utils.py:1493-1561) and the
 readers that hand zarr-backed views to ``fusion.fuse`` / ``registration.register``.  Storage goes through
-``zarr_io`` (Zarr v2 restated, no zarr / ngff-zarr package here); the pyramid's block means run on the GPU
-(``mvs_bin_mean``, the same kernel registration binning uses).  NGFF 0.5 (= Zarr v3) is not written.
+``zarr_io`` (Zarr v2 / v3 restated, no zarr / ngff-zarr package here); the pyramid's block means run on the GPU
+(``mvs_bin_mean``, the same kernel registration binning uses).  ``ngff_version="0.5"`` writes a Zarr v3 hierarchy with the
+metadata under the ``ome`` key (ngff_utils.py:1185-1281, 1820-1905).
 """
 
 from __future__ import annotations
@@ -48,25 +49,49 @@ def calc_ngff_coordinate_transformations_and_axes(stack_properties_res0, res_abs
 
 
 def write_multiscales_metadata(group_path, axes, datasets, ngff_version="0.4", name="/"):
-    """``multiscales`` attribute of the group (ngff_utils.py:1185-1230): only axes, datasets, name and version."""
-    if not str(ngff_version).startswith("0.4"):
-        raise NotImplementedError("only NGFF 0.4 (Zarr v2) is written here")
-    attrs = zarr_io.read_attrs(group_path)
-    attrs["multiscales"] = [{
+    """``multiscales`` attribute of the group (ngff_utils.py:1185-1230): only axes, datasets, name and version.  NGFF 0.4
+    keeps ``multiscales`` (each with its ``version``) at the top of the group attributes, 0.5 nests ``multiscales`` and
+    ``version`` inside an ``ome`` object."""
+    v = str(ngff_version)
+    if not (v.startswith("0.4") or v.startswith("0.5")):
+        raise ValueError(f"ngff_version {ngff_version} not supported")
+    multiscale = {
         "axes": [dict(a) for a in axes],
         "datasets": [{"path": d["path"], "coordinateTransformations": [dict(t) for t in d["coordinateTransformations"]]} for d in datasets],
         "name": name,
-        "version": str(ngff_version),
-    }]
+    }
+    attrs = zarr_io.read_attrs(group_path)
+    if v.startswith("0.4"):
+        multiscale["version"] = v
+        attrs["multiscales"] = [multiscale]
+    else:
+        ome = dict(attrs.get("ome") or {})
+        ome["version"] = v
+        ome["multiscales"] = [multiscale]
+        attrs["ome"] = ome
     zarr_io.write_attrs(group_path, attrs)
 
 
+def zarr_group_creation_kwargs_for_ngff_version(ngff_version):
+    """NGFF 0.4 is a Zarr v2 hierarchy, 0.5 a Zarr v3 one (ngff_utils.py:1243-1255)."""
+    v = str(ngff_version)
+    if v.startswith("0.4"):
+        return {"zarr_format": 2}
+    if v.startswith("0.5"):
+        return {"zarr_format": 3}
+    raise ValueError(f"ngff_version {ngff_version} not supported")
+
+
 def update_zarr_array_creation_kwargs_for_ngff_version(ngff_version, zarr_array_creation_kwargs=None):
-    """NGFF 0.4 arrays use '/' as dimension separator (ngff_utils.py:1258-1281)."""
+    """NGFF 0.4 arrays are Zarr v2 with '/' as dimension separator, 0.5 arrays Zarr v3 (ngff_utils.py:1258-1281)."""
     kw = dict(zarr_array_creation_kwargs or {})
-    if str(ngff_version) != "0.4":
+    if str(ngff_version) == "0.4":
+        kw["dimension_separator"] = "/"
+        kw["zarr_format"] = 2
+    elif str(ngff_version) == "0.5":
+        kw["zarr_format"] = 3
+    else:
         raise ValueError(f"ngff_version {ngff_version} not supported")
-    kw["dimension_separator"] = "/"
     return kw
 
 
@@ -127,11 +152,13 @@ def write_sim_to_ome_zarr(sim, output_zarr_url, downscale_factors_per_spatial_di
     kw = {k: v for k, v in kw.items() if k != "chunks"}
     ns_shape = [int(sim.sizes[d]) for d in nsdims]
 
-    zarr_io.create_group(output_zarr_url, overwrite=overwrite)
+    zarr_io.create_group(output_zarr_url, overwrite=overwrite, **zarr_group_creation_kwargs_for_ngff_version(ngff_version))
+    if kw.get("zarr_format") == 3:
+        kw.setdefault("dimension_names", dims)
     prev = None
     for level, shp in enumerate(res_shapes):
         url = os.path.join(output_zarr_url, str(level))
-        if not overwrite and os.path.exists(os.path.join(url, ".zarray")):
+        if not overwrite and zarr_io.array_exists(url):
             prev = zarr_io.ZarrArray.open(url)
             continue
         arr = zarr_io.ZarrArray.create(url, ns_shape + [shp[d] for d in sdims], chunks, sim.dtype, overwrite=True, **kw)

@@ -1,4 +1,4 @@
-"""Zarr-v2 directory-store arrays for the two ends of the fuse path, without the zarr package.
+"""Zarr v2 / v3 directory-store arrays for the two ends of the fuse path, without the zarr package.
 
 The reference streams tiles out of and fused chunks into Zarr arrays through zarr-python / dask
 (src/multiview_stitcher/fusion/_core.py:134-199 reads only the raw region a chunk needs, :2044-2156 writes each
@@ -13,6 +13,12 @@ storage specification those call sites rely on:
 * one file per chunk, named by the chunk's grid index joined with the separator; every stored chunk has the
   full chunk shape (edge chunks are padded with the fill value); a missing file means "all fill value";
 * ``.zgroup`` / ``.zattrs`` JSON for groups and attributes.
+
+Zarr v3 (NGFF 0.5, ngff_utils.py:1243-1281 of the reference) differs in its metadata only: one ``zarr.json`` per node
+(``node_type`` "group" | "array", user attributes under ``attributes``), ``data_type`` names instead of typestrs, a regular
+``chunk_grid``, ``chunk_key_encoding`` ("default": ``c/<i>/<j>/...``; "v2": ``<i>.<j>...``) and a ``codecs`` pipeline --
+supported: ``bytes`` (little endian) followed by at most one of gzip / zstd / blosc; transpose, sharding and crc32c
+fail loudly.
 
 ``ZarrArray[...]`` is lazy: indexing returns a ``ZarrView`` that reads only the chunks its window touches when
 it is converted with ``np.asarray`` -- which is what ``fusion.fuse`` does per output chunk and view slab, so a
@@ -106,13 +112,100 @@ class _Codec:
                 f"zarr compressor {cid!r} is not supported (null, zlib, gzip, zstd, lz4, blosc)")
 
 
+_V3_DTYPES = {"bool": "|b1", "int8": "|i1", "uint8": "|u1", "int16": "<i2", "uint16": "<u2", "int32": "<i4", "uint32": "<u4",
+              "int64": "<i8", "uint64": "<u8", "float32": "<f4", "float64": "<f8"}
+_V3_NAMES = {np.dtype(v): k for k, v in _V3_DTYPES.items()}
+_BLOSC_SHUFFLE_V3 = {"noshuffle": 0, "shuffle": 1, "bitshuffle": 2}
+
+
+def _v3_codecs_to_compressor(codecs, itemsize):
+    """The ``codecs`` pipeline of a v3 array as the v2-style compressor config ``_Codec`` understands."""
+    codecs = list(codecs or [])
+    if not codecs or codecs[0].get("name") != "bytes":
+        raise NotImplementedError(f"zarr v3 codecs {[c.get('name') for c in codecs]}: the pipeline must start with 'bytes'")
+    endian = (codecs[0].get("configuration") or {}).get("endian", "little")
+    if itemsize > 1 and endian != "little":
+        raise NotImplementedError("big-endian zarr v3 arrays are not supported")
+    rest = codecs[1:]
+    if not rest:
+        return None
+    if len(rest) > 1:
+        raise NotImplementedError(f"zarr v3 codec chains {[c.get('name') for c in rest]} are not supported (one compressor)")
+    name, cfg = rest[0].get("name"), dict(rest[0].get("configuration") or {})
+    if name == "gzip":
+        return {"id": "gzip", "level": int(cfg.get("level", 5))}
+    if name == "zstd":
+        if cfg.get("checksum"):
+            raise NotImplementedError("zstd frames with checksum are not supported")
+        return {"id": "zstd", "level": int(cfg.get("level", 0))}
+    if name == "blosc":
+        return {"id": "blosc", "cname": cfg.get("cname", "zstd"), "clevel": int(cfg.get("clevel", 5)),
+                "shuffle": _BLOSC_SHUFFLE_V3[cfg.get("shuffle", "noshuffle")], "blocksize": int(cfg.get("blocksize", 0))}
+    raise NotImplementedError(f"zarr v3 codec {name!r} is not supported (bytes, gzip, zstd, blosc)")
+
+
+def _compressor_to_v3_codecs(compressor, itemsize):
+    codecs = [{"name": "bytes", "configuration": {"endian": "little"}} if itemsize > 1 else {"name": "bytes"}]
+    if compressor is None:
+        return codecs
+    cid = compressor.get("id")
+    if cid == "gzip":
+        codecs.append({"name": "gzip", "configuration": {"level": int(compressor.get("level", 5))}})
+    elif cid == "zstd":
+        codecs.append({"name": "zstd", "configuration": {"level": int(compressor.get("level", 0)), "checksum": False}})
+    elif cid == "blosc":
+        shuffle = int(compressor.get("shuffle", 1))
+        if shuffle == -1:
+            shuffle = 2 if itemsize == 1 else 1
+        codecs.append({"name": "blosc", "configuration": {
+            "cname": compressor.get("cname", "lz4"), "clevel": int(compressor.get("clevel", 5)),
+            "shuffle": {v: k for k, v in _BLOSC_SHUFFLE_V3.items()}[shuffle], "typesize": int(itemsize),
+            "blocksize": int(compressor.get("blocksize", 0))}})
+    else:
+        raise NotImplementedError(f"compressor {cid!r} has no zarr v3 codec here (gzip, zstd, blosc)")
+    return codecs
+
+
+def _v3_to_v2_meta(meta):
+    """A v3 array's zarr.json in the terms ZarrArray works with."""
+    if meta.get("node_type") != "array":
+        raise ValueError("zarr.json does not describe an array")
+    grid = meta.get("chunk_grid") or {}
+    if grid.get("name") != "regular":
+        raise NotImplementedError(f"zarr v3 chunk grid {grid.get('name')!r} is not supported")
+    dt = meta.get("data_type")
+    if dt not in _V3_DTYPES:
+        raise NotImplementedError(f"zarr v3 data_type {dt!r} is not supported")
+    dtype = np.dtype(_V3_DTYPES[dt])
+    enc = meta.get("chunk_key_encoding") or {"name": "default"}
+    cfg = enc.get("configuration") or {}
+    if enc.get("name") == "default":
+        sep, prefix = cfg.get("separator", "/"), "c"
+    elif enc.get("name") == "v2":
+        sep, prefix = cfg.get("separator", "."), None
+    else:
+        raise NotImplementedError(f"zarr v3 chunk key encoding {enc.get('name')!r} is not supported")
+    if meta.get("storage_transformers"):
+        raise NotImplementedError("zarr v3 storage transformers are not supported")
+    return {"zarr_format": 3, "shape": meta["shape"], "chunks": grid["configuration"]["chunk_shape"], "dtype": dtype.str,
+            "order": "C", "fill_value": meta.get("fill_value"), "filters": None,
+            "compressor": _v3_codecs_to_compressor(meta.get("codecs"), dtype.itemsize), "dimension_separator": sep,
+            "_key_prefix": prefix}
+
+
 class ZarrArray:
-    """One Zarr v2 array in a directory store."""
+    """One Zarr array (v2 or v3) in a directory store."""
 
     def __init__(self, path, meta):
         self.path = str(path)
-        if int(meta.get("zarr_format", 2)) != 2:
-            raise NotImplementedError("only zarr_format 2 is supported")
+        self.zarr_format = int(meta.get("zarr_format", 2))
+        self.key_prefix = None
+        if self.zarr_format == 3:
+            self.meta_v3 = meta
+            meta = _v3_to_v2_meta(meta)
+            self.key_prefix = meta["_key_prefix"]
+        elif self.zarr_format != 2:
+            raise NotImplementedError(f"zarr_format {self.zarr_format} is not supported (2, 3)")
         if meta.get("order", "C") != "C":
             raise NotImplementedError("only C-order chunks are supported")
         if meta.get("filters"):
@@ -130,12 +223,13 @@ class ZarrArray:
     # ---- construction -------------------------------------------------------------------------
     @classmethod
     def open(cls, path):
-        with open(os.path.join(path, ".zarray")) as f:
+        v3 = os.path.join(path, "zarr.json")
+        with open(v3 if os.path.exists(v3) else os.path.join(path, ".zarray")) as f:
             return cls(path, json.load(f))
 
     @classmethod
     def create(cls, path, shape, chunks, dtype, fill_value=0, dimension_separator=".", compressor=None,
-               overwrite=False):
+               overwrite=False, zarr_format=2, dimension_names=None):
         if os.path.exists(path):
             if not overwrite:
                 raise FileExistsError(path)
@@ -144,6 +238,21 @@ class ZarrArray:
         dtype = np.dtype(dtype)
         shape = [int(s) for s in shape]
         chunks = [max(1, min(int(c), s)) if s else int(c) for c, s in zip(chunks, shape)]
+        if int(zarr_format) == 3:
+            if dtype not in _V3_NAMES:
+                raise NotImplementedError(f"dtype {dtype} has no zarr v3 data_type here")
+            _Codec(compressor, dtype.itemsize)   # fail before anything is written
+            meta = {
+                "zarr_format": 3, "node_type": "array", "shape": shape, "data_type": _V3_NAMES[dtype],
+                "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": chunks}},
+                "chunk_key_encoding": {"name": "default", "configuration": {"separator": "/"}},
+                "fill_value": _encode_fill(fill_value, dtype), "codecs": _compressor_to_v3_codecs(compressor, dtype.itemsize),
+                "attributes": {},
+            }
+            if dimension_names is not None:
+                meta["dimension_names"] = [str(d) for d in dimension_names]
+            _write_json(os.path.join(path, "zarr.json"), meta)
+            return cls(path, meta)
         meta = {
             "zarr_format": 2, "shape": shape, "chunks": chunks, "dtype": dtype.str, "order": "C",
             "fill_value": _encode_fill(fill_value, dtype), "compressor": compressor, "filters": None,
@@ -156,7 +265,8 @@ class ZarrArray:
 
     # ---- chunks -------------------------------------------------------------------------------
     def chunk_path(self, idx):
-        return os.path.join(self.path, *self.separator.join(str(int(i)) for i in idx).split("/"))
+        key = self.separator.join(([self.key_prefix] if self.key_prefix else []) + [str(int(i)) for i in idx])
+        return os.path.join(self.path, *key.split("/"))
 
     def read_chunk(self, idx):
         """Full-shape chunk ``idx`` or None when it was never written."""
@@ -305,17 +415,43 @@ def is_zarr_backed(data):
 
 
 # ---- groups and attributes ---------------------------------------------------------------------
-def create_group(path, attrs=None, overwrite=False):
+def array_exists(path):
+    return os.path.exists(os.path.join(path, ".zarray")) or _node_type(path) == "array"
+
+
+def _node_type(path):
+    try:
+        with open(os.path.join(path, "zarr.json")) as f:
+            return json.load(f).get("node_type")
+    except FileNotFoundError:
+        return None
+
+
+def create_group(path, attrs=None, overwrite=False, zarr_format=2):
     if overwrite and os.path.exists(path):
         shutil.rmtree(path)
     os.makedirs(path, exist_ok=True)
-    _write_json(os.path.join(path, ".zgroup"), {"zarr_format": 2})
+    if int(zarr_format) == 3:
+        meta = {"zarr_format": 3, "node_type": "group", "attributes": {}}
+        old = os.path.join(path, "zarr.json")
+        if os.path.exists(old):          # (a farm worker joining a group another worker created keeps its attributes)
+            with open(old) as f:
+                meta["attributes"] = json.load(f).get("attributes", {})
+        _write_json(old, meta)
+    else:
+        _write_json(os.path.join(path, ".zgroup"), {"zarr_format": 2})
     if attrs is not None:
         write_attrs(path, attrs)
     return path
 
 
 def read_attrs(path):
+    """User attributes of a group or array: ``.zattrs`` (v2) or the ``attributes`` member of ``zarr.json`` (v3)."""
+    try:
+        with open(os.path.join(path, "zarr.json")) as f:
+            return dict(json.load(f).get("attributes") or {})
+    except FileNotFoundError:
+        pass
     try:
         with open(os.path.join(path, ".zattrs")) as f:
             return json.load(f)
@@ -324,4 +460,11 @@ def read_attrs(path):
 
 
 def write_attrs(path, attrs):
-    _write_json(os.path.join(path, ".zattrs"), attrs)
+    v3 = os.path.join(path, "zarr.json")
+    if os.path.exists(v3):
+        with open(v3) as f:
+            meta = json.load(f)
+        meta["attributes"] = attrs
+        _write_json(v3, meta)
+    else:
+        _write_json(os.path.join(path, ".zattrs"), attrs)

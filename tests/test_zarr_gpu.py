@@ -169,3 +169,29 @@ def test_batch_options_drive_block_wise_zarr_output(hip_device, tmp_path):
         fusion.fuse(sims, transform_key=key, batch_options={"n_batch": 2})           # needs output_zarr_url
     with pytest.raises(TypeError):
         fusion.fuse(sims, transform_key=key, output_zarr_url=str(tmp_path / "c.zarr"), batch_options={"nbatch": 2})
+
+
+def test_fuse_streams_into_ngff_05_zarr_v3(hip_device, tmp_path):
+    """zarr_options={"ome_zarr": True, "ngff_version": "0.5"}: the fused chunks go into a Zarr v3 hierarchy (zarr.json nodes,
+    c/<i>/... chunk keys, metadata under the "ome" key) with a compressed pyramid; reading it back gives the in-memory result."""
+    from multiview_stitcher_amd import fusion, ngff_utils, sample_data, zarr_io
+
+    key = sample_data.METADATA_TRANSFORM_KEY
+    sims = _dataset(3)
+    chunks = {"z": 32, "y": 96, "x": 128}
+    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=chunks).data)
+    url = str(tmp_path / "v3.zarr")
+    fused = fusion.fuse(sims, transform_key=key, output_chunksize=chunks, output_zarr_url=url,
+                        zarr_options={"ome_zarr": True, "ngff_version": "0.5",
+                                      "zarr_array_creation_kwargs": {"compressor": {"id": "blosc", "cname": "zstd", "clevel": 3, "shuffle": 1}}})
+    assert zarr_io.is_zarr_backed(fused.data)
+    np.testing.assert_array_equal(np.asarray(fused.data), want)
+    grp = json.load(open(os.path.join(url, "zarr.json")))
+    assert grp["node_type"] == "group" and grp["attributes"]["ome"]["version"] == "0.5"
+    arr = json.load(open(os.path.join(url, "0", "zarr.json")))
+    assert arr["chunk_grid"]["configuration"]["chunk_shape"] == [1, 1, 32, 96, 128] and [c["name"] for c in arr["codecs"]] == ["bytes", "blosc"]
+    assert os.path.isdir(os.path.join(url, "0", "c"))
+    ms = ngff_utils.read_msim_from_ome_zarr(url)
+    lvl1 = ms["scale1"] if "scale1" in ms.keys() else None
+    if lvl1 is not None:
+        np.testing.assert_array_equal(np.asarray(lvl1.data)[0, 0], _block_mean(want[0, 0], (1, 2, 2))[: lvl1.data.shape[2]])

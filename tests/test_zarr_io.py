@@ -81,10 +81,10 @@ def test_windows_against_numpy(tmp_path, compressor, sep):
 def test_unknown_codec_and_format_fail_loudly(tmp_path):
     with pytest.raises(NotImplementedError, match="lzma"):
         zarr_io.ZarrArray.create(tmp_path / "b.zarr", (4,), (2,), "u1", compressor={"id": "lzma"})
-    os.makedirs(tmp_path / "v3.zarr")
-    json.dump({"zarr_format": 3, "shape": [1], "chunks": [1], "dtype": "|u1"}, open(tmp_path / "v3.zarr" / ".zarray", "w"))
+    os.makedirs(tmp_path / "v4.zarr")
+    json.dump({"zarr_format": 4, "shape": [1], "chunks": [1], "dtype": "|u1"}, open(tmp_path / "v4.zarr" / ".zarray", "w"))
     with pytest.raises(NotImplementedError):
-        zarr_io.ZarrArray.open(tmp_path / "v3.zarr")
+        zarr_io.ZarrArray.open(tmp_path / "v4.zarr")
     z = zarr_io.ZarrArray.create(tmp_path / "c.zarr", (4, 4), (2, 2), "u1")
     with pytest.raises(IndexError):
         z.write([3, 3], np.zeros((2, 2), "u1"))
@@ -193,3 +193,86 @@ def test_blosc_container_hand_assembled_frames():
     assert zc.blosc_decode(frame) == elems.tobytes()
     with pytest.raises(NotImplementedError):
         zc.blosc_decode(struct.pack("<BBBBIII", 2, 1, 0x10, 1, 8, 8, 16 + 4 + 4 + 3) + struct.pack("<i", 20) + struct.pack("<i", 3) + b"abc")   # blosclz
+
+
+# ---- Zarr v3 / NGFF 0.5 (reference: ngff_utils.py:1185-1281, 1820-1905) -------------------------------------------------
+def _v3_meta(shape, chunks, data_type, codecs, fill=0, enc=None):
+    return {"zarr_format": 3, "node_type": "array", "shape": shape, "data_type": data_type,
+            "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": chunks}},
+            "chunk_key_encoding": enc or {"name": "default", "configuration": {"separator": "/"}},
+            "fill_value": fill, "codecs": codecs, "attributes": {"note": "by hand"}, "dimension_names": ["y", "x"]}
+
+
+def test_v3_reads_a_store_written_by_hand(tmp_path):
+    # what zarr-python 3 writes for a (3, 4) float32 array in (2, 2) chunks with [bytes, gzip]: zarr.json, chunk keys c/<i>/<j>,
+    # little-endian payload, NaN fill as the string "NaN"; chunk c/1/0 missing
+    root = tmp_path / "h3.zarr"
+    os.makedirs(root / "c" / "0")
+    os.makedirs(root / "c" / "1")
+    json.dump(_v3_meta([3, 4], [2, 2], "float32", [{"name": "bytes", "configuration": {"endian": "little"}},
+                                                     {"name": "gzip", "configuration": {"level": 1}}], fill="NaN"),
+              open(root / "zarr.json", "w"))
+    full = np.arange(12, dtype="<f4").reshape(3, 4)
+    pad = np.full((4, 4), np.nan, "<f4")
+    pad[:3] = full
+    for i, j in [(0, 0), (0, 1), (1, 1)]:
+        open(root / "c" / str(i) / str(j), "wb").write(gzip.compress(np.ascontiguousarray(pad[2 * i:2 * i + 2, 2 * j:2 * j + 2]).tobytes(), 1))
+    z = zarr_io.ZarrArray.open(root)
+    assert z.zarr_format == 3 and z.chunks == (2, 2) and z.dtype == np.float32
+    want = full.copy()
+    want[2, 0:2] = np.nan
+    np.testing.assert_array_equal(np.asarray(z), want)
+    assert zarr_io.read_attrs(str(root)) == {"note": "by hand"} and zarr_io.array_exists(str(root))
+    # "v2" chunk key encoding: <i>.<j> next to zarr.json
+    root2 = tmp_path / "k.zarr"
+    os.makedirs(root2)
+    json.dump(_v3_meta([2, 2], [2, 2], "uint8", [{"name": "bytes"}], enc={"name": "v2", "configuration": {"separator": "."}}),
+              open(root2 / "zarr.json", "w"))
+    open(root2 / "0.0", "wb").write(bytes([1, 2, 3, 4]))
+    np.testing.assert_array_equal(np.asarray(zarr_io.ZarrArray.open(root2)), [[1, 2], [3, 4]])
+
+
+def test_v3_known_answer_store_layout_and_unsupported_pieces(tmp_path):
+    a = np.arange(35, dtype="<u2").reshape(5, 7)
+    z = zarr_io.ZarrArray.create(tmp_path / "a3.zarr", a.shape, (2, 4), a.dtype, fill_value=9, zarr_format=3, dimension_names=["y", "x"])
+    z[...] = a
+    meta = json.load(open(tmp_path / "a3.zarr" / "zarr.json"))
+    assert meta == {"zarr_format": 3, "node_type": "array", "shape": [5, 7], "data_type": "uint16",
+                    "chunk_grid": {"name": "regular", "configuration": {"chunk_shape": [2, 4]}},
+                    "chunk_key_encoding": {"name": "default", "configuration": {"separator": "/"}}, "fill_value": 9,
+                    "codecs": [{"name": "bytes", "configuration": {"endian": "little"}}], "attributes": {}, "dimension_names": ["y", "x"]}
+    assert sorted(os.listdir(tmp_path / "a3.zarr")) == ["c", "zarr.json"] and sorted(os.listdir(tmp_path / "a3.zarr" / "c")) == ["0", "1", "2"]
+    raw = np.frombuffer(open(tmp_path / "a3.zarr" / "c" / "2" / "1", "rb").read(), dtype="<u2").reshape(2, 4)
+    np.testing.assert_array_equal(raw, [[32, 33, 34, 9], [9, 9, 9, 9]])
+    np.testing.assert_array_equal(np.asarray(zarr_io.ZarrArray.open(tmp_path / "a3.zarr")), a)
+    for comp in ({"id": "zstd", "level": 3}, {"id": "blosc", "cname": "lz4", "clevel": 5, "shuffle": 1}, {"id": "gzip", "level": 2}):
+        zc = zarr_io.ZarrArray.create(tmp_path / f"c_{comp['id']}.zarr", a.shape, (2, 4), a.dtype, compressor=comp, zarr_format=3)
+        zc[...] = a
+        back = zarr_io.ZarrArray.open(tmp_path / f"c_{comp['id']}.zarr")
+        assert [c["name"] for c in back.meta_v3["codecs"]] == ["bytes", comp["id"]]
+        np.testing.assert_array_equal(np.asarray(back), a)
+    for bad in ([{"name": "transpose", "configuration": {"order": [1, 0]}}, {"name": "bytes"}],
+                [{"name": "sharding_indexed", "configuration": {}}],
+                [{"name": "bytes", "configuration": {"endian": "little"}}, {"name": "crc32c"}]):
+        os.makedirs(tmp_path / "bad.zarr", exist_ok=True)
+        json.dump(_v3_meta([2, 2], [2, 2], "uint16", bad), open(tmp_path / "bad.zarr" / "zarr.json", "w"))
+        with pytest.raises(NotImplementedError):
+            zarr_io.ZarrArray.open(tmp_path / "bad.zarr")
+
+
+def test_ngff_05_round_trip_without_gpu(tmp_path):
+    a = np.random.default_rng(2).integers(0, 4000, (1, 1, 20, 90, 80)).astype(np.uint16)
+    sim = si.to_spatial_image(a, dims=["c", "t", "z", "y", "x"], scale={"z": 2.0, "y": 1.0, "x": 1.0}, translation={"z": 5.0, "y": 7.0, "x": -2.0})
+    url = str(tmp_path / "s5.zarr")
+    back = ngff_utils.write_sim_to_ome_zarr(sim, url, ngff_version="0.5", zarr_array_creation_kwargs={"compressor": {"id": "zstd", "level": 1}})
+    grp = json.load(open(os.path.join(url, "zarr.json")))
+    assert grp["zarr_format"] == 3 and grp["node_type"] == "group" and list(grp["attributes"]) == ["ome"]
+    ome = grp["attributes"]["ome"]
+    assert ome["version"] == "0.5" and sorted(ome["multiscales"][0]) == ["axes", "datasets", "name"]       # version sits in "ome" only
+    arr = json.load(open(os.path.join(url, "0", "zarr.json")))
+    assert arr["dimension_names"] == ["c", "t", "z", "y", "x"] and [c["name"] for c in arr["codecs"]] == ["bytes", "zstd"]
+    assert not os.path.exists(os.path.join(url, ".zattrs")) and not os.path.exists(os.path.join(url, "0", ".zarray"))
+    assert zarr_io.is_zarr_backed(back.data) and si.get_origin_from_sim(back) == {"z": 5.0, "y": 7.0, "x": -2.0}
+    np.testing.assert_array_equal(np.asarray(back.data), a)
+    lazy = ngff_utils.read_sim_from_ome_zarr(url, 0)
+    np.testing.assert_array_equal(np.asarray(lazy.isel({"c": 0, "t": 0}).sel({"z": slice(9.0, 21.0)}).data), a[0, 0, 2:9])
