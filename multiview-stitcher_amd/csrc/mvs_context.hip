@@ -215,6 +215,10 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         c->no_regions = value != 0;
         return MVS_OK;
     }
+    if (!strcmp(key, "stream_rows")) {
+        c->stream_rows = value != 0;
+        return MVS_OK;
+    }
     if (!strcmp(key, "rowlds")) {
         c->rowlds = value != 0;
         return MVS_OK;

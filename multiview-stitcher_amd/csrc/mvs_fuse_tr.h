@@ -68,19 +68,18 @@ __host__ __device__ __forceinline__ float blend_ramp_nb(float x) {
 }
 
 
-// Blend weight profile value W at chunk index (z, y, x) of view V (before the ramp): the closed form of the
-// trilinear interpolation of edt = min_d(ws_d * tent(i_d)); < 0 is never returned, outside the support -> 0.
-__host__ __device__ __forceinline__ float tr_weight_profile(const TrView& V, int z, int y, int x) {
+// Row nodes of view V at (z, y): the x profile of the row is lerp{0, G1, G2} over the folded x coordinate (row_profile).
+// Returns false when the row lies outside the support along z or y (weight 0 on the whole row).
+__host__ __device__ __forceinline__ bool tr_row_nodes(const TrView& V, int z, int y, float& G1, float& G2) {
     float az0 = INFINITY, az1 = INFINITY, fz = 0.f, uz = 0.f;
     const bool has_z = V.wnz > 1;
     if (has_z) {
         uz = fold_u(z, V.sup_ilo[0], V.sup_flo[0], V.sup_ihi[0], V.sup_fhi[0], V.sup_k[0]);
-        if (uz < 0.f) return 0.f;
+        if (uz < 0.f) return false;
         tent_cell(uz, V.ws[0], az0, az1, fz);
     }
     const float uy = fold_u(y, V.sup_ilo[1], V.sup_flo[1], V.sup_ihi[1], V.sup_fhi[1], V.sup_k[1]);
-    const float ux = fold_u(x, V.sup_ilo[2], V.sup_flo[2], V.sup_ihi[2], V.sup_fhi[2], V.sup_k[2]);
-    if (uy < 0.f || ux < 0.f) return 0.f;
+    if (uy < 0.f) return false;
     float ay0, ay1, fy;
     tent_cell(uy, V.ws[1], ay0, ay1, fy);
     const float uz_ = 1.f - fz, uy_ = 1.f - fy;
@@ -88,9 +87,19 @@ __host__ __device__ __forceinline__ float tr_weight_profile(const TrView& V, int
     const float a1 = V.ws[2], a2 = 2.f * V.ws[2];
     float g0 = fmaf(fminf(m01, a1), fy, fminf(m00, a1) * uy_);
     float g1 = fmaf(fminf(m11, a1), fy, fminf(m10, a1) * uy_);
-    const float G1 = has_z ? fmaf(g1, fz, g0 * uz_) : g0;
+    G1 = has_z ? fmaf(g1, fz, g0 * uz_) : g0;
     g0 = fmaf(fminf(m01, a2), fy, fminf(m00, a2) * uy_);
     g1 = fmaf(fminf(m11, a2), fy, fminf(m10, a2) * uy_);
-    const float G2 = has_z ? fmaf(g1, fz, g0 * uz_) : g0;
+    G2 = has_z ? fmaf(g1, fz, g0 * uz_) : g0;
+    return true;
+}
+
+// Blend weight profile value W at chunk index (z, y, x) of view V (before the ramp): the closed form of the
+// trilinear interpolation of edt = min_d(ws_d * tent(i_d)); < 0 is never returned, outside the support -> 0.
+__host__ __device__ __forceinline__ float tr_weight_profile(const TrView& V, int z, int y, int x) {
+    float G1, G2;
+    if (!tr_row_nodes(V, z, y, G1, G2)) return 0.f;
+    const float ux = fold_u(x, V.sup_ilo[2], V.sup_flo[2], V.sup_ihi[2], V.sup_fhi[2], V.sup_k[2]);
+    if (ux < 0.f) return 0.f;
     return row_profile(ux, G1, G2 - G1);
 }
