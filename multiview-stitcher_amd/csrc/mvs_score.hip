@@ -601,6 +601,9 @@ __global__ __launch_bounds__(256) void ssim_yx_batch_kernel(YxBatch B, float* __
 // separate passes moved 50 bytes per voxel and candidate through HBM (14 read + 12 written by the z pass, 24 read by the
 // y / x pass).  Interior outputs (crop = window / 2) never reach a reflected sample, so no boundary handling is needed;
 // the region statistics (nanmax / has-NaN of the candidate image, idempotent) are gathered from every sample loaded.
+// Samples come through raw buffer loads: the pixel's byte offset inside a plane is a per-thread constant, the plane a scalar
+// offset, so a sample costs no address arithmetic (the kernel is bound by the float64 filter arithmetic: ~300 of its ~580
+// vector instructions per plane are f64 adds / multiplies / conversions, all at 1/2 of the fp32 issue rate on gfx950).
 // A candidate is its shifted copy (dz = dy = dx = 0) or, for an integer shift, the moving crop itself read in place.
 struct FusedCand { const float* src; int dz, dy, dx; };
 struct FusedBatch { FusedCand c[kMaxResident]; };
@@ -623,7 +626,11 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
     const int cz = S.nz - 2 * pad, cy = S.ny - 2 * pad, cx = S.nx - 2 * pad;
     float mx = -INFINITY;
     int hn = 0;
+    unsigned long long nanmask = 0;                  // lanes that met a NaN sample of the candidate
     double acc = 0.0;
+    const long long vol_bytes = (long long)S.nz * S.ny * S.nx * 4;      // < 2^31 (checked by the host)
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)im0, 0, (int)vol_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc((void*)C.src, 0, (int)vol_bytes, 0x00020000);
     if (cz > 0 && cy > 0 && cx > 0) {
         const int nty = (cy + TY - 1) / TY, ntx = (cx + TX - 1) / TX, nzs = (cz + zseg - 1) / zseg;
         const int nitems = nty * ntx * nzs;
@@ -634,47 +641,66 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
             const int y0 = pad + ty * TY, x0 = pad + tx * TX;
             const int gx = min(x0 - H + col, S.nx - 1);          // (clamped duplicates feed outputs that are never used)
             const bool xin = (unsigned)(gx + C.dx) < (unsigned)S.nx;
-            int o0[NR], o1[NR];                                    // plane offsets of this thread's pixels in im0 / the candidate (-1: outside)
+            // byte offsets of this thread's pixels inside a plane of im0 / the candidate; the plane itself is a scalar offset
+            // of the buffer loads, so a sample costs no address arithmetic.  A pixel outside the candidate in y / x gets an
+            // offset beyond the buffer (the load returns 0) and counts as a NaN sample.
+            int v0[NR], v1[NR];
+            bool in1[NR], out1 = false;
 #pragma unroll
             for (int k = 0; k < NR; ++k) {
-                const int gy = min(y0 - H + min(wrow + 4 * k, LY - 1), S.ny - 1);
-                o0[k] = gy * sy + gx;
-                o1[k] = (xin && (unsigned)(gy + C.dy) < (unsigned)S.ny) ? (gy + C.dy) * sy + gx + C.dx : -1;
+                const int prow = wrow + 4 * k;
+                const int gy = min(y0 - H + min(prow, LY - 1), S.ny - 1);
+                in1[k] = xin && (unsigned)(gy + C.dy) < (unsigned)S.ny;
+                v0[k] = (gy * sy + gx) * 4;
+                v1[k] = in1[k] ? ((gy + C.dy) * sy + gx + C.dx) * 4 : 0x7ffffff0;
+                out1 = out1 || (!in1[k] && prow < LY && col < LX);
             }
+            if (out1) hn = 1;
             double s1[NR], s3[NR], s4[NR];
 #pragma unroll
             for (int k = 0; k < NR; ++k) { s1[k] = 0.0; s3[k] = 0.0; s4[k] = 0.0; }
-            // plane p's samples are loaded one iteration ahead (new: plane p, old: plane p - WIN) so that their latency hides
-            // behind the LDS phases of plane p - 1
+            // plane p + 1's samples (new: plane p + 1, old: plane p + 1 - WIN) are requested right after plane p's have been
+            // folded into the running sums, so that their latency hides behind the LDS phases of plane p
             float an[NR], bn[NR], ao[NR], bo[NR];
             auto load_plane = [&](int p) __attribute__((always_inline)) {
                 const bool zin = (unsigned)(p + C.dz) < (unsigned)S.nz;
                 const bool have_old = p - (z0 - H) >= WIN;
                 const bool zin_o = have_old && (unsigned)(p - WIN + C.dz) < (unsigned)S.nz;
+                if (!zin) hn = 1;                                   // the whole plane lies outside the candidate
+                const int pn0 = p * sz * 4, pn1 = (p + C.dz) * sz * 4, po0 = (p - WIN) * sz * 4, po1 = (p - WIN + C.dz) * sz * 4;
 #pragma unroll
                 for (int k = 0; k < NR; ++k) {
-                    an[k] = im0[p * sz + o0[k]];
-                    bn[k] = (zin && o1[k] >= 0) ? C.src[(p + C.dz) * sz + o1[k]] : NAN;
-                    ao[k] = have_old ? im0[(p - WIN) * sz + o0[k]] : 0.f;
-                    bo[k] = have_old ? ((zin_o && o1[k] >= 0) ? C.src[(p - WIN + C.dz) * sz + o1[k]] : NAN) : 0.f;
+                    an[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, v0[k], pn0, 0));
+                    bn[k] = zin ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, v1[k], pn1, 0)) : 0.f;
+                    ao[k] = have_old ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, v0[k], po0, 0)) : 0.f;
+                    bo[k] = zin_o ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r1, v1[k], po1, 0)) : 0.f;
                 }
             };
             if (col < LX) load_plane(z0 - H);
+            const int xrow = tid / (TX / NO), xch = tid % (TX / NO);      // x pass: row of the tile, group of NO voxels
+            const bool xact = tid < TY * (TX / NO) && y0 + xrow < S.ny - pad;
             for (int p = z0 - H; p < z1 + H; ++p) {
-                if (col < LX) {
-                    float a_[NR], b_[NR], ao_[NR], bo_[NR];
+                // the fixed image's window means of this plane's outputs: requested now, used after the two LDS phases
+                float fa[NO], faxx[NO];
+                if (xact && p >= z0 + H) {
+                    const int obase = ((p - H) * S.ny + y0 + xrow) * S.nx + x0 + xch * NO;
 #pragma unroll
-                    for (int k = 0; k < NR; ++k) { a_[k] = an[k]; b_[k] = bn[k]; ao_[k] = ao[k]; bo_[k] = bo[k]; }
-                    if (p + 1 < z1 + H) load_plane(p + 1);
+                    for (int k = 0; k < NO; ++k) {
+                        const bool in = x0 + xch * NO + k < S.nx - pad;
+                        fa[k] = in ? ux[obase + k] : 0.f;
+                        faxx[k] = in ? uxx[obase + k] : 0.f;
+                    }
+                }
+                if (col < LX) {
 #pragma unroll
                     for (int k = 0; k < NR; ++k) {
                         const int row = wrow + 4 * k;
                         if (row >= LY) break;
-                        float a = a_[k], b = b_[k], a2 = ao_[k], b2 = bo_[k];
-                        if (b == b) mx = fmaxf(mx, b); else hn = 1;
-                        a = (a != a) ? 0.f : a;
+                        const float a = an[k], a2 = ao[k];           // the fixed image is finite (precondition of this launch)
+                        float b = bn[k], b2 = bo[k];
+                        nanmask |= __ballot(b != b);
+                        mx = fmaxf(mx, in1[k] ? b : -INFINITY);      // (NaN never wins a maximum)
                         b = (b != b) ? 0.f : b;
-                        a2 = (a2 != a2) ? 0.f : a2;
                         b2 = (b2 != b2) ? 0.f : b2;
                         // products in float32 like `im * im`; tmp += new - old like uniform_filter1d
                         s1[k] += (double)b - (double)b2;
@@ -686,9 +712,10 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
                             sz_[2][row][col] = (float)(s4[k] * inv);
                         }
                     }
+                    if (p + 1 < z1 + H) load_plane(p + 1);
                 }
                 if (p < z0 + H) continue;
-                const int zc = p - H;
+
                 __syncthreads();
                 // ---- y pass: column c of the patch, NO rows per item ----
                 if (tid < LX * (TY / NO)) {
@@ -705,10 +732,9 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
                 }
                 __syncthreads();
                 // ---- x pass + SSIM: row `row` of the tile, NO voxels per thread ----
-                if (tid < TY * (TX / NO)) {
-                    const int row = tid / (TX / NO), ch = tid % (TX / NO);
-                    const int y = y0 + row;
-                    if (y < S.ny - pad) {
+                {
+                    const int row = xrow, ch = xch;
+                    if (xact) {
                         float f[3][NO];
 #pragma unroll
                         for (int a = 0; a < 3; ++a) {
@@ -717,11 +743,10 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
                             for (int k = 0; k < NI; ++k) v[k] = sy_[a][row][ch * NO + k];
                             box_means<WIN, NO>(v, f[a]);
                         }
-                        const int obase = (zc * S.ny + y) * S.nx + x0 + ch * NO;
 #pragma unroll
                         for (int k = 0; k < NO; ++k) {
                             if (x0 + ch * NO + k >= S.nx - pad) continue;
-                            const float a = ux[obase + k], axx = uxx[obase + k], b = f[0][k];
+                            const float a = fa[k], axx = faxx[k], b = f[0][k];
                             const float vx = cov_norm * (axx - a * a);
                             const float vy = cov_norm * (f[1][k] - b * b);
                             const float vxy = cov_norm * (f[2][k] - a * b);
@@ -735,6 +760,7 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
             __syncthreads();
         }
     }
+    if (nanmask) hn = 1;
     for (int off = 32; off > 0; off >>= 1) {
         mx = fmaxf(mx, __shfl_down(mx, off));
         hn |= __shfl_down(hn, off);
