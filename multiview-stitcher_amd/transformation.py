@@ -50,6 +50,42 @@ def get_pixel_affine(p, input_origin, input_spacing, output_origin, output_spaci
     return matrix_prime, offset_prime
 
 
+def get_pixel_affines(p_stack, input_origins, input_spacings, output_origin, output_spacing):
+    """``get_pixel_affine`` for a stack of views in one pass: (matrices (n, ndim, ndim), offsets (n, ndim)).  The same
+    elementwise operations on stacked arrays (same bits); the one reduction, ``np.dot(M - I, Ox)``, is an exact zero for a
+    pure translation and is taken per view through ``np.dot`` otherwise."""
+    p_stack = np.asarray(p_stack, dtype=np.float64)
+    ndim = p_stack.shape[1] - 1
+    M, t = p_stack[:, :ndim, :ndim], p_stack[:, :ndim, ndim]
+    sx = np.asarray(output_spacing, dtype=np.float64)
+    sy = np.asarray(input_spacings, dtype=np.float64)
+    Ox = np.asarray(output_origin, dtype=np.float64)
+    Oy = np.asarray(input_origins, dtype=np.float64)
+    matrix_prime = (M * sx[None, None, :]) / sy[:, :, None]
+    lin = M - np.eye(ndim)[None]
+    shift = np.zeros_like(t)
+    for i in np.nonzero(np.any(lin != 0, axis=(1, 2)))[0]:
+        shift[i] = np.dot(lin[i], Ox)
+    offset_prime = ((t + shift) - (Oy - Ox[None, :])) / sy
+    matrix_prime = np.around(matrix_prime, decimals=10)
+    offset_prime = np.around(offset_prime, decimals=10)
+    nearest = np.round(offset_prime)
+    snap = np.abs(offset_prime - nearest) <= 1e-6
+    offset_prime[snap] = nearest[snap]
+    return matrix_prime, offset_prime
+
+
+def embed3_stack(matrices, offsets):
+    """``embed3`` for stacks: (n, 9) row-major matrices and (n, 3) offsets."""
+    n, ndim = offsets.shape
+    m3 = np.tile(np.eye(3), (n, 1, 1))
+    o3 = np.zeros((n, 3))
+    k = 3 - ndim
+    m3[:, k:, k:] = matrices
+    o3[:, k:] = offsets
+    return m3.reshape(n, 9), o3
+
+
 def embed3(matrix, offset):
     """Embed an ndim-D pixel affine into the 3D (z,y,x) form the C ABI takes (2D: z -> z)."""
     ndim = len(offset)

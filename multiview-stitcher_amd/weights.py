@@ -76,6 +76,39 @@ def blending_support(source_bb, blending_widths=None, shrink_distance=0):
     return table, c0, c1 - c0
 
 
+def blending_supports(origins, spacings, shapes, sdims, blending_widths=None, shrink_distance=0):
+    """``blending_support`` for a stack of views ((n, ndim) arrays in ``sdims`` order): (tables, support origins, support
+    spacings); views with the same sampling share one table object."""
+    ndim = len(sdims)
+    if blending_widths is None:
+        blending_widths = DEFAULT_BLENDING_WIDTHS
+    bw = _as_zyx(blending_widths, sdims)
+    origin, spacing, shape = (np.asarray(a, dtype=np.float64) for a in (origins, spacings, shapes))
+    if (isinstance(shrink_distance, dict) and any(shrink_distance.values())) or (
+        not isinstance(shrink_distance, dict) and shrink_distance
+    ):
+        origin, spacing, shape = _shrink_source_bb(origin, spacing, shape, shrink_distance, sdims)
+    support_spacing = (shape - 1) / 4 * spacing
+    edt_support_spacing = support_spacing * (shape - 1 + 2 * 1) / (shape - 1)
+    edt_support_origin = origin - 1 * spacing
+    sampling = edt_support_spacing / bw
+    tables = []
+    for row in sampling:
+        key = tuple(row.tolist())
+        table = _TABLE_CACHE.get(key)
+        if table is None:
+            tent = np.minimum(np.arange(5), 4 - np.arange(5)).astype(np.float64)
+            grids = np.meshgrid(*[tent * row[d] for d in range(ndim)], indexing="ij")
+            table = np.minimum.reduce(grids).astype(np.float32)
+            if len(_TABLE_CACHE) > 64:
+                _TABLE_CACHE.clear()
+            _TABLE_CACHE[key] = table
+        tables.append(table)
+    c0 = edt_support_origin + edt_support_spacing * 0.0
+    c1 = edt_support_origin + edt_support_spacing * 1.0
+    return tables, c0, c1 - c0
+
+
 def fill_view_weights(view, source_bb, affine, target_origin, target_spacing, blending_widths=None, shrink_distance=0):
     """Fill the blending half of an ``mvs_view_t`` (w_matrix, w_offset, edt)."""
     table, sup_origin, sup_spacing = blending_support(source_bb, blending_widths, shrink_distance)

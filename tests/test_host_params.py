@@ -89,3 +89,47 @@ def test_merged_chunksize_is_whole_multiples_within_budget():
     tiny = fusion._merged_chunksize(cs, shape, "zyx", 2, max_bytes=1)
     assert tiny == cs                                                                 # never below the request
     assert fusion._merged_chunksize({"y": 5, "x": 5}, {"y": 18, "x": 18}, "yx", 2) == {"y": 18, "x": 18}
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_stacked_view_records_equal_the_per_view_form(ndim):
+    """fuse_np builds the records of all views of a chunk from stacked arrays (get_pixel_affines, blending_supports,
+    embed3_stack): bit for bit the values of the per-view functions, for pure translations and for general affines."""
+    rng = np.random.default_rng(5)
+    sdims = ["z", "y", "x"][-ndim:]
+    n = 7
+    ps, origins, spacings, shapes = [], [], [], []
+    for i in range(n):
+        p = np.eye(ndim + 1)
+        if i % 3 == 1:       # general affine
+            p[:ndim, :ndim] = np.eye(ndim) + rng.uniform(-0.2, 0.2, (ndim, ndim))
+        if i % 3 == 2:       # anisotropic scaling only
+            p[:ndim, :ndim] = np.diag(rng.uniform(0.5, 2.0, ndim))
+        p[:ndim, ndim] = rng.uniform(-50, 50, ndim)
+        ps.append(p)
+        origins.append(rng.uniform(-1e4, 1e4, ndim))
+        spacings.append(rng.uniform(0.2, 3.0, ndim))
+        shapes.append(rng.integers(20, 600, ndim).astype(np.float64))
+    out_origin, out_spacing = rng.uniform(-100, 100, ndim), rng.uniform(0.3, 2.0, ndim)
+    p_inv = np.linalg.inv(np.stack(ps))
+    mats, offs = transformation.get_pixel_affines(p_inv, np.stack(origins), np.stack(spacings), out_origin, out_spacing)
+    for shrink in (0, 1.5):
+        tables, so, ss = weights.blending_supports(np.stack(origins), np.stack(spacings), np.stack(shapes), sdims, None, shrink)
+        wm, wo = transformation.get_pixel_affines(p_inv, so, ss, out_origin, out_spacing)
+        for i in range(n):
+            m1, o1 = transformation.get_pixel_affine(np.linalg.inv(ps[i]), origins[i], spacings[i], out_origin, out_spacing)
+            np.testing.assert_array_equal(mats[i], m1)
+            np.testing.assert_array_equal(offs[i], o1)
+            bb = {"origin": dict(zip(sdims, origins[i])), "spacing": dict(zip(sdims, spacings[i])), "shape": dict(zip(sdims, shapes[i]))}
+            t1, so1, ss1 = weights.blending_support(bb, None, shrink)
+            np.testing.assert_array_equal(tables[i], t1)
+            np.testing.assert_array_equal(so[i], so1)
+            np.testing.assert_array_equal(ss[i], ss1)
+            wm1, wo1 = transformation.get_pixel_affine(np.linalg.inv(ps[i]), so1, ss1, out_origin, out_spacing)
+            np.testing.assert_array_equal(wm[i], wm1)
+            np.testing.assert_array_equal(wo[i], wo1)
+    m3, o3 = transformation.embed3_stack(mats, offs)
+    for i in range(n):
+        a, b = transformation.embed3(mats[i], offs[i])
+        np.testing.assert_array_equal(m3[i], a.reshape(-1))
+        np.testing.assert_array_equal(o3[i], b)
