@@ -28,6 +28,7 @@ copies = {
     "fuse_launch_windows.csv": "round2_fuse_launch_windows.csv",
     "fuse_variants.txt": "round2_fuse_variants.txt",
     "dma_probe.txt": "round2_dma_probe.txt",
+    "valu_rate.txt": "round2_valu_rate.txt",
     "cb_probe.txt": "round2_cb_probe.txt",
     "pair_overhead.txt": "round2_pair_overhead.txt",
     "host_profile.txt": "round2_host_profile.txt",
@@ -38,7 +39,7 @@ for pat, name in copies.items():
     f = find(pat)
     if f:
         shutil.copyfile(f, os.path.join(DST, name))
-for d in ("int", "frac", "cal", "rowlds", "cb"):
+for d in ("int", "frac", "cal", "rowlds", "stream", "cb"):
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         f = find(f"pmc_{d}_{c}/**/*counter_collection.csv")
         if f:
@@ -55,7 +56,7 @@ out["calibration"] = {"case": "single 512^3 tile: copy_region_kernel reads exact
                       "copy_fetch_size_kb": cal_f["copy_region_kernel<unsigned short, unsigned short>"][0],
                       "copy_write_size_kb": cal_w["copy_region_kernel<unsigned short, unsigned short>"][0]}
 out["calibration"]["fetch_over_write"] = out["calibration"]["copy_fetch_size_kb"] / out["calibration"]["copy_write_size_kb"]
-for tag, key, reps in (("int", "integer_offsets", 2), ("frac", "fractional_offsets", 2), ("rowlds", "rowlds_integer_offsets", 2), ("cb", "content_based_probe", 3)):
+for tag, key, reps in (("int", "integer_offsets", 2), ("frac", "fractional_offsets", 2), ("rowlds", "rowlds_integer_offsets", 2), ("stream", "stream_rows_integer_offsets", 2), ("cb", "content_based_probe", 3)):
     f = per_kernel(find(f"pmc_{tag}_FETCH_SIZE/**/*counter_collection.csv"), reps)
     w = per_kernel(find(f"pmc_{tag}_WRITE_SIZE/**/*counter_collection.csv"), reps)
     fk = sum(v * n for v, n in f.values())
