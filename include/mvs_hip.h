@@ -207,6 +207,13 @@ int mvs_rescale_intensity(int device, const float* in, int32_t mem, int64_t n, f
 int mvs_bin_mean(int device, const void* in, int32_t dtype, int32_t mem, const int64_t shape[3],
                  const int64_t stride[3], const int64_t bin[3], void* out, int32_t out_mem);
 
+/* mvs_bin_mean between device buffers without the final wait: the kernel is queued on the context lane's stream and the
+ * call returns; mvs_synchronize(device) orders later use (other lanes read the result only after it).  Lets a host that
+ * has other work -- registration.register builds and prunes its overlap graph -- bin all tiles of a mosaic meanwhile
+ * (reference: the same coarsen().mean() of registration.py:1732-1741, there part of the lazy dask graph). */
+int mvs_bin_mean_async(int device, const void* in, int32_t dtype, const int64_t shape[3], const int64_t stride[3],
+                       const int64_t bin[3], void* out);
+
 /* Candidate scoring == the loop of registration.py:493-556 for n translation
  * candidates t (z,y,x rows): moving resampled by t (order 1, NaN outside),
  * masks, bounding-box region (region_mode 0 = "union", 1 = "intersection"),

@@ -101,6 +101,10 @@ SIGNATURES = {
         [C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
          C.c_void_p, C.c_int32],
     ),
+    "mvs_bin_mean_async": (
+        C.c_int,
+        [C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p],
+    ),
     "mvs_register_views": (
         C.c_int,
         [C.c_int, C.POINTER(mvs_view_t), C.POINTER(mvs_view_t), C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32,

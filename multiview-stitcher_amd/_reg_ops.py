@@ -197,9 +197,11 @@ def score_candidates(im0, im1, t_candidates, region_mode, data_range, im1_min, d
     return ssim[inverse], spear[inverse], code[inverse]
 
 
-def bin_mean(data, bins, device=0):
+def bin_mean(data, bins, device=0, wait=True, out=None):
     """``coarsen(bins, boundary="trim").mean().astype(dtype)`` (registration.py:1732-1741) on the GPU.
-    ``data``: numpy array or (strided) DeviceArray, spatial dims only; ``bins``: per-axis ints."""
+    ``data``: numpy array or (strided) DeviceArray, spatial dims only; ``bins``: per-axis ints.  ``wait=False`` (device
+    arrays only) queues the kernel and returns: ``_lib.synchronize(device)`` before the result is used; ``out``: a contiguous
+    DeviceArray of the binned shape to write into (one allocation for many tiles)."""
     lib = _lib.init(device)
     nd = data.ndim
     bins = [int(b) for b in bins]
@@ -210,7 +212,10 @@ def bin_mean(data, bins, device=0):
         raise TypeError(f"unsupported dtype {dtype}")
     if is_device_array(data):
         ptr, mem, strides = data.ptr, _lib.MVS_MEM_DEVICE, list(data.strides)
-        out = DeviceArray.empty(oshape, dtype, device)
+        if out is None:
+            out = DeviceArray.empty(oshape, dtype, device)
+        elif tuple(out.shape) != tuple(oshape) or out.dtype != dtype or not out.is_contiguous():
+            raise ValueError("bin_mean: out must be a contiguous DeviceArray of the binned shape and the input dtype")
         optr, omem = out.ptr, _lib.MVS_MEM_DEVICE
     else:
         data = np.ascontiguousarray(data)
@@ -220,6 +225,10 @@ def bin_mean(data, bins, device=0):
     s3 = shape3(shape)
     st3 = strides if nd == 3 else [strides[0] * s3[1], strides[0], strides[1]]
     b3 = [1] * (3 - nd) + bins
+    if not wait and mem == _lib.MVS_MEM_DEVICE:
+        rc = lib.mvs_bin_mean_async(device, ptr, _lib.DTYPE_CODES[dtype], _lib.i64x3(s3), _lib.i64x3(st3), _lib.i64x3(b3), optr)
+        _lib.check(rc, device, "mvs_bin_mean_async")
+        return out
     rc = lib.mvs_bin_mean(device, ptr, _lib.DTYPE_CODES[dtype], mem, _lib.i64x3(s3), _lib.i64x3(st3), _lib.i64x3(b3), optr, omem)
     _lib.check(rc, device, "mvs_bin_mean")
     return out

@@ -589,8 +589,23 @@ __global__ __launch_bounds__(256) void bin_mean_u16x2_kernel(const unsigned shor
 }
 }  // namespace
 
+static int bin_mean_impl(int device, const void* in, int32_t dtype, int32_t mem, const int64_t shape[3], const int64_t stride[3],
+                         const int64_t bin[3], void* out, int32_t out_mem, bool wait);
+
 extern "C" int mvs_bin_mean(int device, const void* in, int32_t dtype, int32_t mem, const int64_t shape[3],
                             const int64_t stride[3], const int64_t bin[3], void* out, int32_t out_mem) {
+    return bin_mean_impl(device, in, dtype, mem, shape, stride, bin, out, out_mem, true);
+}
+
+// The same launch without the final wait (device memory on both sides only): the caller orders later work with
+// mvs_synchronize(device) -- used to bin all tiles of a mosaic while the host builds its overlap graph.
+extern "C" int mvs_bin_mean_async(int device, const void* in, int32_t dtype, const int64_t shape[3], const int64_t stride[3],
+                                  const int64_t bin[3], void* out) {
+    return bin_mean_impl(device, in, dtype, MVS_MEM_DEVICE, shape, stride, bin, out, MVS_MEM_DEVICE, false);
+}
+
+static int bin_mean_impl(int device, const void* in, int32_t dtype, int32_t mem, const int64_t shape[3], const int64_t stride[3],
+                         const int64_t bin[3], void* out, int32_t out_mem, bool wait) {
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
@@ -639,6 +654,6 @@ extern "C" int mvs_bin_mean(int device, const void* in, int32_t dtype, int32_t m
 #undef MVS_BIN
     MVS_HIP_TRY(c, hipGetLastError());
     if (out_mem == MVS_MEM_HOST) MVS_HIP_TRY(c, hipMemcpyAsync(out, dout, (size_t)n * es, hipMemcpyDeviceToHost, c->stream));
-    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (wait) MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MVS_OK;
 }

@@ -11,6 +11,8 @@ from __future__ import annotations
 import logging
 import warnings
 
+import threading
+
 import numpy as np
 
 from . import _lib, _reg_ops, param_utils
@@ -244,7 +246,7 @@ def si_utils_extend(stack_props, extend_by):
     return sp
 
 
-def _bin_sim(sim, binning, device):
+def _bin_sim(sim, binning, device, wait=True, out=None):
     """sim.coarsen(binning, boundary="trim").mean().astype(dtype) incl. the coarsened coordinates
     (registration.py:1732-1741)."""
     from . import spatial_image_utils as si_utils
@@ -253,7 +255,7 @@ def _bin_sim(sim, binning, device):
     bins = [int(binning.get(d, 1)) for d in sdims]
     if max(bins) == 1:
         return sim
-    data = _reg_ops.bin_mean(sim.data, bins, device)
+    data = _reg_ops.bin_mean(sim.data, bins, device, wait=wait) if out is None else _reg_ops.bin_mean(sim.data, bins, device, wait=wait, out=out)
     coords = {}
     for d, b, n in zip(sdims, bins, data.shape):
         c = sim.coords[d][: n * b].reshape(n, b).mean(axis=1)
@@ -561,9 +563,61 @@ def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=Non
             "bbox": np.array([ovp["lowers"][0], ovp["uppers"][0]])}
 
 
+def _prebin_views(sims, registration_binning, device, cache):
+    """Queues the binning of all views of a regular mosaic (one shape, one spacing: every pair asks for the same binning)
+    on the last context lane and puts the results into ``cache``; returns that lane's device id (to be synchronised before
+    the pairs start) or None when there is nothing to do.  register() calls this before it builds the overlap graph, so
+    the GPU bins the tiles while the interpreter builds and prunes the graph.  (A helper thread doing the same through
+    the blocking call starves on the GIL: measured.)"""
+    import threading
+    from . import spatial_image_utils as si_utils
+    from .device import is_device_array
+
+    if len(sims) < 2 or any("t" in s.dims or "c" in s.dims or not is_device_array(s.data) for s in sims):
+        return None
+    shape0, sp0 = si_utils.get_shape_from_sim(sims[0]), si_utils.get_spacing_from_sim(sims[0])
+    for s in sims[1:]:
+        if si_utils.get_shape_from_sim(s) != shape0 or si_utils.get_spacing_from_sim(s) != sp0:
+            return None
+    binning = registration_binning if registration_binning is not None else get_optimal_registration_binning(sims[0], sims[1])
+    if max(binning.values()) <= 1:
+        return None
+    bkey = tuple(sorted(binning.items()))
+    lane_device = (device & 0xff) | (15 << 8)        # the last context lane: the pair workers take lanes from 0 upwards
+
+    from .device import DeviceArray
+    from .transformation import shape3
+
+    sdims = si_utils.get_spatial_dims_from_sim(sims[0])
+    bins = [int(binning.get(d, 1)) for d in sdims]
+    dtype = np.dtype(sims[0].data.dtype)
+    if dtype not in _lib.DTYPE_CODES or any(tuple(s.data.shape) != tuple(sims[0].data.shape) or s.data.dtype != dtype for s in sims):
+        return None
+    nd = len(sdims)
+    shape = [int(v) for v in sims[0].data.shape]
+    oshape = tuple(n // b for n, b in zip(shape, bins))
+    pool = DeviceArray.empty((len(sims),) + oshape, dtype, lane_device)     # one allocation for all binned tiles
+    lib = _lib.init(lane_device)
+    s3, b3 = _lib.i64x3(shape3(shape)), _lib.i64x3([1] * (3 - nd) + bins)
+    code = _lib.DTYPE_CODES[dtype]
+    for i, s in enumerate(sims):
+        data = s.data.on_device(lane_device)
+        st = [int(v) for v in data.strides]
+        st3 = st if nd == 3 else [st[0] * shape[0], st[0], st[1]]
+        out = pool[i]
+        _lib.check(lib.mvs_bin_mean_async(lane_device, data.ptr, code, s3, _lib.i64x3(st3), b3, out.ptr), lane_device, "mvs_bin_mean_async")
+        # the coarsened coordinates of _bin_sim (mean of each group of b: the sum divided by b, as numpy's mean does it)
+        coords = {d: np.add.reduce(s.coords[d][: n * b].reshape(n, b), axis=1) / b for d, b, n in zip(sdims, bins, oshape)}
+        binned = si_utils.SpatialImage(out, sdims, coords, {"transforms": dict(s.attrs.get("transforms", {}))})
+        slot = {"event": threading.Event(), "value": binned, "error": None, "keep": (s.data, data)}
+        slot["event"].set()
+        cache._items[(id(s.data), bkey)] = slot
+    return lane_device
+
+
 def compute_pairwise_registrations(msims, edges, transform_key, registration_binning=None, overlap_tolerance=0.0,
                                    pairwise_reg_func=phase_correlation_registration, pairwise_reg_func_kwargs=None,
-                                   pairwise_executor=None, device=0, host_threads=16):
+                                   pairwise_executor=None, device=0, host_threads=16, _bin_cache=None):
     """registration.compute_pairwise_registrations (registration.py:2622-2714): either hand all edges to a
     user ``pairwise_executor(msims, edges, register_kwargs)`` or loop over them on one device."""
     register_kwargs = dict(transform_key=transform_key, registration_binning=registration_binning,
@@ -574,7 +628,7 @@ def compute_pairwise_registrations(msims, edges, transform_key, registration_bin
         if len(results) != len(edges):
             raise ValueError("pairwise_executor must return one result per edge")
         return results
-    cache = _BinCache()
+    cache = _bin_cache if _bin_cache is not None else _BinCache()
     edges = list(edges)
     n_threads = max(1, min(int(host_threads), len(edges), 16))   # 16 = context lanes per GPU (MVS_MAX_LANES)
     if n_threads == 1:
@@ -582,11 +636,7 @@ def compute_pairwise_registrations(msims, edges, transform_key, registration_bin
     # Pairs are independent.  Every call into libmvs_hip.so releases the GIL; each worker thread drives its own
     # context lane (stream + scratch + lock) of the GPU, so the kernels of one pair fill the host round trips and
     # the Python glue of another.  Results keep the order of `edges`.
-    import threading
-    from concurrent.futures import ThreadPoolExecutor
-
-    lanes = {}
-    lane_lock = threading.Lock()
+    pool, lanes, lane_lock = _pair_pool(n_threads)
 
     def work(i, j):
         # each worker thread owns one context lane of the GPU (`device | lane << 8`: own stream, scratch and lock)
@@ -595,9 +645,24 @@ def compute_pairwise_registrations(msims, edges, transform_key, registration_bin
             lane = lanes.setdefault(tid, len(lanes))
         return register_pair_of_msims(msims[i], msims[j], device=(device & 0xff) | (lane << 8), _bin_cache=cache, **register_kwargs)
 
-    with ThreadPoolExecutor(max_workers=n_threads) as pool:
-        futs = [pool.submit(work, i, j) for i, j in edges]
-        return [f.result() for f in futs]
+    futs = [pool.submit(work, i, j) for i, j in edges]
+    return [f.result() for f in futs]
+
+
+_PAIR_POOLS = {}
+_PAIR_POOLS_LOCK = threading.Lock()
+
+
+def _pair_pool(n_threads):
+    """The worker threads of compute_pairwise_registrations live across calls (starting 16 threads costs ~10 ms of the
+    first pairs' time in every call otherwise); one pool per thread count, with its thread -> lane table."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    with _PAIR_POOLS_LOCK:
+        entry = _PAIR_POOLS.get(n_threads)
+        if entry is None:
+            entry = _PAIR_POOLS[n_threads] = (ThreadPoolExecutor(max_workers=n_threads, thread_name_prefix="mvs-pair"), {}, threading.Lock())
+        return entry
 
 
 class _BinCache:
@@ -722,6 +787,12 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
         sims_reg = [s.isel({"c": 0}) if "c" in s.dims else s for s in sims]
     nt = sims_reg[0].sizes.get("t", 1) if "t" in sims_reg[0].dims else 1
 
+    # tiles of a regular mosaic are binned while the graph is built (the GPU would idle otherwise)
+    bin_cache, prebin = None, None
+    if pairwise_executor is None and nt == 1:
+        bin_cache = _BinCache()
+        prebin = _prebin_views(sims_reg, registration_binning, device, bin_cache)
+
     # (1) graph
     sps = [si_utils.get_stack_properties_from_sim(s) for s in sims_reg]
     affs = [param_utils.select_time(si_utils.get_affine_from_sim(s, transform_key), 0) for s in sims_reg]
@@ -732,6 +803,8 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
     g_views = mv_graph.build_view_adjacency_graph([dict(sp, transform=a) for sp, a in zip(sps, affs)], overlap_tolerance=tol, pairs=pairs)
     g_views = mv_graph.prune_view_adjacency_graph(g_views, pre_registration_pruning_method, pre_reg_pruning_method_kwargs)
     edges = [tuple(sorted(e)) for e in g_views.edges()]
+    if prebin is not None:
+        _lib.synchronize(prebin)      # the binned tiles are complete before any lane reads them
 
     # (2) pairwise registrations per time point
     params_t, all_results, resolution_info = [], [], []
@@ -745,6 +818,7 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
             fields, edges, transform_key, registration_binning, overlap_tolerance, pairwise_reg_func,
             pairwise_reg_func_kwargs, pairwise_executor, device,
             host_threads=(16 if n_parallel_pairwise_regs is None else n_parallel_pairwise_regs),
+            _bin_cache=bin_cache,
         )
         keep = list(range(len(edges)))
         if post_registration_do_quality_filter:

@@ -8,7 +8,7 @@ from multiview_stitcher_amd import _reg_ops, registration, transformation
 from multiview_stitcher_amd import spatial_image_utils as si
 
 
-def _block_mean(data, bins, device=0):
+def _block_mean(data, bins, device=0, wait=True):
     sl = tuple(slice(0, (n // b) * b) for n, b in zip(data.shape, bins))
     shp = []
     for n, b in zip(data.shape, bins):

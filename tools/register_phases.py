@@ -25,6 +25,7 @@ def wrap(mod, name):
     setattr(mod, name, g)
 wrap(mv_graph, "build_view_adjacency_graph"); wrap(mv_graph, "prune_view_adjacency_graph")
 wrap(registration, "compute_pairwise_registrations"); wrap(param_resolution, "groupwise_resolution")
+wrap(registration, "_prebin_views"); wrap(_lib, "synchronize")
 for rep in range(6):
     T.clear()
     t0 = time.perf_counter()
