@@ -141,7 +141,10 @@ def cpu_baseline(args, grid, tile, overlap):
     metric's unit: a 2x2x2 mosaic of small tiles with the same overlap fraction, fused whole, plus its 12
     face-neighbour registrations (one pair per axis orientation is timed, x4) -- once on ONE core and once farmed over
     all host cores with joblib/loky, the reference's own recipe for parallel fusion (misc_utils.py:184-209,
-    docs/fusion_overview.md:185-203): the output is cut into chunks, every chunk and every pair is one task."""
+    docs/fusion_overview.md:185-203).  The all-core leg runs R independent replicas of the sample job, each cut into 64
+    output-chunk tasks + 12 pair tasks, with R chosen so that there are at least twice as many tasks as cores (a farm of
+    20 tasks on 256 cores would measure the task count, not the host).  One pair with the NORTH-STAR crop size (binned
+    overlap of two 512^3 tiles: 51 x 256 x 256) is timed on one core as well."""
     from multiview_stitcher_amd import sample_data
     from oracle import fuse_oracle as fo
     from oracle import reg_oracle as ro
@@ -167,32 +170,48 @@ def cpu_baseline(args, grid, tile, overlap):
         ro.phase_correlation_registration(a, b)
         t_pairs.append(time.perf_counter() - t0)
     t_reg = 4.0 * float(np.sum(t_pairs))            # 12 face pairs in a 2x2x2 grid, 4 per orientation
+    # one pair at the north-star crop size: tiles binned by the reference's heuristic, overlap along the last axis
+    bins = ro.get_optimal_registration_binning(tile, tile, np.ones(3), np.ones(3))
+    bt = np.array([int(n) // int(bins[d]) for n, d in zip(tile, "zyx")])
+    bo = np.array([int(o) // int(bins[d]) for o, d in zip(overlap, "zyx")])
+    a, b = ro.make_pair_for_bench(bt, bo, seed=9)
+    t0 = time.perf_counter()
+    ro.phase_correlation_registration(a, b)
+    t_ns_pair = time.perf_counter() - t0
     out = {"value": vox / (t_reg + t_fuse) / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port",
            "sample": f"oracle (numpy + scipy 1.15: the reference's own affine_transform / fft / uniform_filter / spearmanr calls), "
                      f"1 thread, on a 2x2x2 mosaic of uint16 tiles {ts.tolist()}, overlap {ov.tolist()}: fuse of the whole "
                      f"{int(vox)}-voxel mosaic {t_fuse:.1f} s + 12 pair registrations {t_reg:.1f} s (3 timed, one per axis "
                      f"orientation, {np.round(t_pairs, 2).tolist()} s, x4)",
-           "fuse_only_mvoxels_s": vox / t_fuse / 1e6, "register_pair_s": float(np.mean(t_pairs))}
+           "fuse_only_mvoxels_s": vox / t_fuse / 1e6, "register_pair_s": float(np.mean(t_pairs)),
+           "register_pair_north_star_s": t_ns_pair, "register_pair_north_star_crop": [int(v) for v in a.shape]}
     # ---- all cores: chunk / pair farm with joblib (loky processes, BLAS / pocketfft threads pinned to 1 per worker) ----
     try:
         from joblib import Parallel, delayed
 
         ncores = len(os.sched_getaffinity(0))
         shp = np.asarray(out_bb["shape"])
-        cuts = [np.linspace(0, n, 3).astype(int) for n in shp]          # 2 x 2 x 2 output chunks
+        ncut = 4
+        cuts = [np.linspace(0, n, ncut + 1).astype(int) for n in shp]          # 4 x 4 x 4 output chunks per replica
         subs = []
-        for idx in np.ndindex(2, 2, 2):
+        for idx in np.ndindex(ncut, ncut, ncut):
             lo = np.array([cuts[k][i] for k, i in enumerate(idx)])
             hi = np.array([cuts[k][i + 1] for k, i in enumerate(idx)])
             subs.append(fo.bb(out_bb["origin"] + lo * out_bb["spacing"], out_bb["spacing"], hi - lo))
-        tasks = [delayed(_cpu_fuse_task)(views, params, bbs, sb) for sb in subs]
-        tasks += [delayed(_cpu_pair_task)(*pairs[k % 3]) for k in range(12)]
+        per_replica = len(subs) + 12
+        replicas = max(1, -(-2 * ncores // per_replica))
+        tasks = []
+        for _ in range(replicas):
+            tasks += [delayed(_cpu_pair_task)(*pairs[k % 3]) for k in range(12)]      # (the long tasks first)
+        for _ in range(replicas):
+            tasks += [delayed(_cpu_fuse_task)(views, params, bbs, sb) for sb in subs]
         env = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
         for k in env:
             os.environ[k] = "1"
         try:
-            with Parallel(n_jobs=min(ncores, len(tasks)), backend="loky") as par:
-                par([delayed(_cpu_pair_task)(*(x[:8, :8, :8] for x in pairs[0]))] * min(ncores, len(tasks)))   # spawn + import the workers, untimed
+            nw = min(ncores, len(tasks))
+            with Parallel(n_jobs=nw, backend="loky") as par:
+                par([delayed(_cpu_pair_task)(*(x[:8, :8, :8] for x in pairs[0]))] * nw)   # spawn + import the workers, untimed
                 t0 = time.perf_counter()
                 par(tasks)
                 t_all = time.perf_counter() - t0
@@ -202,25 +221,47 @@ def cpu_baseline(args, grid, tile, overlap):
                     os.environ.pop(k, None)
                 else:
                     os.environ[k] = v
-        out["all_cores"] = {"value": vox / t_all / 1e6, "unit": "Mvoxels/s", "cores": ncores, "workers": min(ncores, len(tasks)),
-                            "wall_s": t_all, "sample": "the same mosaic as 8 output-chunk tasks + 12 pair tasks, joblib loky"}
+        out["all_cores"] = {"value": replicas * vox / t_all / 1e6, "unit": "Mvoxels/s", "cores": ncores, "workers": nw,
+                            "tasks": len(tasks), "replicas": replicas, "wall_s": t_all,
+                            "sample": f"{replicas} replicas of the same mosaic job, each {len(subs)} output-chunk tasks + 12 pair "
+                                      f"tasks, joblib loky, one thread per worker"}
     except Exception as e:      # noqa: BLE001 - the baseline must not take the bench line down
         out["all_cores"] = {"error": repr(e)[:200]}
     return out
 
 
+def csrc_digest():
+    """sha256 over the library's sources: ties a committed PMC measurement to the kernels it was taken with (the GPU box
+    has no .git, so the source text itself is the identity)."""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "multiview-stitcher_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "multiview-stitcher_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def fuse_traffic_bytes(grid, tile):
-    """HBM bytes per fuse launch from the committed PMC passes (FETCH_SIZE x2 per the calibration + WRITE_SIZE,
-    profiles/round2_summary.md, tools/profile_round2.sh); only valid for the workload it was measured on."""
-    for name in ("round2_fuse_traffic.json", "round1_fuse_traffic.json"):
+    """(HBM bytes per fuse launch, where the figure comes from).  The bytes are PMC counters (FETCH_SIZE x2 per the
+    calibration + WRITE_SIZE, separate rocprofv3 --pmc passes: tools/profile_round3.sh) committed under profiles/ together
+    with the digest of the kernel sources they were measured with; when the sources have changed since, or the workload is
+    another one, the figure would be stale and None is returned instead."""
+    if not (list(grid) == [4, 4, 4] and list(tile) == [512, 512, 512]):
+        return None, "no PMC pass for this workload"
+    for name in ("round3_fuse_traffic.json",):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
-            if list(grid) == [4, 4, 4] and list(tile) == [512, 512, 512]:
-                return t["hbm_bytes_per_launch"]
+            src = f"profiles/{name} (git {t.get('git_hash', '?')}, csrc digest {t.get('csrc_digest', '?')})"
+            if t.get("csrc_digest") != csrc_digest():
+                return None, src + ": kernel sources changed since (current digest " + csrc_digest() + "), figure withheld"
+            return t["hbm_bytes_per_launch"], src
         except (OSError, KeyError, ValueError):
             continue
-    return None
+    return None, "no PMC pass committed for the current kernels"
 
 
 def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
@@ -406,8 +447,9 @@ def main():
             key = key_out
         t_reg1 = time.perf_counter()
         if shard:
-            fused, _ = sharding.fuse_shard(sims, rank, world, key, output_chunksize={d: 1 << 30 for d in "zyx"},
-                                           output_on_backend=True, device=local_rank)
+            fused, box = sharding.fuse_shard(sims, rank, world, key, output_chunksize={d: 1 << 30 for d in "zyx"},
+                                             output_on_backend=True, device=local_rank)
+            out_holder["box"] = box
         else:
             fused = fusion.fuse(sims, transform_key=key, output_chunksize={d: 1 << 30 for d in "zyx"},
                                 output_on_backend=True, device=local_rank)
@@ -463,6 +505,13 @@ def main():
 
     fused = out_holder["fused"]
     out_shape = fused.shape
+    dump_dir = os.environ.get("MVS_BENCH_DUMP")
+    if dump_dir:      # (tests) every rank leaves its fused sub-box and where it sits in the mosaic
+        box = out_holder.get("box")
+        off = [int(box["index_offset"][d]) for d in "zyx"] if box is not None else [0, 0, 0]
+        np.save(os.path.join(dump_dir, f"fused_rank{rank}of{world}.npy"), np.asarray(fused.data))
+        with open(os.path.join(dump_dir, f"fused_rank{rank}of{world}.json"), "w") as f:
+            json.dump({"index_offset": off, "shape": [int(v) for v in out_shape]}, f)
     out_vox_local = float(np.prod(out_shape))
     es = 2
     # algorithmic bytes of THIS rank's fuse launch: every input voxel that reaches into its output box once + every
@@ -511,6 +560,7 @@ def main():
             pcie = pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out)
         except Exception as e:   # noqa: BLE001 - an optional leg must not take the bench line down
             pcie = {"error": repr(e)[:300]}
+    traffic, traffic_src = fuse_traffic_bytes(grid, tile) if world == 1 else (None, "N > 1")
     if rank == 0:
         result = {
             "metric": "Mvoxels/s register+fuse, 3D tile grid" if do_register else "Mvoxels/s fuse only, 3D tile grid",
@@ -556,7 +606,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": fuse_traffic_bytes(grid, tile) if world == 1 else None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes,
             },
             "roofline_register": None if not (do_register and reg_pairs) else {

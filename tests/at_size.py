@@ -1,0 +1,147 @@
+"""Oracle checks on SAMPLES of full-size runs (BASELINE.json sizes).
+
+The reference's fusion is chunk-local (fusion/_core.py:1513-1733 takes slabs), and its pairwise registration works on
+the overlap crops of one pair (registration.py:353-565): after a full-size run on the GPU, a handful of output boxes
+and pairs is handed -- with exactly the slabs / crops the run used -- to the CPU oracle and compared at north_star's
+bar.  The oracle tasks are farmed over the host cores with joblib (the box has far more cores than samples).
+"""
+import numpy as np
+
+from oracle import fuse_oracle as fo
+from oracle import reg_oracle as ro
+from tests.helpers import fused_close_stats, reference_noise_floor
+
+
+def _geom(sim, key):
+    from multiview_stitcher_amd import param_utils
+    from multiview_stitcher_amd import spatial_image_utils as si
+
+    sdims = si.get_spatial_dims_from_sim(sim)
+    o = si.get_origin_from_sim(sim, asarray=True).astype(np.float64)
+    s = si.get_spacing_from_sim(sim, asarray=True).astype(np.float64)
+    shape = np.array([int(sim.sizes[d]) for d in sdims])
+    p = np.asarray(param_utils.select_time(si.get_affine_from_sim(sim, key), 0), dtype=np.float64)
+    return sdims, o, s, shape, p
+
+
+def slab_window(sim, key, box_origin, box_spacing, box_shape, margin=2):
+    """Index window [lo, hi) of ``sim`` holding every tap of an order-1 resample onto the world box, or None."""
+    sdims, o, s, shape, p = _geom(sim, key)
+    nd = len(o)
+    corners = np.array(list(np.ndindex(*([2] * nd))), dtype=np.float64) * (np.asarray(box_shape) - 1) * box_spacing + box_origin
+    pinv = np.linalg.inv(p)
+    idx = ((corners @ pinv[:nd, :nd].T + pinv[:nd, nd]) - o) / s
+    lo = np.maximum(np.floor(idx.min(0)).astype(int) - margin, 0)
+    hi = np.minimum(np.ceil(idx.max(0)).astype(int) + margin + 1, shape)
+    if np.any(hi <= lo):
+        return None
+    return lo, hi
+
+
+def fetch(data, lo, hi):
+    """Host copy of the window of a numpy / DeviceArray / Zarr-backed array (spatial axes last)."""
+    lead = (0,) * (len(data.shape) - len(lo))
+    return np.ascontiguousarray(np.asarray(data[lead + tuple(slice(int(a), int(b)) for a, b in zip(lo, hi))]))
+
+
+def fuse_box_task(sims, key, out_origin, out_spacing, lo, shape, halo=0, **oracle_kw):
+    """Arguments of one oracle fuse of the output box [lo, lo + shape) (mosaic index units) + ``halo`` px."""
+    nd = len(lo)
+    lo, shape = np.asarray(lo), np.asarray(shape)
+    box_o = np.asarray(out_origin, dtype=np.float64) + (lo - halo) * np.asarray(out_spacing, dtype=np.float64)
+    box_n = shape + 2 * halo
+    views, params, fvbs = [], [], []
+    for sim in sims:
+        sdims, o, s, n, p = _geom(sim, key)
+        win = slab_window(sim, key, box_o, np.asarray(out_spacing, dtype=np.float64), box_n)
+        if win is None:
+            continue
+        wlo, whi = win
+        views.append({"data": fetch(sim.data, wlo, whi), "origin": o + wlo * s, "spacing": s})
+        params.append(p)
+        fvbs.append(fo.bb(o, s, n))
+    out_bb = fo.bb(box_o, out_spacing, box_n)
+    return dict(views=views, params=params, out_bb=out_bb, fvbs=fvbs, halo=int(halo), kw=oracle_kw, nd=nd)
+
+
+def run_fuse_task(task):
+    """(worker) oracle fuse of one box: the reference's result, its float32 form and its own rounding-noise floor."""
+    if not task["views"]:
+        return None
+    want, want_f, dbg = fo.fuse_np(task["views"], task["params"], task["out_bb"], full_view_bbs=task["fvbs"],
+                                   trim_overlap_in_pixels=task["halo"], return_debug=True, **task["kw"])
+    floor = reference_noise_floor(dbg, want_f) if task["kw"].get("weights") is None else None
+    return want, want_f, floor
+
+
+def run_pair_task(task):
+    """(worker) oracle registration of one pair of crops."""
+    res = ro.phase_correlation_registration(task["fixed"], task["moving"])
+    return {"affine_matrix": np.asarray(res["affine_matrix"]), "quality": float(res["quality"])}
+
+
+def farm(func, tasks, n_jobs=None):
+    """Run the oracle tasks on the host cores (joblib / loky, one BLAS thread per worker)."""
+    import os
+
+    if not tasks:
+        return []
+    try:
+        from joblib import Parallel, delayed
+    except ImportError:   # pragma: no cover
+        return [func(t) for t in tasks]
+    n = min(len(tasks), n_jobs or len(os.sched_getaffinity(0)))
+    if n <= 1:
+        return [func(t) for t in tasks]
+    return Parallel(n_jobs=n, backend="loky")(delayed(func)(t) for t in tasks)
+
+
+def check_boxes(fused_data, tasks, los, shapes, rtol=1e-4, int_boundary_rtol=1e-4):
+    """Compare the windows of the fused mosaic with the farmed oracle results; returns the aggregate statistics of
+    ``tests.helpers.fused_close_stats`` (how many voxels needed the reference's noise floor, and how large it got)."""
+    results = farm(run_fuse_task, tasks)
+    agg = {"voxels": 0, "beyond_plain_bar": 0, "max_floor_used": 0.0, "lsb_flips": 0, "boxes": 0}
+    for res, lo, shape in zip(results, los, shapes):
+        got = fetch(fused_data, lo, np.asarray(lo) + np.asarray(shape))
+        if res is None:
+            assert not got.any(), "box without contributing views must be zero"
+            continue
+        want, want_f, floor = res
+        st = fused_close_stats(got, want, want_f, rtol=rtol, noise_floor=floor, int_boundary_rtol=int_boundary_rtol)
+        agg["voxels"] += st["voxels"]
+        agg["beyond_plain_bar"] += st["beyond_plain_bar"]
+        agg["lsb_flips"] += st["lsb_flips"]
+        agg["max_floor_used"] = max(agg["max_floor_used"], st["max_floor_used"])
+        agg["boxes"] += 1
+    return agg
+
+
+class CapturePairs:
+    """``pairwise_reg_func`` that runs the device registration and keeps the crops of the pairs it sees, so that the very
+    same crops (binned, resampled onto the fixed grid, NaN outside: registration.py:280-350) can go to the oracle."""
+
+    def __init__(self, keep=6):
+        import threading
+
+        self.keep, self.records, self._lock = keep, [], threading.Lock()
+
+    def __call__(self, fixed_data, moving_data, device=0, **kw):
+        from multiview_stitcher_amd import registration
+
+        got = registration.phase_correlation_registration(fixed_data, moving_data, device=device, **kw)
+        with self._lock:
+            shape = tuple(np.asarray(fixed_data.data.shape if hasattr(fixed_data, "data") else fixed_data.shape))
+            orient = int(np.argmin(shape))
+            if sum(1 for r in self.records if r["orient"] == orient) < max(1, self.keep // 3) and not isinstance(got, list):
+                a = np.asarray(fixed_data.data if hasattr(fixed_data, "data") else fixed_data)
+                b = np.asarray(moving_data.data if hasattr(moving_data, "data") else moving_data)
+                self.records.append({"orient": orient, "fixed": a, "moving": b, "got": {
+                    "affine_matrix": np.asarray(got["affine_matrix"]).copy(), "quality": float(got["quality"])}})
+        return got
+
+    def check(self, quality_atol=1e-5):
+        wants = farm(run_pair_task, [{"fixed": r["fixed"], "moving": r["moving"]} for r in self.records])
+        for r, w in zip(self.records, wants):
+            assert np.array_equal(r["got"]["affine_matrix"], w["affine_matrix"]), (r["got"], w)      # selected shift: bit-exact
+            assert abs(r["got"]["quality"] - w["quality"]) <= quality_atol, (r["got"]["quality"], w["quality"])
+        return len(wants)

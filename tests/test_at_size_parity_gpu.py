@@ -1,0 +1,381 @@
+"""Oracle parity AT BASELINE.json SIZES (north star, C2, C3, C4, C5): the runs are full size on the GPU, the oracle checks
+SAMPLES of them -- output boxes of 64^3 (interior, seams, mosaic corner, edges and corners of the tile grid) recomputed by
+``oracle.fuse_oracle.fuse_np`` from exactly the slabs the run used, and one pair per orientation recomputed by
+``oracle.reg_oracle.phase_correlation_registration`` from exactly the (binned, resampled) crops ``register()`` makes.
+Bars: selected shift bit-exact, quality 1e-5, float32 fused voxels 1e-4 relative, integer voxels +-1 LSB only at truncation
+boundaries -- and the number of voxels that need the reference's own rounding-noise floor (tests/helpers.py) is asserted.
+
+The tiles of a mosaic are cut from one ground truth, so for the FUSE checks every tile gets its own intensity offset first:
+otherwise every weighted mean is a mean of identical values and the blend weights would not be exercised."""
+import numpy as np
+import pytest
+
+try:   # torch brings its own HIP runtime: load it before libmvs_hip.so pulls in the system one (as in bench.py)
+    import torch
+except ImportError:   # pragma: no cover
+    torch = None
+
+from tests import at_size
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_torch():
+    if torch is None or not torch.cuda.is_available():
+        pytest.skip("needs torch on the GPU for the on-device mosaic")
+
+
+def _offset_tiles(tiles, step=500, period=8):
+    """tile i += step * (i % period) (uint16 tensors viewed as int16; values stay below 2^15)."""
+    for i, t in enumerate(tiles):
+        t.view(torch.int16).add_(int(step * (i % period)))
+    torch.cuda.synchronize()
+
+
+def _grid_boxes(grid, tile, overlap, out_shape, n=64):
+    grid, tile, overlap, out_shape = (np.asarray(v) for v in (grid, tile, overlap, out_shape))
+    step = tile - overlap
+    seam = step + overlap // 2 - n // 2            # centred on the first overlap zone of an axis
+    mid = tile // 2 - n // 2                       # interior of tile 0 along an axis
+    boxes = [
+        mid,                                       # one view
+        np.array([mid[0], mid[1], seam[2]]),       # x seam (2 views)
+        np.array([mid[0], seam[1], mid[2]]),       # y seam
+        np.array([seam[0], mid[1], mid[2]]),       # z seam
+        np.array([mid[0], seam[1], seam[2]]),      # edge of the tile grid (4 views)
+        seam.copy(),                               # corner of the tile grid (8 views)
+        np.zeros(3, int),                          # low corner of the mosaic (rim)
+        out_shape - n,                             # high corner of the mosaic
+        np.array([256 - n // 2, 256 - n // 2, step[2] - n // 2]),   # across chunk borders and the start of an x ramp
+        np.array([step[0] - 8, mid[1], step[2] + overlap[2] - n + 8]),   # both ends of ramps
+    ]
+    ok = [np.minimum(np.maximum(b, 0), out_shape - n) for b in boxes if np.all(out_shape >= n)]
+    return [b.astype(int) for b in ok]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def test_north_star_sampled_oracle_parity(hip_device):
+    """4 x 4 x 4 grid of 512^3 uint16: register() with the reference's default pruning, three pairs re-registered through
+    the generic pairwise path with their crops captured for the oracle, then the whole mosaic fused and 10 boxes checked."""
+    _need_torch()
+    import bench
+    from multiview_stitcher_amd import _lib, fusion, param_utils, registration
+    from multiview_stitcher_amd import spatial_image_utils as si
+
+    dev = torch.device("cuda", 0)
+    grid, tile = np.array([4, 4, 4]), np.array([512, 512, 512])
+    overlap = np.round(tile * 0.2).astype(int)
+    tiles, jitters, origins = bench.make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=2024)
+    sims = bench.build_sims(tiles, origins, 0)
+    torch.cuda.synchronize()
+    key = si.DEFAULT_TRANSFORM_KEY
+
+    registration.register(sims, transform_key=key, new_transform_key="reg", device=0)      # default: alternating_pattern
+    rec = np.array([param_utils.select_time(si.get_affine_from_sim(s, "reg"), 0)[:3, 3] for s in sims])
+    np.testing.assert_allclose(rec - rec[0], jitters - jitters[0], atol=1e-6)
+
+    # one pair per orientation: lean default path == generic path (crops captured) == oracle on those crops
+    cap = at_size.CapturePairs(keep=3)
+    for i, j in [(0, 1), (0, 4), (0, 16), (21, 22), (21, 25), (21, 37)]:
+        lean = registration.register_pair_of_msims(sims[i], sims[j], key, device=0)
+        gen = registration.register_pair_of_msims(sims[i], sims[j], key, device=0, pairwise_reg_func=cap)
+        assert np.array_equal(np.asarray(lean["transform"]), np.asarray(gen["transform"]))
+        assert abs(lean["quality"] - gen["quality"]) <= 1e-9
+    assert len(cap.records) == 3 and {r["orient"] for r in cap.records} == {0, 1, 2}
+    assert min(r["fixed"].size for r in cap.records) > 3_000_000       # binned 51 x 256 x 256 crops
+    assert cap.check() == 3
+
+    # fuse: per-tile intensity offsets make the weights matter
+    _offset_tiles(tiles)
+    fused = fusion.fuse(sims, transform_key="reg", output_chunksize={d: 1 << 30 for d in "zyx"}, output_on_backend=True, device=0)
+    _lib.synchronize(0)
+    fo_, fs_ = si.get_origin_from_sim(fused, asarray=True), si.get_spacing_from_sim(fused, asarray=True)
+    los = _grid_boxes(grid, tile, overlap, fused.shape)
+    tasks = [at_size.fuse_box_task(sims, "reg", fo_, fs_, lo, (64, 64, 64)) for lo in los]
+    assert max(len(t["views"]) for t in tasks) == 8
+    st = at_size.check_boxes(fused.data, tasks, los, [(64,) * 3] * len(los))
+    assert st["boxes"] == len(los) >= 8
+    # how often the reference's own rounding noise had to be invoked: never on the registered (integer-offset) mosaic
+    assert st["beyond_plain_bar"] <= 1e-3 * st["voxels"], st
+
+    # the API's default chunking (256^3 chunks merged into launch blocks) gives the same mosaic
+    fused_d = fusion.fuse(sims, transform_key="reg", output_on_backend=True, device=0)
+    _lib.synchronize(0)
+    for lo in los[:4]:
+        np.testing.assert_array_equal(at_size.fetch(fused_d.data, lo, lo + 64), at_size.fetch(fused.data, lo, lo + 64))
+
+
+def test_north_star_fractional_offsets_sampled_oracle_parity(hip_device):
+    """The same grid with sub-pixel stage offsets (a sub-pixel-registered mosaic): 2 x 2 x 2 taps per view, float64
+    coordinates like scipy at 1748 voxels per axis.  2 x 4 x 4 tiles keep the run short; the x / y extent is full size."""
+    _need_torch()
+    import bench
+    from multiview_stitcher_amd import _lib, fusion
+    from multiview_stitcher_amd import spatial_image_utils as si
+
+    dev = torch.device("cuda", 0)
+    grid, tile = np.array([2, 4, 4]), np.array([512, 512, 512])
+    overlap = np.round(tile * 0.2).astype(int)
+    tiles, jitters, origins = bench.make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=7, max_jitter=0)
+    rng = np.random.default_rng(3)
+    origins = origins + rng.uniform(-1.5, 1.5, origins.shape)
+    sims = bench.build_sims(tiles, origins, 0)
+    _offset_tiles(tiles)
+    key = si.DEFAULT_TRANSFORM_KEY
+    fused = fusion.fuse(sims, transform_key=key, output_on_backend=True, device=0)       # default chunking, merged blocks
+    _lib.synchronize(0)
+    fo_, fs_ = si.get_origin_from_sim(fused, asarray=True), si.get_spacing_from_sim(fused, asarray=True)
+    los = _grid_boxes(grid, tile, overlap, fused.shape)
+    tasks = [at_size.fuse_box_task(sims, key, fo_, fs_, lo, (64, 64, 64)) for lo in los]
+    st = at_size.check_boxes(fused.data, tasks, los, [(64,) * 3] * len(los))
+    assert st["boxes"] >= 8
+    assert st["beyond_plain_bar"] <= 1e-3 * st["voxels"], st
+    # merged launch blocks == chunk by chunk, voxel for voxel (block-relative coordinates carry the fraction exactly)
+    fused_c = fusion.fuse(sims, transform_key=key, output_on_backend=True, device=0, merge_chunks=False)
+    _lib.synchronize(0)
+    a = torch.as_tensor(bench._SignedView(fused.data), device="cuda")
+    b = torch.as_tensor(bench._SignedView(fused_c.data), device="cuda")
+    assert bool((a == b).all())
+
+
+def test_c2_sampled_oracle_parity(hip_device):
+    """C2: 3 x 3 grid of 2D 2048^2 float32 tiles: register (12 pairs; two captured for the oracle), cosine-blend fuse in
+    2048^2 chunks, 512^2 boxes against the oracle at 1e-4 relative."""
+    _need_torch()
+    from multiview_stitcher_amd import _lib, fusion, param_utils, registration
+    from multiview_stitcher_amd import spatial_image_utils as si
+    from multiview_stitcher_amd.device import DeviceArray
+    from tests.test_full_size_gpu import _mosaic_2d_f32
+
+    dev = torch.device("cuda", 0)
+    tiles, jitters, origins, gt, pad = _mosaic_2d_f32(torch, dev, (3, 3), (2048, 2048), (410, 410), seed=78)
+    torch.cuda.synchronize()
+    sims = []
+    for t, o in zip(tiles, origins):
+        da = DeviceArray.from_pointer(t.data_ptr(), tuple(t.shape), np.float32, 0, owner=t)
+        s = si.to_spatial_image(da, dims=["y", "x"], scale={"y": 1.0, "x": 1.0}, translation=dict(zip("yx", o)))
+        si.set_sim_affine(s, np.eye(3), si.DEFAULT_TRANSFORM_KEY)
+        sims.append(s)
+    key = si.DEFAULT_TRANSFORM_KEY
+    cap = at_size.CapturePairs(keep=6)
+    registration.register(sims, transform_key=key, new_transform_key="reg", device=0, pairwise_reg_func=cap)
+    rec = np.array([param_utils.select_time(si.get_affine_from_sim(s, "reg"), 0)[:2, 2] for s in sims])
+    np.testing.assert_allclose(rec - rec[0], jitters - jitters[0], atol=1e-6)
+    assert {r["orient"] for r in cap.records} == {0, 1} and cap.check() >= 2
+    for i, t in enumerate(tiles):
+        t.mul_(1.0 + 0.25 * (i % 4)).add_(0.1 * (i % 3))
+    torch.cuda.synchronize()
+    fused = fusion.fuse(sims, transform_key="reg", output_chunksize={"y": 2048, "x": 2048}, output_on_backend=True, device=0)
+    _lib.synchronize(0)
+    fo_, fs_ = si.get_origin_from_sim(fused, asarray=True), si.get_spacing_from_sim(fused, asarray=True)
+    n, step = 512, 2048 - 410
+    los = [np.array(v) for v in [(700, 700), (700, step - 50), (step - 50, 700), (step - 100, step - 100), (0, 0),
+                                 (fused.shape[0] - n, fused.shape[1] - n), (2048 - 256, 2048 - 256), (2 * step - 30, step + 300)]]
+    tasks = [at_size.fuse_box_task(sims, "reg", fo_, fs_, lo, (n, n)) for lo in los]
+    st = at_size.check_boxes(fused.data, tasks, los, [(n, n)] * len(los))
+    assert st["boxes"] == 8 and st["beyond_plain_bar"] <= 1e-3 * st["voxels"], st
+
+
+def test_c3_register_and_content_based_sampled_oracle_parity(hip_device):
+    """C3: 4 x 4 x 2 (x, y, z) grid of 256 x 512 x 512 uint16: register() at size (auto-binning {z: 2}; three pairs against
+    the oracle), then content-based weights (sigma 5 / 11, halo 22) in 256^3 chunks.  The reference filters every halo
+    chunk with ``mode="reflect"``, so a sampled box is recomputed by the oracle on a crop of ITS halo chunk: crop borders
+    that coincide with the halo chunk's borders reproduce the reflection, artificial ones lie >= 64 px (the support of
+    the two chained Gaussians, 20 + 44) away from the compared box."""
+    _need_torch()
+    import bench
+    from multiview_stitcher_amd import _lib, fusion, param_utils, registration
+    from multiview_stitcher_amd import spatial_image_utils as si
+
+    dev = torch.device("cuda", 0)
+    grid, tile = np.array([2, 4, 4]), np.array([256, 512, 512])
+    overlap = np.round(tile * 0.2).astype(int)
+    tiles, jitters, origins = bench.make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=31)
+    sims = bench.build_sims(tiles, origins, 0)
+    torch.cuda.synchronize()
+    key = si.DEFAULT_TRANSFORM_KEY
+    registration.register(sims, transform_key=key, new_transform_key="reg", device=0)
+    rec = np.array([param_utils.select_time(si.get_affine_from_sim(s, "reg"), 0)[:3, 3] for s in sims])
+    np.testing.assert_allclose(rec - rec[0], jitters - jitters[0], atol=1e-6)
+    cap = at_size.CapturePairs(keep=3)
+    for i, j in [(0, 1), (0, 4), (0, 16)]:
+        lean = registration.register_pair_of_msims(sims[i], sims[j], key, device=0)
+        gen = registration.register_pair_of_msims(sims[i], sims[j], key, device=0, pairwise_reg_func=cap)
+        assert np.array_equal(np.asarray(lean["transform"]), np.asarray(gen["transform"]))
+    assert len(cap.records) == 3 and cap.check() == 3
+
+    _offset_tiles(tiles, step=300)
+    halo, cs = 22, 256
+    fused = fusion.fuse(sims, transform_key="reg", weights_func=fusion.content_based, output_chunksize={d: cs for d in "zyx"},
+                        output_on_backend=True, device=0)
+    _lib.synchronize(0)
+    fo_, fs_ = si.get_origin_from_sim(fused, asarray=True), si.get_spacing_from_sim(fused, asarray=True)
+    shape = np.array(fused.shape)
+    n, reach = 64, 64
+    # (chunk index, box offset inside the chunk): chunk corners (reflection at the halo border) and interiors, on seams
+    samples = [((0, 1, 1), (0, 0, 0)), ((0, 1, 1), (96, 150, 150)), ((1, 1, 1), (0, 192, 0)), ((0, 0, 0), (30, 30, 30)),
+               ((1, 3, 3), (96, 96, 96)), ((0, 2, 1), (192, 96, 140)), ((0, 1, 5), (100, 150, 10)), ((1, 4, 1), (140, 10, 150))]
+    tasks, los, cmps = [], [], []
+    for cidx, off in samples:
+        c0 = np.array(cidx) * cs
+        cn = np.minimum(c0 + cs, shape) - c0                      # chunk extent (the last chunk of an axis is partial)
+        off = np.minimum(np.array(off), np.maximum(cn - n, 0))
+        bn = np.minimum(n, cn)
+        # halo chunk H = [c0 - halo, c0 + cn + halo); crop = box +- reach, snapped to H's borders when closer than reach
+        h0, h1 = c0 - halo, c0 + cn + halo
+        b0, b1 = c0 + off, c0 + off + bn
+        k0 = np.where(b0 - reach <= h0 + 8, h0, b0 - reach)
+        k1 = np.where(b1 + reach >= h1 - 8, h1, b1 + reach)
+        task = at_size.fuse_box_task(sims, "reg", fo_, fs_, k0, k1 - k0, halo=0, weights="content_based",
+                                     weights_kwargs={"sigma_1": 5, "sigma_2": 11})
+        tasks.append(task)
+        los.append(b0)
+        cmps.append((b0 - k0, bn))
+    results = at_size.farm(at_size.run_fuse_task, tasks)
+    flips = vox = 0
+    for res, lo, (rel, bn) in zip(results, los, cmps):
+        want, want_f, _ = res
+        sl = tuple(slice(int(a), int(a + m)) for a, m in zip(rel, bn))
+        got = at_size.fetch(fused.data, lo, lo + bn)
+        from tests.helpers import fused_close_stats
+        st = fused_close_stats(got, want[sl], want_f[sl])     # +-1 LSB only within 1e-4 of an integer boundary
+        flips += st["lsb_flips"]
+        vox += st["voxels"]
+    assert vox >= 8 * 64 ** 3 // 2 and flips <= 0.02 * vox
+
+
+def test_c4_sampled_oracle_parity(hip_device):
+    """C4: two 512^3 uint16 views, the second under a full affine (90 degrees about x, 2 degree tilt, +-1 % scale,
+    sub-pixel shift, z spacing 2): weighted-average fuse of the union stack through the generic kernel, 64^3 boxes."""
+    _need_torch()
+    from multiview_stitcher_amd import _lib, fusion
+    from multiview_stitcher_amd import spatial_image_utils as si
+    from multiview_stitcher_amd.device import DeviceArray
+
+    dev = torch.device("cuda", 0)
+    n = 512
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    sims, keep = [], []
+    for v in range(2):
+        noise = torch.rand((1, 1, n, n, n), generator=g, device=dev)
+        noise = torch.nn.functional.avg_pool3d(noise, 3, stride=1, padding=1, count_include_pad=False)[0, 0]
+        t = (noise * 4095 + 600 * v).to(torch.int32).to(torch.uint16).contiguous()
+        keep.append(t)
+        da = DeviceArray.from_pointer(t.data_ptr(), (n, n, n), np.uint16, 0, owner=t)
+        sim = si.to_spatial_image(da, dims=["z", "y", "x"], scale={"z": 2.0 if v else 1.0, "y": 1.0, "x": 1.0},
+                                  translation={"z": 0.0, "y": 0.0, "x": 0.0})
+        A = np.eye(4)
+        if v:
+            c, s = np.cos(np.pi / 2), np.sin(np.pi / 2)
+            Rx = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+            a = np.deg2rad(2.0)
+            Rz = np.array([[1.0, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+            A[:3, :3] = Rx @ Rz @ np.diag([1.01, 0.99, 1.0])
+            ctr = np.array([255.5 * 2, 255.5, 255.5])
+            A[:3, 3] = np.array([255.5, 255.5, 255.5]) - A[:3, :3] @ ctr + np.array([3.3, -2.1, 4.7])
+        si.set_sim_affine(sim, A, "k")
+        sims.append(sim)
+    torch.cuda.synchronize()
+    fused = fusion.fuse(sims, transform_key="k", output_on_backend=True, device=0)
+    _lib.synchronize(0)
+    fo_, fs_ = si.get_origin_from_sim(fused, asarray=True), si.get_spacing_from_sim(fused, asarray=True)
+    shape = np.array(fused.shape)
+    rng = np.random.default_rng(1)
+    # world (0..511)^3 is view 0; boxes inside it, on its borders (where view 1 sticks out) and at the stack's corners
+    base = np.round(-fo_ / fs_).astype(int)            # mosaic index of world 0
+    los = [base + 224, base + np.array([0, 200, 200]), base + np.array([448, 100, 300]), base + np.array([200, 448, 0]),
+           np.zeros(3, int), shape - 64, base + np.array([-32, 224, 224]), base + np.array([224, 480, 224])]
+    los += [rng.integers(0, shape - 64) for _ in range(2)]
+    los = [np.minimum(np.maximum(lo, 0), shape - 64) for lo in los]
+    tasks = [at_size.fuse_box_task(sims, "k", fo_, fs_, lo, (64, 64, 64)) for lo in los]
+    assert max(len(t["views"]) for t in tasks) == 2
+    st = at_size.check_boxes(fused.data, tasks, los, [(64,) * 3] * len(los))
+    assert st["boxes"] >= 8 and st["beyond_plain_bar"] <= 1e-2 * st["voxels"], st
+
+
+def test_c5_full_grid_sparse_store_sampled_oracle_parity(hip_device, tmp_path):
+    """C5 at its FULL geometry: 8 x 8 x 4 (x, y, z) grid of 512 x 1024 x 1024 uint16 tiles in Zarr stores (128^3 chunks),
+    output 1742 x 6757 x 6757 = 79.5 G voxels in 256^3 chunks (5103 of them) streamed into a Zarr array.  The planner, the
+    slab windows and the chunk farm run on the whole grid; the voxel DATA is materialised only where the sampled output
+    chunks look (a chunk file that was never written reads as the fill value), which keeps the store at a few GB
+    instead of 275 GB.  Every sampled 256^3 chunk is recomputed by the oracle from the same lazily read slabs.  The
+    registration leg is checked on three real pairs of full-size tiles (auto-binning {z: 3, y: 2, x: 2})."""
+    _need_torch()
+    import bench
+    from multiview_stitcher_amd import fusion, registration, zarr_io
+    from multiview_stitcher_amd import spatial_image_utils as si
+
+    grid, tile = np.array([4, 8, 8]), np.array([512, 1024, 1024])
+    overlap = np.round(tile * 0.2).astype(int)
+    step = tile - overlap
+    key = si.DEFAULT_TRANSFORM_KEY
+    rng = np.random.default_rng(11)
+    sims, arrays, origins = [], [], []
+    for k, idx in enumerate(np.ndindex(*grid)):
+        o = (np.array(idx) * step + rng.integers(-3, 4, 3) * (k > 0)).astype(float)
+        za = zarr_io.ZarrArray.create(str(tmp_path / f"tile{k}.zarr"), tuple(tile), (128, 128, 128), np.uint16)
+        s = si.to_spatial_image(za[...], dims=["z", "y", "x"], scale={d: 1.0 for d in "zyx"}, translation=dict(zip("zyx", o)))
+        si.set_sim_affine(s, np.eye(4), key)
+        sims.append(s)
+        arrays.append(za)
+        origins.append(o)
+    origins = np.array(origins)
+    lo_w = origins.min(0)
+    out_shape = (origins.max(0) + tile - lo_w).astype(int)
+    assert tuple(out_shape) == tuple(int(v) for v in (origins.max(0) - origins.min(0) + tile))
+    cs = 256
+    nblocks = -(-out_shape // cs)
+    assert int(np.prod(nblocks)) >= 5000
+    # sampled chunks: interior, seams, a corner of the tile grid, the far corner of the mosaic (partial chunk)
+    sx = int(step[2]) // cs
+    sampled = [(1, 1, 1), (0, 1, sx), (0, sx, sx), (int(step[0]) // cs, sx, sx), (3, 13, 13),
+               tuple(int(v) for v in nblocks - 1), (2, 20, 7), (5, 9, 22)]
+    sampled = [tuple(int(min(b, nb - 1)) for b, nb in zip(s_, nblocks)) for s_ in sampled]
+    # materialise the tile data the sampled chunks read: value = hash of (tile, z, y, x) below 4096 + a per-tile offset
+    written = 0
+    for bi in sampled:
+        c0 = lo_w + np.array(bi) * cs
+        c1 = np.minimum(c0 + cs, lo_w + out_shape)
+        for k, (za, o) in enumerate(zip(arrays, origins)):
+            a = np.maximum(np.floor(c0 - o).astype(int) - 2, 0) // 128 * 128
+            b = np.minimum(-(-(np.ceil(c1 - o).astype(int) + 3) // 128) * 128, tile)
+            if np.any(b <= a):
+                continue
+            zz, yy, xx = np.meshgrid(*[np.arange(p, q, dtype=np.int64) for p, q in zip(a, b)], indexing="ij", sparse=True)
+            vals = ((zz * 7919 + yy * 104729 + xx * 1299709 + k * 15485863) % 3001 + 150 * (k % 7)).astype(np.uint16)
+            za.write(list(a), vals)
+            written += vals.nbytes
+    assert written < 12 << 30
+    out_url = str(tmp_path / "fused.zarr")
+    wanted = set(sampled)
+    fused = fusion.fuse(sims, transform_key=key, output_chunksize={d: cs for d in "zyx"}, output_zarr_url=out_url,
+                        chunk_filter=lambda bi: tuple(int(v) for v in bi) in wanted, device=0)
+    assert zarr_io.is_zarr_backed(fused.data) and tuple(fused.data.shape[-3:]) == tuple(out_shape)
+    fo_, fs_ = si.get_origin_from_sim(fused, asarray=True), si.get_spacing_from_sim(fused, asarray=True)
+    np.testing.assert_allclose(fo_, lo_w)
+    los = [np.array(bi) * cs for bi in sampled]
+    shapes = [np.minimum(lo + cs, out_shape) - lo for lo in los]
+    tasks = [at_size.fuse_box_task(sims, key, fo_, fs_, lo, shp) for lo, shp in zip(los, shapes)]
+    assert max(len(t["views"]) for t in tasks) == 8
+    st = at_size.check_boxes(fused.data, tasks, los, shapes)
+    assert st["boxes"] == len(sampled) and st["beyond_plain_bar"] <= 1e-3 * st["voxels"], st
+
+    # registration leg: one real pair of full-size tiles per orientation
+    dev = torch.device("cuda", 0)
+    cap = at_size.CapturePairs(keep=3)
+    for axis in range(3):
+        g = np.ones(3, int)
+        g[axis] = 2
+        tl, jit, org = bench.make_mosaic_on_device(torch, dev, g, tile, overlap, seed=50 + axis)
+        ps = bench.build_sims(tl, org, 0)
+        torch.cuda.synchronize()
+        assert registration.get_optimal_registration_binning(ps[0], ps[1]) == {"z": 3, "y": 2, "x": 2}
+        lean = registration.register_pair_of_msims(ps[0], ps[1], key, device=0)
+        gen = registration.register_pair_of_msims(ps[0], ps[1], key, device=0, pairwise_reg_func=cap)
+        assert np.array_equal(np.asarray(lean["transform"]), np.asarray(gen["transform"]))
+        # the pairwise translation is the hidden jitter difference of the two tiles (up to the direction convention)
+        np.testing.assert_allclose(np.abs(np.asarray(lean["transform"])[:3, 3]), np.abs(jit[1] - jit[0]), atol=1e-6)
+        del tl, ps
+        torch.cuda.empty_cache()
+    assert cap.check() == 3

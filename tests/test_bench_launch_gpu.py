@@ -1,0 +1,63 @@
+"""The driver's N > 1 launch of bench.py exercised on the one GPU of the test box: two ranks under
+``python -m torch.distributed.run`` share device 0 (gloo for the control plane, since RCCL needs one GPU per rank), ONE mosaic
+sharded over them (``--mode shard``: tile bricks + halo exchange, pairs by owner of the fixed view, output sub-boxes).
+Checked: the JSON line of the contract, the registration result, and the union of the ranks' fused sub-boxes == the
+single-rank mosaic, voxel for voxel.  (reference: registration.py:2622-2694 one task per pair, fusion/_core.py:1133-1141
+one task per block, browser/executors.py:166-194 the farm.)"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(cmd, env, timeout=900):
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_two_ranks_one_mosaic_equals_single_rank(hip_device, tmp_path):
+    common = ["--grid", "2,2,2", "--tile", "128,128,128", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pcie"]
+    d1, d2 = tmp_path / "n1", tmp_path / "n2"
+    d1.mkdir()
+    d2.mkdir()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(env, MVS_BENCH_DUMP=str(d1)))
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port()), "bench.py", "--gpus", "2"] + common,
+               dict(env, MVS_BENCH_DUMP=str(d2), MVS_BENCH_BACKEND="gloo"))
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["mode"] == "shard" and two["scaling"] == "strong"
+    for line in (one, two):
+        assert line["config"]["registration_max_abs_error_px"] < 1e-6
+        assert line["steps"] == 1 and line["warmup"] == 0 and line["unit"] == "Mvoxels/s" and line["value"] > 0
+    # both ranks registered a share of the pairs and fused a share of the mosaic
+    assert 0 < two["config"]["pairs_per_step_rank0"] < one["config"]["pairs_per_step_rank0"]
+    full = np.load(d1 / "fused_rank0of1.npy")
+    got = np.zeros_like(full)
+    covered = np.zeros(full.shape, dtype=bool)
+    for r in range(2):
+        part = np.load(d2 / f"fused_rank{r}of2.npy")
+        meta = json.load(open(d2 / f"fused_rank{r}of2.json"))
+        sl = tuple(slice(o, o + n) for o, n in zip(meta["index_offset"], part.shape))
+        assert not covered[sl].any()
+        got[sl] = part
+        covered[sl] = True
+    assert covered.all()
+    np.testing.assert_array_equal(got, full)
