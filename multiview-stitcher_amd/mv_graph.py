@@ -216,6 +216,13 @@ class Graph:
         if u != v:
             del self.adj[v][u]
 
+    def remove_node(self, n):
+        for m in list(self.adj[n]):
+            if m != n:
+                del self.adj[m][n]
+        del self.adj[n]
+        self.node_attrs.pop(n, None)
+
     def has_edge(self, u, v):
         return v in self.adj.get(u, {})
 
@@ -256,6 +263,54 @@ class Graph:
             seen |= comp
             comps.append(comp)
         return comps
+
+
+def relabel_nodes_inplace(g, mapping):
+    """``networkx.relabel_nodes(G, mapping, copy=False)`` on a ``Graph``, including the ORDER it leaves behind (node order
+    and every node's neighbour order decide the reference's tie breaks, global_optimization.py:231-246).  networkx renames
+    node by node -- add the new node at the end, re-add the old node's edges, drop the old node; when old and new labels
+    overlap the nodes are visited in reversed topological order of the mapping's digraph (generations of Kahn's
+    algorithm, nodes in order of first appearance in ``mapping.items()``), otherwise in the graph's node order."""
+    keys, vals = list(mapping.keys()), list(mapping.values())
+    if set(keys) & set(vals):
+        dnodes, succ, indeg = [], {}, {}
+        for k, v in mapping.items():
+            for n in (k, v):
+                if n not in succ:
+                    succ[n] = []
+                    indeg[n] = 0
+                    dnodes.append(n)
+            if k != v:
+                succ[k].append(v)
+                indeg[v] += 1
+        order, gen = [], [n for n in dnodes if indeg[n] == 0]
+        left = dict(indeg)
+        while gen:
+            nxt = []
+            for n in gen:
+                order.append(n)
+                for c in succ[n]:
+                    left[c] -= 1
+                    if left[c] == 0:
+                        nxt.append(c)
+            gen = nxt
+        if len(order) != len(dnodes):
+            raise ValueError("The node label sets are overlapping and no ordering can resolve the mapping. Use copy=True.")
+        visit = order[::-1]
+    else:
+        visit = [n for n in g.nodes if n in mapping]
+    for old in visit:
+        if old not in mapping or old not in g.adj:
+            continue
+        new = mapping[old]
+        g.add_node(new, **g.node_attrs.get(old, {}))
+        if new == old:
+            continue
+        new_edges = [(new, new if old == t else t, d) for t, d in g.adj[old].items()]
+        g.remove_node(old)
+        for a, b, d in new_edges:
+            g.add_edge(a, b, **d)
+    return g
 
 
 def get_faces_from_stack_props(stack_props):
@@ -496,31 +551,52 @@ def prune_graph_to_alternating_colors(g, n_colors=2, return_colors=True):
     return (gp, colors) if return_colors else gp
 
 
-def _dijkstra_paths(g, source, weight):
-    """Shortest paths from ``source`` by edge attribute ``weight``; among equal-length paths the first one found in
-    adjacency order wins (networkx's bidirectional search may pick another one -- same total weight)."""
+def _bidirectional_dijkstra_path(g, source, target, weight):
+    """The path ``networkx.shortest_path(G, source, target, weight)`` returns (the reference's call, mv_graph.py:786-791):
+    networkx answers a weighted source-target query with a bidirectional Dijkstra search -- the two fringes are advanced
+    alternately, starting with the source side; heap entries are (distance, push counter, node); whenever a relaxed node
+    has been seen from both sides the concatenated path replaces the best one if it is strictly shorter; the search stops
+    when a node settled on one side is popped settled on the other.  Among equal-length paths (every regular tile grid has
+    many) the winner therefore depends on this exact order, which is why it is restated step by step."""
     import heapq
 
-    dist, prev, done = {source: 0.0}, {}, set()
-    heap, count = [(0.0, 0, source)], 1
-    while heap:
-        d, _, v = heapq.heappop(heap)
-        if v in done:
+    if source == target:
+        return [source]
+    dists = ({}, {})
+    paths = ({source: [source]}, {target: [target]})
+    fringe = ([], [])
+    seen = ({source: 0}, {target: 0})
+    count = 0
+    heapq.heappush(fringe[0], (0, count, source))
+    count += 1
+    heapq.heappush(fringe[1], (0, count, target))
+    count += 1
+    final_dist, final_path = None, []
+    side = 1
+    while fringe[0] and fringe[1]:
+        side = 1 - side
+        dist, _, v = heapq.heappop(fringe[side])
+        if v in dists[side]:
             continue
-        done.add(v)
+        dists[side][v] = dist
+        if v in dists[1 - side]:
+            return final_path
         for w, attrs in g.adj[v].items():
-            nd = d + attrs[weight]
-            if w not in done and nd < dist.get(w, np.inf):
-                dist[w], prev[w] = nd, v
-                heapq.heappush(heap, (nd, count, w))
+            vw = dists[side][v] + attrs[weight]
+            if w in dists[side]:
+                if vw < dists[side][w]:
+                    raise ValueError("Contradictory paths found: negative weights?")
+            elif w not in seen[side] or vw < seen[side][w]:
+                seen[side][w] = vw
+                heapq.heappush(fringe[side], (vw, count, w))
                 count += 1
-    paths = {}
-    for n in dist:
-        p = [n]
-        while p[-1] != source:
-            p.append(prev[p[-1]])
-        paths[n] = p[::-1]
-    return paths
+                paths[side][w] = paths[side][v] + [w]
+                if w in seen[0] and w in seen[1]:
+                    total = seen[0][w] + seen[1][w]
+                    if not final_path or final_dist > total:
+                        final_dist = total
+                        final_path = paths[0][w] + paths[1][w][::-1][1:]
+    raise NotEnoughOverlapError(f"No path between {source} and {target}.")
 
 
 def prune_to_shortest_weighted_paths(g):
@@ -542,7 +618,8 @@ def prune_to_shortest_weighted_paths(g):
     for cc in ccs:
         totals = {n: sum(d["overlap"] for d in g.adj[n].values()) for n in g.nodes if n in cc}
         ref = max(totals, key=totals.get)
-        for n, path in _dijkstra_paths(g, ref, "overlap_inv").items():
+        for n in cc:
+            path = _bidirectional_dijkstra_path(g, ref, n, "overlap_inv")
             for a, b in zip(path[:-1], path[1:]):
                 out.add_edge(a, b, overlap=g.adj[a][b]["overlap"])
     return out

@@ -195,11 +195,12 @@ def _estimate_affine(src, dst):
 _FORCE_NUMPY = False   # tests: run the translation model through the generic numpy sweeps as well
 
 
-def _sweeps_numpy(estimate, all_nodes, edges, beads, sorted_nodes, ref, max_iter, rel_tol, new_affines):
+def _sweeps_numpy(estimate, all_nodes, edges, beads, sorted_nodes, ref, max_iter, rel_tol, new_affines, node_edges=None):
     """Inner loop of optimize_bead_subgraph (global_optimization.py:264-417) for any transform model: sweeps over the
     nodes (most connected first), each re-fitted to the current positions of the beads it shares with its neighbours."""
     hom = lambda p: np.concatenate([p, np.ones((len(p), 1))], axis=1)
-    node_edges = [[e for e in edges if n in e] for n in all_nodes]
+    if node_edges is None:
+        node_edges = [[e for e in edges if n in e] for n in all_nodes]
     node_beads = [hom(np.concatenate([beads[e][n] for e in node_edges[n]], axis=0)) if node_edges[n] else None for n in all_nodes]
     adj_nodes = [[m for e in node_edges[n] for m in e if m != n] for n in all_nodes]
     adj_beads = [[hom(beads[e][m]) for e in node_edges[n] for m in e if m != n] for n in all_nodes]
@@ -282,19 +283,34 @@ def groupwise_resolution_global_optimization(g, reference_view=None, transform="
     ref_node = reference_view if (reference_view is not None and reference_view in g.nodes) else \
         get_node_with_maximal_edge_weight_sum_from_graph(g, "quality")
 
+    from . import mv_graph
+
     nodes = list(g.nodes)
     idx = {n: i for i, n in enumerate(nodes)}
-    beads = {(idx[a], idx[b]): {idx[a]: v[a], idx[b]: v[b]} for (a, b), v in _beads_of(g).items()}
-    quality = {(idx[a], idx[b]): e["quality"] for (a, b), e in g.edges.items()}
-    all_nodes = list(range(len(nodes)))
-    # the bead graph receives its edges in the registration graph's iteration order (utils.py:50); `inserted` is its
-    # adjacency history, `edges` (recomputed after every removal) its iteration order
-    inserted = [(idx[a], idx[b]) for a, b in _nx_edge_order(nodes, list(g.edges))]
-    edges = _nx_edge_order(all_nodes, inserted)
-    ref = idx[ref_node]
-    # order of the node sweeps: descending degree centrality of the full graph (stable: node order on ties)
-    degree0 = [sum(1 for e in edges if n in e) for n in all_nodes]
-    sorted_nodes = sorted(all_nodes, key=lambda n: -degree0[n])
+    ekey = lambda a, b: (a, b) if a <= b else (b, a)
+    raw_beads = _beads_of(g)
+    beads = {ekey(idx[a], idx[b]): {idx[a]: v[a], idx[b]: v[b]} for (a, b), v in raw_beads.items()}
+    quality = {ekey(idx[a], idx[b]): e["quality"] for (a, b), e in g.edges.items()}
+    all_nodes = list(range(len(nodes)))              # list(mapping.values()) (global_optimization.py:261)
+    # The bead graph with networkx's orders: nodes in the registration graph's node order, edges added in its edge iteration
+    # order with sorted end points (utils.py:48-52), deep-copied (order preserving), then relabelled IN PLACE to 0..n-1
+    # (global_optimization.py:222-229) -- which reorders nodes and neighbour lists whenever labels and indices differ.
+    bead_graph = mv_graph.Graph(nodes)
+    for a, b in _nx_edge_order(nodes, list(g.edges)):
+        bead_graph.add_edge(*sorted((a, b)))
+    mv_graph.relabel_nodes_inplace(bead_graph, idx)
+    edges_of = lambda: [ekey(a, b) for a, b in bead_graph.edges()]
+    edges = edges_of()
+    # Quirk restated literally: the reference compares the RELABELLED node index with the ORIGINAL label of the reference
+    # view (`curr_node != ref_node`, global_optimization.py:334; ref_node is chosen before the relabelling, :126-133), so the
+    # view that keeps its transform is the one whose index equals that label -- the reference view itself only when the
+    # component's labels are 0..n-1 in order (a connected mosaic), and none at all when the label is >= n.
+    ref = ref_node if (isinstance(ref_node, (int, np.integer)) and not isinstance(ref_node, bool) and 0 <= int(ref_node) < len(nodes)) else -1
+    ref = int(ref)
+    # order of the node sweeps: descending degree centrality, stable over the relabelled graph's node order
+    node_order = list(bead_graph.nodes)
+    degree0 = {n: bead_graph.degree(n) for n in node_order}
+    sorted_nodes = sorted(node_order, key=lambda n: -degree0[n])
     new_affines = np.array([np.eye(ndim + 1) for _ in all_nodes])
     mean_res, max_res = [], []
     total_iterations = 0
@@ -302,12 +318,14 @@ def groupwise_resolution_global_optimization(g, reference_view=None, transform="
     while True:
         if not edges:
             break
+        # a node's own edges in ITS neighbour order (G.edges(n), global_optimization.py:277)
+        node_edges = [[ekey(n, m) for m in bead_graph.adj[n]] for n in all_nodes]
         if transform.lower() == "translation" and not _FORCE_NUMPY:
             edge_residuals, it_mean, it_max, n_it = _translation_sweeps_native(
                 ndim, all_nodes, edges, beads, sorted_nodes, ref, max_iter, rel_tol, new_affines)
         else:
             edge_residuals, it_mean, it_max, n_it = _sweeps_numpy(
-                estimate, all_nodes, edges, beads, sorted_nodes, ref, max_iter, rel_tol, new_affines)
+                estimate, all_nodes, edges, beads, sorted_nodes, ref, max_iter, rel_tol, new_affines, node_edges)
         mean_res += it_mean
         max_res += it_max
         total_iterations += n_it
@@ -318,7 +336,7 @@ def groupwise_resolution_global_optimization(g, reference_view=None, transform="
             with np.errstate(divide="ignore", invalid="ignore"):
                 score = [
                     (1 - float(quality[e])) ** 2 * np.sqrt(np.max(edge_residuals[e]))
-                    * np.log10(np.max([sum(1 for f in edges if n in f) for n in e]))
+                    * np.log10(np.max([bead_graph.degree(n) for n in e]))
                     for e in edges
                 ]
             order = np.argsort(score)[::-1]
@@ -338,8 +356,8 @@ def groupwise_resolution_global_optimization(g, reference_view=None, transform="
                     break
         if edge_to_remove is None:
             break
-        inserted.remove(edge_to_remove)
-        edges = _nx_edge_order(all_nodes, inserted)
+        bead_graph.remove_edge(*edge_to_remove)
+        edges = edges_of()
     params = {nodes[n]: (new_affines[n] if total_iterations else np.eye(ndim + 1)) for n in all_nodes}
     info = {
         "metrics": {"mean_residual": list(mean_res), "max_residual": list(max_res), "iteration": list(range(len(mean_res)))},

@@ -96,17 +96,43 @@ def farm(func, tasks, n_jobs=None):
     return Parallel(n_jobs=n, backend="loky")(delayed(func)(t) for t in tasks)
 
 
+def _marginal(task, index):
+    """Is output voxel ``index`` of the task's box numerically ON a border of one of its views?  scipy decides in-bounds by
+    ``c < 0 or c > n - 1`` on a double coordinate derived from the slab's origin (transformation.py:72-83,
+    ni_interpolation.c); a voxel whose exact coordinate IS 0 or n - 1 (the corner of a view that defines the corner of the
+    union stack) lands inside or outside depending on the last bit of that derivation, i.e. on which slab was cut."""
+    bb_ = task["out_bb"]
+    world = bb_["origin"] + (np.asarray(index) + task["halo"]) * bb_["spacing"]
+    nd = len(world)
+    for p, fvb in zip(task["params"], task["fvbs"]):
+        pinv = np.linalg.inv(p)
+        pix = ((pinv[:nd, :nd] @ world + pinv[:nd, nd]) - fvb["origin"]) / fvb["spacing"]
+        on = (np.abs(pix) < 1e-6) | (np.abs(pix - (fvb["shape"] - 1)) < 1e-6)
+        inside = np.all((pix > -1e-6) & (pix < fvb["shape"] - 1 + 1e-6))
+        if inside and on.any():
+            return True
+    return False
+
+
 def check_boxes(fused_data, tasks, los, shapes, rtol=1e-4, int_boundary_rtol=1e-4):
     """Compare the windows of the fused mosaic with the farmed oracle results; returns the aggregate statistics of
-    ``tests.helpers.fused_close_stats`` (how many voxels needed the reference's noise floor, and how large it got)."""
+    ``tests.helpers.fused_close_stats`` (how many voxels needed the reference's noise floor, and how large it got) plus
+    ``marginal_voxels``: voxels exactly on a view border (see ``_marginal``), taken out of the comparison."""
     results = farm(run_fuse_task, tasks)
-    agg = {"voxels": 0, "beyond_plain_bar": 0, "max_floor_used": 0.0, "lsb_flips": 0, "boxes": 0}
-    for res, lo, shape in zip(results, los, shapes):
+    agg = {"voxels": 0, "beyond_plain_bar": 0, "max_floor_used": 0.0, "lsb_flips": 0, "boxes": 0, "marginal_voxels": 0}
+    for task, res, lo, shape in zip(tasks, results, los, shapes):
         got = fetch(fused_data, lo, np.asarray(lo) + np.asarray(shape))
         if res is None:
             assert not got.any(), "box without contributing views must be zero"
             continue
         want, want_f, floor = res
+        if np.issubdtype(got.dtype, np.integer):
+            far = np.argwhere(np.abs(got.astype(np.int64) - want.astype(np.int64)) > 1)
+            assert len(far) <= 64, f"{len(far)} voxels differ by more than one count"
+            for idx in far:
+                assert _marginal(task, idx), (lo, idx, got[tuple(idx)], want[tuple(idx)])
+                got[tuple(idx)] = want[tuple(idx)]
+                agg["marginal_voxels"] += 1
         st = fused_close_stats(got, want, want_f, rtol=rtol, noise_floor=floor, int_boundary_rtol=int_boundary_rtol)
         agg["voxels"] += st["voxels"]
         agg["beyond_plain_bar"] += st["beyond_plain_bar"]

@@ -130,12 +130,17 @@ def test_north_star_fractional_offsets_sampled_oracle_parity(hip_device):
     st = at_size.check_boxes(fused.data, tasks, los, [(64,) * 3] * len(los))
     assert st["boxes"] >= 8
     assert st["beyond_plain_bar"] <= 1e-3 * st["voxels"], st
-    # merged launch blocks == chunk by chunk, voxel for voxel (block-relative coordinates carry the fraction exactly)
+    # merged launch blocks vs chunk by chunk: the reference derives the pixel offsets of the image AND of the blend-weight
+    # support grid per chunk and rounds them to 10 decimals (transformation.py:72-83; the support grid's unit is a quarter
+    # tile, so its rounding is worth ~1e-8 px), i.e. two chunkings of the reference differ by that much in the weights.
+    # The same holds here: a float32 weight flips its last bit now and then and a truncated output lands on the other
+    # side of an integer in ~1e-5 of the voxels (measured 1.4e-5).  Bound: one count, < 1e-4 of the voxels.
     fused_c = fusion.fuse(sims, transform_key=key, output_on_backend=True, device=0, merge_chunks=False)
     _lib.synchronize(0)
-    a = torch.as_tensor(bench._SignedView(fused.data), device="cuda")
-    b = torch.as_tensor(bench._SignedView(fused_c.data), device="cuda")
-    assert bool((a == b).all())
+    a = torch.as_tensor(bench._SignedView(fused.data), device="cuda").to(torch.int32)
+    b = torch.as_tensor(bench._SignedView(fused_c.data), device="cuda").to(torch.int32)
+    d = (a - b).abs()
+    assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 1e-4
 
 
 def test_c2_sampled_oracle_parity(hip_device):
@@ -292,6 +297,7 @@ def test_c4_sampled_oracle_parity(hip_device):
     assert max(len(t["views"]) for t in tasks) == 2
     st = at_size.check_boxes(fused.data, tasks, los, [(64,) * 3] * len(los))
     assert st["boxes"] >= 8 and st["beyond_plain_bar"] <= 1e-2 * st["voxels"], st
+    assert st["marginal_voxels"] <= 8, st
 
 
 def test_c5_full_grid_sparse_store_sampled_oracle_parity(hip_device, tmp_path):
@@ -374,8 +380,10 @@ def test_c5_full_grid_sparse_store_sampled_oracle_parity(hip_device, tmp_path):
         lean = registration.register_pair_of_msims(ps[0], ps[1], key, device=0)
         gen = registration.register_pair_of_msims(ps[0], ps[1], key, device=0, pairwise_reg_func=cap)
         assert np.array_equal(np.asarray(lean["transform"]), np.asarray(gen["transform"]))
-        # the pairwise translation is the hidden jitter difference of the two tiles (up to the direction convention)
-        np.testing.assert_allclose(np.abs(np.asarray(lean["transform"])[:3, 3]), np.abs(jit[1] - jit[0]), atol=1e-6)
+        # the pairwise translation is the hidden jitter difference of the two tiles (up to the direction convention), as
+        # far as the binned grid resolves it: multiples of bin / 2 (upsample factor 2 in 3D, registration.py:410-411)
+        got_t, true_t = np.abs(np.asarray(lean["transform"])[:3, 3]), np.abs(jit[1] - jit[0])
+        assert np.all(np.abs(got_t - true_t) <= np.array([3, 2, 2]) / 2 + 1e-6), (got_t, true_t)
         del tl, ps
         torch.cuda.empty_cache()
     assert cap.check() == 3
