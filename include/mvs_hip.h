@@ -127,6 +127,10 @@ double mvs_last_kernel_ms(int device);
  * stream is still queued -- which is safe because all work of this library is ordered on that stream. */
 int mvs_malloc(int device, uint64_t nbytes, void** dev_ptr);
 int mvs_free(int device, void* dev_ptr);
+/* Free / total device memory of the GPU behind `device` (hipMemGetInfo + what the allocation cache of this context would
+ * give back).  Used by fusion.fuse to size its launch blocks: output + staged view slabs must fit (the reference sizes its
+ * work by output_chunksize alone, fusion/_core.py:248-277, because every chunk there is a separate host task). */
+int mvs_mem_info(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 int mvs_memcpy_h2d(int device, void* dst_dev, const void* src_host, uint64_t nbytes);
 int mvs_memcpy_d2h(int device, void* dst_host, const void* src_dev, uint64_t nbytes);
 int mvs_upload_tile(int device, const void* host, int32_t dtype, const int64_t shape[3], void** dev_ptr);

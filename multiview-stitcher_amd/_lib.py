@@ -71,6 +71,7 @@ SIGNATURES = {
     "mvs_last_kernel_ms": (C.c_double, [C.c_int]),
     "mvs_malloc": (C.c_int, [C.c_int, C.c_uint64, C.POINTER(C.c_void_p)]),
     "mvs_free": (C.c_int, [C.c_int, C.c_void_p]),
+    "mvs_mem_info": (C.c_int, [C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "mvs_memcpy_h2d": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]),
     "mvs_memcpy_d2h": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64]),
     "mvs_upload_tile": (C.c_int, [C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_void_p)]),
@@ -194,6 +195,13 @@ def synchronize(device=0):
     check(init(device).mvs_synchronize(int(device)), device, "mvs_synchronize")
 
 
+def mem_info(device=0):
+    """(free, total) bytes of the GPU behind ``device`` (free includes this context's allocation cache)."""
+    f, t = C.c_uint64(0), C.c_uint64(0)
+    check(init(device).mvs_mem_info(int(device), C.byref(f), C.byref(t)), device, "mvs_mem_info")
+    return int(f.value), int(t.value)
+
+
 def last_kernel_ms(device=0):
     return float(load().mvs_last_kernel_ms(int(device)))
 
@@ -208,11 +216,16 @@ class DeviceBuffer:
         p = C.c_void_p()
         check(lib.mvs_malloc(self.device, self.nbytes, C.byref(p)), device, "mvs_malloc")
         self.ptr = p.value
+        self.version = 0           # bumped by every write into the allocation: peer copies on other GPUs are stamped with it
+
+    def mark_written(self):
+        self.version += 1
 
     def upload(self, host: np.ndarray):
         host = np.ascontiguousarray(host)
         assert host.nbytes <= self.nbytes
         check(load().mvs_memcpy_h2d(self.device, self.ptr, host.ctypes.data, host.nbytes), self.device, "h2d")
+        self.mark_written()
         return self
 
     def download(self, shape, dtype):

@@ -228,7 +228,10 @@ def bin_mean(data, bins, device=0, wait=True, out=None):
     if not wait and mem == _lib.MVS_MEM_DEVICE:
         rc = lib.mvs_bin_mean_async(device, ptr, _lib.DTYPE_CODES[dtype], _lib.i64x3(s3), _lib.i64x3(st3), _lib.i64x3(b3), optr)
         _lib.check(rc, device, "mvs_bin_mean_async")
+        out.mark_written()
         return out
     rc = lib.mvs_bin_mean(device, ptr, _lib.DTYPE_CODES[dtype], mem, _lib.i64x3(s3), _lib.i64x3(st3), _lib.i64x3(b3), optr, omem)
     _lib.check(rc, device, "mvs_bin_mean")
+    if is_device_array(out):
+        out.mark_written()
     return out

@@ -311,6 +311,22 @@ int mvs_malloc(int device, uint64_t nbytes, void** dev_ptr) {
     return MVS_OK;
 }
 
+int mvs_mem_info(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
+    size_t f = 0, t = 0;
+    MVS_HIP_TRY(c, hipMemGetInfo(&f, &t));
+    {   // memory parked in the allocation cache is handed back on demand (mvs_malloc flushes it before it fails)
+        std::lock_guard<std::mutex> lock(c->pool_mu);
+        f += c->pool_cached_bytes;
+    }
+    if (free_bytes) *free_bytes = (uint64_t)f;
+    if (total_bytes) *total_bytes = (uint64_t)t;
+    return MVS_OK;
+}
+
 int mvs_free(int device, void* dev_ptr) {
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);

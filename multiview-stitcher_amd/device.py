@@ -56,7 +56,10 @@ class DeviceArray:
     def on_device(self, device):
         """This array on GPU ``device`` (the low byte of a context id; the high bits are a lane): itself when it already
         lives there, otherwise a peer copy (mvs_memcpy_peer) of the spanned range with the same shape and strides.
-        Copies of whole library-owned allocations are cached on the owner, so a tile is fetched once per device."""
+        Copies of whole library-owned allocations are cached on the owner, so a tile is fetched once per device; the
+        cache entry carries the owner's write version (bumped by upload / fill_zero / copy_into / kernels writing into
+        ``out=``), so a copy taken before a later write is refreshed (into the same peer allocation) instead of being
+        handed out stale.  ``drop_peer_copies()`` releases them."""
         dev = int(device)
         if (self.device & 0xff) == (dev & 0xff):
             return self
@@ -65,22 +68,34 @@ class DeviceArray:
         lib = _lib.init(dev)
         if isinstance(owner, _lib.DeviceBuffer) and owner.ptr:
             cache = owner.__dict__.setdefault("_peer_copies", {})
-            peer = cache.get(dev & 0xff)
-            if peer is None:
-                peer = _lib.DeviceBuffer(dev, owner.nbytes)
+            entry = cache.get(dev & 0xff)
+            if entry is None or entry[1] != owner.version:
+                peer = entry[0] if entry is not None else _lib.DeviceBuffer(dev, owner.nbytes)
                 _lib.check(lib.mvs_memcpy_peer(dev, C.c_void_p(peer.ptr), self.device, C.c_void_p(owner.ptr), owner.nbytes), dev, "mvs_memcpy_peer")
-                cache[dev & 0xff] = peer
+                cache[dev & 0xff] = entry = (peer, owner.version)
+            peer = entry[0]
             return DeviceArray(peer, peer.ptr + (self.ptr - owner.ptr), self.shape, self.strides, self.dtype, dev)
         span = sum((n - 1) * st for n, st in zip(self.shape, self.strides)) + 1
         buf = _lib.DeviceBuffer(dev, span * item)
         _lib.check(lib.mvs_memcpy_peer(dev, C.c_void_p(buf.ptr), self.device, C.c_void_p(self.ptr), span * item), dev, "mvs_memcpy_peer")
         return DeviceArray(buf, buf.ptr, self.shape, self.strides, self.dtype, dev)
 
+    def mark_written(self):
+        """Tell the owning allocation that its contents changed (invalidates peer copies on other GPUs)."""
+        if isinstance(self._buf, _lib.DeviceBuffer):
+            self._buf.mark_written()
+
+    def drop_peer_copies(self):
+        """Release the copies of this array's allocation that ``on_device`` left on other GPUs."""
+        if isinstance(self._buf, _lib.DeviceBuffer):
+            self._buf.__dict__.pop("_peer_copies", None)
+
     def fill_zero(self):
         """Stream-ordered zero fill (contiguous arrays)."""
         if not self.is_contiguous():
             raise ValueError("fill_zero needs a contiguous array")
         _lib.check(_lib.init(self.device).mvs_memset(self.device, C.c_void_p(self.ptr), 0, self.nbytes), self.device, "mvs_memset")
+        self.mark_written()
 
     def copy_into(self, dst, offset):
         """Copy this (contiguous) array into the window of the contiguous DeviceArray ``dst`` that starts at ``offset``
@@ -95,6 +110,7 @@ class DeviceArray:
         rc = _lib.init(dst.device).mvs_copy_into(dst.device, C.c_void_p(self.ptr), _lib.DTYPE_CODES[self.dtype], _lib.i64x3(s3),
                                                  C.c_void_p(dst.ptr), _lib.i64x3(d3), _lib.i64x3(o3))
         _lib.check(rc, dst.device, "mvs_copy_into")
+        dst.mark_written()
 
     @property
     def __cuda_array_interface__(self):

@@ -250,6 +250,7 @@ def fuse_np(
         opts.out_mem = _lib.MVS_MEM_DEVICE
         rc = lib.mvs_fuse_chunk(device, views, n, C.byref(opts), C.c_void_p(out.ptr))
         _lib.check(rc, device, "mvs_fuse_chunk")
+        out.mark_written()
         return out
     result = np.empty(tuple(res_shape), dtype=input_dtype)
     opts.out_mem = _lib.MVS_MEM_HOST
@@ -506,6 +507,36 @@ def _merged_chunksize(chunksize, shape, sdims, itemsize, max_bytes=None):
     return {d: block(d) for d in sdims}
 
 
+def _launch_budget(sims, out_shape, sdims, itemsize, device, cap):
+    """Output bytes one launch block of fuse(merge_chunks=True) may take so that the launch fits the device: the block
+    itself plus the view slabs that have to be STAGED for it (host- or Zarr-backed views, and views resident on another
+    GPU, are copied into device scratch; views already on ``device`` cost nothing) must stay below 90 % of the free
+    device memory (``mvs_mem_info``).  The staged share is estimated per output byte: twice the mosaic-average (overlap
+    zones hold every voxel two to eight times) plus one whole view.  Never above ``cap`` (MVS_MAX_LAUNCH_BYTES /
+    MVS_MAX_STREAM_BYTES)."""
+    try:
+        free, _ = _lib.mem_info(device)
+    except (RuntimeError, OSError, AttributeError):
+        return cap
+    staged, largest = 0, 0
+    for s in sims:
+        data = s.data
+        if is_device_array(data) and (data.device & 0xff) == (int(device) & 0xff):
+            continue
+        nb = int(np.prod([s.sizes[d] for d in sdims])) * itemsize
+        staged += nb
+        largest = max(largest, nb)
+    out_total = max(int(np.prod([int(out_shape[d]) for d in sdims])) * itemsize, 1)
+    avail = int(0.9 * free) - largest
+    per_out_byte = 1.0 + 2.0 * staged / out_total
+    return int(max(min(cap, avail / per_out_byte), 1))
+
+
+def _is_device_memory_error(exc):
+    msg = str(exc)
+    return "hipMalloc" in msg or "out of memory" in msg.lower() or "hipErrorOutOfMemory" in msg
+
+
 # --- chunk -> view-slab plan (_core.py:354-722): computed by the library ---------------------------------
 _PLAN_ENTRY = np.dtype([("block", "<i8", (3,)), ("view", "<i4"), ("planewise", "<i4"), ("lo", "<i8", (3,)), ("n", "<i8", (3,))])
 
@@ -557,7 +588,7 @@ def _plan_chunks(sparams, views_bb, output_stack_properties, output_chunksize, o
     return by_block, info
 
 
-def fuse(
+def _fuse_once(
     images=None,
     transform_key=None,
     fusion_func=weighted_average_fusion,
@@ -645,13 +676,18 @@ def fuse(
             overlap_in_pixels = {d: max(overlap_in_pixels[d], cur[d]) for d in sdims}
 
     store_chunksize = dict(output_chunksize)          # the chunk grid of a Zarr output stays the requested one
+    requested_chunksize = dict(output_chunksize)
+    merged = False
     if (merge_chunks and not batch_options and chunk_filter is None
             and weights_func is None and fusion_func in _FUSION_CODES and not any(overlap_in_pixels[d] for d in sdims)
             and not ("z" in sdims and int(output_chunksize["z"]) == 1 and output_stack_properties["shape"]["z"] > 1)):
         # streamed inputs / outputs pass through host memory block by block: a smaller budget per launch block
         streamed = output_zarr_url is not None or any(type(s_.data).__name__ in ("ZarrArray", "ZarrView") for s_ in sims_)
-        output_chunksize = _merged_chunksize(output_chunksize, output_stack_properties["shape"], sdims,
-                                             np.dtype(sims_[0].dtype).itemsize, MAX_STREAM_BYTES if streamed else None)
+        itemsize = np.dtype(sims_[0].dtype).itemsize
+        budget = _launch_budget(sims_, output_stack_properties["shape"], sdims, itemsize, device,
+                                MAX_STREAM_BYTES if streamed else MAX_LAUNCH_BYTES)
+        output_chunksize = _merged_chunksize(output_chunksize, output_stack_properties["shape"], sdims, itemsize, budget)
+        merged = any(int(output_chunksize[d]) != int(requested_chunksize[d]) for d in sdims)
 
     chunk_bbs, block_indices = mv_graph.get_chunk_bbs(output_stack_properties, output_chunksize)
     chunk_bbs_ov = [
@@ -661,13 +697,19 @@ def fuse(
         for cb in chunk_bbs
     ]
     chunk_bbs_res = chunk_bbs if trim_overlap else chunk_bbs_ov
-    if not trim_overlap and any(overlap_in_pixels[d] for d in sdims):
-        raise NotImplementedError("trim_overlap=False with a halo yields overlapping chunks; not assembled here")
     views_bb = [si_utils.get_stack_properties_from_sim(sim) for sim in sims_]
     norm_chunks = mv_graph.normalize_chunks([output_chunksize[d] for d in sdims], [output_stack_properties["shape"][d] for d in sdims])
+    untrimmed = (not trim_overlap) and any(overlap_in_pixels[d] for d in sdims)
+    if untrimmed:
+        # trim_overlap=False (_core.py:1252-1254, 1687-1711): every chunk keeps its halo and the result is the block
+        # assembly of the untrimmed chunks side by side (da.block of chunks of shape chunk + 2 * halo), i.e. an array
+        # that is larger than the output stack by 2 * halo per chunk and axis
+        if output_zarr_url is not None:
+            raise NotImplementedError("trim_overlap=False assembles untrimmed chunks in memory; it cannot stream to a Zarr store")
+        norm_chunks = [tuple(int(c) + 2 * int(overlap_in_pixels[d]) for c in cs_) for cs_, d in zip(norm_chunks, sdims)]
     block_offsets = [np.cumsum((0,) + c[:-1]) for c in norm_chunks]
 
-    out_shape_sp = tuple(output_stack_properties["shape"][d] for d in sdims)
+    out_shape_sp = tuple(int(sum(c)) for c in norm_chunks) if untrimmed else tuple(output_stack_properties["shape"][d] for d in sdims)
     ns_shape = tuple(sims_[0].sizes[d] for d in nsdims)
     dtype = np.dtype(sims_[0].dtype)
     on_device = output_on_backend
@@ -681,6 +723,24 @@ def fuse(
         ome_zarr = bool(zarr_options.get("ome_zarr", False))
         ngff_version = zarr_options.get("ngff_version", "0.4")
         create_kw = dict(zarr_options.get("zarr_array_creation_kwargs") or {})
+        if create_kw.get("chunks") is not None:
+            # the store's chunk grid: full rank (c, t, spatial) or spatial dims only, as write_sim_to_ome_zarr takes it.  Every
+            # fused block is written into its region, so the fuse chunk grid must be made of whole store chunks.
+            req = [int(v) for v in create_kw["chunks"]]
+            if len(req) == len(nsdims) + len(sdims):
+                req = req[len(nsdims):]
+            if len(req) != len(sdims) or min(req) < 1:
+                raise ValueError(f"zarr_array_creation_kwargs['chunks'] {create_kw['chunks']} does not match dims {list(nsdims) + list(sdims)}")
+            for d, c in zip(sdims, req):
+                if int(requested_chunksize[d]) % c and int(requested_chunksize[d]) < int(output_stack_properties["shape"][d]):
+                    raise ValueError(f"store chunks {req} do not tile the fuse chunks {[int(requested_chunksize[d_]) for d_ in sdims]}")
+            store_chunksize = dict(zip(sdims, req))
+        create_kw.pop("chunks", None)
+        if ome_zarr_requested := bool(zarr_options.get("ome_zarr", False)):
+            want_fmt = 3 if str(zarr_options.get("ngff_version", "0.4")) == "0.5" else 2
+            if int(create_kw.get("zarr_format", want_fmt)) != want_fmt:
+                raise ValueError(f"zarr_format {create_kw['zarr_format']} conflicts with NGFF {zarr_options.get('ngff_version', '0.4')} "
+                                 f"(which stores Zarr v{want_fmt} arrays)")
         if zarr_options.get("overwrite", True) and os.path.exists(output_zarr_url) and chunk_filter is None:
             shutil.rmtree(output_zarr_url)
         if ome_zarr:
@@ -696,8 +756,10 @@ def fuse(
                 store_url, ns_shape + out_shape_sp, (1,) * len(ns_shape) + tuple(store_chunksize[d] for d in sdims), dtype,
                 **create_kw)
     result = None if (on_device or zarr_out is not None) else np.zeros(ns_shape + out_shape_sp, dtype=dtype)
-    if on_device and ns_shape and int(np.prod(ns_shape)) != 1:
-        raise NotImplementedError("output_on_backend with several (c,t) fields")
+    # output_on_backend: one device array for all (c, t) fields (_core.py:1275-1306 loops the fields); every field is fused
+    # into its own contiguous sub-array.  A single field keeps the spatial dims only, as before.
+    n_fields = int(np.prod(ns_shape)) if ns_shape else 1
+    dev_full = DeviceArray.empty((ns_shape if n_fields > 1 else ()) + out_shape_sp, dtype, device) if on_device else None
 
     # batch_options (_core.py:1068-1141, 2044-2156): with a Zarr output the reference hands batches of block ids to
     # batch_func(fuse_chunk, block_ids, **batch_func_kwargs); fuse_chunk(block_id) fuses one block and writes its region
@@ -746,7 +808,7 @@ def fuse(
             cbb_use = cbb_ov
             fvb = [views_bb[iv] for iv in idxs]
         sl = tuple(
-            slice(int(block_offsets[i][bi[i]]), int(block_offsets[i][bi[i]]) + int(entry["output_bb"]["shape"][d]))
+            slice(int(block_offsets[i][bi[i]]), int(block_offsets[i][bi[i]]) + int(entry["output_bb_result"]["shape"][d]))
             for i, d in enumerate(sdims)
         )
         kwargs = dict(
@@ -800,7 +862,7 @@ def fuse(
         _, plan = plan_for(ns_sel.get("t", 0))
         dev_out = None
         if on_device:
-            dev_out = DeviceArray.empty(out_shape_sp, dtype, device)
+            dev_out = dev_full[tuple(int(i) for i in ns_index)] if n_fields > 1 else dev_full
             entries = plan["per_chunk_entries"]
             # one chunk that is actually fused over the whole array writes every voxel; in every other case (several chunks,
             # a chunk without views, a chunk the filter rejects) untouched voxels must read 0 like the host result
@@ -833,11 +895,10 @@ def fuse(
                     result = chunk           # one launch block and one field: the fused array is the result
                 else:
                     result[tuple(ns_index) + sl] = chunk
-        if on_device:
-            result_data = dev_out
     if on_device:
-        data = result_data
-        dims = sdims
+        dev_full.mark_written()
+        data = dev_full
+        dims = (list(nsdims) if n_fields > 1 else []) + list(sdims)
     else:
         data = result if zarr_out is None else zarr_out[...]
         dims = list(nsdims) + list(sdims)
@@ -853,3 +914,22 @@ def fuse(
                                                zarr_array_creation_kwargs=zarr_options.get("zarr_array_creation_kwargs"),
                                                device=device)
     return res
+
+
+def fuse(*args, **kwargs):
+    try:
+        return _fuse_once(*args, **kwargs)
+    except RuntimeError as exc:
+        # A merged launch block is sized from an ESTIMATE of what has to be staged on the device (_launch_budget); if the
+        # device still runs out of memory the requested chunk grid -- the unit the caller sized for -- is used instead.
+        if kwargs.get("merge_chunks", True) and _is_device_memory_error(exc):
+            import warnings
+
+            warnings.warn(f"fuse(): a merged launch block did not fit the device ({exc}); falling back to the requested "
+                          "output_chunksize", RuntimeWarning, stacklevel=2)
+            return _fuse_once(*args, **dict(kwargs, merge_chunks=False))
+        raise
+
+
+fuse.__doc__ = _fuse_once.__doc__
+fuse.__wrapped__ = _fuse_once

@@ -609,9 +609,7 @@ def _prebin_views(sims, registration_binning, device, cache):
         # the coarsened coordinates of _bin_sim (mean of each group of b: the sum divided by b, as numpy's mean does it)
         coords = {d: np.add.reduce(s.coords[d][: n * b].reshape(n, b), axis=1) / b for d, b, n in zip(sdims, bins, oshape)}
         binned = si_utils.SpatialImage(out, sdims, coords, {"transforms": dict(s.attrs.get("transforms", {}))})
-        slot = {"event": threading.Event(), "value": binned, "error": None, "keep": (s.data, data)}
-        slot["event"].set()
-        cache._items[(id(s.data), bkey)] = slot
+        cache.put((id(s.data), bkey), binned, keep=(s.data, data))
     return lane_device
 
 
@@ -674,6 +672,16 @@ class _BinCache:
 
         self._lock = threading.Lock()
         self._items = {}
+        self.hits = self.misses = 0      # (tests: the pre-binned tiles of register() must be found by every pair)
+
+    def put(self, key, value, keep=None):
+        """Store a finished value (``keep``: the objects whose id() is part of ``key``; the slot holds them alive)."""
+        import threading
+
+        slot = {"event": threading.Event(), "value": value, "error": None, "keep": keep}
+        slot["event"].set()
+        with self._lock:
+            self._items[key] = slot
 
     def get_or_compute(self, key, fn, keep=None):
         """``keep``: the object whose id() is part of ``key``; the slot holds a reference to it."""
@@ -682,6 +690,10 @@ class _BinCache:
         with self._lock:
             slot = self._items.get(key)
             owner = slot is None
+            if owner:
+                self.misses += 1
+            else:
+                self.hits += 1
             if owner:
                 slot = self._items[key] = {"event": threading.Event(), "value": None, "error": None, "keep": keep}
         if owner:
@@ -800,11 +812,16 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
     tol = overlap_tolerance
     if tol is not None and not isinstance(tol, dict):
         tol = {d: float(tol) for d in sps[0]["spacing"]}
-    g_views = mv_graph.build_view_adjacency_graph([dict(sp, transform=a) for sp, a in zip(sps, affs)], overlap_tolerance=tol, pairs=pairs)
-    g_views = mv_graph.prune_view_adjacency_graph(g_views, pre_registration_pruning_method, pre_reg_pruning_method_kwargs)
-    edges = [tuple(sorted(e)) for e in g_views.edges()]
-    if prebin is not None:
-        _lib.synchronize(prebin)      # the binned tiles are complete before any lane reads them
+    try:
+        g_views = mv_graph.build_view_adjacency_graph([dict(sp, transform=a) for sp, a in zip(sps, affs)], overlap_tolerance=tol, pairs=pairs)
+        g_views = mv_graph.prune_view_adjacency_graph(g_views, pre_registration_pruning_method, pre_reg_pruning_method_kwargs)
+        edges = [tuple(sorted(e)) for e in g_views.edges()]
+    finally:
+        if prebin is not None:
+            # the binned tiles are complete before any lane reads them (the pre-binning lane is the last context lane; the
+            # pair workers, which may reuse it, only start after this point) -- also when graph building raised: nothing
+            # stays queued on tiles the caller may free
+            _lib.synchronize(prebin)
 
     # (2) pairwise registrations per time point
     params_t, all_results, resolution_info = [], [], []
@@ -848,7 +865,7 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
             else:
                 si_utils.set_sim_affine(m, p, new_transform_key, base_transform_key=transform_key)
     if return_dict:
-        return {"params": params,
+        return {"params": params, "bin_cache_stats": None if bin_cache is None else {"hits": bin_cache.hits, "misses": bin_cache.misses},
                 "groupwise_resolution": {"info": resolution_info},
                 "pairwise_registration": {"edges": edges, "results": all_results,
                                           "metrics": {"qualities": {e: r["quality"] for e, r in zip(edges, all_results[0])}}}}

@@ -71,7 +71,11 @@ def run_fuse_task(task):
     want, want_f, dbg = fo.fuse_np(task["views"], task["params"], task["out_bb"], full_view_bbs=task["fvbs"],
                                    trim_overlap_in_pixels=task["halo"], return_debug=True, **task["kw"])
     floor = reference_noise_floor(dbg, want_f) if task["kw"].get("weights") is None else None
-    return want, want_f, floor
+    wsum = None
+    if dbg["raw_weights"] is not None:
+        t = dbg["trim"]
+        wsum = dbg["raw_weights"].sum(0)[tuple(slice(a, -a) if a > 0 else slice(None) for a in t)].astype(np.float32)
+    return want, want_f, floor, wsum
 
 
 def run_pair_task(task):
@@ -125,12 +129,16 @@ def check_boxes(fused_data, tasks, los, shapes, rtol=1e-4, int_boundary_rtol=1e-
         if res is None:
             assert not got.any(), "box without contributing views must be zero"
             continue
-        want, want_f, floor = res
+        want, want_f, floor, wsum = res
         if np.issubdtype(got.dtype, np.integer):
             far = np.argwhere(np.abs(got.astype(np.int64) - want.astype(np.int64)) > 1)
             assert len(far) <= 64, f"{len(far)} voxels differ by more than one count"
             for idx in far:
-                assert _marginal(task, idx), (lo, idx, got[tuple(idx)], want[tuple(idx)])
+                # (a) exactly on a view border, or (b) on the knife edge of the reference's weight quantisation: its
+                # float32 cos((1 - x) pi) makes every weight a multiple of 2^-25, so where ALL weights of a voxel are a few
+                # quanta (the outermost voxels of the mosaic) one rounding decides between "0 / 0 -> 0" and "w v / w = v"
+                knife = wsum is not None and float(wsum[tuple(idx)]) <= 8 * 2.0 ** -25
+                assert _marginal(task, idx) or knife, (lo, idx, got[tuple(idx)], want[tuple(idx)], None if wsum is None else wsum[tuple(idx)])
                 got[tuple(idx)] = want[tuple(idx)]
                 agg["marginal_voxels"] += 1
         st = fused_close_stats(got, want, want_f, rtol=rtol, noise_floor=floor, int_boundary_rtol=int_boundary_rtol)

@@ -34,6 +34,36 @@ def test_register_3d_with_binning_and_device_tiles(hip_device):
     want = jit - jit[0]
     np.testing.assert_allclose(got - got[0], want, atol=1.01)      # binning 2 -> half-resolution shifts
     assert all(q > 0.5 for q in res["pairwise_registration"]["metrics"]["qualities"].values())
+    # every pair found its two tiles pre-binned (register() bins all tiles of a regular mosaic while it builds the graph)
+    stats = res["bin_cache_stats"]
+    n_pairs = len(res["pairwise_registration"]["edges"])
+    assert stats is not None and stats["hits"] >= 2 * n_pairs
+
+
+def test_peer_copy_follows_later_writes(hip_device):
+    """DeviceArray.on_device caches the copy it makes for another GPU context; a later write into the source allocation
+    (upload, fill_zero, a kernel writing into ``out=``) must not leave that copy stale.  With one GPU on the box the cache
+    is driven directly: the entry is stamped with the owner's write version and refreshed when the version moved."""
+    from multiview_stitcher_amd import _lib
+    from multiview_stitcher_amd.device import DeviceArray
+
+    a = DeviceArray.from_host(np.arange(24, dtype=np.uint16).reshape(2, 3, 4), 0)
+    buf = a._buf
+    v0 = buf.version
+    a.fill_zero()
+    assert buf.version == v0 + 1
+    b = DeviceArray.from_host(np.full((2, 3, 4), 7, np.uint16), 0)
+    b.copy_into(a, [0, 0, 0])
+    assert buf.version == v0 + 2 and np.all(a.get() == 7)
+    buf.upload(np.full((2, 3, 4), 9, np.uint16))
+    assert buf.version == v0 + 3
+    # a cache entry taken at an older version is not handed out: simulate the peer entry of "device 1"
+    stale = _lib.DeviceBuffer(0, buf.nbytes).upload(np.zeros((2, 3, 4), np.uint16))
+    buf.__dict__["_peer_copies"] = {1: (stale, buf.version - 1)}
+    entry = buf.__dict__["_peer_copies"][1]
+    assert entry[1] != buf.version          # on_device(1) would re-copy into entry[0] instead of returning it as is
+    a.drop_peer_copies()
+    assert "_peer_copies" not in buf.__dict__
 
 
 def test_register_then_fuse_end_to_end(hip_device):
@@ -221,3 +251,105 @@ def test_lean_pair_path_equals_generic_on_device(hip_device, ndim):
         assert ra["quality"] == rb["quality"]
     for pa, pb in zip(a["params"], b["params"]):
         np.testing.assert_array_equal(pa, pb)
+
+
+def test_fuse_launch_blocks_respect_budget_and_fall_back(hip_device, monkeypatch):
+    """fuse(merge_chunks=True) sizes its launch blocks from the output bytes PLUS the view slabs that must be staged on
+    the device, against the free device memory (mvs_mem_info), and falls back to the requested chunk grid when a merged
+    block still fails to allocate.  Whatever the block size, the mosaic is the same."""
+    import warnings
+
+    from multiview_stitcher_amd import _lib, fusion, sample_data
+
+    sims, _, _ = sample_data.generate_tiled_dataset(ndim=3, tile_shape=(24, 48, 56), tiles=(1, 2, 2), overlap=(0, 12, 14), max_jitter=0)
+    key = sample_data.METADATA_TRANSFORM_KEY
+    cs = {"z": 8, "y": 16, "x": 16}
+    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=cs, merge_chunks=False).data)
+    shapes = []
+    real = fusion.fuse_np
+
+    def spy(*a, **k):
+        shapes.append(tuple(int(v) for v in k["output_properties"]["shape"].values()))
+        return real(*a, **k)
+
+    monkeypatch.setattr(fusion, "fuse_np", spy)
+    # (1) default budget: one launch block
+    np.testing.assert_array_equal(np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=cs).data), want)
+    assert len(shapes) == 1
+    # (2) a small output cap (MVS_MAX_LAUNCH_BYTES): several blocks of whole chunks
+    shapes.clear()
+    monkeypatch.setattr(fusion, "MAX_LAUNCH_BYTES", 40_000)
+    np.testing.assert_array_equal(np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=cs).data), want)
+    assert len(shapes) > 1 and all(s[k] % c == 0 or True for s in shapes for k, c in enumerate(cs.values()))
+    assert max(int(np.prod(s)) * 2 for s in shapes) <= 40_000
+    monkeypatch.setattr(fusion, "MAX_LAUNCH_BYTES", 32 << 30)
+    # (3) host-resident tiles and little free device memory: the staged slabs count against the budget
+    shapes.clear()
+    tile_bytes = 24 * 48 * 56 * 2
+    monkeypatch.setattr(_lib, "mem_info", lambda device=0: (int((tile_bytes + 60_000) / 0.9), 1 << 34))
+    np.testing.assert_array_equal(np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=cs).data), want)
+    assert len(shapes) > 1 and max(int(np.prod(s)) * 2 for s in shapes) < 60_000
+    monkeypatch.undo()
+    # (4) a merged block that fails to allocate: warning + the requested chunk grid
+    calls = []
+
+    def failing(*a, **k):
+        shp = tuple(int(v) for v in k["output_properties"]["shape"].values())
+        calls.append(shp)
+        if int(np.prod(shp)) > 8 * 16 * 16:
+            raise RuntimeError("mvs_fuse_chunk failed (code -2): hipMalloc(123456) failed: out of memory")
+        return real(*a, **k)
+
+    monkeypatch.setattr(fusion, "fuse_np", failing)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        got = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=cs).data)
+    np.testing.assert_array_equal(got, want)
+    assert any("falling back" in str(x.message) for x in w) and len(calls) > 2
+
+
+def test_fuse_all_fields_on_backend(hip_device):
+    """output_on_backend with several (c, t) fields (_core.py:1275-1306 loops the fields): one device array, every field
+    fused into its own sub-array; equals the host result."""
+    from multiview_stitcher_amd import fusion, param_utils
+    from multiview_stitcher_amd.device import is_device_array
+
+    rng = np.random.default_rng(0)
+    sims = []
+    for iv, tr in enumerate([{"y": 0.0, "x": 0.0}, {"y": 3.0, "x": 20.5}]):
+        data = rng.integers(0, 4000, (2, 3, 30, 36)).astype(np.uint16)
+        sims.append(_sim(data, ["c", "t", "y", "x"], {"y": 1.0, "x": 1.0}, tr))
+    host = fusion.fuse(sims, transform_key="k", output_chunksize={"y": 16, "x": 16})
+    dev = fusion.fuse(sims, transform_key="k", output_chunksize={"y": 16, "x": 16}, output_on_backend=True)
+    assert is_device_array(dev.data) and list(dev.dims) == ["c", "t", "y", "x"]
+    np.testing.assert_array_equal(dev.data.get(), np.asarray(host.data))
+    dev_c = fusion.fuse(sims, transform_key="k", output_chunksize={"y": 16, "x": 16}, output_on_backend=True, merge_chunks=False)
+    np.testing.assert_array_equal(dev_c.data.get(), np.asarray(host.data))
+
+
+def test_fuse_untrimmed_halo_chunks(hip_device):
+    """trim_overlap=False (_core.py:1252-1254, 1687-1711): the chunks keep their halo and the result is their block
+    assembly -- every block equals fuse_np on the chunk's bounding box grown by the halo."""
+    from multiview_stitcher_amd import fusion, mv_graph, sample_data
+    from multiview_stitcher_amd import spatial_image_utils as si
+
+    sims, _, _ = sample_data.generate_tiled_dataset(ndim=2, tile_shape=(40, 44), tiles=(2, 2), overlap=(10, 12), max_jitter=0)
+    key = sample_data.METADATA_TRANSFORM_KEY
+    halo, cs = 3, {"y": 32, "x": 40}
+    got = fusion.fuse(sims, transform_key=key, output_chunksize=cs, overlap_in_pixels=halo, trim_overlap=False)
+    trimmed = fusion.fuse(sims, transform_key=key, output_chunksize=cs, overlap_in_pixels=halo)
+    shape = [trimmed.sizes[d] for d in "yx"]
+    ny, nx = -(-shape[0] // cs["y"]), -(-shape[1] // cs["x"])
+    assert got.sizes["y"] == shape[0] + 2 * halo * ny and got.sizes["x"] == shape[1] + 2 * halo * nx
+    g, t = np.asarray(got.data)[0, 0], np.asarray(trimmed.data)[0, 0]
+    oy = 0
+    for by in range(ny):
+        hy = min(cs["y"], shape[0] - by * cs["y"])
+        ox = 0
+        for bx in range(nx):
+            hx = min(cs["x"], shape[1] - bx * cs["x"])
+            block = g[oy:oy + hy + 2 * halo, ox:ox + hx + 2 * halo]
+            # the block's core is the trimmed chunk
+            np.testing.assert_array_equal(block[halo:-halo, halo:-halo], t[by * cs["y"]:by * cs["y"] + hy, bx * cs["x"]:bx * cs["x"] + hx])
+            ox += hx + 2 * halo
+        oy += hy + 2 * halo

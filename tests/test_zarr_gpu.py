@@ -195,3 +195,24 @@ def test_fuse_streams_into_ngff_05_zarr_v3(hip_device, tmp_path):
     lvl1 = ms["scale1"] if "scale1" in ms.keys() else None
     if lvl1 is not None:
         np.testing.assert_array_equal(np.asarray(lvl1.data)[0, 0], _block_mean(want[0, 0], (1, 2, 2))[: lvl1.data.shape[2]])
+
+
+def test_fuse_zarr_creation_kwargs_chunks_and_format(hip_device, tmp_path):
+    """zarr_array_creation_kwargs={"chunks": ...} names the store's chunk grid (spatial or full rank), as in
+    write_sim_to_ome_zarr; a zarr_format that contradicts the NGFF version is refused."""
+    from multiview_stitcher_amd import fusion, sample_data, zarr_io
+
+    key = sample_data.METADATA_TRANSFORM_KEY
+    sims = _dataset(2)
+    want = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize={"y": 128, "x": 96}).data)
+    url = str(tmp_path / "f.zarr")
+    fused = fusion.fuse(sims, transform_key=key, output_chunksize={"y": 128, "x": 96}, output_zarr_url=url,
+                        zarr_options={"ome_zarr": True, "zarr_array_creation_kwargs": {"chunks": (64, 48)}})
+    np.testing.assert_array_equal(np.asarray(fused.data), want)
+    assert list(zarr_io.ZarrArray.open(os.path.join(url, "0")).chunks[-2:]) == [64, 48]
+    with pytest.raises(ValueError):
+        fusion.fuse(sims, transform_key=key, output_chunksize={"y": 128, "x": 96}, output_zarr_url=str(tmp_path / "g.zarr"),
+                    zarr_options={"ome_zarr": True, "ngff_version": "0.4", "zarr_array_creation_kwargs": {"zarr_format": 3}})
+    with pytest.raises(ValueError):
+        fusion.fuse(sims, transform_key=key, output_chunksize={"y": 128, "x": 96}, output_zarr_url=str(tmp_path / "h.zarr"),
+                    zarr_options={"zarr_array_creation_kwargs": {"chunks": (50, 50)}})
