@@ -101,7 +101,6 @@ static void pool_flush(MvsContext* c) {
 }
 
 double mvs_rows_last_plan_ms(MvsContext* c);       // mvs_fuse_rows.hip
-double mvs_rowlds_last_plan_ms(MvsContext* c);     // mvs_fuse_rowlds.hip
 double mvs_regions_last_plan_ms(MvsContext* c);    // mvs_fuse_region.hip
 
 extern "C" {
@@ -215,14 +214,6 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         c->no_regions = value != 0;
         return MVS_OK;
     }
-    if (!strcmp(key, "stream_rows")) {
-        c->stream_rows = value != 0;
-        return MVS_OK;
-    }
-    if (!strcmp(key, "rowlds")) {
-        c->rowlds = value != 0;
-        return MVS_OK;
-    }
     if (!strcmp(key, "rows_v1")) {
         c->rows_v1 = value != 0;
         return MVS_OK;
@@ -259,7 +250,7 @@ int mvs_get_counter(int device, const char* key, int32_t reset, double* value_ou
     if (!strcmp(key, "reg_pairs")) { *value_out = (double)c->reg_pairs; if (reset) c->reg_pairs = 0; return MVS_OK; }
     if (!strcmp(key, "reg_candidates")) { *value_out = (double)c->reg_candidates; if (reset) c->reg_candidates = 0; return MVS_OK; }
     if (!strcmp(key, "fuse_plan_ms")) {
-        *value_out = mvs_rows_last_plan_ms(c) + mvs_rowlds_last_plan_ms(c) + mvs_regions_last_plan_ms(c);
+        *value_out = mvs_rows_last_plan_ms(c) + mvs_regions_last_plan_ms(c);
         return MVS_OK;
     }
     return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_get_counter: unknown key '%s'", key);

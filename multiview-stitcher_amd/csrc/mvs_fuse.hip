@@ -1112,8 +1112,6 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
 
 int mvs_fuse_rows(MvsContext* c, const TrView* htr, const TrView* dtr, int n_views, int dtype, void* dout, const int64_t os[3],
                   const int64_t trim[3], bool* done);      // mvs_fuse_rows.hip
-int mvs_fuse_rowlds(MvsContext* c, const TrView* htr, const TrView* dtr, int n_views, int dtype, void* dout, const int64_t os[3],
-                    const int64_t trim[3], bool* done);    // mvs_fuse_rowlds.hip
 
 int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_views,
                            const mvs_fuse_opts_t* opts, void* out);   // mvs_gauss.hip
@@ -1251,12 +1249,6 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     int* tr_overflow_ptr = nullptr;
     bool regions_done = false;
-    if (use_tr && opts->fusion == MVS_FUSE_WEIGHTED_AVERAGE && c->rowlds) {
-        // LDS-staged row-owning kernel (uint16, one tap per view); falls through otherwise
-        rc = mvs_fuse_rowlds(c, htr, (const TrView*)((const char*)dviews + views_bytes + cull_bytes), n_views, dtype, dout, os,
-                             opts->trim, &regions_done);
-        if (rc) return rc;
-    }
     if (!regions_done && use_tr && opts->fusion == MVS_FUSE_WEIGHTED_AVERAGE && (c->rows_v1 || (dtype == MVS_F32 && opts->order == 1))) {
         // direct-load row-owning kernels.  Float tiles take them by default: they read both taps of every axis even at
         // integer offsets, so a NaN next to a tap poisons the sample exactly as scipy's zero-weight multiply does

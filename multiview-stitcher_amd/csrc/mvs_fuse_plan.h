@@ -1,5 +1,5 @@
 // mvs_fuse_plan.h -- internal: host-side helpers shared by the row-owning fuse paths (mvs_fuse_rows.hip,
-// mvs_fuse_rowlds.hip): geometry hash and the clustered break points of one axis.
+// formerly mvs_fuse_rowlds.hip): geometry hash and the clustered break points of one axis.
 #pragma once
 #include "mvs_fuse_tr.h"
 

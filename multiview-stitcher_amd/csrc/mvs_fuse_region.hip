@@ -15,7 +15,6 @@
 //                                      row-uniform nodes (G1, dG) evaluated once per plane by 32 lanes
 // The unrolled NV = 1, 2, 4 instantiations keep all per-view constants in scalar registers.
 #include "mvs_fuse_tr.h"
-#include "mvs_fuse_stream.h"
 
 #include <algorithm>
 #include <chrono>
@@ -911,7 +910,6 @@ struct PlanCache {
     int class_count[5] = {0, 0, 0, 0, 0};   // bricks of regions with <=1, 2, <=4, >4 views, and copy-class bricks (contiguous, in this order)
     size_t rbytes = 0;
     bool valid = false;
-    bool has_stream = false;   // part of the chunk belongs to the streaming row kernel (mvs_fuse_stream.hip), whose tables are cached under the same hash
 };
 PlanCache g_plan[MVS_MAX_DEVICES * MVS_MAX_LANES];
 double g_region_plan_ms[MVS_MAX_DEVICES * MVS_MAX_LANES];
@@ -1006,10 +1004,6 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
     char* dbuf = nullptr;
     int nitems = 0;
     size_t rbytes = 0;
-    const bool use_stream = c->stream_rows && dtype == MVS_U16 && o[2] >= 512;
-    std::vector<StreamStrip> stream_strips;
-    bool stream_rebuild = false;
-    h ^= use_stream ? 0x51ed270b7f4a7c15ull : 0ull;
     if (pc.valid && pc.hash == h && (c->dev[8].ptr || pc.nitems == 0)) {
         dbuf = (char*)c->dev[8].ptr;      // same geometry as the previous call: the plan is still on the device
         nitems = pc.nitems;
@@ -1017,7 +1011,6 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
     } else {
         std::vector<int> pts[3];
         for (int d = 0; d < 3; ++d) axis_breakpoints(htr, n_views, d, t[d], o[d], &pts[d]);
-        stream_strips.clear();
         const size_t ncell = (pts[0].size() - 1) * (pts[1].size() - 1) * (pts[2].size() - 1);
         if (ncell == 0 || ncell > 60000) return MVS_OK;
         std::vector<Region> regions;
@@ -1032,18 +1025,6 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
                 yviews.clear();
                 for (int v : zviews)
                     if (htr[v].lo[1] < pts[1][iy + 1] && htr[v].hi[1] >= pts[1][iy]) yviews.push_back(v);
-                // strips whose views all cover every row go to the streaming row kernel (mvs_fuse_stream.hip) as a whole
-                if (use_stream) {
-                    const int sz0 = pts[0][iz], sz1 = pts[0][iz + 1], sy0 = pts[1][iy], sy1 = pts[1][iy + 1];
-                    bool ok = true;
-                    for (int v : yviews)
-                        ok = ok && mvs_stream_view_ok(htr[v]) && htr[v].lo[0] <= sz0 && htr[v].hi[0] >= sz1 - 1 && htr[v].lo[1] <= sy0 &&
-                             htr[v].hi[1] >= sy1 - 1;
-                    if (ok) {
-                        stream_strips.push_back(StreamStrip{sz0, sz1, sy0, sy1, yviews});
-                        continue;
-                    }
-                }
                 for (size_t ix = 0; ix + 1 < pts[2].size(); ++ix) {
                     Region R;
                     memset(&R, 0, sizeof(R));
@@ -1141,7 +1122,7 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
             pc.class_count[k] = (int)items_by_class[k].size();
             items.insert(items.end(), items_by_class[k].begin(), items_by_class[k].end());
         }
-        if ((items.empty() && stream_strips.empty()) || items.size() > (1u << 28)) return MVS_OK;
+        if (items.empty() || items.size() > (1u << 28)) return MVS_OK;
         rbytes = (regions.size() * sizeof(Region) + 255) / 256 * 256;
         const size_t ibytes = items.size() * sizeof(Item);
         char* hbuf = (char*)mvs_pinned_slot(c, 1, rbytes + ibytes + 256);   // slot 0 holds the view parameters still in flight
@@ -1158,14 +1139,6 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
         pc.nitems = nitems;
         pc.rbytes = rbytes;
         pc.valid = true;
-        pc.has_stream = !stream_strips.empty();
-        stream_rebuild = true;
-        if (getenv("MVS_PLAN_STATS")) {
-            double vox = 0;
-            for (auto& ls : stream_strips) vox += (double)(ls.z1 - ls.z0) * (ls.y1 - ls.y0) * o[2];
-            fprintf(stderr, "[mvs plan] stream strips %zu of %zu: %.1f %% of the voxels\n", stream_strips.size(),
-                    (pts[0].size() - 1) * (pts[1].size() - 1), 100.0 * vox / ((double)o[0] * o[1] * o[2]));
-        }
         g_region_plan_ms[mvs_ctx_index(c->device)] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_plan0).count();
     }
     RegionParams P;
@@ -1193,11 +1166,6 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
     }
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));   // kernel time only (the plan is host work, cached per geometry)
     if (fork) MVS_HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-    if (pc.has_stream) {
-        // whole strips stream on the main stream, the boxes of the remaining strips on the side streams
-        const int rcs = mvs_fuse_stream(c, htr, dtr, n_views, stream_rebuild ? &stream_strips : nullptr, h, dout, o, t, c->stream);
-        if (rcs) return rcs;
-    }
     const int side_of_class[5] = {0, -1, 1, 2, 3};          // class -> side stream (-1: main)
     bool side_used[4] = {false, false, false, false};
     int item0 = 0;

@@ -62,8 +62,6 @@ struct MvsContext {
     hipEvent_t pinned_ev[2] = {nullptr, nullptr};
     bool pinned_pending[2] = {false, false};
     bool no_regions = false;      // test switch: skip the region kernel (use the column kernel)
-    bool stream_rows = false;     // opt-in: strips fully covered by their views go to the streaming row kernel (mvs_fuse_stream.hip)
-    bool rowlds = false;          // opt-in: LDS-staged row kernel (mvs_fuse_rowlds.hip) before the other fast paths
     bool rows_v1 = false;         // opt-in: direct-load row kernels (mvs_fuse_rows.hip) for every dtype (default: float tiles only)
     // caching device allocator behind mvs_malloc / mvs_free: freed blocks are kept (size-keyed) and handed out
     // again, because hipMalloc / hipFree cost ~0.4 ms each and the registration path allocates per pair.

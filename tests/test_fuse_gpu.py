@@ -9,22 +9,18 @@ from tests.helpers import (assert_fused_close, bb_to_dicts, reference_noise_floo
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["fast", "generic", "rows", "rowlds", "stream"], autouse=True)
+@pytest.fixture(params=["fast", "generic", "rows"], autouse=True)
 def kernel_path(request, hip_device):
     """Every parity case runs through each kernel family: the default translation fast path (region kernels; float
-    tiles: row kernels), the generic affine kernel forced, and the two opt-in row-owning paths (direct-load rows for
-    every dtype; LDS-staged rows for uint16 single-tap views) -- all must match the oracle."""
+    tiles: row kernels), the generic affine kernel forced, and the direct-load row kernels for every dtype -- all must match
+    the oracle."""
     from multiview_stitcher_amd import _lib
 
     _lib.set_option("force_generic", 1 if request.param == "generic" else 0)
     _lib.set_option("rows_v1", 1 if request.param == "rows" else 0)
-    _lib.set_option("rowlds", 1 if request.param == "rowlds" else 0)
-    _lib.set_option("stream_rows", 1 if request.param == "stream" else 0)
     yield request.param
     _lib.set_option("force_generic", 0)
     _lib.set_option("rows_v1", 0)
-    _lib.set_option("rowlds", 0)
-    _lib.set_option("stream_rows", 0)
 
 
 def _grid_case(ndim, dtype, tiles, tile_shape, overlap, frac_shift, seed=0, spacing=None):

@@ -32,9 +32,7 @@ for idx in np.ndindex(*grid):
     sims.append(sim)
 torch.cuda.synchronize()
 _lib.set_option("ablate", int(os.environ.get("MVS_ABLATE", "0")))
-_lib.set_option("rowlds", int(os.environ.get("MVS_ROWLDS", "0")))                 # 1: LDS-staged row kernel first
 _lib.set_option("rows_v1", int(os.environ.get("MVS_ROWS_V1", "0")))               # 1: direct-load row kernels before the region kernels
-_lib.set_option("stream_rows", int(os.environ.get("MVS_STREAM", "0")))             # 1: fully covered strips go to the streaming row kernel
 _lib.set_option("serial_classes", int(os.environ.get("MVS_SERIAL", "0")))   # 1: class kernels one after the other (A/B of the side streams)
 ms = []
 for _ in range(reps):
@@ -45,7 +43,7 @@ byt = len(sims) * float(np.prod(tile)) * 2 + vox * 2
 print("shape", out.shape, "kernel ms", ms, "GB/s", byt / (min(ms) * 1e-3) / 1e9)
 if os.environ.get("MVS_COMPARE"):        # the same mosaic through the region kernels alone: must agree voxel for voxel
     a = out.data.get().astype(np.int32)
-    _lib.set_option("stream_rows", 0); _lib.set_option("rowlds", 0); _lib.set_option("rows_v1", 0)
+    _lib.set_option("rows_v1", 0); _lib.set_option("force_generic", 1)
     ref = fusion.fuse(sims, transform_key="k", output_chunksize={d: 1 << 30 for d in "zyx"}, output_on_backend=True, device=0)
     d = a - ref.data.get().astype(np.int32)
     print("compare: differing voxels", int((d != 0).sum()), "max |d|", int(np.abs(d).max()), "of", d.size)
