@@ -954,14 +954,15 @@ static void prepare_translation_view(DevView* d, int order, int fusion, const in
 
 // Single-view resample to float32 with an arbitrary cval (transformation.py:136-139).
 template <typename TIn, int ORDER>
-__global__ __launch_bounds__(256) void resample_kernel(DevView V, float* out, int oz, int oy, int ox, float cval) {
+__global__ __launch_bounds__(256) void resample_kernel(DevView V, float* out, int oz, int oy, int ox, float cval, int z0, int y0, int x0) {
     const long long n = (long long)oz * oy * ox;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         int x = (int)(i % ox);
         long long t = i / ox;
         int y = (int)(t % oy);
         int z = (int)(t / oy);
-        const double pz = (double)z, py = (double)y, px = (double)x;
+        // (z0, y0, x0): chunk index of the output box's first voxel -- the coordinates are those of the whole chunk
+        const double pz = (double)(z + z0), py = (double)(y + y0), px = (double)(x + x0);
         const double cz = ((pz * V.m[0] + py * V.m[1]) + px * V.m[2]) + V.off[0];
         const double cy = ((pz * V.m[3] + py * V.m[4]) + px * V.m[5]) + V.off[1];
         const double cx = ((pz * V.m[6] + py * V.m[7]) + px * V.m[8]) + V.off[2];
@@ -1018,14 +1019,14 @@ static bool is_integer_crop(const DevView& V, int dtype, int t[3]) {
 }
 
 // Blend-weight volume of one view (weights.py:391-511), float32.
-__global__ __launch_bounds__(256) void blend_kernel(DevView V, float* out, int oz, int oy, int ox) {
+__global__ __launch_bounds__(256) void blend_kernel(DevView V, float* out, int oz, int oy, int ox, int z0, int y0, int x0) {
     const long long n = (long long)oz * oy * ox;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         int x = (int)(i % ox);
         long long t = i / ox;
         int y = (int)(t % oy);
         int z = (int)(t / oy);
-        const double pz = (double)z, py = (double)y, px = (double)x;
+        const double pz = (double)(z + z0), py = (double)(y + y0), px = (double)(x + x0);
         const double cz = ((pz * V.wm[0] + py * V.wm[1]) + px * V.wm[2]) + V.woff[0];
         const double cy = ((pz * V.wm[3] + py * V.wm[4]) + px * V.wm[5]) + V.woff[1];
         const double cx = ((pz * V.wm[6] + py * V.wm[7]) + px * V.wm[8]) + V.woff[2];
@@ -1412,7 +1413,7 @@ extern "C" int mvs_blend_weights(int device, const mvs_view_t* view, int32_t ndi
     int nblocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     hipLaunchKernelGGL(blend_kernel, dim3(nblocks), dim3(256), 0, c->stream, d, dout, (int)out_shape[0],
-                       (int)out_shape[1], (int)out_shape[2]);
+                       (int)out_shape[1], (int)out_shape[2], 0, 0, 0);
     MVS_HIP_TRY(c, hipGetLastError());
     MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
     c->timing_valid = true;
@@ -1428,10 +1429,12 @@ int mvs_fill_dev_view(MvsContext* c, const mvs_view_t& v, int ndim, const void* 
     return fill_dev_view(c, v, ndim, dev_data, d);
 }
 
-void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, float cval, float* out, const int64_t shape[3]) {
+void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, float cval, float* out, const int64_t shape[3], const int* box0) {
     const long long n = (long long)shape[0] * shape[1] * shape[2];
     int t[3];
+    const int b0[3] = {box0 ? box0[0] : 0, box0 ? box0[1] : 0, box0 ? box0[2] : 0};
     if (!c->force_generic && is_integer_crop(d, dtype, t)) {
+        for (int k = 0; k < 3; ++k) t[k] += b0[k];
         const long long ng = (long long)shape[0] * shape[1] * ((shape[2] + 7) / 8);
         const int nb = (int)std::min<long long>((ng + 255) / 256, 256 * 16);
         if (dtype == MVS_U8)
@@ -1444,7 +1447,7 @@ void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, 
     }
     const int nblocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
 #define MVS_RS(T, O) hipLaunchKernelGGL((resample_kernel<T, O>), dim3(nblocks), dim3(256), 0, c->stream, d, out, \
-                                        (int)shape[0], (int)shape[1], (int)shape[2], cval)
+                                        (int)shape[0], (int)shape[1], (int)shape[2], cval, b0[0], b0[1], b0[2])
     switch (dtype) {
         case MVS_U8: if (order) MVS_RS(unsigned char, 1); else MVS_RS(unsigned char, 0); break;
         case MVS_U16: if (order) MVS_RS(unsigned short, 1); else MVS_RS(unsigned short, 0); break;
@@ -1453,8 +1456,47 @@ void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, 
 #undef MVS_RS
 }
 
-void mvs_launch_blend(MvsContext* c, const DevView& d, float* out, const int64_t shape[3]) {
+void mvs_launch_blend(MvsContext* c, const DevView& d, float* out, const int64_t shape[3], const int* box0) {
     const long long n = (long long)shape[0] * shape[1] * shape[2];
     const int nblocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(blend_kernel, dim3(nblocks), dim3(256), 0, c->stream, d, out, (int)shape[0], (int)shape[1], (int)shape[2]);
+    hipLaunchKernelGGL(blend_kernel, dim3(nblocks), dim3(256), 0, c->stream, d, out, (int)shape[0], (int)shape[1], (int)shape[2],
+                       box0 ? box0[0] : 0, box0 ? box0[1] : 0, box0 ? box0[2] : 0);
+}
+
+// Chunk-index box [lo, hi] (inclusive; lo > hi: empty) outside of which view `d` is certainly out of bounds: exact for
+// translations (the interval scipy's in-bounds test yields, as in the fast path), the bounding box of the slab's corners mapped
+// into the chunk (+- 2 voxels) otherwise.
+void mvs_view_chunk_box(const DevView& d, const int64_t shape[3], int lo[3], int hi[3]) {
+    static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    bool ident = true;
+    for (int k = 0; k < 9; ++k) ident = ident && d.m[k] == I9[k];
+    const int n[3] = {d.nz, d.ny, d.nx};
+    if (ident) {
+        for (int k = 0; k < 3; ++k) {
+            if (!(fabs(d.off[k]) < 1e9)) { lo[k] = 0; hi[k] = (int)shape[k] - 1; continue; }
+            exact_valid_range(d.off[k], n[k], (int)shape[k], &lo[k], &hi[k]);
+        }
+        return;
+    }
+    const double* m = d.m;
+    const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    for (int k = 0; k < 3; ++k) { lo[k] = 0; hi[k] = (int)shape[k] - 1; }
+    if (!(fabs(det) > 1e-12)) return;
+    const double inv[9] = {(m[4] * m[8] - m[5] * m[7]) / det, (m[2] * m[7] - m[1] * m[8]) / det, (m[1] * m[5] - m[2] * m[4]) / det,
+                           (m[5] * m[6] - m[3] * m[8]) / det, (m[0] * m[8] - m[2] * m[6]) / det, (m[2] * m[3] - m[0] * m[5]) / det,
+                           (m[3] * m[7] - m[4] * m[6]) / det, (m[1] * m[6] - m[0] * m[7]) / det, (m[0] * m[4] - m[1] * m[3]) / det};
+    double bl[3] = {1e300, 1e300, 1e300}, bh[3] = {-1e300, -1e300, -1e300};
+    for (int q = 0; q < 8; ++q) {
+        const double in[3] = {(q & 4) ? (double)(n[0] - 1) - d.off[0] : -d.off[0], (q & 2) ? (double)(n[1] - 1) - d.off[1] : -d.off[1],
+                              (q & 1) ? (double)(n[2] - 1) - d.off[2] : -d.off[2]};
+        for (int k = 0; k < 3; ++k) {
+            const double o = inv[3 * k] * in[0] + inv[3 * k + 1] * in[1] + inv[3 * k + 2] * in[2];
+            bl[k] = std::min(bl[k], o);
+            bh[k] = std::max(bh[k], o);
+        }
+    }
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = (int)std::max(0.0, std::floor(bl[k]) - 2.0);
+        hi[k] = (int)std::min((double)shape[k] - 1.0, std::ceil(bh[k]) + 2.0);
+    }
 }

@@ -30,5 +30,8 @@ struct DevView {
 
 
 int mvs_fill_dev_view(MvsContext* c, const mvs_view_t& v, int ndim, const void* dev_data, DevView* d);
-void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, float cval, float* out, const int64_t shape[3]);
-void mvs_launch_blend(MvsContext* c, const DevView& d, float* out, const int64_t shape[3]);
+// `box0` (may be null): chunk index of the output array's first voxel -- the output is a sub-box of the chunk, evaluated with the
+// chunk's own coordinates
+void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, float cval, float* out, const int64_t shape[3], const int* box0 = nullptr);
+void mvs_launch_blend(MvsContext* c, const DevView& d, float* out, const int64_t shape[3], const int* box0 = nullptr);
+void mvs_view_chunk_box(const DevView& d, const int64_t shape[3], int lo[3], int hi[3]);
