@@ -68,6 +68,8 @@ typedef struct mvs_view_t {
     float edt[125];        /* support table, (nz,5,5) row-major, nz = 5 (3D) or 1 (2D);
                               distance_transform_edt of weights.py:459-464 cast to f32 */
     int32_t reserved;
+    int64_t index_offset[3]; /* index frame (see mvs_fuse_opts_t.index_origin): first pixel of this slab in the pixel grid
+                              that `offset` refers to; 0 = `offset` refers to the slab itself (the reference's per-chunk form) */
 } mvs_view_t;
 
 typedef struct mvs_fuse_opts_t {
@@ -81,6 +83,15 @@ typedef struct mvs_fuse_opts_t {
     float sigma_2;
     int32_t out_dtype;     /* dtype of the result = input dtype (_core.py:1713)       */
     int32_t out_mem;       /* where `out` lives                                       */
+    int64_t index_origin[3]; /* INDEX FRAME.  The reference derives matrix / offset / w_offset per chunk from the chunk's and
+                              the slab's origins and rounds them to 10 decimals (transformation.py:72-83), so two chunkings of
+                              one mosaic differ by ~1e-9 px in the blend weights -- one count on ~1e-5 of the voxels.  A caller
+                              that fuses a stack chunk by chunk (fusion.fuse, the multi-GPU shards) may instead derive every
+                              view's parameters ONCE, for output index 0 = a common frame origin (the stack's first voxel) and
+                              for pixel 0 of the WHOLE view, and pass here the index of this chunk's first voxel (incl. halo)
+                              in that frame and in mvs_view_t.index_offset the first pixel of each slab.  The integer parts
+                              are then shifted as integers: every voxel gets the same parameters whatever chunk it falls in.
+                              All zeros (the default) = the reference's per-chunk form. */
 } mvs_fuse_opts_t;
 
 /* ---- context ---------------------------------------------------------------- */

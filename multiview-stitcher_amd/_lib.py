@@ -38,6 +38,7 @@ class mvs_view_t(C.Structure):
         ("w_offset", C.c_double * 3),
         ("edt", C.c_float * 125),
         ("reserved", C.c_int32),
+        ("index_offset", C.c_int64 * 3),
     ]
 
 
@@ -53,6 +54,7 @@ class mvs_fuse_opts_t(C.Structure):
         ("sigma_2", C.c_float),
         ("out_dtype", C.c_int32),
         ("out_mem", C.c_int32),
+        ("index_origin", C.c_int64 * 3),
     ]
 
 

@@ -866,29 +866,40 @@ __global__ __launch_bounds__(256) void fuse_tr_kernel(TrParams P) {
 // ---- host side of the fast path ---------------------------------------------------------------
 // c(i) = fl(i + off) is what the generic kernel (and scipy) test against [0, n-1] for an identity
 // matrix; it is monotone in i, so the in-bounds set is an integer interval found exactly here.
-static void exact_valid_range(double off, int n, int n_out, int* lo_out, int* hi_out) {
+// Index frame (mvs_fuse_opts_t.index_origin): `off` refers to frame index i = chunk index + org and to the whole view's pixel
+// grid, in which the slab starts at pixel `ioff`: in bounds iff ioff <= fl(i + off) <= ioff + n - 1.
+static void exact_valid_range(double off, int n, int n_out, int* lo_out, int* hi_out, long long org = 0, long long ioff = 0) {
     auto c = [off](long long i) { return (double)i + off; };
-    long long lo = (long long)ceil(-off);
-    while (lo > 0 && c(lo - 1) >= 0.0) --lo;
-    while (c(lo) < 0.0) ++lo;
-    long long hi = (long long)floor((double)(n - 1) - off);
-    while (c(hi + 1) <= (double)(n - 1)) ++hi;
-    while (c(hi) > (double)(n - 1)) --hi;
+    const double cmin = (double)ioff, cmax = (double)(ioff + n - 1);
+    long long lo = (long long)ceil(cmin - off);
+    while (c(lo - 1) >= cmin) --lo;
+    while (c(lo) < cmin) ++lo;
+    long long hi = (long long)floor(cmax - off);
+    while (c(hi + 1) <= cmax) ++hi;
+    while (c(hi) > cmax) --hi;
+    lo -= org;
+    hi -= org;
     if (lo < 0) lo = 0;
     if (hi > n_out - 1) hi = n_out - 1;
-    *lo_out = (int)lo;
-    *hi_out = (int)hi;   // lo > hi: the view never contributes
+    *lo_out = (int)std::min<long long>(lo, 0x7fffffff);
+    *hi_out = (int)std::max<long long>(hi, -1);   // lo > hi: the view never contributes
 }
 
 // Decide whether a view qualifies for the translation fast path and derive its constants.
-static void prepare_translation_view(DevView* d, int order, int fusion, const int64_t chunk_shape[3], size_t elem_size) {
+static void prepare_translation_view(DevView* d, int order, int fusion, const int64_t chunk_shape[3], size_t elem_size,
+                                     const int64_t* org = nullptr, const int64_t* ioff = nullptr) {
+    static const int64_t zero3[3] = {0, 0, 0};
+    if (!org) org = zero3;
+    if (!ioff) ioff = zero3;
     d->tr_ok = 0;
     static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     for (int k = 0; k < 9; ++k)
         if (d->m[k] != I9[k]) return;
     const int n[3] = {d->nz, d->ny, d->nx};
     for (int k = 0; k < 3; ++k) {
-        if (!(fabs(d->off[k]) < 65536.0) || n[k] > 65536 || chunk_shape[k] > 65536) return;
+        if (!(fabs(d->off[k]) < 1048576.0) || n[k] > 65536 || chunk_shape[k] > 65536) return;
+        if (std::llabs(org[k]) > (1 << 24) || std::llabs(ioff[k]) > (1 << 24)) return;
+        if (!(fabs(d->off[k] + (double)(org[k] - ioff[k])) < 65536.0)) return;
     }
     if (fusion == MVS_FUSE_WEIGHTED_AVERAGE) {
         const int offd[6] = {1, 2, 3, 5, 6, 7};
@@ -922,13 +933,13 @@ static void prepare_translation_view(DevView* d, int order, int fusion, const in
             if (k == 0 && nz == 1) continue;
             const double wm = d->wm[k * 4], wo = d->woff[k];
             if (!(wm > 0.0)) return;
-            const double lo = -wo / wm;          // chunk index where the support coordinate is 0
+            const double lo = -wo / wm;          // frame index where the support coordinate is 0
             const double hi = (4.0 - wo) / wm;   // ... and 4
             if (!(fabs(lo) < 1e6) || !(fabs(hi) < 1e6)) return;
             d->sup_k[k] = (float)wm;
-            d->sup_ilo[k] = (int)floor(lo);
+            d->sup_ilo[k] = (int)((long long)floor(lo) - org[k]);     // chunk index = frame index - org (integers: exact)
             d->sup_flo[k] = (float)(lo - floor(lo));
-            d->sup_ihi[k] = (int)ceil(hi);
+            d->sup_ihi[k] = (int)((long long)ceil(hi) - org[k]);
             d->sup_fhi[k] = (float)(ceil(hi) - hi);
         }
     }
@@ -938,15 +949,17 @@ static void prepare_translation_view(DevView* d, int order, int fusion, const in
     if ((long long)d->span * (long long)elem_size >= (1ll << 31) - (1ll << 27) || (long long)d->stride_z * (long long)elem_size >= (1ll << 26)) return;
     for (int k = 0; k < 3; ++k) {
         const double off = d->off[k];
+        // slab pixel = chunk index + org + off - ioff: the integer parts are combined as integers, so the fraction (and with
+        // it every interpolation weight) does not depend on which chunk / slab the voxel is seen through
         if (order == 0) {
-            d->io[k] = (int)floor(off + 0.5);
+            d->io[k] = (int)((long long)floor(off + 0.5) + org[k] - ioff[k]);
             d->fw[k] = 0.f;
         } else {
             const double f = floor(off);
-            d->io[k] = (int)f;
+            d->io[k] = (int)((long long)f + org[k] - ioff[k]);
             d->fw[k] = (float)(off - f);
         }
-        exact_valid_range(off, n[k], (int)chunk_shape[k], &d->lo[k], &d->hi[k]);
+        exact_valid_range(off, n[k], (int)chunk_shape[k], &d->lo[k], &d->hi[k], org[k], ioff[k]);
     }
     d->pad[0] = (order == 0) ? 0.f : 1.f;   // carried into TrView.linear
     d->tr_ok = 1;
@@ -1189,7 +1202,8 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
         }
         rc = fill_dev_view(c, views[i], opts->ndim, dptr, &hviews[i]);
         if (rc) return rc;
-        prepare_translation_view(&hviews[i], opts->order, opts->fusion, opts->out_shape, es);
+        prepare_translation_view(&hviews[i], opts->order, opts->fusion, opts->out_shape, es, opts->index_origin, views[i].index_offset);
+        mvs_view_to_chunk_frame(&hviews[i], opts->index_origin, views[i].index_offset);
     }
     bool use_tr = !c->force_generic;
     for (int i = 0; i < n_views && use_tr; ++i) use_tr = hviews[i].tr_ok != 0;
@@ -1461,6 +1475,18 @@ void mvs_launch_blend(MvsContext* c, const DevView& d, float* out, const int64_t
     const int nblocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(blend_kernel, dim3(nblocks), dim3(256), 0, c->stream, d, out, (int)shape[0], (int)shape[1], (int)shape[2],
                        box0 ? box0[0] : 0, box0 ? box0[1] : 0, box0 ? box0[2] : 0);
+}
+
+// Index frame -> chunk frame for the kernels that evaluate the full affine map per voxel (generic fuse kernel, resample,
+// blend): c = M (p + org) + off - ioff = M p + (off + M org - ioff).  (The translation fast path keeps the integer parts apart,
+// see prepare_translation_view; here the last bit of a coordinate may depend on the chunk, as it does in the reference.)
+void mvs_view_to_chunk_frame(DevView* d, const int64_t org[3], const int64_t ioff[3]) {
+    if (!(org[0] | org[1] | org[2] | ioff[0] | ioff[1] | ioff[2])) return;
+    const double o[3] = {(double)org[0], (double)org[1], (double)org[2]};
+    for (int k = 0; k < 3; ++k) {
+        d->off[k] = (((o[0] * d->m[3 * k] + o[1] * d->m[3 * k + 1]) + o[2] * d->m[3 * k + 2]) + d->off[k]) - (double)ioff[k];
+        d->woff[k] = ((o[0] * d->wm[3 * k] + o[1] * d->wm[3 * k + 1]) + o[2] * d->wm[3 * k + 2]) + d->woff[k];
+    }
 }
 
 // Chunk-index box [lo, hi] (inclusive; lo > hi: empty) outside of which view `d` is certainly out of bounds: exact for

@@ -35,3 +35,4 @@ int mvs_fill_dev_view(MvsContext* c, const mvs_view_t& v, int ndim, const void* 
 void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, float cval, float* out, const int64_t shape[3], const int* box0 = nullptr);
 void mvs_launch_blend(MvsContext* c, const DevView& d, float* out, const int64_t shape[3], const int* box0 = nullptr);
 void mvs_view_chunk_box(const DevView& d, const int64_t shape[3], int lo[3], int hi[3]);
+void mvs_view_to_chunk_frame(DevView* d, const int64_t org[3], const int64_t ioff[3]);

@@ -346,6 +346,7 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
         }
         int rc = mvs_fill_dev_view(c, views[i], opts->ndim, dptr, &dvs[i]);
         if (rc) return rc;
+        mvs_view_to_chunk_frame(&dvs[i], opts->index_origin, views[i].index_offset);
         int lo[3], hi[3];
         mvs_view_chunk_box(dvs[i], cs, lo, hi);
         CbBox& B = boxes[i];

@@ -128,6 +128,7 @@ def fuse_np(
     output_on_backend=False,
     device=0,
     out=None,
+    frame_origin=None,
 ):
     """Fuse the slabs ``sims`` of one output chunk (fusion.fuse_np, _core.py:1513-1733).
 
@@ -137,6 +138,13 @@ def fuse_np(
     box (for blending weights and spacing, _core.py:1611-1646).  Returns an
     array of the chunk shape minus the trimmed halo in the input dtype; a
     ``DeviceArray`` when ``output_on_backend`` (or ``out``) is given.
+
+    ``frame_origin`` (dict per spatial dim, optional): the INDEX FRAME of include/mvs_hip.h.  The reference derives the
+    pixel offsets of every view -- and of its blend-weight support grid -- from the chunk's and the slab's origins and
+    rounds them to 10 decimals (transformation.py:72-83), so two chunkings of one stack differ by ~1e-9 px in the
+    weights.  With a frame origin (``fuse`` passes the output stack's) the parameters are derived once per view, for that
+    origin and the WHOLE view, and the chunk / slab enter as integer index shifts: a voxel gets the same result whatever
+    chunk, launch block or shard it is computed in.  Needs chunk and slab origins on the frame's grids (else ignored).
     """
     if backend not in ("hip", None):
         raise ValueError("multiview_stitcher_amd.fusion.fuse_np only implements backend='hip'")
@@ -174,12 +182,24 @@ def fuse_np(
     p_inv = np.linalg.inv(p_stack)
     in_spacings = np.stack([_as_zyx(sp if sp is not None else si_utils.get_spacing_from_sim(sim), sdims) for sim, sp in zip(sims, spacings)])
     in_origins = np.stack([si_utils.get_origin_from_sim(sim, asarray=True) for sim in sims])
-    matrices, offsets = get_pixel_affines(p_inv, in_origins, in_spacings, out_origin, out_spacing)
     fv = [_bb_dicts(b, sdims) for b in full_view_bbs]
+    full_origins = np.stack([_as_zyx(b["origin"], sdims) for b in fv])
+    # index frame: chunk and slabs as integer shifts of parameters derived for (frame origin, whole view)
+    index_origin, index_offsets = np.zeros(3, np.int64), np.zeros((n, 3), np.int64)
+    ref_out_origin, ref_in_origins = out_origin, in_origins
+    if frame_origin is not None:
+        f_origin = _as_zyx(frame_origin, sdims)
+        io_ = (out_origin - f_origin) / out_spacing
+        so_ = (in_origins - full_origins) / in_spacings
+        if np.all(np.abs(io_ - np.round(io_)) < 1e-6) and np.all(np.abs(so_ - np.round(so_)) < 1e-6):
+            index_origin[3 - ndim:] = np.round(io_).astype(np.int64)
+            index_offsets[:, 3 - ndim:] = np.round(so_).astype(np.int64)
+            ref_out_origin, ref_in_origins = f_origin, full_origins
+    matrices, offsets = get_pixel_affines(p_inv, ref_in_origins, in_spacings, ref_out_origin, out_spacing)
     tables, sup_origins, sup_spacings = weights.blending_supports(
-        np.stack([_as_zyx(b["origin"], sdims) for b in fv]), np.stack([_as_zyx(b["spacing"], sdims) for b in fv]),
+        full_origins, np.stack([_as_zyx(b["spacing"], sdims) for b in fv]),
         np.stack([_as_zyx(b["shape"], sdims) for b in fv]), sdims, blending_widths, shrink_distance)
-    w_matrices, w_offsets = get_pixel_affines(p_inv, sup_origins, sup_spacings, out_origin, out_spacing)
+    w_matrices, w_offsets = get_pixel_affines(p_inv, sup_origins, sup_spacings, ref_out_origin, out_spacing)
     ptrs, shapes, strides = np.zeros(n, np.uint64), np.ones((n, 3), np.int64), np.zeros((n, 3), np.int64)
     mems = np.full(n, _lib.MVS_MEM_DEVICE, np.int32)
     for i, sim in enumerate(sims):
@@ -217,6 +237,7 @@ def fuse_np(
     field("offset", np.float64, 3)[:] = o3
     field("w_matrix", np.float64, 9)[:] = wm3
     field("w_offset", np.float64, 3)[:] = wo3
+    field("index_offset", np.int64, 3)[:] = index_offsets
     edt = field("edt", np.float32, 125)
     edt[:] = 0
     for i, table in enumerate(tables):
@@ -241,6 +262,8 @@ def fuse_np(
     opts.sigma_1 = float(wk.get("sigma_1", 5))
     opts.sigma_2 = float(wk.get("sigma_2", 11))
     opts.out_dtype = _lib.DTYPE_CODES[input_dtype]
+    for k in range(3):
+        opts.index_origin[k] = int(index_origin[k])
 
     if out is not None or output_on_backend:
         if out is None:
@@ -614,6 +637,7 @@ def _fuse_once(
     device=0,
     chunk_filter=None,
     merge_chunks=True,
+    frame_origin=None,
 ):
     """Fuse input views (fusion.fuse, _core.py:782-1501), eagerly, on the HIP backend.
 
@@ -634,6 +658,9 @@ def _fuse_once(
     of output for in-memory results (the whole mosaic when it fits: one ``mvs_fuse_chunk`` launch instead of hundreds), up to
     ``MAX_STREAM_BYTES`` when tiles are read from or the result is written to a Zarr store (a block is fused in one launch
     and written into its chunk files).  ``batch_options`` and ``chunk_filter`` address single chunks and switch this off.
+    ``frame_origin``: origin of the index frame all chunks are fused in (see ``fuse_np``); default: the output stack's
+    origin, so chunked, merged and unchunked runs of one stack agree voxel for voxel.  ``sharding.fuse_shard`` passes the
+    origin of the WHOLE mosaic, so that every rank's sub-box equals the corresponding part of the single-GPU result.
     """
     if images is None:
         if sims is None:
@@ -819,6 +846,9 @@ def _fuse_once(
             interpolation_order=interpolation_order, full_view_bbs=fvb, blending_widths=blending_widths,
             shrink_distance=shrink_distance, backend="hip", device=dev,
         )
+        if fusion_func in _FUSION_CODES and (weights_func is None or weights_func is content_based):
+            fo_ = frame_origin if frame_origin is not None else output_stack_properties["origin"]
+            kwargs["frame_origin"] = {d: fo_[d] for d in cbb_use["origin"]}
         return kwargs, sl
 
     if batch_options:

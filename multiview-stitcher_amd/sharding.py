@@ -203,6 +203,9 @@ def fuse_shard(sims, rank, world_size, transform_key, output_stack_properties=No
     boxes, _ = output_subboxes(osp, world_size, sdims)
     box = boxes[rank]
     sub = {k: box[k] for k in ("origin", "spacing", "shape")}
+    # the index frame of the WHOLE mosaic: every rank derives the views' parameters for the same origin and only shifts
+    # integer indices, so the union of the sub-boxes equals the single-GPU mosaic voxel for voxel
+    fuse_kwargs.setdefault("frame_origin", dict(osp["origin"]))
     fused = fusion.fuse(list(sims), transform_key=transform_key, output_stack_properties=sub, **fuse_kwargs)
     return fused, box
 

@@ -25,9 +25,9 @@ def test_header_symbols_exported_and_bound():
 
 
 def test_struct_sizes_match_header_layout():
-    # mvs_view_t: ptr + 2*i32 + 3*i64 + 3*i64 + 9+3+9+3 doubles + 125 floats + i32 (+pad to 8)
-    assert ctypes.sizeof(_lib.mvs_view_t) == 8 + 8 + 24 + 24 + 24 * 8 + 125 * 4 + 4
-    assert ctypes.sizeof(_lib.mvs_fuse_opts_t) == 16 + 24 + 24 + 8 + 8
+    # mvs_view_t: ptr + 2*i32 + 3*i64 + 3*i64 + 9+3+9+3 doubles + 125 floats + i32 + 3*i64 (index_offset)
+    assert ctypes.sizeof(_lib.mvs_view_t) == 8 + 8 + 24 + 24 + 24 * 8 + 125 * 4 + 4 + 24
+    assert ctypes.sizeof(_lib.mvs_fuse_opts_t) == 16 + 24 + 24 + 8 + 8 + 24
 
 
 def test_version_and_no_device_error_path():

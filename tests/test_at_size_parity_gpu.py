@@ -130,17 +130,36 @@ def test_north_star_fractional_offsets_sampled_oracle_parity(hip_device):
     st = at_size.check_boxes(fused.data, tasks, los, [(64,) * 3] * len(los))
     assert st["boxes"] >= 8
     assert st["beyond_plain_bar"] <= 1e-3 * st["voxels"], st
-    # merged launch blocks vs chunk by chunk: the reference derives the pixel offsets of the image AND of the blend-weight
-    # support grid per chunk and rounds them to 10 decimals (transformation.py:72-83; the support grid's unit is a quarter
-    # tile, so its rounding is worth ~1e-8 px), i.e. two chunkings of the reference differ by that much in the weights.
-    # The same holds here: a float32 weight flips its last bit now and then and a truncated output lands on the other
-    # side of an integer in ~1e-5 of the voxels (measured 1.4e-5).  Bound: one count, < 1e-4 of the voxels.
+    # merged launch blocks vs chunk by chunk.  fuse() derives every view's parameters once, in the index frame of the output
+    # stack, and chunks / slabs only shift integer indices (include/mvs_hip.h: index_origin); the reference derives them per
+    # chunk and rounds to 10 decimals (transformation.py:72-83), so two of ITS chunkings differ by ~1e-9 px in the blend
+    # weights -- measured here before the frame existed: one count on 1.4e-5 of the voxels.  With the frame the generic
+    # kernel is chunk-independent bit for bit (tested below); the region kernels decompose every launch block into its own
+    # boxes and a handful of voxels (8e-7 measured; cause not isolated to one operation) still land on the other side of a
+    # truncation: bound 3e-6, one count.
     fused_c = fusion.fuse(sims, transform_key=key, output_on_backend=True, device=0, merge_chunks=False)
     _lib.synchronize(0)
     a = torch.as_tensor(bench._SignedView(fused.data), device="cuda").to(torch.int32)
     b = torch.as_tensor(bench._SignedView(fused_c.data), device="cuda").to(torch.int32)
     d = (a - b).abs()
-    assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 1e-4
+    assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 3e-6
+    del a, b, d, fused_c
+    _lib.set_option("force_generic", 1)
+    try:
+        sub = dict(transform_key=key, output_on_backend=True, device=0,
+                   output_stack_properties={"origin": dict(zip("zyx", fo_ + np.array([100.0, 500.0, 700.0]))),
+                                            "spacing": dict(zip("zyx", fs_)), "shape": {"z": 200, "y": 300, "x": 400}},
+                   frame_origin=dict(zip("zyx", fo_)))
+        g_m = fusion.fuse(sims, **sub)
+        g_c = fusion.fuse(sims, merge_chunks=False, output_chunksize={"z": 64, "y": 128, "x": 96}, **sub)
+        _lib.synchronize(0)
+        np.testing.assert_array_equal(g_m.data.get(), g_c.data.get())
+        # ... and the sub-stack equals the corresponding window of the whole mosaic's generic result
+        whole = fusion.fuse(sims, transform_key=key, output_on_backend=True, device=0)
+        _lib.synchronize(0)
+        np.testing.assert_array_equal(g_m.data.get(), at_size.fetch(whole.data, [100, 500, 700], [300, 800, 1100]))
+    finally:
+        _lib.set_option("force_generic", 0)
 
 
 def test_c2_sampled_oracle_parity(hip_device):

@@ -79,10 +79,12 @@ def test_two_rank_shard_equals_single_device(hip_device):
         covered[sl] = True
     assert covered.all()
     np.testing.assert_array_equal(got, want)
-    # one launch block per sub-box (merge_chunks, the default): equal up to the float32 rounding of block-relative
-    # coordinates (the registered offsets are fractional)
+    # one launch block per sub-box (merge_chunks, the default): the same mosaic voxel for voxel -- the sub-boxes are fused in
+    # the index frame of the whole mosaic, chunks and launch blocks only shift integer indices
     for r in range(world):
         fused, box = sharding.fuse_shard(rank_sims[r], r, world, "reg", device=0 | (r << 8))
         sl = tuple(slice(box["index_offset"][d], box["index_offset"][d] + box["shape"][d]) for d in "zyx")
-        diff = np.asarray(fused.data).astype(np.int64) - want[(Ellipsis,) + sl].astype(np.int64)
-        assert np.abs(diff).max() <= 1 and (diff != 0).mean() < 0.02
+        # (a few voxels per million: the region kernels' box decomposition differs per launch block, see
+        # tests/test_at_size_parity_gpu.py::test_north_star_fractional_offsets...; the parameters themselves are identical)
+        d = np.abs(np.asarray(fused.data).astype(np.int64) - want[(Ellipsis,) + sl].astype(np.int64))
+        assert d.max() <= 1 and (d != 0).mean() < 2e-5
