@@ -747,11 +747,11 @@ __global__ __launch_bounds__(256) void fuse_tr_kernel(TrParams P) {
 #pragma unroll
                     for (int j = 0; j < kVPT; ++j) okj[j] = (unsigned)(j - jlo) <= (unsigned)jw;
                 }
-                float dl0 = 0.f, dh0 = 0.f, kx = 0.f;
+                float dlb = 0.f, dhb = 0.f, flo_ = 0.f, fhi_ = 0.f, kx = 0.f;     // (one rounding per voxel: see mvs_fuse_region.hip)
                 if (WA && needw) {
                     kx = rlf(sk_x, l0);
-                    dl0 = (float)(xc0 - rl(silo_x, l0)) - rlf(sflo_x, l0);
-                    dh0 = (float)(rl(sihi_x, l0) - xc0) - rlf(sfhi_x, l0);
+                    dlb = (float)(xc0 - rl(silo_x, l0)); flo_ = rlf(sflo_x, l0);
+                    dhb = (float)(rl(sihi_x, l0) - xc0); fhi_ = rlf(sfhi_x, l0);
                 }
                 const float uy = 1.f - wy;
                 float wt[kVPT] = {1.f, 1.f, 1.f, 1.f};
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(256) void fuse_tr_kernel(TrParams P) {
                             } else {
 #pragma unroll
                                 for (int j = 0; j < kVPT; ++j) {
-                                    const float u = fminf(dl0 + (float)j, dh0 - (float)j) * kx;
+                                    const float u = fminf((dlb + (float)j) - flo_, (dhb - (float)j) - fhi_) * kx;
                                     const float W = row_profile(u, G1r, dGr);
                                     wr[j] = (u >= 0.f && inside) ? blend_ramp_nb(W) : 0.f;
                                 }

@@ -524,11 +524,15 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
                     const float G1 = nd[0], dG = nd[1];
                     const int inside = nd[2] != 0.f;
                     const float kx = rec_fieldf<F_SK_X>(R, v);
-                    const float dl0 = (float)(xl - rec_field<F_SILO_X>(R, v)) - rec_fieldf<F_SFLO_X>(R, v);
-                    const float dh0 = (float)(rec_field<F_SIHI_X>(R, v) - xl) - rec_fieldf<F_SFHI_X>(R, v);
+                    // distances to the two ends of the support: (integer part + j) - fraction, ONE rounding per voxel exactly as
+                    // fold_u does it -- (base - fraction) + j would round twice and make the last bit of a weight depend on
+                    // where the lane's 8-voxel group starts, i.e. on the box decomposition of the launch block
+                    const float dlb = (float)(xl - rec_field<F_SILO_X>(R, v)), flo_ = rec_fieldf<F_SFLO_X>(R, v);
+                    const float dhb = (float)(rec_field<F_SIHI_X>(R, v) - xl), fhi_ = rec_fieldf<F_SFHI_X>(R, v);
+                    const float dl0 = dlb - flo_, dh0 = dhb - fhi_;
                     // The profile is concave along x, so over the lane's 8 voxels its minimum sits at voxel 0 or 7:
                     // two evaluations tell whether the whole segment has weight 1.
-                    const float u0 = fminf(dl0, dh0) * kx, u7 = fminf(dl0 + 7.f, dh0 - 7.f) * kx;
+                    const float u0 = fminf(dl0, dh0) * kx, u7 = fminf((dlb + 7.f) - flo_, (dhb - 7.f) - fhi_) * kx;
                     const float W0 = (u0 >= 0.f && inside) ? row_profile(u0, G1, dG) : 0.f;
                     const float W7 = (u7 >= 0.f && inside) ? row_profile(u7, G1, dG) : 0.f;
                     const bool lane_unit = fminf(W0, W7) >= ((nv == 1) ? 3e-4f : 1.f);   // one view: any weight > 0 yields the value
@@ -543,7 +547,7 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
                     } else {
 #pragma unroll
                         for (int j = 0; j < kRV; ++j) {
-                            const float u = fminf(dl0 + (float)j, dh0 - (float)j) * kx;
+                            const float u = fminf((dlb + (float)j) - flo_, (dhb - (float)j) - fhi_) * kx;
                             const float W = (u >= 0.f && inside) ? row_profile(u, G1, dG) : 0.f;
                             w[j] = blend_ramp_nb(W);
                         }

@@ -469,11 +469,11 @@ __device__ __forceinline__ void blend_cell(const TrView* __restrict__ views, con
                     bool inside;
                     row_nodes(V, zc, yl, G1, dG, inside);
                     const float kx = V.sup_k[2];
-                    const float dl0 = (float)(xl - V.sup_ilo[2]) - V.sup_flo[2];
-                    const float dh0 = (float)(V.sup_ihi[2] - xl) - V.sup_fhi[2];
+                    const float dlb = (float)(xl - V.sup_ilo[2]), dhb = (float)(V.sup_ihi[2] - xl);     // (one rounding per voxel: see mvs_fuse_region.hip)
+                    const float dl0 = dlb - V.sup_flo[2], dh0 = dhb - V.sup_fhi[2];
                     // The profile is concave along x, so over the lane's 8 voxels its minimum sits at voxel 0 or 7:
                     // two evaluations tell whether the whole segment has weight 1.
-                    const float u0 = fminf(dl0, dh0) * kx, u7 = fminf(dl0 + 7.f, dh0 - 7.f) * kx;
+                    const float u0 = fminf(dl0, dh0) * kx, u7 = fminf((dlb + 7.f) - V.sup_flo[2], (dhb - 7.f) - V.sup_fhi[2]) * kx;
                     const float W0 = (u0 >= 0.f && inside) ? row_profile(u0, G1, dG) : 0.f;
                     const float W7 = (u7 >= 0.f && inside) ? row_profile(u7, G1, dG) : 0.f;
                     const bool lane_unit = fminf(W0, W7) >= need;
@@ -488,7 +488,7 @@ __device__ __forceinline__ void blend_cell(const TrView* __restrict__ views, con
                     } else {
 #pragma unroll
                         for (int j = 0; j < kRV; ++j) {
-                            const float u = fminf(dl0 + (float)j, dh0 - (float)j) * kx;
+                            const float u = fminf((dlb + (float)j) - V.sup_flo[2], (dhb - (float)j) - V.sup_fhi[2]) * kx;
                             const float W = (u >= 0.f && inside) ? row_profile(u, G1, dG) : 0.f;
                             w[j] = blend_ramp_nb(W);
                         }
