@@ -272,6 +272,194 @@ int get_plan(MvsContext* c, int n, FftPlan* out) {
     return MVS_OK;
 }
 
+// ---- lengths beyond the LDS core (powers of two > 4096, other lengths > 2048): four-step transform in device memory ----
+// A line of length M = M1 x M2 (both powers of two <= 4096) is copied into a contiguous scratch line and seen as a matrix
+// [j1][j2], j = j1 M2 + j2: (A) M2 transforms of length M1 along j1, (B) twiddle exp(-+2 pi i k1 j2 / M), (C) M1 transforms of
+// length M2 along j2 -- all by the LDS kernel above, reading and writing the scratch array once per step; X[k2 M1 + k1] ends up
+// at [k1][k2].  A power-of-two length is scattered back from that transposed order.  Any other length runs as Bluestein's
+// chirp-z on this core: M >= 2 n - 1, the spectrum of the chirp filter is stored in the SAME transposed order, and the inverse
+// transform runs the three steps backwards (C', B', A'), which returns natural order -- no transpose at all.
+struct BigPlan {
+    int n = 0, M = 0, M1 = 0, M2 = 0;
+    bool pow2 = false;
+    float2* chirp = nullptr;     // n (Bluestein)
+    float2* bfft_t = nullptr;    // M, transposed order, scaled by 1 / M (Bluestein)
+};
+std::map<long long, BigPlan> g_big_plans;
+
+__global__ __launch_bounds__(256) void big_gather_kernel(const float2* __restrict__ data, float2* __restrict__ scr, long long l0, int nl, int n, int M,
+                                                         long long stride, long long inner, long long outer_stride,
+                                                         const float2* __restrict__ chirp, int inv) {
+    const long long total = (long long)nl * M;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        // lines fastest when they are adjacent in memory (stride != 1), positions fastest otherwise: coalesced either way
+        int line, k;
+        if (stride == 1) { line = (int)(i / M); k = (int)(i - (long long)line * M); }
+        else { k = (int)(i / nl); line = (int)(i - (long long)k * nl); }
+        float2 v = make_float2(0.f, 0.f);
+        if (k < n) {
+            const long long l = l0 + line;
+            v = data[(l / inner) * outer_stride + (l % inner) + (long long)k * stride];
+            if (chirp) {
+                if (inv) v.y = -v.y;              // IDFT(x) = conj(DFT(conj x))
+                v = cmul(v, chirp[k]);
+            }
+        }
+        scr[(long long)line * M + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void big_twiddle_kernel(float2* __restrict__ scr, long long total, int M, int M2, int log2M2, int conj_tw) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int pos = (int)(i & (M - 1));
+        const int k1 = pos >> log2M2, j2 = pos & (M2 - 1);
+        const int t = (int)(((long long)k1 * j2) & (M - 1));          // exp(-2 pi i t / M), the product taken modulo M exactly
+        float sn, cs;
+        sincospif(-2.f * (float)t / (float)M, &sn, &cs);
+        float2 w = make_float2(cs, conj_tw ? -sn : sn);
+        scr[i] = cmul(scr[i], w);
+    }
+}
+
+__global__ __launch_bounds__(256) void big_mul_kernel(float2* __restrict__ scr, const float2* __restrict__ b, long long total, int M) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x)
+        scr[i] = cmul(scr[i], b[i & (M - 1)]);
+}
+
+__global__ __launch_bounds__(256) void big_scatter_kernel(float2* __restrict__ data, const float2* __restrict__ scr, long long l0, int nl, int n, int M,
+                                                          int M1, int M2, long long stride, long long inner, long long outer_stride,
+                                                          const float2* __restrict__ chirp, int inv, int transposed) {
+    const long long total = (long long)nl * n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        int line, k;
+        if (stride == 1) { line = (int)(i / n); k = (int)(i - (long long)line * n); }
+        else { k = (int)(i / nl); line = (int)(i - (long long)k * nl); }
+        const int pos = transposed ? (k % M1) * M2 + (k / M1) : k;      // X[k2 M1 + k1] sits at [k1][k2]
+        float2 v = scr[(long long)line * M + pos];
+        if (chirp) {
+            v = cmul(v, chirp[k]);
+            if (inv) v.y = -v.y;
+        }
+        const long long l = l0 + line;
+        data[(l / inner) * outer_stride + (l % inner) + (long long)k * stride] = v;
+    }
+}
+
+int get_big_plan(MvsContext* c, int n, BigPlan* out) {
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    const long long key = ((long long)mvs_hip_device(c->device) << 32) | (unsigned)n;
+    auto it = g_big_plans.find(key);
+    if (it != g_big_plans.end()) { *out = it->second; return MVS_OK; }
+    BigPlan p;
+    p.n = n;
+    p.pow2 = (n & (n - 1)) == 0;
+    int M = 1;
+    if (p.pow2) M = n;
+    else while (M < 2 * n - 1) M <<= 1;
+    int log2M = 0;
+    while ((1 << log2M) < M) ++log2M;
+    p.M = M;
+    p.M1 = 1 << ((log2M + 1) / 2);
+    p.M2 = M / p.M1;
+    if (!p.pow2) {
+        std::vector<double> wr(n), wi(n);
+        std::vector<float2> chirp(n);
+        for (int k = 0; k < n; ++k) {
+            const long long k2 = ((long long)k * k) % (2LL * n);
+            const double a = -M_PI * (double)k2 / (double)n;
+            wr[k] = cos(a); wi[k] = sin(a);
+            chirp[k] = make_float2((float)wr[k], (float)wi[k]);
+        }
+        std::vector<double> br(M, 0.0), bi(M, 0.0);
+        br[0] = wr[0]; bi[0] = -wi[0];
+        for (int k = 1; k < n; ++k) {
+            br[k] = br[M - k] = wr[k];
+            bi[k] = bi[M - k] = -wi[k];
+        }
+        host_fft_pow2(br, bi);
+        std::vector<float2> bt(M);
+        for (int k1 = 0; k1 < p.M1; ++k1)
+            for (int k2 = 0; k2 < p.M2; ++k2) {
+                const int k = k2 * p.M1 + k1;
+                bt[(size_t)k1 * p.M2 + k2] = make_float2((float)(br[k] / M), (float)(bi[k] / M));
+            }
+        MVS_HIP_TRY(c, hipMalloc(&p.chirp, (size_t)n * sizeof(float2)));
+        MVS_HIP_TRY(c, hipMemcpy(p.chirp, chirp.data(), (size_t)n * sizeof(float2), hipMemcpyHostToDevice));
+        MVS_HIP_TRY(c, hipMalloc(&p.bfft_t, (size_t)M * sizeof(float2)));
+        MVS_HIP_TRY(c, hipMemcpy(p.bfft_t, bt.data(), (size_t)M * sizeof(float2), hipMemcpyHostToDevice));
+    }
+    g_big_plans[key] = p;
+    *out = p;
+    return MVS_OK;
+}
+
+// batched power-of-two line transforms (length <= 4096) of a scratch array through the LDS kernel
+int launch_pow2_lines(MvsContext* c, float2* data, int len, long long n_lines, long long stride, long long inner, long long outer_stride, bool inverse) {
+    FftPlan p;
+    int rc = get_plan(c, len, &p);
+    if (rc) return rc;
+    FftArgs A;
+    A.data = data;
+    A.n = len; A.M = p.M; A.log2M = p.log2M;
+    A.inverse = inverse ? 1 : 0;
+    A.tw = p.tw; A.chirp = nullptr; A.bfft = nullptr;
+    A.stride = stride; A.n_lines = n_lines; A.inner = inner; A.outer_stride = outer_stride;
+    int lpb = std::max(1, std::min(8, (stride == 1 ? 2048 : 4096) / p.M));
+    A.lpb = lpb;
+    const size_t lds = (2ull * lpb * p.M + p.M / 2 + 1) * sizeof(float2);
+    const long long nblocks = (n_lines + lpb - 1) / lpb;
+    if (nblocks > 0x7fffffffLL) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "FFT: too many lines");
+    MVS_HIP_TRY(c, hipFuncSetAttribute((const void*)fft_lines_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(fft_lines_kernel<false>, dim3((unsigned)nblocks), dim3(256), lds, c->stream, A);
+    MVS_HIP_TRY(c, hipGetLastError());
+    return MVS_OK;
+}
+
+int fft_axis_big(MvsContext* c, float2* data, int n, long long n_lines, long long stride, long long inner, long long outer_stride, bool inverse) {
+    if (n > (1 << 22)) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "FFT length %d > 4194304 not supported", n);
+    BigPlan p;
+    int rc = get_big_plan(c, n, &p);
+    if (rc) return rc;
+    int log2M2 = 0;
+    while ((1 << log2M2) < p.M2) ++log2M2;
+    const long long batch = std::max<long long>(1, std::min<long long>(n_lines, ((long long)256 << 20) / ((long long)p.M * 8)));
+    void* scr_v = nullptr;
+    rc = mvs_malloc(c->device, (uint64_t)batch * p.M * sizeof(float2), &scr_v);
+    if (rc) return rc;
+    float2* scr = (float2*)scr_v;
+    auto grid = [](long long total) { return (unsigned)std::min<long long>((total + 255) / 256, 256 * 32); };
+    for (long long l0 = 0; l0 < n_lines && !rc; l0 += batch) {
+        const int nl = (int)std::min<long long>(batch, n_lines - l0);
+        const long long total = (long long)nl * p.M;
+        const bool blu = !p.pow2;
+        // (when the lines are adjacent in memory, the batch must not straddle an outer block: the gather / scatter kernels
+        // address every line on its own, so any batch is fine)
+        hipLaunchKernelGGL(big_gather_kernel, dim3(grid(total)), dim3(256), 0, c->stream, data, scr, l0, nl, n, p.M, stride, inner, outer_stride,
+                           blu ? p.chirp : nullptr, inverse ? 1 : 0);
+        const bool inv1 = blu ? false : inverse;             // Bluestein: forward core transform first, inverse second
+        rc = launch_pow2_lines(c, scr, p.M1, (long long)nl * p.M2, p.M2, p.M2, p.M, inv1);                  // (A)
+        if (rc) break;
+        hipLaunchKernelGGL(big_twiddle_kernel, dim3(grid(total)), dim3(256), 0, c->stream, scr, total, p.M, p.M2, log2M2, inv1 ? 1 : 0);   // (B)
+        rc = launch_pow2_lines(c, scr, p.M2, (long long)nl * p.M1, 1, 1, p.M2, inv1);                       // (C)
+        if (rc) break;
+        if (blu) {
+            hipLaunchKernelGGL(big_mul_kernel, dim3(grid(total)), dim3(256), 0, c->stream, scr, p.bfft_t, total, p.M);
+            rc = launch_pow2_lines(c, scr, p.M2, (long long)nl * p.M1, 1, 1, p.M2, true);                   // (C')
+            if (rc) break;
+            hipLaunchKernelGGL(big_twiddle_kernel, dim3(grid(total)), dim3(256), 0, c->stream, scr, total, p.M, p.M2, log2M2, 1);          // (B')
+            rc = launch_pow2_lines(c, scr, p.M1, (long long)nl * p.M2, p.M2, p.M2, p.M, true);              // (A')
+            if (rc) break;
+        }
+        hipLaunchKernelGGL(big_scatter_kernel, dim3(grid((long long)nl * n)), dim3(256), 0, c->stream, data, scr, l0, nl, n, p.M, p.M1, p.M2, stride,
+                           inner, outer_stride, blu ? p.chirp : nullptr, inverse ? 1 : 0, blu ? 0 : 1);
+    }
+    hipError_t e = hipGetLastError();
+    mvs_free(c->device, scr_v);          // (stream-ordered pool: the block is only handed out again to work queued after this)
+    if (rc) return rc;
+    if (e != hipSuccess) return mvs_fail(c, MVS_ERR_HIP, "FFT four-step launch failed: %s", hipGetErrorString(e));
+    return MVS_OK;
+}
+
 }  // namespace
 
 // In-place 3D (or 2D when shape[0]==1) complex64 FFT of a C-contiguous (nz,ny,nx) array on c->stream.
@@ -281,7 +469,15 @@ int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inver
     for (int axis = 2; axis >= 0; --axis) {
         const int n = (int)shape[axis];
         if (n == 1) continue;
-        if (n > 4096) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "FFT length %d > 4096 not supported", n);
+        const bool pow2n = (n & (n - 1)) == 0;
+        if (n > 4096 || (!pow2n && n > 2048)) {      // beyond the LDS core (Bluestein of n > 2048 needs M = 8192 points per line)
+            int rcb;
+            if (axis == 2) rcb = fft_axis_big(c, data, n, nz * ny, 1, 1, nx, inverse);
+            else if (axis == 1) rcb = fft_axis_big(c, data, n, nz * nx, nx, nx, ny * nx, inverse);
+            else rcb = fft_axis_big(c, data, n, ny * nx, ny * nx, ny * nx, 0, inverse);
+            if (rcb) return rcb;
+            continue;
+        }
         FftPlan p;
         int rc = get_plan(c, n, &p);
         if (rc) return rc;

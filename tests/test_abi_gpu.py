@@ -21,10 +21,10 @@ def test_invalid_arguments_return_codes_and_messages(hip_device):
     assert rc < 0 and lib.mvs_last_error(0)
     with pytest.raises(RuntimeError, match="mvs_phasecorr"):
         _lib.check(rc, 0, "mvs_phasecorr")
-    # transform lengths above 4096 are refused, not silently mishandled
-    big = np.zeros((1, 2, 4100), np.complex64)
-    rc = lib.mvs_fft_c2c(0, big.ctypes.data, _lib.MVS_MEM_HOST, 2, _lib.i64x3((1, 2, 4100)), 0)
-    assert rc < 0 and b"4096" in lib.mvs_last_error(0)
+    # transform lengths beyond the four-step path (2^22) are refused, not silently mishandled
+    big = np.zeros((1, 1, (1 << 22) + 2), np.complex64)
+    rc = lib.mvs_fft_c2c(0, big.ctypes.data, _lib.MVS_MEM_HOST, 2, _lib.i64x3((1, 1, (1 << 22) + 2)), 0)
+    assert rc < 0 and b"4194304" in lib.mvs_last_error(0)
 
 
 def test_pool_recycles_blocks_and_copy_into_checks_bounds(hip_device):

@@ -221,6 +221,39 @@ def test_fft_c2c_matches_numpy(hip_device, shape, inverse):
     assert np.abs(got - want).max() <= 3e-6 * scale * np.log2(a.size)
 
 
+@pytest.mark.parametrize("shape", [(3, 8192), (2, 5000), (4, 3000), (4100, 5), (2, 8200, 3), (1, 16384), (1, 65536 + 2)])
+@pytest.mark.parametrize("inverse", [False, True])
+def test_fft_c2c_long_axes_match_numpy(hip_device, shape, inverse):
+    """Axes beyond the LDS core -- powers of two above 4096, other lengths above 2048 (scipy.fft inside registration.py:422-431
+    has no limit: an unbinned pair of an 8k camera frame) -- run as a four-step transform in device memory (Bluestein on top of
+    it for lengths that are no power of two); contiguous and strided axes, both directions."""
+    from multiview_stitcher_amd import _reg_ops
+
+    rng = np.random.default_rng(2)
+    a = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+    want = np.fft.ifftn(a.astype(np.complex128)) * a.size if inverse else np.fft.fftn(a.astype(np.complex128))
+    got = _reg_ops.fftn(a, inverse=inverse)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= 3e-6 * scale * np.log2(a.size)
+
+
+def test_phase_correlation_of_a_long_2d_pair(hip_device):
+    """A 2D overlap crop with an 8192-long axis (powers of two above 4096) and a 2500-long one (Bluestein above 2048):
+    integer peak index equal to the oracle's."""
+    from multiview_stitcher_amd import _reg_ops
+
+    rng = np.random.default_rng(3)
+    from scipy import ndimage
+    big = ndimage.gaussian_filter(rng.random((2600, 8300)).astype(np.float32), 2.0)
+    a = np.ascontiguousarray(big[40:2540, 50:8242])
+    b = np.ascontiguousarray(big[47:2547, 39:8231])
+    a, b = ro.rescale_intensity_01(a).astype(np.float32), ro.rescale_intensity_01(b).astype(np.float32)
+    want = ro.phase_cross_correlation(a, b, upsample_factor=1, normalization="phase")
+    got = _reg_ops.phase_cross_correlation(a, b, 1, "phase", device=0)
+    np.testing.assert_array_equal(np.asarray(got), np.asarray(want, dtype=np.float32))
+    np.testing.assert_array_equal(np.abs(np.asarray(got)), [7.0, 11.0])
+
+
 @pytest.mark.parametrize("case", ["2d", "3d", "3d_nan", "2d_nan_union", "upsample1"])
 def test_register_crops_equals_the_stepwise_flow(hip_device, case):
     """mvs_register_crops (the whole phase_correlation_registration in one call) against the step-by-step Python flow
