@@ -129,6 +129,27 @@ def _cpu_fuse_task(views, params, bbs, sub_bb):
     return float(np.prod(sub_bb["shape"]))
 
 
+def _slabs_for_chunk(views, params, bbs, sub_bb, margin=2):
+    """The reference hands every chunk task only the SLAB of each view that reaches into the chunk (fusion/_core.py:1371-1386);
+    so does this farm: (views, params, full-view boxes) restricted to the windows an order-1 resample onto ``sub_bb`` needs
+    (identity / translation parameters: the mosaic of the baseline sample)."""
+    out_v, out_p, out_b = [], [], []
+    lo_w = sub_bb["origin"]
+    hi_w = sub_bb["origin"] + (sub_bb["shape"] - 1) * sub_bb["spacing"]
+    for v, p, b in zip(views, params, bbs):
+        t = np.asarray(p)[:-1, -1]
+        a = np.floor((lo_w - t - v["origin"]) / v["spacing"]).astype(int) - margin
+        e = np.ceil((hi_w - t - v["origin"]) / v["spacing"]).astype(int) + margin + 1
+        a, e = np.maximum(a, 0), np.minimum(e, np.asarray(v["data"].shape))
+        if np.any(e <= a):
+            continue
+        sl = tuple(slice(int(x), int(y)) for x, y in zip(a, e))
+        out_v.append({"data": np.ascontiguousarray(v["data"][sl]), "origin": v["origin"] + a * v["spacing"], "spacing": v["spacing"]})
+        out_p.append(p)
+        out_b.append(b)
+    return out_v, out_p, out_b
+
+
 def _cpu_pair_task(a, b):
     from oracle import reg_oracle as ro
 
@@ -203,13 +224,14 @@ def cpu_baseline(args, grid, tile, overlap):
         tasks = []
         for _ in range(replicas):
             tasks += [delayed(_cpu_pair_task)(*pairs[k % 3]) for k in range(12)]      # (the long tasks first)
+        chunk_args = [_slabs_for_chunk(views, params, bbs, sb) + (sb,) for sb in subs]
         for _ in range(replicas):
-            tasks += [delayed(_cpu_fuse_task)(views, params, bbs, sb) for sb in subs]
+            tasks += [delayed(_cpu_fuse_task)(*a) for a in chunk_args if a[0]]
         env = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
         for k in env:
             os.environ[k] = "1"
         try:
-            nw = min(ncores, len(tasks))
+            nw = min(int(os.environ.get("MVS_CPU_WORKERS", ncores)), len(tasks))
             with Parallel(n_jobs=nw, backend="loky") as par:
                 par([delayed(_cpu_pair_task)(*(x[:8, :8, :8] for x in pairs[0]))] * nw)   # spawn + import the workers, untimed
                 t0 = time.perf_counter()
@@ -223,7 +245,8 @@ def cpu_baseline(args, grid, tile, overlap):
                     os.environ[k] = v
         out["all_cores"] = {"value": replicas * vox / t_all / 1e6, "unit": "Mvoxels/s", "cores": ncores, "workers": nw,
                             "tasks": len(tasks), "replicas": replicas, "wall_s": t_all,
-                            "sample": f"{replicas} replicas of the same mosaic job, each {len(subs)} output-chunk tasks + 12 pair "
+                            "sample": f"{replicas} replicas of the same mosaic job, each {len(subs)} output-chunk tasks (every task gets the "
+                                      f"slabs of the views reaching into its chunk, as the reference's chunk tasks do) + 12 pair "
                                       f"tasks, joblib loky, one thread per worker"}
     except Exception as e:      # noqa: BLE001 - the baseline must not take the bench line down
         out["all_cores"] = {"error": repr(e)[:200]}
