@@ -41,9 +41,13 @@ for _ in range(reps):
 vox = float(np.prod(out.shape))
 byt = len(sims) * float(np.prod(tile)) * 2 + vox * 2
 print("shape", out.shape, "kernel ms", ms, "GB/s", byt / (min(ms) * 1e-3) / 1e9)
-if os.environ.get("MVS_COMPARE"):        # the same mosaic through the region kernels alone: must agree voxel for voxel
+if os.environ.get("MVS_COMPARE"):        # the same mosaic through the generic kernel: must agree up to the knife-edge voxels
     a = out.data.get().astype(np.int32)
     _lib.set_option("rows_v1", 0); _lib.set_option("force_generic", 1)
     ref = fusion.fuse(sims, transform_key="k", output_chunksize={d: 1 << 30 for d in "zyx"}, output_on_backend=True, device=0)
+    print("generic kernel ms", _lib.last_kernel_ms(0))
     d = a - ref.data.get().astype(np.int32)
+    nz = np.argwhere(d != 0)
     print("compare: differing voxels", int((d != 0).sum()), "max |d|", int(np.abs(d).max()), "of", d.size)
+    for p in nz[:12]:
+        print("   ", tuple(int(v) for v in p), int(a[tuple(p)]), int(a[tuple(p)] - d[tuple(p)]))
