@@ -147,7 +147,24 @@ def check_boxes(fused_data, tasks, los, shapes, rtol=1e-4, int_boundary_rtol=1e-
         agg["lsb_flips"] += st["lsb_flips"]
         agg["max_floor_used"] = max(agg["max_floor_used"], st["max_floor_used"])
         agg["boxes"] += 1
+    _record(agg)
     return agg
+
+
+def _record(agg):
+    """With MVS_AT_SIZE_STATS=<file> every check appends its statistics (test id + counts) as one JSON line: the numbers behind
+    "how many voxels needed the noise floor" end up under profiles/ (tools/profile_round3.sh)."""
+    import json
+    import os
+
+    path = os.environ.get("MVS_AT_SIZE_STATS")
+    if not path:
+        return
+    rec = dict(agg)
+    rec["test"] = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    rec["beyond_plain_bar_frac"] = rec["beyond_plain_bar"] / max(rec["voxels"], 1)
+    with open(path, "a") as f:
+        f.write(json.dumps(rec) + "\n")
 
 
 class CapturePairs:

@@ -35,6 +35,7 @@ copies = {
     "host_profile.txt": "round3_host_profile.txt",
     "bench_line.json": "round3_bench_line.json",
     "pmc_summary.txt": "round3_pmc_summary.txt",
+    "at_size_parity.jsonl": "round3_at_size_parity.jsonl",
 }
 for pat, name in copies.items():
     f = find(pat)

@@ -5,6 +5,7 @@
 #   2. PMC passes (ONE counter per run, kernel-filtered) of the fuse launch: FETCH_SIZE / WRITE_SIZE for the region kernels
 #      (integer and fractional offsets, single-tile calibration) and for the content-based chunk pipeline
 #   3. HIP-event timings of the fuse launch, the content-based probe, host overheads, the bench line itself
+#   4. the at-size parity tests with their statistics recorded
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r3prof
@@ -35,4 +36,8 @@ python tools/cb_probe.py > $O/cb_probe.txt 2>&1
 python tools/pair_overhead.py > $O/pair_overhead.txt 2>&1
 python tools/host_profile.py 2>&1 | cut -c1-170 | grep -v "^$" | head -70 > $O/host_profile.txt
 timeout 1500 python bench.py --steps 10 --warmup 2 > $O/bench_line.json 2> $O/bench_line.err
+# 4. parity at BASELINE sizes: the statistics of every sampled-oracle check (voxels compared, how many needed the noise floor)
+rm -f $O/at_size_parity.jsonl
+MVS_AT_SIZE_STATS=$O/at_size_parity.jsonl timeout 900 python -m pytest tests/test_at_size_parity_gpu.py -q -m gpu > $O/at_size_parity.log 2>&1
+tail -2 $O/at_size_parity.log
 tail -3 $O/bench.log; cat $O/fuse_variants.txt; cat $O/cb_probe.txt | tail -3; head -c 2500 $O/bench_line.json
