@@ -4,7 +4,8 @@
 // the reference's registration.py:422-431.  The transform sizes are the overlap-crop shapes themselves
 // (registration.py:314-316: 104, 411, 27, 53, ...) and circular correlation depends on N, so there is no
 // padding to friendlier sizes: powers of two run as a radix-2 Stockham autosort FFT, every other N as
-// a Bluestein chirp-z transform built on the same Stockham core of size M = pow2 >= 2N-1.
+// a Bluestein chirp-z transform built on the same Stockham core of size M = pow2 >= 2N-1 -- except short lines (N <= 64: the
+// ~50-voxel axis of a binned overlap crop), which run as a direct DFT with the whole line in registers (dft_direct_kernel).
 //
 // A 3D transform is three passes over HBM (one per axis).  Each workgroup stages `lpb` lines in LDS
 // (two ping-pong buffers), runs log2(M) butterfly stages there and writes the lines back, so every
@@ -13,6 +14,7 @@
 #include "mvs_fft.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <vector>
 
@@ -200,6 +202,151 @@ struct FftPlan {
 
 std::map<long long, FftPlan> g_plans;   // key: device * 2^32 + n
 std::mutex g_plan_mu;
+
+// ---- direct DFT of short lines (n <= NMAX, not a power of two) --------------------------------------------------------------
+// Bluestein pays two length-M transforms (M >= 2 n - 1: 128 points for n = 51) plus three chirp multiplications per line, all
+// through LDS with a barrier per butterfly stage; for a short line the n^2 multiply-adds of the definition are cheaper.  A thread
+// owns one line: its n samples sit in registers (the j loop is unrolled to NMAX and leaves at n), the outputs are produced four
+// at a time, and the four factors exp(-2 pi i (j k mod n) / n) of a (k block, j) step are uniform across the wavefront: one
+// 32-byte scalar load from a table laid out in exactly that order, used as scalar operands of the multiply-adds.  In place: all
+// inputs are read before the first output is written.  Lines along y / z: the lines of a wavefront are adjacent x positions
+// (coalesced as in the LDS kernel); lines along x are staged through LDS so that global accesses stay contiguous.
+struct DftArgs {
+    float2* data;
+    long long n_lines;
+    int n;
+    long long stride, inner, outer_stride;
+    int inverse;
+    const float2* wtab;       // [ceil(n / 4)][round_up(n, 8)][4]: exp(-2 pi i (j k mod n) / n) for k = 4 kb + q (0 for j, k beyond n)
+};
+
+// KS wavefronts share a workgroup's 64 lines (and its table): wavefront w produces the output blocks w, w + KS, ... -- with one
+// wavefront per line set a 256 x 256 x 51 crop gives every SIMD exactly one wavefront and nothing hides the LDS latency.
+template <int NMAX, bool CONTIG, int KS>
+__global__ __launch_bounds__(64 * KS) void dft_direct_kernel(DftArgs A) {
+    // LDS: the factor table (uniform-address reads: broadcasts) and, for lines along x (CONTIG), a staging area [k][line] that turns
+    // contiguous global accesses into one line per thread
+    extern __shared__ float4 dft_lds[];
+    const int n = A.n;
+    const long long l0 = (long long)blockIdx.x * 64;
+    const int nl = (int)min((long long)64, A.n_lines - l0);
+    const int t = threadIdx.x & 63, ks = threadIdx.x >> 6;
+    const bool inv = A.inverse != 0;
+    const bool mine = t < nl;
+    const int nkb = (n + 3) >> 2, nj = (n + 7) & ~7;
+    float2* stage = reinterpret_cast<float2*>(dft_lds + (size_t)nkb * nj * 2);      // behind the table (lines along x only)
+    float2 x[NMAX];
+    long long base = 0;
+    if (CONTIG) {
+        // lines along x of a C-contiguous array: the nl lines of the workgroup are ONE contiguous run of nl * n samples
+        const int total = nl * n;
+        const float2* run = A.data + l0 * (long long)n;
+        for (int i = threadIdx.x; i < total; i += 64 * KS) {
+            const int line = i / n, k = i - line * n;
+            stage[k * 65 + line] = run[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) x[j] = (j < n) ? stage[j * 65 + t] : make_float2(0.f, 0.f);
+        __syncthreads();
+    } else {
+        const long long l = l0 + (mine ? t : 0);
+        base = (l / A.inner) * A.outer_stride + (l % A.inner);
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) {
+            x[j] = make_float2(0.f, 0.f);
+            if (j < n) x[j] = A.data[base + (long long)j * A.stride];
+        }
+    }
+    {   // the factor table: nkb * nj entries of 4 complex factors (32 bytes)
+        const float4* src = reinterpret_cast<const float4*>(A.wtab);
+        const int n16 = nkb * nj * 2;
+        for (int i = threadIdx.x; i < n16; i += 64 * KS) dft_lds[i] = src[i];
+    }
+    __syncthreads();
+    if (inv) {                                           // IDFT(x) = conj(DFT(conj x)), unnormalised
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) x[j].y = -x[j].y;
+    }
+    for (int kb = __builtin_amdgcn_readfirstlane(ks); kb < nkb; kb += KS) {      // (ks is uniform per wavefront)
+        // X = sum_j (x.re + i x.im) W = P + i Q with P = sum x.re W, Q = sum x.im W: both are plain packed multiply-adds of a
+        // broadcast real with the (re, im) pair of the factor -- no sign flips, no swaps inside the loop
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 P[4], Q[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { P[q] = (f2){0.f, 0.f}; Q[q] = (f2){0.f, 0.f}; }
+        const float4* wrow = dft_lds + (size_t)kb * nj * 2;
+#pragma unroll
+        for (int jb = 0; jb < NMAX; jb += 8) {
+            // 8 samples per uniform branch (samples and factors beyond n are zero)
+            if (jb < n) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float4 wa = wrow[(jb + u) * 2], wb = wrow[(jb + u) * 2 + 1];
+                    const f2 w[4] = {(f2){wa.x, wa.y}, (f2){wa.z, wa.w}, (f2){wb.x, wb.y}, (f2){wb.z, wb.w}};
+                    // v_pk_fma_f32 with the real (imaginary) part of the sample broadcast to both halves by the operand selects:
+                    // the sample stays ONE register pair (written as intrinsics the compiler keeps (re, re) and (im, im) copies
+                    // of all 64 samples and runs out of registers for a second wavefront per SIMD)
+                    const f2 xp = (f2){x[jb + u].x, x[jb + u].y};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(P[q]) : "v"(xp), "v"(w[q]));
+                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(Q[q]) : "v"(xp), "v"(w[q]));
+                    }
+                }
+            }
+        }
+        float2 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = make_float2(P[q].x - Q[q].y, P[q].y + Q[q].x);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int k = 4 * kb + q;
+            if (k < n) {
+                float2 v = acc[q];
+                if (inv) v.y = -v.y;
+                if (CONTIG) stage[k * 65 + t] = v;       // (all samples were read out of the staging area before the first barrier)
+                else if (mine) A.data[base + (long long)k * A.stride] = v;
+            }
+        }
+    }
+    if (CONTIG) {
+        __syncthreads();
+        const int total = nl * n;
+        float2* run = A.data + l0 * (long long)n;
+        for (int i = threadIdx.x; i < total; i += 64 * KS) {
+            const int line = i / n, k = i - line * n;
+            run[i] = stage[k * 65 + line];
+        }
+    }
+}
+
+constexpr int kDirectMax = 64;
+std::map<long long, float2*> g_direct_tabs;      // key: device * 2^32 + n
+
+int get_direct_table(MvsContext* c, int n, const float2** out) {
+    std::lock_guard<std::mutex> lock(g_plan_mu);
+    const long long key = ((long long)mvs_hip_device(c->device) << 32) | (unsigned)n;
+    auto it = g_direct_tabs.find(key);
+    if (it != g_direct_tabs.end()) { *out = it->second; return MVS_OK; }
+    const int nkb = (n + 3) / 4, nj = (n + 7) / 8 * 8;
+    std::vector<float2> tab((size_t)nkb * nj * 4, make_float2(0.f, 0.f));
+    for (int kb = 0; kb < nkb; ++kb)
+        for (int j = 0; j < n; ++j)
+            for (int q = 0; q < 4; ++q) {
+                const int k = 4 * kb + q;
+                if (k >= n) continue;
+                const double a = -2.0 * M_PI * (double)(((long long)j * k) % n) / (double)n;
+                tab[((size_t)kb * nj + j) * 4 + q] = make_float2((float)cos(a), (float)sin(a));
+            }
+    float2* d = nullptr;
+    MVS_HIP_TRY(c, hipMalloc(&d, tab.size() * sizeof(float2)));
+    MVS_HIP_TRY(c, hipMemcpy(d, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
+    g_direct_tabs[key] = d;
+    *out = d;
+    return MVS_OK;
+}
+
 
 void host_fft_pow2(std::vector<double>& re, std::vector<double>& im) {
     const size_t n = re.size();
@@ -476,6 +623,29 @@ int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inver
             else if (axis == 1) rcb = fft_axis_big(c, data, n, nz * nx, nx, nx, ny * nx, inverse);
             else rcb = fft_axis_big(c, data, n, ny * nx, ny * nx, ny * nx, 0, inverse);
             if (rcb) return rcb;
+            continue;
+        }
+        if (!pow2n && n <= kDirectMax) {               // short lines: direct DFT in registers
+            DftArgs D;
+            D.data = data;
+            D.n = n;
+            D.inverse = inverse ? 1 : 0;
+            int rcd = get_direct_table(c, n, &D.wtab);
+            if (rcd) return rcd;
+            if (axis == 2) { D.stride = 1; D.n_lines = nz * ny; D.inner = 1; D.outer_stride = nx; }
+            else if (axis == 1) { D.stride = nx; D.n_lines = nz * nx; D.inner = nx; D.outer_stride = ny * nx; }
+            else { D.stride = ny * nx; D.n_lines = ny * nx; D.inner = ny * nx; D.outer_stride = 0; }
+            const long long nblocks = (D.n_lines + 63) / 64;
+            const int nmax = n <= 32 ? 32 : 64;
+            const size_t tab_bytes = (size_t)((n + 3) / 4) * ((n + 7) / 8 * 8) * 32, stage_bytes = (size_t)nmax * 65 * sizeof(float2);   // rows padded to 65: the transposing accesses spread over the banks
+            const size_t lds = axis == 2 ? tab_bytes + stage_bytes : tab_bytes;
+#define MVS_DFT(NM, CT, KS) do { MVS_HIP_TRY(c, hipFuncSetAttribute((const void*)dft_direct_kernel<NM, CT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                                 hipLaunchKernelGGL((dft_direct_kernel<NM, CT, KS>), dim3((unsigned)nblocks), dim3(64 * KS), lds, c->stream, D); } while (0)
+            // 4 wavefronts per line set: measured 35.6 / 53.5 us (y or z / x lines of 51 samples, 256 x 256 of them) against 37.6 / 90 with 2
+            if (axis == 2) { if (nmax == 32) MVS_DFT(32, true, 4); else MVS_DFT(64, true, 4); }
+            else { if (nmax == 32) MVS_DFT(32, false, 4); else MVS_DFT(64, false, 4); }
+#undef MVS_DFT
+            MVS_HIP_TRY(c, hipGetLastError());
             continue;
         }
         FftPlan p;
