@@ -79,6 +79,24 @@ void* mvs_pinned_slot(MvsContext* c, int slot, size_t nbytes) {
 
 void* mvs_pinned(MvsContext* c, size_t nbytes) { return mvs_pinned_slot(c, 0, nbytes); }
 
+int mvs_mailbox(MvsContext* c, size_t nbytes, void** host, void** dev) {
+    if (nbytes > c->mbox_cap || !c->mbox_host) {
+        if (c->mbox_host) {
+            hipStreamSynchronize(c->stream);      // queued kernels may still write the old one
+            hipHostFree(c->mbox_host);
+            c->mbox_host = c->mbox_dev = nullptr;
+            c->mbox_cap = 0;
+        }
+        const size_t cap = std::max<size_t>(nbytes * 2, (size_t)256 << 10);
+        MVS_HIP_TRY(c, hipHostMalloc(&c->mbox_host, cap, hipHostMallocMapped));
+        MVS_HIP_TRY(c, hipHostGetDevicePointer(&c->mbox_dev, c->mbox_host, 0));
+        c->mbox_cap = cap;
+    }
+    *host = c->mbox_host;
+    *dev = c->mbox_dev;
+    return MVS_OK;
+}
+
 void mvs_pinned_mark(MvsContext* c, int slot) {
     const int k = slot ? 1 : 0;
     if (hipEventRecord(c->pinned_ev[k], c->stream) == hipSuccess) c->pinned_pending[k] = true;
@@ -157,6 +175,9 @@ void mvs_shutdown(int device) {
         s.ptr = nullptr;
         s.cap = 0;
     }
+    if (c->mbox_host) hipHostFree(c->mbox_host);
+    c->mbox_host = c->mbox_dev = nullptr;
+    c->mbox_cap = 0;
     if (c->pinned) hipHostFree(c->pinned);
     if (c->pinned2) hipHostFree(c->pinned2);
     c->pinned = c->pinned2 = nullptr;

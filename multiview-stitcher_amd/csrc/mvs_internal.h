@@ -61,6 +61,11 @@ struct MvsContext {
     // (calls that leave their result on the device return without synchronising): one event per staging slot
     hipEvent_t pinned_ev[2] = {nullptr, nullptr};
     bool pinned_pending[2] = {false, false};
+    // "mailbox": pinned host memory the device writes small results into directly (reduction partials, peak candidates): the host
+    // reads them after the stream wait -- no copy launch, no staging through pageable memory
+    void* mbox_host = nullptr;
+    void* mbox_dev = nullptr;
+    size_t mbox_cap = 0;
     bool no_regions = false;      // test switch: skip the region kernel (use the column kernel)
     bool rows_v1 = false;         // opt-in: direct-load row kernels (mvs_fuse_rows.hip) for every dtype (default: float tiles only)
     // caching device allocator behind mvs_malloc / mvs_free: freed blocks are kept (size-keyed) and handed out
@@ -80,6 +85,9 @@ void* mvs_scratch(MvsContext* c, int slot, size_t nbytes);   // nullptr on failu
 void* mvs_pinned(MvsContext* c, size_t nbytes);
 void* mvs_pinned_slot(MvsContext* c, int slot, size_t nbytes);   // slot 0 == mvs_pinned; waits for the slot's last upload
 void mvs_pinned_mark(MvsContext* c, int slot);                    // call after enqueueing the copies that read the slot
+// nbytes of the context's mailbox: *host for the CPU, *dev for kernels (same memory).  Valid until the next call that asks for more;
+// the caller waits for the stream before it reads.  Returns an MVS_* code.
+int mvs_mailbox(MvsContext* c, size_t nbytes, void** host, void** dev);
 
 #define MVS_HIP_TRY(c, expr)                                                         \
     do {                                                                             \

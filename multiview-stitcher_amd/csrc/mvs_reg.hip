@@ -203,6 +203,11 @@ __global__ void rescale_kernel(const float* __restrict__ src, float* __restrict_
 
 inline int grid_for(long long n) { return (int)std::min<long long>((n + 255) / 256, 256 * 8); }
 
+// a few bytes of device memory into the host-resident mailbox (instead of a copy launch through pageable memory)
+__global__ void peek_kernel(const unsigned int* __restrict__ src, unsigned int* __restrict__ dst, int nwords) {
+    for (int i = threadIdx.x; i < nwords; i += blockDim.x) dst[i] = src[i];
+}
+
 // fftfreq(n, d)[x] as numpy defines it
 inline double fftfreq(int n, double d, int x) {
     const int half = (n - 1) / 2 + 1;
@@ -241,8 +246,10 @@ int mvs_device_nanminmax(MvsContext* c, const float* d_in, long long n, float* m
 int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, long long n, float* out0, float* out1,
                             float mn[2], float mx[2], long long nvalid[2], long long n_not_u16[2]) {
     const int nb = grid_for(n);
-    char* scratch = (char*)mvs_scratch(c, 3, (size_t)nb * 32);
-    if (!scratch) return MVS_ERR_HIP;
+    void *mb_host = nullptr, *mb_dev = nullptr;       // the per-block partials land in host memory directly
+    int rcm = mvs_mailbox(c, (size_t)nb * 32, &mb_host, &mb_dev);
+    if (rcm) return rcm;
+    char* scratch = (char*)mb_dev;
     const float* ins[2] = {in0, in1};
     for (int k = 0; k < 2; ++k) {
         char* part = scratch + (size_t)k * nb * 16;
@@ -250,12 +257,10 @@ int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, l
                            (long long*)(part + (size_t)nb * 8));
     }
     MVS_HIP_TRY(c, hipGetLastError());
-    std::vector<char> h((size_t)nb * 32);
-    MVS_HIP_TRY(c, hipMemcpyAsync(h.data(), scratch, h.size(), hipMemcpyDeviceToHost, c->stream));
     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     float* outs[2] = {out0, out1};
     for (int k = 0; k < 2; ++k) {
-        const char* part = h.data() + (size_t)k * nb * 16;
+        const char* part = (const char*)mb_host + (size_t)k * nb * 16;
         const float* hmin = (const float*)part;
         const float* hmax = hmin + nb;
         const long long* hval = (const long long*)(part + (size_t)nb * 8);
@@ -386,9 +391,15 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
   // Two different normalisations: both correlations come out of ONE inverse transform (real and imaginary channel, see
   // xpower_packed_kernel) and one host round trip; otherwise one complex transform per normalisation.
   const bool packed = n_norm == 2 && (normalizations[0] != 0) != (normalizations[1] != 0) && !c->materialize_shifts;
-  char* red = (char*)mvs_scratch(c, 3, (size_t)gb * 32);
-  if (!red) return MVS_ERR_HIP;
-  std::vector<char> h((size_t)gb * 32);
+  // mailbox (host memory written by the kernels): [peak partials gb * 32 | z0 | refinement results of every normalisation]
+  const int up_U0 = (int)ceilf((float)upsample_factor * 1.5f);
+  const size_t res_elems = upsample_factor > 1 ? (ndim == 3 ? (size_t)up_U0 * up_U0 * up_U0 : (size_t)up_U0 * up_U0) : 0;
+  const size_t mb_red = (size_t)gb * 32, mb_z0 = mb_red, mb_res = mb_red + 256, mb_res_stride = (res_elems * sizeof(float2) + 255) / 256 * 256;
+  void *mb_host = nullptr, *mb_dev = nullptr;
+  rc = mvs_mailbox(c, mb_res + mb_res_stride * (size_t)n_norm, &mb_host, &mb_dev);
+  if (rc) return rc;
+  char* red = (char*)mb_dev;
+  const char* hred = (const char*)mb_host;
   float packed_scale[2] = {1.f, 1.f};
   if (packed) {
     hipLaunchKernelGGL(xpower_packed_kernel, dim3(gb), dim3(256), 0, c->stream, Z, P1, P2, CC, nz, ny, nx, normalizations[0] ? 1 : 0,
@@ -398,10 +409,10 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     hipLaunchKernelGGL(argmax_abs_kernel<1>, dim3(gb), dim3(256), 0, c->stream, CC, n, (float*)red, (long long*)(red + (size_t)gb * 8));
     hipLaunchKernelGGL(argmax_abs_kernel<2>, dim3(gb), dim3(256), 0, c->stream, CC, n, (float*)(red + (size_t)gb * 16), (long long*)(red + (size_t)gb * 24));
     MVS_HIP_TRY(c, hipGetLastError());
-    float2 z0;
-    MVS_HIP_TRY(c, hipMemcpyAsync(h.data(), red, h.size(), hipMemcpyDeviceToHost, c->stream));
-    MVS_HIP_TRY(c, hipMemcpyAsync(&z0, Z, sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+    hipLaunchKernelGGL(peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned int*)Z, (unsigned int*)((char*)mb_dev + mb_z0), 2);
+    MVS_HIP_TRY(c, hipGetLastError());
     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const float2 z0 = *(const float2*)((const char*)mb_host + mb_z0);
     // the channel scales of xpower_packed_kernel (exact powers of two), to report the peak height unscaled
     const float dc = std::fabs(z0.x * z0.y);
     const float s_plain = (dc > 0.f && dc < INFINITY) ? std::ldexp(1.f, -std::ilogb(dc)) : 1.f;
@@ -410,7 +421,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
   }
   // Per normalisation: integer peak -> upsampled DFT around it.  The refinements of all normalisations are queued before
   // the host waits once for their results (phase 2 below).
-  struct NormState { float shift[3]; std::vector<float2> hk, hres; size_t nout = 0; };   // hk stays alive until the wait (async upload)
+  struct NormState { float shift[3]; std::vector<float2> hk; size_t nout = 0; };   // hk stays alive until the wait (async upload)
   std::vector<NormState> state((size_t)n_norm);
   const int up_U = (int)ceilf((float)upsample_factor * 1.5f);
   const size_t up_kbytes = ((size_t)up_U * (size_t)(nz + ny + nx) * sizeof(float2) + 255) / 256 * 256;
@@ -426,14 +437,13 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     int64_t* peak_index_out = peak_indices_out ? peak_indices_out + 3 * inorm : nullptr;
     float* peak_abs_out = peak_abs_out_all ? peak_abs_out_all + inorm : nullptr;
     const float2* P = normalization ? P1 : P2;
-    const char* hpart = h.data() + (packed ? (size_t)inorm * gb * 16 : 0);
+    const char* hpart = hred + (packed ? (size_t)inorm * gb * 16 : 0);
     if (!packed) {
         hipLaunchKernelGGL(xpower_packed_kernel, dim3(gb), dim3(256), 0, c->stream, Z, P1, P2, CC, nz, ny, nx, normalization ? 1 : 0, -1);
         rc = mvs_fft3_c2c(c, CC, shape, true);   // cc (unnormalised inverse: argmax is scale invariant)
         if (rc) return rc;
         hipLaunchKernelGGL(argmax_abs_kernel<0>, dim3(gb), dim3(256), 0, c->stream, CC, n, (float*)red, (long long*)(red + (size_t)gb * 8));
         MVS_HIP_TRY(c, hipGetLastError());
-        MVS_HIP_TRY(c, hipMemcpyAsync(h.data(), red, (size_t)gb * 16, hipMemcpyDeviceToHost, c->stream));
         MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     float best = -1.f;
@@ -486,6 +496,8 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
         float2* o1 = (float2*)((char*)dk + up_kbytes);
         float2* o2 = o1 + s1;
         float2* o3 = o2 + s2;
+        float2* mres = (float2*)((char*)mb_dev + mb_res + mb_res_stride * (size_t)inorm);     // the last stage writes host memory
+        if (ndim == 3) o3 = mres; else o2 = mres;
         MVS_HIP_TRY(c, hipMemcpyAsync(dk, hk.data(), kbytes, hipMemcpyHostToDevice, c->stream));
         // stage 1: x  -> (z, y, ux)
         hipLaunchKernelGGL(updft_x_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, P, dk + koff[2], o1, nrows, nx, U);
@@ -501,8 +513,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
         }
         MVS_HIP_TRY(c, hipGetLastError());
         state[inorm].nout = nout;
-        state[inorm].hres.resize(nout);
-        MVS_HIP_TRY(c, hipMemcpyAsync(state[inorm].hres.data(), res, nout * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+        (void)res;
     }
   }
   MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
@@ -516,7 +527,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
         const int U = up_U;
         const float dftshift = truncf((float)U / 2.f);
         const int k0 = (ndim == 3) ? 0 : 1;
-        const std::vector<float2>& hres = state[inorm].hres;
+        const float2* hres = (const float2*)((const char*)mb_host + mb_res + mb_res_stride * (size_t)inorm);
         // argmax |.| (conj does not change the modulus), lowest flat index
         float bu = -1.f;
         size_t iu = 0;

@@ -1288,6 +1288,21 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     unsigned int* d_parts = B.take<unsigned int>((size_t)kHistParts * (kHistBinsMax / 2 + 1));   // per-workgroup packed histograms
     unsigned int* d_counter = B.take<unsigned int>(64);
     if (!d_counter) return mvs_fail(c, MVS_ERR_HIP, "mvs_score_candidates: scratch layout");
+    // results the host reads (reduction partials of the rank correlation, voxel and region statistics) are written by the kernels
+    // straight into the context's mailbox (pinned host memory): no copy launches
+    const size_t mb_partial = 0, mb_vox = ((size_t)gb * 4 * sizeof(double) + 255) / 256 * 256;
+    const size_t mb_reg = mb_vox + ((size_t)(kMaxResident + 2) * sizeof(VoxStats) + 255) / 256 * 256;
+    void *mb_host = nullptr, *mb_dev = nullptr;
+    {
+        const int rcm = mvs_mailbox(c, mb_reg + (size_t)kMaxResident * sizeof(RegionStats), &mb_host, &mb_dev);
+        if (rcm) return rcm;
+    }
+    partial = (double*)((char*)mb_dev + mb_partial);
+    vox_out = (VoxStats*)((char*)mb_dev + mb_vox);
+    reg_out = (RegionStats*)((char*)mb_dev + mb_reg);
+    const double* h_partial = (const double*)((const char*)mb_host + mb_partial);
+    const VoxStats* h_vox = (const VoxStats*)((const char*)mb_host + mb_vox);
+    const RegionStats* h_reg = (const RegionStats*)((const char*)mb_host + mb_reg);
 
     // valid voxels of im1 and the bboxes of both images (registration.py:400, 491)
     VoxStats h_im[2];
@@ -1303,8 +1318,9 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         hipLaunchKernelGGL(image_stats_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im0, S, vox_partial);
         hipLaunchKernelGGL(image_stats_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im1, S, vox_partial + kStatBlocks);
         hipLaunchKernelGGL(finish_voxstats_kernel, dim3(2), dim3(256), 0, c->stream, vox_partial, vox_out);
-        MVS_HIP_TRY(c, hipMemcpyAsync(h_im, vox_out, sizeof(h_im), hipMemcpyDeviceToHost, c->stream));
         MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        h_im[0] = h_vox[0];
+        h_im[1] = h_vox[1];
     }
     const int* bb0 = h_im[0].bb;
     const int* bbm = h_im[1].bb;
@@ -1391,9 +1407,9 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                                    d_rank + nbx, partial);
                 hipLaunchKernelGGL(hist_rank_kernel<true>, dim3(gb), dim3(256), 0, c->stream, c->raw_u16_keys[0], c->raw_u16_keys[1], S, t[0], t[1],
                                    t[2], (int)kx0, (int)nbx, (int)ky0, (int)nby, d_hist, d_hist + nbx, d_rank, d_rank + nbx, partial + 4, (unsigned int*)nullptr);
-                std::vector<double> hp((size_t)gb + 4);
-                MVS_HIP_TRY(c, hipMemcpyAsync(hp.data(), partial, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, c->stream));
+                MVS_HIP_TRY(c, hipGetLastError());
                 MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+                const double* hp = h_partial;
                 double sxy = 0;
                 for (int i = 0; i < gb; ++i) sxy += hp[4 + i];
                 spearman_out[ic] = sxy / std::sqrt(hp[0] * hp[2]);
@@ -1415,9 +1431,9 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         }
         MVS_HIP_TRY(c, rocprim::radix_sort_pairs(sort_temp, sort_temp_bytes, setA[3], setB[0], setA[4], setB[1], (size_t)m, 0, 32, c->stream));
         hipLaunchKernelGGL(rankcorr_kernel, dim3(mgb), dim3(256), 0, c->stream, setB[0], setB[1], m, 0.5 * ((double)m + 1.0), partial);
-        std::vector<double> hp((size_t)mgb * 3);
-        MVS_HIP_TRY(c, hipMemcpyAsync(hp.data(), partial, sizeof(double) * hp.size(), hipMemcpyDeviceToHost, c->stream));
+        MVS_HIP_TRY(c, hipGetLastError());
         MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const double* hp = h_partial;
         double sxy = 0, sxx = 0, syy = 0;
         for (int i = 0; i < mgb; ++i) { sxy += hp[i * 3]; sxx += hp[i * 3 + 1]; syy += hp[i * 3 + 2]; }
         spearman_out[ic] = sxy / std::sqrt(sxx * syy);
@@ -1496,8 +1512,8 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             hipLaunchKernelGGL(shift_batch_kernel, dim3(kStatBlocks, n_shift_batch), dim3(256), 0, c->stream, im1, im0, S, shift_batch, im1_all_finite);
         if (!on_the_fly) {
             hipLaunchKernelGGL(finish_voxstats_kernel, dim3(nb), dim3(256), 0, c->stream, vox_partial, vox_out);
-            MVS_HIP_TRY(c, hipMemcpyAsync(h_vs, vox_out, sizeof(VoxStats) * nb, hipMemcpyDeviceToHost, c->stream));
             MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+            for (int j = 0; j < nb; ++j) h_vs[j] = h_vox[j];
         }
 
         // ---- phase B: SSIM passes of every candidate that keeps enough jointly valid voxels ----
@@ -1579,8 +1595,8 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         for (int j = 0; j < nb; ++j) any = any || scored[j];
         if (any) {
             hipLaunchKernelGGL(finish_region_kernel, dim3(nb), dim3(256), 0, c->stream, pmax, phasnan, psum, reg_out);
-            MVS_HIP_TRY(c, hipMemcpyAsync(h_rs, reg_out, sizeof(RegionStats) * nb, hipMemcpyDeviceToHost, c->stream));
             MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+            for (int j = 0; j < nb; ++j) h_rs[j] = h_reg[j];
         }
         for (int j = 0; j < nb; ++j) {
             const int ic = todo[b0 + j];
