@@ -4,8 +4,9 @@
 // the reference's registration.py:422-431.  The transform sizes are the overlap-crop shapes themselves
 // (registration.py:314-316: 104, 411, 27, 53, ...) and circular correlation depends on N, so there is no
 // padding to friendlier sizes: powers of two run as a radix-2 Stockham autosort FFT, every other N as
-// a Bluestein chirp-z transform built on the same Stockham core of size M = pow2 >= 2N-1 -- except short lines (N <= 64: the
-// ~50-voxel axis of a binned overlap crop), which run as a direct DFT with the whole line in registers (dft_direct_kernel).
+// a Bluestein chirp-z transform built on the same Stockham core of size M = pow2 >= 2N-1.  Short lines -- powers of two up to
+// 256 and Bluestein sizes M <= 256 (N <= 128: the ~50-voxel axis of a binned overlap crop) -- run in registers around one or two
+// LDS exchanges instead (fft_reg2_kernel, bluestein_reg_kernel).
 //
 // A 3D transform is three passes over HBM (one per axis).  Each workgroup stages `lpb` lines in LDS
 // (two ping-pong buffers), runs log2(M) butterfly stages there and writes the lines back, so every
@@ -192,6 +193,181 @@ __global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs A) {
     }
 }
 
+// ---- short power-of-two lines (M = 64, 128, 256) in registers -----------------------------------------------------------------
+// M = R1 x R2: a thread gathers R1 samples of its line at stride R2, transforms them in registers (radix 4 x 4 / 4 x 2 / 4), applies
+// the twiddles exp(-2 pi i j' p / M) and leaves them in LDS; after ONE barrier a thread picks up the R2 values of one residue p and
+// transforms those: X[p + R1 k'].  Two register transforms, one LDS round trip and one barrier replace the log4(M) butterfly
+// stages of the Stockham kernel with their LDS round trip, barrier and index arithmetic each (28.5 -> 13.7 us for a
+// 256-point pass over a 256 x 256 x 51 crop).  The inverse is the forward transform of the input with real and imaginary parts
+// swapped, swapped back on output.
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 mul_mi(float2 a) { return make_float2(a.y, -a.x); }          // a * (-i)
+
+__device__ __forceinline__ void dft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    const float2 s02 = cadd(a0, a2), d02 = csub(a0, a2), s13 = cadd(a1, a3), d13 = mul_mi(csub(a1, a3));
+    a0 = cadd(s02, s13); a1 = cadd(d02, d13); a2 = csub(s02, s13); a3 = csub(d02, d13);
+}
+template <int R> __device__ __forceinline__ void dft_reg(float2 (&v)[R]);
+template <> __device__ __forceinline__ void dft_reg<4>(float2 (&v)[4]) { dft4(v[0], v[1], v[2], v[3]); }
+template <> __device__ __forceinline__ void dft_reg<8>(float2 (&v)[8]) {
+    // 8 = 4 x 2: DFT4 over q of v[2 q + r] (r = 0, 1), twiddle W8^(r p), DFT2 over r: X[p + 4 k] for k = 0, 1
+    dft4(v[0], v[2], v[4], v[6]);
+    dft4(v[1], v[3], v[5], v[7]);
+    constexpr float h = 0.70710678118654752440f;
+    const float2 t1 = make_float2((v[3].x + v[3].y) * h, (v[3].y - v[3].x) * h);       // * W8^1
+    const float2 t2 = mul_mi(v[5]);                                                    // * W8^2
+    const float2 t3 = make_float2((v[7].y - v[7].x) * h, -(v[7].x + v[7].y) * h);      // * W8^3
+    const float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+    v[1] = cadd(e1, t1); v[5] = csub(e1, t1);
+    v[2] = cadd(e2, t2); v[6] = csub(e2, t2);
+    v[3] = cadd(e3, t3); v[7] = csub(e3, t3);
+}
+template <> __device__ __forceinline__ void dft_reg<16>(float2 (&v)[16]) {
+    // 16 = 4 x 4: DFT4 over q of v[4 q + r], twiddle W16^(r p), DFT4 over r: X[p + 4 k]
+    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dft4(v[r], v[4 + r], v[8 + r], v[12 + r]);        // now v[4 p + r] holds y_r[p]
+    auto cm = [](float2 a, float wr, float wi) { return make_float2(a.x * wr - a.y * wi, a.x * wi + a.y * wr); };
+    // W16^k = (cos(pi k / 8), -sin(pi k / 8))
+    v[4 + 1] = cm(v[4 + 1], c1, -s1);  v[4 + 2] = cm(v[4 + 2], h, -h);    v[4 + 3] = cm(v[4 + 3], s1, -c1);
+    v[8 + 1] = cm(v[8 + 1], h, -h);    v[8 + 2] = mul_mi(v[8 + 2]);       v[8 + 3] = cm(v[8 + 3], -h, -h);
+    v[12 + 1] = cm(v[12 + 1], s1, -c1); v[12 + 2] = cm(v[12 + 2], -h, -h); v[12 + 3] = cm(v[12 + 3], -c1, s1);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) dft4(v[4 * p], v[4 * p + 1], v[4 * p + 2], v[4 * p + 3]);   // v[4 p + k] = X[p + 4 k]
+    // natural order: X[p + 4 k] sits at 4 p + k -> transpose the 4 x 4 block
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int k = p + 1; k < 4; ++k) { const float2 t = v[4 * p + k]; v[4 * p + k] = v[4 * k + p]; v[4 * k + p] = t; }
+}
+
+template <int R1, int R2>
+__global__ __launch_bounds__(256) void fft_reg2_kernel(FftArgs A) {
+    constexpr int M = R1 * R2, TPL = R1 > R2 ? R1 : R2, LPB = 256 / TPL;      // threads per line, lines per workgroup
+    constexpr int PS = R2 + 1, LS = R1 * PS + 1;                                // padded strides (float2): residue p, line
+    __shared__ float2 ex[LPB * LS];
+    __shared__ float2 tw[M / 2];
+    for (int t = threadIdx.x; t < M / 2; t += 256) tw[t] = A.tw[t];
+    const bool inv = A.inverse != 0;
+    const bool contig = A.stride == 1;
+    // along x threads run along the line first, along y / z along the lines (adjacent x positions) first: coalesced either way
+    const int line = contig ? (int)threadIdx.x / TPL : (int)threadIdx.x % LPB;
+    const int idx = contig ? (int)threadIdx.x % TPL : (int)threadIdx.x / LPB;
+    const long long l = (long long)blockIdx.x * LPB + line;
+    const bool live = l < A.n_lines;
+    const long long base = live ? line_base(A, (int)l) : 0;
+    float2* row = ex + line * LS;
+    __syncthreads();                                                             // (twiddles)
+    if (idx < R2) {                                                              // pass 1: j' = idx
+        float2 v[R1];
+#pragma unroll
+        for (int q = 0; q < R1; ++q) {
+            v[q] = make_float2(0.f, 0.f);
+            if (live) v[q] = A.data[base + (long long)(q * R2 + idx) * A.stride];
+            if (inv) v[q] = make_float2(v[q].y, v[q].x);
+        }
+        dft_reg<R1>(v);
+#pragma unroll
+        for (int p = 0; p < R1; ++p) {
+            const float2 w = p == 0 ? make_float2(1.f, 0.f) : tw_at(tw, idx * p, M / 2);
+            row[p * PS + idx] = p == 0 ? v[0] : cmul(v[p], w);
+        }
+    }
+    __syncthreads();
+    if (idx < R1) {                                                              // pass 2: p = idx
+        float2 u[R2];
+#pragma unroll
+        for (int j = 0; j < R2; ++j) u[j] = row[idx * PS + j];
+        dft_reg<R2>(u);
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < R2; ++k) {
+                const float2 o = inv ? make_float2(u[k].y, u[k].x) : u[k];
+                A.data[base + (long long)(idx + R1 * k) * A.stride] = o;
+            }
+        }
+    }
+}
+
+// Bluestein's chirp-z for short lines on the same register transforms (n <= 128: M = 64, 128 or 256 points): sample x chirp ->
+// forward transform (R1 then R2) -> x spectrum of the chirp filter -> inverse transform with the factors the other way round (R2
+// then R1: a thread ends the forward transform holding the residue class p mod R1, which is exactly what the first pass of an
+// (R2, R1) transform wants, so nothing moves in between) -> x chirp.  Two LDS exchanges per line instead of 2 log4(M) + 3.
+template <int R1, int R2>
+__global__ __launch_bounds__(256) void bluestein_reg_kernel(FftArgs A) {
+    constexpr int M = R1 * R2, TPL = R1 > R2 ? R1 : R2, LPB = 256 / TPL;
+    constexpr int PS = TPL + 1, LS = TPL * PS + 1;                               // padded strides (float2) that fit both exchanges
+    __shared__ float2 ex[LPB * LS];
+    __shared__ float2 tw[M / 2];
+    for (int t = threadIdx.x; t < M / 2; t += 256) tw[t] = A.tw[t];
+    const int n = A.n;
+    const bool inv = A.inverse != 0;
+    const bool contig = A.stride == 1;
+    const int line = contig ? (int)threadIdx.x / TPL : (int)threadIdx.x % LPB;
+    const int idx = contig ? (int)threadIdx.x % TPL : (int)threadIdx.x / LPB;
+    const long long l = (long long)blockIdx.x * LPB + line;
+    const bool live = l < A.n_lines;
+    const long long base = live ? line_base(A, (int)l) : 0;
+    float2* row = ex + line * LS;
+    __syncthreads();                                                             // (twiddles)
+    if (idx < R2) {                                                              // forward, pass 1: j' = idx
+        float2 v[R1];
+#pragma unroll
+        for (int q = 0; q < R1; ++q) {
+            const int j = q * R2 + idx;
+            v[q] = make_float2(0.f, 0.f);
+            if (live && j < n) {
+                float2 x = A.data[base + (long long)j * A.stride];
+                if (inv) x.y = -x.y;                                             // IDFT(x) = conj(DFT(conj x))
+                v[q] = cmul(x, A.chirp[j]);
+            }
+        }
+        dft_reg<R1>(v);
+#pragma unroll
+        for (int p = 0; p < R1; ++p) row[p * PS + idx] = p == 0 ? v[0] : cmul(v[p], tw_at(tw, idx * p, M / 2));
+    }
+    __syncthreads();
+    float2 u[R2];
+    if (idx < R1) {                                                              // forward, pass 2: p = idx holds X[p + R1 k]
+#pragma unroll
+        for (int j = 0; j < R2; ++j) u[j] = row[idx * PS + j];
+        dft_reg<R2>(u);
+        // x filter spectrum (scaled by 1 / M on the host); swap re / im: the inverse transform is a forward one of the swapped input
+#pragma unroll
+        for (int k = 0; k < R2; ++k) {
+            const float2 y = cmul(u[k], A.bfft[idx + R1 * k]);
+            u[k] = make_float2(y.y, y.x);
+        }
+        // inverse, pass 1 with the factors swapped (R2 then R1): this thread is j'' = idx and holds the samples q R1 + idx, q < R2
+        dft_reg<R2>(u);
+    }
+    __syncthreads();                                                             // everybody has read the first exchange
+    if (idx < R1) {
+#pragma unroll
+        for (int p = 0; p < R2; ++p) row[p * PS + idx] = p == 0 ? u[0] : cmul(u[p], tw_at(tw, idx * p, M / 2));
+    }
+    __syncthreads();
+    if (idx < R2) {                                                              // inverse, pass 2: p'' = idx -> Y[p'' + R2 k], k < R1
+        float2 w[R1];
+#pragma unroll
+        for (int j = 0; j < R1; ++j) w[j] = row[idx * PS + j];
+        dft_reg<R1>(w);
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < R1; ++k) {
+                const int m = idx + R2 * k;
+                if (m < n) {
+                    float2 y = cmul(make_float2(w[k].y, w[k].x), A.chirp[m]);
+                    if (inv) y.y = -y.y;
+                    A.data[base + (long long)m * A.stride] = y;
+                }
+            }
+        }
+    }
+}
+
 struct FftPlan {
     int n = 0, M = 0, log2M = 0;
     bool bluestein = false;
@@ -202,151 +378,6 @@ struct FftPlan {
 
 std::map<long long, FftPlan> g_plans;   // key: device * 2^32 + n
 std::mutex g_plan_mu;
-
-// ---- direct DFT of short lines (n <= NMAX, not a power of two) --------------------------------------------------------------
-// Bluestein pays two length-M transforms (M >= 2 n - 1: 128 points for n = 51) plus three chirp multiplications per line, all
-// through LDS with a barrier per butterfly stage; for a short line the n^2 multiply-adds of the definition are cheaper.  A thread
-// owns one line: its n samples sit in registers (the j loop is unrolled to NMAX and leaves at n), the outputs are produced four
-// at a time, and the four factors exp(-2 pi i (j k mod n) / n) of a (k block, j) step are uniform across the wavefront: one
-// 32-byte scalar load from a table laid out in exactly that order, used as scalar operands of the multiply-adds.  In place: all
-// inputs are read before the first output is written.  Lines along y / z: the lines of a wavefront are adjacent x positions
-// (coalesced as in the LDS kernel); lines along x are staged through LDS so that global accesses stay contiguous.
-struct DftArgs {
-    float2* data;
-    long long n_lines;
-    int n;
-    long long stride, inner, outer_stride;
-    int inverse;
-    const float2* wtab;       // [ceil(n / 4)][round_up(n, 8)][4]: exp(-2 pi i (j k mod n) / n) for k = 4 kb + q (0 for j, k beyond n)
-};
-
-// KS wavefronts share a workgroup's 64 lines (and its table): wavefront w produces the output blocks w, w + KS, ... -- with one
-// wavefront per line set a 256 x 256 x 51 crop gives every SIMD exactly one wavefront and nothing hides the LDS latency.
-template <int NMAX, bool CONTIG, int KS>
-__global__ __launch_bounds__(64 * KS) void dft_direct_kernel(DftArgs A) {
-    // LDS: the factor table (uniform-address reads: broadcasts) and, for lines along x (CONTIG), a staging area [k][line] that turns
-    // contiguous global accesses into one line per thread
-    extern __shared__ float4 dft_lds[];
-    const int n = A.n;
-    const long long l0 = (long long)blockIdx.x * 64;
-    const int nl = (int)min((long long)64, A.n_lines - l0);
-    const int t = threadIdx.x & 63, ks = threadIdx.x >> 6;
-    const bool inv = A.inverse != 0;
-    const bool mine = t < nl;
-    const int nkb = (n + 3) >> 2, nj = (n + 7) & ~7;
-    float2* stage = reinterpret_cast<float2*>(dft_lds + (size_t)nkb * nj * 2);      // behind the table (lines along x only)
-    float2 x[NMAX];
-    long long base = 0;
-    if (CONTIG) {
-        // lines along x of a C-contiguous array: the nl lines of the workgroup are ONE contiguous run of nl * n samples
-        const int total = nl * n;
-        const float2* run = A.data + l0 * (long long)n;
-        for (int i = threadIdx.x; i < total; i += 64 * KS) {
-            const int line = i / n, k = i - line * n;
-            stage[k * 65 + line] = run[i];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j) x[j] = (j < n) ? stage[j * 65 + t] : make_float2(0.f, 0.f);
-        __syncthreads();
-    } else {
-        const long long l = l0 + (mine ? t : 0);
-        base = (l / A.inner) * A.outer_stride + (l % A.inner);
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j) {
-            x[j] = make_float2(0.f, 0.f);
-            if (j < n) x[j] = A.data[base + (long long)j * A.stride];
-        }
-    }
-    {   // the factor table: nkb * nj entries of 4 complex factors (32 bytes)
-        const float4* src = reinterpret_cast<const float4*>(A.wtab);
-        const int n16 = nkb * nj * 2;
-        for (int i = threadIdx.x; i < n16; i += 64 * KS) dft_lds[i] = src[i];
-    }
-    __syncthreads();
-    if (inv) {                                           // IDFT(x) = conj(DFT(conj x)), unnormalised
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j) x[j].y = -x[j].y;
-    }
-    for (int kb = __builtin_amdgcn_readfirstlane(ks); kb < nkb; kb += KS) {      // (ks is uniform per wavefront)
-        // X = sum_j (x.re + i x.im) W = P + i Q with P = sum x.re W, Q = sum x.im W: both are plain packed multiply-adds of a
-        // broadcast real with the (re, im) pair of the factor -- no sign flips, no swaps inside the loop
-        typedef float f2 __attribute__((ext_vector_type(2)));
-        f2 P[4], Q[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { P[q] = (f2){0.f, 0.f}; Q[q] = (f2){0.f, 0.f}; }
-        const float4* wrow = dft_lds + (size_t)kb * nj * 2;
-#pragma unroll
-        for (int jb = 0; jb < NMAX; jb += 8) {
-            // 8 samples per uniform branch (samples and factors beyond n are zero)
-            if (jb < n) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float4 wa = wrow[(jb + u) * 2], wb = wrow[(jb + u) * 2 + 1];
-                    const f2 w[4] = {(f2){wa.x, wa.y}, (f2){wa.z, wa.w}, (f2){wb.x, wb.y}, (f2){wb.z, wb.w}};
-                    // v_pk_fma_f32 with the real (imaginary) part of the sample broadcast to both halves by the operand selects:
-                    // the sample stays ONE register pair (written as intrinsics the compiler keeps (re, re) and (im, im) copies
-                    // of all 64 samples and runs out of registers for a second wavefront per SIMD)
-                    const f2 xp = (f2){x[jb + u].x, x[jb + u].y};
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(P[q]) : "v"(xp), "v"(w[q]));
-                        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(Q[q]) : "v"(xp), "v"(w[q]));
-                    }
-                }
-            }
-        }
-        float2 acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = make_float2(P[q].x - Q[q].y, P[q].y + Q[q].x);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = 4 * kb + q;
-            if (k < n) {
-                float2 v = acc[q];
-                if (inv) v.y = -v.y;
-                if (CONTIG) stage[k * 65 + t] = v;       // (all samples were read out of the staging area before the first barrier)
-                else if (mine) A.data[base + (long long)k * A.stride] = v;
-            }
-        }
-    }
-    if (CONTIG) {
-        __syncthreads();
-        const int total = nl * n;
-        float2* run = A.data + l0 * (long long)n;
-        for (int i = threadIdx.x; i < total; i += 64 * KS) {
-            const int line = i / n, k = i - line * n;
-            run[i] = stage[k * 65 + line];
-        }
-    }
-}
-
-constexpr int kDirectMax = 64;
-std::map<long long, float2*> g_direct_tabs;      // key: device * 2^32 + n
-
-int get_direct_table(MvsContext* c, int n, const float2** out) {
-    std::lock_guard<std::mutex> lock(g_plan_mu);
-    const long long key = ((long long)mvs_hip_device(c->device) << 32) | (unsigned)n;
-    auto it = g_direct_tabs.find(key);
-    if (it != g_direct_tabs.end()) { *out = it->second; return MVS_OK; }
-    const int nkb = (n + 3) / 4, nj = (n + 7) / 8 * 8;
-    std::vector<float2> tab((size_t)nkb * nj * 4, make_float2(0.f, 0.f));
-    for (int kb = 0; kb < nkb; ++kb)
-        for (int j = 0; j < n; ++j)
-            for (int q = 0; q < 4; ++q) {
-                const int k = 4 * kb + q;
-                if (k >= n) continue;
-                const double a = -2.0 * M_PI * (double)(((long long)j * k) % n) / (double)n;
-                tab[((size_t)kb * nj + j) * 4 + q] = make_float2((float)cos(a), (float)sin(a));
-            }
-    float2* d = nullptr;
-    MVS_HIP_TRY(c, hipMalloc(&d, tab.size() * sizeof(float2)));
-    MVS_HIP_TRY(c, hipMemcpy(d, tab.data(), tab.size() * sizeof(float2), hipMemcpyHostToDevice));
-    g_direct_tabs[key] = d;
-    *out = d;
-    return MVS_OK;
-}
-
 
 void host_fft_pow2(std::vector<double>& re, std::vector<double>& im) {
     const size_t n = re.size();
@@ -625,29 +656,6 @@ int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inver
             if (rcb) return rcb;
             continue;
         }
-        if (!pow2n && n <= kDirectMax) {               // short lines: direct DFT in registers
-            DftArgs D;
-            D.data = data;
-            D.n = n;
-            D.inverse = inverse ? 1 : 0;
-            int rcd = get_direct_table(c, n, &D.wtab);
-            if (rcd) return rcd;
-            if (axis == 2) { D.stride = 1; D.n_lines = nz * ny; D.inner = 1; D.outer_stride = nx; }
-            else if (axis == 1) { D.stride = nx; D.n_lines = nz * nx; D.inner = nx; D.outer_stride = ny * nx; }
-            else { D.stride = ny * nx; D.n_lines = ny * nx; D.inner = ny * nx; D.outer_stride = 0; }
-            const long long nblocks = (D.n_lines + 63) / 64;
-            const int nmax = n <= 32 ? 32 : 64;
-            const size_t tab_bytes = (size_t)((n + 3) / 4) * ((n + 7) / 8 * 8) * 32, stage_bytes = (size_t)nmax * 65 * sizeof(float2);   // rows padded to 65: the transposing accesses spread over the banks
-            const size_t lds = axis == 2 ? tab_bytes + stage_bytes : tab_bytes;
-#define MVS_DFT(NM, CT, KS) do { MVS_HIP_TRY(c, hipFuncSetAttribute((const void*)dft_direct_kernel<NM, CT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                                 hipLaunchKernelGGL((dft_direct_kernel<NM, CT, KS>), dim3((unsigned)nblocks), dim3(64 * KS), lds, c->stream, D); } while (0)
-            // 4 wavefronts per line set: measured 35.6 / 53.5 us (y or z / x lines of 51 samples, 256 x 256 of them) against 37.6 / 90 with 2
-            if (axis == 2) { if (nmax == 32) MVS_DFT(32, true, 4); else MVS_DFT(64, true, 4); }
-            else { if (nmax == 32) MVS_DFT(32, false, 4); else MVS_DFT(64, false, 4); }
-#undef MVS_DFT
-            MVS_HIP_TRY(c, hipGetLastError());
-            continue;
-        }
         FftPlan p;
         int rc = get_plan(c, n, &p);
         if (rc) return rc;
@@ -665,7 +673,17 @@ int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inver
         A.lpb = lpb;
         const size_t lds = (2ull * lpb * p.M + p.M / 2 + 1) * sizeof(float2);   // two line buffers + the twiddles
         const long long nblocks = (A.n_lines + lpb - 1) / lpb;
-        if (p.bluestein) {
+        if (!p.bluestein && (n == 64 || n == 128 || n == 256)) {
+            // short power-of-two lines: two register transforms around one LDS exchange
+            if (n == 256) hipLaunchKernelGGL((fft_reg2_kernel<16, 16>), dim3((unsigned)((A.n_lines + 15) / 16)), dim3(256), 0, c->stream, A);
+            else if (n == 128) hipLaunchKernelGGL((fft_reg2_kernel<16, 8>), dim3((unsigned)((A.n_lines + 15) / 16)), dim3(256), 0, c->stream, A);
+            else hipLaunchKernelGGL((fft_reg2_kernel<8, 8>), dim3((unsigned)((A.n_lines + 31) / 32)), dim3(256), 0, c->stream, A);
+        } else if (p.bluestein && p.M <= 256 && p.M >= 64) {
+            // ... and Bluestein lines of up to 128 samples
+            if (p.M == 256) hipLaunchKernelGGL((bluestein_reg_kernel<16, 16>), dim3((unsigned)((A.n_lines + 15) / 16)), dim3(256), 0, c->stream, A);
+            else if (p.M == 128) hipLaunchKernelGGL((bluestein_reg_kernel<16, 8>), dim3((unsigned)((A.n_lines + 15) / 16)), dim3(256), 0, c->stream, A);
+            else hipLaunchKernelGGL((bluestein_reg_kernel<8, 8>), dim3((unsigned)((A.n_lines + 31) / 32)), dim3(256), 0, c->stream, A);
+        } else if (p.bluestein) {
             MVS_HIP_TRY(c, hipFuncSetAttribute((const void*)fft_lines_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(fft_lines_kernel<true>, dim3((unsigned)nblocks), dim3(256), lds, c->stream, A);
         } else {

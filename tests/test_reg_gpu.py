@@ -208,11 +208,12 @@ def test_context_lanes_give_identical_results(hip_device):
 
 
 @pytest.mark.parametrize("shape", [(8, 8), (64, 128), (6, 10), (60, 104), (16, 32, 64), (5, 12, 27), (51, 64, 30), (4, 51, 16), (3, 7, 51),
-                                   (51, 3, 5), (33, 34, 35), (63, 130), (130, 63), (2, 3, 70), (65, 66, 3)])
+                                   (51, 3, 5), (33, 34, 35), (63, 130), (130, 63), (2, 3, 70), (65, 66, 3), (256, 19, 128), (5, 256, 64), (3, 128, 256), (64, 7)])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_fft_c2c_matches_numpy(hip_device, shape, inverse):
-    """mvs_fft_c2c against numpy.fft on general complex input (Stockham radix-4/2 for powers of two; other lengths: direct DFT up to
-    64 samples -- along x, y and z, ragged last workgroup included -- Bluestein above)."""
+    """mvs_fft_c2c against numpy.fft on general complex input (powers of two: register transforms for 64 / 128 / 256 samples, Stockham
+    radix-4/2 otherwise; other lengths: Bluestein, in registers up to 128 samples -- along x, y and z, ragged last workgroup
+    included)."""
     from multiview_stitcher_amd import _reg_ops
 
     rng = np.random.default_rng(1)
