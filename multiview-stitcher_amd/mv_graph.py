@@ -200,16 +200,26 @@ class Graph:
     nodes = property(lambda self: list(self.adj))
 
     def add_node(self, n, **attrs):
-        self.adj.setdefault(n, {})
-        self.node_attrs.setdefault(n, {}).update(attrs)
+        if n not in self.adj:
+            self.adj[n] = {}
+            self.node_attrs[n] = {}
+        if attrs:
+            self.node_attrs[n].update(attrs)
 
     def add_edge(self, u, v, **attrs):
-        self.add_node(u)
-        self.add_node(v)
-        d = self.adj[u].get(v, {})
+        adj = self.adj
+        if u not in adj:
+            adj[u] = {}
+            self.node_attrs[u] = {}
+        if v not in adj:
+            adj[v] = {}
+            self.node_attrs[v] = {}
+        d = adj[u].get(v)
+        if d is None:
+            d = {}
         d.update(attrs)
-        self.adj[u][v] = d
-        self.adj[v][u] = d
+        adj[u][v] = d
+        adj[v][u] = d
 
     def remove_edge(self, u, v):
         del self.adj[u][v]
@@ -227,25 +237,32 @@ class Graph:
         return v in self.adj.get(u, {})
 
     def edges(self, data=False):
-        seen, out = set(), []
-        for n, nbrs in self.adj.items():
-            for m, d in nbrs.items():
-                if m not in seen:
-                    out.append((n, m, d) if data else (n, m))
-            seen.add(n)
-        return out
+        # every edge once, reported from its endpoint that comes first in node order, neighbours in adjacency order (networkx's
+        # order): a neighbour counts as "seen" when its node comes strictly earlier
+        pos = {n: i for i, n in enumerate(self.adj)}
+        if data:
+            return [(n, m, d) for n, nbrs in self.adj.items() for m, d in nbrs.items() if pos[m] >= pos[n]]
+        return [(n, m) for n, nbrs in self.adj.items() for m in nbrs if pos[m] >= pos[n]]
 
     def degree(self, n):
         return len(self.adj[n])
 
     def copy(self):
         g = Graph()
-        for n in self.adj:
-            g.add_node(n, **self.node_attrs[n])
-        for u, v, d in self.edges(data=True):
-            g.add_edge(u, v, **dict(d))
-        # keep every node's neighbour order (add_edge above inserts in edge order, which can differ for the far endpoint)
-        g.adj = {n: {m: g.adj[n][m] for m in self.adj[n]} for n in self.adj}
+        g.node_attrs = {n: dict(a) for n, a in self.node_attrs.items()}
+        # one attribute dict per edge, shared by both directions like in the original; node and neighbour orders are kept
+        fresh = {}
+        adj = {}
+        for n, nbrs in self.adj.items():
+            row = {}
+            for m, d in nbrs.items():
+                k = id(d)
+                c = fresh.get(k)
+                if c is None:
+                    c = fresh[k] = dict(d)
+                row[m] = c
+            adj[n] = row
+        g.adj = adj
         return g
 
     def connected_components(self):
@@ -363,9 +380,12 @@ def _axis_aligned_box(stack_props, tol=1e-12):
     if "transform" in stack_props:
         a = param_utils.select_time(np.asarray(stack_props["transform"], dtype=np.float64), 0)
         lin = a[:n, :n]
-        if np.any(np.abs(lin - np.diag(np.diag(lin))) > tol) or np.any(np.diag(lin) <= 0):
+        dg = lin.diagonal()
+        off = lin.copy()
+        off[np.arange(n), np.arange(n)] = 0.0
+        if np.any(np.abs(off) > tol) or np.any(dg <= 0):
             return None
-        lo, hi = np.diag(lin) * lo + a[:n, n], np.diag(lin) * hi + a[:n, n]
+        lo, hi = dg * lo + a[:n, n], dg * hi + a[:n, n]
     return lo, hi
 
 
@@ -423,7 +443,8 @@ def build_view_adjacency_graph(stack_props_list, overlap_tolerance=None, pairs=N
         pairs = [(i, j) for i in range(len(sps)) for j in tree.query_ball_point(centers[i], diam + 1) if i != j]
     # overlap volume per unordered pair (the reference evaluates (i, j) and (j, i); the volume is symmetric): all pairs of
     # axis-aligned views in one vectorised closed form, the others one by one through the halfspace intersection
-    keys = list(dict.fromkeys((min(i, j), max(i, j)) for i, j in pairs))
+    pair_keys = [(i, j) if i < j else (j, i) for i, j in pairs]
+    keys = list(dict.fromkeys(pair_keys))
     boxes = [_axis_aligned_box(sp) for sp in sps]
     cache = {}
     aa = [k for k in keys if boxes[k[0]] is not None and boxes[k[1]] is not None]
@@ -437,9 +458,10 @@ def build_view_adjacency_graph(stack_props_list, overlap_tolerance=None, pairs=N
     for k in keys:
         if k not in cache:
             cache[k] = get_overlap_between_pair_of_stack_props(sps[k[0]], sps[k[1]])[0]
-    for i, j in pairs:
-        if cache[(min(i, j), max(i, j))] > 0:        # "overlap 0 means one pixel overlap" is not an edge
-            g.add_edge(i, j, overlap=cache[(min(i, j), max(i, j))])
+    for (i, j), k in zip(pairs, pair_keys):
+        ov = cache[k]
+        if ov > 0:        # "overlap 0 means one pixel overlap" is not an edge
+            g.add_edge(i, j, overlap=ov)
     return g
 
 
@@ -516,8 +538,9 @@ def _edge_betweenness_centrality_python(g):
 def greedy_color(g):
     """networkx.coloring.greedy_color, strategy largest_first: nodes by descending degree (stable), smallest free colour."""
     colors = {}
-    for u in sorted(g.nodes, key=g.degree, reverse=True):
-        used = {colors[v] for v in g.adj[u] if v in colors}
+    adj = g.adj
+    for u in sorted(adj, key=lambda n: len(adj[n]), reverse=True):
+        used = {colors[v] for v in adj[u] if v in colors}
         c = 0
         while c in used:
             c += 1
@@ -540,13 +563,17 @@ def prune_graph_to_alternating_colors(g, n_colors=2, return_colors=True):
     vals = {(a, b): cent[(a, b)] + d["overlap"] for a, b, d in gp.edges(data=True)}
     levels = sorted(np.unique(list(vals.values())))
     k = 0
+    colors, changed = None, True
     while True:
-        colors = greedy_color(gp)
-        if len(set(colors.values())) <= n_colors:
-            break
-        drop = [(a, b) for a, b in gp.edges() if vals[(a, b)] <= levels[k] and min(gp.degree(a), gp.degree(b)) > 1]
+        if changed:       # (a level that removes nothing leaves the colouring as it was)
+            colors = greedy_color(gp)
+            if len(set(colors.values())) <= n_colors:
+                break
+        adj, lev = gp.adj, levels[k]
+        drop = [(a, b) for a, b in gp.edges() if vals[(a, b)] <= lev and len(adj[a]) > 1 and len(adj[b]) > 1]
         for a, b in drop:
             gp.remove_edge(a, b)
+        changed = bool(drop)
         k += 1
     return (gp, colors) if return_colors else gp
 
