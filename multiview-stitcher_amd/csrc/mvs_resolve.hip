@@ -18,64 +18,96 @@ extern "C" int mvs_beads_translation_sweeps(int32_t ndim, int32_t n_nodes, int32
     for (int e = 0; e < n_edges; ++e)
         for (int k = 0; k < 2; ++k)
             if (edge_nodes[2 * e + k] < 0 || edge_nodes[2 * e + k] >= n_nodes) return MVS_ERR_INVALID_ARG;
-    // incident edges per node, in edge order (the order the reference concatenates a node's beads in)
-    std::vector<std::vector<int>> inc((size_t)n_nodes);
-    for (int e = 0; e < n_edges; ++e) {
-        inc[(size_t)edge_nodes[2 * e]].push_back(e);
-        inc[(size_t)edge_nodes[2 * e + 1]].push_back(e);
-    }
+    // The translation model makes every sum over beads affine in the translations: with d0 = bead_a - bead_b (constant) the bead
+    // difference of edge e is v = d0 + (T_a - T_b), so the mean a node's update needs is sum_e +-(D0_e + n_beads (T_a - T_b)) / count
+    // with D0_e = sum_b d0 -- O(degree) per node instead of O(degree x beads x dims) -- and only the residual norms need the beads
+    // themselves.  Same quantities as the bead-by-bead form up to the rounding of a differently ordered sum (1e-16 relative; the
+    // numpy form and this one are compared to 1e-10 in tests/test_param_resolution.py).  The sweeps are bound by the latency of
+    // their addition chains, so the residual sums run in four independent accumulators.
     const size_t per_edge = (size_t)n_beads * (size_t)ndim;
-    std::vector<double> prev((size_t)n_edges * (size_t)n_beads, 0.0);
+    std::vector<double> d0((size_t)n_edges * per_edge), D0((size_t)n_edges * 3, 0.0);
+    for (int e = 0; e < n_edges; ++e)
+        for (int b = 0; b < n_beads; ++b)
+            for (int d = 0; d < ndim; ++d) {
+                const double v = beads_a[(size_t)e * per_edge + b * ndim + d] - beads_b[(size_t)e * per_edge + b * ndim + d];
+                d0[(size_t)e * per_edge + b * ndim + d] = v;
+                D0[(size_t)e * 3 + d] += v;
+            }
+    // incident edges per node (flattened): edge index and the sign of v in the node's update (+1 when the node is the b side)
+    std::vector<int> inc_off((size_t)n_nodes + 1, 0), inc_edge((size_t)n_edges * 2), inc_other((size_t)n_edges * 2);
+    std::vector<double> inc_sign((size_t)n_edges * 2);
+    for (int e = 0; e < n_edges; ++e) { ++inc_off[(size_t)edge_nodes[2 * e] + 1]; ++inc_off[(size_t)edge_nodes[2 * e + 1] + 1]; }
+    for (int n = 0; n < n_nodes; ++n) inc_off[(size_t)n + 1] += inc_off[(size_t)n];
+    {
+        std::vector<int> fill(inc_off.begin(), inc_off.end() - 1);
+        for (int e = 0; e < n_edges; ++e) {
+            const int a = edge_nodes[2 * e], b2 = edge_nodes[2 * e + 1];
+            inc_edge[(size_t)fill[a]] = e; inc_other[(size_t)fill[a]] = b2; inc_sign[(size_t)fill[a]++] = -1.0;
+            inc_edge[(size_t)fill[b2]] = e; inc_other[(size_t)fill[b2]] = a; inc_sign[(size_t)fill[b2]++] = 1.0;
+        }
+    }
+    const double nb = (double)n_beads;
+    const size_t nres = (size_t)n_edges * (size_t)n_beads;
+    std::vector<double> prev(nres, 0.0);
     int it = 0;
     for (; it < max_iter; ++it) {
         for (int s = 0; s < n_nodes; ++s) {
             const int c = order[s];
             if (c < 0 || c >= n_nodes) return MVS_ERR_INVALID_ARG;
-            if (inc[(size_t)c].empty() || c == ref_node) continue;
+            const int i0 = inc_off[(size_t)c], i1 = inc_off[(size_t)c + 1];
+            if (i0 == i1 || c == ref_node) continue;
             // TranslationTransform.estimate: mean over all bead pairs of (adjacent bead - own bead), both in world coordinates
             double sum[3] = {0.0, 0.0, 0.0};
-            for (int e : inc[(size_t)c]) {
-                const bool c_is_a = edge_nodes[2 * e] == c;
-                const int other = c_is_a ? edge_nodes[2 * e + 1] : edge_nodes[2 * e];
-                const double* own = (c_is_a ? beads_a : beads_b) + (size_t)e * per_edge;
-                const double* adj = (c_is_a ? beads_b : beads_a) + (size_t)e * per_edge;
-                for (int b = 0; b < n_beads; ++b)
-                    for (int d = 0; d < ndim; ++d)
-                        sum[d] += (adj[b * ndim + d] + translations[(size_t)other * ndim + d]) -
-                                  (own[b * ndim + d] + translations[(size_t)c * ndim + d]);
+            for (int i = i0; i < i1; ++i) {
+                const int e = inc_edge[(size_t)i], o = inc_other[(size_t)i];
+                const double sg = inc_sign[(size_t)i];
+                // sign * (D0 + nb (T_a - T_b)): for the b side (sign +1) a = other, for the a side (sign -1) a = c
+                for (int d = 0; d < ndim; ++d) {
+                    const double ta = sg > 0.0 ? translations[(size_t)o * ndim + d] : translations[(size_t)c * ndim + d];
+                    const double tb = sg > 0.0 ? translations[(size_t)c * ndim + d] : translations[(size_t)o * ndim + d];
+                    sum[d] += sg * (D0[(size_t)e * 3 + d] + nb * (ta - tb));
+                }
             }
-            const double cnt = (double)(inc[(size_t)c].size() * (size_t)n_beads);
+            const double cnt = (double)((size_t)(i1 - i0) * (size_t)n_beads);
             for (int d = 0; d < ndim; ++d) translations[(size_t)c * ndim + d] += sum[d] / cnt;
         }
         // bead residuals of every edge, their mean of means and overall maximum
         double mean_acc = 0.0, mx = 0.0;
         for (int e = 0; e < n_edges; ++e) {
             const int a = edge_nodes[2 * e], b2 = edge_nodes[2 * e + 1];
-            double esum = 0.0;
+            double dt[3] = {0.0, 0.0, 0.0};
+            for (int d = 0; d < ndim; ++d) dt[d] = translations[(size_t)a * ndim + d] - translations[(size_t)b2 * ndim + d];
+            double es[4] = {0.0, 0.0, 0.0, 0.0};
+            const double* dp = d0.data() + (size_t)e * per_edge;
+            double* rp = edge_residuals + (size_t)e * n_beads;
             for (int b = 0; b < n_beads; ++b) {
                 double q = 0.0;
                 for (int d = 0; d < ndim; ++d) {
-                    const double v = (beads_a[(size_t)e * per_edge + b * ndim + d] + translations[(size_t)a * ndim + d]) -
-                                     (beads_b[(size_t)e * per_edge + b * ndim + d] + translations[(size_t)b2 * ndim + d]);
+                    const double v = dp[b * ndim + d] + dt[d];
                     q += v * v;
                 }
                 const double r = std::sqrt(q);
-                edge_residuals[(size_t)e * n_beads + b] = r;
-                esum += r;
-                mx = std::fmax(mx, r);
+                rp[b] = r;
+                es[b & 3] += r;
             }
-            mean_acc += esum / (double)n_beads;
+            const double esum = (es[0] + es[1]) + (es[2] + es[3]);
+            mean_acc += esum / nb;
         }
+        double m4[4] = {0.0, 0.0, 0.0, 0.0};
+        for (size_t i = 0; i < nres; ++i) m4[i & 3] = std::fmax(m4[i & 3], edge_residuals[i]);
+        mx = std::fmax(std::fmax(m4[0], m4[1]), std::fmax(m4[2], m4[3]));
         mean_hist[it] = n_edges ? mean_acc / (double)n_edges : 0.0;
         max_hist[it] = mx;
         bool converged = false;
         if (it > 5) {   // global_optimization.py:399-417: largest relative change of any bead residual
-            double rel = 0.0;
-            if (mx > 0.0)
-                for (size_t i = 0; i < prev.size(); ++i) rel = std::fmax(rel, std::fabs((edge_residuals[i] - prev[i]) / mx));
+            // max_i |d_i / mx| == (max_i |d_i|) / mx: the division by mx > 0 is monotonic, so it is applied to the largest |d_i| only
+            double c4[4] = {0.0, 0.0, 0.0, 0.0};
+            for (size_t i = 0; i < nres; ++i) c4[i & 3] = std::fmax(c4[i & 3], std::fabs(edge_residuals[i] - prev[i]));
+            const double dmax = std::fmax(std::fmax(c4[0], c4[1]), std::fmax(c4[2], c4[3]));
+            const double rel = mx > 0.0 ? dmax / mx : 0.0;
             converged = rel < rel_tol;
         }
-        for (size_t i = 0; i < prev.size(); ++i) prev[i] = edge_residuals[i];
+        for (size_t i = 0; i < nres; ++i) prev[i] = edge_residuals[i];
         if (converged) { ++it; break; }
     }
     *n_iter_out = it;
