@@ -107,6 +107,46 @@ __global__ __launch_bounds__(256) void argmax_abs_kernel(const float2* __restric
     }
 }
 
+// Both channels of a packed correlation in ONE pass over the array: argmax |Re| into (pval, pidx), argmax |Im| into (pval2, pidx2)
+// -- the same comparisons as argmax_abs_kernel<1> and <2> -- and, from block 0, the DC term of the forward transform (z0_src[0])
+// into z0_dst (host memory): one launch instead of three.
+__global__ __launch_bounds__(256) void argmax_abs2_kernel(const float2* __restrict__ c, long long n, float* __restrict__ pval,
+                                                          long long* __restrict__ pidx, float* __restrict__ pval2, long long* __restrict__ pidx2,
+                                                          const float2* __restrict__ z0_src, float2* __restrict__ z0_dst) {
+    float best[2] = {-1.f, -1.f};
+    long long bi[2] = {0x7fffffffffffffffLL, 0x7fffffffffffffffLL};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float2 v = c[i];
+        const float a[2] = {fabsf(v.x), fabsf(v.y)};
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (a[k] > best[k] || (a[k] == best[k] && i < bi[k])) { best[k] = a[k]; bi[k] = i; }
+    }
+    __shared__ float sv[2][4];
+    __shared__ long long si[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_down(best[k], off);
+            const long long oi = __shfl_down(bi[k], off);
+            if (ob > best[k] || (ob == best[k] && oi < bi[k])) { best[k] = ob; bi[k] = oi; }
+        }
+        if (lane == 0) { sv[k][wave] = best[k]; si[k][wave] = bi[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            for (int w = 1; w < 4; ++w)
+                if (sv[k][w] > best[k] || (sv[k][w] == best[k] && si[k][w] < bi[k])) { best[k] = sv[k][w]; bi[k] = si[k][w]; }
+        }
+        pval[blockIdx.x] = best[0]; pidx[blockIdx.x] = bi[0];
+        pval2[blockIdx.x] = best[1]; pidx2[blockIdx.x] = bi[1];
+        if (blockIdx.x == 0) *z0_dst = *z0_src;
+    }
+}
+
 // Upsampled DFT, stage 1: contract the last (x) axis with kernel K (U x nx), input conj(P).
 // out[(row) * U + a] = sum_x K[a][x] * conj(P[row][x]); one wavefront per row.
 __global__ __launch_bounds__(256) void updft_x_kernel(const float2* __restrict__ P, const float2* __restrict__ K,
@@ -203,11 +243,6 @@ __global__ void rescale_kernel(const float* __restrict__ src, float* __restrict_
 
 inline int grid_for(long long n) { return (int)std::min<long long>((n + 255) / 256, 256 * 8); }
 
-// a few bytes of device memory into the host-resident mailbox (instead of a copy launch through pageable memory)
-__global__ void peek_kernel(const unsigned int* __restrict__ src, unsigned int* __restrict__ dst, int nwords) {
-    for (int i = threadIdx.x; i < nwords; i += blockDim.x) dst[i] = src[i];
-}
-
 // fftfreq(n, d)[x] as numpy defines it
 inline double fftfreq(int n, double d, int x) {
     const int half = (n - 1) / 2 + 1;
@@ -245,7 +280,7 @@ int mvs_device_nanminmax(MvsContext* c, const float* d_in, long long n, float* m
 // arithmetic as two mvs_rescale_intensity calls.
 int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, long long n, float* out0, float* out1,
                             float mn[2], float mx[2], long long nvalid[2], long long n_not_u16[2]) {
-    const int nb = grid_for(n);
+    const int nb = std::min(grid_for(n), 512);      // (each block writes its partials over the host link: fewer, longer blocks)
     void *mb_host = nullptr, *mb_dev = nullptr;       // the per-block partials land in host memory directly
     int rcm = mvs_mailbox(c, (size_t)nb * 32, &mb_host, &mb_dev);
     if (rcm) return rcm;
@@ -394,7 +429,8 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
   // mailbox (host memory written by the kernels): [peak partials gb * 32 | z0 | refinement results of every normalisation]
   const int up_U0 = (int)ceilf((float)upsample_factor * 1.5f);
   const size_t res_elems = upsample_factor > 1 ? (ndim == 3 ? (size_t)up_U0 * up_U0 * up_U0 : (size_t)up_U0 * up_U0) : 0;
-  const size_t mb_red = (size_t)gb * 32, mb_z0 = mb_red, mb_res = mb_red + 256, mb_res_stride = (res_elems * sizeof(float2) + 255) / 256 * 256;
+  const int ga = std::min(gb, 512);      // blocks of the peak searches: one host-memory write each
+  const size_t mb_red = (size_t)ga * 32, mb_z0 = mb_red, mb_res = mb_red + 256, mb_res_stride = (res_elems * sizeof(float2) + 255) / 256 * 256;
   void *mb_host = nullptr, *mb_dev = nullptr;
   rc = mvs_mailbox(c, mb_res + mb_res_stride * (size_t)n_norm, &mb_host, &mb_dev);
   if (rc) return rc;
@@ -406,10 +442,8 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
                        normalizations[1] ? 1 : 0);
     rc = mvs_fft3_c2c(c, CC, shape, true);
     if (rc) return rc;
-    hipLaunchKernelGGL(argmax_abs_kernel<1>, dim3(gb), dim3(256), 0, c->stream, CC, n, (float*)red, (long long*)(red + (size_t)gb * 8));
-    hipLaunchKernelGGL(argmax_abs_kernel<2>, dim3(gb), dim3(256), 0, c->stream, CC, n, (float*)(red + (size_t)gb * 16), (long long*)(red + (size_t)gb * 24));
-    MVS_HIP_TRY(c, hipGetLastError());
-    hipLaunchKernelGGL(peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned int*)Z, (unsigned int*)((char*)mb_dev + mb_z0), 2);
+    hipLaunchKernelGGL(argmax_abs2_kernel, dim3(ga), dim3(256), 0, c->stream, CC, n, (float*)red, (long long*)(red + (size_t)ga * 8),
+                       (float*)(red + (size_t)ga * 16), (long long*)(red + (size_t)ga * 24), Z, (float2*)((char*)mb_dev + mb_z0));
     MVS_HIP_TRY(c, hipGetLastError());
     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     const float2 z0 = *(const float2*)((const char*)mb_host + mb_z0);
@@ -437,12 +471,12 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     int64_t* peak_index_out = peak_indices_out ? peak_indices_out + 3 * inorm : nullptr;
     float* peak_abs_out = peak_abs_out_all ? peak_abs_out_all + inorm : nullptr;
     const float2* P = normalization ? P1 : P2;
-    const char* hpart = hred + (packed ? (size_t)inorm * gb * 16 : 0);
+    const char* hpart = hred + (packed ? (size_t)inorm * ga * 16 : 0);
     if (!packed) {
         hipLaunchKernelGGL(xpower_packed_kernel, dim3(gb), dim3(256), 0, c->stream, Z, P1, P2, CC, nz, ny, nx, normalization ? 1 : 0, -1);
         rc = mvs_fft3_c2c(c, CC, shape, true);   // cc (unnormalised inverse: argmax is scale invariant)
         if (rc) return rc;
-        hipLaunchKernelGGL(argmax_abs_kernel<0>, dim3(gb), dim3(256), 0, c->stream, CC, n, (float*)red, (long long*)(red + (size_t)gb * 8));
+        hipLaunchKernelGGL(argmax_abs_kernel<0>, dim3(ga), dim3(256), 0, c->stream, CC, n, (float*)red, (long long*)(red + (size_t)ga * 8));
         MVS_HIP_TRY(c, hipGetLastError());
         MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
@@ -450,8 +484,8 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     long long bi = 0;
     {
         const float* hv = (const float*)hpart;
-        const long long* hi = (const long long*)(hpart + (size_t)gb * 8);
-        for (int i = 0; i < gb; ++i)
+        const long long* hi = (const long long*)(hpart + (size_t)ga * 8);
+        for (int i = 0; i < ga; ++i)
             if (hv[i] > best || (hv[i] == best && hi[i] < bi)) { best = hv[i]; bi = hi[i]; }
     }
     if (packed) best /= packed_scale[inorm];
