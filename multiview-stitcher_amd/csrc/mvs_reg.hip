@@ -241,6 +241,56 @@ __global__ void rescale_kernel(const float* __restrict__ src, float* __restrict_
     }
 }
 
+// both crops of a pair in one launch (blockIdx.y = image): same bodies
+struct PairPtrs { const float* in[2]; float* out[2]; float lo[2], hi[2]; int degenerate[2]; };
+__global__ __launch_bounds__(256) void nanminmax_pair_kernel(PairPtrs P, long long n, char* __restrict__ partials, int nb) {
+    const int k = blockIdx.y;
+    const float* __restrict__ a = P.in[k];
+    char* part = partials + (size_t)k * nb * 16;
+    float mn = INFINITY, mx = -INFINITY;
+    long long nv = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float v = a[i];
+        if (v == v) {
+            mn = fminf(mn, v); mx = fmaxf(mx, v); ++nv;
+            if (!(v >= 0.f && v <= 65535.f && v == floorf(v))) nv += 1ll << 32;      // (see nanminmax_kernel)
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        mn = fminf(mn, __shfl_down(mn, off));
+        mx = fmaxf(mx, __shfl_down(mx, off));
+        nv += __shfl_down(nv, off);
+    }
+    __shared__ float smn[4], smx[4];
+    __shared__ long long snv[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { smn[wave] = mn; smx[wave] = mx; snv[wave] = nv; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) { mn = fminf(mn, smn[w]); mx = fmaxf(mx, smx[w]); nv += snv[w]; }
+        ((float*)part)[blockIdx.x] = mn;
+        ((float*)part)[nb + blockIdx.x] = mx;
+        ((long long*)(part + (size_t)nb * 8))[blockIdx.x] = nv;
+    }
+}
+__global__ void rescale_pair_kernel(PairPtrs P, long long n) {
+    const int k = blockIdx.y;
+    const float* __restrict__ src = P.in[k];
+    float* __restrict__ dst = P.out[k];
+    const float lo = P.lo[k], hi = P.hi[k];
+    const int degenerate = P.degenerate[k];
+    const float d = hi - lo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float v = src[i];
+        if (v == v) {
+            v = fminf(fmaxf(v, lo), hi);
+            if (!degenerate) v = (v - lo) / d;
+            v = v * 1.0f + 0.0f;
+        }
+        dst[i] = v;
+    }
+}
+
 inline int grid_for(long long n) { return (int)std::min<long long>((n + 255) / 256, 256 * 8); }
 
 // fftfreq(n, d)[x] as numpy defines it
@@ -285,15 +335,11 @@ int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, l
     int rcm = mvs_mailbox(c, (size_t)nb * 32, &mb_host, &mb_dev);
     if (rcm) return rcm;
     char* scratch = (char*)mb_dev;
-    const float* ins[2] = {in0, in1};
-    for (int k = 0; k < 2; ++k) {
-        char* part = scratch + (size_t)k * nb * 16;
-        hipLaunchKernelGGL(nanminmax_kernel, dim3(nb), dim3(256), 0, c->stream, ins[k], n, (float*)part, (float*)part + nb,
-                           (long long*)(part + (size_t)nb * 8));
-    }
+    PairPtrs PP;
+    PP.in[0] = in0; PP.in[1] = in1; PP.out[0] = out0; PP.out[1] = out1;
+    hipLaunchKernelGGL(nanminmax_pair_kernel, dim3(nb, 2), dim3(256), 0, c->stream, PP, n, scratch, nb);
     MVS_HIP_TRY(c, hipGetLastError());
     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
-    float* outs[2] = {out0, out1};
     for (int k = 0; k < 2; ++k) {
         const char* part = (const char*)mb_host + (size_t)k * nb * 16;
         const float* hmin = (const float*)part;
@@ -306,8 +352,9 @@ int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, l
         v &= 0xffffffffll;
         if (v == 0) { a = NAN; b = NAN; }
         mn[k] = a; mx[k] = b; nvalid[k] = v;
-        hipLaunchKernelGGL(rescale_kernel, dim3(nb), dim3(256), 0, c->stream, ins[k], outs[k], n, a, b, a == b ? 1 : 0);
+        PP.lo[k] = a; PP.hi[k] = b; PP.degenerate[k] = a == b ? 1 : 0;
     }
+    hipLaunchKernelGGL(rescale_pair_kernel, dim3(nb, 2), dim3(256), 0, c->stream, PP, n);
     MVS_HIP_TRY(c, hipGetLastError());
     return MVS_OK;
 }
