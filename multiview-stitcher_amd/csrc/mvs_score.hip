@@ -1581,9 +1581,10 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             scored[j] = true;
         }
         if (any_batched && !c->ssim_two_pass) {
-            // one resident round of workgroups (3 per CU); z segments only when the tiles alone do not fill the GPU
             const int tiles = ((S.ny - 6 + 15) / 16) * ((S.nx - 6 + 55) / 56), cz = S.nz - 6;
-            const int nzs = std::max(1, std::min(768 / std::max(tiles * nb, 1), (cz + 7) / 8));
+            // ~1536 workgroups (two resident rounds of 3 per CU): 243 instead of 282 us per pair with 768 -- a workgroup spends its
+            // time waiting (two barriers and a load round trip per plane), so a second round hides more than its 6 halo planes cost
+            const int nzs = std::max(1, std::min(1536 / std::max(tiles * nb, 1), (cz + 7) / 8));
             hipLaunchKernelGGL(ssim_fused_batch_kernel<7>, dim3(kStatBlocks, nb), dim3(256), 0, c->stream, im0, S, fused_batch, setB[2], setB[3],
                                (cz + nzs - 1) / nzs, batch_cov_norm, C1, C2, pmax, phasnan, psum);
         } else if (any_batched) {
