@@ -1264,7 +1264,8 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     const size_t stat_bytes = (size_t)(kMaxResident + 2) * kStatBlocks * (sizeof(VoxStats) + 4 + 4 + 8) + (kMaxResident + 2) * 64;
     // batched launches (one z pass / one y-x pass for all candidates of a batch) keep three z-filtered arrays per candidate
     const bool may_batch = ndim == 3 && region_mode == 0 && !quality_for_all && !c->materialize_shifts && (long long)n * 12 * nres <= (3ll << 30);
-    const size_t need = (size_t)n * 4 * (10 + nres + (may_batch ? 3 * nres : 0)) + 256 * (12 + 4 * nres) + sort_temp_bytes + (size_t)gb * 32 + stat_bytes + 64 * 1024 + (size_t)(kHistBinsMax + 64) * 8 + (size_t)kHistParts * (kHistBinsMax / 2 + 1) * 4 + 2048;
+    constexpr int kMaxCls = 4;      // fraction classes of half-pixel shifts that get ONE shifted copy shared by their candidates
+    const size_t need = (size_t)n * 4 * (10 + nres + (may_batch ? 3 * nres + kMaxCls : 0)) + 256 * (12 + 4 * nres + kMaxCls) + sort_temp_bytes + (size_t)gb * 32 + stat_bytes + 64 * 1024 + (size_t)(kHistBinsMax + 64) * 8 + (size_t)kHistParts * (kHistBinsMax / 2 + 1) * 4 + 2048;
     char* base = (char*)mvs_scratch(c, 6, need);
     if (!base) return MVS_ERR_HIP;
     DeviceBump B{base, need, 0};
@@ -1275,6 +1276,13 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     for (int a = 0; a < 5; ++a) setB[a] = B.take<float>(n);
     std::vector<float*> cand3((size_t)(may_batch ? 3 * nres : 0));
     for (float*& q : cand3) q = B.take<float>(n);
+    // In 3D the phase correlation refines to half pixels, so the candidates of a pair -- t, -t, -(t - N), -t - N per axis -- share the
+    // fractional part of their shift per axis, and every candidate image is an INTEGER shift of one "fraction-only" shifted copy of the
+    // moving image (same taps, weights and order: c = o + t is exact in double).  One copy per fraction class instead of one per
+    // candidate; the fused SSIM walk reads it at o + floor(t) exactly as it reads the moving image itself for integer shifts.
+    struct ClsBuf { int key; float* buf; } cls[kMaxCls];
+    int n_cls = 0;
+    for (int k = 0; k < kMaxCls; ++k) cls[k] = ClsBuf{-1, may_batch ? B.take<float>(n) : nullptr};
     void* sort_temp = B.take<char>(sort_temp_bytes);
     double* partial = B.take<double>((size_t)gb * 4);
     VoxStats* vox_partial = B.take<VoxStats>((size_t)(kMaxResident + 2) * kStatBlocks);
@@ -1366,6 +1374,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
 
     // Spearman over the jointly valid voxels of candidate ic, whose shifted image is `im1t`: compaction, sort by x
     // carrying y, ranks of x in sorted order, sort by y carrying rank(x), correlation sums in y-sorted order
+    // im1t == nullptr: the candidate has no shifted copy of its own; it is made (into im1t_buf[0]) only if the sorting path needs it
     auto spearman_from = [&](int ic, const float* im1t) -> int {
         {
             // histogram ranks: both crops hold 16-bit integers (the caller vouches: raw_u16_keys) and are finite, every
@@ -1416,6 +1425,14 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 return MVS_OK;
             }
         }
+        if (!im1t) {
+            double t[3] = {0.0, 0.0, 0.0};
+            for (int k = 0; k < ndim; ++k) t[k0 + k] = t_candidates[ic * ndim + k];
+            hipLaunchKernelGGL(shift_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im1, im0, im1t_buf[0], S, t[0], t[1], t[2], im1_all_finite, vox_partial);
+            std::fill(resident.begin(), resident.end(), -1);
+            resident[ic] = 0;
+            im1t = im1t_buf[0];
+        }
         MVS_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 4, c->stream));
         const float* raw0 = c->raw_u16_keys[0];      // 16-bit integer keys for the fixed image when the caller vouches for them
         hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, c->stream, im0, im1t, n, setA[0], setA[1], d_counter, raw0);
@@ -1448,6 +1465,26 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         shared_x = true;
         launch_ssim_shared_x<7>(c->stream, im0, S, S, setA, setB, pmax, phasnan);
     }
+    // slot of the fraction class of a shift whose components are all multiples of 1/2 (bit k of the key: axis k has the fraction
+    // 1/2), -1 when the candidate keeps a copy of its own (other fractions, integer shift, no slot left, mode off); *fresh: the
+    // class copy still has to be written
+    auto share_cls = [&](const double t[3], bool* fresh) -> int {
+        *fresh = false;
+        if (!may_batch || !im1_all_finite || c->materialize_shifts || c->ssim_two_pass) return -1;
+        int key = 0;
+        for (int k = 0; k < 3; ++k) {
+            const double t2 = t[k] * 2.0;
+            if (!(std::floor(t2) == t2 && std::fabs(t[k]) < 1e6)) return -1;
+            key |= (t[k] != std::floor(t[k])) ? (1 << k) : 0;
+        }
+        if (key == 0) return -1;
+        for (int q = 0; q < n_cls; ++q)
+            if (cls[q].key == key) return q;
+        if (n_cls == kMaxCls) return -1;
+        cls[n_cls].key = key;
+        *fresh = true;
+        return n_cls++;
+    };
     for (size_t b0 = 0; b0 < todo.size(); b0 += (size_t)nres) {
         const int nb = (int)std::min<size_t>((size_t)nres, todo.size() - b0);
         std::fill(resident.begin(), resident.end(), -1);
@@ -1455,6 +1492,8 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         VoxStats h_vs[kMaxResident];
         ShiftArg shifts[kMaxResident];
         bool otf[kMaxResident] = {};
+        int cls_of[kMaxResident];      // fraction class whose copy the candidate reads (-1: its own copy / the moving image)
+        for (int j = 0; j < kMaxResident; ++j) cls_of[j] = -1;
         const bool batched = on_the_fly && shared_x && may_batch;
         ShiftBatch shift_batch;
         int n_shift_batch = 0;
@@ -1486,6 +1525,20 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 // by the windowed z pass), but nobody waits for its statistics.
                 otf[j] = t[0] == std::floor(t[0]) && t[1] == std::floor(t[1]) && t[2] == std::floor(t[2]);
                 if (otf[j]) continue;
+                if (batched) {
+                    bool fresh = false;
+                    const int q = share_cls(t, &fresh);
+                    if (q >= 0) {
+                        cls_of[j] = q;
+                        if (fresh) {      // the class copy: the fraction-only shift, through the same launch as the other copies
+                            const int key = cls[q].key;
+                            ShiftCand sc{cls[q].buf, 0.5 * (key & 1), 0.5 * ((key >> 1) & 1), 0.5 * ((key >> 2) & 1), 1,
+                                         HalfShift{0, 0, 0, key & 1, (key >> 1) & 1, (key >> 2) & 1}};
+                            shift_batch.c[n_shift_batch++] = sc;
+                        }
+                        continue;
+                    }
+                }
                 if (batched) {      // all fractional shifts of the batch in one launch, after this loop
                     ShiftCand sc{im1t_buf[j], t[0], t[1], t[2], 0, HalfShift{0, 0, 0, 0, 0, 0}};
                     if (!c->materialize_shifts) {
@@ -1566,11 +1619,20 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             const float* second = otf[j] ? im1 : im1t_buf[j];
             const ShiftArg* sa = otf[j] ? &shifts[j] : nullptr;
             const bool full = R.nz == S.nz && R.ny == S.ny && R.nx == S.nx;
+            if (cls_of[j] >= 0 && !(batched && win == 7 && full)) {
+                // (cannot happen for a whole-volume region with a 7-wide window; keeps the single-candidate paths below whole)
+                hipLaunchKernelGGL(shift_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im1, im0, im1t_buf[j], S, shifts[j].tz, shifts[j].ty,
+                                   shifts[j].tx, im1_all_finite, vox_partial + (size_t)j * kStatBlocks);
+                resident[ic] = j;
+                cls_of[j] = -1;
+            }
             if (batched && win == 7 && full) {     // joins the two batched launches below
                 float* d1 = cand3[(size_t)3 * j], *d3 = cand3[(size_t)3 * j + 1], *d4 = cand3[(size_t)3 * j + 2];
                 first_batch.c[j] = FirstCand{second, d1, d3, d4, shifts[j], otf[j] ? 1 : 0};
                 yx_batch.c[j] = YxCand{d1, d3, d4};
-                fused_batch.c[j] = otf[j] ? FusedCand{im1, (int)shifts[j].tz, (int)shifts[j].ty, (int)shifts[j].tx} : FusedCand{im1t_buf[j], 0, 0, 0};
+                fused_batch.c[j] = otf[j] ? FusedCand{im1, (int)shifts[j].tz, (int)shifts[j].ty, (int)shifts[j].tx}
+                                   : cls_of[j] >= 0 ? FusedCand{cls[cls_of[j]].buf, (int)std::floor(shifts[j].tz), (int)std::floor(shifts[j].ty), (int)std::floor(shifts[j].tx)}
+                                                    : FusedCand{im1t_buf[j], 0, 0, 0};
                 any_batched = true;
                 batch_cov_norm = cov_norm;
             }
@@ -1645,16 +1707,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         for (int ic = 0; ic < n_candidates; ++ic) {
             if (code_out[ic] != 0) continue;
             if (!(ssim_out[ic] == best)) { spearman_out[ic] = NAN; continue; }
-            float* im1t = im1t_buf[0];
-            if (resident[ic] >= 0) im1t = im1t_buf[resident[ic]];
-            else {
-                double t[3] = {0.0, 0.0, 0.0};
-                for (int k = 0; k < ndim; ++k) t[k0 + k] = t_candidates[ic * ndim + k];
-                hipLaunchKernelGGL(shift_kernel, dim3(kStatBlocks), dim3(256), 0, c->stream, im1, im0, im1t, S, t[0], t[1], t[2], im1_all_finite, vox_partial);
-                std::fill(resident.begin(), resident.end(), -1);
-                resident[ic] = 0;
-            }
-            rc = spearman_from(ic, im1t);
+            rc = spearman_from(ic, resident[ic] >= 0 ? im1t_buf[resident[ic]] : (const float*)nullptr);
             if (rc) return rc;
         }
     }
