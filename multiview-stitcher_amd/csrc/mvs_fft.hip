@@ -38,6 +38,11 @@ struct FftArgs {
     const float2* tw;         // exp(-2 pi i m / M), m < M/2
     const float2* chirp;      // Bluestein: w_n = exp(-i pi n^2 / N), n < N
     const float2* bfft;       // Bluestein: FFT_M of the wrapped conj chirp, scaled by 1/M
+    // fusions of the register kernels (nullptr: off), see MvsFftFuse
+    const float* re_src = nullptr;
+    const float* im_src = nullptr;
+    float* peak_val[2] = {nullptr, nullptr};
+    long long* peak_idx[2] = {nullptr, nullptr};
 };
 
 // Stockham autosort stages on `lpb` lines of length M held in LDS: radix-4 passes (half the LDS round trips and
@@ -243,6 +248,48 @@ template <> __device__ __forceinline__ void dft_reg<16>(float2 (&v)[16]) {
         for (int k = p + 1; k < 4; ++k) { const float2 t = v[4 * p + k]; v[4 * p + k] = v[4 * k + p]; v[4 * k + p] = t; }
 }
 
+__device__ __forceinline__ float2 fft_load(const FftArgs& A, long long i) {
+    if (!A.re_src) return A.data[i];
+    float re = A.re_src[i], im = A.im_src[i];      // the pair a + i b of two real volumes, NaN -> 0 (np.nan_to_num, registration.py:403-408)
+    re = (re != re) ? 0.f : re;
+    im = (im != im) ? 0.f : im;
+    return make_float2(re, im);
+}
+// running argmax |Re| / |Im| with the lowest flat index among equal values (np.argmax)
+struct Peak2 { float v[2]; long long i[2]; };
+__device__ __forceinline__ void peak_init(Peak2& p) { p.v[0] = p.v[1] = -1.f; p.i[0] = p.i[1] = 0x7fffffffffffffffLL; }
+__device__ __forceinline__ void peak_add(Peak2& p, float2 o, long long idx) {
+    const float a[2] = {fabsf(o.x), fabsf(o.y)};
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+        if (a[k] > p.v[k] || (a[k] == p.v[k] && idx < p.i[k])) { p.v[k] = a[k]; p.i[k] = idx; }
+}
+// workgroup reduction (256 threads) and the write of the workgroup's partials
+__device__ __forceinline__ void peak_flush(Peak2 p, const FftArgs& A) {
+    __shared__ float sv[2][4];
+    __shared__ long long si[2][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_down(p.v[k], off);
+            const long long oi = __shfl_down(p.i[k], off);
+            if (ob > p.v[k] || (ob == p.v[k] && oi < p.i[k])) { p.v[k] = ob; p.i[k] = oi; }
+        }
+        if (lane == 0) { sv[k][wave] = p.v[k]; si[k][wave] = p.i[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            for (int w = 1; w < 4; ++w)
+                if (sv[k][w] > p.v[k] || (sv[k][w] == p.v[k] && si[k][w] < p.i[k])) { p.v[k] = sv[k][w]; p.i[k] = si[k][w]; }
+            A.peak_val[k][blockIdx.x] = p.v[k];
+            A.peak_idx[k][blockIdx.x] = p.i[k];
+        }
+    }
+}
+
 template <int R1, int R2>
 __global__ __launch_bounds__(256) void fft_reg2_kernel(FftArgs A) {
     constexpr int M = R1 * R2, TPL = R1 > R2 ? R1 : R2, LPB = 256 / TPL;      // threads per line, lines per workgroup
@@ -259,13 +306,15 @@ __global__ __launch_bounds__(256) void fft_reg2_kernel(FftArgs A) {
     const bool live = l < A.n_lines;
     const long long base = live ? line_base(A, (int)l) : 0;
     float2* row = ex + line * LS;
+    Peak2 pk;
+    peak_init(pk);
     __syncthreads();                                                             // (twiddles)
     if (idx < R2) {                                                              // pass 1: j' = idx
         float2 v[R1];
 #pragma unroll
         for (int q = 0; q < R1; ++q) {
             v[q] = make_float2(0.f, 0.f);
-            if (live) v[q] = A.data[base + (long long)(q * R2 + idx) * A.stride];
+            if (live) v[q] = fft_load(A, base + (long long)(q * R2 + idx) * A.stride);
             if (inv) v[q] = make_float2(v[q].y, v[q].x);
         }
         dft_reg<R1>(v);
@@ -285,10 +334,12 @@ __global__ __launch_bounds__(256) void fft_reg2_kernel(FftArgs A) {
 #pragma unroll
             for (int k = 0; k < R2; ++k) {
                 const float2 o = inv ? make_float2(u[k].y, u[k].x) : u[k];
-                A.data[base + (long long)(idx + R1 * k) * A.stride] = o;
+                const long long at = base + (long long)(idx + R1 * k) * A.stride;
+                if (A.peak_val[0]) peak_add(pk, o, at); else A.data[at] = o;
             }
         }
     }
+    if (A.peak_val[0]) peak_flush(pk, A);
 }
 
 // Bluestein's chirp-z for short lines on the same register transforms (n <= 128: M = 64, 128 or 256 points): sample x chirp ->
@@ -311,6 +362,8 @@ __global__ __launch_bounds__(256) void bluestein_reg_kernel(FftArgs A) {
     const bool live = l < A.n_lines;
     const long long base = live ? line_base(A, (int)l) : 0;
     float2* row = ex + line * LS;
+    Peak2 pk;
+    peak_init(pk);
     __syncthreads();                                                             // (twiddles)
     if (idx < R2) {                                                              // forward, pass 1: j' = idx
         float2 v[R1];
@@ -319,7 +372,7 @@ __global__ __launch_bounds__(256) void bluestein_reg_kernel(FftArgs A) {
             const int j = q * R2 + idx;
             v[q] = make_float2(0.f, 0.f);
             if (live && j < n) {
-                float2 x = A.data[base + (long long)j * A.stride];
+                float2 x = fft_load(A, base + (long long)j * A.stride);
                 if (inv) x.y = -x.y;                                             // IDFT(x) = conj(DFT(conj x))
                 v[q] = cmul(x, A.chirp[j]);
             }
@@ -361,11 +414,13 @@ __global__ __launch_bounds__(256) void bluestein_reg_kernel(FftArgs A) {
                 if (m < n) {
                     float2 y = cmul(make_float2(w[k].y, w[k].x), A.chirp[m]);
                     if (inv) y.y = -y.y;
-                    A.data[base + (long long)m * A.stride] = y;
+                    const long long at = base + (long long)m * A.stride;
+                    if (A.peak_val[0]) peak_add(pk, y, at); else A.data[at] = y;
                 }
             }
         }
     }
+    if (A.peak_val[0]) peak_flush(pk, A);
 }
 
 struct FftPlan {
@@ -642,8 +697,21 @@ int fft_axis_big(MvsContext* c, float2* data, int n, long long n_lines, long lon
 
 // In-place 3D (or 2D when shape[0]==1) complex64 FFT of a C-contiguous (nz,ny,nx) array on c->stream.
 // inverse: unnormalised conjugate transform (the caller applies 1/N where it matters).
-int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inverse) {
+// does a line of n samples run on the register kernels (which carry the MvsFftFuse options)?
+bool mvs_fft_reg_length(int n) {
+    if (n < 2) return false;
+    if ((n & (n - 1)) == 0) return n == 64 || n == 128 || n == 256;
+    int M = 1;
+    while (M < 2 * n - 1) M <<= 1;
+    return M >= 64 && M <= 256;
+}
+
+int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inverse, MvsFftFuse* fuse) {
     const long long nz = shape[0], ny = shape[1], nx = shape[2];
+    int first_axis = -1, last_axis = -1;
+    for (int axis = 2; axis >= 0; --axis)
+        if (shape[axis] > 1) { if (first_axis < 0) first_axis = axis; last_axis = axis; }
+    if (fuse) { fuse->n_peak = 0; fuse->src_used = false; }
     for (int axis = 2; axis >= 0; --axis) {
         const int n = (int)shape[axis];
         if (n == 1) continue;
@@ -673,16 +741,32 @@ int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inver
         A.lpb = lpb;
         const size_t lds = (2ull * lpb * p.M + p.M / 2 + 1) * sizeof(float2);   // two line buffers + the twiddles
         const long long nblocks = (A.n_lines + lpb - 1) / lpb;
-        if (!p.bluestein && (n == 64 || n == 128 || n == 256)) {
-            // short power-of-two lines: two register transforms around one LDS exchange
-            if (n == 256) hipLaunchKernelGGL((fft_reg2_kernel<16, 16>), dim3((unsigned)((A.n_lines + 15) / 16)), dim3(256), 0, c->stream, A);
-            else if (n == 128) hipLaunchKernelGGL((fft_reg2_kernel<16, 8>), dim3((unsigned)((A.n_lines + 15) / 16)), dim3(256), 0, c->stream, A);
-            else hipLaunchKernelGGL((fft_reg2_kernel<8, 8>), dim3((unsigned)((A.n_lines + 31) / 32)), dim3(256), 0, c->stream, A);
-        } else if (p.bluestein && p.M <= 256 && p.M >= 64) {
-            // ... and Bluestein lines of up to 128 samples
-            if (p.M == 256) hipLaunchKernelGGL((bluestein_reg_kernel<16, 16>), dim3((unsigned)((A.n_lines + 15) / 16)), dim3(256), 0, c->stream, A);
-            else if (p.M == 128) hipLaunchKernelGGL((bluestein_reg_kernel<16, 8>), dim3((unsigned)((A.n_lines + 15) / 16)), dim3(256), 0, c->stream, A);
-            else hipLaunchKernelGGL((bluestein_reg_kernel<8, 8>), dim3((unsigned)((A.n_lines + 31) / 32)), dim3(256), 0, c->stream, A);
+        const bool reg_pow2 = !p.bluestein && (n == 64 || n == 128 || n == 256);
+        const bool reg_blue = p.bluestein && p.M <= 256 && p.M >= 64;
+        if (reg_pow2 || reg_blue) {
+            const int lpw = ((reg_pow2 && n == 64) || (reg_blue && p.M == 64)) ? 32 : 16;      // lines per workgroup
+            const unsigned grid = (unsigned)((A.n_lines + lpw - 1) / lpw);
+            // the fusions at the two ends of the transform (MvsFftFuse)
+            if (fuse && axis == first_axis && fuse->re_src && fuse->im_src) {
+                A.re_src = fuse->re_src;
+                A.im_src = fuse->im_src;
+                fuse->src_used = true;
+            }
+            if (fuse && axis == last_axis && fuse->peak_val[0] && (long long)grid <= fuse->peak_cap) {
+                for (int k = 0; k < 2; ++k) { A.peak_val[k] = fuse->peak_val[k]; A.peak_idx[k] = fuse->peak_idx[k]; }
+                fuse->n_peak = (int)grid;
+            }
+            if (reg_pow2) {
+                // short power-of-two lines: two register transforms around one LDS exchange
+                if (n == 256) hipLaunchKernelGGL((fft_reg2_kernel<16, 16>), dim3(grid), dim3(256), 0, c->stream, A);
+                else if (n == 128) hipLaunchKernelGGL((fft_reg2_kernel<16, 8>), dim3(grid), dim3(256), 0, c->stream, A);
+                else hipLaunchKernelGGL((fft_reg2_kernel<8, 8>), dim3(grid), dim3(256), 0, c->stream, A);
+            } else {
+                // ... and Bluestein lines of up to 128 samples
+                if (p.M == 256) hipLaunchKernelGGL((bluestein_reg_kernel<16, 16>), dim3(grid), dim3(256), 0, c->stream, A);
+                else if (p.M == 128) hipLaunchKernelGGL((bluestein_reg_kernel<16, 8>), dim3(grid), dim3(256), 0, c->stream, A);
+                else hipLaunchKernelGGL((bluestein_reg_kernel<8, 8>), dim3(grid), dim3(256), 0, c->stream, A);
+            }
         } else if (p.bluestein) {
             MVS_HIP_TRY(c, hipFuncSetAttribute((const void*)fft_lines_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(fft_lines_kernel<true>, dim3((unsigned)nblocks), dim3(256), lds, c->stream, A);

@@ -293,6 +293,11 @@ __global__ void rescale_pair_kernel(PairPtrs P, long long n) {
 
 inline int grid_for(long long n) { return (int)std::min<long long>((n + 255) / 256, 256 * 8); }
 
+// a few bytes of device memory into the host-resident mailbox
+__global__ void peek_kernel(const unsigned int* __restrict__ src, unsigned int* __restrict__ dst, int nwords) {
+    for (int i = threadIdx.x; i < nwords; i += blockDim.x) dst[i] = src[i];
+}
+
 // fftfreq(n, d)[x] as numpy defines it
 inline double fftfreq(int n, double d, int x) {
     const int half = (n - 1) / 2 + 1;
@@ -467,8 +472,19 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
 
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     const int gb = grid_for(n);
-    hipLaunchKernelGGL(pack_pair_kernel, dim3(gb), dim3(256), 0, c->stream, da, db, Z, n);
-    rc = mvs_fft3_c2c(c, Z, shape, false);
+    // first / last transformed axis (the transform runs x, y, z; axes of length 1 are skipped)
+    int first_axis = -1, last_axis = -1;
+    for (int axis = 2; axis >= 0; --axis)
+        if (shape[axis] > 1) { if (first_axis < 0) first_axis = axis; last_axis = axis; }
+    if (first_axis >= 0 && mvs_fft_reg_length((int)shape[first_axis])) {
+        MvsFftFuse ff;      // the first pass reads a and b themselves: no packed copy is written and read back
+        ff.re_src = da;
+        ff.im_src = db;
+        rc = mvs_fft3_c2c(c, Z, shape, false, &ff);
+    } else {
+        hipLaunchKernelGGL(pack_pair_kernel, dim3(gb), dim3(256), 0, c->stream, da, db, Z, n);
+        rc = mvs_fft3_c2c(c, Z, shape, false);
+    }
     if (rc) return rc;
   // Two different normalisations: both correlations come out of ONE inverse transform (real and imaginary channel, see
   // xpower_packed_kernel) and one host round trip; otherwise one complex transform per normalisation.
@@ -476,7 +492,14 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
   // mailbox (host memory written by the kernels): [peak partials gb * 32 | z0 | refinement results of every normalisation]
   const int up_U0 = (int)ceilf((float)upsample_factor * 1.5f);
   const size_t res_elems = upsample_factor > 1 ? (ndim == 3 ? (size_t)up_U0 * up_U0 * up_U0 : (size_t)up_U0 * up_U0) : 0;
-  const int ga = std::min(gb, 512);      // blocks of the peak searches: one host-memory write each
+  // blocks of the peak searches (one host-memory write each): 512 for the stand-alone kernel, or the workgroups of the inverse
+  // transform's last pass when that pass does the search itself (16 or 32 lines each)
+  int ga = std::min(gb, 512);
+  {
+      int la = -1;
+      for (int axis = 2; axis >= 0; --axis) if (shape[axis] > 1) la = axis;
+      if (la >= 0 && mvs_fft_reg_length((int)shape[la])) ga = std::max<long long>(ga, (n / shape[la] + 15) / 16);
+  }
   const size_t mb_red = (size_t)ga * 32, mb_z0 = mb_red, mb_res = mb_red + 256, mb_res_stride = (res_elems * sizeof(float2) + 255) / 256 * 256;
   void *mb_host = nullptr, *mb_dev = nullptr;
   rc = mvs_mailbox(c, mb_res + mb_res_stride * (size_t)n_norm, &mb_host, &mb_dev);
@@ -484,13 +507,27 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
   char* red = (char*)mb_dev;
   const char* hred = (const char*)mb_host;
   float packed_scale[2] = {1.f, 1.f};
+  int n_red_packed = ga;
   if (packed) {
     hipLaunchKernelGGL(xpower_packed_kernel, dim3(gb), dim3(256), 0, c->stream, Z, P1, P2, CC, nz, ny, nx, normalizations[0] ? 1 : 0,
                        normalizations[1] ? 1 : 0);
-    rc = mvs_fft3_c2c(c, CC, shape, true);
+    // the correlation volume is only ever searched for its two peaks: when the last pass of the inverse transform runs on the
+    // register kernels it reduces its output to per-workgroup maxima instead of storing it (no 27 MB written and read back)
+    MvsFftFuse fp;
+    if (last_axis >= 0 && mvs_fft_reg_length((int)shape[last_axis])) {
+        fp.peak_val[0] = (float*)red; fp.peak_idx[0] = (long long*)(red + (size_t)ga * 8);
+        fp.peak_val[1] = (float*)(red + (size_t)ga * 16); fp.peak_idx[1] = (long long*)(red + (size_t)ga * 24);
+        fp.peak_cap = ga;
+    }
+    rc = mvs_fft3_c2c(c, CC, shape, true, &fp);
     if (rc) return rc;
-    hipLaunchKernelGGL(argmax_abs2_kernel, dim3(ga), dim3(256), 0, c->stream, CC, n, (float*)red, (long long*)(red + (size_t)ga * 8),
-                       (float*)(red + (size_t)ga * 16), (long long*)(red + (size_t)ga * 24), Z, (float2*)((char*)mb_dev + mb_z0));
+    if (fp.n_peak > 0) {
+        n_red_packed = fp.n_peak;
+        hipLaunchKernelGGL(peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned int*)Z, (unsigned int*)((char*)mb_dev + mb_z0), 2);
+    } else {
+        hipLaunchKernelGGL(argmax_abs2_kernel, dim3(ga), dim3(256), 0, c->stream, CC, n, (float*)red, (long long*)(red + (size_t)ga * 8),
+                           (float*)(red + (size_t)ga * 16), (long long*)(red + (size_t)ga * 24), Z, (float2*)((char*)mb_dev + mb_z0));
+    }
     MVS_HIP_TRY(c, hipGetLastError());
     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     const float2 z0 = *(const float2*)((const char*)mb_host + mb_z0);
@@ -519,6 +556,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     float* peak_abs_out = peak_abs_out_all ? peak_abs_out_all + inorm : nullptr;
     const float2* P = normalization ? P1 : P2;
     const char* hpart = hred + (packed ? (size_t)inorm * ga * 16 : 0);
+    const int n_part = packed ? n_red_packed : ga;
     if (!packed) {
         hipLaunchKernelGGL(xpower_packed_kernel, dim3(gb), dim3(256), 0, c->stream, Z, P1, P2, CC, nz, ny, nx, normalization ? 1 : 0, -1);
         rc = mvs_fft3_c2c(c, CC, shape, true);   // cc (unnormalised inverse: argmax is scale invariant)
@@ -532,7 +570,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     {
         const float* hv = (const float*)hpart;
         const long long* hi = (const long long*)(hpart + (size_t)ga * 8);
-        for (int i = 0; i < ga; ++i)
+        for (int i = 0; i < n_part; ++i)
             if (hv[i] > best || (hv[i] == best && hi[i] < bi)) { best = hv[i]; bi = hi[i]; }
     }
     if (packed) best /= packed_scale[inorm];

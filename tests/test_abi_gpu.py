@@ -35,9 +35,16 @@ def test_pool_recycles_blocks_and_copy_into_checks_bounds(hip_device):
     p1, p2 = C.c_void_p(), C.c_void_p()
     assert lib.mvs_malloc(0, 3 << 20, C.byref(p1)) == 0
     assert lib.mvs_free(0, p1) == 0
-    assert lib.mvs_malloc(0, 3 << 20, C.byref(p2)) == 0          # same size class: the cached block comes back
-    assert p2.value == p1.value
-    assert lib.mvs_free(0, p2) == 0
+    # same size class: the cached block comes back -- possibly after other cached blocks of that class (left by earlier tests)
+    got = []
+    for _ in range(64):
+        assert lib.mvs_malloc(0, 3 << 20, C.byref(p2)) == 0
+        got.append(p2.value)
+        if p2.value == p1.value:
+            break
+    assert p1.value in got
+    for q in got:
+        assert lib.mvs_free(0, C.c_void_p(q)) == 0
     small = DeviceArray.from_host(np.ones((4, 4), np.uint16), 0)
     dst = DeviceArray.empty((6, 6), np.uint16, 0)
     with pytest.raises(RuntimeError, match="does not fit"):
