@@ -989,14 +989,19 @@ __global__ __launch_bounds__(256) void resample_kernel(DevView V, float* out, in
 // tile grid): scipy's order-0 / order-1 value at an integer coordinate of finite data is the sample itself (second tap weight
 // 0), so the resample is a crop + conversion -- 8 outputs per thread, one 16-byte (8-byte for uint8) load where the whole group
 // lies inside the tile.
+// `stats` (optional): per-block minimum, maximum and number of the values written from inside the tile -- [float min[nb]][float
+// max[nb]][long long count[nb]], the partials mvs_rescale_pair_device otherwise gets from a pass of its own over the crop (the values
+// are integers of the tile's type, so the "not a 16-bit integer" half of that count is 0).
 template <typename TIn>
 __global__ __launch_bounds__(256) void crop_int_kernel(const TIn* __restrict__ data, long long stride_z, long long stride_y, int nz, int ny,
                                                        int nx, int tz, int ty, int tx, float* __restrict__ out, int oz, int oy, int ox,
-                                                       float cval) {
+                                                       float cval, char* __restrict__ stats) {
     typedef TIn in8_t __attribute__((ext_vector_type(8), aligned(sizeof(TIn))));
     typedef float f4_t __attribute__((ext_vector_type(4), aligned(4)));
     const int gpr = (ox + 7) / 8;                                   // groups of 8 outputs per row
     const long long ngroups = (long long)oz * oy * gpr;
+    float smn = INFINITY, smx = -INFINITY;
+    long long snv = 0;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (long long)gridDim.x * blockDim.x) {
         const int xg = (int)(g % gpr) * 8;
         const long long row = g / gpr;
@@ -1012,8 +1017,37 @@ __global__ __launch_bounds__(256) void crop_int_kernel(const TIn* __restrict__ d
             b.x = (float)v[4]; b.y = (float)v[5]; b.z = (float)v[6]; b.w = (float)v[7];
             *reinterpret_cast<f4_t*>(o) = a;
             *reinterpret_cast<f4_t*>(o + 4) = b;
+            if (stats) {
+                smn = fminf(smn, fminf(fminf(fminf(a.x, a.y), fminf(a.z, a.w)), fminf(fminf(b.x, b.y), fminf(b.z, b.w))));
+                smx = fmaxf(smx, fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))));
+                snv += 8;
+            }
         } else {
-            for (int j = 0; j < 8 && xg + j < ox; ++j) o[j] = (zy && ix + j >= 0 && ix + j < nx) ? (float)p[j] : cval;
+            for (int j = 0; j < 8 && xg + j < ox; ++j) {
+                const bool in = zy && ix + j >= 0 && ix + j < nx;
+                const float v = in ? (float)p[j] : cval;
+                o[j] = v;
+                if (stats && in) { smn = fminf(smn, v); smx = fmaxf(smx, v); ++snv; }
+            }
+        }
+    }
+    if (stats) {
+        for (int off = 32; off > 0; off >>= 1) {
+            smn = fminf(smn, __shfl_down(smn, off));
+            smx = fmaxf(smx, __shfl_down(smx, off));
+            snv += __shfl_down(snv, off);
+        }
+        __shared__ float s_mn[4], s_mx[4];
+        __shared__ long long s_nv[4];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) { s_mn[wave] = smn; s_mx[wave] = smx; s_nv[wave] = snv; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) { smn = fminf(smn, s_mn[w]); smx = fmaxf(smx, s_mx[w]); snv += s_nv[w]; }
+            const int nb = gridDim.x;
+            ((float*)stats)[blockIdx.x] = smn;
+            ((float*)stats)[nb + blockIdx.x] = smx;
+            ((long long*)(stats + (size_t)nb * 8))[blockIdx.x] = snv;
         }
     }
 }
@@ -1450,13 +1484,19 @@ void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, 
     if (!c->force_generic && is_integer_crop(d, dtype, t)) {
         for (int k = 0; k < 3; ++k) t[k] += b0[k];
         const long long ng = (long long)shape[0] * shape[1] * ((shape[2] + 7) / 8);
-        const int nb = (int)std::min<long long>((ng + 255) / 256, 256 * 16);
+        int nb = (int)std::min<long long>((ng + 255) / 256, 256 * 16);
+        char* stats = nullptr;
+        if (c->crop_stats_dst && c->crop_stats_nb > 0 && cval != cval && !box0) {      // (NaN outside: "valid" == inside the tile)
+            stats = c->crop_stats_dst;
+            nb = c->crop_stats_nb;
+            c->crop_stats_done[c->crop_stats_k & 1] = true;
+        }
         if (dtype == MVS_U8)
             hipLaunchKernelGGL(crop_int_kernel<unsigned char>, dim3(nb), dim3(256), 0, c->stream, (const unsigned char*)d.data, d.stride_z, d.stride_y,
-                               d.nz, d.ny, d.nx, t[0], t[1], t[2], out, (int)shape[0], (int)shape[1], (int)shape[2], cval);
+                               d.nz, d.ny, d.nx, t[0], t[1], t[2], out, (int)shape[0], (int)shape[1], (int)shape[2], cval, stats);
         else
             hipLaunchKernelGGL(crop_int_kernel<unsigned short>, dim3(nb), dim3(256), 0, c->stream, (const unsigned short*)d.data, d.stride_z, d.stride_y,
-                               d.nz, d.ny, d.nx, t[0], t[1], t[2], out, (int)shape[0], (int)shape[1], (int)shape[2], cval);
+                               d.nz, d.ny, d.nx, t[0], t[1], t[2], out, (int)shape[0], (int)shape[1], (int)shape[2], cval, stats);
         return;
     }
     const int nblocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);

@@ -66,6 +66,12 @@ struct MvsContext {
     void* mbox_host = nullptr;
     void* mbox_dev = nullptr;
     size_t mbox_cap = 0;
+    // set by mvs_register_views around its two crops: the integer crop kernel also reduces min / max / #valid of what it writes into
+    // per-block partials (layout of nanminmax_pair_kernel) at crop_stats_dst, with crop_stats_nb blocks; crop_stats_done[k] tells
+    // mvs_rescale_pair_device that image k's partials are already there
+    char* crop_stats_dst = nullptr;
+    int crop_stats_nb = 0, crop_stats_k = 0;
+    bool crop_stats_done[2] = {false, false};
     bool no_regions = false;      // test switch: skip the region kernel (use the column kernel)
     bool rows_v1 = false;         // opt-in: direct-load row kernels (mvs_fuse_rows.hip) for every dtype (default: float tiles only)
     // caching device allocator behind mvs_malloc / mvs_free: freed blocks are kept (size-keyed) and handed out

@@ -198,11 +198,26 @@ extern "C" int mvs_register_views(int device, const mvs_view_t* fixed_view, cons
     float* crop0 = (float*)mvs_scratch(c, 11, (size_t)n * 4);
     float* crop1 = (float*)mvs_scratch(c, 12, (size_t)n * 4);
     if (!crop0 || !crop1) return MVS_ERR_HIP;
+    // crops of integer tiles under whole-pixel translations: the crop kernel reduces min / max / #valid of what it writes, so the
+    // normalisation needs no pass of its own over the crops (same partial layout and block count as mvs_rescale_pair_device)
+    const int nb_stats = (int)std::min<int64_t>(std::min<int64_t>((n + 255) / 256, 256 * 8), 512);
+    void *mb_host = nullptr, *mb_dev = nullptr;
+    rc = mvs_mailbox(c, (size_t)nb_stats * 32, &mb_host, &mb_dev);
+    if (rc) return rc;
+    c->crop_stats_done[0] = c->crop_stats_done[1] = false;
+    c->crop_stats_nb = nb_stats;
     c->defer_sync = true;
+    c->crop_stats_k = 0;
+    c->crop_stats_dst = (char*)mb_dev;
     rc = mvs_resample(device, fixed_view, out_shape, 1, NAN, crop0, MVS_MEM_DEVICE);
+    c->crop_stats_k = 1;
+    c->crop_stats_dst = (char*)mb_dev + (size_t)nb_stats * 16;
     if (!rc) rc = mvs_resample(device, moving_view, out_shape, 1, NAN, crop1, MVS_MEM_DEVICE);
     c->defer_sync = false;
-    if (rc) return rc;
-    return mvs_register_crops(device, crop0, crop1, MVS_MEM_DEVICE, ndim, out_shape, upsample_factor, region_mode, constant_check, t_out,
-                              quality_out, status_out, n_candidates_out);
+    c->crop_stats_dst = nullptr;
+    if (rc) { c->crop_stats_done[0] = c->crop_stats_done[1] = false; return rc; }
+    rc = mvs_register_crops(device, crop0, crop1, MVS_MEM_DEVICE, ndim, out_shape, upsample_factor, region_mode, constant_check, t_out,
+                            quality_out, status_out, n_candidates_out);
+    c->crop_stats_done[0] = c->crop_stats_done[1] = false;
+    return rc;
 }

@@ -342,7 +342,9 @@ int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, l
     char* scratch = (char*)mb_dev;
     PairPtrs PP;
     PP.in[0] = in0; PP.in[1] = in1; PP.out[0] = out0; PP.out[1] = out1;
-    hipLaunchKernelGGL(nanminmax_pair_kernel, dim3(nb, 2), dim3(256), 0, c->stream, PP, n, scratch, nb);
+    // (mvs_register_views: the crop kernels have left these partials already -- same layout, same block count)
+    if (!(c->crop_stats_done[0] && c->crop_stats_done[1] && c->crop_stats_nb == nb))
+        hipLaunchKernelGGL(nanminmax_pair_kernel, dim3(nb, 2), dim3(256), 0, c->stream, PP, n, scratch, nb);
     MVS_HIP_TRY(c, hipGetLastError());
     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (int k = 0; k < 2; ++k) {
