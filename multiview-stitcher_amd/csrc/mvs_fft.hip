@@ -43,6 +43,9 @@ struct FftArgs {
     const float* im_src = nullptr;
     float* peak_val[2] = {nullptr, nullptr};
     long long* peak_idx[2] = {nullptr, nullptr};
+    const float2* xp_src = nullptr;     // x pass only (stride 1, line = kz * xp_ny + ky)
+    float2* xp_p2 = nullptr;
+    int xp_ny = 0, xp_nz = 0, xp_sel_a = 0, xp_sel_b = 0;
 };
 
 // Stockham autosort stages on `lpb` lines of length M held in LDS: radix-4 passes (half the LDS round trips and
@@ -255,6 +258,25 @@ __device__ __forceinline__ float2 fft_load(const FftArgs& A, long long i) {
     im = (im != im) ? 0.f : im;
     return make_float2(re, im);
 }
+// The first pass of the inverse transform of the phase correlation, along x: its input is made from the packed spectrum Z (xp_src)
+// and its mirror Z(-k) on the fly, the cross power goes to xp_p2 (mvs_xpower_value, mvs_fft.h).
+struct XpLine { long long mbase; float scale_phase, scale_plain; };
+__device__ __forceinline__ XpLine xp_line(const FftArgs& A, long long l) {
+    XpLine x;
+    const int ky = (int)(l % A.xp_ny), kz = (int)(l / A.xp_ny);
+    const int my = ky ? A.xp_ny - ky : 0, mz = kz ? A.xp_nz - kz : 0;
+    x.mbase = ((long long)mz * A.xp_ny + my) * A.n;
+    x.scale_phase = x.scale_plain = 1.f;
+    if (A.xp_sel_b >= 0) mvs_xpower_scales(A.xp_src[0], (long long)A.xp_nz * A.xp_ny * A.n, &x.scale_phase, &x.scale_plain);
+    return x;
+}
+__device__ __forceinline__ float2 xp_load(const FftArgs& A, const XpLine& xl, long long base, int kx) {
+    const int mx = kx ? A.n - kx : 0;
+    float2 p, p1;
+    const float2 v = mvs_xpower_value(A.xp_src[base + kx], A.xp_src[xl.mbase + mx], A.xp_sel_a, A.xp_sel_b, xl.scale_phase, xl.scale_plain, &p, &p1);
+    A.xp_p2[base + kx] = p;
+    return v;
+}
 // running argmax |Re| / |Im| with the lowest flat index among equal values (np.argmax)
 struct Peak2 { float v[2]; long long i[2]; };
 __device__ __forceinline__ void peak_init(Peak2& p) { p.v[0] = p.v[1] = -1.f; p.i[0] = p.i[1] = 0x7fffffffffffffffLL; }
@@ -308,13 +330,15 @@ __global__ __launch_bounds__(256) void fft_reg2_kernel(FftArgs A) {
     float2* row = ex + line * LS;
     Peak2 pk;
     peak_init(pk);
+    XpLine xl;
+    if (A.xp_src) xl = xp_line(A, live ? l : 0);
     __syncthreads();                                                             // (twiddles)
     if (idx < R2) {                                                              // pass 1: j' = idx
         float2 v[R1];
 #pragma unroll
         for (int q = 0; q < R1; ++q) {
             v[q] = make_float2(0.f, 0.f);
-            if (live) v[q] = fft_load(A, base + (long long)(q * R2 + idx) * A.stride);
+            if (live) v[q] = A.xp_src ? xp_load(A, xl, base, q * R2 + idx) : fft_load(A, base + (long long)(q * R2 + idx) * A.stride);
             if (inv) v[q] = make_float2(v[q].y, v[q].x);
         }
         dft_reg<R1>(v);
@@ -364,6 +388,8 @@ __global__ __launch_bounds__(256) void bluestein_reg_kernel(FftArgs A) {
     float2* row = ex + line * LS;
     Peak2 pk;
     peak_init(pk);
+    XpLine xl;
+    if (A.xp_src) xl = xp_line(A, live ? l : 0);
     __syncthreads();                                                             // (twiddles)
     if (idx < R2) {                                                              // forward, pass 1: j' = idx
         float2 v[R1];
@@ -372,7 +398,7 @@ __global__ __launch_bounds__(256) void bluestein_reg_kernel(FftArgs A) {
             const int j = q * R2 + idx;
             v[q] = make_float2(0.f, 0.f);
             if (live && j < n) {
-                float2 x = fft_load(A, base + (long long)j * A.stride);
+                float2 x = A.xp_src ? xp_load(A, xl, base, j) : fft_load(A, base + (long long)j * A.stride);
                 if (inv) x.y = -x.y;                                             // IDFT(x) = conj(DFT(conj x))
                 v[q] = cmul(x, A.chirp[j]);
             }
@@ -711,7 +737,7 @@ int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inver
     int first_axis = -1, last_axis = -1;
     for (int axis = 2; axis >= 0; --axis)
         if (shape[axis] > 1) { if (first_axis < 0) first_axis = axis; last_axis = axis; }
-    if (fuse) { fuse->n_peak = 0; fuse->src_used = false; }
+    if (fuse) { fuse->n_peak = 0; fuse->src_used = false; fuse->xp_used = false; }
     for (int axis = 2; axis >= 0; --axis) {
         const int n = (int)shape[axis];
         if (n == 1) continue;
@@ -751,6 +777,12 @@ int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inver
                 A.re_src = fuse->re_src;
                 A.im_src = fuse->im_src;
                 fuse->src_used = true;
+            }
+            if (fuse && axis == first_axis && axis == 2 && inverse && fuse->xp_src && fuse->xp_p2) {
+                A.xp_src = fuse->xp_src; A.xp_p2 = fuse->xp_p2;
+                A.xp_ny = (int)ny; A.xp_nz = (int)nz;
+                A.xp_sel_a = fuse->xp_sel_a; A.xp_sel_b = fuse->xp_sel_b;
+                fuse->xp_used = true;
             }
             if (fuse && axis == last_axis && fuse->peak_val[0] && (long long)grid <= fuse->peak_cap) {
                 for (int k = 0; k < 2; ++k) { A.peak_val[k] = fuse->peak_val[k]; A.peak_idx[k] = fuse->peak_idx[k]; }

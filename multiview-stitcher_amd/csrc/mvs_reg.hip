@@ -35,39 +35,22 @@ __global__ void pack_pair_kernel(const float* __restrict__ a, const float* __res
 __global__ void xpower_packed_kernel(const float2* __restrict__ Z, float2* __restrict__ P1, float2* __restrict__ P2,
                                      float2* __restrict__ C, int nz, int ny, int nx, int sel_a, int sel_b) {
     const long long n = (long long)nz * ny * nx;
-    const float floor_ = 100.f * FLT_EPSILON;
     float scale_phase = 1.f, scale_plain = 1.f;
-    if (sel_b >= 0) {
-        const float2 z0 = Z[0];                                    // sum(a) + i sum(b): the DC term of the plain cross power is their product
-        const float dc = fabsf(z0.x * z0.y);
-        scale_plain = (dc > 0.f && dc < INFINITY) ? ldexpf(1.f, -ilogbf(dc)) : 1.f;
-        scale_phase = ldexpf(1.f, -ilogbf((float)n));
-    }
+    if (sel_b >= 0) mvs_xpower_scales(Z[0], n, &scale_phase, &scale_plain);   // Z[0] = sum(a) + i sum(b)
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int kx = (int)(i % nx);
         const long long t = i / nx;
         const int ky = (int)(t % ny), kz = (int)(t / ny);
         const int mx = kx ? nx - kx : 0, my = ky ? ny - ky : 0, mz = kz ? nz - kz : 0;
-        const float2 z = Z[i], m = Z[((long long)mz * ny + my) * nx + mx];
-        const float2 f = make_float2(0.5f * (z.x + m.x), 0.5f * (z.y - m.y));
-        const float2 g = make_float2(0.5f * (z.y + m.y), -0.5f * (z.x - m.x));
-        const float2 p = make_float2(f.x * g.x + f.y * g.y, f.y * g.x - f.x * g.y);   // f * conj(g)
-        const float a = fmaxf(hypotf(p.x, p.y), floor_);
-        const float2 p1 = make_float2(p.x / a, p.y / a);
+        // Two correlations in one transform only work if both have the same order of magnitude: float32 rounding of the
+        // larger one leaks into the other channel.  The phase-normalised correlation is <= N, the plain one about
+        // N * sum(a) * sum(b) for non-negative images (its DC term dominates): both are brought to O(1) by exact
+        // powers of two (scale_phase, scale_plain), which commute with every operation of the transform, so each
+        // channel holds the bits of its separate transform times its scale, plus ~1e-7 of the other channel.
+        float2 p, p1;
+        C[i] = mvs_xpower_value(Z[i], Z[((long long)mz * ny + my) * nx + mx], sel_a, sel_b, scale_phase, scale_plain, &p, &p1);
         P1[i] = p1;
         P2[i] = p;
-        const float2 pa = sel_a ? p1 : p;
-        if (sel_b < 0) C[i] = pa;
-        else {
-            // Two correlations in one transform only work if both have the same order of magnitude: float32 rounding of the
-            // larger one leaks into the other channel.  The phase-normalised correlation is <= N, the plain one about
-            // N * sum(a) * sum(b) for non-negative images (its DC term dominates): both are brought to O(1) by exact
-            // powers of two (scale_phase, scale_plain), which commute with every operation of the transform, so each
-            // channel holds the bits of its separate transform times its scale, plus ~1e-7 of the other channel.
-            const float2 pb = sel_b ? p1 : p;
-            const float sa = sel_a ? scale_phase : scale_plain, sb = sel_b ? scale_phase : scale_plain;
-            C[i] = make_float2(pa.x * sa - pb.y * sb, pa.y * sa + pb.x * sb);
-        }
     }
 }
 
@@ -169,6 +152,65 @@ __global__ __launch_bounds__(256) void updft_x_kernel(const float2* __restrict__
         }
         if (lane == 0) out[row * U + a] = acc;
     }
+}
+
+// Stage 1 of BOTH normalisations of a packed phase correlation in one pass over the plain cross power P2: the phase-normalised
+// one is formed on the fly (the same expression as mvs_xpower_value's p1, so the values are those xpower_packed_kernel would
+// have stored), which is why that array is neither written nor read.  Per normalisation the sums run in updft_x_kernel's order.
+struct UpdftX2 { const float2* K[2]; float2* out[2]; int phase[2]; };
+template <int UM>
+__global__ __launch_bounds__(256) void updft_x2_kernel(const float2* __restrict__ P2, UpdftX2 q, long long nrows, int nx, int U) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= nrows) return;
+    const float floor_ = 100.f * FLT_EPSILON;
+    float2 acc[2][UM];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int a = 0; a < UM; ++a) acc[j][a] = make_float2(0.f, 0.f);
+    // a lane's samples of 256 consecutive x are loaded together (a wavefront has only nx / 64 of them: one load in flight at a
+    // time leaves it waiting on memory latency), then consumed in ascending x like the one-at-a-time loop
+    for (int x0 = lane; x0 < nx; x0 += 256) {
+        float2 pv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pv[i] = (x0 + 64 * i < nx) ? P2[row * nx + x0 + 64 * i] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int x = x0 + 64 * i;
+            if (x < nx) {
+                const float2 p = pv[i];
+                const float m = fmaxf(hypotf(p.x, p.y), floor_);
+                const float2 p1 = make_float2(p.x / m, p.y / m);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float2 v = q.phase[j] ? p1 : p;
+#pragma unroll
+                    for (int a = 0; a < UM; ++a) {
+                        if (a < U) {
+                            const float2 k = q.K[j][a * nx + x];
+                            // k * conj(v)
+                            acc[j][a].x += k.x * v.x + k.y * v.y;
+                            acc[j][a].y += k.y * v.x - k.x * v.y;
+                        }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int a = 0; a < UM; ++a) {
+            if (a < U) {
+                float2 r = acc[j][a];
+                for (int off = 32; off > 0; off >>= 1) {
+                    r.x += __shfl_down(r.x, off);
+                    r.y += __shfl_down(r.y, off);
+                }
+                if (lane == 0) q.out[j][row * U + a] = r;
+            }
+        }
 }
 
 // Generic later stage: in has shape (n_outer, n_red, n_inner) -> out (n_outer, U, n_inner):
@@ -510,9 +552,14 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
   const char* hred = (const char*)mb_host;
   float packed_scale[2] = {1.f, 1.f};
   int n_red_packed = ga;
+  // ... and when its first pass (along x) runs on them and the refinement is small, the cross power is formed inside that pass
+  // (MvsFftFuse::xp_src) and both refinements' first stage read it in one launch (updft_x2_kernel): the combined spectrum and the
+  // phase-normalised cross power are never stored.
+  const bool fuse_xp = packed && first_axis == 2 && mvs_fft_reg_length((int)nx) && up_U0 <= 4;
   if (packed) {
-    hipLaunchKernelGGL(xpower_packed_kernel, dim3(gb), dim3(256), 0, c->stream, Z, P1, P2, CC, nz, ny, nx, normalizations[0] ? 1 : 0,
-                       normalizations[1] ? 1 : 0);
+    if (!fuse_xp)
+        hipLaunchKernelGGL(xpower_packed_kernel, dim3(gb), dim3(256), 0, c->stream, Z, P1, P2, CC, nz, ny, nx, normalizations[0] ? 1 : 0,
+                           normalizations[1] ? 1 : 0);
     // the correlation volume is only ever searched for its two peaks: when the last pass of the inverse transform runs on the
     // register kernels it reduces its output to per-workgroup maxima instead of storing it (no 27 MB written and read back)
     MvsFftFuse fp;
@@ -521,8 +568,10 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
         fp.peak_val[1] = (float*)(red + (size_t)ga * 16); fp.peak_idx[1] = (long long*)(red + (size_t)ga * 24);
         fp.peak_cap = ga;
     }
+    if (fuse_xp) { fp.xp_src = Z; fp.xp_p2 = P2; fp.xp_sel_a = normalizations[0] ? 1 : 0; fp.xp_sel_b = normalizations[1] ? 1 : 0; }
     rc = mvs_fft3_c2c(c, CC, shape, true, &fp);
     if (rc) return rc;
+    if (fuse_xp && !fp.xp_used) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "phase correlation: the fused cross-power pass was not taken");
     if (fp.n_peak > 0) {
         n_red_packed = fp.n_peak;
         hipLaunchKernelGGL(peek_kernel, dim3(1), dim3(64), 0, c->stream, (const unsigned int*)Z, (unsigned int*)((char*)mb_dev + mb_z0), 2);
@@ -541,7 +590,10 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
   }
   // Per normalisation: integer peak -> upsampled DFT around it.  The refinements of all normalisations are queued before
   // the host waits once for their results (phase 2 below).
-  struct NormState { float shift[3]; std::vector<float2> hk; size_t nout = 0; };   // hk stays alive until the wait (async upload)
+  struct NormState {
+      float shift[3]; std::vector<float2> hk; size_t nout = 0;                    // hk stays alive until the wait (async upload)
+      const float2* P = nullptr; float2 *dk = nullptr, *o1 = nullptr, *o2 = nullptr, *o3 = nullptr; size_t koff[3] = {0, 0, 0};
+  };
   std::vector<NormState> state((size_t)n_norm);
   const int up_U = (int)ceilf((float)upsample_factor * 1.5f);
   const size_t up_kbytes = ((size_t)up_U * (size_t)(nz + ny + nx) * sizeof(float2) + 255) / 256 * 256;
@@ -620,21 +672,28 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
         float2* mres = (float2*)((char*)mb_dev + mb_res + mb_res_stride * (size_t)inorm);     // the last stage writes host memory
         if (ndim == 3) o3 = mres; else o2 = mres;
         MVS_HIP_TRY(c, hipMemcpyAsync(dk, hk.data(), kbytes, hipMemcpyHostToDevice, c->stream));
-        // stage 1: x  -> (z, y, ux)
-        hipLaunchKernelGGL(updft_x_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, P, dk + koff[2], o1, nrows, nx, U);
-        // stage 2: y  -> (z, uy, ux)
-        hipLaunchKernelGGL(updft_mid_kernel, dim3((unsigned)std::min<long long>(((long long)s2 + 3) / 4, 4096)), dim3(256), 0, c->stream, o1, dk + koff[1], o2, nz, ny, U, U);
-        size_t nout = s2;
-        float2* res = o2;
-        if (ndim == 3) {
+        NormState& st = state[inorm];
+        st.P = P; st.dk = dk; st.o1 = o1; st.o2 = o2; st.o3 = o3;
+        for (int k = 0; k < 3; ++k) st.koff[k] = koff[k];
+        st.nout = ndim == 3 ? s3 : s2;
+        if (!fuse_xp) {
+            // stage 1: x  -> (z, y, ux)
+            hipLaunchKernelGGL(updft_x_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, P, dk + koff[2], o1, nrows, nx, U);
+        } else if (inorm == n_norm - 1) {
+            // stage 1 of both normalisations from the plain cross power alone
+            UpdftX2 q;
+            for (int j = 0; j < 2; ++j) { q.K[j] = state[j].dk + state[j].koff[2]; q.out[j] = state[j].o1; q.phase[j] = normalizations[j] ? 1 : 0; }
+            hipLaunchKernelGGL(updft_x2_kernel<4>, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, P2, q, nrows, nx, U);
+        }
+        for (int j = (fuse_xp ? (inorm == n_norm - 1 ? 0 : n_norm) : inorm); j <= inorm && j < n_norm; ++j) {
+            const NormState& sj = state[j];
+            // stage 2: y  -> (z, uy, ux)
+            hipLaunchKernelGGL(updft_mid_kernel, dim3((unsigned)std::min<long long>(((long long)s2 + 3) / 4, 4096)), dim3(256), 0, c->stream, sj.o1, sj.dk + sj.koff[1], sj.o2, nz, ny, U, U);
             // stage 3: z -> (uz, uy, ux)
-            hipLaunchKernelGGL(updft_mid_kernel, dim3((unsigned)std::min<long long>(((long long)s3 + 3) / 4, 4096)), dim3(256), 0, c->stream, o2, dk + koff[0], o3, 1, nz, U * U, U);
-            nout = s3;
-            res = o3;
+            if (ndim == 3)
+                hipLaunchKernelGGL(updft_mid_kernel, dim3((unsigned)std::min<long long>(((long long)s3 + 3) / 4, 4096)), dim3(256), 0, c->stream, sj.o2, sj.dk + sj.koff[0], sj.o3, 1, nz, U * U, U);
         }
         MVS_HIP_TRY(c, hipGetLastError());
-        state[inorm].nout = nout;
-        (void)res;
     }
   }
   MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
