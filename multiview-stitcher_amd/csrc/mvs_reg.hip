@@ -546,7 +546,10 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
   }
   const size_t mb_red = (size_t)ga * 32, mb_z0 = mb_red, mb_res = mb_red + 256, mb_res_stride = (res_elems * sizeof(float2) + 255) / 256 * 256;
   void *mb_host = nullptr, *mb_dev = nullptr;
-  rc = mvs_mailbox(c, mb_res + mb_res_stride * (size_t)n_norm, &mb_host, &mb_dev);
+  // ... | the kernel vectors of every refinement (pinned: their upload is a plain asynchronous copy, no staging through the runtime)]
+  const size_t mb_k = mb_res + mb_res_stride * (size_t)n_norm;
+  const size_t mb_kbytes = upsample_factor > 1 ? ((size_t)up_U0 * (size_t)(nz + ny + nx) * sizeof(float2) + 255) / 256 * 256 : 0;
+  rc = mvs_mailbox(c, mb_k + mb_kbytes * (size_t)n_norm, &mb_host, &mb_dev);
   if (rc) return rc;
   char* red = (char*)mb_dev;
   const char* hred = (const char*)mb_host;
@@ -591,7 +594,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
   // Per normalisation: integer peak -> upsampled DFT around it.  The refinements of all normalisations are queued before
   // the host waits once for their results (phase 2 below).
   struct NormState {
-      float shift[3]; std::vector<float2> hk; size_t nout = 0;                    // hk stays alive until the wait (async upload)
+      float shift[3]; size_t nout = 0;
       const float2* P = nullptr; float2 *dk = nullptr, *o1 = nullptr, *o2 = nullptr, *o3 = nullptr; size_t koff[3] = {0, 0, 0};
   };
   std::vector<NormState> state((size_t)n_norm);
@@ -651,18 +654,18 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
         }
         // kernels exp(-2 pi i (a - off) * fftfreq(n, uf)[x]) computed in double, cast to complex64
         const int k0 = (ndim == 3) ? 0 : 1;
-        std::vector<float2>& hk = state[inorm].hk;
-        size_t koff[3] = {0, 0, 0};
+        float2* hk = (float2*)((char*)mb_host + mb_k + mb_kbytes * (size_t)inorm);   // stays untouched until the wait below
+        size_t koff[3] = {0, 0, 0}, nk = 0;
         for (int k = k0; k < 3; ++k) {
-            koff[k] = hk.size();
+            koff[k] = nk;
             const int nn = (int)shape[k];
             for (int a = 0; a < U; ++a)
                 for (int x = 0; x < nn; ++x) {
                     const double ph = -2.0 * M_PI * ((double)a - (double)offs[k]) * fftfreq(nn, (double)uf, x);
-                    hk.push_back(make_float2((float)cos(ph), (float)sin(ph)));
+                    hk[nk++] = make_float2((float)cos(ph), (float)sin(ph));
                 }
         }
-        const size_t kbytes = hk.size() * sizeof(float2);
+        const size_t kbytes = nk * sizeof(float2);
         const long long nrows = (long long)nz * ny;
         const size_t s1 = (size_t)nrows * U, s2 = (size_t)nz * U * U, s3 = (size_t)U * U * U;
         float2* dk = (float2*)(up_base + (size_t)inorm * up_bytes);
@@ -671,7 +674,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
         float2* o3 = o2 + s2;
         float2* mres = (float2*)((char*)mb_dev + mb_res + mb_res_stride * (size_t)inorm);     // the last stage writes host memory
         if (ndim == 3) o3 = mres; else o2 = mres;
-        MVS_HIP_TRY(c, hipMemcpyAsync(dk, hk.data(), kbytes, hipMemcpyHostToDevice, c->stream));
+        MVS_HIP_TRY(c, hipMemcpyAsync(dk, hk, kbytes, hipMemcpyHostToDevice, c->stream));
         NormState& st = state[inorm];
         st.P = P; st.dk = dk; st.o1 = o1; st.o2 = o2; st.o3 = o3;
         for (int k = 0; k < 3; ++k) st.koff[k] = koff[k];
