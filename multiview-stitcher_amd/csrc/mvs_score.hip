@@ -617,7 +617,7 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
     constexpr int NO = 4, NI = NO + 2 * H;           // outputs / inputs of one y- or x-pass item
     constexpr int NR = (LY + 3) / 4;                 // patch rows per thread: row = (tid >> 6) + 4 k, column = tid & 63
     constexpr double inv = 1.0 / (double)WIN;
-    static_assert(LX <= 64 && TY % NO == 0 && TX % NO == 0 && (TY * TX) / NO <= 256 && LX * (TY / NO) <= 256, "tile layout");
+    static_assert(LX <= 64 && TY % NO == 0 && TX % NO == 0 && (TY * TX) / NO <= 256 && TY / NO == 4, "tile layout");
     __shared__ float sz_[3][LY][LX + 1];             // z-filtered y, yy, xy of the current plane (tile + halo)
     __shared__ float sy_[3][TY][LX + 1];             // ... filtered along y as well
     const FusedCand C = B.c[blockIdx.y];
@@ -718,8 +718,8 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
 
                 __syncthreads();
                 // ---- y pass: column c of the patch, NO rows per item ----
-                if (tid < LX * (TY / NO)) {
-                    const int c = tid % LX, rc = tid / LX;
+                if (col < LX) {                                   // one wavefront per group of NO rows: lanes = consecutive columns (no bank conflicts)
+                    const int c = col, rc = wrow;
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
                         float v[NI], f[NO];
