@@ -4,9 +4,55 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
+#include <immintrin.h>
+
 #include "mvs_hip.h"
+
+// The residual pass of one sweep for the common case (3D, 8 beads per edge) on 4-wide vectors: lane = bead & 3, i.e. exactly the
+// four accumulators of the scalar loops below, the same operations in the same order (separate multiplies and adds, no fused
+// ones), so the results are bit-identical to the scalar form (tests/test_param_resolution.py runs both).  d0 is stored per edge as
+// [x of beads 0..7 | y of beads 0..7 | z of beads 0..7].  Returns the sum over edges of (edge mean) and updates the three maxima.
+__attribute__((target("avx2"))) static double residual_pass_avx2(int n_edges, const int32_t* edge_nodes, const double* d0soa,
+                                                                 const double* translations, double* edge_residuals, double* prev,
+                                                                 bool with_prev, double* mx_out, double* dmax_out) {
+    __m256d m4 = _mm256_setzero_pd(), c4 = _mm256_setzero_pd();
+    const __m256d absmask = _mm256_castsi256_pd(_mm256_set1_epi64x(0x7fffffffffffffffLL));
+    double mean_acc = 0.0;
+    for (int e = 0; e < n_edges; ++e) {
+        const int a = edge_nodes[2 * e], b2 = edge_nodes[2 * e + 1];
+        const double* dp = d0soa + (size_t)e * 24;
+        double* rp = edge_residuals + (size_t)e * 8;
+        double* pp = prev + (size_t)e * 8;
+        __m256d es = _mm256_setzero_pd();
+        __m256d dt[3];
+        for (int d = 0; d < 3; ++d) dt[d] = _mm256_set1_pd(translations[(size_t)a * 3 + d] - translations[(size_t)b2 * 3 + d]);
+        for (int h = 0; h < 2; ++h) {
+            __m256d q = _mm256_setzero_pd();
+            for (int d = 0; d < 3; ++d) {
+                const __m256d v = _mm256_add_pd(_mm256_loadu_pd(dp + d * 8 + h * 4), dt[d]);
+                q = _mm256_add_pd(q, _mm256_mul_pd(v, v));
+            }
+            const __m256d r = _mm256_sqrt_pd(q);
+            es = _mm256_add_pd(es, r);
+            m4 = _mm256_max_pd(r, m4);                              // (r, m4): a NaN residual leaves the maximum alone, like fmax
+            if (with_prev) c4 = _mm256_max_pd(_mm256_and_pd(_mm256_sub_pd(r, _mm256_loadu_pd(pp + h * 4)), absmask), c4);
+            _mm256_storeu_pd(rp + h * 4, r);
+            _mm256_storeu_pd(pp + h * 4, r);
+        }
+        double esv[4];
+        _mm256_storeu_pd(esv, es);
+        mean_acc += ((esv[0] + esv[1]) + (esv[2] + esv[3])) / 8.0;
+    }
+    double mv[4], cv[4];
+    _mm256_storeu_pd(mv, m4);
+    _mm256_storeu_pd(cv, c4);
+    *mx_out = std::fmax(std::fmax(mv[0], mv[1]), std::fmax(mv[2], mv[3]));
+    *dmax_out = std::fmax(std::fmax(cv[0], cv[1]), std::fmax(cv[2], cv[3]));
+    return mean_acc;
+}
 
 extern "C" int mvs_beads_translation_sweeps(int32_t ndim, int32_t n_nodes, int32_t n_edges, const int32_t* edge_nodes,
                                             const double* beads_a, const double* beads_b, int32_t n_beads, const int32_t* order,
@@ -49,6 +95,16 @@ extern "C" int mvs_beads_translation_sweeps(int32_t ndim, int32_t n_nodes, int32
     const double nb = (double)n_beads;
     const size_t nres = (size_t)n_edges * (size_t)n_beads;
     std::vector<double> prev(nres, 0.0);
+    // vector form of the residual pass (3D mosaics: 8 beads per edge), unless switched off for the A/B test
+    static const bool no_simd = getenv("MVS_RESOLVE_SCALAR") != nullptr;
+    const bool simd = ndim == 3 && n_beads == 8 && !no_simd && __builtin_cpu_supports("avx2");
+    std::vector<double> d0soa;
+    if (simd) {
+        d0soa.resize((size_t)n_edges * 24);
+        for (int e = 0; e < n_edges; ++e)
+            for (int b = 0; b < 8; ++b)
+                for (int d = 0; d < 3; ++d) d0soa[(size_t)e * 24 + d * 8 + b] = d0[(size_t)e * 24 + b * 3 + d];
+    }
     int it = 0;
     for (; it < max_iter; ++it) {
         for (int s = 0; s < n_nodes; ++s) {
@@ -73,6 +129,14 @@ extern "C" int mvs_beads_translation_sweeps(int32_t ndim, int32_t n_nodes, int32
         }
         // bead residuals of every edge, their mean of means and overall maximum
         double mean_acc = 0.0, mx = 0.0;
+        if (simd) {
+            double dmax = 0.0;
+            mean_acc = residual_pass_avx2(n_edges, edge_nodes, d0soa.data(), translations, edge_residuals, prev.data(), it > 5, &mx, &dmax);
+            mean_hist[it] = n_edges ? mean_acc / (double)n_edges : 0.0;
+            max_hist[it] = mx;
+            if (it > 5 && (mx > 0.0 ? dmax / mx : 0.0) < rel_tol) { ++it; break; }
+            continue;
+        }
         for (int e = 0; e < n_edges; ++e) {
             const int a = edge_nodes[2 * e], b2 = edge_nodes[2 * e + 1];
             double dt[3] = {0.0, 0.0, 0.0};

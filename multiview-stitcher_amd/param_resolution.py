@@ -257,6 +257,19 @@ def _translation_sweeps_native(ndim, all_nodes, edges, beads, sorted_nodes, ref,
     return {e: res[k] for k, e in enumerate(edges)}, list(mh[:n]), list(xh[:n]), n
 
 
+def _edge_means(nodes, edge_residuals):
+    """{(node a, node b): mean bead residual} -- one reduction over the (edges, beads) array instead of a numpy call per edge."""
+    keys = list(edge_residuals)
+    if not keys:
+        return {}
+    rows = [np.asarray(edge_residuals[k], dtype=np.float64).ravel() for k in keys]
+    if len({len(r) for r in rows}) == 1:
+        means = np.stack(rows).mean(axis=1).tolist()
+    else:
+        means = [float(np.mean(r)) for r in rows]
+    return {(nodes[a], nodes[b]): m for (a, b), m in zip(keys, means)}
+
+
 _ESTIMATORS = {
     "translation": _estimate_translation,
     "rigid": lambda s, d: _umeyama(s, d, False),
@@ -362,7 +375,7 @@ def groupwise_resolution_global_optimization(g, reference_view=None, transform="
     info = {
         "metrics": {"mean_residual": list(mean_res), "max_residual": list(max_res), "iteration": list(range(len(mean_res)))},
         "used_edges": [tuple(sorted((nodes[a], nodes[b]))) for a, b in edges],
-        "edge_residuals_final": {(nodes[a], nodes[b]): float(np.mean(r)) for (a, b), r in edge_residuals.items()},
+        "edge_residuals_final": _edge_means(nodes, edge_residuals),
     }
     return params, info
 

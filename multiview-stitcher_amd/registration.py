@@ -600,14 +600,19 @@ def _prebin_views(sims, registration_binning, device, cache):
     lib = _lib.init(lane_device)
     s3, b3 = _lib.i64x3(shape3(shape)), _lib.i64x3([1] * (3 - nd) + bins)
     code = _lib.DTYPE_CODES[dtype]
+    # the coarsened coordinates of _bin_sim (mean of each group of b: the sum divided by b, as numpy's mean does it), all views
+    # of an axis in one reduction (the same additions per element as view by view)
+    all_coords = {}
+    for d, b, n in zip(sdims, bins, oshape):
+        stack = np.stack([np.asarray(s.coords[d])[: n * b] for s in sims])
+        all_coords[d] = np.add.reduce(stack.reshape(len(sims), n, b), axis=2) / b
     for i, s in enumerate(sims):
         data = s.data.on_device(lane_device)
         st = [int(v) for v in data.strides]
         st3 = st if nd == 3 else [st[0] * shape[0], st[0], st[1]]
         out = pool[i]
         _lib.check(lib.mvs_bin_mean_async(lane_device, data.ptr, code, s3, _lib.i64x3(st3), b3, out.ptr), lane_device, "mvs_bin_mean_async")
-        # the coarsened coordinates of _bin_sim (mean of each group of b: the sum divided by b, as numpy's mean does it)
-        coords = {d: np.add.reduce(s.coords[d][: n * b].reshape(n, b), axis=1) / b for d, b, n in zip(sdims, bins, oshape)}
+        coords = {d: all_coords[d][i] for d in sdims}
         binned = si_utils.SpatialImage(out, sdims, coords, {"transforms": dict(s.attrs.get("transforms", {}))})
         cache.put((id(s.data), bkey), binned, keep=(s.data, data))
     return lane_device

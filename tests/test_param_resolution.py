@@ -156,6 +156,32 @@ def test_native_translation_sweeps_equal_numpy_sweeps(ndim, monkeypatch):
     np.testing.assert_allclose(m_nat["mean_residual"], m_np["mean_residual"], rtol=1e-9, atol=1e-12)
 
 
+def test_vector_residual_pass_is_bitwise_the_scalar_one():
+    """The AVX2 form of the sweeps' residual pass (3D, 8 beads per edge) against the scalar loops (MVS_RESOLVE_SCALAR=1, read once
+    per process, hence two subprocesses): parameters and the whole per-sweep history bit for bit."""
+    import os, subprocess, sys
+    script = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from test_param_resolution import _grid_graph\n"
+        "from multiview_stitcher_amd import param_resolution as pr\n"
+        "g, _ = _grid_graph(4, 3, 3, noise=0.3, seed=5, quality=0.8)\n"
+        "p, i = pr.groupwise_resolution(g, 'global_optimization', reference_view=2)\n"
+        "m = i['metrics'][0]\n"
+        "print(json.dumps([[float(x).hex() for x in np.ravel(p[v])] for v in sorted(p)] + [[float(x).hex() for x in m['mean_residual']], [float(x).hex() for x in m['max_residual']]]))\n"
+    ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for scalar in (False, True):
+        env = dict(os.environ)
+        env.pop("MVS_RESOLVE_SCALAR", None)
+        if scalar:
+            env["MVS_RESOLVE_SCALAR"] = "1"
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
+
+
 # ---- linear two-pass resolver (param_resolution/linear_two_pass.py) ------------------------------------------------------
 def test_linear_two_pass_translation_solves_a_consistent_grid_exactly():
     g, tau = _grid_graph(4, 3, ndim=3, seed=3)
