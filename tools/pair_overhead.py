@@ -32,7 +32,7 @@ def rp(*a, **k):
 
 _reg_ops.register_views = rv
 registration.register_pair_of_msims = rp
-for threads in (16, 8, 1):
+for threads in (16, 1):     # (other lane counts: tools/sweep_threads.sh -- a second pool in the same process is not representative)
     for rep in range(3):
         lib_t.clear(); pair_t.clear()
         t0 = time.perf_counter()
