@@ -9,8 +9,9 @@ DST = os.path.join(ROOT, "profiles")
 
 
 def find(pattern):
+    # gpurun MERGES a run's files into gpurun_out/ (files of earlier runs stay): the newest match is the current run's
     hits = glob.glob(os.path.join(SRC, pattern), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 def per_kernel(path, reps):
