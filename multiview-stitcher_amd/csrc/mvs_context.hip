@@ -243,6 +243,10 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         c->serial_classes = value != 0;
         return MVS_OK;
     }
+    if (!strcmp(key, "reg_unfused")) {
+        c->reg_unfused = value != 0;
+        return MVS_OK;
+    }
     if (!strcmp(key, "ssim_two_pass")) {
         c->ssim_two_pass = value != 0;
         return MVS_OK;

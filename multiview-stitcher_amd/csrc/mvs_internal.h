@@ -47,6 +47,7 @@ struct MvsContext {
     bool serial_classes = false;       // option "serial_classes": launch them one after the other on the main stream instead
     bool defer_sync = false;           // set by composite entry points: mvs_resample to device memory returns without waiting
     bool both_crops_finite = false;    // set by mvs_register_crops around its mvs_score_candidates call (under the context lock)
+    bool reg_unfused = false;          // test switch: the phase correlation runs its separate launches (pack, cross power, peak search, min / max) instead of the fused passes
     bool ssim_two_pass = false;        // test switch: batched candidates go through the separate z and y/x SSIM launches instead of the fused walk
     bool materialize_shifts = false;   // test switch: candidate scoring always writes the shifted copies (no on-the-fly SSIM z pass)
     std::recursive_mutex mu;      // recursive: composite entry points (mvs_pair.hip) call the public ones under the lock

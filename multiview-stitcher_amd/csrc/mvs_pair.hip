@@ -208,10 +208,10 @@ extern "C" int mvs_register_views(int device, const mvs_view_t* fixed_view, cons
     c->crop_stats_nb = nb_stats;
     c->defer_sync = true;
     c->crop_stats_k = 0;
-    c->crop_stats_dst = (char*)mb_dev;
+    c->crop_stats_dst = c->reg_unfused ? nullptr : (char*)mb_dev;
     rc = mvs_resample(device, fixed_view, out_shape, 1, NAN, crop0, MVS_MEM_DEVICE);
     c->crop_stats_k = 1;
-    c->crop_stats_dst = (char*)mb_dev + (size_t)nb_stats * 16;
+    c->crop_stats_dst = c->reg_unfused ? nullptr : (char*)mb_dev + (size_t)nb_stats * 16;
     if (!rc) rc = mvs_resample(device, moving_view, out_shape, 1, NAN, crop1, MVS_MEM_DEVICE);
     c->defer_sync = false;
     c->crop_stats_dst = nullptr;

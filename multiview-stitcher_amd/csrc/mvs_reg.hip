@@ -521,7 +521,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     int first_axis = -1, last_axis = -1;
     for (int axis = 2; axis >= 0; --axis)
         if (shape[axis] > 1) { if (first_axis < 0) first_axis = axis; last_axis = axis; }
-    if (first_axis >= 0 && mvs_fft_reg_length((int)shape[first_axis])) {
+    if (first_axis >= 0 && mvs_fft_reg_length((int)shape[first_axis]) && !c->reg_unfused) {
         MvsFftFuse ff;      // the first pass reads a and b themselves: no packed copy is written and read back
         ff.re_src = da;
         ff.im_src = db;
@@ -559,7 +559,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
   // ... and when its first pass (along x) runs on them and the refinement is small, the cross power is formed inside that pass
   // (MvsFftFuse::xp_src) and both refinements' first stage read it in one launch (updft_x2_kernel): the combined spectrum and the
   // phase-normalised cross power are never stored.
-  const bool fuse_xp = packed && first_axis == 2 && mvs_fft_reg_length((int)nx) && up_U0 <= 4;
+  const bool fuse_xp = packed && first_axis == 2 && mvs_fft_reg_length((int)nx) && up_U0 <= 4 && !c->reg_unfused;
   if (packed) {
     if (!fuse_xp)
         hipLaunchKernelGGL(xpower_packed_kernel, dim3(gb), dim3(256), 0, c->stream, Z, P1, P2, CC, nz, ny, nx, normalizations[0] ? 1 : 0,
@@ -567,7 +567,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     // the correlation volume is only ever searched for its two peaks: when the last pass of the inverse transform runs on the
     // register kernels it reduces its output to per-workgroup maxima instead of storing it (no 27 MB written and read back)
     MvsFftFuse fp;
-    if (last_axis >= 0 && mvs_fft_reg_length((int)shape[last_axis])) {
+    if (last_axis >= 0 && mvs_fft_reg_length((int)shape[last_axis]) && !c->reg_unfused) {
         fp.peak_val[0] = (float*)red; fp.peak_idx[0] = (long long*)(red + (size_t)ga * 8);
         fp.peak_val[1] = (float*)(red + (size_t)ga * 16); fp.peak_idx[1] = (long long*)(red + (size_t)ga * 24);
         fp.peak_cap = ga;

@@ -450,6 +450,57 @@ def test_many_candidates_span_several_batches(hip_device):
     assert tuple(cands[best]) == (1, -2, 3) and np.isfinite(spear[best]) and np.isnan(spear).sum() == (codes == 0).sum() - 1
 
 
+@pytest.mark.parametrize("shape", [(51, 256, 256), (40, 56, 64), (30, 50, 70), (64, 64, 128), (20, 40, 300), (70, 300, 33)])
+def test_fused_transform_ends_equal_separate_launches(hip_device, shape):
+    """The fusions at the ends of the two transforms of the phase correlation (first pass of the forward transform reads the real
+    crops, first pass of the inverse forms the cross power, its last pass reduces to the peaks, one first refinement stage for both
+    normalisations) against the separate launches they replace (option "reg_unfused": pack, cross-power kernel, stored
+    correlation + peak search, one refinement stage per normalisation): integer peaks, peak heights and refined shifts bit for bit.
+    The shapes mix register-length axes (64 / 128 / 256, Bluestein up to 128 samples), where the fusions are taken, with axes
+    that run on the LDS kernel, where they are not."""
+    from multiview_stitcher_amd import _lib, _reg_ops
+
+    a, b = _pair(shape, (2, -3, 4), noise=0.01)
+    a, b = np.nan_to_num(ro.rescale_intensity_01(a)), np.nan_to_num(ro.rescale_intensity_01(b))
+    res = []
+    for flag in (1, 0):
+        _lib.set_option("reg_unfused", flag)
+        try:
+            res.append(_reg_ops.phase_cross_correlation_multi(a, b, upsample_factor=2, normalizations=("phase", None)))
+        finally:
+            _lib.set_option("reg_unfused", 0)
+    for (s0, d0), (s1, d1) in zip(*res):
+        np.testing.assert_array_equal(s0, s1)
+        np.testing.assert_array_equal(d0["peak_index"], d1["peak_index"])
+        assert d0["peak_abs"] == d1["peak_abs"]
+    np.testing.assert_allclose(res[1][0][0], [2, -3, 4], atol=0.51)
+
+
+def test_crop_statistics_of_the_crop_kernel_equal_the_separate_reduction(hip_device):
+    """register() on device-resident uint16 tiles: the integer crop kernel reduces min / max / #valid of what it writes (no pass of
+    its own over the crops for the normalisation) -- against option "reg_unfused", where the reduction kernel runs: parameters and
+    qualities bit for bit."""
+    from multiview_stitcher_amd import _lib, device, registration, sample_data, spatial_image_utils as si
+
+    sims, jit, _ = sample_data.generate_tiled_dataset(ndim=3, tile_shape=(48, 96, 96), tiles=(1, 2, 2), overlap=(0, 32, 32),
+                                                      dtype=np.uint16, max_jitter=2, seed=5)
+    sims = [device.to_device(s.isel({"c": 0, "t": 0}), 0) for s in sims]
+    res = []
+    for flag in (1, 0):
+        for lane in range(16):
+            _lib.set_option("reg_unfused", flag, device=lane << 8)
+        try:
+            res.append(registration.register(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, new_transform_key=None,
+                                             registration_binning={"z": 1, "y": 2, "x": 2}, return_dict=True))
+        finally:
+            for lane in range(16):
+                _lib.set_option("reg_unfused", 0, device=lane << 8)
+    for p0, p1 in zip(res[0]["params"], res[1]["params"]):
+        np.testing.assert_array_equal(p0, p1)
+    q0, q1 = (r["pairwise_registration"]["metrics"]["qualities"] for r in res)
+    assert q0 == q1 and len(q0) >= 3
+
+
 @pytest.mark.parametrize("shape", [(51, 128, 120), (96, 51, 70), (40, 90, 29), (9, 30, 64)])
 def test_fused_ssim_walk_equals_separate_passes_and_oracle(hip_device, shape):
     """Finite 3D crops, several candidates: one launch walks z per (y, x) tile and keeps the z- and y-filtered planes in LDS
