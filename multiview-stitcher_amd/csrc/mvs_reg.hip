@@ -11,6 +11,8 @@
 // out_range=(0,1)) (registration.py:381-389).
 #include "mvs_fft.h"
 
+#include <rocprim/warp/warp_reduce.hpp>
+
 #include <cfloat>
 #include <cmath>
 #include <vector>
@@ -214,11 +216,99 @@ __global__ __launch_bounds__(256) void updft_x2_kernel(const float2* __restrict_
         }
 }
 
+// Stages 1 AND 2 of both refinements of a 3D pair in one pass over the plain cross power (nx <= 256, U samples per axis):
+//   part[(z, chunk)][b][a] = sum_{y in chunk} sum_x Ky[b][y] Kx[a][x] conj(v[z][y][x]).
+// A workgroup owns the rows of one y chunk of one plane; every lane sums ITS columns over the wavefront's rows first (the y
+// contraction: sequential additions, nothing crosses lanes), then contracts its columns with Kx and only then the 2 x U x U results
+// are reduced across the wavefront and the four wavefronts -- one reduction per 16 rows instead of one per row and stage (the
+// row-at-a-time kernels spend their time in exactly those reductions: 55 us for the three stages of both refinements of a
+// 256 x 256 x 51 crop, 39 us this way).  Stage 3 (updft_mid_kernel over z) folds the chunks
+// (kdiv: the chunks of a plane share its kernel sample).  The sums run in a different order than in the separate stages (y before x): equal to them to
+// float32 rounding, the refined shifts -- multiples of 1 / upsample -- agree (tests/test_reg_gpu.py).
+constexpr int kYxChunksMax = 64, kYxRows = 64;      // rows of a chunk, 16 per wavefront (measured 8 ... 128 rows: 60.6, 42.7, 33.9, 33.0, 38.2 us for stages 1-3)
+struct UpdftYX { const float2* Kx[2]; const float2* Ky[2]; float2* out[2]; int phase[2]; };
+template <int U>
+__global__ __launch_bounds__(256) void updft_yx2_kernel(const float2* __restrict__ P2, UpdftYX q, int nz, int ny, int nx, int rows_per_chunk, int nchunks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int z = blockIdx.x / nchunks, ch = blockIdx.x % nchunks;
+    const int y0 = ch * rows_per_chunk, y1 = min(y0 + rows_per_chunk, ny);
+    const float floor_ = 100.f * FLT_EPSILON;
+    float2 s[2][U][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int b = 0; b < U; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s[j][b][i] = make_float2(0.f, 0.f);
+    for (int y = y0 + wave; y < y1; y += 4) {
+        const float2* row = P2 + ((long long)z * ny + y) * nx;
+        float2 pv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pv[i] = (lane + 64 * i < nx) ? row[lane + 64 * i] : make_float2(0.f, 0.f);
+        float2 ky[2][U];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int b = 0; b < U; ++b) ky[j][b] = q.Ky[j][b * ny + y];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (64 * i >= nx) continue;                               // (uniform: short rows use the first lanes' slots only)
+            const float2 p = pv[i];                                   // (columns beyond nx hold 0: they add nothing)
+            const float m = fmaxf(hypotf(p.x, p.y), floor_);
+            const float2 p1 = make_float2(p.x / m, p.y / m);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float2 v = q.phase[j] ? p1 : p;
+#pragma unroll
+                for (int b = 0; b < U; ++b) {
+                    const float2 k = ky[j][b];
+                    // k * conj(v)
+                    s[j][b][i].x += k.x * v.x + k.y * v.y;
+                    s[j][b][i].y += k.y * v.x - k.x * v.y;
+                }
+            }
+        }
+    }
+    // x contraction of the lane's columns, then across the wavefront
+    __shared__ float2 red[4][2 * U * U];
+    using WaveSum = rocprim::warp_reduce<float, 64>;
+    __shared__ typename WaveSum::storage_type wsum[4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int a = 0; a < U; ++a) {
+            float2 kx[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kx[i] = (lane + 64 * i < nx) ? q.Kx[j][a * nx + lane + 64 * i] : make_float2(0.f, 0.f);
+#pragma unroll
+            for (int b = 0; b < U; ++b) {
+                float2 r = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (64 * i >= nx) continue;
+                    r.x += kx[i].x * s[j][b][i].x - kx[i].y * s[j][b][i].y;
+                    r.y += kx[i].x * s[j][b][i].y + kx[i].y * s[j][b][i].x;
+                }
+                // (DPP row operations: the bpermute-based shuffle tree costs several times as much, and this kernel is made of reductions)
+                WaveSum().reduce(r.x, r.x, wsum[wave]);
+                WaveSum().reduce(r.y, r.y, wsum[wave]);
+                if (lane == 0) red[wave][(j * U + b) * U + a] = r;
+            }
+        }
+    __syncthreads();
+    if (threadIdx.x < 2 * U * U) {
+        const int t = threadIdx.x, j = t / (U * U), ba = t % (U * U);
+        float2 r = red[0][t];
+        for (int w = 1; w < 4; ++w) { r.x += red[w][t].x; r.y += red[w][t].y; }
+        q.out[j][(long long)blockIdx.x * (U * U) + ba] = r;
+    }
+}
+
 // Generic later stage: in has shape (n_outer, n_red, n_inner) -> out (n_outer, U, n_inner):
 // out[o][b][i] = sum_r K[b][r] * in[o][r][i]; one wavefront per output element, lanes stride over r (the outputs are
 // few -- U^2 nz or U^3 -- and the reduction long, so a thread per output would leave the GPU idle behind a serial loop).
 __global__ __launch_bounds__(256) void updft_mid_kernel(const float2* __restrict__ in, const float2* __restrict__ K, float2* __restrict__ out,
-                                                        int n_outer, int n_red, int n_inner, int U) {
+                                                        int n_outer, int n_red, int n_inner, int U, int kdiv = 1) {
     const long long total = (long long)n_outer * U * n_inner;
     const int lane = threadIdx.x & 63;
     for (long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); t < total; t += (long long)gridDim.x * 4) {
@@ -228,7 +318,7 @@ __global__ __launch_bounds__(256) void updft_mid_kernel(const float2* __restrict
         float2 acc = make_float2(0.f, 0.f);
         for (int r = lane; r < n_red; r += 64) {
             const float2 v = in[((long long)o * n_red + r) * n_inner + i];
-            const float2 k = K[b * n_red + r];
+            const float2 k = kdiv == 1 ? K[b * n_red + r] : K[b * (n_red / kdiv) + r / kdiv];   // kdiv consecutive entries share a kernel sample
             acc.x += k.x * v.x - k.y * v.y;
             acc.y += k.x * v.y + k.y * v.x;
         }
@@ -560,6 +650,10 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
   // (MvsFftFuse::xp_src) and both refinements' first stage read it in one launch (updft_x2_kernel): the combined spectrum and the
   // phase-normalised cross power are never stored.
   const bool fuse_xp = packed && first_axis == 2 && mvs_fft_reg_length((int)nx) && up_U0 <= 4 && !c->reg_unfused;
+  // ... and in 3D (refinement of 3 samples per axis: upsample factor 2) the first TWO stages of both refinements are one pass
+  // over it (updft_yx2_kernel): a lane sums its columns over the rows of a chunk before anything is reduced across lanes
+  const bool fuse_yx = fuse_xp && ndim == 3 && up_U0 == 3 && nx <= 256 && ny >= 4;
+  const int yx_chunks = fuse_yx ? std::max(1, std::min(kYxChunksMax, ((int)ny + kYxRows - 1) / kYxRows)) : 1;
   if (packed) {
     if (!fuse_xp)
         hipLaunchKernelGGL(xpower_packed_kernel, dim3(gb), dim3(256), 0, c->stream, Z, P1, P2, CC, nz, ny, nx, normalizations[0] ? 1 : 0,
@@ -687,6 +781,23 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
         if (!fuse_xp) {
             // stage 1: x  -> (z, y, ux)
             hipLaunchKernelGGL(updft_x_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, c->stream, P, dk + koff[2], o1, nrows, nx, U);
+        } else if (fuse_yx) {
+            if (inorm == n_norm - 1) {
+                // stages 1 and 2 of both normalisations: partial sums per (z, y chunk), folded by stage 3; they live in o1 (chunks * U <= ny)
+                UpdftYX q;
+                for (int j = 0; j < 2; ++j) {
+                    q.Kx[j] = state[j].dk + state[j].koff[2]; q.Ky[j] = state[j].dk + state[j].koff[1]; q.out[j] = state[j].o1;
+                    q.phase[j] = normalizations[j] ? 1 : 0;
+                }
+                const int rows_per_chunk = ((int)ny + yx_chunks - 1) / yx_chunks;
+                hipLaunchKernelGGL(updft_yx2_kernel<3>, dim3((unsigned)(nz * yx_chunks)), dim3(256), 0, c->stream, P2, q, (int)nz, (int)ny, (int)nx,
+                                   rows_per_chunk, yx_chunks);
+                for (int j = 0; j < n_norm; ++j)
+                    hipLaunchKernelGGL(updft_mid_kernel, dim3((unsigned)std::min<long long>(((long long)s3 + 3) / 4, 4096)), dim3(256), 0, c->stream,
+                                       state[j].o1, state[j].dk + state[j].koff[0], state[j].o3, 1, (int)nz * yx_chunks, U * U, U, yx_chunks);
+            }
+            MVS_HIP_TRY(c, hipGetLastError());
+            continue;
         } else if (inorm == n_norm - 1) {
             // stage 1 of both normalisations from the plain cross power alone
             UpdftX2 q;
