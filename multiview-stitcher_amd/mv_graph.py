@@ -389,6 +389,28 @@ def _axis_aligned_box(stack_props, tol=1e-12):
     return lo, hi
 
 
+def _axis_aligned_boxes(sps, tol=1e-12):
+    """[_axis_aligned_box(sp) for sp in sps]: all views of a regular mosaic (same axes, a static transform each) in one set of
+    array operations -- the same element-wise arithmetic, so the same boxes; anything else view by view."""
+    try:
+        sdims = [d for d in ["z", "y", "x"] if d in sps[0]["spacing"]]
+        n = len(sdims)
+        if not all("transform" in sp and list(sp["spacing"]) == list(sps[0]["spacing"]) and np.shape(sp["transform"]) == (n + 1, n + 1) for sp in sps):
+            raise ValueError
+        lo = np.array([[sp["origin"][d] for d in sdims] for sp in sps], dtype=np.float64)
+        hi = lo + (np.array([[sp["shape"][d] for d in sdims] for sp in sps]) - 1) * np.array([[sp["spacing"][d] for d in sdims] for sp in sps])
+        a = np.array([np.asarray(sp["transform"], dtype=np.float64) for sp in sps])
+        lin = a[:, :n, :n]
+        dg = np.diagonal(lin, axis1=1, axis2=2)
+        off = lin.copy()
+        off[:, np.arange(n), np.arange(n)] = 0.0
+        bad = np.any(np.abs(off) > tol, axis=(1, 2)) | np.any(dg <= 0, axis=1)
+        lo2, hi2 = dg * lo + a[:, :n, n], dg * hi + a[:, :n, n]
+        return [None if bad[i] else (lo2[i], hi2[i]) for i in range(len(sps))]
+    except (ValueError, KeyError, TypeError):
+        return [_axis_aligned_box(sp, tol) for sp in sps]
+
+
 def get_overlap_between_pair_of_stack_props(stack_props1, stack_props2):
     """Volume (area in 2D) of the intersection of two views in world coordinates (mv_graph.py:301-338); -1 when the
     intersection is degenerate / empty.  Axis-aligned pairs: product of the interval overlaps, the value Qhull returns
@@ -440,12 +462,12 @@ def build_view_adjacency_graph(stack_props_list, overlap_tolerance=None, pairs=N
         centers = np.array([get_center_from_stack_props(sp) for sp in sps])
         diam = max(np.linalg.norm([sp["shape"][d] * sp["spacing"][d] for d in sp["spacing"]]) for sp in sps)
         tree = cKDTree(centers)
-        pairs = [(i, j) for i in range(len(sps)) for j in tree.query_ball_point(centers[i], diam + 1) if i != j]
+        pairs = [(i, j) for i, nbrs in enumerate(tree.query_ball_point(centers, diam + 1)) for j in nbrs if i != j]   # (one query for all views)
     # overlap volume per unordered pair (the reference evaluates (i, j) and (j, i); the volume is symmetric): all pairs of
     # axis-aligned views in one vectorised closed form, the others one by one through the halfspace intersection
     pair_keys = [(i, j) if i < j else (j, i) for i, j in pairs]
     keys = list(dict.fromkeys(pair_keys))
-    boxes = [_axis_aligned_box(sp) for sp in sps]
+    boxes = _axis_aligned_boxes(sps)
     cache = {}
     aa = [k for k in keys if boxes[k[0]] is not None and boxes[k[1]] is not None]
     if aa:
@@ -458,9 +480,11 @@ def build_view_adjacency_graph(stack_props_list, overlap_tolerance=None, pairs=N
     for k in keys:
         if k not in cache:
             cache[k] = get_overlap_between_pair_of_stack_props(sps[k[0]], sps[k[1]])[0]
+    added = set()
     for (i, j), k in zip(pairs, pair_keys):
         ov = cache[k]
-        if ov > 0:        # "overlap 0 means one pixel overlap" is not an edge
+        if ov > 0 and k not in added:        # "overlap 0 means one pixel overlap" is not an edge; (j, i) after (i, j) changes nothing
+            added.add(k)
             g.add_edge(i, j, overlap=ov)
     return g
 
@@ -535,15 +559,19 @@ def _edge_betweenness_centrality_python(g):
     return bet
 
 
-def greedy_color(g):
-    """networkx.coloring.greedy_color, strategy largest_first: nodes by descending degree (stable), smallest free colour."""
+def greedy_color(g, limit=None):
+    """networkx.coloring.greedy_color, strategy largest_first: nodes by descending degree (stable), smallest free colour.
+    ``limit``: return None as soon as a node needs colour ``limit`` (the caller only asks whether ``limit`` colours suffice)."""
     colors = {}
     adj = g.adj
+    get = colors.get
     for u in sorted(adj, key=lambda n: len(adj[n]), reverse=True):
-        used = {colors[v] for v in adj[u] if v in colors}
+        used = {get(v) for v in adj[u]}          # (None for neighbours without a colour yet)
         c = 0
         while c in used:
             c += 1
+        if limit is not None and c >= limit:
+            return None
         colors[u] = c
     return colors
 
@@ -562,17 +590,28 @@ def prune_graph_to_alternating_colors(g, n_colors=2, return_colors=True):
         cent = {e: (c - cmin) / (cmax - cmin) * 0.5 * min_overlap for e, c in cent.items()}
     vals = {(a, b): cent[(a, b)] + d["overlap"] for a, b, d in gp.edges(data=True)}
     levels = sorted(np.unique(list(vals.values())))
+    # the edges in rising order of their value: a level looks at the ones it newly reaches and at those an earlier level had
+    # to keep (an end point of degree 1) -- the same set as a scan of all remaining edges, without the scan
+    rising = sorted(vals, key=vals.get)
+    nxt, kept = 0, []
     k = 0
     colors, changed = None, True
     while True:
         if changed:       # (a level that removes nothing leaves the colouring as it was)
-            colors = greedy_color(gp)
-            if len(set(colors.values())) <= n_colors:
+            colors = greedy_color(gp, limit=n_colors)
+            if colors is not None:      # (every colour used is below n_colors)
                 break
         adj, lev = gp.adj, levels[k]
-        drop = [(a, b) for a, b in gp.edges() if vals[(a, b)] <= lev and len(adj[a]) > 1 and len(adj[b]) > 1]
-        for a, b in drop:
-            gp.remove_edge(a, b)
+        while nxt < len(rising) and vals[rising[nxt]] <= lev:
+            kept.append(rising[nxt])
+            nxt += 1
+        # (degrees as they are BEFORE this level removes anything, like the list the full scan builds first)
+        drop = [(a, b) for a, b in kept if len(adj[a]) > 1 and len(adj[b]) > 1]
+        if drop:
+            gone = set(drop)
+            kept = [e for e in kept if e not in gone]
+            for a, b in drop:
+                gp.remove_edge(a, b)
         changed = bool(drop)
         k += 1
     return (gp, colors) if return_colors else gp
