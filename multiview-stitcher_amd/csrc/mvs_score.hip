@@ -778,6 +778,109 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
     }
 }
 
+// ---- the fixed image's own window means (x, x * x) by the same walk: one launch instead of the z pass + the y / x pass, and the
+// z-filtered volumes (2 x 13 MB written and read back) never exist.  Same tiles, same per-thread running sums and rounding points
+// as ssim_fused_batch_kernel with two quantities instead of three; the results go to ux / uxx on the cropped interior (all the
+// candidates' walks read).  Equal to the separate passes up to where the float64 running sums start (1e-16 relative before the
+// float32 rounding of each pass).  The fixed image is finite (precondition of the shared terms).
+template <int WIN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void ssim_fixed_walk_kernel(const float* __restrict__ im0, Shape3 S, float* __restrict__ ux, float* __restrict__ uxx, int zseg) {
+    constexpr int H = WIN / 2, pad = (WIN - 1) / 2, TY = 16, TX = 56, LY = TY + 2 * H, LX = TX + 2 * H;
+    constexpr int NO = 4, NI = NO + 2 * H;
+    constexpr int NR = (LY + 3) / 4;
+    constexpr double inv = 1.0 / (double)WIN;
+    static_assert(LX <= 64 && TY % NO == 0 && TX % NO == 0 && (TY * TX) / NO <= 256 && TY / NO == 4, "tile layout");
+    __shared__ float sz_[2][LY][LX + 1];
+    __shared__ float sy_[2][TY][LX + 1];
+    const int tid = threadIdx.x, col = tid & 63, wrow = tid >> 6;
+    const int cz = S.nz - 2 * pad, cy = S.ny - 2 * pad, cx = S.nx - 2 * pad;
+    if (cz <= 0 || cy <= 0 || cx <= 0) return;
+    const long long vol_bytes = (long long)S.nz * S.ny * S.nx * 4;      // < 2^31 (checked by the host)
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)im0, 0, (int)vol_bytes, 0x00020000);
+    const int nty = (cy + TY - 1) / TY, ntx = (cx + TX - 1) / TX, nzs = (cz + zseg - 1) / zseg;
+    const int nitems = nty * ntx * nzs;
+    const int sy = S.nx, sz = S.ny * S.nx;
+    for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int tx = item % ntx, ty = (item / ntx) % nty, zs = item / (ntx * nty);
+        const int z0 = pad + zs * zseg, z1 = min(z0 + zseg, S.nz - pad);
+        const int y0 = pad + ty * TY, x0 = pad + tx * TX;
+        const int gx = min(x0 - H + col, S.nx - 1);          // (clamped duplicates feed outputs that are never used)
+        int v0[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+            const int gy = min(y0 - H + min(wrow + 4 * k, LY - 1), S.ny - 1);
+            v0[k] = (gy * sy + gx) * 4;
+        }
+        double s1[NR], s2[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
+        float an[NR], ao[NR];
+        auto load_plane = [&](int p) __attribute__((always_inline)) {
+            const bool have_old = p - (z0 - H) >= WIN;
+            const int pn0 = p * sz * 4, po0 = (p - WIN) * sz * 4;
+#pragma unroll
+            for (int k = 0; k < NR; ++k) {
+                an[k] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, v0[k], pn0, 0));
+                ao[k] = have_old ? __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r0, v0[k], po0, 0)) : 0.f;
+            }
+        };
+        if (col < LX) load_plane(z0 - H);
+        const int xrow = tid / (TX / NO), xch = tid % (TX / NO);
+        const bool xact = tid < TY * (TX / NO) && y0 + xrow < S.ny - pad;
+        for (int p = z0 - H; p < z1 + H; ++p) {
+            if (col < LX) {
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    const int row = wrow + 4 * k;
+                    if (row >= LY) break;
+                    const float a = an[k], a2 = ao[k];
+                    // products in float32 like `im * im`; tmp += new - old like uniform_filter1d
+                    s1[k] += (double)a - (double)a2;
+                    s2[k] += (double)(a * a) - (double)(a2 * a2);
+                    if (p >= z0 + H) {
+                        sz_[0][row][col] = (float)(s1[k] * inv);
+                        sz_[1][row][col] = (float)(s2[k] * inv);
+                    }
+                }
+                if (p + 1 < z1 + H) load_plane(p + 1);
+            }
+            if (p < z0 + H) continue;
+            __syncthreads();
+            if (col < LX) {                                   // y pass: one wavefront per group of NO rows
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float v[NI], f[NO];
+#pragma unroll
+                    for (int k = 0; k < NI; ++k) v[k] = sz_[a][wrow * NO + k][col];
+                    box_means<WIN, NO>(v, f);
+#pragma unroll
+                    for (int k = 0; k < NO; ++k) sy_[a][wrow * NO + k][col] = f[k];
+                }
+            }
+            __syncthreads();
+            if (xact) {                                       // x pass: NO voxels of a row per thread
+                float f[2][NO];
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    float v[NI];
+#pragma unroll
+                    for (int k = 0; k < NI; ++k) v[k] = sy_[a][xrow][xch * NO + k];
+                    box_means<WIN, NO>(v, f[a]);
+                }
+                const int obase = ((p - H) * S.ny + y0 + xrow) * S.nx + x0 + xch * NO;
+#pragma unroll
+                for (int k = 0; k < NO; ++k) {
+                    if (x0 + xch * NO + k >= S.nx - pad) continue;
+                    ux[obase + k] = f[0][k];
+                    uxx[obase + k] = f[1][k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // folds the per-workgroup partials of one candidate's SSIM passes
 __global__ __launch_bounds__(256) void finish_region_kernel(const float* __restrict__ pmax, const int* __restrict__ phasnan,
                                                             const double* __restrict__ psum, RegionStats* __restrict__ out) {
@@ -1175,11 +1278,18 @@ struct DeviceBump {   // bump allocator over one scratch slot
 // every candidate: z pass + y/x pass once, results in setB[2], setB[3] (shared_x of launch_ssim_passes).
 template <int WIN>
 void launch_ssim_shared_x(hipStream_t stream, const float* im0, Shape3 S, Shape3 R, float* const setA[5], float* const setB[5],
-                          float* pmax, int* phasnan) {
+                          float* pmax, int* phasnan, bool walk) {
     Five P1, P2;
     for (int a = 0; a < 5; ++a) { P1.src[a] = nullptr; P1.dst[a] = setA[a]; P2.src[a] = setA[a]; P2.dst[a] = nullptr; }
     P2.dst[0] = setB[2];
     P2.dst[2] = setB[3];
+    if (walk && WIN == 7 && R.nz == S.nz && R.ny == S.ny && R.nx == S.nx) {
+        // one launch: z walk per (y, x) tile, about one resident round of work items
+        const int tiles = ((S.ny - 6 + 15) / 16) * ((S.nx - 6 + 55) / 56), cz = S.nz - 6;
+        const int nzs = std::max(1, std::min(768 / std::max(tiles, 1), (cz + 7) / 8));
+        hipLaunchKernelGGL(ssim_fixed_walk_kernel<7>, dim3(kStatBlocks), dim3(256), 0, stream, im0, S, setB[2], setB[3], (cz + nzs - 1) / nzs);
+        return;
+    }
     hipLaunchKernelGGL((ssim_first_pass_kernel<WIN, false, 1>), dim3(kStatBlocks), dim3(256), 0, stream, im0, im0, S, 0, 0, 0, R, 0, P1, pmax, phasnan,
                        ShiftArg{0.0, 0.0, 0.0, 0});
     hipLaunchKernelGGL((ssim_yx_fused_kernel<WIN, 1>), dim3(kStatBlocks), dim3(256), 0, stream, P2, R, 0.f, 0.f, 0.f, (double*)nullptr);
@@ -1463,7 +1573,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     if (ndim == 3 && region_mode == 0 && im0_all_finite && todo.size() >= 2 && std::min(S.nz, std::min(S.ny, S.nx)) >= 7 &&
         !c->materialize_shifts) {
         shared_x = true;
-        launch_ssim_shared_x<7>(c->stream, im0, S, S, setA, setB, pmax, phasnan);
+        launch_ssim_shared_x<7>(c->stream, im0, S, S, setA, setB, pmax, phasnan, !c->ssim_two_pass && (long long)S.nz * S.ny * S.nx * 4 < (1ll << 31));
     }
     // slot of the fraction class of a shift whose components are all multiples of 1/2 (bit k of the key: axis k has the fraction
     // 1/2), -1 when the candidate keeps a copy of its own (other fractions, integer shift, no slot left, mode off); *fresh: the
