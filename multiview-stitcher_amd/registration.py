@@ -671,6 +671,17 @@ def _pair_pool(n_threads):
         return entry
 
 
+def _set_event():
+    import threading
+
+    e = threading.Event()
+    e.set()
+    return e
+
+
+_FINISHED = _set_event()
+
+
 class _BinCache:
     """Binned tiles shared by the pairs of one compute_pairwise_registrations call (each tile is binned once).
     Thread safe: the first thread asking for a key computes it, the others wait for that result."""
@@ -684,10 +695,7 @@ class _BinCache:
 
     def put(self, key, value, keep=None):
         """Store a finished value (``keep``: the objects whose id() is part of ``key``; the slot holds them alive)."""
-        import threading
-
-        slot = {"event": threading.Event(), "value": value, "error": None, "keep": keep}
-        slot["event"].set()
+        slot = {"event": _FINISHED, "value": value, "error": None, "keep": keep}      # (one shared, already set event)
         with self._lock:
             self._items[key] = slot
 
