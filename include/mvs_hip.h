@@ -117,7 +117,11 @@ int mvs_synchronize(int device);
  * (whole output rows per workgroup, mvs_fuse_rows.hip) are tried before the region kernels for every dtype (default: for
  * float32 tiles only, where they reproduce scipy's NaN propagation through zero-weight taps).  "rowlds" = 1: the LDS-staged
  * row-owning kernel (uint16, one tap per view; mvs_fuse_rowlds.hip) is tried first.  Both opt-in paths must agree with
- * the default ones (tests compare all of them with the oracle). */
+ * the default ones (tests compare all of them with the oracle).  "ssim_two_pass" = 1: batched SSIM candidates (and the fixed
+ * image's window means) go through the separate z and y / x launches instead of the fused z walks (equal to 1e-9).
+ * "reg_unfused" = 1: the phase correlation runs its separate launches (pack, cross power, stored correlation + peak search,
+ * one refinement stage per normalisation, a min / max pass over the crops) instead of the fused passes at the ends of the two
+ * transforms (bit for bit the same peaks and shifts; tests compare). */
 int mvs_set_option(int device, const char* key, int64_t value);
 /* Measurement counters of one context (bench.py): "reg_alg_bytes" = algorithmic HBM bytes of the pairwise registrations
  * since the last reset (28 n per phase-correlation variant + 20 n per scored candidate + 64 n for the rank correlation, n = crop
