@@ -44,6 +44,8 @@ extern "C" {
 #define MVS_ERR_HIP (-2)
 #define MVS_ERR_NOT_INITIALISED (-3)
 #define MVS_ERR_UNSUPPORTED (-4)
+/* a HIP call failed with hipErrorOutOfMemory (device or pinned host allocation): the caller may retry with smaller units */
+#define MVS_ERR_OUT_OF_MEMORY (-5)
 
 enum mvs_dtype { MVS_U8 = 0, MVS_U16 = 1, MVS_F32 = 2 };
 enum mvs_mem { MVS_MEM_HOST = 0, MVS_MEM_DEVICE = 1 };
@@ -115,9 +117,9 @@ int mvs_synchronize(int device);
  * the translation fast path of mvs_fuse_chunk run one after the other on the context's stream (default: side by side on
  * side streams, joined before the call's work is considered done).  "rows_v1" = 1: the direct-load row-owning kernels
  * (whole output rows per workgroup, mvs_fuse_rows.hip) are tried before the region kernels for every dtype (default: for
- * float32 tiles only, where they reproduce scipy's NaN propagation through zero-weight taps).  "rowlds" = 1: the LDS-staged
- * row-owning kernel (uint16, one tap per view; mvs_fuse_rowlds.hip) is tried first.  Both opt-in paths must agree with
- * the default ones (tests compare all of them with the oracle).  "ssim_two_pass" = 1: batched SSIM candidates (and the fixed
+ * float32 tiles only, where they reproduce scipy's NaN propagation through zero-weight taps); it must agree with the
+ * default path (tests compare both with the oracle).  Unknown keys -- among them the retired "rowlds" and "stream_rows"
+ * of rounds 1-2 -- return MVS_ERR_INVALID_ARG.  "ssim_two_pass" = 1: batched SSIM candidates (and the fixed
  * image's window means) go through the separate z and y / x launches instead of the fused z walks (equal to 1e-9).
  * "reg_unfused" = 1: the phase correlation runs its separate launches (pack, cross power, stored correlation + peak search,
  * one refinement stage per normalisation, a min / max pass over the crops) instead of the fused passes at the ends of the two
@@ -201,8 +203,9 @@ int mvs_phasecorr(int device, const float* fixed, const float* moving, int32_t m
                   int32_t upsample_factor, double shift_out[3],
                   int64_t peak_index_out[3], float* peak_abs_out);
 /* In-place complex64 (interleaved re, im) transform of one C-contiguous (z,y,x) array == numpy.fft.fftn /
- * ifftn (inverse != 0: conjugate transform WITHOUT the 1/N).  Any axis length up to 4096 (powers of two:
- * Stockham; others: Bluestein).  The building block of mvs_phasecorr, exposed for tests and custom
+ * ifftn (inverse != 0: conjugate transform WITHOUT the 1/N).  Any axis length up to 2^22 (powers of two: register /
+ * LDS Stockham up to 4096, four-step in device scratch beyond; other lengths: Bluestein on the same cores, four-step above
+ * 2048; longer axes return MVS_ERR_UNSUPPORTED).  The building block of mvs_phasecorr, exposed for tests and custom
  * pairwise registration functions. */
 int mvs_fft_c2c(int device, void* data, int32_t mem, int32_t ndim, const int64_t shape[3], int32_t inverse);
 /* The same for n_norm normalisations of ONE image pair (the reference calls phase_cross_correlation
@@ -280,7 +283,11 @@ int mvs_register_views(int device, const mvs_view_t* fixed_view, const mvs_view_
  * all their beads, to their translation.  After each sweep the bead residuals |a + t_a - b - t_b| are stored
  * (edge_residuals: n_edges x n_beads), their mean of edge means and maximum are appended to mean_hist / max_hist
  * (max_iter doubles each); from the 7th sweep on the loop stops when max |r - r_previous| / max r < rel_tol.
- * translations (n_nodes x ndim) is in/out; n_iter_out = sweeps done. */
+ * translations (n_nodes x ndim) is in/out; n_iter_out = sweeps done.
+ * Contract with the numpy form of the same sweeps (param_resolution.py, used for the models with a linear part): the node
+ * update is evaluated in affine form (sum over a node's edges of +-(D0_e + n_beads (T_a - T_b))), i.e. its additions run in
+ * another order than the bead-by-bead sum -- equal to 1e-10 in translations, residuals and both histories, NOT bit for bit
+ * (tests/test_param_resolution.py).  The AVX2 residual pass (x86-64 hosts that have it) equals the scalar loops bit for bit. */
 int mvs_beads_translation_sweeps(int32_t ndim, int32_t n_nodes, int32_t n_edges, const int32_t* edge_nodes,
                                  const double* beads_a, const double* beads_b, int32_t n_beads, const int32_t* order,
                                  int32_t ref_node, int32_t max_iter, double rel_tol, double* translations,

@@ -172,10 +172,26 @@ def load():
     return _lib
 
 
+ERR_OUT_OF_MEMORY = -5          # MVS_ERR_OUT_OF_MEMORY (include/mvs_hip.h): a HIP call failed with hipErrorOutOfMemory
+
+
+class MvsError(RuntimeError):
+    """A library call returned a non-zero code; ``code`` is the MVS_ERR_* value of include/mvs_hip.h."""
+
+    def __init__(self, message, code):
+        super().__init__(message)
+        self.code = int(code)
+
+
+class DeviceMemoryError(MvsError):
+    """MVS_ERR_OUT_OF_MEMORY: the device (or pinned host) allocation of a call did not fit."""
+
+
 def check(rc, device=0, what="mvs call"):
     if rc != 0:
         msg = load().mvs_last_error(int(device))
-        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+        cls = DeviceMemoryError if rc == ERR_OUT_OF_MEMORY else MvsError
+        raise cls(f"{what} failed (code {rc}): {msg.decode() if msg else ''}", rc)
 
 
 def init(device=0):

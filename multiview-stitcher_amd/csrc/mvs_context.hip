@@ -17,7 +17,7 @@ int mvs_fail(MvsContext* c, int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (c) c->last_error = buf;
+    if (c) { c->last_error = buf; c->last_code = code; }
     return code;
 }
 
@@ -44,7 +44,7 @@ void* mvs_scratch(MvsContext* c, int slot, size_t nbytes) {
     size_t cap = nbytes + (nbytes >> 3) + 4096;
     hipError_t e = hipMalloc(&s.ptr, cap);
     if (e != hipSuccess) {
-        mvs_fail(c, MVS_ERR_HIP, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+        mvs_fail(c, e == hipErrorOutOfMemory ? MVS_ERR_OUT_OF_MEMORY : MVS_ERR_HIP, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
         s.ptr = nullptr;
         return nullptr;
     }
@@ -69,7 +69,7 @@ void* mvs_pinned_slot(MvsContext* c, int slot, size_t nbytes) {
     size_t cap = nbytes * 2 + 4096;
     hipError_t e = hipHostMalloc(&p, cap, hipHostMallocDefault);
     if (e != hipSuccess) {
-        mvs_fail(c, MVS_ERR_HIP, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+        mvs_fail(c, e == hipErrorOutOfMemory ? MVS_ERR_OUT_OF_MEMORY : MVS_ERR_HIP, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
         p = nullptr;
         return nullptr;
     }
@@ -91,6 +91,7 @@ int mvs_mailbox(MvsContext* c, size_t nbytes, void** host, void** dev) {
         MVS_HIP_TRY(c, hipHostMalloc(&c->mbox_host, cap, hipHostMallocMapped));
         MVS_HIP_TRY(c, hipHostGetDevicePointer(&c->mbox_dev, c->mbox_host, 0));
         c->mbox_cap = cap;
+        ++c->mbox_gen;
     }
     *host = c->mbox_host;
     *dev = c->mbox_dev;

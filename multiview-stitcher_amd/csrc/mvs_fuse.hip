@@ -1215,15 +1215,15 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
     char* slab_base = nullptr;
     if (host_bytes) {
         slab_base = (char*)mvs_scratch(c, 0, host_bytes);
-        if (!slab_base) return MVS_ERR_HIP;
+        if (!slab_base) return mvs_alloc_failed(c);
     }
     const size_t views_bytes = align_up(sizeof(DevView) * (size_t)n_views, 256);
     const size_t cull_bytes = align_up(sizeof(int) * 6 * (size_t)n_views, 256);
     const size_t params_bytes = views_bytes + cull_bytes + sizeof(TrView) * (size_t)n_views;
     DevView* hviews = (DevView*)mvs_pinned(c, params_bytes);
-    if (!hviews) return MVS_ERR_HIP;
+    if (!hviews) return mvs_alloc_failed(c);
     DevView* dviews = (DevView*)mvs_scratch(c, 2, params_bytes);
-    if (!dviews) return MVS_ERR_HIP;
+    if (!dviews) return mvs_alloc_failed(c);
 
     size_t cursor = 0;
     for (int i = 0; i < n_views; ++i) {
@@ -1266,7 +1266,7 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
     void* dout = out;
     if (opts->out_mem == MVS_MEM_HOST) {
         dout = mvs_scratch(c, 1, out_bytes);
-        if (!dout) return MVS_ERR_HIP;
+        if (!dout) return mvs_alloc_failed(c);
     }
 
     FuseParams P;
@@ -1330,7 +1330,7 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
         T.is3d = (os[0] > 1) ? 1 : 0;
         T.ablate = c->ablate;
         float* xtab = (float*)mvs_scratch(c, 3, (xtab_total + 64) * sizeof(float) + 256);
-        if (!xtab) return MVS_ERR_HIP;
+        if (!xtab) return mvs_alloc_failed(c);
         T.xtab = xtab;
         T.overflow = (int*)(xtab + xtab_total + 64);
         MVS_HIP_TRY(c, hipMemsetAsync(T.overflow, 0, sizeof(int), c->stream));
@@ -1397,7 +1397,7 @@ int stage_single_view(MvsContext* c, const mvs_view_t* view, int ndim, bool need
                 return mvs_fail(c, MVS_ERR_UNSUPPORTED, "host slabs must be C-contiguous");
             size_t nb = (size_t)view->shape[0] * view->shape[1] * view->shape[2] * es;
             void* s = mvs_scratch(c, 0, nb);
-            if (!s) return MVS_ERR_HIP;
+            if (!s) return mvs_alloc_failed(c);
             MVS_HIP_TRY(c, hipMemcpyAsync(s, view->data, nb, hipMemcpyHostToDevice, c->stream));
             dptr = s;
         }
@@ -1427,7 +1427,7 @@ extern "C" int mvs_resample(int device, const mvs_view_t* view, const int64_t ou
     float* dout = out;
     if (out_mem == MVS_MEM_HOST) {
         dout = (float*)mvs_scratch(c, 1, (size_t)n * 4);
-        if (!dout) return MVS_ERR_HIP;
+        if (!dout) return mvs_alloc_failed(c);
     }
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     mvs_launch_resample(c, d, view->dtype, order, cval, dout, out_shape);
@@ -1456,7 +1456,7 @@ extern "C" int mvs_blend_weights(int device, const mvs_view_t* view, int32_t ndi
     float* dout = out;
     if (out_mem == MVS_MEM_HOST) {
         dout = (float*)mvs_scratch(c, 1, (size_t)n * 4);
-        if (!dout) return MVS_ERR_HIP;
+        if (!dout) return mvs_alloc_failed(c);
     }
     int nblocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));

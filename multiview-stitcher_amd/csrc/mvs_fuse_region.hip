@@ -1130,10 +1130,10 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
         rbytes = (regions.size() * sizeof(Region) + 255) / 256 * 256;
         const size_t ibytes = items.size() * sizeof(Item);
         char* hbuf = (char*)mvs_pinned_slot(c, 1, rbytes + ibytes + 256);   // slot 0 holds the view parameters still in flight
-        if (!hbuf) return MVS_ERR_HIP;
+        if (!hbuf) return mvs_alloc_failed(c);
         pc.valid = false;
         dbuf = (char*)mvs_scratch(c, 8, rbytes + ibytes + 256);
-        if (!dbuf) return MVS_ERR_HIP;
+        if (!dbuf) return mvs_alloc_failed(c);
         memcpy(hbuf, regions.data(), regions.size() * sizeof(Region));
         memcpy(hbuf + rbytes, items.data(), ibytes);
         MVS_HIP_TRY(c, hipMemcpyAsync(dbuf, hbuf, rbytes + ibytes, hipMemcpyHostToDevice, c->stream));

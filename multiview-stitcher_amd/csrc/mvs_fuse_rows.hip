@@ -138,10 +138,10 @@ int mvs_fuse_rows(MvsContext* c, const TrView* htr, const TrView* dtr, int n_vie
         const size_t ibytes = nitems * sizeof(RowItem);
         const size_t total = sbytes + cbytes + ibytes;
         char* hbuf = (char*)mvs_pinned_slot(c, 1, total + 256);   // slot 0 holds the view parameters still in flight
-        if (!hbuf) return MVS_ERR_HIP;
+        if (!hbuf) return mvs_alloc_failed(c);
         pc.valid = false;
         dbuf = (char*)mvs_scratch(c, 13, total + 256);
-        if (!dbuf) return MVS_ERR_HIP;
+        if (!dbuf) return mvs_alloc_failed(c);
         memcpy(hbuf, strips.data(), strips.size() * sizeof(Strip));
         memcpy(hbuf + sbytes, cells.data(), cells.size() * sizeof(Cell));
         size_t cur = sbytes + cbytes;

@@ -331,7 +331,7 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
     char* slab_base = nullptr;
     if (host_bytes) {
         slab_base = (char*)mvs_scratch(c, 0, host_bytes);
-        if (!slab_base) return MVS_ERR_HIP;
+        if (!slab_base) return mvs_alloc_failed(c);
     }
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
     size_t cursor = 0;
@@ -366,7 +366,7 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
     const size_t pool_b = (size_t)pool * 4, tmp_b = ((size_t)max_box * 4 + 255) / 256 * 256;
     const size_t need = 3 * pool_b + 6 * tmp_b + 64 * 1024 + (size_t)n_views * sizeof(CbBox) + 512;
     char* base = (char*)mvs_scratch(c, 6, need);
-    if (!base) return MVS_ERR_HIP;
+    if (!base) return mvs_alloc_failed(c);
     float* I = (float*)base;
     float* BW = (float*)(base + pool_b);
     float* F = (float*)(base + 2 * pool_b);
@@ -456,7 +456,7 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
     void* dout = out;
     if (opts->out_mem == MVS_MEM_HOST) {
         dout = mvs_scratch(c, 1, out_bytes);
-        if (!dout) return MVS_ERR_HIP;
+        if (!dout) return mvs_alloc_failed(c);
     }
     const int gbo = grid_for(no);
     const int tz = (int)opts->trim[0], ty = (int)opts->trim[1], tx = (int)opts->trim[2];

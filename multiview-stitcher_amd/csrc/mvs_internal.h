@@ -64,14 +64,18 @@ struct MvsContext {
     bool pinned_pending[2] = {false, false};
     // "mailbox": pinned host memory the device writes small results into directly (reduction partials, peak candidates): the host
     // reads them after the stream wait -- no copy launch, no staging through pageable memory
+    int last_code = 0;            // code of the most recent mvs_fail on this context
     void* mbox_host = nullptr;
     void* mbox_dev = nullptr;
     size_t mbox_cap = 0;
+    uint64_t mbox_gen = 0;        // bumped whenever the mailbox is reallocated (its old contents are gone)
     // set by mvs_register_views around its two crops: the integer crop kernel also reduces min / max / #valid of what it writes into
     // per-block partials (layout of nanminmax_pair_kernel) at crop_stats_dst, with crop_stats_nb blocks; crop_stats_done[k] tells
     // mvs_rescale_pair_device that image k's partials are already there
     char* crop_stats_dst = nullptr;
     int crop_stats_nb = 0, crop_stats_k = 0;
+    uint64_t crop_stats_gen = 0;  // mbox_gen at the time the partials were parked: a reallocated mailbox invalidates them
+    void* crop_stats_base = nullptr;
     bool crop_stats_done[2] = {false, false};
     bool no_regions = false;      // test switch: skip the region kernel (use the column kernel)
     bool rows_v1 = false;         // opt-in: direct-load row kernels (mvs_fuse_rows.hip) for every dtype (default: float tiles only)
@@ -96,12 +100,15 @@ void mvs_pinned_mark(MvsContext* c, int slot);                    // call after 
 // the caller waits for the stream before it reads.  Returns an MVS_* code.
 int mvs_mailbox(MvsContext* c, size_t nbytes, void** host, void** dev);
 
+// the code of the failure mvs_scratch / mvs_pinned recorded when they returned NULL (MVS_ERR_OUT_OF_MEMORY or MVS_ERR_HIP)
+static inline int mvs_alloc_failed(const MvsContext* c) { return c->last_code ? c->last_code : MVS_ERR_HIP; }
+
 #define MVS_HIP_TRY(c, expr)                                                         \
     do {                                                                             \
         hipError_t _e = (expr);                                                      \
         if (_e != hipSuccess)                                                        \
-            return mvs_fail((c), MVS_ERR_HIP, "%s failed: %s (%s:%d)", #expr,        \
-                            hipGetErrorString(_e), __FILE__, __LINE__);              \
+            return mvs_fail((c), _e == hipErrorOutOfMemory ? MVS_ERR_OUT_OF_MEMORY : MVS_ERR_HIP,  \
+                            "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
 static inline size_t mvs_dtype_size(int dtype) {

@@ -41,7 +41,7 @@ extern "C" int mvs_register_crops(int device, const float* fixed, const float* m
     // ---- normalise (registration.py:381-389); also nanmin / nanmax / #valid of the inputs ----
     float* r0 = (float*)mvs_scratch(c, 9, (size_t)n * 4);
     float* r1 = (float*)mvs_scratch(c, 10, (size_t)n * 4);
-    if (!r0 || !r1) return MVS_ERR_HIP;
+    if (!r0 || !r1) return mvs_alloc_failed(c);
     float min0, max0, min1, max1;
     int64_t nv0, nv1;
     const float* raw_keys0 = nullptr;
@@ -197,7 +197,7 @@ extern "C" int mvs_register_views(int device, const mvs_view_t* fixed_view, cons
     const int64_t n = out_shape[0] * out_shape[1] * out_shape[2];
     float* crop0 = (float*)mvs_scratch(c, 11, (size_t)n * 4);
     float* crop1 = (float*)mvs_scratch(c, 12, (size_t)n * 4);
-    if (!crop0 || !crop1) return MVS_ERR_HIP;
+    if (!crop0 || !crop1) return mvs_alloc_failed(c);
     // crops of integer tiles under whole-pixel translations: the crop kernel reduces min / max / #valid of what it writes, so the
     // normalisation needs no pass of its own over the crops (same partial layout and block count as mvs_rescale_pair_device)
     const int nb_stats = (int)std::min<int64_t>(std::min<int64_t>((n + 255) / 256, 256 * 8), 512);
@@ -206,6 +206,8 @@ extern "C" int mvs_register_views(int device, const mvs_view_t* fixed_view, cons
     if (rc) return rc;
     c->crop_stats_done[0] = c->crop_stats_done[1] = false;
     c->crop_stats_nb = nb_stats;
+    c->crop_stats_gen = c->mbox_gen;
+    c->crop_stats_base = mb_dev;
     c->defer_sync = true;
     c->crop_stats_k = 0;
     c->crop_stats_dst = c->reg_unfused ? nullptr : (char*)mb_dev;

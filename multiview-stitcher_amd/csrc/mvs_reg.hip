@@ -442,7 +442,7 @@ inline double fftfreq(int n, double d, int x) {
 int mvs_device_nanminmax(MvsContext* c, const float* d_in, long long n, float* mn, float* mx, long long* nvalid) {
     const int nb = grid_for(n);
     char* scratch = (char*)mvs_scratch(c, 3, (size_t)nb * 16);
-    if (!scratch) return MVS_ERR_HIP;
+    if (!scratch) return mvs_alloc_failed(c);
     float* pmin = (float*)scratch;
     float* pmax = pmin + nb;
     long long* pval = (long long*)(scratch + (size_t)nb * 8);
@@ -476,7 +476,9 @@ int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, l
     PairPtrs PP;
     PP.in[0] = in0; PP.in[1] = in1; PP.out[0] = out0; PP.out[1] = out1;
     // (mvs_register_views: the crop kernels have left these partials already -- same layout, same block count)
-    if (!(c->crop_stats_done[0] && c->crop_stats_done[1] && c->crop_stats_nb == nb))
+    // ... and only in the very allocation they were written to: a mailbox that was reallocated in between has lost them
+    if (!(c->crop_stats_done[0] && c->crop_stats_done[1] && c->crop_stats_nb == nb && c->crop_stats_gen == c->mbox_gen &&
+          c->crop_stats_base == mb_dev))
         hipLaunchKernelGGL(nanminmax_pair_kernel, dim3(nb, 2), dim3(256), 0, c->stream, PP, n, scratch, nb);
     MVS_HIP_TRY(c, hipGetLastError());
     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -503,7 +505,7 @@ int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, l
 int mvs_stage_float_volume(MvsContext* c, const float* src, int32_t mem, long long n, int slot, float** dptr) {
     if (mem == MVS_MEM_DEVICE) { *dptr = (float*)src; return MVS_OK; }
     float* d = (float*)mvs_scratch(c, slot, (size_t)n * 4);
-    if (!d) return MVS_ERR_HIP;
+    if (!d) return mvs_alloc_failed(c);
     MVS_HIP_TRY(c, hipMemcpyAsync(d, src, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
     *dptr = d;
     return MVS_OK;
@@ -527,7 +529,7 @@ extern "C" int mvs_rescale_intensity(int device, const float* in, int32_t mem, i
     float* dout = out;
     if (out_mem == MVS_MEM_HOST) {
         dout = (float*)mvs_scratch(c, 5, (size_t)n * 4);
-        if (!dout) return MVS_ERR_HIP;
+        if (!dout) return mvs_alloc_failed(c);
     }
     hipLaunchKernelGGL(rescale_kernel, dim3(grid_for(n)), dim3(256), 0, c->stream, din, dout, (long long)n, mn, mx, mn == mx ? 1 : 0);
     MVS_HIP_TRY(c, hipGetLastError());
@@ -555,7 +557,7 @@ extern "C" int mvs_fft_c2c(int device, void* data, int32_t mem, int32_t ndim, co
     float2* d = (float2*)data;
     if (mem == MVS_MEM_HOST) {
         d = (float2*)mvs_scratch(c, 6, bytes);
-        if (!d) return MVS_ERR_HIP;
+        if (!d) return mvs_alloc_failed(c);
         MVS_HIP_TRY(c, hipMemcpyAsync(d, data, bytes, hipMemcpyHostToDevice, c->stream));
     }
     rc = mvs_fft3_c2c(c, d, shape, inverse != 0);
@@ -600,7 +602,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     // without phase normalisation, kept for the upsampled DFT), CC (inverse transform; both correlations in one transform
     // when two normalisations are asked for)
     float2* Z = (float2*)mvs_scratch(c, 6, (size_t)n * 8 * 4);
-    if (!Z) return MVS_ERR_HIP;
+    if (!Z) return mvs_alloc_failed(c);
     float2* P1 = Z + n;
     float2* P2 = P1 + n;
     float2* CC = P2 + n;
@@ -700,7 +702,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
   char* up_base = nullptr;
   if (upsample_factor > 1) {
       up_base = (char*)mvs_scratch(c, 7, up_bytes * (size_t)n_norm);
-      if (!up_base) return MVS_ERR_HIP;
+      if (!up_base) return mvs_alloc_failed(c);
   }
   for (int inorm = 0; inorm < n_norm; ++inorm) {
     const int normalization = normalizations[inorm];
@@ -937,7 +939,7 @@ static int bin_mean_impl(int device, const void* in, int32_t dtype, int32_t mem,
             return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_bin_mean: host input must be C-contiguous");
         const size_t nb = (size_t)shape[0] * shape[1] * shape[2] * es;
         void* s = mvs_scratch(c, 4, nb);
-        if (!s) return MVS_ERR_HIP;
+        if (!s) return mvs_alloc_failed(c);
         MVS_HIP_TRY(c, hipMemcpyAsync(s, in, nb, hipMemcpyHostToDevice, c->stream));
         din = s;
     }
@@ -945,7 +947,7 @@ static int bin_mean_impl(int device, const void* in, int32_t dtype, int32_t mem,
     void* dout = out;
     if (out_mem == MVS_MEM_HOST) {
         dout = mvs_scratch(c, 5, (size_t)n * es);
-        if (!dout) return MVS_ERR_HIP;
+        if (!dout) return mvs_alloc_failed(c);
     }
     const int gb = grid_for(n);
 #define MVS_BIN(T) hipLaunchKernelGGL(bin_mean_kernel<T>, dim3(gb), dim3(256), 0, c->stream, (const T*)din, sz, sy, (T*)dout, \

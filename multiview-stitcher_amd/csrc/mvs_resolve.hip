@@ -7,10 +7,14 @@
 #include <cstdlib>
 #include <vector>
 
+#if defined(__x86_64__)
 #include <immintrin.h>
+#define MVS_RESOLVE_AVX2 1
+#endif
 
 #include "mvs_hip.h"
 
+#ifdef MVS_RESOLVE_AVX2
 // The residual pass of one sweep for the common case (3D, 8 beads per edge) on 4-wide vectors: lane = bead & 3, i.e. exactly the
 // four accumulators of the scalar loops below, the same operations in the same order (separate multiplies and adds, no fused
 // ones), so the results are bit-identical to the scalar form (tests/test_param_resolution.py runs both).  d0 is stored per edge as
@@ -53,6 +57,7 @@ __attribute__((target("avx2"))) static double residual_pass_avx2(int n_edges, co
     *dmax_out = std::fmax(std::fmax(cv[0], cv[1]), std::fmax(cv[2], cv[3]));
     return mean_acc;
 }
+#endif      // MVS_RESOLVE_AVX2 (other hosts: the scalar loops below, same results bit for bit)
 
 extern "C" int mvs_beads_translation_sweeps(int32_t ndim, int32_t n_nodes, int32_t n_edges, const int32_t* edge_nodes,
                                             const double* beads_a, const double* beads_b, int32_t n_beads, const int32_t* order,
@@ -97,7 +102,12 @@ extern "C" int mvs_beads_translation_sweeps(int32_t ndim, int32_t n_nodes, int32
     std::vector<double> prev(nres, 0.0);
     // vector form of the residual pass (3D mosaics: 8 beads per edge), unless switched off for the A/B test
     static const bool no_simd = getenv("MVS_RESOLVE_SCALAR") != nullptr;
+#ifdef MVS_RESOLVE_AVX2
     const bool simd = ndim == 3 && n_beads == 8 && !no_simd && __builtin_cpu_supports("avx2");
+#else
+    const bool simd = false;
+    (void)no_simd;
+#endif
     std::vector<double> d0soa;
     if (simd) {
         d0soa.resize((size_t)n_edges * 24);
@@ -129,6 +139,7 @@ extern "C" int mvs_beads_translation_sweeps(int32_t ndim, int32_t n_nodes, int32
         }
         // bead residuals of every edge, their mean of means and overall maximum
         double mean_acc = 0.0, mx = 0.0;
+#ifdef MVS_RESOLVE_AVX2
         if (simd) {
             double dmax = 0.0;
             mean_acc = residual_pass_avx2(n_edges, edge_nodes, d0soa.data(), translations, edge_residuals, prev.data(), it > 5, &mx, &dmax);
@@ -137,6 +148,7 @@ extern "C" int mvs_beads_translation_sweeps(int32_t ndim, int32_t n_nodes, int32
             if (it > 5 && (mx > 0.0 ? dmax / mx : 0.0) < rel_tol) { ++it; break; }
             continue;
         }
+#endif
         for (int e = 0; e < n_edges; ++e) {
             const int a = edge_nodes[2 * e], b2 = edge_nodes[2 * e + 1];
             double dt[3] = {0.0, 0.0, 0.0};

@@ -1377,7 +1377,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
     constexpr int kMaxCls = 4;      // fraction classes of half-pixel shifts that get ONE shifted copy shared by their candidates
     const size_t need = (size_t)n * 4 * (10 + nres + (may_batch ? 3 * nres + kMaxCls : 0)) + 256 * (12 + 4 * nres + kMaxCls) + sort_temp_bytes + (size_t)gb * 32 + stat_bytes + 64 * 1024 + (size_t)(kHistBinsMax + 64) * 8 + (size_t)kHistParts * (kHistBinsMax / 2 + 1) * 4 + 2048;
     char* base = (char*)mvs_scratch(c, 6, need);
-    if (!base) return MVS_ERR_HIP;
+    if (!base) return mvs_alloc_failed(c);
     DeviceBump B{base, need, 0};
     std::vector<float*> im1t_buf(nres);
     for (int i = 0; i < nres; ++i) im1t_buf[i] = B.take<float>(n);

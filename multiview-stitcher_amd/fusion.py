@@ -144,7 +144,11 @@ def fuse_np(
     rounds them to 10 decimals (transformation.py:72-83), so two chunkings of one stack differ by ~1e-9 px in the
     weights.  With a frame origin (``fuse`` passes the output stack's) the parameters are derived once per view, for that
     origin and the WHOLE view, and the chunk / slab enter as integer index shifts: a voxel gets the same result whatever
-    chunk, launch block or shard it is computed in.  Needs chunk and slab origins on the frame's grids (else ignored).
+    chunk, launch block or shard it is computed in.  Needs chunk and slab origins on the frame's grids for ALL views of the
+    chunk; otherwise an ``IndexFrameWarning`` is issued and the chunk falls back to per-chunk parameters (``fuse_shard``
+    turns that warning into an error: its guarantee would be lost).  Voxel-exact agreement across chunkings holds on the
+    translation fast path (identity pixel matrices); the generic kernel folds ``M @ origin`` into its offsets in floating
+    point, so rotated / scaled views agree across chunkings to rounding (~1e-9 px in the coordinates), not bit for bit.
     """
     if backend not in ("hip", None):
         raise ValueError("multiview_stitcher_amd.fusion.fuse_np only implements backend='hip'")
@@ -195,6 +199,15 @@ def fuse_np(
             index_origin[3 - ndim:] = np.round(io_).astype(np.int64)
             index_offsets[:, 3 - ndim:] = np.round(so_).astype(np.int64)
             ref_out_origin, ref_in_origins = f_origin, full_origins
+        else:
+            import warnings
+
+            warnings.warn(
+                "fuse_np: frame_origin cannot be applied -- the chunk origin or a slab origin is not on the frame's grid "
+                f"(largest distance from it: chunk {float(np.abs(io_ - np.round(io_)).max()):.3g} px, slabs "
+                f"{float(np.abs(so_ - np.round(so_)).max()):.3g} px); the parameters of this chunk are derived per chunk, so its "
+                "voxels may differ in the last bit from the same voxels fused through another chunk, launch block or shard",
+                IndexFrameWarning, stacklevel=2)
     matrices, offsets = get_pixel_affines(p_inv, ref_in_origins, in_spacings, ref_out_origin, out_spacing)
     tables, sup_origins, sup_spacings = weights.blending_supports(
         full_origins, np.stack([_as_zyx(b["spacing"], sdims) for b in fv]),
@@ -555,9 +568,13 @@ def _launch_budget(sims, out_shape, sdims, itemsize, device, cap):
     return int(max(min(cap, avail / per_out_byte), 1))
 
 
+class IndexFrameWarning(RuntimeWarning):
+    """fuse_np was given a frame_origin it could not apply (an origin off the frame's grid)."""
+
+
 def _is_device_memory_error(exc):
-    msg = str(exc)
-    return "hipMalloc" in msg or "out of memory" in msg.lower() or "hipErrorOutOfMemory" in msg
+    """Out of device memory, by the library's error CODE (MVS_ERR_OUT_OF_MEMORY <- hipErrorOutOfMemory), not by message text."""
+    return isinstance(exc, _lib.DeviceMemoryError)
 
 
 # --- chunk -> view-slab plan (_core.py:354-722): computed by the library ---------------------------------
@@ -947,18 +964,30 @@ def _fuse_once(
 
 
 def fuse(*args, **kwargs):
+    import inspect
+    import traceback
+    import warnings
+
+    bound = inspect.signature(_fuse_once).bind(*args, **kwargs)      # wherever merge_chunks was passed, it can be overridden
+    failure = None
     try:
-        return _fuse_once(*args, **kwargs)
-    except RuntimeError as exc:
+        return _fuse_once(*bound.args, **bound.kwargs)
+    except _lib.DeviceMemoryError as exc:
         # A merged launch block is sized from an ESTIMATE of what has to be staged on the device (_launch_budget); if the
         # device still runs out of memory the requested chunk grid -- the unit the caller sized for -- is used instead.
-        if kwargs.get("merge_chunks", True) and _is_device_memory_error(exc):
-            import warnings
+        if not bound.arguments.get("merge_chunks", True):
+            raise
+        failure = str(exc)
+        # the retry must not run inside this handler: the traceback keeps the failed attempt's frames -- and with them the
+        # mosaic-sized device buffer, staged peer copies and keep lists -- alive on a device that has just run out of memory
+        traceback.clear_frames(exc.__traceback__)
+    import gc
 
-            warnings.warn(f"fuse(): a merged launch block did not fit the device ({exc}); falling back to the requested "
-                          "output_chunksize", RuntimeWarning, stacklevel=2)
-            return _fuse_once(*args, **dict(kwargs, merge_chunks=False))
-        raise
+    gc.collect()
+    warnings.warn(f"fuse(): a merged launch block did not fit the device ({failure}); falling back to the requested "
+                  "output_chunksize", RuntimeWarning, stacklevel=2)
+    bound.arguments["merge_chunks"] = False
+    return _fuse_once(*bound.args, **bound.kwargs)
 
 
 fuse.__doc__ = _fuse_once.__doc__

@@ -206,7 +206,12 @@ def fuse_shard(sims, rank, world_size, transform_key, output_stack_properties=No
     # the index frame of the WHOLE mosaic: every rank derives the views' parameters for the same origin and only shifts
     # integer indices, so the union of the sub-boxes equals the single-GPU mosaic voxel for voxel
     fuse_kwargs.setdefault("frame_origin", dict(osp["origin"]))
-    fused = fusion.fuse(list(sims), transform_key=transform_key, output_stack_properties=sub, **fuse_kwargs)
+    import warnings
+
+    with warnings.catch_warnings():
+        # a frame that cannot be applied would silently void the union-equals-mosaic guarantee of this function
+        warnings.simplefilter("error", fusion.IndexFrameWarning)
+        fused = fusion.fuse(list(sims), transform_key=transform_key, output_stack_properties=sub, **fuse_kwargs)
     return fused, box
 
 

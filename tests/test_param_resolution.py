@@ -156,6 +156,27 @@ def test_native_translation_sweeps_equal_numpy_sweeps(ndim, monkeypatch):
     np.testing.assert_allclose(m_nat["mean_residual"], m_np["mean_residual"], rtol=1e-9, atol=1e-12)
 
 
+def test_native_and_numpy_sweeps_agree_on_a_near_tie_of_the_edge_removal(monkeypatch):
+    """The native sweeps add in another order than the numpy form (1e-10 contract, include/mvs_hip.h), and the edge removed per
+    outer iteration is an argmax over scores built from the residuals: two bad edges of mirror-image placement whose scores
+    differ by ~1e-6 relative -- far above the 1e-10 contract, far below anything a user would set apart -- must be removed in
+    the same order by both paths, with the same surviving edges and parameters."""
+    g, _ = _grid_graph(4, 4, 2, noise=0.0, seed=3, quality=0.8)
+    for e, shift in (((1, 2), 40.0), ((13, 14), 40.0 * (1 + 1e-6))):       # mirror images in the 4 x 4 grid
+        g.edges[e]["transform"] = param_utils.affine_from_translation([0.0, shift]) @ g.edges[e]["transform"]
+        g.edges[e]["quality"] = 0.3
+    out = []
+    for force in (False, True):
+        monkeypatch.setattr(pr, "_FORCE_NUMPY", force)
+        out.append(pr.groupwise_resolution(g, "global_optimization", reference_view=0))
+    (p_nat, i_nat), (p_np, i_np) = out
+    assert i_nat["used_edges"] == i_np["used_edges"]
+    assert (1, 2) not in i_nat["used_edges"][0] and (13, 14) not in i_nat["used_edges"][0]
+    assert i_nat["metrics"][0]["iteration"] == i_np["metrics"][0]["iteration"]          # same sweeps per outer iteration
+    for v in p_np:
+        np.testing.assert_allclose(p_nat[v], p_np[v], rtol=0, atol=1e-10)
+
+
 def test_vector_residual_pass_is_bitwise_the_scalar_one():
     """The AVX2 form of the sweeps' residual pass (3D, 8 beads per edge) against the scalar loops (MVS_RESOLVE_SCALAR=1, read once
     per process, hence two subprocesses): parameters and the whole per-sweep history bit for bit."""

@@ -304,7 +304,7 @@ def test_fuse_launch_blocks_respect_budget_and_fall_back(hip_device, monkeypatch
         shp = tuple(int(v) for v in k["output_properties"]["shape"].values())
         calls.append(shp)
         if int(np.prod(shp)) > 8 * 16 * 16:
-            raise RuntimeError("mvs_fuse_chunk failed (code -2): hipMalloc(123456) failed: out of memory")
+            raise _lib.DeviceMemoryError("mvs_fuse_chunk failed (code -5): hipMalloc(123456) failed: out of memory", -5)
         return real(*a, **k)
 
     monkeypatch.setattr(fusion, "fuse_np", failing)
@@ -313,6 +313,23 @@ def test_fuse_launch_blocks_respect_budget_and_fall_back(hip_device, monkeypatch
         got = np.asarray(fusion.fuse(sims, transform_key=key, output_chunksize=cs).data)
     same(got)
     assert any("falling back" in str(x.message) for x in w) and len(calls) > 2
+    # merge_chunks passed positionally is overridden all the same (the arguments are bound to the signature); other errors
+    # -- also ones that merely mention an allocation -- are not retried
+    import inspect
+
+    names = list(inspect.signature(fusion._fuse_once).parameters)
+    args = [p.default for p in inspect.signature(fusion._fuse_once).parameters.values()][:names.index("merge_chunks") + 1]
+    args[0], args[names.index("transform_key")], args[names.index("output_chunksize")], args[-1] = sims, key, cs, True
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        same(np.asarray(fusion.fuse(*args).data))
+
+    def failing_other(*a, **k):
+        raise RuntimeError("mvs_fuse_chunk failed (code -2): hipMalloc mentioned, but not an out-of-memory code")
+
+    monkeypatch.setattr(fusion, "fuse_np", failing_other)
+    with pytest.raises(RuntimeError, match="code -2"):
+        fusion.fuse(sims, transform_key=key, output_chunksize=cs)
 
 
 def test_fuse_all_fields_on_backend(hip_device):

@@ -2,7 +2,7 @@
 # SQ instruction-mix counters of the fuse kernels (one pass)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc; rm -rf $O; mkdir -p $O
-MVS_ROWLDS=${ROWLDS:-1} MVS_ABLATE=${ABL:-0} timeout 300 rocprofv3 --kernel-include-regex "fuse|copy_region" --pmc ${PMC:-SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES} --output-format csv -d $O/p -- python $R/tools/fuse_probe.py 2 ${1:-0} > $O/probe.log 2>&1
+MVS_ABLATE=${ABL:-0} timeout 300 rocprofv3 --kernel-include-regex "fuse|copy_region" --pmc ${PMC:-SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES} --output-format csv -d $O/p -- python $R/tools/fuse_probe.py 2 ${1:-0} > $O/probe.log 2>&1
 grep -h "kernel ms" $O/probe.log | tail -1
 python - <<PY
 import csv,glob,collections
