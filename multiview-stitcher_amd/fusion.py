@@ -152,6 +152,9 @@ def fuse_np(
     """
     if backend not in ("hip", None):
         raise ValueError("multiview_stitcher_amd.fusion.fuse_np only implements backend='hip'")
+    from .transformation import check_interpolation_order
+
+    check_interpolation_order(interpolation_order, "interpolation_order")
     lib = _lib.init(device)
     sdims = si_utils.get_spatial_dims_from_sim(sims[0])
     ndim = len(sdims)
@@ -697,6 +700,9 @@ def _fuse_once(
         images = [msi_utils.get_sim_from_msim(im) for im in images]
     sims_ = list(images)
 
+    from .transformation import check_interpolation_order
+
+    check_interpolation_order(interpolation_order, "interpolation_order")
     output_chunksize = process_output_chunksize(sims_, output_chunksize)
     output_stack_properties = process_output_stack_properties(
         sims_, output_spacing, output_origin, output_shape, output_stack_properties, output_stack_mode, transform_key

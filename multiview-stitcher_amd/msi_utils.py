@@ -105,6 +105,34 @@ def get_sim_from_msim(msim, scale="scale0"):
     return sim
 
 
+def get_res_level_from_binning_factors(msim, binning_factors):
+    """msi_utils.get_res_level_from_binning_factors (msi_utils.py:688-773): the LOWEST resolution level whose integer
+    downsampling factors (shape of scale0 / shape of the level, per spatial dim) do not exceed the requested binning and
+    divide it; returns ``(scale_key, remaining_binning)`` -- scale0 with the full binning when no other level qualifies."""
+    sim0 = msim["scale0"]
+    sdims = si_utils.get_spatial_dims_from_sim(sim0)
+    shape0 = {d: sim0.sizes[d] for d in sdims}
+    best_scale, best_remaining = "scale0", dict(binning_factors)
+    for scale_key in get_sorted_scale_keys(msim):
+        sim = msim[scale_key]
+        factors = {d: shape0[d] / sim.sizes[d] for d in sdims}
+        valid = True
+        for d in sdims:
+            if d not in binning_factors:
+                continue
+            if not np.isclose(factors[d], round(factors[d]), rtol=1e-6):
+                valid = False
+                break
+            f = int(round(factors[d]))
+            if f > binning_factors[d] or binning_factors[d] % f != 0:
+                valid = False
+                break
+        if valid:
+            best_scale = scale_key
+            best_remaining = {d: (binning_factors[d] // int(round(factors[d])) if d in binning_factors else 1) for d in sdims}
+    return best_scale, best_remaining
+
+
 def get_transform_from_msim(msim, transform_key=None):
     return msim.transforms[transform_key]
 

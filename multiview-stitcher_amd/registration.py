@@ -504,17 +504,62 @@ def _geom_of(sim, transform_key, cache):
     return cache.get_or_compute(("geom", id(sim), transform_key), lambda: _TileGeom(sim, transform_key), keep=sim)
 
 
+def _select_registration_level(msim1, msim2, registration_binning, reg_res_level):
+    """The three branches of registration.py:1639-1717: which resolution level of the two images is registered and which
+    binning is still applied to it.  ``reg_res_level`` alone: that level, no binning; with ``registration_binning``: that
+    level, the binning divided by the level's downsampling factors (which must divide it); neither / binning alone: the
+    (optimal) binning split into the lowest level that divides it and a remainder.  Plain SpatialImages count as
+    images with scale0 only.  Returns (sim1, sim2, remaining_binning)."""
+    from . import msi_utils
+    from . import spatial_image_utils as si_utils
+
+    ms = [m if msi_utils.is_msim(m) else None for m in (msim1, msim2)]
+
+    def level(i, scale_key):
+        m = (msim1, msim2)[i]
+        return msi_utils.get_sim_from_msim(m, scale=scale_key) if ms[i] is not None else m
+
+    def scale_keys(i):
+        return msi_utils.get_sorted_scale_keys(ms[i]) if ms[i] is not None else ["scale0"]
+
+    sim1_0, sim2_0 = level(0, "scale0"), level(1, "scale0")
+    sdims = si_utils.get_spatial_dims_from_sim(sim1_0)
+    if reg_res_level is not None:
+        scale_key = f"scale{reg_res_level}"
+        if scale_key not in scale_keys(0) or scale_key not in scale_keys(1):
+            raise ValueError(f"Resolution level {reg_res_level} (scale{reg_res_level}) does not exist in the multiscale image")
+        sim1, sim2 = level(0, scale_key), level(1, scale_key)
+        if registration_binning is None:
+            return sim1, sim2, {d: 1 for d in sdims}
+        factors = {d: sim1_0.sizes[d] / sim1.sizes[d] for d in sdims}
+        for d in sdims:
+            if d in registration_binning and registration_binning[d] % int(round(factors[d])) != 0:
+                raise ValueError(
+                    f"Resolution level {reg_res_level} has downsampling factor {int(round(factors[d]))} for dimension {d}, which "
+                    f"is not a divisor of registration_binning[{d}]={registration_binning[d]}")
+        # (like the reference, every spatial dim must be present in registration_binning here: registration.py:1674-1677)
+        return sim1, sim2, {d: registration_binning[d] // int(round(factors[d])) for d in sdims}
+    if registration_binning is None:
+        registration_binning = get_optimal_registration_binning(sim1_0, sim2_0)
+    if ms[0] is None or len(scale_keys(0)) == 1:
+        return sim1_0, sim2_0, dict(registration_binning)
+    scale_key, remaining = msi_utils.get_res_level_from_binning_factors(ms[0], registration_binning)
+    if scale_key not in scale_keys(1):
+        raise ValueError(f"{scale_key} does not exist in the second multiscale image")
+    return level(0, scale_key), level(1, scale_key), remaining
+
+
 def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=None, overlap_tolerance=None,
                            pairwise_reg_func=phase_correlation_registration, pairwise_reg_func_kwargs=None, device=0,
-                           _bin_cache=None):
+                           _bin_cache=None, reg_res_level=None):
     """registration.register_pair_of_msims (registration.py:1547-2058) for pixel-space registration functions
-    (the form the reference's phase correlation has): returns {"transform", "quality", "bbox"}."""
+    (the form the reference's phase correlation has): returns {"transform", "quality", "bbox"}.  ``reg_res_level`` /
+    ``registration_binning`` pick the pyramid level of multiscale inputs as the reference does (registration.py:1639-1717)."""
     from . import msi_utils
     from . import spatial_image_utils as si_utils
 
     pairwise_reg_func_kwargs = dict(pairwise_reg_func_kwargs or {})
-    sim1 = msi_utils.get_sim_from_msim(msim1) if msi_utils.is_msim(msim1) else msim1
-    sim2 = msi_utils.get_sim_from_msim(msim2) if msi_utils.is_msim(msim2) else msim2
+    sim1, sim2, registration_binning = _select_registration_level(msim1, msim2, registration_binning, reg_res_level)
     sdims = si_utils.get_spatial_dims_from_sim(sim1)
     ndim = len(sdims)
     if overlap_tolerance is None:
@@ -523,8 +568,6 @@ def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=Non
         overlap_tolerance = {d: float(overlap_tolerance) for d in sdims}
     else:
         overlap_tolerance = {d: float(overlap_tolerance.get(d, 0.0)) for d in sdims}
-    if registration_binning is None:
-        registration_binning = get_optimal_registration_binning(sim1, sim2)
 
     def binned(sim):
         if max(registration_binning.values()) <= 1:
@@ -623,12 +666,14 @@ def _prebin_views(sims, registration_binning, device, cache):
 
 def compute_pairwise_registrations(msims, edges, transform_key, registration_binning=None, overlap_tolerance=0.0,
                                    pairwise_reg_func=phase_correlation_registration, pairwise_reg_func_kwargs=None,
-                                   pairwise_executor=None, device=0, host_threads=16, _bin_cache=None):
+                                   pairwise_executor=None, device=0, host_threads=16, _bin_cache=None, reg_res_level=None):
     """registration.compute_pairwise_registrations (registration.py:2622-2714): either hand all edges to a
     user ``pairwise_executor(msims, edges, register_kwargs)`` or loop over them on one device."""
     register_kwargs = dict(transform_key=transform_key, registration_binning=registration_binning,
                            overlap_tolerance=overlap_tolerance, pairwise_reg_func=pairwise_reg_func,
                            pairwise_reg_func_kwargs=pairwise_reg_func_kwargs)
+    if reg_res_level is not None:       # (absent by default: executors written for the round-1 keyword set keep working)
+        register_kwargs["reg_res_level"] = reg_res_level
     if pairwise_executor is not None:
         results = pairwise_executor(msims, list(edges), register_kwargs)
         if len(results) != len(edges):
@@ -787,8 +832,12 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
              groupwise_resolution_kwargs=None, pre_registration_pruning_method="alternating_pattern",
              pre_reg_pruning_method_kwargs=None,
              post_registration_do_quality_filter=False, post_registration_quality_threshold=0.2, pairs=None,
-             n_parallel_pairwise_regs=None, pairwise_executor=None, return_dict=False, device=0):
+             n_parallel_pairwise_regs=None, pairwise_executor=None, return_dict=False, device=0, reg_res_level=None):
     """Register views to a common coordinate system (registration.register, registration.py:2227-2620).
+
+    ``reg_res_level`` / ``registration_binning`` select the pyramid level of multiscale inputs per pair exactly as the
+    reference does (registration.py:1639-1717, 2236, 2525): a level alone, a level plus the remaining binning, or -- by
+    default -- the lowest level that divides the (optimal) binning.  The overlap graph is always built on scale0.
 
     Flow as in the reference: (1) overlap graph, (2) pairwise registrations of the selected edges,
     (3) groupwise resolution, (4) write ``new_transform_key`` (rebased on ``transform_key``).
@@ -810,14 +859,23 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
         if reg_channel is None and reg_channel_index is None:
             raise Exception("Please choose a registration channel.")
         ci = reg_channel_index if reg_channel is None else int(np.nonzero(sims[0].coords["c"] == reg_channel)[0][0])
-        sims_reg = [s.isel({"c": ci}) for s in sims]
     else:
-        sims_reg = [s.isel({"c": 0}) if "c" in s.dims else s for s in sims]
+        ci = 0
+
+    def channel_of(s):
+        return s.isel({"c": ci}) if "c" in s.dims else s
+
+    sims_reg = [channel_of(s) for s in sims]
     nt = sims_reg[0].sizes.get("t", 1) if "t" in sims_reg[0].dims else 1
+    # pyramid levels take part only when an image has more than scale0 or a level is asked for (registration.py:1639-1717)
+    multiscale = reg_res_level is not None or any(msi_utils.is_msim(m) and len(m.keys()) > 1 for m in msims)
+    if multiscale:
+        levels_reg = [[channel_of(msi_utils.get_sim_from_msim(m, scale=k)) for k in msi_utils.get_sorted_scale_keys(m)]
+                      if msi_utils.is_msim(m) else [channel_of(m)] for m in msims]
 
     # tiles of a regular mosaic are binned while the graph is built (the GPU would idle otherwise)
     bin_cache, prebin = None, None
-    if pairwise_executor is None and nt == 1:
+    if pairwise_executor is None and nt == 1 and not multiscale:
         bin_cache = _BinCache()
         prebin = _prebin_views(sims_reg, registration_binning, device, bin_cache)
 
@@ -844,14 +902,23 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
     for it in range(nt):
         # per-time-point fields are shallow copies with their OWN transforms dict: the caller's images are never modified
         # (t-stacked affines of an image without a t axis would otherwise collapse to one time point for good)
-        fields = [s.isel({"t": it}) if "t" in s.dims else s.copy() for s in sims_reg]
-        for f, s in zip(fields, sims_reg):
+        def field_of(s):
+            f = s.isel({"t": it}) if "t" in s.dims else s.copy()
             f.attrs["transforms"] = {k: param_utils.select_time(v, it) for k, v in s.attrs.get("transforms", {}).items()}
+            return f
+
+        if multiscale:
+            fields = []
+            for lv in levels_reg:
+                fl = [field_of(s) for s in lv]
+                fields.append(msi_utils.MultiscaleSpatialImage(fl, fl[0].attrs["transforms"]))
+        else:
+            fields = [field_of(s) for s in sims_reg]
         results = compute_pairwise_registrations(
             fields, edges, transform_key, registration_binning, overlap_tolerance, pairwise_reg_func,
             pairwise_reg_func_kwargs, pairwise_executor, device,
             host_threads=(16 if n_parallel_pairwise_regs is None else n_parallel_pairwise_regs),
-            _bin_cache=bin_cache,
+            _bin_cache=bin_cache, reg_res_level=reg_res_level,
         )
         keep = list(range(len(edges)))
         if post_registration_do_quality_filter:

@@ -118,6 +118,16 @@ def fill_view_geometry(view, data_ptr, dtype_code, mem, shape, strides_elems, ma
     view.matrix[:] = m3.reshape(-1).tolist()
 
 
+def check_interpolation_order(order, name):
+    """The reference forwards ``order`` to scipy.ndimage.affine_transform unchanged (transformation.py:85-94,
+    fusion/_core.py:797, 1627); the HIP resampler has nearest (0) and bi / trilinear (1) taps only.  Higher spline orders
+    are refused HERE, at call time and under the reference's parameter name, not from inside a chunk."""
+    if isinstance(order, bool) or not isinstance(order, (int, np.integer)) or int(order) not in (0, 1):
+        raise NotImplementedError(
+            f"{name}={order!r}: the HIP backend resamples with order 0 (nearest) or 1 (linear) only; spline orders 2-5 of "
+            "scipy.ndimage.affine_transform (prefiltered B-splines) are not implemented")
+
+
 def resample_array(data, matrix, offset, output_shape, order=1, cval=0.0, device=0, out_on_device=None):
     """scipy.ndimage.affine_transform(data, matrix, offset, output_shape, order, 'constant', cval)
     for order 0|1 on the GPU; float32 result (transformation.py:136-139).  ``data`` may be a numpy
@@ -185,6 +195,7 @@ def transform_sim(
     kwargs = {"mode": "constant", "cval": 0.0, "order": 1} | affine_transform_kwargs
     if kwargs["mode"] != "constant":
         raise NotImplementedError("HIP resampler implements mode='constant' only")
+    check_interpolation_order(kwargs["order"], "order")
     out_shape = tuple(int(output_stack_properties["shape"][d]) for d in sdims) if isinstance(
         output_stack_properties["shape"], dict) else tuple(int(s) for s in output_stack_properties["shape"])
     in_shape = tuple(si_utils.get_shape_from_sim(sim, asarray=True))

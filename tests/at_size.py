@@ -118,18 +118,28 @@ def _marginal(task, index):
     return False
 
 
-def check_boxes(fused_data, tasks, los, shapes, rtol=1e-4, int_boundary_rtol=1e-4):
+def check_boxes(fused_data, tasks, los, shapes, rtol=1e-4, int_boundary_rtol=1e-4, windows=None):
     """Compare the windows of the fused mosaic with the farmed oracle results; returns the aggregate statistics of
     ``tests.helpers.fused_close_stats`` (how many voxels needed the reference's noise floor, and how large it got) plus
     ``marginal_voxels``: voxels exactly on a view border (see ``_marginal``), taken out of the comparison."""
     results = farm(run_fuse_task, tasks)
     agg = {"voxels": 0, "beyond_plain_bar": 0, "max_floor_used": 0.0, "lsb_flips": 0, "boxes": 0, "marginal_voxels": 0}
+    agg_seen = []
     for task, res, lo, shape in zip(tasks, results, los, shapes):
         got = fetch(fused_data, lo, np.asarray(lo) + np.asarray(shape))
         if res is None:
             assert not got.any(), "box without contributing views must be zero"
+            agg_seen.append(0)
             continue
         want, want_f, floor, wsum = res
+        if windows is not None:
+            # the oracle fused a LARGER box (reach of a neighbourhood filter around the compared one): windows[k] = offset of
+            # the compared box inside it
+            sl = tuple(slice(int(a), int(a + m)) for a, m in zip(windows[len(agg_seen)], shape))
+            want, want_f = want[sl], want_f[sl]
+            floor = None if floor is None else floor[sl]
+            wsum = None if wsum is None else wsum[sl]
+        agg_seen.append(1)
         if np.issubdtype(got.dtype, np.integer):
             far = np.argwhere(np.abs(got.astype(np.int64) - want.astype(np.int64)) > 1)
             assert len(far) <= 64, f"{len(far)} voxels differ by more than one count"
@@ -175,6 +185,7 @@ class CapturePairs:
         import threading
 
         self.keep, self.records, self._lock = keep, [], threading.Lock()
+        self.tag = None        # set by the caller before a call: stored with the record (e.g. the pair's view indices)
 
     def __call__(self, fixed_data, moving_data, device=0, **kw):
         from multiview_stitcher_amd import registration
@@ -186,7 +197,7 @@ class CapturePairs:
             if sum(1 for r in self.records if r["orient"] == orient) < max(1, self.keep // 3) and not isinstance(got, list):
                 a = np.asarray(fixed_data.data if hasattr(fixed_data, "data") else fixed_data)
                 b = np.asarray(moving_data.data if hasattr(moving_data, "data") else moving_data)
-                self.records.append({"orient": orient, "fixed": a, "moving": b, "got": {
+                self.records.append({"orient": orient, "fixed": a, "moving": b, "tag": self.tag, "got": {
                     "affine_matrix": np.asarray(got["affine_matrix"]).copy(), "quality": float(got["quality"])}})
         return got
 
@@ -196,3 +207,30 @@ class CapturePairs:
             assert np.array_equal(r["got"]["affine_matrix"], w["affine_matrix"]), (r["got"], w)      # selected shift: bit-exact
             assert abs(r["got"]["quality"] - w["quality"]) <= quality_atol, (r["got"]["quality"], w["quality"])
         return len(wants)
+
+
+def oracle_registration_crops(tile1, tile2, origin1, origin2, spacing, affine1=None, affine2=None):
+    """The two crops ``phase_correlation_registration`` receives for a pair, made by the ORACLE from the raw tiles:
+    registration binning (registration.py:114-191), ``coarsen(binning).mean().astype(dtype)`` (registration.py:1732-1741),
+    the overlap boxes of the binned views (registration.py:194-277) and the resample of both onto the fixed view's grid
+    over its box (registration.py:280-350).  ``tile*``: host arrays (z, y, x), ``origin*`` / ``spacing``: physical, zyx."""
+    nd = tile1.ndim
+    spacing = np.asarray(spacing, dtype=np.float64)
+    binning = ro.get_optimal_registration_binning(tile1.shape, tile2.shape, spacing, spacing)
+    b = np.array([binning[d] for d in ["z", "y", "x"][-nd:]])
+    views, stacks = [], []
+    for tile, origin in ((tile1, origin1), (tile2, origin2)):
+        n = (np.array(tile.shape) // b) * b
+        t = tile[tuple(slice(0, int(v)) for v in n)]
+        shp = []
+        for k in range(nd):
+            shp += [int(n[k] // b[k]), int(b[k])]
+        binned = t.reshape(shp).mean(axis=tuple(range(1, 2 * nd, 2))).astype(tile.dtype)        # float64 mean, truncating cast
+        o = np.asarray(origin, dtype=np.float64) + (b - 1) * spacing / 2
+        views.append({"data": binned, "origin": o, "spacing": spacing * b})
+        stacks.append({"origin": o, "spacing": spacing * b, "shape": np.array(binned.shape)})
+    a1 = np.eye(nd + 1) if affine1 is None else np.asarray(affine1)
+    a2 = np.eye(nd + 1) if affine2 is None else np.asarray(affine2)
+    lowers, uppers, _ = ro.get_overlap_bboxes(stacks[0], a1, stacks[1], a2)
+    fixed, moving, _, _ = ro.sims_to_intrinsic_coord_system(views[0], views[1], a1, a2, lowers, uppers)
+    return fixed, moving, binning

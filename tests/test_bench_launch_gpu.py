@@ -66,3 +66,43 @@ def test_two_ranks_one_mosaic_equals_single_rank(hip_device, tmp_path):
     # every rank fuses its sub-box in the index frame of the whole mosaic (sharding.fuse_shard -> fuse(frame_origin=...)):
     # the union equals the single-rank mosaic voxel for voxel
     np.testing.assert_array_equal(got, full)
+
+
+def test_eight_ranks_one_mosaic_equals_single_rank(hip_device, tmp_path):
+    """The north star's partition -- 8 ranks, a 2 x 2 x 2 brick of the 4 x 4 x 4 tile grid each -- launched for real: eight
+    processes under ``torch.distributed.run`` share the box's one GPU (gloo control plane), exchange their one-tile halos with
+    the isend / irecv schedule of ``sharding.exchange_halo`` (seven peers per rank instead of the one the 2-rank test has),
+    register the pairs whose fixed view they own, all-gather the results, resolve replicated and fuse their sub-box.  Small
+    tiles (96^3) keep eight contexts on one GPU cheap; the partition logic does not depend on the tile size."""
+    common = ["--grid", "4,4,4", "--tile", "96,96,96", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pcie"]
+    d1, d8 = tmp_path / "n1", tmp_path / "n8"
+    d1.mkdir()
+    d8.mkdir()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = _run([sys.executable, "bench.py", "--gpus", "1"] + common, dict(env, MVS_BENCH_DUMP=str(d1)))
+    eight = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                  "--master-port", str(_free_port()), "bench.py", "--gpus", "8"] + common,
+                 dict(env, MVS_BENCH_DUMP=str(d8), MVS_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4"), timeout=1500)
+    assert eight["n_gpus"] == 8 and eight["config"]["mode"] == "shard" and eight["scaling"] == "strong"
+    assert eight["config"]["registration_max_abs_error_px"] == pytest.approx(one["config"]["registration_max_abs_error_px"], abs=1e-9)
+    full = np.load(d1 / "fused_rank0of1.npy")
+    got = np.zeros_like(full)
+    covered = np.zeros(full.shape, dtype=bool)
+    pairs, held = [], []
+    for r in range(8):
+        part = np.load(d8 / f"fused_rank{r}of8.npy")
+        meta = json.load(open(d8 / f"fused_rank{r}of8.json"))
+        assert meta["mode"] == "shard" and part.size > 0 and meta["pairs_registered"] > 0      # every rank registered and fused
+        assert meta["halo_exchange_ms"] is not None                                            # ... after a completed exchange
+        pairs.append(meta["pairs_registered"])
+        held.append(meta["tiles_held"])
+        sl = tuple(slice(o, o + n) for o, n in zip(meta["index_offset"], part.shape))
+        assert not covered[sl].any()                                                           # sub-boxes are disjoint
+        got[sl] = part
+        covered[sl] = True
+    assert covered.all()
+    # the 144 pairs of the pruned overlap graph are split by the owner of the fixed view; a rank holds its 2 x 2 x 2 brick plus a
+    # one-tile halo (27 tiles at a corner brick of this grid), never the whole mosaic
+    assert sum(pairs) == json.load(open(d1 / "fused_rank0of1.json"))["pairs_registered"] == 144
+    assert all(8 <= h <= 27 for h in held), held
+    np.testing.assert_array_equal(got, full)

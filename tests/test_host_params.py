@@ -133,3 +133,70 @@ def test_stacked_view_records_equal_the_per_view_form(ndim):
         a, b = transformation.embed3(mats[i], offs[i])
         np.testing.assert_array_equal(m3[i], a.reshape(-1))
         np.testing.assert_array_equal(o3[i], b)
+
+
+# ---- pyramid level selection of the pairwise registration (registration.py:1639-1717, msi_utils.py:688-773) -----------------
+def _msim_with_levels(shape=(64, 96, 128), factors=(2, 2)):
+    from multiview_stitcher_amd import msi_utils
+    from multiview_stitcher_amd import spatial_image_utils as si_utils
+
+    rng = np.random.default_rng(0)
+    sim = si_utils.to_spatial_image(rng.integers(0, 1000, shape).astype(np.uint16), ["z", "y", "x"],
+                                    {"z": 2.0, "y": 0.5, "x": 0.5}, {"z": 3.0, "y": -7.0, "x": 11.0})
+    si_utils.set_sim_affine(sim, np.eye(4), "k")
+    return msi_utils.get_msim_from_sim(sim, scale_factors=list(factors))
+
+
+def test_res_level_from_binning_factors_follows_the_reference():
+    from multiview_stitcher_amd import msi_utils
+
+    m = _msim_with_levels()                # scale1 = 2x, scale2 = 4x on every axis
+    f = msi_utils.get_res_level_from_binning_factors
+    assert f(m, {"z": 1, "y": 1, "x": 1}) == ("scale0", {"z": 1, "y": 1, "x": 1})
+    assert f(m, {"z": 2, "y": 2, "x": 2}) == ("scale1", {"z": 1, "y": 1, "x": 1})
+    assert f(m, {"z": 4, "y": 8, "x": 8}) == ("scale2", {"z": 1, "y": 2, "x": 2})
+    assert f(m, {"z": 2, "y": 4, "x": 4}) == ("scale1", {"z": 1, "y": 2, "x": 2})      # scale2 would over-bin z
+    assert f(m, {"z": 3, "y": 3, "x": 3}) == ("scale0", {"z": 3, "y": 3, "x": 3})      # 2 does not divide 3
+    assert f(m, {"z": 1, "y": 2, "x": 2}) == ("scale0", {"z": 1, "y": 2, "x": 2})      # z must stay at 1
+    # a dim missing from the request places no constraint and gets no further binning (msi_utils.py:734-735, 762-763)
+    assert f(m, {"y": 4, "x": 4}) == ("scale2", {"z": 1, "y": 1, "x": 1})
+
+
+def test_select_registration_level_branches():
+    from multiview_stitcher_amd import msi_utils, registration
+
+    m1, m2 = _msim_with_levels(), _msim_with_levels()
+    sel = registration._select_registration_level
+    s1, s2, b = sel(m1, m2, None, 1)                                   # level alone: no binning
+    assert s1.shape == (32, 48, 64) and s2.shape == (32, 48, 64) and b == {"z": 1, "y": 1, "x": 1}
+    s1, _, b = sel(m1, m2, {"z": 2, "y": 4, "x": 4}, 1)               # level + binning: the rest is still applied
+    assert s1.shape == (32, 48, 64) and b == {"z": 1, "y": 2, "x": 2}
+    with pytest.raises(ValueError, match="not a divisor"):
+        sel(m1, m2, {"z": 3, "y": 4, "x": 4}, 1)
+    with pytest.raises(ValueError, match="does not exist"):
+        sel(m1, m2, None, 5)
+    s1, _, b = sel(m1, m2, {"z": 4, "y": 4, "x": 4}, None)            # binning alone: the lowest level that divides it
+    assert s1.shape == (16, 24, 32) and b == {"z": 1, "y": 1, "x": 1}
+    # level sims carry their own (shifted) origin and coarser spacing: scale = spacing * f, origin + (f - 1) * spacing / 2
+    from multiview_stitcher_amd import spatial_image_utils as si_utils
+    assert si_utils.get_spacing_from_sim(s1) == {"z": 8.0, "y": 2.0, "x": 2.0}
+    assert si_utils.get_origin_from_sim(s1) == {"z": 3.0 + 3.0, "y": -7.0 + 0.75, "x": 11.0 + 0.75}
+    # plain SpatialImages are scale0-only images
+    a, b_ = msi_utils.get_sim_from_msim(m1), msi_utils.get_sim_from_msim(m2)
+    s1, s2, b = sel(a, b_, {"z": 1, "y": 2, "x": 2}, None)
+    assert s1 is a and s2 is b_ and b == {"z": 1, "y": 2, "x": 2}
+    with pytest.raises(ValueError, match="does not exist"):
+        sel(a, b_, None, 1)
+
+
+def test_spline_orders_above_one_are_refused_at_call_time():
+    """``order`` > 1 used to surface as MVS_ERR_UNSUPPORTED from inside a chunk."""
+    from multiview_stitcher_amd import fusion, msi_utils
+
+    sim = msi_utils.get_sim_from_msim(_msim_with_levels(factors=()))
+    with pytest.raises(NotImplementedError, match="interpolation_order=3"):
+        fusion.fuse([sim, sim], transform_key="k", interpolation_order=3)
+    with pytest.raises(NotImplementedError, match="order=3"):
+        transformation.transform_sim(sim, np.eye(4), output_stack_properties={"origin": {"z": 0, "y": 0, "x": 0}, "spacing": {"z": 1, "y": 1, "x": 1}, "shape": {"z": 4, "y": 4, "x": 4}}, order=3)
+    with pytest.raises(NotImplementedError, match="interpolation_order=2"):
+        fusion.fuse_np([sim], [np.eye(4)], {"origin": {"z": 0, "y": 0, "x": 0}, "spacing": {"z": 1, "y": 1, "x": 1}, "shape": {"z": 4, "y": 4, "x": 4}}, interpolation_order=2)
