@@ -153,6 +153,24 @@ def _slabs_for_chunk(views, params, bbs, sub_bb, margin=2):
 _CPU_FARM = {}
 
 
+def _cpu_quota_cores():
+    """CPU quota of this container in cores (cgroup v2 cpu.max / v1 cfs quota), None when unlimited or unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
 def _cpu_farm_task(shm_dir, kind, index):
     """(worker) one task of the all-core baseline: kind 0 = oracle fuse of output chunk ``index``, 1 = oracle registration
     of pair ``index``, -1 = warm-up (imports + memory maps only).  Inputs are memory-mapped from ``shm_dir`` by the worker
@@ -171,7 +189,7 @@ def _cpu_farm_task(shm_dir, kind, index):
                  for k in range(meta["n_pairs"])]
         st = _CPU_FARM[shm_dir] = (views, meta, pairs)
     views, meta, pairs = st
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     if kind == 1:
         a, b = pairs[index]
         ro.phase_correlation_registration(np.array(a), np.array(b))
@@ -179,7 +197,7 @@ def _cpu_farm_task(shm_dir, kind, index):
         sb = meta["subs"][index]
         v, p, b = _slabs_for_chunk(views, meta["params"], meta["bbs"], sb)
         fo.fuse_np(list(v), p, sb, full_view_bbs=list(b))
-    return time.perf_counter() - t0
+    return time.perf_counter() - t0, time.process_time() - c0      # (wall, CPU) seconds of this task
 
 
 def _cpu_pair_task(a, b):
@@ -278,7 +296,9 @@ def cpu_baseline(args, grid, tile, overlap):
             pickle.dump({"views": [{"origin": v["origin"], "spacing": v["spacing"]} for v in views], "params": params,
                          "bbs": list(bbs), "subs": subs, "n_pairs": len(pairs)}, f)
         per_replica = len(subs) + 12
-        replicas = max(1, -(-8 * nphys // per_replica))       # >= 8 tasks per worker: the tail of 2.6-s pair tasks stays short
+        quota0 = _cpu_quota_cores()
+        n_target = nphys if quota0 is None else max(1, min(nphys, int(np.ceil(quota0))))
+        replicas = max(1, -(-8 * n_target // per_replica))       # >= 8 tasks per worker: the tail of 2.6-s pair tasks stays short
         tasks = []
         for _ in range(replicas):
             tasks += [delayed(_cpu_farm_task)(shm_dir, 1, k % 3) for k in range(12)]      # (the long tasks first)
@@ -288,12 +308,15 @@ def cpu_baseline(args, grid, tile, overlap):
         for k in env:
             os.environ[k] = "1"
         try:
-            nw = min(int(os.environ.get("MVS_CPU_WORKERS", nphys)), len(tasks))
+            quota = _cpu_quota_cores()
+            nw_default = nphys if quota is None else max(1, min(nphys, int(np.ceil(quota))))
+            nw = min(int(os.environ.get("MVS_CPU_WORKERS", nw_default)), len(tasks))
             with Parallel(n_jobs=nw, backend="loky", batch_size=1, pre_dispatch="all") as par:
                 par([delayed(_cpu_farm_task)(shm_dir, -1, 0)] * (2 * nw))     # spawn the workers, import scipy, map the files: untimed
                 t0 = time.perf_counter()
-                secs = par(tasks)
+                both = par(tasks)
                 t_all = time.perf_counter() - t0
+                secs, cpu_secs = [b_[0] for b_ in both], [b_[1] for b_ in both]
         finally:
             for k, v in env.items():
                 if v is None:
@@ -303,7 +326,12 @@ def cpu_baseline(args, grid, tile, overlap):
         out["all_cores"] = {"value": replicas * vox / t_all / 1e6, "unit": "Mvoxels/s", "cores": ncores, "physical_cores": nphys,
                             "workers": nw, "tasks": len(tasks), "replicas": replicas, "wall_s": t_all,
                             "task_seconds_sum": float(np.sum(secs)), "task_seconds_max": float(np.max(secs)),
-                            "parallel_efficiency": float(np.sum(secs)) / t_all,
+                            "task_cpu_seconds_sum": float(np.sum(cpu_secs)),
+                            # cores the farm really had: CPU seconds its tasks consumed per second of wall time (a container
+                            # with a CPU quota below its visible core count shows up here: wall-based occupancy stays high,
+                            # this figure does not)
+                            "parallel_efficiency": float(np.sum(cpu_secs)) / t_all,
+                            "worker_occupancy": float(np.sum(secs)) / t_all, "cpu_quota_cores": _cpu_quota_cores(),
                             "sample": f"{replicas} replicas of the same mosaic job, each {len(subs)} output-chunk tasks (every task cuts "
                                       f"the slabs of the views reaching into its chunk out of memory-mapped tiles, as the reference's "
                                       f"chunk tasks read theirs from Zarr) + 12 pair tasks, joblib loky, one worker per physical "

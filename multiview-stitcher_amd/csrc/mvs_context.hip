@@ -256,6 +256,10 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         c->materialize_shifts = value != 0;
         return MVS_OK;
     }
+    if (!strcmp(key, "fft_no_line")) {
+        c->fft_no_line = value != 0;
+        return MVS_OK;
+    }
     if (!strcmp(key, "ablate")) {
         c->ablate = (int)value;
         return MVS_OK;

@@ -13,6 +13,7 @@
 // pass reads and writes each complex element exactly once.  Lines along y/z are taken `lpb` adjacent
 // x positions at a time so that global accesses stay coalesced along x.
 #include "mvs_fft.h"
+#include "mvs_fft_dev.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -25,28 +26,6 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
     return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-struct FftArgs {
-    float2* data;
-    long long n_lines;        // number of lines of this pass
-    int n;                    // transform length
-    int M, log2M;             // Stockham size (== n for powers of two)
-    long long stride;         // element stride along the transform axis
-    long long inner;          // lines are enumerated l = outer * inner + i: base = outer * outer_stride + i
-    long long outer_stride;
-    int lpb;                  // lines per workgroup
-    int inverse;              // 1: conjugate transform (unnormalised)
-    const float2* tw;         // exp(-2 pi i m / M), m < M/2
-    const float2* chirp;      // Bluestein: w_n = exp(-i pi n^2 / N), n < N
-    const float2* bfft;       // Bluestein: FFT_M of the wrapped conj chirp, scaled by 1/M
-    // fusions of the register kernels (nullptr: off), see MvsFftFuse
-    const float* re_src = nullptr;
-    const float* im_src = nullptr;
-    float* peak_val[2] = {nullptr, nullptr};
-    long long* peak_idx[2] = {nullptr, nullptr};
-    const float2* xp_src = nullptr;     // x pass only (stride 1, line = kz * xp_ny + ky)
-    float2* xp_p2 = nullptr;
-    int xp_ny = 0, xp_nz = 0, xp_sel_a = 0, xp_sel_b = 0;
-};
 
 // Stockham autosort stages on `lpb` lines of length M held in LDS: radix-4 passes (half the LDS round trips and
 // barriers of radix 2) plus one radix-2 pass when log2 M is odd.  `tw` = exp(-2 pi i m / M), m < M/2, also in LDS.
@@ -105,11 +84,6 @@ __device__ __forceinline__ float2* stockham(float2* a, float2* b, int lpb, int M
     return a;
 }
 
-// element offset of line l of this pass
-__device__ __forceinline__ long long line_base(const FftArgs& A, int l) {
-    const int inner = (int)A.inner;
-    return (long long)(l / inner) * A.outer_stride + (l % inner);
-}
 
 template <bool BLUESTEIN>
 __global__ __launch_bounds__(256) void fft_lines_kernel(FftArgs A) {
@@ -251,41 +225,6 @@ template <> __device__ __forceinline__ void dft_reg<16>(float2 (&v)[16]) {
         for (int k = p + 1; k < 4; ++k) { const float2 t = v[4 * p + k]; v[4 * p + k] = v[4 * k + p]; v[4 * k + p] = t; }
 }
 
-__device__ __forceinline__ float2 fft_load(const FftArgs& A, long long i) {
-    if (!A.re_src) return A.data[i];
-    float re = A.re_src[i], im = A.im_src[i];      // the pair a + i b of two real volumes, NaN -> 0 (np.nan_to_num, registration.py:403-408)
-    re = (re != re) ? 0.f : re;
-    im = (im != im) ? 0.f : im;
-    return make_float2(re, im);
-}
-// The first pass of the inverse transform of the phase correlation, along x: its input is made from the packed spectrum Z (xp_src)
-// and its mirror Z(-k) on the fly, the cross power goes to xp_p2 (mvs_xpower_value, mvs_fft.h).
-struct XpLine { long long mbase; float scale_phase, scale_plain; };
-__device__ __forceinline__ XpLine xp_line(const FftArgs& A, long long l) {
-    XpLine x;
-    const int ky = (int)(l % A.xp_ny), kz = (int)(l / A.xp_ny);
-    const int my = ky ? A.xp_ny - ky : 0, mz = kz ? A.xp_nz - kz : 0;
-    x.mbase = ((long long)mz * A.xp_ny + my) * A.n;
-    x.scale_phase = x.scale_plain = 1.f;
-    if (A.xp_sel_b >= 0) mvs_xpower_scales(A.xp_src[0], (long long)A.xp_nz * A.xp_ny * A.n, &x.scale_phase, &x.scale_plain);
-    return x;
-}
-__device__ __forceinline__ float2 xp_load(const FftArgs& A, const XpLine& xl, long long base, int kx) {
-    const int mx = kx ? A.n - kx : 0;
-    float2 p, p1;
-    const float2 v = mvs_xpower_value(A.xp_src[base + kx], A.xp_src[xl.mbase + mx], A.xp_sel_a, A.xp_sel_b, xl.scale_phase, xl.scale_plain, &p, &p1);
-    A.xp_p2[base + kx] = p;
-    return v;
-}
-// running argmax |Re| / |Im| with the lowest flat index among equal values (np.argmax)
-struct Peak2 { float v[2]; long long i[2]; };
-__device__ __forceinline__ void peak_init(Peak2& p) { p.v[0] = p.v[1] = -1.f; p.i[0] = p.i[1] = 0x7fffffffffffffffLL; }
-__device__ __forceinline__ void peak_add(Peak2& p, float2 o, long long idx) {
-    const float a[2] = {fabsf(o.x), fabsf(o.y)};
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-        if (a[k] > p.v[k] || (a[k] == p.v[k] && idx < p.i[k])) { p.v[k] = a[k]; p.i[k] = idx; }
-}
 // workgroup reduction (256 threads) and the write of the workgroup's partials
 __device__ __forceinline__ void peak_flush(Peak2 p, const FftArgs& A) {
     __shared__ float sv[2][4];
@@ -726,6 +665,7 @@ int fft_axis_big(MvsContext* c, float2* data, int n, long long n_lines, long lon
 // does a line of n samples run on the register kernels (which carry the MvsFftFuse options)?
 bool mvs_fft_reg_length(int n) {
     if (n < 2) return false;
+    if (mvs_dft_line_length(n)) return true;
     if ((n & (n - 1)) == 0) return n == 64 || n == 128 || n == 256;
     int M = 1;
     while (M < 2 * n - 1) M <<= 1;
@@ -769,8 +709,9 @@ int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inver
         const long long nblocks = (A.n_lines + lpb - 1) / lpb;
         const bool reg_pow2 = !p.bluestein && (n == 64 || n == 128 || n == 256);
         const bool reg_blue = p.bluestein && p.M <= 256 && p.M >= 64;
-        if (reg_pow2 || reg_blue) {
-            const int lpw = ((reg_pow2 && n == 64) || (reg_blue && p.M == 64)) ? 32 : 16;      // lines per workgroup
+        const bool reg_line = mvs_dft_line_length(n) && !c->fft_no_line;
+        if (reg_pow2 || reg_blue || reg_line) {
+            const int lpw = reg_line ? 64 : ((reg_pow2 && n == 64) || (reg_blue && p.M == 64)) ? 32 : 16;      // lines per workgroup
             const unsigned grid = (unsigned)((A.n_lines + lpw - 1) / lpw);
             // the fusions at the two ends of the transform (MvsFftFuse)
             if (fuse && axis == first_axis && fuse->re_src && fuse->im_src) {
@@ -788,7 +729,10 @@ int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inver
                 for (int k = 0; k < 2; ++k) { A.peak_val[k] = fuse->peak_val[k]; A.peak_idx[k] = fuse->peak_idx[k]; }
                 fuse->n_peak = (int)grid;
             }
-            if (reg_pow2) {
+            if (reg_line) {
+                // short composite lines: the whole line in the registers of one thread (mvs_dft_small.h)
+                if (!(n <= 44 ? mvs_launch_dft_line_lo(c, A, grid) : mvs_launch_dft_line_hi(c, A, grid))) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "FFT: no whole-line kernel for n = %d", n);
+            } else if (reg_pow2) {
                 // short power-of-two lines: two register transforms around one LDS exchange
                 if (n == 256) hipLaunchKernelGGL((fft_reg2_kernel<16, 16>), dim3(grid), dim3(256), 0, c->stream, A);
                 else if (n == 128) hipLaunchKernelGGL((fft_reg2_kernel<16, 8>), dim3(grid), dim3(256), 0, c->stream, A);

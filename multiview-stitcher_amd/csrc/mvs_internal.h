@@ -77,6 +77,7 @@ struct MvsContext {
     uint64_t crop_stats_gen = 0;  // mbox_gen at the time the partials were parked: a reallocated mailbox invalidates them
     void* crop_stats_base = nullptr;
     bool crop_stats_done[2] = {false, false};
+    bool fft_no_line = false;     // test switch: lengths of the whole-line DFT kernel run on the Bluestein kernels instead
     bool no_regions = false;      // test switch: skip the region kernel (use the column kernel)
     bool rows_v1 = false;         // opt-in: direct-load row kernels (mvs_fuse_rows.hip) for every dtype (default: float tiles only)
     // caching device allocator behind mvs_malloc / mvs_free: freed blocks are kept (size-keyed) and handed out

@@ -234,3 +234,19 @@ def oracle_registration_crops(tile1, tile2, origin1, origin2, spacing, affine1=N
     lowers, uppers, _ = ro.get_overlap_bboxes(stacks[0], a1, stacks[1], a2)
     fixed, moving, _, _ = ro.sims_to_intrinsic_coord_system(views[0], views[1], a1, a2, lowers, uppers)
     return fixed, moving, binning
+
+
+def assert_crops_equal(got, want, exact=True):
+    """Device crop against the oracle's.  The reference sizes the crop as floor((upper - lower) / spacing + 1) from the vertices
+    Qhull returns for the intersection polytope (registration.py:241-277, 319): for views on one pixel grid that quotient is an
+    integer up to Qhull's round-off (1e-13), so the reference's own crop is N or N - 1 samples long depending on the sign of that
+    round-off.  The product evaluates axis-aligned pairs in closed form (the exact N); a shorter oracle crop is therefore compared
+    on the common window (its samples are the same samples: the origin moves by the same 1e-13)."""
+    assert got.ndim == want.ndim and all(0 <= g - w <= 1 for g, w in zip(got.shape, want.shape)), (got.shape, want.shape)
+    g = got[tuple(slice(0, n) for n in want.shape)]
+    assert np.array_equal(np.isnan(g), np.isnan(want))
+    if exact:
+        np.testing.assert_array_equal(g, want)
+    else:
+        np.testing.assert_allclose(g, want, rtol=1e-6, atol=0, equal_nan=True)
+    return bool(np.array_equal(g, want, equal_nan=True))

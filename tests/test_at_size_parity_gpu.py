@@ -431,8 +431,8 @@ def test_c1_two_tiles_2d_whole_mosaic_oracle_parity(hip_device):
         np.asarray(flat[0].data), np.asarray(flat[1].data), si.get_origin_from_sim(flat[0], asarray=True),
         si.get_origin_from_sim(flat[1], asarray=True), si.get_spacing_from_sim(flat[0], asarray=True))
     assert binning == {"y": 1, "x": 1}
-    np.testing.assert_array_equal(cap.records[0]["fixed"], fixed)
-    np.testing.assert_array_equal(cap.records[0]["moving"], moving)
+    at_size.assert_crops_equal(cap.records[0]["fixed"], fixed)
+    at_size.assert_crops_equal(cap.records[0]["moving"], moving)
     # hidden jitter recovered (upsample factor 10 in 2D: 0.1 px grid)
     got = np.array([param_utils.select_time(p, 0)[:-1, -1] for p in res["params"]])
     np.testing.assert_allclose(got[1] - got[0], jit[1] - jit[0], atol=0.11)
@@ -516,9 +516,7 @@ def test_north_star_device_results_through_the_resolution_and_pruning_oracles(hi
         i, j = r["tag"]
         fixed, moving, binning = at_size.oracle_registration_crops(host[i], host[j], origins[i], origins[j], [1.0, 1.0, 1.0])
         assert binning == {"z": 2, "y": 2, "x": 2}
-        assert fixed.shape == r["fixed"].shape and min(fixed.shape) >= 50
+        assert min(fixed.shape) >= 50
         for got, want in ((r["fixed"], fixed), (r["moving"], moving)):
-            assert np.array_equal(np.isnan(got), np.isnan(want))
-            np.testing.assert_allclose(got, want, rtol=1e-6, atol=0, equal_nan=True)
-            n_equal += int(np.array_equal(got, want, equal_nan=True))
+            n_equal += int(at_size.assert_crops_equal(got, want, exact=False))
     assert n_equal == 6          # half-pixel taps of integer-valued voxels are exact in float32: the crops are the same bits

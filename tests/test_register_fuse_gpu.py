@@ -377,3 +377,61 @@ def test_fuse_untrimmed_halo_chunks(hip_device):
             np.testing.assert_array_equal(block[halo:-halo, halo:-halo], t[by * cs["y"]:by * cs["y"] + hy, bx * cs["x"]:bx * cs["x"] + hx])
             ox += hx + 2 * halo
         oy += hy + 2 * halo
+
+
+def test_register_on_a_pyramid_level(hip_device):
+    """reg_res_level / registration_binning on multiscale images (registration.py:1639-1717): registering level 1 of the
+    pyramids is registering the level-1 images themselves; a binning of 2 picks level 1 by itself (msi_utils.py:688-773);
+    level + binning applies the remaining factor; the overlap graph stays on scale0."""
+    from multiview_stitcher_amd import msi_utils, registration, sample_data
+
+    sims, jit, _ = sample_data.generate_tiled_dataset(ndim=3, tile_shape=(32, 128, 128), tiles=(1, 2, 2), overlap=(0, 40, 40),
+                                                      dtype=np.uint16, max_jitter=2, seed=4)
+    key = sample_data.METADATA_TRANSFORM_KEY
+    sf = [{"z": 1, "y": 2, "x": 2}]
+    msims = [msi_utils.get_msim_from_sim(s, scale_factors=sf) for s in sims]
+    lvl1 = [msi_utils.get_sim_from_msim(m, scale="scale1") for m in msims]
+    kw = dict(transform_key=key, reg_channel_index=0, return_dict=True, groupwise_resolution_kwargs={"reference_view": 0})
+    a = registration.register(msims, reg_res_level=1, **kw)
+    b = registration.register(lvl1, registration_binning={"z": 1, "y": 1, "x": 1}, **kw)
+    c = registration.register(msims, registration_binning={"z": 1, "y": 2, "x": 2}, **kw)       # picks scale1, remainder 1
+    assert a["pairwise_registration"]["edges"] == c["pairwise_registration"]["edges"]
+    for ra, rb, rc in zip(a["pairwise_registration"]["results"][0], b["pairwise_registration"]["results"][0], c["pairwise_registration"]["results"][0]):
+        np.testing.assert_array_equal(ra["transform"], rb["transform"])
+        np.testing.assert_array_equal(ra["transform"], rc["transform"])
+        assert ra["quality"] == rb["quality"] == rc["quality"]
+    from multiview_stitcher_amd import param_utils
+    got = np.array([param_utils.select_time(p, 0)[:-1, -1] for p in a["params"]])
+    np.testing.assert_allclose(got - got[0], jit - jit[0], atol=1.01)        # half-resolution shifts in y / x
+    # level 1 + a total binning of 4 in y / x: the remaining factor 2 is applied to level 1
+    d = registration.register(msims, reg_res_level=1, registration_binning={"z": 1, "y": 4, "x": 4}, **kw)
+    e = registration.register(lvl1, registration_binning={"z": 1, "y": 2, "x": 2}, **kw)
+    for rd, re_ in zip(d["pairwise_registration"]["results"][0], e["pairwise_registration"]["results"][0]):
+        np.testing.assert_array_equal(rd["transform"], re_["transform"])
+    with pytest.raises(ValueError, match="does not exist"):
+        registration.register(msims, reg_res_level=3, **kw)
+
+
+def test_index_frame_that_cannot_be_applied_warns(hip_device):
+    """fuse_np silently dropped a frame_origin whose grid the chunk does not sit on -- and with it the
+    voxel-for-voxel guarantee across chunkings.  It warns now; fuse_shard turns the warning into an error."""
+    import warnings
+
+    from multiview_stitcher_amd import fusion, sample_data
+    from tests.helpers import bb_to_dicts, sim_to_view, squeeze_field, union_bb
+
+    sims, _, _ = sample_data.generate_tiled_dataset(ndim=3, tile_shape=(16, 40, 48), tiles=(1, 1, 2), overlap=(0, 0, 10), max_jitter=0)
+    sims = [squeeze_field(s) for s in sims]
+    params = [np.eye(4) for _ in sims]
+    views, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(3))
+    sd = ["z", "y", "x"]
+    fvb = [bb_to_dicts(b, sd) for b in bbs]
+    on_grid = {d: float(out_bb["origin"][k]) - 4.0 for k, d in enumerate(sd)}
+    off_grid = {d: float(out_bb["origin"][k]) - 4.3 for k, d in enumerate(sd)}
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", fusion.IndexFrameWarning)
+        want = fusion.fuse_np(sims, params, bb_to_dicts(out_bb, sd), full_view_bbs=fvb, frame_origin=on_grid)
+    with pytest.warns(fusion.IndexFrameWarning, match="frame_origin cannot be applied"):
+        got = fusion.fuse_np(sims, params, bb_to_dicts(out_bb, sd), full_view_bbs=fvb, frame_origin=off_grid)
+    np.testing.assert_array_equal(got, want)       # (integer offsets: the per-chunk fallback gives the same voxels here)
