@@ -391,10 +391,18 @@ def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
         h.copy_(t.view(torch.int16))
         host_tiles.append(h)
     torch.cuda.synchronize()
-    copy_stream = torch.cuda.Stream(device=dev)
-    n_slabs = 4
+    # The copy stream gets a priority of its own: HIP multiplexes the streams of a process onto a few hardware queues PER PRIORITY
+    # LEVEL, and a stream whose queue holds the barrier packets of 64 queued tile uploads stalls every compute stream that
+    # shares the queue -- with a normal-priority copy stream the first wave of pairs took 242 ms (until the last tile had
+    # arrived) instead of ~11 and the registration did not overlap with the uploads at all.
+    copy_stream = torch.cuda.Stream(device=dev, priority=-1)
+    n_slabs = 8
+
+    trace = {}
 
     def run():
+        import threading
+
         events = []
         t0 = time.perf_counter()
         with torch.cuda.stream(copy_stream):
@@ -403,6 +411,14 @@ def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
                 events.append(ev)
+        trace.clear()
+        trace["waves"] = []
+
+        def upload_watch():      # when did the last tile arrive?  (H2D rate of the phase, reported next to the pipeline's figures)
+            events[-1].synchronize()
+            trace["upload_done_ms"] = (time.perf_counter() - t0) * 1e3
+        watcher = threading.Thread(target=upload_watch)
+        watcher.start()
 
         def executor(msims, edges, register_kwargs):
             order = sorted(range(len(edges)), key=lambda k: max(edges[k]))
@@ -410,12 +426,14 @@ def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
             kw = dict(register_kwargs)
             tk, rb, ot = kw.pop("transform_key"), kw.pop("registration_binning", None), kw.pop("overlap_tolerance", 0.0)
             prf, prk = kw.pop("pairwise_reg_func"), kw.pop("pairwise_reg_func_kwargs", None)
-            wave = max(1, len(order) // 8)
+            wave = max(1, len(order) // 16)      # (short waves: what runs after the last tile has arrived is pure tail)
             for a in range(0, len(order), wave):
                 ks = order[a:a + wave]
                 events[max(max(edges[k]) for k in ks)].synchronize()      # both tiles of every pair of this wave are resident
+                tw0 = (time.perf_counter() - t0) * 1e3
                 part = registration.compute_pairwise_registrations(msims, [edges[k] for k in ks], tk, rb, ot, prf, prk, None,
                                                                    local_rank, host_threads=8)
+                trace["waves"].append((round(tw0, 1), round((time.perf_counter() - t0) * 1e3, 1), len(ks)))
                 for k, r in zip(ks, part):
                     results[k] = r
             return results
@@ -441,6 +459,7 @@ def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
             keep.append((fused, d))
         copy_stream.synchronize()
         t1 = time.perf_counter()
+        watcher.join()
         vox = float(nz) * osp["shape"]["y"] * osp["shape"]["x"]
         return t1 - t0, t_reg - t0, vox, host_slabs
 
@@ -449,6 +468,8 @@ def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
     h2d_gb = sum(t.numel() * 2 for t in tiles) / 1e9
     return {"value": vox / total / 1e6, "unit": "Mvoxels/s", "ms": total * 1e3, "register_phase_ms": t_reg * 1e3,
             "h2d_gb": h2d_gb, "d2h_gb": vox * 2 / 1e9, "fuse_slabs": n_slabs,
+            "upload_done_ms": trace.get("upload_done_ms"), "h2d_gb_per_s": h2d_gb / (trace["upload_done_ms"] * 1e-3) if trace.get("upload_done_ms") else None,
+            "d2h_gb_per_s": vox * 2 / 1e9 / max(total - t_reg, 1e-9), "register_waves_ms": trace.get("waves"),
             "note": "tiles in pinned host memory -> async uploads in tile order overlapped with the registration of the pairs "
                     "already resident -> resolution -> fuse in z slabs, each slab's download overlapped with the next slab's fuse"}
 

@@ -401,8 +401,22 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
     const int nvalid_x = min(max(x1 - xq, 0), kRV);
     const int xl = (nvalid_x > 0) ? xq : x0b;      // lanes beyond the region read a valid window, nothing is stored
     int allone_mask = masks & 0xff;
-    const int partial_mask = (masks >> 16) & 0xff;
+    int partial_mask = (masks >> 16) & 0xff;
     const bool allpos = (masks >> 15) & 1;   // host: every view covers the box with weight > 0 everywhere
+    // "Partial" is a property of the BOX: after the clustering of nearby view borders (the tiles of a registered grid row differ by
+    // a few pixels) a view misses a sliver at one end of the box.  A brick away from that sliver is covered completely: its
+    // voxels need no bounds test, and it qualifies for the unit / lean paths below like a brick of a fully covered box.
+    if (partial_mask) {
+        const int ze = min(z0b + kRB, z1) - 1, ye = min(y0b + 32, y1) - 1, xe = min(x0b + L.BXW, x1) - 1;
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            if (v < nv && ((partial_mask >> v) & 1)) {
+                const bool covered = rec_field<F_LO_Z>(R, v) <= z0b && rec_field<F_HI_Z>(R, v) >= ze && rec_field<F_LO_Y>(R, v) <= y0b &&
+                                     rec_field<F_HI_Y>(R, v) >= ye && rec_field<F_LO_X>(R, v) <= x0b && rec_field<F_HI_X>(R, v) >= xe;
+                if (covered) partial_mask &= ~(1 << v);
+            }
+        }
+    }
     // The host classified whole regions; the set {weight == 1} is curved (near an edge of a view the profile is a
     // product of the axis coordinates), so most of a region can be "unit" without the region being so.  Refine per
     // brick: the profile is concave along every axis line, hence its minimum over the brick sits at one of the 8
@@ -428,6 +442,15 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
         }
     }
     const bool all_unit = (allone_mask & ((1 << nv) - 1)) == ((1 << nv) - 1);
+    // "Anchored" brick: at least one view covers it completely with blend weight exactly 1.  Then the weight sum is >= 1 at every
+    // voxel (no 0 / 0, nothing to check for finiteness with integer tiles), and a voxel that only this view reaches comes out as
+    // v * 1 / 1 = v exactly -- the two cases the single-contributor bookkeeping (last / wlast) and the finite test exist for cannot
+    // occur, whatever the other views do (ramp weights, weights that round to 0, partial coverage after border clustering): plain
+    // weighted sums are exact enough everywhere in the brick.  This is every ramp brick of a face / edge overlap of a tile grid
+    // (one neighbour is always deep inside its own support there); only bricks on the rim of the mosaic and in the curved
+    // corner zones stay on the general path.
+    const bool anchored = !ISF && (allone_mask & ~partial_mask & ((1 << nv) - 1)) != 0;
+    const bool plain = !ISF && (allpos || anchored);
     TOut* out = (TOut*)P.out;
     bool allint = true;   // every view has an integer offset: one tap row per view
 #pragma unroll
@@ -560,12 +583,14 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
                         num[j] += ok ? val[j] : 0.f;
                         den[j] += ok ? 1.f : 0.f;
                     }
-                } else if (allpos && !ISF) {
-                    // every view of the region is in bounds with a strictly positive weight everywhere: plain weighted sums
+                } else if (plain) {
+                    // every view of the region is in bounds with a strictly positive weight everywhere, or the brick is anchored
+                    // by a full unit view: plain weighted sums (a partial view weighs 0 outside its valid box)
 #pragma unroll
                     for (int j = 0; j < kRV; ++j) {
-                        num[j] = fmaf(w[j], val[j], num[j]);
-                        den[j] += w[j];
+                        const float we = (partial && !inb[j]) ? 0.f : w[j];
+                        num[j] = fmaf(we, val[j], num[j]);
+                        den[j] += we;
                     }
                 } else {
 #pragma unroll
@@ -590,12 +615,12 @@ __device__ __forceinline__ void region_brick(const RegionParams& P, const RecReg
             for (int j = 0; j < kRV; ++j) {
                 float o;
                 if (nv == 1 && all_unit && !partial_mask && !ISF) o = num[j];      // a single full view with weight 1
-                else if (allpos && !ISF) o = num[j] * __builtin_amdgcn_rcpf(den[j]);
+                else if (plain) o = num[j] * __builtin_amdgcn_rcpf(den[j]);        // den > 0, finite integer data: nothing to check
                 else {
                     o = num[j] * __builtin_amdgcn_rcpf(den[j]);
                     o = (den[j] == wlast[j]) ? last[j] : o;                        // single ramp contributor: exact value
+                    if (!(fabsf(o) <= 3.4028234e38f)) o = 0.f;
                 }
-                if (!(fabsf(o) <= 3.4028234e38f)) o = 0.f;
                 q[j] = o;
             }
             if (row_ok && nvalid_x > 0) {
@@ -1157,16 +1182,9 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
     // NV = 4 / 8 classes by their weight arithmetic): they run side by side -- NV = 2, the largest, on the main stream, the
     // others on side streams that start after everything queued so far (fork event) and are waited for at the end (join).
     const bool fork = !c->serial_classes && nitems >= 4096;   // small chunks: five event round trips cost more than the overlap gains
-    if (fork && !c->ev_fork) {      // once per context (tens of ms: outside the timed section)
-        MVS_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        int prio_lo = 0, prio_hi = 0;
-        hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        for (int a = 0; a < 4; ++a) {
-            // lowest priority: the NV = 2 class on the main stream is the longest of the five and ends the launch, the others
-            // fill in around it (11.7 -> 11.3 ms on the jittered mosaic against equal priorities)
-            MVS_HIP_TRY(c, hipStreamCreateWithPriority(&c->aux_stream[a], hipStreamNonBlocking, prio_lo));
-            MVS_HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join[a], hipEventDisableTiming));
-        }
+    if (fork) {      // side streams: created once per context (tens of ms: outside the timed section)
+        const int rca = mvs_ensure_aux_streams(c);
+        if (rca) return rca;
     }
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));   // kernel time only (the plan is host work, cached per geometry)
     if (fork) MVS_HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));

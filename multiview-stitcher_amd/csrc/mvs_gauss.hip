@@ -22,6 +22,7 @@
 // 1.3 chunk volumes of filter work instead of 8 on the 2x2x2 probe.
 #include "mvs_fuse_dev.h"
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -223,6 +224,164 @@ __global__ __launch_bounds__(256) void gauss1d_lds_kernel(const float* __restric
     }
 }
 
+// ---- the value line and the mask line of a NaN-aware Gaussian in ONE launch (round 4) -----------------------------------------
+// NG_s(U) = gaussian(U, NaN -> 0) / gaussian(valid mask): both filters read the same voxels, so a workgroup stages the T lines of
+// BOTH arrays, filters both and -- on the last axis -- divides them on the spot.  What no longer travels through HBM:
+//   * prep_kernel's three arrays (A, V0, M): the first pass derives value and mask from the resampled view and its normalised
+//     blending weight itself (SRC_PREP; SRC_VMASK for the second filter, whose value input is the squared deviation);
+//   * the separate finish kernels: the last pass of the first filter stores (A - VV / WW)^2 with NaN -> 0 (DST_SQ), the last pass
+//     of the second one F = VV / WW with NaN where A is NaN (DST_F), A recomputed from the view at the output voxel;
+//   * half of the launches (6 instead of 12 line passes per view) and the second staging of every line set.
+// Same arithmetic as gauss1d_lds_kernel per quantity (scipy's order, double accumulation, float32 result per axis, the
+// constant-tile short cut per quantity).
+enum { SRC_AB = 0, SRC_PREP = 1, SRC_VMASK = 2, DST_AB = 0, DST_SQ = 1, DST_F = 2 };
+struct PairIO {
+    const float* a; const float* b;        // SRC_AB: value / mask lines; SRC_VMASK: a = value lines
+    const float* im; const float* bw;      // resampled view and normalised blending weight (SRC_PREP / SRC_VMASK / DST_SQ / DST_F)
+    float* oa; float* ob;                  // DST_AB: both results; DST_SQ / DST_F: oa = the single result
+    int src, dst;
+};
+
+__device__ __forceinline__ float cb_valid_value(const PairIO& P, long long i) {      // A: the view with NaN where bw < 1e-7
+    float x = P.im[i];
+    if (P.bw[i] < 1e-7f) x = NAN;
+    return x;
+}
+
+__global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines L, int radius, const double* __restrict__ fw, int pos_fastest) {
+    extern __shared__ float sl[];
+    const int T = L.T, TP = T + 1, len = L.len;
+    const int span = len + 2 * radius;
+    float* sq[2] = {sl, sl + (size_t)span * TP};
+    const long long l0 = (long long)blockIdx.x * T;
+    const int nl = (int)min((long long)T, L.n_lines - l0);
+    const int total = T * len;
+    auto gindex = [&](int line, int pos) { const long long l = l0 + line; return (l / L.inner) * L.outer_stride + (l % L.inner) + (long long)pos * L.stride; };
+    auto load2 = [&](long long i, float& v, float& m) {
+        if (P.src == SRC_AB) { v = P.a[i]; m = P.b[i]; }
+        else {
+            const float x = cb_valid_value(P, i);
+            const bool ok = (x == x);
+            m = ok ? 1.f : 0.f;
+            v = (P.src == SRC_PREP) ? (ok ? x : 0.f) : P.a[i];
+        }
+    };
+    // ---- stage the lines of both quantities; note per quantity whether every sample has the bits of the first one ----
+    float first[2];
+    load2(gindex(0, 0), first[0], first[1]);
+    int same0 = 1, same1 = 1;
+    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
+        int line, pos;
+        if (pos_fastest) { line = idx / len; pos = idx - line * len; }
+        else { pos = idx / T; line = idx - pos * T; }
+        float v = 0.f, m = 0.f;
+        if (line < nl) {
+            load2(gindex(line, pos), v, m);
+            same0 &= (__float_as_uint(v) == __float_as_uint(first[0])) ? 1 : 0;
+            same1 &= (__float_as_uint(m) == __float_as_uint(first[1])) ? 1 : 0;
+        }
+        sq[0][(pos + radius) * TP + line] = v;
+        sq[1][(pos + radius) * TP + line] = m;
+    }
+    const bool box_is_line = (L.b0 == 0 && L.len == L.full);
+    const int flags = __syncthreads_or((same0 ? 0 : 1) | (same1 ? 0 : 2));
+    bool cst[2];
+    cst[0] = !(flags & 1) && (box_is_line || __float_as_uint(first[0]) == 0u);
+    cst[1] = !(flags & 2) && (box_is_line || __float_as_uint(first[1]) == 0u);
+    float cval[2] = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (cst[q]) {
+            double acc = (double)first[q] * fw[radius];
+            for (int j = radius; j >= 1; --j) acc = fma((double)first[q] + (double)first[q], fw[radius - j], acc);
+            cval[q] = (float)acc;
+        }
+    // ---- halo of the quantities that are filtered: chunk line reflected at the chunk's ends, zeros where that leaves the box ----
+    for (int idx = threadIdx.x; idx < 2 * radius * T; idx += blockDim.x) {
+        const int h = idx / T, line = idx - h * T;
+        const int p = (h < radius) ? (h - radius) : (len + h - radius);
+        const int q = box_reflect(p, L.b0, len, L.full);
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            if (!cst[k]) sq[k][(p + radius) * TP + line] = (q >= 0) ? sq[k][(q + radius) * TP + line] : 0.f;
+    }
+    __syncthreads();
+    constexpr int K = 8;
+    const int nblk = (len + K - 1) / K;
+    const int qmax = len - 1 + 2 * radius;
+    for (int idx = threadIdx.x; idx < T * nblk; idx += blockDim.x) {
+        const int blk = idx / T, line = idx - blk * T;
+        if (line >= nl) continue;
+        const int p0 = blk * K;
+        float res[2][K];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (cst[q]) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) res[q][k] = cval[q];
+                continue;
+            }
+            const float* c = sq[q] + line;
+            double PA[K], PB[K], acc[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                PA[k] = (double)c[min(p0 + k, qmax) * TP];
+                PB[k] = (double)c[min(p0 + k + 2 * radius, qmax) * TP];
+                acc[k] = (double)c[min(p0 + k + radius, qmax) * TP] * fw[radius];
+            }
+            for (int jb = radius; jb >= 1; jb -= K) {
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    const int j = jb - s;
+                    if (j < 1) break;
+                    const double w = fw[radius - j];
+#pragma unroll
+                    for (int k = 0; k < K; ++k) acc[k] = fma(PA[(k + s) % K] + PB[(k - s + K) % K], w, acc[k]);
+                    PA[s % K] = (double)c[min(p0 + K - j + radius, qmax) * TP];
+                    PB[(K - 1 - s) % K] = (double)c[(p0 + j - 1 + radius) * TP];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) res[q][k] = (float)acc[k];
+        }
+        const long long obase = gindex(line, p0);
+        if (P.dst == DST_AB) {
+            if (L.stride == 1 && p0 + K <= len && ((obase & 3) == 0)) {
+                float4* o4 = reinterpret_cast<float4*>(P.oa + obase);
+                o4[0] = make_float4(res[0][0], res[0][1], res[0][2], res[0][3]);
+                o4[1] = make_float4(res[0][4], res[0][5], res[0][6], res[0][7]);
+                o4 = reinterpret_cast<float4*>(P.ob + obase);
+                o4[0] = make_float4(res[1][0], res[1][1], res[1][2], res[1][3]);
+                o4[1] = make_float4(res[1][4], res[1][5], res[1][6], res[1][7]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    if (p0 + k < len) { P.oa[obase + (long long)k * L.stride] = res[0][k]; P.ob[obase + (long long)k * L.stride] = res[1][k]; }
+            }
+        } else {
+            // Z = VV / WW where A is valid (weights.py:314-320); DST_SQ: (A - Z)^2 with NaN -> 0; DST_F: Z, NaN where A is NaN
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (p0 + k >= len) break;
+                const long long i = obase + (long long)k * L.stride;
+                const float a = cb_valid_value(P, i);
+                float o;
+                if (P.dst == DST_SQ) {
+                    o = 0.f;
+                    if (a == a) {
+                        const float d = a - res[0][k] / res[1][k];
+                        const float qd = d * d;
+                        o = (qd == qd) ? qd : 0.f;
+                    }
+                } else {
+                    o = (a == a) ? res[0][k] / res[1][k] : NAN;
+                }
+                P.oa[i] = o;
+            }
+        }
+    }
+}
+
 // Z = VV / WW with WW[nan] = 1, Z[nan] = NaN (weights.py:314-320); then D = (A - Z)^2, V1 = D with NaN -> 0
 __global__ void ng_finish_sq_kernel(const float* __restrict__ VV, const float* __restrict__ WW, const float* __restrict__ A,
                                     long long n, float* __restrict__ V1) {
@@ -364,7 +523,27 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
 
     // ---- scratch layout (slot 6): pools I, BW, F (one box per view), 6 temporaries of the largest box, filter kernels, boxes ----
     const size_t pool_b = (size_t)pool * 4, tmp_b = ((size_t)max_box * 4 + 255) / 256 * 256;
-    const size_t need = 3 * pool_b + 6 * tmp_b + 64 * 1024 + (size_t)n_views * sizeof(CbBox) + 512;
+    // paired line passes (gauss1d_pair_kernel): can every line set of every view be staged twice in 60 KiB of LDS?
+    const int ndim = opts->ndim;
+    int r1, r2;
+    std::vector<double> w1, w2;
+    gaussian_kernel((double)opts->sigma_1, &r1, &w1);
+    gaussian_kernel((double)opts->sigma_2, &r2, &w2);
+    auto pair_T = [&](int len, int radius, int axis) {      // lines per workgroup of a paired pass, 0: does not fit
+        const size_t span = (size_t)len + 2 * (size_t)radius;
+        int T = (axis == 2) ? 8 : 16;
+        while (T > 1 && span * (T + 1) * 8 > 60 * 1024) T >>= 1;
+        if (span * (T + 1) * 8 > 60 * 1024 || (axis != 2 && T < 4)) return 0;
+        return T;
+    };
+    bool paired = !c->cb_unpaired;
+    for (int i = 0; i < n_views && paired; ++i)
+        for (int axis = 3 - ndim; axis < 3; ++axis)
+            if (boxes[i].n[axis] > 0 && (!pair_T(boxes[i].n[axis], r1, axis) || !pair_T(boxes[i].n[axis], r2, axis))) paired = false;
+    // temporaries: paired path 5 arrays PER VIEW (the views' filter chains run side by side on the context's side streams);
+    // sequential path 6 arrays of the largest box, shared
+    const size_t tmp_total = paired ? 5 * pool_b : 6 * tmp_b;
+    const size_t need = 3 * pool_b + tmp_total + 64 * 1024 + (size_t)n_views * sizeof(CbBox) + 512;
     char* base = (char*)mvs_scratch(c, 6, need);
     if (!base) return mvs_alloc_failed(c);
     float* I = (float*)base;
@@ -376,13 +555,9 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
     float* T0 = (float*)((char*)M + tmp_b);
     float* T1 = (float*)((char*)T0 + tmp_b);
     float* T2 = (float*)((char*)T1 + tmp_b);
-    double* dfw = (double*)(((uintptr_t)((char*)T2 + tmp_b) + 255) / 256 * 256);
+    double* dfw = (double*)(((uintptr_t)(base + 3 * pool_b + tmp_total) + 255) / 256 * 256);
     CbBox* dboxes = (CbBox*)((char*)dfw + 32 * 1024);
 
-    int r1, r2;
-    std::vector<double> w1, w2;
-    gaussian_kernel((double)opts->sigma_1, &r1, &w1);
-    gaussian_kernel((double)opts->sigma_2, &r2, &w2);
     if ((w1.size() + w2.size()) * 8 > 32 * 1024) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "content_based: sigma too large");
     double* dfw1 = dfw;
     double* dfw2 = dfw + w1.size();
@@ -401,7 +576,6 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
     const int gb = grid_for(n);
     hipLaunchKernelGGL(mask_normalize_kernel, dim3(gb), dim3(256), 0, c->stream, BW, I, dboxes, n_views, S);
 
-    const int ndim = opts->ndim;
     auto gauss = [&](const float* src, float* dst, const CbBox& B, int radius, const double* fw) {
         // scipy filters axis 0, 1, 2 in turn; a 2D chunk has no z axis
         const Shape3 Sb = {B.n[0], B.n[1], B.n[2]};
@@ -434,7 +608,70 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
             cur = d;
         }
     };
-    for (int v = 0; v < n_views; ++v) {
+    // ---- paired path: per view 2 x ndim launches; the views' chains are independent (own temporaries), so the largest box runs
+    // on the context's stream and the others fill in around it on the four side streams ----
+    if (paired) {
+        int rcs = mvs_ensure_aux_streams(c);
+        if (rcs) return rcs;
+        std::vector<int> order;
+        for (int v = 0; v < n_views; ++v)
+            if ((long long)boxes[v].n[0] * boxes[v].n[1] * boxes[v].n[2] > 0) order.push_back(v);
+        std::sort(order.begin(), order.end(), [&](int a, int b) {
+            return (long long)boxes[a].n[0] * boxes[a].n[1] * boxes[a].n[2] > (long long)boxes[b].n[0] * boxes[b].n[1] * boxes[b].n[2]; });
+        MVS_HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+        bool side_used[4] = {false, false, false, false};
+        float* TP5 = A;      // 5 pools laid out one after the other: [k * pool + B.off]
+        for (size_t oi = 0; oi < order.size(); ++oi) {
+            const int v = order[oi];
+            const CbBox& B = boxes[v];
+            hipStream_t st = c->stream;
+            if (oi > 0) {
+                const int a = (int)((oi - 1) & 3);
+                st = c->aux_stream[a];
+                if (!side_used[a]) { MVS_HIP_TRY(c, hipStreamWaitEvent(st, c->ev_fork, 0)); side_used[a] = true; }
+            }
+            float* t[5];
+            for (int k = 0; k < 5; ++k) t[k] = TP5 + (size_t)k * (size_t)pool + B.off;
+            const float* Iv = I + B.off;
+            const float* Bv = BW + B.off;
+            for (int f = 0; f < 2; ++f) {
+                const int radius = f ? r2 : r1;
+                const double* fw = f ? dfw2 : dfw1;
+                const float *ina = nullptr, *inb = nullptr;
+                int pass = 0;
+                for (int axis = 3 - ndim; axis < 3; ++axis, ++pass) {
+                    const bool firstp = axis == 3 - ndim, lastp = axis == 2;
+                    PairIO P;
+                    P.im = Iv; P.bw = Bv;
+                    P.a = firstp ? (f ? t[4] : nullptr) : ina;
+                    P.b = firstp ? nullptr : inb;
+                    P.src = firstp ? (f ? SRC_VMASK : SRC_PREP) : SRC_AB;
+                    P.dst = lastp ? (f ? DST_F : DST_SQ) : DST_AB;
+                    P.oa = lastp ? (f ? F + B.off : t[4]) : t[2 * (pass & 1)];
+                    P.ob = lastp ? nullptr : t[2 * (pass & 1) + 1];
+                    GaussLines L;
+                    const long long nz = B.n[0], ny = B.n[1], nx = B.n[2];
+                    if (axis == 2) { L.len = B.n[2]; L.stride = 1; L.n_lines = nz * ny; L.inner = 1; L.outer_stride = nx; }
+                    else if (axis == 1) { L.len = B.n[1]; L.stride = nx; L.n_lines = nz * nx; L.inner = nx; L.outer_stride = ny * nx; }
+                    else { L.len = B.n[0]; L.stride = ny * nx; L.n_lines = ny * nx; L.inner = ny * nx; L.outer_stride = 0; }
+                    L.b0 = B.lo[axis];
+                    L.full = (&S.nz)[axis];
+                    L.T = pair_T(L.len, radius, axis);
+                    const size_t lds = (size_t)(L.len + 2 * radius) * (L.T + 1) * 8;
+                    const long long nb = (L.n_lines + L.T - 1) / L.T;
+                    hipLaunchKernelGGL(gauss1d_pair_kernel, dim3((unsigned)nb), dim3(256), lds, st, P, L, radius, fw, axis == 2 ? 1 : 0);
+                    ina = P.oa; inb = P.ob;
+                }
+            }
+        }
+        MVS_HIP_TRY(c, hipGetLastError());
+        for (int a = 0; a < 4; ++a)
+            if (side_used[a]) {
+                MVS_HIP_TRY(c, hipEventRecord(c->ev_join[a], c->aux_stream[a]));
+                MVS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join[a], 0));
+            }
+    }
+    for (int v = 0; v < n_views && !paired; ++v) {
         const CbBox& B = boxes[v];
         const long long bn = (long long)B.n[0] * B.n[1] * B.n[2];
         if (bn == 0) continue;

@@ -77,6 +77,7 @@ struct MvsContext {
     uint64_t crop_stats_gen = 0;  // mbox_gen at the time the partials were parked: a reallocated mailbox invalidates them
     void* crop_stats_base = nullptr;
     bool crop_stats_done[2] = {false, false};
+    bool cb_unpaired = false;     // test switch: content-based weights through the separate value / mask line passes of rounds 1-3
     bool fft_no_line = false;     // test switch: lengths of the whole-line DFT kernel run on the Bluestein kernels instead
     bool no_regions = false;      // test switch: skip the region kernel (use the column kernel)
     bool rows_v1 = false;         // opt-in: direct-load row kernels (mvs_fuse_rows.hip) for every dtype (default: float tiles only)
@@ -100,6 +101,10 @@ void mvs_pinned_mark(MvsContext* c, int slot);                    // call after 
 // nbytes of the context's mailbox: *host for the CPU, *dev for kernels (same memory).  Valid until the next call that asks for more;
 // the caller waits for the stream before it reads.  Returns an MVS_* code.
 int mvs_mailbox(MvsContext* c, size_t nbytes, void** host, void** dev);
+// the context's four low-priority side streams + fork / join events (created at first use)
+int mvs_ensure_aux_streams(MvsContext* c);
+// stream-ordered copy of a few KB out of the mailbox (device-visible pointer) by a kernel, not by the copy engine; 16-byte granularity
+int mvs_upload_from_mapped(MvsContext* c, void* dst_dev, const void* src_mapped_dev, size_t nbytes);
 
 // the code of the failure mvs_scratch / mvs_pinned recorded when they returned NULL (MVS_ERR_OUT_OF_MEMORY or MVS_ERR_HIP)
 static inline int mvs_alloc_failed(const MvsContext* c) { return c->last_code ? c->last_code : MVS_ERR_HIP; }

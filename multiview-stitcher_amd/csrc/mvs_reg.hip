@@ -773,9 +773,13 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
         float2* mres = (float2*)((char*)mb_dev + mb_res + mb_res_stride * (size_t)inorm);     // the last stage writes host memory
         if (ndim == 3) o3 = mres; else o2 = mres;
         // one upload for all normalisations when their launches follow the last one (same strides in the mailbox and on the device)
-        if (!fuse_xp) MVS_HIP_TRY(c, hipMemcpyAsync(dk, hk, kbytes, hipMemcpyHostToDevice, c->stream));
+        // (copied by a kernel out of the mapped mailbox: a DMA upload would queue behind any tile upload in flight)
+        const char* hk_dev = (const char*)mb_dev + mb_k + mb_kbytes * (size_t)inorm;
+        int rcu = MVS_OK;
+        if (!fuse_xp) rcu = mvs_upload_from_mapped(c, dk, hk_dev, (kbytes + 15) / 16 * 16);
         else if (inorm == n_norm - 1)
-            MVS_HIP_TRY(c, hipMemcpyAsync(up_base, (char*)mb_host + mb_k, (size_t)inorm * up_kbytes + kbytes, hipMemcpyHostToDevice, c->stream));
+            rcu = mvs_upload_from_mapped(c, up_base, (const char*)mb_dev + mb_k, ((size_t)inorm * up_kbytes + kbytes + 15) / 16 * 16);
+        if (rcu) return rcu;
         NormState& st = state[inorm];
         st.P = P; st.dk = dk; st.o1 = o1; st.o2 = o2; st.o3 = o3;
         for (int k = 0; k < 3; ++k) st.koff[k] = koff[k];

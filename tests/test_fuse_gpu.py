@@ -262,6 +262,36 @@ def test_fuse_content_based_default_sigmas_3d(hip_device, dtype, kernel_path):
         _assert_cb_float_close(got, want)
 
 
+@pytest.mark.parametrize("ndim,dtype", [(3, np.uint16), (3, np.float32), (2, np.float32)])
+def test_content_based_paired_passes_equal_separate_passes(hip_device, ndim, dtype, kernel_path):
+    """Round 4: value and mask lines of every NaN-aware Gaussian are filtered in one launch (gauss1d_pair_kernel), the
+    preparation and the two quotients fused into the first / last pass, the views' chains side by side on the context's side
+    streams.  Same arithmetic per quantity -> bit for bit the result of the separate passes (option ``cb_unpaired``)."""
+    from multiview_stitcher_amd import _lib, fusion, spatial_image_utils as si
+
+    if kernel_path != "fast":
+        pytest.skip("content-based weights have a single implementation")
+    if ndim == 3:
+        sims, params = _grid_case(3, dtype, (2, 2, 2), (70, 60, 66), (30, 24, 26), True, seed=21)
+        sig, halo = {"sigma_1": 5.0, "sigma_2": 11.0}, 22
+    else:
+        sims, params = _grid_case(2, dtype, (2, 2), (120, 140), (40, 44), True, seed=22)
+        sig, halo = {"sigma_1": 2.0, "sigma_2": 4.0}, 8
+    sdims = si.get_spatial_dims_from_sim(sims[0])
+    views, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(ndim))
+    kw = dict(weights_func=fusion.content_based, weights_func_kwargs=sig, full_view_bbs=[bb_to_dicts(b, sdims) for b in bbs],
+              trim_overlap_in_pixels=halo)
+    got = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw)
+    _lib.set_option("cb_unpaired", 1)
+    try:
+        ref = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw)
+    finally:
+        _lib.set_option("cb_unpaired", 0)
+    np.testing.assert_array_equal(got, ref)
+    assert len(sims) == 2 ** ndim and np.isfinite(got.astype(np.float64)).all()
+
+
 def test_fuse_content_based_chunked_workflow(hip_device, kernel_path):
     """fusion.fuse(weights_func=content_based): halo = 2*sigma_2 from required_overlap, chunks trimmed (T/test_fusion.py:845-896)."""
     from multiview_stitcher_amd import fusion, sample_data
