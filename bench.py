@@ -360,12 +360,12 @@ def csrc_digest():
 
 def fuse_traffic_bytes(grid, tile):
     """(HBM bytes per fuse launch, where the figure comes from).  The bytes are PMC counters (FETCH_SIZE x2 per the
-    calibration + WRITE_SIZE, separate rocprofv3 --pmc passes: tools/profile_round3.sh) committed under profiles/ together
+    calibration + WRITE_SIZE, separate rocprofv3 --pmc passes: tools/profile_round4.sh) committed under profiles/ together
     with the digest of the kernel sources they were measured with; when the sources have changed since, or the workload is
     another one, the figure would be stale and None is returned instead."""
     if not (list(grid) == [4, 4, 4] and list(tile) == [512, 512, 512]):
         return None, "no PMC pass for this workload"
-    for name in ("round3_fuse_traffic.json",):
+    for name in ("round4_fuse_traffic.json", "round3_fuse_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
@@ -426,7 +426,7 @@ def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
             kw = dict(register_kwargs)
             tk, rb, ot = kw.pop("transform_key"), kw.pop("registration_binning", None), kw.pop("overlap_tolerance", 0.0)
             prf, prk = kw.pop("pairwise_reg_func"), kw.pop("pairwise_reg_func_kwargs", None)
-            wave = max(1, len(order) // 16)      # (short waves: what runs after the last tile has arrived is pure tail)
+            wave = max(1, len(order) // 8)
             for a in range(0, len(order), wave):
                 ks = order[a:a + wave]
                 events[max(max(edges[k]) for k in ks)].synchronize()      # both tiles of every pair of this wave are resident

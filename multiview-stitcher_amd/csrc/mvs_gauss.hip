@@ -248,40 +248,82 @@ __device__ __forceinline__ float cb_valid_value(const PairIO& P, long long i) { 
     return x;
 }
 
+template <int SRC, int DST>
 __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines L, int radius, const double* __restrict__ fw, int pos_fastest) {
     extern __shared__ float sl[];
-    const int T = L.T, TP = T + 1, len = L.len;
+    // T is a power of two (host: pair_T), so (line, position) come out of shifts and masks; the lines' first elements are worked
+    // out once per workgroup (one 64-bit division per LINE instead of two per staged and stored SAMPLE: the index arithmetic
+    // was most of this kernel's time -- 0.4 TB/s before)
+    const int T = L.T, TP = T + 1, len = L.len, lt = 31 - __clz(T);
     const int span = len + 2 * radius;
     float* sq[2] = {sl, sl + (size_t)span * TP};
+    __shared__ long long lbase[32];
     const long long l0 = (long long)blockIdx.x * T;
     const int nl = (int)min((long long)T, L.n_lines - l0);
-    const int total = T * len;
-    auto gindex = [&](int line, int pos) { const long long l = l0 + line; return (l / L.inner) * L.outer_stride + (l % L.inner) + (long long)pos * L.stride; };
-    auto load2 = [&](long long i, float& v, float& m) {
-        if (P.src == SRC_AB) { v = P.a[i]; m = P.b[i]; }
+    if ((int)threadIdx.x < T) {
+        const long long l = min(l0 + threadIdx.x, L.n_lines - 1);
+        lbase[threadIdx.x] = (l / L.inner) * L.outer_stride + (l % L.inner);
+    }
+    __syncthreads();
+    // raw loads first (r0, r1[, r2]), interpretation afterwards: a batch of samples is requested without any control flow in between
+    auto load_raw = [&](long long i, float& r0, float& r1, float& r2) {
+        if constexpr (SRC == SRC_AB) { r0 = P.a[i]; r1 = P.b[i]; r2 = 0.f; }
+        else if constexpr (SRC == SRC_PREP) { r0 = P.im[i]; r1 = P.bw[i]; r2 = 0.f; }
+        else { r0 = P.im[i]; r1 = P.bw[i]; r2 = P.a[i]; }
+    };
+    auto interpret = [&](float r0, float r1, float r2, float& v, float& m) {
+        if constexpr (SRC == SRC_AB) { v = r0; m = r1; }
         else {
-            const float x = cb_valid_value(P, i);
-            const bool ok = (x == x);
+            const bool ok = (r0 == r0) && !(r1 < 1e-7f);      // A = the view with NaN where bw < 1e-7
             m = ok ? 1.f : 0.f;
-            v = (P.src == SRC_PREP) ? (ok ? x : 0.f) : P.a[i];
+            v = (SRC == SRC_PREP) ? (ok ? r0 : 0.f) : r2;
         }
     };
     // ---- stage the lines of both quantities; note per quantity whether every sample has the bits of the first one ----
     float first[2];
-    load2(gindex(0, 0), first[0], first[1]);
+    {
+        float r0, r1, r2;
+        load_raw(lbase[0], r0, r1, r2);
+        interpret(r0, r1, r2, first[0], first[1]);
+    }
     int same0 = 1, same1 = 1;
-    for (int idx = threadIdx.x; idx < total; idx += blockDim.x) {
-        int line, pos;
-        if (pos_fastest) { line = idx / len; pos = idx - line * len; }
-        else { pos = idx / T; line = idx - pos * T; }
-        float v = 0.f, m = 0.f;
-        if (line < nl) {
-            load2(gindex(line, pos), v, m);
-            same0 &= (__float_as_uint(v) == __float_as_uint(first[0])) ? 1 : 0;
-            same1 &= (__float_as_uint(m) == __float_as_uint(first[1])) ? 1 : 0;
+    // A workgroup is a short dependent chain (stage -> filter -> store) and only a few of them fit a CU, so the staging loop
+    // must not pay one memory round trip per sample: the loads of NB samples are issued back to back before the first of them
+    // is written to LDS (one round trip per batch: the pass was bound by exactly this latency, 190 us for 270 MB).
+    constexpr int NB = 8;
+    const int per_line = pos_fastest ? (int)blockDim.x : ((int)blockDim.x >> lt);      // positions a sweep of the workgroup covers per line
+    const int my_line = pos_fastest ? 0 : (int)(threadIdx.x & (T - 1));
+    const int my_pos0 = pos_fastest ? (int)threadIdx.x : (int)(threadIdx.x >> lt);
+    const int sweeps = (len + per_line - 1) / per_line;
+    const int n_my = pos_fastest ? sweeps * T : sweeps;             // samples of this thread: (sweep[, line]) pairs
+    for (int b0 = 0; b0 < n_my; b0 += NB) {
+        float q0[NB], q1[NB], q2[NB];
+        int bl[NB], bp[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int e = b0 + u;
+            // pos_fastest: e = line * sweeps + sweep (threads run along a line); else e = sweep (threads run across the lines)
+            const int line = pos_fastest ? e / sweeps : my_line;
+            const int sweep = pos_fastest ? e - line * sweeps : e;
+            const int pos = my_pos0 + sweep * per_line;
+            bl[u] = line; bp[u] = pos;
+            // (clamped address: the load itself is unconditional, what it returns is discarded below when out of range)
+            load_raw(lbase[min(line, nl - 1)] + (long long)min(pos, len - 1) * L.stride, q0[u], q1[u], q2[u]);
         }
-        sq[0][(pos + radius) * TP + line] = v;
-        sq[1][(pos + radius) * TP + line] = m;
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int e = b0 + u;
+            if (e < n_my && bp[u] < len && bl[u] < T) {
+                float v = 0.f, m = 0.f;
+                if (bl[u] < nl) {
+                    interpret(q0[u], q1[u], q2[u], v, m);
+                    same0 &= (__float_as_uint(v) == __float_as_uint(first[0])) ? 1 : 0;
+                    same1 &= (__float_as_uint(m) == __float_as_uint(first[1])) ? 1 : 0;
+                }
+                sq[0][(bp[u] + radius) * TP + bl[u]] = v;
+                sq[1][(bp[u] + radius) * TP + bl[u]] = m;
+            }
+        }
     }
     const bool box_is_line = (L.b0 == 0 && L.len == L.full);
     const int flags = __syncthreads_or((same0 ? 0 : 1) | (same1 ? 0 : 2));
@@ -298,7 +340,7 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
         }
     // ---- halo of the quantities that are filtered: chunk line reflected at the chunk's ends, zeros where that leaves the box ----
     for (int idx = threadIdx.x; idx < 2 * radius * T; idx += blockDim.x) {
-        const int h = idx / T, line = idx - h * T;
+        const int h = idx >> lt, line = idx & (T - 1);
         const int p = (h < radius) ? (h - radius) : (len + h - radius);
         const int q = box_reflect(p, L.b0, len, L.full);
 #pragma unroll
@@ -310,7 +352,7 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
     const int nblk = (len + K - 1) / K;
     const int qmax = len - 1 + 2 * radius;
     for (int idx = threadIdx.x; idx < T * nblk; idx += blockDim.x) {
-        const int blk = idx / T, line = idx - blk * T;
+        const int blk = idx >> lt, line = idx & (T - 1);
         if (line >= nl) continue;
         const int p0 = blk * K;
         float res[2][K];
@@ -344,8 +386,8 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
 #pragma unroll
             for (int k = 0; k < K; ++k) res[q][k] = (float)acc[k];
         }
-        const long long obase = gindex(line, p0);
-        if (P.dst == DST_AB) {
+        const long long obase = lbase[line] + (long long)p0 * L.stride;
+        if constexpr (DST == DST_AB) {
             if (L.stride == 1 && p0 + K <= len && ((obase & 3) == 0)) {
                 float4* o4 = reinterpret_cast<float4*>(P.oa + obase);
                 o4[0] = make_float4(res[0][0], res[0][1], res[0][2], res[0][3]);
@@ -366,7 +408,7 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
                 const long long i = obase + (long long)k * L.stride;
                 const float a = cb_valid_value(P, i);
                 float o;
-                if (P.dst == DST_SQ) {
+                if constexpr (DST == DST_SQ) {
                     o = 0.f;
                     if (a == a) {
                         const float d = a - res[0][k] / res[1][k];
@@ -625,7 +667,7 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
             const int v = order[oi];
             const CbBox& B = boxes[v];
             hipStream_t st = c->stream;
-            if (oi > 0) {
+            if (oi > 0 && !c->serial_classes) {      // ("serial_classes": everything on the context's stream, for per-kernel timings)
                 const int a = (int)((oi - 1) & 3);
                 st = c->aux_stream[a];
                 if (!side_used[a]) { MVS_HIP_TRY(c, hipStreamWaitEvent(st, c->ev_fork, 0)); side_used[a] = true; }
@@ -659,7 +701,17 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
                     L.T = pair_T(L.len, radius, axis);
                     const size_t lds = (size_t)(L.len + 2 * radius) * (L.T + 1) * 8;
                     const long long nb = (L.n_lines + L.T - 1) / L.T;
-                    hipLaunchKernelGGL(gauss1d_pair_kernel, dim3((unsigned)nb), dim3(256), lds, st, P, L, radius, fw, axis == 2 ? 1 : 0);
+                    const dim3 g((unsigned)nb), b(256);
+                    const int pf = axis == 2 ? 1 : 0;
+#define MVS_PAIR(S_, D_) hipLaunchKernelGGL((gauss1d_pair_kernel<S_, D_>), g, b, lds, st, P, L, radius, fw, pf)
+                    if (P.src == SRC_PREP && P.dst == DST_AB) MVS_PAIR(SRC_PREP, DST_AB);
+                    else if (P.src == SRC_PREP && P.dst == DST_SQ) MVS_PAIR(SRC_PREP, DST_SQ);
+                    else if (P.src == SRC_VMASK && P.dst == DST_AB) MVS_PAIR(SRC_VMASK, DST_AB);
+                    else if (P.src == SRC_VMASK && P.dst == DST_F) MVS_PAIR(SRC_VMASK, DST_F);
+                    else if (P.src == SRC_AB && P.dst == DST_AB) MVS_PAIR(SRC_AB, DST_AB);
+                    else if (P.src == SRC_AB && P.dst == DST_SQ) MVS_PAIR(SRC_AB, DST_SQ);
+                    else MVS_PAIR(SRC_AB, DST_F);
+#undef MVS_PAIR
                     ina = P.oa; inb = P.ob;
                 }
             }

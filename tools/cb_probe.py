@@ -11,6 +11,8 @@ grid, tile = np.array([2, 2, 2]), np.array([256, 256, 256])
 overlap = np.round(tile * 0.2).astype(int)
 tiles, jit, org = bench.make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=5, max_jitter=0)
 sims = bench.build_sims(tiles, org, 0)
+_lib.set_option("serial_classes", int(os.environ.get("MVS_SERIAL", "0")))      # 1: the views' filter chains one after the other (per-kernel timings)
+_lib.set_option("cb_unpaired", int(os.environ.get("MVS_CB_UNPAIRED", "0")))
 torch.cuda.synchronize()   # the tiles are produced on torch's stream, the library runs on its own
 for rep in range(3):
     t0 = time.perf_counter()
