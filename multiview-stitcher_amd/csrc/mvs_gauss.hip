@@ -326,10 +326,12 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
         }
     }
     const bool box_is_line = (L.b0 == 0 && L.len == L.full);
-    const int flags = __syncthreads_or((same0 ? 0 : 1) | (same1 ? 0 : 2));
+    // (__syncthreads_or reduces the TRUTH of its argument, not its bits: one reduction per quantity)
+    const int varies0 = __syncthreads_or(same0 ? 0 : 1);
+    const int varies1 = __syncthreads_or(same1 ? 0 : 1);
     bool cst[2];
-    cst[0] = !(flags & 1) && (box_is_line || __float_as_uint(first[0]) == 0u);
-    cst[1] = !(flags & 2) && (box_is_line || __float_as_uint(first[1]) == 0u);
+    cst[0] = !varies0 && (box_is_line || __float_as_uint(first[0]) == 0u);
+    cst[1] = !varies1 && (box_is_line || __float_as_uint(first[1]) == 0u);
     float cval[2] = {0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 2; ++q)

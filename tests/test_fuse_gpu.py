@@ -262,7 +262,7 @@ def test_fuse_content_based_default_sigmas_3d(hip_device, dtype, kernel_path):
         _assert_cb_float_close(got, want)
 
 
-@pytest.mark.parametrize("ndim,dtype", [(3, np.uint16), (3, np.float32), (2, np.float32)])
+@pytest.mark.parametrize("ndim,dtype", [(3, np.uint16), (3, np.float32), (2, np.float32), (-3, np.uint16)])
 def test_content_based_paired_passes_equal_separate_passes(hip_device, ndim, dtype, kernel_path):
     """Round 4: value and mask lines of every NaN-aware Gaussian are filtered in one launch (gauss1d_pair_kernel), the
     preparation and the two quotients fused into the first / last pass, the views' chains side by side on the context's side
@@ -271,7 +271,13 @@ def test_content_based_paired_passes_equal_separate_passes(hip_device, ndim, dty
 
     if kernel_path != "fast":
         pytest.skip("content-based weights have a single implementation")
-    if ndim == 3:
+    if ndim == -3:
+        # long lines along z, boxes that start inside the chunk on every axis (a view whose first staged sample is invalid while
+        # the rest of the tile is not: the constant-tile short cut must decide per quantity)
+        ndim = 3
+        sims, params = _grid_case(3, dtype, (2, 2, 2), (300, 60, 70), (80, 20, 24), True, seed=21)
+        sig, halo = {"sigma_1": 5.0, "sigma_2": 11.0}, 22
+    elif ndim == 3:
         sims, params = _grid_case(3, dtype, (2, 2, 2), (70, 60, 66), (30, 24, 26), True, seed=21)
         sig, halo = {"sigma_1": 5.0, "sigma_2": 11.0}, 22
     else:
