@@ -288,6 +288,10 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         c->materialize_shifts = value != 0;
         return MVS_OK;
     }
+    if (!strcmp(key, "cb_nosplit")) {
+        c->cb_nosplit = value != 0;
+        return MVS_OK;
+    }
     if (!strcmp(key, "cb_unpaired")) {
         c->cb_unpaired = value != 0;
         return MVS_OK;

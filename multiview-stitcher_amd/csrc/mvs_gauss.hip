@@ -248,15 +248,20 @@ __device__ __forceinline__ float cb_valid_value(const PairIO& P, long long i) { 
     return x;
 }
 
-template <int SRC, int DST>
+// SPLIT: the passes that are not the last of their filter need no coupling between the two quantities (DST_AB), so a workgroup
+// takes ONE of them (blockIdx.y: 0 value, 1 mask) and stages twice as many lines in the same LDS (T = 32: lines along y / z then
+// move in 128-byte pieces instead of 64-byte ones); still one launch per pass.
+template <int SRC, int DST, bool SPLIT>
 __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines L, int radius, const double* __restrict__ fw, int pos_fastest) {
+    static_assert(!SPLIT || DST == DST_AB, "split passes store both quantities as they are");
     extern __shared__ float sl[];
-    // T is a power of two (host: pair_T), so (line, position) come out of shifts and masks; the lines' first elements are worked
-    // out once per workgroup (one 64-bit division per LINE instead of two per staged and stored SAMPLE: the index arithmetic
-    // was most of this kernel's time -- 0.4 TB/s before)
+    // T is a power of two (host: pair_T / split_T), so (line, position) come out of shifts and masks; the lines' first elements
+    // are worked out once per workgroup (one 64-bit division per LINE instead of two per staged and stored SAMPLE)
+    constexpr int NQ = SPLIT ? 1 : 2;
+    const int qs = SPLIT ? (int)blockIdx.y : 0;       // SPLIT: the quantity of this workgroup
     const int T = L.T, TP = T + 1, len = L.len, lt = 31 - __clz(T);
     const int span = len + 2 * radius;
-    float* sq[2] = {sl, sl + (size_t)span * TP};
+    float* sq[2] = {sl, sl + (SPLIT ? 0 : (size_t)span * TP)};
     __shared__ long long lbase[32];
     const long long l0 = (long long)blockIdx.x * T;
     const int nl = (int)min((long long)T, L.n_lines - l0);
@@ -265,21 +270,28 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
         lbase[threadIdx.x] = (l / L.inner) * L.outer_stride + (l % L.inner);
     }
     __syncthreads();
-    // raw loads first (r0, r1[, r2]), interpretation afterwards: a batch of samples is requested without any control flow in between
+    // raw loads first, interpretation afterwards: a batch of samples is requested without any control flow in between.
+    // SPLIT: two loads from X / Y -- the array itself twice where the quantity is stored as it is (value of SRC_AB / SRC_VMASK,
+    // mask of SRC_AB), the view and its blending weight where it is derived from them.
+    const bool direct = SPLIT && (SRC == SRC_AB || (SRC == SRC_VMASK && qs == 0));
+    const float* X = !SPLIT ? nullptr : (SRC == SRC_AB ? (qs ? P.b : P.a) : (direct ? P.a : P.im));
+    const float* Y = !SPLIT ? nullptr : (direct ? X : P.bw);
     auto load_raw = [&](long long i, float& r0, float& r1, float& r2) {
-        if constexpr (SRC == SRC_AB) { r0 = P.a[i]; r1 = P.b[i]; r2 = 0.f; }
+        if constexpr (SPLIT) { r0 = X[i]; r1 = Y[i]; r2 = 0.f; }
+        else if constexpr (SRC == SRC_AB) { r0 = P.a[i]; r1 = P.b[i]; r2 = 0.f; }
         else if constexpr (SRC == SRC_PREP) { r0 = P.im[i]; r1 = P.bw[i]; r2 = 0.f; }
         else { r0 = P.im[i]; r1 = P.bw[i]; r2 = P.a[i]; }
     };
-    auto interpret = [&](float r0, float r1, float r2, float& v, float& m) {
+    auto interpret = [&](float r0, float r1, float r2, float& v, float& m) {      // SPLIT: the workgroup's quantity comes back in v
         if constexpr (SRC == SRC_AB) { v = r0; m = r1; }
         else {
             const bool ok = (r0 == r0) && !(r1 < 1e-7f);      // A = the view with NaN where bw < 1e-7
             m = ok ? 1.f : 0.f;
             v = (SRC == SRC_PREP) ? (ok ? r0 : 0.f) : r2;
+            if constexpr (SPLIT) v = direct ? r0 : (qs ? m : v);
         }
     };
-    // ---- stage the lines of both quantities; note per quantity whether every sample has the bits of the first one ----
+    // ---- stage the lines; note per quantity whether every sample has the bits of the first one ----
     float first[2];
     {
         float r0, r1, r2;
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
     int same0 = 1, same1 = 1;
     // A workgroup is a short dependent chain (stage -> filter -> store) and only a few of them fit a CU, so the staging loop
     // must not pay one memory round trip per sample: the loads of NB samples are issued back to back before the first of them
-    // is written to LDS (one round trip per batch: the pass was bound by exactly this latency, 190 us for 270 MB).
+    // is written to LDS.
     constexpr int NB = 8;
     const int per_line = pos_fastest ? (int)blockDim.x : ((int)blockDim.x >> lt);      // positions a sweep of the workgroup covers per line
     const int my_line = pos_fastest ? 0 : (int)(threadIdx.x & (T - 1));
@@ -318,23 +330,23 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
                 if (bl[u] < nl) {
                     interpret(q0[u], q1[u], q2[u], v, m);
                     same0 &= (__float_as_uint(v) == __float_as_uint(first[0])) ? 1 : 0;
-                    same1 &= (__float_as_uint(m) == __float_as_uint(first[1])) ? 1 : 0;
+                    if (!SPLIT) same1 &= (__float_as_uint(m) == __float_as_uint(first[1])) ? 1 : 0;
                 }
                 sq[0][(bp[u] + radius) * TP + bl[u]] = v;
-                sq[1][(bp[u] + radius) * TP + bl[u]] = m;
+                if (!SPLIT) sq[1][(bp[u] + radius) * TP + bl[u]] = m;
             }
         }
     }
     const bool box_is_line = (L.b0 == 0 && L.len == L.full);
     // (__syncthreads_or reduces the TRUTH of its argument, not its bits: one reduction per quantity)
     const int varies0 = __syncthreads_or(same0 ? 0 : 1);
-    const int varies1 = __syncthreads_or(same1 ? 0 : 1);
+    const int varies1 = SPLIT ? 1 : __syncthreads_or(same1 ? 0 : 1);
     bool cst[2];
     cst[0] = !varies0 && (box_is_line || __float_as_uint(first[0]) == 0u);
-    cst[1] = !varies1 && (box_is_line || __float_as_uint(first[1]) == 0u);
+    cst[1] = !SPLIT && !varies1 && (box_is_line || __float_as_uint(first[1]) == 0u);
     float cval[2] = {0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < NQ; ++q)
         if (cst[q]) {
             double acc = (double)first[q] * fw[radius];
             for (int j = radius; j >= 1; --j) acc = fma((double)first[q] + (double)first[q], fw[radius - j], acc);
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
         const int p = (h < radius) ? (h - radius) : (len + h - radius);
         const int q = box_reflect(p, L.b0, len, L.full);
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < NQ; ++k)
             if (!cst[k]) sq[k][(p + radius) * TP + line] = (q >= 0) ? sq[k][(q + radius) * TP + line] : 0.f;
     }
     __syncthreads();
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
         const int p0 = blk * K;
         float res[2][K];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             if (cst[q]) {
 #pragma unroll
                 for (int k = 0; k < K; ++k) res[q][k] = cval[q];
@@ -389,7 +401,18 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
             for (int k = 0; k < K; ++k) res[q][k] = (float)acc[k];
         }
         const long long obase = lbase[line] + (long long)p0 * L.stride;
-        if constexpr (DST == DST_AB) {
+        if constexpr (SPLIT) {
+            float* o = qs ? P.ob : P.oa;
+            if (L.stride == 1 && p0 + K <= len && ((obase & 3) == 0)) {
+                float4* o4 = reinterpret_cast<float4*>(o + obase);
+                o4[0] = make_float4(res[0][0], res[0][1], res[0][2], res[0][3]);
+                o4[1] = make_float4(res[0][4], res[0][5], res[0][6], res[0][7]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    if (p0 + k < len) o[obase + (long long)k * L.stride] = res[0][k];
+            }
+        } else if constexpr (DST == DST_AB) {
             if (L.stride == 1 && p0 + K <= len && ((obase & 3) == 0)) {
                 float4* o4 = reinterpret_cast<float4*>(P.oa + obase);
                 o4[0] = make_float4(res[0][0], res[0][1], res[0][2], res[0][3]);
@@ -580,6 +603,12 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
         if (span * (T + 1) * 8 > 60 * 1024 || (axis != 2 && T < 4)) return 0;
         return T;
     };
+    auto split_T = [&](int len, int radius) {         // lines per workgroup of a split pass (one quantity in LDS), 0: does not fit
+        const size_t span = (size_t)len + 2 * (size_t)radius;
+        int T = 32;      // (8 / 16 / 32 measured: 30.9 / 28.5 / 28.1 ms per probe call)
+        while (T > 1 && span * (T + 1) * 4 > 60 * 1024) T >>= 1;
+        return (span * (T + 1) * 4 > 60 * 1024 || T < 8) ? 0 : T;
+    };
     bool paired = !c->cb_unpaired;
     for (int i = 0; i < n_views && paired; ++i)
         for (int axis = 3 - ndim; axis < 3; ++axis)
@@ -700,19 +729,27 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
                     else { L.len = B.n[0]; L.stride = ny * nx; L.n_lines = ny * nx; L.inner = ny * nx; L.outer_stride = 0; }
                     L.b0 = B.lo[axis];
                     L.full = (&S.nz)[axis];
-                    L.T = pair_T(L.len, radius, axis);
-                    const size_t lds = (size_t)(L.len + 2 * radius) * (L.T + 1) * 8;
+                    // passes along y / z that only hand both quantities on: one quantity per workgroup, twice the lines (128-byte pieces)
+                    const int Ts = (P.dst == DST_AB && axis != 2 && !c->cb_nosplit) ? split_T(L.len, radius) : 0;
+                    const bool split = Ts > 0;
+                    L.T = split ? Ts : pair_T(L.len, radius, axis);
+                    const size_t lds = (size_t)(L.len + 2 * radius) * (L.T + 1) * (split ? 4 : 8);
                     const long long nb = (L.n_lines + L.T - 1) / L.T;
-                    const dim3 g((unsigned)nb), b(256);
+                    const dim3 g((unsigned)nb, split ? 2 : 1), b(256);
                     const int pf = axis == 2 ? 1 : 0;
-#define MVS_PAIR(S_, D_) hipLaunchKernelGGL((gauss1d_pair_kernel<S_, D_>), g, b, lds, st, P, L, radius, fw, pf)
-                    if (P.src == SRC_PREP && P.dst == DST_AB) MVS_PAIR(SRC_PREP, DST_AB);
-                    else if (P.src == SRC_PREP && P.dst == DST_SQ) MVS_PAIR(SRC_PREP, DST_SQ);
-                    else if (P.src == SRC_VMASK && P.dst == DST_AB) MVS_PAIR(SRC_VMASK, DST_AB);
-                    else if (P.src == SRC_VMASK && P.dst == DST_F) MVS_PAIR(SRC_VMASK, DST_F);
-                    else if (P.src == SRC_AB && P.dst == DST_AB) MVS_PAIR(SRC_AB, DST_AB);
-                    else if (P.src == SRC_AB && P.dst == DST_SQ) MVS_PAIR(SRC_AB, DST_SQ);
-                    else MVS_PAIR(SRC_AB, DST_F);
+#define MVS_PAIR(S_, D_, SP_) hipLaunchKernelGGL((gauss1d_pair_kernel<S_, D_, SP_>), g, b, lds, st, P, L, radius, fw, pf)
+                    if (split) {
+                        if (P.src == SRC_PREP) MVS_PAIR(SRC_PREP, DST_AB, true);
+                        else if (P.src == SRC_VMASK) MVS_PAIR(SRC_VMASK, DST_AB, true);
+                        else MVS_PAIR(SRC_AB, DST_AB, true);
+                    }
+                    else if (P.src == SRC_PREP && P.dst == DST_AB) MVS_PAIR(SRC_PREP, DST_AB, false);
+                    else if (P.src == SRC_PREP && P.dst == DST_SQ) MVS_PAIR(SRC_PREP, DST_SQ, false);
+                    else if (P.src == SRC_VMASK && P.dst == DST_AB) MVS_PAIR(SRC_VMASK, DST_AB, false);
+                    else if (P.src == SRC_VMASK && P.dst == DST_F) MVS_PAIR(SRC_VMASK, DST_F, false);
+                    else if (P.src == SRC_AB && P.dst == DST_AB) MVS_PAIR(SRC_AB, DST_AB, false);
+                    else if (P.src == SRC_AB && P.dst == DST_SQ) MVS_PAIR(SRC_AB, DST_SQ, false);
+                    else MVS_PAIR(SRC_AB, DST_F, false);
 #undef MVS_PAIR
                     ina = P.oa; inb = P.ob;
                 }

@@ -77,6 +77,7 @@ struct MvsContext {
     uint64_t crop_stats_gen = 0;  // mbox_gen at the time the partials were parked: a reallocated mailbox invalidates them
     void* crop_stats_base = nullptr;
     bool crop_stats_done[2] = {false, false};
+    bool cb_nosplit = false;      // test switch: the y / z passes of the paired path keep both quantities in one workgroup
     bool cb_unpaired = false;     // test switch: content-based weights through the separate value / mask line passes of rounds 1-3
     bool fft_no_line = false;     // test switch: lengths of the whole-line DFT kernel run on the Bluestein kernels instead
     bool no_regions = false;      // test switch: skip the region kernel (use the column kernel)

@@ -296,6 +296,13 @@ def test_content_based_paired_passes_equal_separate_passes(hip_device, ndim, dty
         _lib.set_option("cb_unpaired", 0)
     np.testing.assert_array_equal(got, ref)
     assert len(sims) == 2 ** ndim and np.isfinite(got.astype(np.float64)).all()
+    # ... and so are the paired y / z passes that keep both quantities in one workgroup (the default splits them: one quantity
+    # per workgroup, twice the lines)
+    _lib.set_option("cb_nosplit", 1)
+    try:
+        np.testing.assert_array_equal(fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw), ref)
+    finally:
+        _lib.set_option("cb_nosplit", 0)
 
 
 def test_fuse_content_based_chunked_workflow(hip_device, kernel_path):

@@ -13,6 +13,7 @@ tiles, jit, org = bench.make_mosaic_on_device(torch, dev, grid, tile, overlap, s
 sims = bench.build_sims(tiles, org, 0)
 _lib.set_option("serial_classes", int(os.environ.get("MVS_SERIAL", "0")))      # 1: the views' filter chains one after the other (per-kernel timings)
 _lib.set_option("cb_unpaired", int(os.environ.get("MVS_CB_UNPAIRED", "0")))
+_lib.set_option("cb_nosplit", int(os.environ.get("MVS_CB_NOSPLIT", "0")))
 torch.cuda.synchronize()   # the tiles are produced on torch's stream, the library runs on its own
 for rep in range(3):
     t0 = time.perf_counter()
