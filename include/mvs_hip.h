@@ -123,7 +123,11 @@ int mvs_synchronize(int device);
  * image's window means) go through the separate z and y / x launches instead of the fused z walks (equal to 1e-9).
  * "reg_unfused" = 1: the phase correlation runs its separate launches (pack, cross power, stored correlation + peak search,
  * one refinement stage per normalisation, a min / max pass over the crops) instead of the fused passes at the ends of the two
- * transforms (bit for bit the same peaks and shifts; tests compare). */
+ * transforms (bit for bit the same peaks and shifts; tests compare).  "fft_no_line" = 1: axes of 17-64 samples with prime factors
+ * <= 19 run on the Bluestein kernels instead of the whole-line register transforms (mvs_dft_small.h; equal to float32 rounding).
+ * "cb_unpaired" = 1: content-based weights filter value and mask lines in separate launches with separate preparation / quotient
+ * kernels (rounds 1-3) instead of gauss1d_pair_kernel; "cb_nosplit" = 1: the paired path keeps both quantities in one workgroup
+ * on every pass (all three bit for bit equal; tests compare). */
 int mvs_set_option(int device, const char* key, int64_t value);
 /* Measurement counters of one context (bench.py): "reg_alg_bytes" = algorithmic HBM bytes of the pairwise registrations
  * since the last reset (28 n per phase-correlation variant + 20 n per scored candidate + 64 n for the rank correlation, n = crop

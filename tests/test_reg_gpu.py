@@ -224,6 +224,49 @@ def test_fft_c2c_matches_numpy(hip_device, shape, inverse):
     assert np.abs(got - want).max() <= 3e-6 * scale * np.log2(a.size)
 
 
+def _line_lengths():
+    """The lengths the whole-line register DFT is built for: non-powers of two from 17 to 64 with prime factors <= 19."""
+    out = []
+    for n in range(17, 65):
+        if n & (n - 1) == 0:
+            continue
+        m = n
+        for p in (2, 3, 5, 7, 11, 13, 17, 19):
+            while m % p == 0:
+                m //= p
+        if m == 1:
+            out.append(n)
+    return out
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_whole_line_dft_every_length_every_axis(hip_device, inverse):
+    """csrc/mvs_dft_small.h on the device: every supported length (33 of them: prime-factor splits such as 51 = 3 x 17,
+    Cooley-Tukey ones such as 49 = 7 x 7 and 27 = 3 x 9, dense prime leaves up to 19) as the x, the y and the z axis of a small
+    volume -- contiguous lines staged through LDS and strided lines loaded directly, ragged last workgroup included -- against
+    numpy, and bit for bit against itself when the same lines are transformed through the other access path's neighbours."""
+    from multiview_stitcher_amd import _lib, _reg_ops
+
+    rng = np.random.default_rng(3)
+    lengths = _line_lengths()
+    assert len(lengths) == 33 and 51 in lengths and 49 in lengths and 57 in lengths
+    for n in lengths:
+        for shape in ((5, 7, n), (3, n, 9), (n, 2, 37)):
+            a = (rng.standard_normal(shape) + 1j * rng.standard_normal(shape)).astype(np.complex64)
+            want = np.fft.ifftn(a.astype(np.complex128)) * a.size if inverse else np.fft.fftn(a.astype(np.complex128))
+            got = _reg_ops.fftn(a, inverse=inverse)
+            assert np.abs(got - want).max() <= 3e-6 * np.abs(want).max() * np.log2(a.size), (n, shape)
+    # the Bluestein kernels the lengths ran on before (option fft_no_line) agree to float32 rounding
+    a = (rng.standard_normal((6, 51, 40)) + 1j * rng.standard_normal((6, 51, 40))).astype(np.complex64)
+    got = _reg_ops.fftn(a, inverse=inverse)
+    _lib.set_option("fft_no_line", 1)
+    try:
+        ref = _reg_ops.fftn(a, inverse=inverse)
+    finally:
+        _lib.set_option("fft_no_line", 0)
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max() * np.log2(a.size)
+
+
 @pytest.mark.parametrize("shape", [(3, 8192), (2, 5000), (4, 3000), (4100, 5), (2, 8200, 3), (1, 16384), (1, 65536 + 2)])
 @pytest.mark.parametrize("inverse", [False, True])
 def test_fft_c2c_long_axes_match_numpy(hip_device, shape, inverse):
