@@ -421,21 +421,30 @@ def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
         watcher.start()
 
         def executor(msims, edges, register_kwargs):
+            # one task per pair, in the order in which the pairs' later tile arrives; a worker waits for THAT tile's upload and
+            # registers the pair on its own context lane -- no wave barrier, so what runs after the last tile has arrived is
+            # the three pairs of the last tile (waves of 18 pairs left an 11 ms tail)
             order = sorted(range(len(edges)), key=lambda k: max(edges[k]))
             results = [None] * len(edges)
-            kw = dict(register_kwargs)
-            tk, rb, ot = kw.pop("transform_key"), kw.pop("registration_binning", None), kw.pop("overlap_tolerance", 0.0)
-            prf, prk = kw.pop("pairwise_reg_func"), kw.pop("pairwise_reg_func_kwargs", None)
-            wave = max(1, len(order) // 8)
-            for a in range(0, len(order), wave):
-                ks = order[a:a + wave]
-                events[max(max(edges[k]) for k in ks)].synchronize()      # both tiles of every pair of this wave are resident
-                tw0 = (time.perf_counter() - t0) * 1e3
-                part = registration.compute_pairwise_registrations(msims, [edges[k] for k in ks], tk, rb, ot, prf, prk, None,
-                                                                   local_rank, host_threads=8)
-                trace["waves"].append((round(tw0, 1), round((time.perf_counter() - t0) * 1e3, 1), len(ks)))
-                for k, r in zip(ks, part):
-                    results[k] = r
+            pool, lanes, lane_lock = registration._pair_pool(8)
+            cache = registration._BinCache()
+            t_first = [None]
+
+            def work(k):
+                events[max(edges[k])].synchronize()      # both tiles of the pair are resident
+                if t_first[0] is None:
+                    t_first[0] = (time.perf_counter() - t0) * 1e3
+                tid = threading.get_ident()
+                with lane_lock:
+                    lane = lanes.setdefault(tid, len(lanes))
+                i, j = edges[k]
+                results[k] = registration.register_pair_of_msims(msims[i], msims[j], device=(local_rank & 0xff) | (lane << 8),
+                                                                 _bin_cache=cache, **register_kwargs)
+
+            futs = [pool.submit(work, k) for k in order]
+            for f in futs:
+                f.result()
+            trace["waves"].append((round(t_first[0], 1), round((time.perf_counter() - t0) * 1e3, 1), len(edges)))
             return results
 
         registration.register(sims, transform_key=key_in, new_transform_key=key_out, device=local_rank,
@@ -470,8 +479,10 @@ def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
             "h2d_gb": h2d_gb, "d2h_gb": vox * 2 / 1e9, "fuse_slabs": n_slabs,
             "upload_done_ms": trace.get("upload_done_ms"), "h2d_gb_per_s": h2d_gb / (trace["upload_done_ms"] * 1e-3) if trace.get("upload_done_ms") else None,
             "d2h_gb_per_s": vox * 2 / 1e9 / max(total - t_reg, 1e-9), "register_waves_ms": trace.get("waves"),
-            "note": "tiles in pinned host memory -> async uploads in tile order overlapped with the registration of the pairs "
-                    "already resident -> resolution -> fuse in z slabs, each slab's download overlapped with the next slab's fuse"}
+            "note": "tiles in pinned host memory -> async uploads in tile order (copy stream of its own priority) overlapped with the "
+                    "registration of the pairs whose tiles have arrived (one task per pair, 8 lanes) -> resolution -> fuse in z slabs, "
+                    "each slab's download overlapped with the next slab's fuse; register_waves_ms = (first pair started, last pair "
+                    "done, pairs)"}
 
 
 class _SignedView:

@@ -696,8 +696,45 @@ def _fuse_once(
         raise ValueError("multiview_stitcher_amd.fusion.fuse only implements backend='hip'")
     from . import msi_utils
 
-    if all(msi_utils.is_msim(im) for im in images):
-        images = [msi_utils.get_sim_from_msim(im) for im in images]
+    is_ms = [msi_utils.is_msim(im) for im in images]
+    if any(is_ms) and not all(is_ms):
+        raise ValueError("All input images must be of the same kind: either all SpatialImages or all MultiscaleSpatialImages.")
+    if all(is_ms):
+        # MultiscaleSpatialImages in, a multiscale result out (fusion/_core.py:939-1064): scale0 defines the finest output
+        # geometry; every output level is FUSED from the coarsest input level that is still fine enough for it (not
+        # downsampled from the level above); a Zarr output is one level fused from the matching input level.
+        msims = list(images)
+        common = dict(transform_key=transform_key, fusion_func=fusion_func, fusion_func_kwargs=fusion_func_kwargs,
+                      weights_func=weights_func, weights_func_kwargs=weights_func_kwargs, output_stack_mode=output_stack_mode,
+                      output_chunksize=output_chunksize, overlap_in_pixels=overlap_in_pixels, trim_overlap=trim_overlap,
+                      interpolation_order=interpolation_order, blending_widths=blending_widths, backend=backend, device=device,
+                      chunk_filter=chunk_filter, merge_chunks=merge_chunks, frame_origin=frame_origin)
+        scale0 = [msi_utils.get_sim_from_msim(m, scale="scale0") for m in msims]
+        sdims0 = si_utils.get_spatial_dims_from_sim(scale0[0])
+        osp0 = _bb_dicts(process_output_stack_properties(scale0, output_spacing, output_origin, output_shape, output_stack_properties,
+                                                         output_stack_mode, transform_key), sdims0)
+
+        def level_sims(spacing):
+            return [msi_utils.get_sim_from_msim(m, scale="scale%d" % msi_utils.get_res_level_from_spacing(m, spacing)) for m in msims]
+
+        if output_zarr_url is not None:
+            fused = fuse(images=level_sims(osp0["spacing"]), output_stack_properties=osp0, output_zarr_url=output_zarr_url,
+                               zarr_options=zarr_options, batch_options=batch_options, **common)
+            if (zarr_options or {}).get("ome_zarr", False) and chunk_filter is None:
+                from . import ngff_utils
+
+                return ngff_utils.read_msim_from_ome_zarr(output_zarr_url, transform_key=transform_key if transform_key is not None
+                                                          else si_utils.DEFAULT_TRANSFORM_KEY)
+            return msi_utils.get_msim_from_sim(fused, scale_factors=[])
+        shapes, _, abs_factors = msi_utils.calc_resolution_levels({d: int(osp0["shape"][d]) for d in sdims0})
+        fused_levels = []
+        for shape, f in zip(shapes, abs_factors):
+            props = {"shape": dict(shape), "spacing": {d: osp0["spacing"][d] * f[d] for d in sdims0},
+                     # centre-of-pixel convention of downsampled levels (as in the OME-Zarr pyramid)
+                     "origin": {d: osp0["origin"][d] + (f[d] - 1) * osp0["spacing"][d] / 2 for d in sdims0}}
+            fused_levels.append(fuse(images=level_sims(props["spacing"]), output_stack_properties=props,
+                                           output_on_backend=output_on_backend, **common))
+        return msi_utils.get_msim_from_sims(fused_levels)
     sims_ = list(images)
 
     from .transformation import check_interpolation_order

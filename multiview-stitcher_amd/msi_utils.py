@@ -105,6 +105,36 @@ def get_sim_from_msim(msim, scale="scale0"):
     return sim
 
 
+def get_res_level_from_spacing(msim, spacing):
+    """msi_utils.get_res_level_from_spacing (msi_utils.py:655-685): index of the coarsest level whose spacing is still <= the
+    target spacing in every requested dimension (levels are scanned from scale0 and the scan stops at the first that is not)."""
+    best = 0
+    for i, key in enumerate(get_sorted_scale_keys(msim)):
+        actual = si_utils.get_spacing_from_sim(msim[key])
+        if all(actual[d] <= spacing[d] for d in spacing):
+            best = i
+        else:
+            break
+    return best
+
+
+def get_msim_from_sims(sims):
+    """msi_utils.get_msim_from_sims (msi_utils.py:433-480): a multiscale image from already computed levels -- ordered by
+    decreasing spatial shape (which must be comparable), transforms taken from the finest one."""
+    sims = list(sims)
+    if not sims:
+        raise ValueError("sims must contain at least one image.")
+    dims = list(sims[0].dims)
+    if any(list(s.dims) != dims for s in sims[1:]):
+        raise ValueError("All sims must have the same dimensions.")
+    sdims = si_utils.get_spatial_dims_from_sim(sims[0])
+    sims = sorted(sims, key=lambda s: tuple(s.sizes[d] for d in sdims), reverse=True)
+    for a, b in zip(sims, sims[1:]):
+        if not all(b.sizes[d] <= a.sizes[d] for d in sdims):
+            raise ValueError("sims cannot be ordered into resolution levels (shapes are not comparable).")
+    return MultiscaleSpatialImage(sims, copy.deepcopy(sims[0].attrs.get("transforms", {})))
+
+
 def get_res_level_from_binning_factors(msim, binning_factors):
     """msi_utils.get_res_level_from_binning_factors (msi_utils.py:688-773): the LOWEST resolution level whose integer
     downsampling factors (shape of scale0 / shape of the level, per spatial dim) do not exceed the requested binning and

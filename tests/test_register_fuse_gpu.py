@@ -143,7 +143,9 @@ def test_kat_fractional_translation_grid(hip_device):
     for iv, tr in enumerate([{"y": 0, "x": 0}, {"y": a, "x": 0}, {"y": 0, "x": a}, {"y": a, "x": a}]):
         sim = _sim(np.full((2, 10, 10), iv + 1, dtype=np.uint16), ["c", "y", "x"], {"y": 1, "x": 1}, tr)
         msims.append(msi_utils.get_msim_from_sim(sim, scale_factors=[]))
-    fused = fusion.fuse(images=msims, transform_key="k", output_chunksize={"y": 5, "x": 5}, merge_chunks=False)
+    fused_msim = fusion.fuse(images=msims, transform_key="k", output_chunksize={"y": 5, "x": 5}, merge_chunks=False)
+    assert msi_utils.is_msim(fused_msim)              # MultiscaleSpatialImages in, a multiscale result out (_core.py:939-1064)
+    fused = msi_utils.get_sim_from_msim(fused_msim, scale="scale0")
     d = np.asarray(fused.data)
     assert fused.sizes["y"] == 18 and fused.sizes["x"] == 18
     assert d.max() == 4 and d.min() > 0
@@ -435,3 +437,35 @@ def test_index_frame_that_cannot_be_applied_warns(hip_device):
     with pytest.warns(fusion.IndexFrameWarning, match="frame_origin cannot be applied"):
         got = fusion.fuse_np(sims, params, bb_to_dicts(out_bb, sd), full_view_bbs=fvb, frame_origin=off_grid)
     np.testing.assert_array_equal(got, want)       # (integer offsets: the per-chunk fallback gives the same voxels here)
+
+
+def test_fuse_of_multiscale_images_is_multiscale(hip_device, tmp_path):
+    """fusion/_core.py:939-1064: every output level is FUSED from the coarsest input level that is still fine enough for it
+    (centre-of-pixel origins of the coarser levels), not downsampled from the level above; mixed inputs are refused; with a Zarr
+    output one level is written and a multiscale image comes back."""
+    from multiview_stitcher_amd import fusion, msi_utils, sample_data
+    from multiview_stitcher_amd import spatial_image_utils as si
+
+    sims, _, _ = sample_data.generate_tiled_dataset(ndim=2, tile_shape=(160, 200), tiles=(2, 2), overlap=(30, 30), dtype=np.uint16,
+                                                    max_jitter=0, seed=3)
+    key = sample_data.METADATA_TRANSFORM_KEY
+    msims = [msi_utils.get_msim_from_sim(s, scale_factors=[2]) for s in sims]
+    out = fusion.fuse(msims, transform_key=key)
+    assert msi_utils.is_msim(out) and msi_utils.get_sorted_scale_keys(out) == ["scale0", "scale1"]
+    lvl0 = msi_utils.get_sim_from_msim(out, scale="scale0")
+    lvl1 = msi_utils.get_sim_from_msim(out, scale="scale1")
+    want0 = fusion.fuse(sims, transform_key=key)
+    np.testing.assert_array_equal(np.asarray(lvl0.data), np.asarray(want0.data))
+    sp0, o0 = si.get_spacing_from_sim(want0), si.get_origin_from_sim(want0)
+    assert si.get_spacing_from_sim(lvl1) == {d: 2 * sp0[d] for d in sp0}
+    assert si.get_origin_from_sim(lvl1) == {d: o0[d] + sp0[d] / 2 for d in sp0}
+    assert lvl1.sizes["y"] == want0.sizes["y"] // 2 and lvl1.sizes["x"] == want0.sizes["x"] // 2
+    # level 1 of the result == the level-1 input images fused onto the level-1 output grid
+    props1 = {"shape": {d: int(lvl1.sizes[d]) for d in sp0}, "spacing": si.get_spacing_from_sim(lvl1), "origin": si.get_origin_from_sim(lvl1)}
+    want1 = fusion.fuse([msi_utils.get_sim_from_msim(m, scale="scale1") for m in msims], transform_key=key, output_stack_properties=props1)
+    np.testing.assert_array_equal(np.asarray(lvl1.data), np.asarray(want1.data))
+    with pytest.raises(ValueError, match="same kind"):
+        fusion.fuse([msims[0], sims[1]], transform_key=key)
+    z = fusion.fuse(msims, transform_key=key, output_zarr_url=str(tmp_path / "f.zarr"), output_chunksize={"y": 128, "x": 128})
+    assert msi_utils.is_msim(z) and msi_utils.get_sorted_scale_keys(z) == ["scale0"]
+    np.testing.assert_array_equal(np.asarray(msi_utils.get_sim_from_msim(z).data), np.asarray(want0.data))
