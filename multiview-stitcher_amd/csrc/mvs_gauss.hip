@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -64,6 +65,43 @@ __global__ void mask_normalize_kernel(float* __restrict__ bw, const float* __res
             const long long k = box_index(boxes[v], z, y, x);
             if (k >= 0) bw[k] /= wsum;
         }
+    }
+}
+
+// The same for chunks seen by at most 8 views (every tile grid): the view loop is unrolled, a view's pool index is worked out once
+// per voxel in 32-bit arithmetic and kept in a register, and the masked weight is written once, already normalised (the general
+// kernel stores it, re-reads it and divides in place: 20 instead of 12 bytes per view and voxel).
+struct CbBox32 { int lo[3], n[3], off; };
+struct CbBoxes8 { CbBox32 b[8]; };
+__device__ __forceinline__ int box_index32(const CbBox32& B, int z, int y, int x) {
+    const int bz = z - B.lo[0], by = y - B.lo[1], bx = x - B.lo[2];
+    if ((unsigned)bz >= (unsigned)B.n[0] || (unsigned)by >= (unsigned)B.n[1] || (unsigned)bx >= (unsigned)B.n[2]) return -1;
+    return B.off + (bz * B.n[1] + by) * B.n[2] + bx;
+}
+__global__ __launch_bounds__(256) void mask_normalize8_kernel(float* __restrict__ bw, const float* __restrict__ im, CbBoxes8 BX, int nviews, Shape3 S) {
+    const long long n = (long long)S.nz * S.ny * S.nx;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % S.nx);
+        const long long t = i / S.nx;
+        const int y = (int)(t % S.ny), z = (int)(t / S.ny);
+        int kk[8];
+        float w[8];
+        float wsum = 0.f;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            kk[v] = v < nviews ? box_index32(BX.b[v], z, y, x) : -1;
+            w[v] = 0.f;
+            if (kk[v] >= 0) {
+                w[v] = bw[kk[v]];
+                const float xv = im[kk[v]];
+                if (xv != xv) w[v] = 0.f;      // w * False
+                wsum += w[v];                  // np.nansum over axis 0 adds view by view in float32
+            }
+        }
+        if (wsum == 0.f) wsum = 1.f;
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+            if (kk[v] >= 0) bw[kk[v]] = w[v] / wsum;
     }
 }
 
@@ -515,6 +553,51 @@ __global__ void cb_fuse_kernel(const float* __restrict__ im, const float* __rest
     }
 }
 
+// cb_fuse_kernel for at most 8 views: indices, F and the weights stay in registers over the three sums (same additions in the
+// same view order)
+template <typename TOut>
+__global__ __launch_bounds__(256) void cb_fuse8_kernel(const float* __restrict__ im, const float* __restrict__ bw, const float* __restrict__ F,
+                                                       CbBoxes8 BX, int nviews, int tz, int ty, int tx, Shape3 O, TOut* __restrict__ out) {
+    const long long no = (long long)O.nz * O.ny * O.nx;
+    for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < no; o += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(o % O.nx);
+        const long long t = o / O.nx;
+        const int y = (int)(t % O.ny), z = (int)(t / O.ny);
+        int kk[8];
+        float f[8], a[8];
+        float fsum = 0.f;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            kk[v] = v < nviews ? box_index32(BX.b[v], z + tz, y + ty, x + tx) : -1;
+            f[v] = 0.f;
+            if (kk[v] >= 0) {
+                f[v] = F[kk[v]];
+                if (f[v] == f[v]) fsum += f[v];
+            }
+        }
+        if (fsum == 0.f) fsum = 1.f;
+        float asum = 0.f;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            a[v] = 0.f;
+            if (kk[v] >= 0) {
+                a[v] = bw[kk[v]] * (f[v] / fsum);
+                if (a[v] == a[v]) asum += a[v];
+            }
+        }
+        if (asum == 0.f) asum = 1.f;
+        float acc = 0.f;
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+            if (kk[v] >= 0) {
+                const float p = im[kk[v]] * (a[v] / asum);
+                if (p == p) acc += p;
+            }
+        if (!(fabsf(acc) <= 3.4028234e38f)) acc = 0.f;
+        out[o] = cast_cb<TOut>(acc);
+    }
+}
+
 // scipy.ndimage._filters._gaussian_kernel1d(sigma, 0, radius), radius = int(truncate * sigma + 0.5)
 void gaussian_kernel(double sigma, int* radius_out, std::vector<double>* w) {
     const int radius = (int)(4.0 * sigma + 0.5);
@@ -613,9 +696,8 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
     for (int i = 0; i < n_views && paired; ++i)
         for (int axis = 3 - ndim; axis < 3; ++axis)
             if (boxes[i].n[axis] > 0 && (!pair_T(boxes[i].n[axis], r1, axis) || !pair_T(boxes[i].n[axis], r2, axis))) paired = false;
-    // temporaries: paired path 5 arrays PER VIEW (the views' filter chains run side by side on the context's side streams);
-    // sequential path 6 arrays of the largest box, shared
-    const size_t tmp_total = paired ? 5 * pool_b : 6 * tmp_b;
+    // temporaries of the largest box, shared by the views: 5 arrays on the paired path, 6 on the separate-pass path
+    const size_t tmp_total = (paired ? 5 : 6) * tmp_b;
     const size_t need = 3 * pool_b + tmp_total + 64 * 1024 + (size_t)n_views * sizeof(CbBox) + 512;
     char* base = (char*)mvs_scratch(c, 6, need);
     if (!base) return mvs_alloc_failed(c);
@@ -634,10 +716,20 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
     if ((w1.size() + w2.size()) * 8 > 32 * 1024) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "content_based: sigma too large");
     double* dfw1 = dfw;
     double* dfw2 = dfw + w1.size();
-    // (pageable sources: the copies complete before the call returns to this code, so the vectors may go out of scope later)
-    MVS_HIP_TRY(c, hipMemcpyAsync(dfw1, w1.data(), w1.size() * 8, hipMemcpyHostToDevice, c->stream));
-    MVS_HIP_TRY(c, hipMemcpyAsync(dfw2, w2.data(), w2.size() * 8, hipMemcpyHostToDevice, c->stream));
-    MVS_HIP_TRY(c, hipMemcpyAsync(dboxes, boxes.data(), (size_t)n_views * sizeof(CbBox), hipMemcpyHostToDevice, c->stream));
+    // filter kernels and boxes travel through the context's pinned staging slot (waited for before it is refilled: mvs_pinned_slot /
+    // mvs_pinned_mark), so the call does not have to wait for its own work: with the result on the device it returns as soon as
+    // everything is queued, and the host prepares the next chunk while this one is filtered (the probe spent ~0.4 ms per chunk idle)
+    {
+        const size_t wb = (w1.size() + w2.size()) * 8, bb = (size_t)n_views * sizeof(CbBox);
+        char* hp = (char*)mvs_pinned_slot(c, 0, wb + bb + 64);
+        if (!hp) return mvs_alloc_failed(c);
+        memcpy(hp, w1.data(), w1.size() * 8);
+        memcpy(hp + w1.size() * 8, w2.data(), w2.size() * 8);
+        memcpy(hp + wb, boxes.data(), bb);
+        MVS_HIP_TRY(c, hipMemcpyAsync(dfw1, hp, wb, hipMemcpyHostToDevice, c->stream));
+        MVS_HIP_TRY(c, hipMemcpyAsync(dboxes, hp + wb, bb, hipMemcpyHostToDevice, c->stream));
+        mvs_pinned_mark(c, 0);
+    }
 
     for (int i = 0; i < n_views; ++i) {
         const CbBox& B = boxes[i];
@@ -647,7 +739,17 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
         mvs_launch_blend(c, dvs[i], BW + B.off, bs, B.lo);
     }
     const int gb = grid_for(n);
-    hipLaunchKernelGGL(mask_normalize_kernel, dim3(gb), dim3(256), 0, c->stream, BW, I, dboxes, n_views, S);
+    // <= 8 views and a pool below 2^31 floats: boxes as a kernel argument, 32-bit indices kept in registers
+    const bool small = n_views <= 8 && pool < (1ll << 31);
+    CbBoxes8 bx8;
+    memset(&bx8, 0, sizeof(bx8));
+    if (small)
+        for (int i = 0; i < n_views; ++i) {
+            for (int k = 0; k < 3; ++k) { bx8.b[i].lo[k] = boxes[i].lo[k]; bx8.b[i].n[k] = boxes[i].n[k]; }
+            bx8.b[i].off = (int)boxes[i].off;
+        }
+    if (small) hipLaunchKernelGGL(mask_normalize8_kernel, dim3(gb), dim3(256), 0, c->stream, BW, I, bx8, n_views, S);
+    else hipLaunchKernelGGL(mask_normalize_kernel, dim3(gb), dim3(256), 0, c->stream, BW, I, dboxes, n_views, S);
 
     auto gauss = [&](const float* src, float* dst, const CbBox& B, int radius, const double* fw) {
         // scipy filters axis 0, 1, 2 in turn; a 2D chunk has no z axis
@@ -681,30 +783,21 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
             cur = d;
         }
     };
-    // ---- paired path: per view 2 x ndim launches; the views' chains are independent (own temporaries), so the largest box runs
-    // on the context's stream and the others fill in around it on the four side streams ----
+    // ---- paired path: per view 2 x ndim launches, one view after the other on the context's stream.  (Round 4 first ran the
+    // views' chains side by side on the side streams -- 27.0 ms per probe call against 27.5 serial; once the call stopped waiting
+    // for its own work (below) the serial form took 23.4 ms and the forked one 32-33: consecutive chunks overlap on ONE stream by
+    // themselves, and the fork / join events between low-priority side streams only got in their way.) ----
     if (paired) {
-        int rcs = mvs_ensure_aux_streams(c);
-        if (rcs) return rcs;
         std::vector<int> order;
         for (int v = 0; v < n_views; ++v)
             if ((long long)boxes[v].n[0] * boxes[v].n[1] * boxes[v].n[2] > 0) order.push_back(v);
-        std::sort(order.begin(), order.end(), [&](int a, int b) {
-            return (long long)boxes[a].n[0] * boxes[a].n[1] * boxes[a].n[2] > (long long)boxes[b].n[0] * boxes[b].n[1] * boxes[b].n[2]; });
-        MVS_HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-        bool side_used[4] = {false, false, false, false};
-        float* TP5 = A;      // 5 pools laid out one after the other: [k * pool + B.off]
+        float* TP5 = A;      // 5 temporaries of the largest box, shared by the views
         for (size_t oi = 0; oi < order.size(); ++oi) {
             const int v = order[oi];
             const CbBox& B = boxes[v];
             hipStream_t st = c->stream;
-            if (oi > 0 && !c->serial_classes) {      // ("serial_classes": everything on the context's stream, for per-kernel timings)
-                const int a = (int)((oi - 1) & 3);
-                st = c->aux_stream[a];
-                if (!side_used[a]) { MVS_HIP_TRY(c, hipStreamWaitEvent(st, c->ev_fork, 0)); side_used[a] = true; }
-            }
             float* t[5];
-            for (int k = 0; k < 5; ++k) t[k] = TP5 + (size_t)k * (size_t)pool + B.off;
+            for (int k = 0; k < 5; ++k) t[k] = (float*)((char*)TP5 + (size_t)k * tmp_b);
             const float* Iv = I + B.off;
             const float* Bv = BW + B.off;
             for (int f = 0; f < 2; ++f) {
@@ -756,11 +849,6 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
             }
         }
         MVS_HIP_TRY(c, hipGetLastError());
-        for (int a = 0; a < 4; ++a)
-            if (side_used[a]) {
-                MVS_HIP_TRY(c, hipEventRecord(c->ev_join[a], c->aux_stream[a]));
-                MVS_HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join[a], 0));
-            }
     }
     for (int v = 0; v < n_views && !paired; ++v) {
         const CbBox& B = boxes[v];
@@ -788,6 +876,13 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
     }
     const int gbo = grid_for(no);
     const int tz = (int)opts->trim[0], ty = (int)opts->trim[1], tx = (int)opts->trim[2];
+    if (small) {
+        switch (dtype) {
+            case MVS_U8: hipLaunchKernelGGL(cb_fuse8_kernel<unsigned char>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, bx8, n_views, tz, ty, tx, O, (unsigned char*)dout); break;
+            case MVS_U16: hipLaunchKernelGGL(cb_fuse8_kernel<unsigned short>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, bx8, n_views, tz, ty, tx, O, (unsigned short*)dout); break;
+            default: hipLaunchKernelGGL(cb_fuse8_kernel<float>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, bx8, n_views, tz, ty, tx, O, (float*)dout); break;
+        }
+    } else
     switch (dtype) {
         case MVS_U8: hipLaunchKernelGGL(cb_fuse_kernel<unsigned char>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, dboxes, n_views, tz, ty, tx, O, (unsigned char*)dout); break;
         case MVS_U16: hipLaunchKernelGGL(cb_fuse_kernel<unsigned short>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, dboxes, n_views, tz, ty, tx, O, (unsigned short*)dout); break;
@@ -796,7 +891,11 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
     MVS_HIP_TRY(c, hipGetLastError());
     MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
     c->timing_valid = true;
-    if (opts->out_mem == MVS_MEM_HOST) MVS_HIP_TRY(c, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
-    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (opts->out_mem == MVS_MEM_HOST) {
+        MVS_HIP_TRY(c, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else if (host_bytes) {
+        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));      // host slabs were staged through scratch that the next call may overwrite
+    }
     return MVS_OK;
 }
