@@ -54,3 +54,25 @@ def test_pool_recycles_blocks_and_copy_into_checks_bounds(hip_device):
     want = np.zeros((6, 6), np.uint16)
     want[2:6, 1:5] = 1
     np.testing.assert_array_equal(dst.get(), want)
+
+
+def test_out_of_memory_has_its_own_code_and_exception(hip_device):
+    """A HIP allocation that fails with hipErrorOutOfMemory comes back as MVS_ERR_OUT_OF_MEMORY (-5), which the Python shim raises
+    as DeviceMemoryError -- the class fuse()'s fallback from merged launch blocks to the requested chunk grid keys on (ADVICE
+    round 3: no matching of message text); other failures stay MvsError with their own code; unknown options are refused."""
+    from multiview_stitcher_amd import _lib
+
+    lib = _lib.init(0)
+    free_b, total_b = _lib.mem_info(0)
+    p = C.c_void_p()
+    rc = lib.mvs_malloc(0, C.c_size_t(total_b * 4), C.byref(p))                  # four times the device: cannot succeed
+    assert rc == _lib.ERR_OUT_OF_MEMORY, (rc, lib.mvs_last_error(0))
+    with pytest.raises(_lib.DeviceMemoryError) as ei:
+        _lib.DeviceBuffer(0, total_b * 4)
+    assert ei.value.code == -5 and isinstance(ei.value, RuntimeError)
+    # the context is still usable afterwards
+    buf = _lib.DeviceBuffer(0, 1 << 20)
+    buf.free()
+    with pytest.raises(_lib.MvsError) as ei:
+        _lib.set_option("rowlds", 1)                                             # retired in round 3
+    assert ei.value.code == -1 and not isinstance(ei.value, _lib.DeviceMemoryError)
