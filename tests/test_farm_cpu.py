@@ -203,3 +203,61 @@ def test_gloo_two_ranks_sharded_pair_executor(tmp_path):
     )
     assert out.returncode == 0, out.stderr[-3000:]
     assert "OK [" in out.stdout, out.stdout
+
+
+def test_gloo_eight_ranks_halo_exchange_and_sharded_pairs(tmp_path):
+    """The north star's partition launched with EIGHT processes on the CPU (gloo): 4 x 4 x 4 tiles, one 2 x 2 x 2 brick per rank.
+    The point-to-point halo exchange (``sharding.exchange_halo``: batched isend / irecv, seven possible peers per rank) delivers
+    exactly the tiles ``rank_tiles`` lists, with the owner's content; the sharded pair executor splits the 144 pairs by the owner
+    of the fixed view and every rank ends with all 144 results in edge order.  (The same launch on the GPU box, with the real
+    registration and fusion: tests/test_bench_launch_gpu.py.)"""
+    script = tmp_path / "w8.py"
+    script.write_text(textwrap.dedent(f"""
+        import os, sys
+        sys.path.insert(0, {ROOT!r})
+        import numpy as np
+        import torch, torch.distributed as dist
+        from multiview_stitcher_amd import sharding
+        sys.path.insert(0, os.path.join({ROOT!r}, "tests"))
+        from test_farm_cpu import _grid_meta
+        dist.init_process_group("gloo")
+        r, w = dist.get_rank(), dist.get_world_size()
+        sps, affs, osp, edges = _grid_meta((4, 4, 4), 64, 12)
+        boxes, counts = sharding.output_subboxes(osp, w)
+        assert counts == [2, 2, 2]
+        owners = sharding.tile_owners(sps, affs, boxes)
+        assert sorted(np.bincount(owners).tolist()) == [8] * 8
+        needs = [sharding.rank_tiles(sps, affs, boxes, edges, owners, q, margin=8.0) for q in range(w)]
+        tiles = [torch.full((3, 4, 5), v, dtype=torch.int16).view(torch.uint16) if owners[v] == r else None for v in range(len(sps))]
+        got = sharding.exchange_halo(torch, dist, tiles, owners, needs, r, w, "cpu", via_host=True)
+        held = [v for v, t in enumerate(got) if t is not None]
+        assert held == needs[r], (r, held, needs[r])
+        assert 8 < len(held) <= 27 and all(int(got[v].view(torch.int16)[0, 0, 0]) == v and got[v].dtype == torch.uint16 for v in held)
+        ex = sharding.ShardedPairExecutor(r, w, owners, register_fn=lambda a, b, **kw: {{"transform": np.eye(4) * (a + 1), "quality": float(b),
+                                                                                     "bbox": np.zeros((2, 3)), "rank": r}})
+        res = ex(list(range(len(sps))), edges, {{}})
+        assert len(res) == 144 and all(q["quality"] == float(j) and q["transform"][0, 0] == i + 1 for (i, j), q in zip(edges, res))
+        by_rank = np.bincount([q["rank"] for q in res], minlength=w)
+        assert by_rank.sum() == 144 and by_rank.min() > 0 and all(q["rank"] == owners[i] for (i, j), q in zip(edges, res))
+        peers = sorted({{owners[v] for v in held}} - {{r}})
+        counts_all = [None] * w
+        dist.all_gather_object(counts_all, (len(held), len(peers), int(by_rank[r])))
+        if r == 0:
+            print("OK", counts_all)
+        dist.destroy_process_group()
+    """))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = subprocess.run(
+        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), str(script)],
+        capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="1"),
+    )
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "OK [" in out.stdout, out.stdout
+    # every rank exchanged with all seven others (a 2 x 2 x 2 brick of this grid touches every other brick)
+    import ast
+    counts_all = ast.literal_eval(out.stdout[out.stdout.index("OK [") + 3:].splitlines()[0])
+    assert all(c[1] == 7 for c in counts_all), counts_all
