@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -163,6 +164,7 @@ __global__ __launch_bounds__(256) void gauss1d_kernel(const float* __restrict__ 
 // index arithmetic, no reflection and no global load per tap (the tap-by-tap kernel above spends its time there: the
 // sigma = 11 filter has 89 taps).  Same accumulation order, same rounding.  LDS layout [pos + radius][line], line
 // pitch T + 1 (odd) so that both access directions are bank-conflict free.
+constexpr int kGaussK = 8;      // outputs per thread of the LDS line filters
 struct GaussLines { long long n_lines; int len; long long stride; long long inner; long long outer_stride; int T; int b0, full; };
 
 __global__ __launch_bounds__(256) void gauss1d_lds_kernel(const float* __restrict__ src, float* __restrict__ dst, GaussLines L, int radius,
@@ -289,6 +291,9 @@ __device__ __forceinline__ float cb_valid_value(const PairIO& P, long long i) { 
 // SPLIT: the passes that are not the last of their filter need no coupling between the two quantities (DST_AB), so a workgroup
 // takes ONE of them (blockIdx.y: 0 value, 1 mask) and stages twice as many lines in the same LDS (T = 32: lines along y / z then
 // move in 128-byte pieces instead of 64-byte ones); still one launch per pass.
+#ifndef MVS_CB_NB
+#define MVS_CB_NB 8      // samples a thread requests back to back while staging (memory-level parallelism of a workgroup)
+#endif
 template <int SRC, int DST, bool SPLIT>
 __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines L, int radius, const double* __restrict__ fw, int pos_fastest) {
     static_assert(!SPLIT || DST == DST_AB, "split passes store both quantities as they are");
@@ -299,7 +304,7 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
     const int qs = SPLIT ? (int)blockIdx.y : 0;       // SPLIT: the quantity of this workgroup
     const int T = L.T, TP = T + 1, len = L.len, lt = 31 - __clz(T);
     const int span = len + 2 * radius;
-    float* sq[2] = {sl, sl + (SPLIT ? 0 : (size_t)span * TP)};
+    float* sq[2] = {sl, sl + (SPLIT ? 0 : (size_t)(span + kGaussK) * TP)};      // (kGaussK spare rows behind each array: see the filter loop)
     __shared__ long long lbase[32];
     const long long l0 = (long long)blockIdx.x * T;
     const int nl = (int)min((long long)T, L.n_lines - l0);
@@ -314,8 +319,8 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
     const bool direct = SPLIT && (SRC == SRC_AB || (SRC == SRC_VMASK && qs == 0));
     const float* X = !SPLIT ? nullptr : (SRC == SRC_AB ? (qs ? P.b : P.a) : (direct ? P.a : P.im));
     const float* Y = !SPLIT ? nullptr : (direct ? X : P.bw);
-    auto load_raw = [&](long long i, float& r0, float& r1, float& r2) {
-        if constexpr (SPLIT) { r0 = X[i]; r1 = Y[i]; r2 = 0.f; }
+    auto load_raw = [&](long long i, float& r0, float& r1, float& r2, auto one_array) {
+        if constexpr (SPLIT) { r0 = X[i]; r1 = decltype(one_array)::value ? r0 : Y[i]; r2 = 0.f; }
         else if constexpr (SRC == SRC_AB) { r0 = P.a[i]; r1 = P.b[i]; r2 = 0.f; }
         else if constexpr (SRC == SRC_PREP) { r0 = P.im[i]; r1 = P.bw[i]; r2 = 0.f; }
         else { r0 = P.im[i]; r1 = P.bw[i]; r2 = P.a[i]; }
@@ -333,19 +338,20 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
     float first[2];
     {
         float r0, r1, r2;
-        load_raw(lbase[0], r0, r1, r2);
+        load_raw(lbase[0], r0, r1, r2, std::false_type{});
         interpret(r0, r1, r2, first[0], first[1]);
     }
     int same0 = 1, same1 = 1;
     // A workgroup is a short dependent chain (stage -> filter -> store) and only a few of them fit a CU, so the staging loop
     // must not pay one memory round trip per sample: the loads of NB samples are issued back to back before the first of them
     // is written to LDS.
-    constexpr int NB = 8;
+    constexpr int NB = MVS_CB_NB;
     const int per_line = pos_fastest ? (int)blockDim.x : ((int)blockDim.x >> lt);      // positions a sweep of the workgroup covers per line
     const int my_line = pos_fastest ? 0 : (int)(threadIdx.x & (T - 1));
     const int my_pos0 = pos_fastest ? (int)threadIdx.x : (int)(threadIdx.x >> lt);
     const int sweeps = (len + per_line - 1) / per_line;
     const int n_my = pos_fastest ? sweeps * T : sweeps;             // samples of this thread: (sweep[, line]) pairs
+    auto stage = [&](auto one_array) __attribute__((always_inline)) {
     for (int b0 = 0; b0 < n_my; b0 += NB) {
         float q0[NB], q1[NB], q2[NB];
         int bl[NB], bp[NB];
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
             const int pos = my_pos0 + sweep * per_line;
             bl[u] = line; bp[u] = pos;
             // (clamped address: the load itself is unconditional, what it returns is discarded below when out of range)
-            load_raw(lbase[min(line, nl - 1)] + (long long)min(pos, len - 1) * L.stride, q0[u], q1[u], q2[u]);
+            load_raw(lbase[min(line, nl - 1)] + (long long)min(pos, len - 1) * L.stride, q0[u], q1[u], q2[u], one_array);
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -375,6 +381,10 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
             }
         }
     }
+    };
+    // (a quantity stored as it is needs ONE array: the second load of the general form would only occupy a slot of the batch)
+    if (direct) stage(std::true_type{});
+    else stage(std::false_type{});
     const bool box_is_line = (L.b0 == 0 && L.len == L.full);
     // (__syncthreads_or reduces the TRUTH of its argument, not its bits: one reduction per quantity)
     const int varies0 = __syncthreads_or(same0 ? 0 : 1);
@@ -400,9 +410,13 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
             if (!cst[k]) sq[k][(p + radius) * TP + line] = (q >= 0) ? sq[k][(q + radius) * TP + line] : 0.f;
     }
     __syncthreads();
-    constexpr int K = 8;
+    // ---- filter: K consecutive outputs of one line per thread (the scheme of gauss1d_lds_kernel).  What differs is how a step
+    // is fed: the windows' new samples come from two LDS pointers that move by one row per pair (no index arithmetic, no clamp:
+    // the arrays end in K spare rows, whatever they hold only reaches outputs beyond the line's end, which are not stored), the
+    // weights of K pairs are fetched together, and the K-pair blocks of the loop are free of branches, so that the reads and
+    // conversions of a pair overlap the float64 arithmetic of the previous one. ----
+    constexpr int K = kGaussK;
     const int nblk = (len + K - 1) / K;
-    const int qmax = len - 1 + 2 * radius;
     for (int idx = threadIdx.x; idx < T * nblk; idx += blockDim.x) {
         const int blk = idx >> lt, line = idx & (T - 1);
         if (line >= nl) continue;
@@ -415,25 +429,41 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
                 for (int k = 0; k < K; ++k) res[q][k] = cval[q];
                 continue;
             }
-            const float* c = sq[q] + line;
+            const float* c = sq[q] + line;                  // sample at position x: c[(x + radius) * TP]
             double PA[K], PB[K], acc[K];
+            const double wc = fw[radius];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                PA[k] = (double)c[min(p0 + k, qmax) * TP];
-                PB[k] = (double)c[min(p0 + k + 2 * radius, qmax) * TP];
-                acc[k] = (double)c[min(p0 + k + radius, qmax) * TP] * fw[radius];
+                PA[k] = (double)c[(p0 + k) * TP];
+                PB[k] = (double)c[(p0 + k + 2 * radius) * TP];
+                acc[k] = (double)c[(p0 + k + radius) * TP] * wc;
             }
-            for (int jb = radius; jb >= 1; jb -= K) {
+            // pair j - 1 needs one new sample per window: rows p0 + K + (radius - j) and p0 + 2 radius - 1 - (radius - j)
+            const float* qa = c + (p0 + K) * TP;
+            const float* qb = c + (p0 + 2 * radius - 1) * TP;
+            int jb = radius;
+            for (; jb >= K; jb -= K) {
+                double w[K];
+#pragma unroll
+                for (int s = 0; s < K; ++s) w[s] = fw[radius - jb + s];
 #pragma unroll
                 for (int s = 0; s < K; ++s) {
-                    const int j = jb - s;
-                    if (j < 1) break;
-                    const double w = fw[radius - j];
 #pragma unroll
-                    for (int k = 0; k < K; ++k) acc[k] = fma(PA[(k + s) % K] + PB[(k - s + K) % K], w, acc[k]);
-                    PA[s % K] = (double)c[min(p0 + K - j + radius, qmax) * TP];
-                    PB[(K - 1 - s) % K] = (double)c[(p0 + j - 1 + radius) * TP];
+                    for (int k = 0; k < K; ++k) acc[k] = fma(PA[(k + s) % K] + PB[(k - s + K) % K], w[s], acc[k]);
+                    PA[s] = (double)qa[s * TP];
+                    PB[K - 1 - s] = (double)qb[-s * TP];
                 }
+                qa += K * TP;
+                qb -= K * TP;
+            }
+#pragma unroll
+            for (int s = 0; s < K - 1; ++s) {                // the remaining jb < K pairs
+                if (s >= jb) break;
+                const double w = fw[radius - jb + s];
+#pragma unroll
+                for (int k = 0; k < K; ++k) acc[k] = fma(PA[(k + s) % K] + PB[(k - s + K) % K], w, acc[k]);
+                PA[s] = (double)qa[s * TP];
+                PB[K - 1 - s] = (double)qb[-s * TP];
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) res[q][k] = (float)acc[k];
@@ -826,7 +856,7 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
                     const int Ts = (P.dst == DST_AB && axis != 2 && !c->cb_nosplit) ? split_T(L.len, radius) : 0;
                     const bool split = Ts > 0;
                     L.T = split ? Ts : pair_T(L.len, radius, axis);
-                    const size_t lds = (size_t)(L.len + 2 * radius) * (L.T + 1) * (split ? 4 : 8);
+                    const size_t lds = (size_t)(L.len + 2 * radius + kGaussK) * (L.T + 1) * (split ? 4 : 8);
                     const long long nb = (L.n_lines + L.T - 1) / L.T;
                     const dim3 g((unsigned)nb, split ? 2 : 1), b(256);
                     const int pf = axis == 2 ? 1 : 0;
