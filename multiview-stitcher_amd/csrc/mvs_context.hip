@@ -44,6 +44,7 @@ void* mvs_scratch(MvsContext* c, int slot, size_t nbytes) {
     size_t cap = nbytes + (nbytes >> 3) + 4096;
     hipError_t e = hipMalloc(&s.ptr, cap);
     if (e != hipSuccess) {
+        (void)hipGetLastError();      // reported here; must not surface again at the next launch check of this thread
         mvs_fail(c, e == hipErrorOutOfMemory ? MVS_ERR_OUT_OF_MEMORY : MVS_ERR_HIP, "hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
         s.ptr = nullptr;
         return nullptr;
@@ -69,6 +70,7 @@ void* mvs_pinned_slot(MvsContext* c, int slot, size_t nbytes) {
     size_t cap = nbytes * 2 + 4096;
     hipError_t e = hipHostMalloc(&p, cap, hipHostMallocDefault);
     if (e != hipSuccess) {
+        (void)hipGetLastError();
         mvs_fail(c, e == hipErrorOutOfMemory ? MVS_ERR_OUT_OF_MEMORY : MVS_ERR_HIP, "hipHostMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
         p = nullptr;
         return nullptr;
@@ -185,6 +187,10 @@ int mvs_init(int device) {
     c->device = device;
     // extra lanes serve pair-sized work: keep their allocation caches small (lane 0 may hold whole mosaics)
     c->pool_cache_limit = ((device >> 8) ? (size_t)4 : (size_t)32) << 30;
+    {   // A/B switch for all context lanes of a process (bench.py, tools/): MVS_SSIM_PRUNE=0 scores every candidate in full
+        const char* ev = getenv("MVS_SSIM_PRUNE");
+        if (ev && *ev) c->ssim_prune = atoi(ev) != 0;
+    }
     c->ready = true;
     c->last_error.clear();
     return MVS_OK;
@@ -284,6 +290,10 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         c->ssim_two_pass = value != 0;
         return MVS_OK;
     }
+    if (!strcmp(key, "ssim_prune")) {
+        c->ssim_prune = value != 0;
+        return MVS_OK;
+    }
     if (!strcmp(key, "materialize_shifts")) {
         c->materialize_shifts = value != 0;
         return MVS_OK;
@@ -319,6 +329,8 @@ int mvs_get_counter(int device, const char* key, int32_t reset, double* value_ou
     if (!strcmp(key, "reg_alg_bytes")) { *value_out = c->reg_alg_bytes; if (reset) c->reg_alg_bytes = 0.0; return MVS_OK; }
     if (!strcmp(key, "reg_pairs")) { *value_out = (double)c->reg_pairs; if (reset) c->reg_pairs = 0; return MVS_OK; }
     if (!strcmp(key, "reg_candidates")) { *value_out = (double)c->reg_candidates; if (reset) c->reg_candidates = 0; return MVS_OK; }
+    if (!strcmp(key, "reg_pruned")) { *value_out = (double)c->reg_pruned; if (reset) c->reg_pruned = 0; return MVS_OK; }
+    if (!strcmp(key, "reg_cand_volumes")) { *value_out = c->reg_cand_volumes; if (reset) c->reg_cand_volumes = 0.0; return MVS_OK; }
     if (!strcmp(key, "fuse_plan_ms")) {
         *value_out = mvs_rows_last_plan_ms(c) + mvs_regions_last_plan_ms(c);
         return MVS_OK;

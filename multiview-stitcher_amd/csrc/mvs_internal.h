@@ -38,7 +38,8 @@ struct MvsContext {
     // measurement: algorithmic HBM bytes of the pairwise registrations run on this context since the last reset (SURVEY 8d:
     // 28 n per phase-correlation variant, 20 n per scored candidate, 64 n for the rank correlation; n = crop voxels)
     double reg_alg_bytes = 0.0;
-    long long reg_pairs = 0, reg_candidates = 0;
+    long long reg_pairs = 0, reg_candidates = 0, reg_pruned = 0;   // reg_pruned: candidates the pruned arg-max search left unfinished
+    double reg_cand_volumes = 0.0;     // candidate volumes the SSIM walk actually went through (a pruned candidate counts its fraction)
     float raw_range[4] = {0.f, 0.f, 0.f, 0.f};            // with raw_u16_keys: min, max of the fixed crop, min, max of the moving crop
     const float* raw_u16_keys[2] = {nullptr, nullptr};   // set by mvs_register_crops: integer-valued originals of the two crops (16-bit rank keys)
     // the class kernels of one fuse launch run on side streams next to the main one (fork / join by events)
@@ -48,6 +49,9 @@ struct MvsContext {
     bool defer_sync = false;           // set by composite entry points: mvs_resample to device memory returns without waiting
     bool both_crops_finite = false;    // set by mvs_register_crops around its mvs_score_candidates call (under the context lock)
     bool reg_unfused = false;          // test switch: the phase correlation runs its separate launches (pack, cross power, peak search, min / max) instead of the fused passes
+    bool score_argmax_only = false;    // set by mvs_register_crops around its mvs_score_candidates call: only the arg-max candidate is needed
+    double score_value_bound = INFINITY;   // ... with the largest absolute value of the two (rescaled) crops
+    bool ssim_prune = true;            // option "ssim_prune" (default 1; environment MVS_SSIM_PRUNE=0 turns it off for new contexts)
     bool ssim_two_pass = false;        // test switch: batched candidates go through the separate z and y/x SSIM launches instead of the fused walk
     bool materialize_shifts = false;   // test switch: candidate scoring always writes the shifted copies (no on-the-fly SSIM z pass)
     std::recursive_mutex mu;      // recursive: composite entry points (mvs_pair.hip) call the public ones under the lock
@@ -113,9 +117,11 @@ static inline int mvs_alloc_failed(const MvsContext* c) { return c->last_code ? 
 #define MVS_HIP_TRY(c, expr)                                                         \
     do {                                                                             \
         hipError_t _e = (expr);                                                      \
-        if (_e != hipSuccess)                                                        \
+        if (_e != hipSuccess) {                                                      \
+            (void)hipGetLastError(); /* the runtime keeps the error for the next hipGetLastError(): it is reported here, once */ \
             return mvs_fail((c), _e == hipErrorOutOfMemory ? MVS_ERR_OUT_OF_MEMORY : MVS_ERR_HIP,  \
                             "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+        }                                                                            \
     } while (0)
 
 static inline size_t mvs_dtype_size(int dtype) {

@@ -150,9 +150,15 @@ extern "C" int mvs_register_crops(int device, const float* fixed, const float* m
     c->raw_u16_keys[0] = c->materialize_shifts ? nullptr : raw_keys0;
     c->raw_u16_keys[1] = c->materialize_shifts ? nullptr : raw_keys1;
     c->raw_range[0] = min0; c->raw_range[1] = max0; c->raw_range[2] = min1; c->raw_range[3] = max1;
+    // only the arg-max candidate (and its rank correlation) leaves this function: the scoring may stop a candidate as soon as
+    // it provably cannot win (see the pruned search in mvs_score_candidates); the rescaled values lie in [lo, hi]
+    c->score_argmax_only = true;
+    c->score_value_bound = (double)std::max(std::max(std::fabs(lo0), std::fabs(hi0)), std::max(std::fabs(lo1), std::fabs(hi1)));
     rc = mvs_score_candidates(device, r0, r1, MVS_MEM_DEVICE, ndim, shape, uniq.data(), n_uniq, region_mode, (double)data_range, im1_min, 0,
                               ssim_u.data(), spear_u.data(), code_u.data());
     c->both_crops_finite = false;
+    c->score_argmax_only = false;
+    c->score_value_bound = INFINITY;
     c->raw_u16_keys[0] = c->raw_u16_keys[1] = nullptr;
     if (rc) return rc;
     int n_scored = 0;      // candidates that went through the shift + SSIM kernels (the others were rejected from their boxes)

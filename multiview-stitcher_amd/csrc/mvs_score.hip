@@ -605,7 +605,9 @@ __global__ __launch_bounds__(256) void ssim_yx_batch_kernel(YxBatch B, float* __
 // offset, so a sample costs no address arithmetic (the kernel is bound by the float64 filter arithmetic: ~300 of its ~580
 // vector instructions per plane are f64 adds / multiplies / conversions, all at 1/2 of the fp32 issue rate on gfx950).
 // A candidate is its shifted copy (dz = dy = dx = 0) or, for an integer shift, the moving crop itself read in place.
-struct FusedCand { const float* src; int dz, dy, dx; };
+// sel: the work items (tile x z segment, numbered x fastest) this launch walks for the candidate, as a set of residues of the
+// item number modulo 16 -- 0xffff: all of them; the pruned argmax search (mvs_score_candidates) scores a candidate in rounds
+struct FusedCand { const float* src; int dz, dy, dx; unsigned int sel; };
 struct FusedBatch { FusedCand c[kMaxResident]; };
 template <int WIN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
@@ -621,7 +623,8 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
     __shared__ float sz_[3][LY][LX + 1];             // z-filtered y, yy, xy of the current plane (tile + halo)
     __shared__ float sy_[3][TY][LX + 1];             // ... filtered along y as well
     const FusedCand C = B.c[blockIdx.y];
-    if (!C.src) return;
+    const int nselres = __popc(C.sel & 0xffffu);
+    if (!C.src || nselres == 0) return;
     const int tid = threadIdx.x, col = tid & 63, wrow = tid >> 6;
     const int cz = S.nz - 2 * pad, cy = S.ny - 2 * pad, cx = S.nx - 2 * pad;
     float mx = -INFINITY;
@@ -635,7 +638,12 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
         const int nty = (cy + TY - 1) / TY, ntx = (cx + TX - 1) / TX, nzs = (cz + zseg - 1) / zseg;
         const int nitems = nty * ntx * nzs;
         const int sy = S.nx, sz = S.ny * S.nx;
-        for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const int nsel = ((nitems + 15) >> 4) * nselres;             // selected items: residue k of group g is number g * nselres + k
+        for (int si = blockIdx.x; si < nsel; si += gridDim.x) {
+            unsigned int rest = C.sel & 0xffffu;
+            for (int k = si % nselres; k > 0; --k) rest &= rest - 1;  // (uniform: scalar work)
+            const int item = (si / nselres) * 16 + (__ffs(rest) - 1);
+            if (item >= nitems) continue;
             const int tx = item % ntx, ty = (item / ntx) % nty, zs = item / (ntx * nty);
             const int z0 = pad + zs * zseg, z1 = min(z0 + zseg, S.nz - pad);
             const int y0 = pad + ty * TY, x0 = pad + tx * TX;
@@ -883,12 +891,13 @@ void ssim_fixed_walk_kernel(const float* __restrict__ im0, Shape3 S, float* __re
 
 // folds the per-workgroup partials of one candidate's SSIM passes
 __global__ __launch_bounds__(256) void finish_region_kernel(const float* __restrict__ pmax, const int* __restrict__ phasnan,
-                                                            const double* __restrict__ psum, RegionStats* __restrict__ out) {
+                                                            const double* __restrict__ psum, RegionStats* __restrict__ out,
+                                                            int nblk = kStatBlocks) {
     const size_t o = (size_t)blockIdx.x * kStatBlocks;
     float mx = -INFINITY;
     int hn = 0;
     double sum = 0.0;
-    for (int i = threadIdx.x; i < kStatBlocks; i += 256) { mx = fmaxf(mx, pmax[o + i]); hn |= phasnan[o + i]; sum += psum[o + i]; }
+    for (int i = threadIdx.x; i < nblk; i += 256) { mx = fmaxf(mx, pmax[o + i]); hn |= phasnan[o + i]; sum += psum[o + i]; }
     for (int off = 32; off > 0; off >>= 1) {
         mx = fmaxf(mx, __shfl_down(mx, off)); hn |= __shfl_down(hn, off); sum += __shfl_down(sum, off);
     }
@@ -1691,7 +1700,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         for (int j = 0; j < nb; ++j) {
             first_batch.c[j] = FirstCand{nullptr, nullptr, nullptr, nullptr, ShiftArg{0.0, 0.0, 0.0, 0}, 0};
             yx_batch.c[j] = YxCand{nullptr, nullptr, nullptr};
-            fused_batch.c[j] = FusedCand{nullptr, 0, 0, 0};
+            fused_batch.c[j] = FusedCand{nullptr, 0, 0, 0, 0xffffu};
         }
         for (int j = 0; j < nb; ++j) {
             const int ic = todo[b0 + j];
@@ -1740,9 +1749,9 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 float* d1 = cand3[(size_t)3 * j], *d3 = cand3[(size_t)3 * j + 1], *d4 = cand3[(size_t)3 * j + 2];
                 first_batch.c[j] = FirstCand{second, d1, d3, d4, shifts[j], otf[j] ? 1 : 0};
                 yx_batch.c[j] = YxCand{d1, d3, d4};
-                fused_batch.c[j] = otf[j] ? FusedCand{im1, (int)shifts[j].tz, (int)shifts[j].ty, (int)shifts[j].tx}
-                                   : cls_of[j] >= 0 ? FusedCand{cls[cls_of[j]].buf, (int)std::floor(shifts[j].tz), (int)std::floor(shifts[j].ty), (int)std::floor(shifts[j].tx)}
-                                                    : FusedCand{im1t_buf[j], 0, 0, 0};
+                fused_batch.c[j] = otf[j] ? FusedCand{im1, (int)shifts[j].tz, (int)shifts[j].ty, (int)shifts[j].tx, 0xffffu}
+                                   : cls_of[j] >= 0 ? FusedCand{cls[cls_of[j]].buf, (int)std::floor(shifts[j].tz), (int)std::floor(shifts[j].ty), (int)std::floor(shifts[j].tx), 0xffffu}
+                                                    : FusedCand{im1t_buf[j], 0, 0, 0, 0xffffu};
                 any_batched = true;
                 batch_cov_norm = cov_norm;
             }
@@ -1752,22 +1761,126 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             else launch_ssim_passes<3>(c->stream, im0, second, S, lo, R, ndim, setA, setB, cov_norm, C1, C2, pm, ph, ps, sa);
             scored[j] = true;
         }
+        RegionStats h_rs[kMaxResident];
+        bool have_rs = false;
         if (any_batched && !c->ssim_two_pass) {
             const int tiles = ((S.ny - 6 + 15) / 16) * ((S.nx - 6 + 55) / 56), cz = S.nz - 6;
-            // ~1536 workgroups (two resident rounds of 3 per CU): 243 instead of 282 us per pair with 768 -- a workgroup spends its
-            // time waiting (two barriers and a load round trip per plane), so a second round hides more than its 6 halo planes cost
-            const int nzs = std::max(1, std::min(1536 / std::max(tiles * nb, 1), (cz + 7) / 8));
-            hipLaunchKernelGGL(ssim_fused_batch_kernel<7>, dim3(kStatBlocks, nb), dim3(256), 0, c->stream, im0, S, fused_batch, setB[2], setB[3],
-                               (cz + nzs - 1) / nzs, batch_cov_norm, C1, C2, pmax, phasnan, psum);
+            // ---- pruned argmax search (the caller needs the arg-max candidate only: mvs_register_crops) -------------------------------
+            // The SSIM of a candidate is the mean of per-voxel values S <= 1 (S = l * cs with l <= 1 by the AM-GM inequality and
+            // |cs| <= 1 by Cauchy-Schwarz; the float32 window means move a variance by at most a few 2^-23 M^2, M the largest value,
+            // against C2 = (0.03 R)^2 in the denominator: S <= 1 + slack with the slack below).  So once ONE candidate is scored
+            // completely (sum S*), a candidate with partial sum p over n of the N voxels can at best reach p + (N - n)(1 + slack); if
+            // that is below S* it cannot be the arg max, whatever the rest of its volume holds -- the reference's nanargmax picks the
+            // same candidate, and the Spearman coefficient is only ever evaluated for that one.  All candidates are walked on 1 / 16 of
+            // the work items (spread over the volume), the leader is completed, the others continue in rounds (to 1/4, 1/2, all) only
+            // while their bound still reaches the best complete sum.  The wrong-sign / wrapped candidates of a registered pair score
+            // ~0.1 against ~0.9 and leave after the first round: ~1.5 instead of ~9 candidate volumes per pair.
+            bool prune = c->score_argmax_only && c->ssim_prune && todo.size() <= (size_t)nres;
+            int n_in = 0;
+            for (int j = 0; j < nb; ++j) {
+                if (fused_batch.c[j].src) ++n_in;
+                else if (scored[j]) prune = false;          // a candidate on the separate passes: everything is scored in full
+            }
+            const double vb = c->score_value_bound;
+            const double slack = 1e-2 * std::max(1.0, (vb / data_range) * (vb / data_range));
+            prune = prune && n_in >= 2 && data_range > 0.0 && std::isfinite(slack) && slack <= 0.05;
+            if (!prune) {
+                // ~1536 workgroups (two resident rounds of 3 per CU): 243 instead of 282 us per pair with 768 -- a workgroup spends its
+                // time waiting (two barriers and a load round trip per plane), so a second round hides more than its 6 halo planes cost
+                const int nzs = std::max(1, std::min(1536 / std::max(tiles * nb, 1), (cz + 7) / 8));
+                hipLaunchKernelGGL(ssim_fused_batch_kernel<7>, dim3(kStatBlocks, nb), dim3(256), 0, c->stream, im0, S, fused_batch, setB[2], setB[3],
+                                   (cz + nzs - 1) / nzs, batch_cov_norm, C1, C2, pmax, phasnan, psum);
+                c->reg_cand_volumes += (double)n_in;
+            } else {
+                const int cy = S.ny - 6, cx = S.nx - 6, nty = (cy + 15) / 16, ntx = (cx + 55) / 56;
+                const int nzs0 = std::max(1, std::min(320 / std::max(tiles, 1), (cz + 7) / 8));
+                const int zseg = (cz + nzs0 - 1) / nzs0, nzs = (cz + zseg - 1) / zseg, nitems = nty * ntx * nzs;
+                double vol_res[16];                     // output voxels of the work items of every residue class (the kernel's own geometry)
+                for (int r = 0; r < 16; ++r) vol_res[r] = 0.0;
+                for (int item = 0; item < nitems; ++item) {
+                    const int tx = item % ntx, ty = (item / ntx) % nty, zs = item / (ntx * nty);
+                    const int z0 = 3 + zs * zseg, z1 = std::min(z0 + zseg, S.nz - 3);
+                    vol_res[item & 15] += (double)(z1 - z0) * (double)std::min(16, cy - ty * 16) * (double)std::min(56, cx - tx * 56);
+                }
+                const double Ntot = (double)cz * (double)cy * (double)cx;
+                auto vol_of = [&](unsigned int m) { double v = 0.0; for (int r = 0; r < 16; ++r) if ((m >> r) & 1u) v += vol_res[r]; return v; };
+                double acc[kMaxResident];
+                float amx[kMaxResident];
+                int ahn[kMaxResident];
+                unsigned int done[kMaxResident], masks[kMaxResident];
+                for (int j = 0; j < kMaxResident; ++j) { acc[j] = 0.0; amx[j] = -INFINITY; ahn[j] = 0; done[j] = 0; masks[j] = 0; }
+                auto run_round = [&]() -> int {
+                    FusedBatch fb = fused_batch;
+                    int maxsel = 0;
+                    for (int j = 0; j < nb; ++j) {
+                        fb.c[j].sel = masks[j];
+                        if (!masks[j] || !fb.c[j].src) { fb.c[j].src = nullptr; masks[j] = 0; continue; }
+                        maxsel = std::max(maxsel, ((nitems + 15) >> 4) * __builtin_popcount(masks[j]));
+                    }
+                    if (maxsel == 0) return MVS_OK;
+                    const int gx = std::min(kStatBlocks, maxsel);
+                    hipLaunchKernelGGL(ssim_fused_batch_kernel<7>, dim3(gx, nb), dim3(256), 0, c->stream, im0, S, fb, setB[2], setB[3], zseg,
+                                       batch_cov_norm, C1, C2, pmax, phasnan, psum);
+                    hipLaunchKernelGGL(finish_region_kernel, dim3(nb), dim3(256), 0, c->stream, pmax, phasnan, psum, reg_out, gx);
+                    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+                    for (int j = 0; j < nb; ++j) {
+                        if (!masks[j]) continue;
+                        acc[j] += h_reg[j].ssim_sum;
+                        amx[j] = fmaxf(amx[j], h_reg[j].mx);
+                        ahn[j] |= h_reg[j].hasnan;
+                        done[j] |= masks[j];
+                        masks[j] = 0;
+                    }
+                    return MVS_OK;
+                };
+                for (int j = 0; j < nb; ++j) masks[j] = fused_batch.c[j].src ? 0x0001u : 0u;
+                rc = run_round();
+                if (rc) return rc;
+                int leader = -1;
+                for (int j = 0; j < nb; ++j)
+                    if (fused_batch.c[j].src && (leader < 0 || acc[j] > acc[leader])) leader = j;
+                masks[leader] = 0xfffeu;
+                rc = run_round();
+                if (rc) return rc;
+                double s_best = acc[leader];
+                bool pruned[kMaxResident];
+                double ub[kMaxResident];
+                for (int j = 0; j < kMaxResident; ++j) { pruned[j] = false; ub[j] = 0.0; }
+                const unsigned int stages[3] = {0x000eu, 0x00f0u, 0xff00u};
+                for (int st = 0; st <= 3; ++st) {
+                    bool more = false;
+                    for (int j = 0; j < nb; ++j) {
+                        if (!fused_batch.c[j].src || done[j] == 0xffffu || pruned[j]) continue;
+                        // (a candidate whose samples so far do not exceed im1_min may still be the reference's `continue` case: in full)
+                        ub[j] = acc[j] + (Ntot - vol_of(done[j])) * (1.0 + slack);
+                        if ((double)amx[j] > im1_min && ub[j] < s_best - 1e-9 * Ntot) { pruned[j] = true; continue; }
+                        if (st < 3) { masks[j] = stages[st]; more = true; }
+                    }
+                    if (!more) break;
+                    rc = run_round();
+                    if (rc) return rc;
+                    for (int j = 0; j < nb; ++j)
+                        if (fused_batch.c[j].src && done[j] == 0xffffu && acc[j] > s_best) s_best = acc[j];
+                }
+                for (int j = 0; j < nb; ++j) {
+                    h_rs[j].mx = amx[j];
+                    h_rs[j].hasnan = ahn[j];
+                    h_rs[j].ssim_sum = pruned[j] ? ub[j] : acc[j];        // pruned: the bound it could not exceed (< the best sum)
+                    if (fused_batch.c[j].src) {
+                        c->reg_cand_volumes += vol_of(done[j]) / Ntot;
+                        c->reg_pruned += pruned[j] ? 1 : 0;
+                    }
+                }
+                have_rs = true;
+            }
         } else if (any_batched) {
             hipLaunchKernelGGL(ssim_first_pass_batch_kernel<7>, dim3(kStatBlocks, nb), dim3(256), 0, c->stream, im0, S, first_batch, pmax, phasnan);
             hipLaunchKernelGGL(ssim_yx_batch_kernel<7>, dim3(kStatBlocks, nb), dim3(256), 0, c->stream, yx_batch, setB[2], setB[3], S, batch_cov_norm, C1, C2, psum);
         }
-        RegionStats h_rs[kMaxResident];
         bool any = false;
         for (int j = 0; j < nb; ++j) any = any || scored[j];
-        if (any) {
-            hipLaunchKernelGGL(finish_region_kernel, dim3(nb), dim3(256), 0, c->stream, pmax, phasnan, psum, reg_out);
+        if (any && !have_rs) {
+            hipLaunchKernelGGL(finish_region_kernel, dim3(nb), dim3(256), 0, c->stream, pmax, phasnan, psum, reg_out, kStatBlocks);
             MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
             for (int j = 0; j < nb; ++j) h_rs[j] = h_reg[j];
         }

@@ -73,6 +73,12 @@ def test_out_of_memory_has_its_own_code_and_exception(hip_device):
     # the context is still usable afterwards
     buf = _lib.DeviceBuffer(0, 1 << 20)
     buf.free()
+    # ... and the failed allocation does not linger in the runtime's per-thread "last error": the next call that checks
+    # hipGetLastError() after its launches (mvs_resample) must come back clean
+    from multiview_stitcher_amd import transformation
+    src = np.arange(64, dtype=np.float32).reshape(4, 4, 4)
+    got = transformation.resample_array(src, np.eye(3), np.zeros(3), (4, 4, 4), 1, 0.0, 0)
+    np.testing.assert_array_equal(got, src)
     with pytest.raises(_lib.MvsError) as ei:
         _lib.set_option("rowlds", 1)                                             # retired in round 3
     assert ei.value.code == -1 and not isinstance(ei.value, _lib.DeviceMemoryError)

@@ -578,3 +578,37 @@ def test_fused_ssim_walk_equals_separate_passes_and_oracle(hip_device, shape):
         assert code == c1[i]
         if code == 0:
             assert abs(s1[i] - s) <= 2e-5 * max(abs(s), 1e-3)
+
+
+@pytest.mark.parametrize("shape,shift,noise", [((40, 96, 120), (2, -3, 4), 0.0), ((40, 96, 120), (2, -3, 4), 0.02),
+                                               ((40, 96, 120), (2, -3, 4), 0.08), ((40, 96, 120), (1, 0, -5), 0.3),
+                                               ((96, 40, 130), (-3, 2, 6), 0.01), ((120, 100, 36), (5, -4, 1), 0.05)])
+def test_pruned_argmax_search_equals_full_scoring(hip_device, shape, shift, noise):
+    """mvs_register_crops needs the arg-max candidate only: candidates whose SSIM bound (partial sum + (1 + slack) per voxel
+    not yet visited) falls below a completely scored one are not finished (option "ssim_prune", default on).  The selected
+    translation, the quality and the status are those of the full scoring -- bit for bit, at every noise level (clean pairs
+    prune after 1/16 of the volume, noisy ones later or never) -- and those of the oracle."""
+    from multiview_stitcher_amd import _lib, _reg_ops
+
+    a, b = _pair(shape, shift, seed=3, sigma=1.5, noise=noise)
+    res = {}
+    stats = {}
+    for flag in (1, 0):
+        _lib.set_option("ssim_prune", flag)
+        try:
+            for key in ("reg_pruned", "reg_cand_volumes", "reg_candidates"):
+                _lib.get_counter(key, reset=True)
+            res[flag] = _reg_ops.register_crops(a, b, 2)
+            stats[flag] = {key: _lib.get_counter(key, reset=True) for key in ("reg_pruned", "reg_cand_volumes", "reg_candidates")}
+        finally:
+            _lib.set_option("ssim_prune", 1)
+    np.testing.assert_array_equal(res[1][0], res[0][0])
+    assert res[1][1] == res[0][1] and res[1][2:] == res[0][2:]
+    want = ro.phase_correlation_registration(a, b)
+    np.testing.assert_array_equal(res[1][0], want["affine_matrix"][:-1, -1])
+    assert abs(res[1][1] - want["quality"]) <= 1e-5
+    assert stats[0]["reg_pruned"] == 0 and stats[0]["reg_cand_volumes"] == stats[0]["reg_candidates"]
+    assert stats[1]["reg_cand_volumes"] <= stats[1]["reg_candidates"] + 1e-9
+    if noise == 0.0:      # the wrong-sign candidates of a clean pair leave after the first round
+        assert stats[1]["reg_pruned"] >= stats[1]["reg_candidates"] - 2, stats
+        assert stats[1]["reg_cand_volumes"] < 0.4 * stats[1]["reg_candidates"], stats
