@@ -627,7 +627,7 @@ def main():
     for lst in (kernel_ms, reg_ms, fuse_ms, pair_ms, plan_ms):
         lst.clear()
     for lane in range(16):
-        for key in ("reg_alg_bytes", "reg_pairs", "reg_candidates"):
+        for key in ("reg_alg_bytes", "reg_pairs", "reg_candidates", "reg_pruned", "reg_cand_volumes"):
             _lib.get_counter(key, local_rank | (lane << 8), reset=True)
     torch.cuda.synchronize()
     if world > 1:
@@ -648,6 +648,8 @@ def main():
     reg_bytes = sum(_lib.get_counter("reg_alg_bytes", local_rank | (lane << 8)) for lane in range(16))
     reg_pairs = sum(_lib.get_counter("reg_pairs", local_rank | (lane << 8)) for lane in range(16))
     reg_cands = sum(_lib.get_counter("reg_candidates", local_rank | (lane << 8)) for lane in range(16))
+    reg_pruned = sum(_lib.get_counter("reg_pruned", local_rank | (lane << 8)) for lane in range(16))
+    reg_cand_vols = sum(_lib.get_counter("reg_cand_volumes", local_rank | (lane << 8)) for lane in range(16))
 
     fused = out_holder["fused"]
     out_shape = fused.shape
@@ -746,6 +748,9 @@ def main():
                 "pairwise_ms_per_step": pair_wall_ms,
                 "pairs_per_step_rank0": reg_pairs / max(args.steps, 1) if do_register else None,
                 "scored_candidates_per_pair": (reg_cands / reg_pairs) if reg_pairs else None,
+                "ssim_prune": os.environ.get("MVS_SSIM_PRUNE", "1") != "0",
+                "candidates_left_unfinished_per_pair": (reg_pruned / reg_pairs) if reg_pairs else None,
+                "candidate_volumes_walked_per_pair": (reg_cand_vols / reg_pairs) if reg_pairs else None,
                 "fuse_ms_per_step": float(np.mean(fuse_ms)),
                 "fuse_kernel_ms": k_ms,
                 "fuse_plan_cold_ms": cold_plan_ms,
@@ -768,7 +773,7 @@ def main():
                 "bound": "hbm",
                 "kernel": "pairwise registrations of rank 0 (binning, crops, FFTs, cross power, argmax, upsampled DFT, shifts, SSIM, ranks)",
                 "algorithmic_bytes_per_step": reg_bytes / args.steps,
-                "model": "SURVEY 8d: per pair of n binned overlap voxels 2 x 28 n (phase correlation, two normalisations) + 20 n per scored candidate + 64 n (rank correlation)",
+                "model": "SURVEY 8d: per pair of n binned overlap voxels 2 x 28 n (phase correlation, two normalisations) + 20 n per candidate VOLUME the SSIM walk went through (a candidate the pruned arg-max search stopped counts the fraction it was scored on: config.candidate_volumes_walked_per_pair) + 64 n (rank correlation)",
                 "duration_ms": pair_wall_ms,
                 "achieved": reg_bytes / args.steps / (pair_wall_ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBS,

@@ -154,6 +154,7 @@ extern "C" int mvs_register_crops(int device, const float* fixed, const float* m
     // it provably cannot win (see the pruned search in mvs_score_candidates); the rescaled values lie in [lo, hi]
     c->score_argmax_only = true;
     c->score_value_bound = (double)std::max(std::max(std::fabs(lo0), std::fabs(hi0)), std::max(std::fabs(lo1), std::fabs(hi1)));
+    const double cand_vol0 = c->reg_cand_volumes;
     rc = mvs_score_candidates(device, r0, r1, MVS_MEM_DEVICE, ndim, shape, uniq.data(), n_uniq, region_mode, (double)data_range, im1_min, 0,
                               ssim_u.data(), spear_u.data(), code_u.data());
     c->both_crops_finite = false;
@@ -163,7 +164,10 @@ extern "C" int mvs_register_crops(int device, const float* fixed, const float* m
     if (rc) return rc;
     int n_scored = 0;      // candidates that went through the shift + SSIM kernels (the others were rejected from their boxes)
     for (int u = 0; u < n_uniq; ++u) n_scored += (code_u[u] == 0) ? 1 : 0;
-    c->reg_alg_bytes += (double)n * (2.0 * 28.0 + 20.0 * (double)n_scored + 64.0);
+    // candidate volumes the SSIM walk went through: a candidate the pruned search stopped counts the fraction it was scored on
+    double cand_vol = c->reg_cand_volumes - cand_vol0;
+    if (!(cand_vol > 0.0)) { cand_vol = (double)n_scored; c->reg_cand_volumes = cand_vol0 + cand_vol; }   // (paths that do not count themselves)
+    c->reg_alg_bytes += (double)n * (2.0 * 28.0 + 20.0 * cand_vol + 64.0);
     c->reg_pairs += 1;
     c->reg_candidates += n_scored;
 

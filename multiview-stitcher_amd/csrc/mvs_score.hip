@@ -1793,7 +1793,8 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 c->reg_cand_volumes += (double)n_in;
             } else {
                 const int cy = S.ny - 6, cx = S.nx - 6, nty = (cy + 15) / 16, ntx = (cx + 55) / 56;
-                const int nzs0 = std::max(1, std::min(320 / std::max(tiles, 1), (cz + 7) / 8));
+                static const int target_items = [] { const char* e = getenv("MVS_SSIM_PRUNE_ITEMS"); return (e && atoi(e) > 0) ? atoi(e) : 320; }();
+                const int nzs0 = std::max(1, std::min(target_items / std::max(tiles, 1), (cz + 7) / 8));
                 const int zseg = (cz + nzs0 - 1) / nzs0, nzs = (cz + zseg - 1) / zseg, nitems = nty * ntx * nzs;
                 double vol_res[16];                     // output voxels of the work items of every residue class (the kernel's own geometry)
                 for (int r = 0; r < 16; ++r) vol_res[r] = 0.0;
@@ -1839,28 +1840,50 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 int leader = -1;
                 for (int j = 0; j < nb; ++j)
                     if (fused_batch.c[j].src && (leader < 0 || acc[j] > acc[leader])) leader = j;
-                masks[leader] = 0xfffeu;
-                rc = run_round();
-                if (rc) return rc;
-                double s_best = acc[leader];
                 bool pruned[kMaxResident];
                 double ub[kMaxResident];
                 for (int j = 0; j < kMaxResident; ++j) { pruned[j] = false; ub[j] = 0.0; }
-                const unsigned int stages[3] = {0x000eu, 0x00f0u, 0xff00u};
-                for (int st = 0; st <= 3; ++st) {
+                bool have_best = false;
+                double s_best = 0.0;
+                static const bool dbg = getenv("MVS_PRUNE_DEBUG") != nullptr;
+                for (int round = 0; round < 18; ++round) {
+                    // Plan: the leader is completed; every other open candidate advances to the fraction at which its bound would
+                    // fall below the reference sum if its mean stayed what it is so far (residues are taken in rising order; the
+                    // reference is the best complete sum, before there is one the leader's extrapolated sum -- a guess that only
+                    // sizes the round: candidates are dropped against complete sums alone).
+                    const double s_ref = have_best ? s_best : acc[leader] / std::max(vol_of(done[leader]), 1.0) * Ntot;
                     bool more = false;
                     for (int j = 0; j < nb; ++j) {
                         if (!fused_batch.c[j].src || done[j] == 0xffffu || pruned[j]) continue;
-                        // (a candidate whose samples so far do not exceed im1_min may still be the reference's `continue` case: in full)
-                        ub[j] = acc[j] + (Ntot - vol_of(done[j])) * (1.0 + slack);
-                        if ((double)amx[j] > im1_min && ub[j] < s_best - 1e-9 * Ntot) { pruned[j] = true; continue; }
-                        if (st < 3) { masks[j] = stages[st]; more = true; }
+                        const int k_done = __builtin_popcount(done[j]);
+                        int k_to = 16;
+                        if (j != leader && (double)amx[j] > im1_min) {
+                            const double mean_c = acc[j] / std::max(vol_of(done[j]), 1.0);
+                            const double den = (1.0 + slack) - mean_c;
+                            const double f = den > 0.0 ? ((1.0 + slack) - s_ref / Ntot) / den : 2.0;
+                            if (f < 1.0) k_to = std::min(16, std::max(k_done + 1, (int)std::ceil(16.0 * f * 1.15 + 0.25)));
+                            if (k_to >= 12) k_to = 16;
+                        }
+                        masks[j] = ((1u << k_to) - 1u) & ~((1u << k_done) - 1u);
+                        more = true;
                     }
                     if (!more) break;
                     rc = run_round();
                     if (rc) return rc;
                     for (int j = 0; j < nb; ++j)
-                        if (fused_batch.c[j].src && done[j] == 0xffffu && acc[j] > s_best) s_best = acc[j];
+                        if (fused_batch.c[j].src && done[j] == 0xffffu && (!have_best || acc[j] > s_best)) { s_best = acc[j]; have_best = true; }
+                    for (int j = 0; j < nb; ++j) {
+                        if (!fused_batch.c[j].src || done[j] == 0xffffu || pruned[j]) continue;
+                        // (a candidate whose samples so far do not exceed im1_min may still be the reference's `continue` case: in full)
+                        ub[j] = acc[j] + (Ntot - vol_of(done[j])) * (1.0 + slack);
+                        if ((double)amx[j] > im1_min && ub[j] < s_best - 1e-9 * Ntot) pruned[j] = true;
+                    }
+                }
+                if (dbg) {
+                    fprintf(stderr, "prune: best %.4f |", s_best / Ntot);
+                    for (int j = 0; j < nb; ++j)
+                        if (fused_batch.c[j].src) fprintf(stderr, " %d/16:%.3f%s", __builtin_popcount(done[j]), acc[j] / std::max(vol_of(done[j]), 1.0), pruned[j] ? "x" : "");
+                    fprintf(stderr, "\n");
                 }
                 for (int j = 0; j < nb; ++j) {
                     h_rs[j].mx = amx[j];
