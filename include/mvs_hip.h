@@ -127,11 +127,19 @@ int mvs_synchronize(int device);
  * <= 19 run on the Bluestein kernels instead of the whole-line register transforms (mvs_dft_small.h; equal to float32 rounding).
  * "cb_unpaired" = 1: content-based weights filter value and mask lines in separate launches with separate preparation / quotient
  * kernels (rounds 1-3) instead of gauss1d_pair_kernel; "cb_nosplit" = 1: the paired path keeps both quantities in one workgroup
- * on every pass (all three bit for bit equal; tests compare). */
+ * on every pass (all three bit for bit equal; tests compare).  "ssim_prune" = 0: mvs_register_crops / mvs_register_views score
+ * every candidate completely (default 1: the arg-max search below; the environment variable MVS_SSIM_PRUNE=0 sets the default
+ * of every context created afterwards).  The reference keeps only the candidate with the best SSIM and its rank correlation
+ * (registration.py:558-565), and the per-voxel SSIM is <= 1, so a candidate whose partial sum plus (1 + slack) per voxel not
+ * yet visited is below the sum of a completely scored candidate cannot win: the candidates of a pair are walked in rounds over
+ * growing parts of the volume and dropped as soon as that holds (same selected translation, same quality, same status --
+ * tests compare both settings and the oracle).  mvs_score_candidates itself always scores in full. */
 int mvs_set_option(int device, const char* key, int64_t value);
 /* Measurement counters of one context (bench.py): "reg_alg_bytes" = algorithmic HBM bytes of the pairwise registrations
  * since the last reset (28 n per phase-correlation variant + 20 n per scored candidate + 64 n for the rank correlation, n = crop
- * voxels), "reg_pairs", "reg_candidates", "fuse_plan_ms" = host time the last mvs_fuse_chunk spent decomposing the chunk
+ * voxels; a candidate the arg-max search stopped counts the fraction of its volume it was scored on), "reg_pairs",
+ * "reg_candidates" (candidates that entered the scoring), "reg_pruned" (of these, left unfinished), "reg_cand_volumes"
+ * (candidate volumes the SSIM passes went through), "fuse_plan_ms" = host time the last mvs_fuse_chunk spent decomposing the chunk
  * (0 when the plan cached for the same geometry was reused).  reset != 0 clears an accumulating counter after reading. */
 int mvs_get_counter(int device, const char* key, int32_t reset, double* value_out);
 /* Device time (ms, hipEvent) spent in the kernels of the most recent compute

@@ -56,6 +56,10 @@ class RegGraph:
     def connected_components(self, edges=None):
         """Components in order of their first node (nx.connected_components)."""
         edges = list(self.edges if edges is None else edges)
+        adj = {}                                  # neighbours in edge order (what neighbors() returns), built in one pass
+        for a, b in edges:
+            adj.setdefault(a, []).append(b)
+            adj.setdefault(b, []).append(a)
         seen, comps = set(), []
         for start in self.nodes:
             if start in seen:
@@ -63,7 +67,7 @@ class RegGraph:
             comp, stack = {start}, [start]
             while stack:
                 v = stack.pop()
-                for w in self.neighbors(v, edges):
+                for w in adj.get(v, ()):
                     if w not in comp:
                         comp.add(w)
                         stack.append(w)
@@ -137,7 +141,12 @@ def compute_edge_residuals(g, params):
 
 def get_node_with_maximal_edge_weight_sum_from_graph(g, weight_key="quality"):
     """mv_graph.py:341-352 (first maximum in node order)."""
-    totals = {n: np.sum([e[weight_key] for k, e in g.edges.items() if n in k]) for n in g.nodes}
+    per_node = {n: [] for n in g.nodes}           # the weights of a node's edges in edge order, gathered in one pass
+    for k, e in g.edges.items():
+        per_node[k[0]].append(e[weight_key])
+        if k[1] != k[0]:
+            per_node[k[1]].append(e[weight_key])
+    totals = {n: np.sum(w) for n, w in per_node.items()}
     return max(totals, key=totals.get)
 
 
