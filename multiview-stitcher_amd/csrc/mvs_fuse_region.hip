@@ -1083,6 +1083,10 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
                         R.ids[nv++] = v;
                     }
                     if (nv > 0 && all_positive) R.allone_mask |= 1 << 15;
+                    // profiling only (WRONG results): every view counts as a full unit view, i.e. every brick takes the plain-average
+                    // path -- the floor of what the weight evaluation can be brought down to
+                    static const bool ablate_unit = getenv("MVS_FUSE_ALL_UNIT") != nullptr;
+                    if (ablate_unit) R.allone_mask = ((1 << nv) - 1) | (1 << 15);
                     // brick width: 16 voxels for thin boxes, 512 (one full tile row per load instruction: the longest
                     // contiguous runs, 4.0 instead of 3.0 TB/s on the copy class) for wide copy-class boxes, else 128
                     int lxb = (R.x1 - R.x0 <= 32) ? 1 : 4;
@@ -1090,6 +1094,8 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
                     // overlap zones along x (about 100 voxels wide): 64-voxel bricks, so that each brick holds only ONE of the
                     // zone's two ramp ends and the other view classifies as "unit" (measured best of 16/32/64/128)
                     if (nv >= 2 && R.x1 - R.x0 > 32 && R.x1 - R.x0 <= 136) lxb = 3;
+                    // (measured, round 4: 256- / 512-voxel bricks for the wide NV >= 2 boxes -- the copy class's layout -- lose:
+                    // launch 10.06 -> 10.3 / 11.2 ms; every wavefront then spans a ramp end and takes the per-voxel weights)
                     R.nviews = nv | (lxb << 8);
                     const int rid = (int)regions.size();
                     if (rid >= 65536) return MVS_OK;
