@@ -1081,6 +1081,66 @@ __global__ __launch_bounds__(256) void blend_kernel(DevView V, float* out, int o
     }
 }
 
+// ---- the boxes of ALL views of a chunk in one launch each (content-based weights, mvs_gauss.hip): a chunk of a tile grid sees one
+// view nearly whole and up to seven by a face, an edge or a corner, i.e. seven launches of a few microseconds of work each per
+// quantity, which cost their launch latency one after the other on the chunk's stream.  View v owns the workgroups
+// [blk0[v], blk0[v + 1]) of the launch (in proportion to its voxels); same arithmetic per voxel as crop_int_kernel / blend_kernel.
+struct BoxItem { const void* data; long long stride_z, stride_y; int nz, ny, nx, tz, ty, tx; float* out; int oz, oy, ox, z0, y0, x0; };
+struct BoxBatch { BoxItem v[8]; int blk0[9]; };
+template <typename TIn>
+__global__ __launch_bounds__(256) void crop_int_batch_kernel(BoxBatch B, float cval) {
+    typedef TIn in8_t __attribute__((ext_vector_type(8), aligned(sizeof(TIn))));
+    typedef float f4_t __attribute__((ext_vector_type(4), aligned(4)));
+    int v = 0;
+    while (v < 7 && (int)blockIdx.x >= B.blk0[v + 1]) ++v;
+    const BoxItem& C = B.v[v];
+    const int bx = (int)blockIdx.x - B.blk0[v], nbk = B.blk0[v + 1] - B.blk0[v];
+    const TIn* data = (const TIn*)C.data;
+    const int gpr = (C.ox + 7) / 8;
+    const long long ngroups = (long long)C.oz * C.oy * gpr;
+    for (long long g = (long long)bx * blockDim.x + threadIdx.x; g < ngroups; g += (long long)nbk * blockDim.x) {
+        const int xg = (int)(g % gpr) * 8;
+        const long long row = g / gpr;
+        const int y = (int)(row % C.oy), z = (int)(row / C.oy);
+        const int iz = z + C.tz, iy = y + C.ty, ix = xg + C.tx;
+        float* o = C.out + row * C.ox + xg;
+        const bool zy = iz >= 0 && iz < C.nz && iy >= 0 && iy < C.ny;
+        const TIn* p = data + (long long)iz * C.stride_z + (long long)iy * C.stride_y + ix;
+        if (zy && xg + 8 <= C.ox && ix >= 0 && ix + 8 <= C.nx) {
+            const in8_t q = *reinterpret_cast<const in8_t*>(p);
+            f4_t a, b;
+            a.x = (float)q[0]; a.y = (float)q[1]; a.z = (float)q[2]; a.w = (float)q[3];
+            b.x = (float)q[4]; b.y = (float)q[5]; b.z = (float)q[6]; b.w = (float)q[7];
+            *reinterpret_cast<f4_t*>(o) = a;
+            *reinterpret_cast<f4_t*>(o + 4) = b;
+        } else {
+            for (int j = 0; j < 8 && xg + j < C.ox; ++j) {
+                const bool in = zy && ix + j >= 0 && ix + j < C.nx;
+                o[j] = in ? (float)p[j] : cval;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void blend_batch_kernel(const DevView* __restrict__ views, BoxBatch B) {
+    int v = 0;
+    while (v < 7 && (int)blockIdx.x >= B.blk0[v + 1]) ++v;
+    const BoxItem& I = B.v[v];
+    const DevView& V = views[v];
+    const int bx = (int)blockIdx.x - B.blk0[v], nbk = B.blk0[v + 1] - B.blk0[v];
+    const long long n = (long long)I.oz * I.oy * I.ox;
+    for (long long i = (long long)bx * blockDim.x + threadIdx.x; i < n; i += (long long)nbk * blockDim.x) {
+        int x = (int)(i % I.ox);
+        long long t = i / I.ox;
+        int y = (int)(t % I.oy);
+        int z = (int)(t / I.oy);
+        const double pz = (double)(z + I.z0), py = (double)(y + I.y0), px = (double)(x + I.x0);
+        const double cz = ((pz * V.wm[0] + py * V.wm[1]) + px * V.wm[2]) + V.woff[0];
+        const double cy = ((pz * V.wm[3] + py * V.wm[4]) + px * V.wm[5]) + V.woff[1];
+        const double cx = ((pz * V.wm[6] + py * V.wm[7]) + px * V.wm[8]) + V.woff[2];
+        I.out[i] = blend_weight<false>(V.edt, V.wnz, cz, cy, cx);
+    }
+}
+
 int fill_dev_view(MvsContext* c, const mvs_view_t& v, int ndim, const void* dev_data, DevView* d) {
     if (v.stride[2] != 1) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "view stride along x must be 1");
     for (int k = 0; k < 3; ++k)
@@ -1515,6 +1575,58 @@ void mvs_launch_blend(MvsContext* c, const DevView& d, float* out, const int64_t
     const int nblocks = (int)std::min<long long>((n + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(blend_kernel, dim3(nblocks), dim3(256), 0, c->stream, d, out, (int)shape[0], (int)shape[1], (int)shape[2],
                        box0 ? box0[0] : 0, box0 ? box0[1] : 0, box0 ? box0[2] : 0);
+}
+
+// Resampled view and blend weights of the boxes of up to 8 views in two launches (see BoxBatch).  `dviews`: the views' records in
+// device memory (same order as `hviews`); boxes with no voxels are skipped.  Falls back to one launch per view for what the batched
+// kernels do not cover (a view that is not a whole-pixel translation of an integer tile goes through mvs_launch_resample).
+void mvs_launch_boxes_batch(MvsContext* c, const DevView* hviews, const DevView* dviews, int n_views, int dtype, int order, float cval,
+                            float* const* res_out, float* const* blend_out, const int64_t (*shapes)[3], const int (*box0)[3]) {
+    if (n_views > 8 || c->force_generic) {
+        for (int i = 0; i < n_views; ++i) {
+            if (shapes[i][0] * shapes[i][1] * shapes[i][2] == 0) continue;
+            mvs_launch_resample(c, hviews[i], dtype, order, cval, res_out[i], shapes[i], box0[i]);
+            mvs_launch_blend(c, hviews[i], blend_out[i], shapes[i], box0[i]);
+        }
+        return;
+    }
+    BoxBatch R, W;
+    memset(&R, 0, sizeof(R));
+    memset(&W, 0, sizeof(W));
+    int nr = 0, nw = 0;
+    for (int i = 0; i < 8; ++i) {
+        R.blk0[i] = nr;
+        W.blk0[i] = nw;
+        if (i >= n_views) continue;
+        const long long n = (long long)shapes[i][0] * shapes[i][1] * shapes[i][2];
+        if (n == 0) continue;
+        BoxItem it;
+        memset(&it, 0, sizeof(it));
+        it.oz = (int)shapes[i][0]; it.oy = (int)shapes[i][1]; it.ox = (int)shapes[i][2];
+        it.z0 = box0[i][0]; it.y0 = box0[i][1]; it.x0 = box0[i][2];
+        int t[3];
+        if (is_integer_crop(hviews[i], dtype, t)) {
+            it.data = hviews[i].data; it.stride_z = hviews[i].stride_z; it.stride_y = hviews[i].stride_y;
+            it.nz = hviews[i].nz; it.ny = hviews[i].ny; it.nx = hviews[i].nx;
+            it.tz = t[0] + box0[i][0]; it.ty = t[1] + box0[i][1]; it.tx = t[2] + box0[i][2];
+            it.out = res_out[i];
+            R.v[i] = it;
+            const long long ng = (long long)shapes[i][0] * shapes[i][1] * ((shapes[i][2] + 7) / 8);
+            nr += (int)std::min<long long>((ng + 255) / 256, 256 * 16);
+        } else {
+            mvs_launch_resample(c, hviews[i], dtype, order, cval, res_out[i], shapes[i], box0[i]);
+        }
+        it.out = blend_out[i];
+        W.v[i] = it;
+        nw += (int)std::min<long long>((n + 255) / 256, 256 * 16);
+    }
+    R.blk0[8] = nr;
+    W.blk0[8] = nw;
+    if (nr > 0) {
+        if (dtype == MVS_U8) hipLaunchKernelGGL(crop_int_batch_kernel<unsigned char>, dim3(nr), dim3(256), 0, c->stream, R, cval);
+        else hipLaunchKernelGGL(crop_int_batch_kernel<unsigned short>, dim3(nr), dim3(256), 0, c->stream, R, cval);
+    }
+    if (nw > 0) hipLaunchKernelGGL(blend_batch_kernel, dim3(nw), dim3(256), 0, c->stream, dviews, W);
 }
 
 // Index frame -> chunk frame for the kernels that evaluate the full affine map per voxel (generic fuse kernel, resample,

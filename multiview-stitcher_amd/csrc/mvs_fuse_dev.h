@@ -34,5 +34,8 @@ int mvs_fill_dev_view(MvsContext* c, const mvs_view_t& v, int ndim, const void* 
 // chunk's own coordinates
 void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, float cval, float* out, const int64_t shape[3], const int* box0 = nullptr);
 void mvs_launch_blend(MvsContext* c, const DevView& d, float* out, const int64_t shape[3], const int* box0 = nullptr);
+// both for the boxes of up to 8 views in two launches (`dviews`: the same records in device memory)
+void mvs_launch_boxes_batch(MvsContext* c, const DevView* hviews, const DevView* dviews, int n_views, int dtype, int order, float cval,
+                            float* const* res_out, float* const* blend_out, const int64_t (*shapes)[3], const int (*box0)[3]);
 void mvs_view_chunk_box(const DevView& d, const int64_t shape[3], int lo[3], int hi[3]);
 void mvs_view_to_chunk_frame(DevView* d, const int64_t org[3], const int64_t ioff[3]);

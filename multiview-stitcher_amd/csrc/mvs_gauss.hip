@@ -728,7 +728,7 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
             if (boxes[i].n[axis] > 0 && (!pair_T(boxes[i].n[axis], r1, axis) || !pair_T(boxes[i].n[axis], r2, axis))) paired = false;
     // temporaries of the largest box, shared by the views: 5 arrays on the paired path, 6 on the separate-pass path
     const size_t tmp_total = (paired ? 5 : 6) * tmp_b;
-    const size_t need = 3 * pool_b + tmp_total + 64 * 1024 + (size_t)n_views * sizeof(CbBox) + 512;
+    const size_t need = 3 * pool_b + tmp_total + 64 * 1024 + (size_t)n_views * (sizeof(CbBox) + sizeof(DevView)) + 1024;
     char* base = (char*)mvs_scratch(c, 6, need);
     if (!base) return mvs_alloc_failed(c);
     float* I = (float*)base;
@@ -742,6 +742,7 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
     float* T2 = (float*)((char*)T1 + tmp_b);
     double* dfw = (double*)(((uintptr_t)(base + 3 * pool_b + tmp_total) + 255) / 256 * 256);
     CbBox* dboxes = (CbBox*)((char*)dfw + 32 * 1024);
+    DevView* dviews_dev = (DevView*)(((uintptr_t)(dboxes + n_views) + 255) / 256 * 256);      // the views' records for the batched box launches
 
     if ((w1.size() + w2.size()) * 8 > 32 * 1024) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "content_based: sigma too large");
     double* dfw1 = dfw;
@@ -750,23 +751,31 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
     // mvs_pinned_mark), so the call does not have to wait for its own work: with the result on the device it returns as soon as
     // everything is queued, and the host prepares the next chunk while this one is filtered (the probe spent ~0.4 ms per chunk idle)
     {
-        const size_t wb = (w1.size() + w2.size()) * 8, bb = (size_t)n_views * sizeof(CbBox);
-        char* hp = (char*)mvs_pinned_slot(c, 0, wb + bb + 64);
+        const size_t wb = (w1.size() + w2.size()) * 8, bb = (size_t)n_views * sizeof(CbBox), vb = (size_t)n_views * sizeof(DevView);
+        char* hp = (char*)mvs_pinned_slot(c, 0, wb + bb + vb + 64);
         if (!hp) return mvs_alloc_failed(c);
         memcpy(hp, w1.data(), w1.size() * 8);
         memcpy(hp + w1.size() * 8, w2.data(), w2.size() * 8);
         memcpy(hp + wb, boxes.data(), bb);
+        memcpy(hp + wb + bb, &dvs[0], vb);
         MVS_HIP_TRY(c, hipMemcpyAsync(dfw1, hp, wb, hipMemcpyHostToDevice, c->stream));
         MVS_HIP_TRY(c, hipMemcpyAsync(dboxes, hp + wb, bb, hipMemcpyHostToDevice, c->stream));
+        MVS_HIP_TRY(c, hipMemcpyAsync(dviews_dev, hp + wb + bb, vb, hipMemcpyHostToDevice, c->stream));
         mvs_pinned_mark(c, 0);
     }
 
-    for (int i = 0; i < n_views; ++i) {
-        const CbBox& B = boxes[i];
-        const int64_t bs[3] = {B.n[0], B.n[1], B.n[2]};
-        if (bs[0] * bs[1] * bs[2] == 0) continue;
-        mvs_launch_resample(c, dvs[i], dtype, opts->order, NAN, I + B.off, bs, B.lo);
-        mvs_launch_blend(c, dvs[i], BW + B.off, bs, B.lo);
+    {   // resampled views and blend weights on the views' boxes: two launches for all views of the chunk (<= 8 views)
+        std::vector<float*> res_out(n_views), blend_out(n_views);
+        std::vector<int64_t> shp((size_t)n_views * 3);
+        std::vector<int> b0((size_t)n_views * 3);
+        for (int i = 0; i < n_views; ++i) {
+            const CbBox& B = boxes[i];
+            res_out[i] = I + B.off;
+            blend_out[i] = BW + B.off;
+            for (int k = 0; k < 3; ++k) { shp[(size_t)i * 3 + k] = B.n[k]; b0[(size_t)i * 3 + k] = B.lo[k]; }
+        }
+        mvs_launch_boxes_batch(c, &dvs[0], dviews_dev, n_views, dtype, opts->order, NAN, res_out.data(), blend_out.data(),
+                               (const int64_t (*)[3])shp.data(), (const int (*)[3])b0.data());
     }
     const int gb = grid_for(n);
     // <= 8 views and a pool below 2^31 floats: boxes as a kernel argument, 32-bit indices kept in registers
