@@ -495,22 +495,22 @@ int mvs_upload_tile(int device, const void* host, int32_t dtype, const int64_t s
     return mvs_memcpy_h2d(device, *dev_ptr, host, n);
 }
 
-// rows of `nbytes_row` bytes: src is contiguous (row r at r * nbytes_row), dst rows sit at (z * dst_pitch_z + y * dst_pitch_y)
+// rows of `nbytes_row` bytes: src is contiguous (row r at r * nbytes_row), dst rows sit at (z * dst_pitch_z + y * dst_pitch_y).
+// A thread moves 16-byte pieces (work items = (row, piece), so short rows fill the launch as well as long ones); neither end
+// needs any alignment (rows of a uint16 mosaic of odd width start at odd 2-byte offsets): global memory takes unaligned vectors.
 __global__ __launch_bounds__(256) void copy_box_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int nz, int ny,
                                                        long long nbytes_row, long long dst_pitch_y, long long dst_pitch_z) {
-    const int rows = nz * ny;
-    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
-        const int z = r / ny, y = r - z * ny;
-        const unsigned char* s = src + (long long)r * nbytes_row;
-        unsigned char* d = dst + (long long)z * dst_pitch_z + (long long)y * dst_pitch_y;
-        // 4-byte words when both ends allow it (element sizes are 1, 2, 4: the tails are at most 3 bytes)
-        const bool w4 = (((unsigned long long)s | (unsigned long long)d | (unsigned long long)nbytes_row) & 3ull) == 0;
-        if (w4) {
-            const long long nw = nbytes_row >> 2;
-            for (long long i = threadIdx.x; i < nw; i += blockDim.x) reinterpret_cast<unsigned int*>(d)[i] = reinterpret_cast<const unsigned int*>(s)[i];
-        } else {
-            for (long long i = threadIdx.x; i < nbytes_row; i += blockDim.x) d[i] = s[i];
-        }
+    typedef unsigned int u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+    const long long rows = (long long)nz * ny, ppr = (nbytes_row + 15) >> 4, total = rows * ppr;
+    for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
+        const long long r = w / ppr, pc = w - r * ppr;
+        const int z = (int)(r / ny), y = (int)(r - (long long)z * ny);
+        const unsigned char* s = src + r * nbytes_row + pc * 16;
+        unsigned char* d = dst + (long long)z * dst_pitch_z + (long long)y * dst_pitch_y + pc * 16;
+        const long long left = nbytes_row - pc * 16;
+        if (left >= 16) *reinterpret_cast<u32x4_a1*>(d) = *reinterpret_cast<const u32x4_a1*>(s);
+        else
+            for (int i = 0; i < (int)left; ++i) d[i] = s[i];
     }
 }
 
@@ -543,7 +543,8 @@ int mvs_copy_into(int device, const void* src_dev, int32_t dtype, const int64_t 
     const long long py = dst_shape[2] * (long long)es, pz = dst_shape[1] * py;
     unsigned char* d0 = (unsigned char*)dst_dev + dst_offset[0] * pz + dst_offset[1] * py + dst_offset[2] * (long long)es;
     const int rows = (int)(shape[0] * shape[1]);
-    hipLaunchKernelGGL(copy_box_kernel, dim3(std::min(rows, 65536)), dim3(256), 0, c->stream, (const unsigned char*)src_dev, d0, (int)shape[0],
+    const long long pieces = (long long)rows * ((shape[2] * (long long)es + 15) >> 4);
+    hipLaunchKernelGGL(copy_box_kernel, dim3((unsigned)std::min<long long>((pieces + 255) / 256, 65536)), dim3(256), 0, c->stream, (const unsigned char*)src_dev, d0, (int)shape[0],
                        (int)shape[1], (long long)shape[2] * (long long)es, py, pz);
     MVS_HIP_TRY(c, hipGetLastError());
     return MVS_OK;

@@ -728,7 +728,7 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
             if (boxes[i].n[axis] > 0 && (!pair_T(boxes[i].n[axis], r1, axis) || !pair_T(boxes[i].n[axis], r2, axis))) paired = false;
     // temporaries of the largest box, shared by the views: 5 arrays on the paired path, 6 on the separate-pass path
     const size_t tmp_total = (paired ? 5 : 6) * tmp_b;
-    const size_t need = 3 * pool_b + tmp_total + 64 * 1024 + (size_t)n_views * (sizeof(CbBox) + sizeof(DevView)) + 1024;
+    const size_t need = 3 * pool_b + tmp_total + 64 * 1024 + (size_t)n_views * (sizeof(CbBox) + sizeof(DevView)) + 2048;
     char* base = (char*)mvs_scratch(c, 6, need);
     if (!base) return mvs_alloc_failed(c);
     float* I = (float*)base;
@@ -740,27 +740,26 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
     float* T0 = (float*)((char*)M + tmp_b);
     float* T1 = (float*)((char*)T0 + tmp_b);
     float* T2 = (float*)((char*)T1 + tmp_b);
-    double* dfw = (double*)(((uintptr_t)(base + 3 * pool_b + tmp_total) + 255) / 256 * 256);
-    CbBox* dboxes = (CbBox*)((char*)dfw + 32 * 1024);
-    DevView* dviews_dev = (DevView*)(((uintptr_t)(dboxes + n_views) + 255) / 256 * 256);      // the views' records for the batched box launches
-
+    // filter kernels, boxes and view records: ONE device block in the layout of the host staging block below (one upload per chunk)
+    char* dblock = (char*)(((uintptr_t)(base + 3 * pool_b + tmp_total) + 255) / 256 * 256);
     if ((w1.size() + w2.size()) * 8 > 32 * 1024) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "content_based: sigma too large");
-    double* dfw1 = dfw;
-    double* dfw2 = dfw + w1.size();
-    // filter kernels and boxes travel through the context's pinned staging slot (waited for before it is refilled: mvs_pinned_slot /
+    const size_t wb = ((w1.size() + w2.size()) * 8 + 255) / 256 * 256, bb = ((size_t)n_views * sizeof(CbBox) + 255) / 256 * 256,
+                 vb = (size_t)n_views * sizeof(DevView);
+    double* dfw1 = (double*)dblock;
+    double* dfw2 = dfw1 + w1.size();
+    CbBox* dboxes = (CbBox*)(dblock + wb);
+    DevView* dviews_dev = (DevView*)(dblock + wb + bb);      // the views' records for the batched box launches
+    // The block travels through the context's pinned staging slot (waited for before it is refilled: mvs_pinned_slot /
     // mvs_pinned_mark), so the call does not have to wait for its own work: with the result on the device it returns as soon as
     // everything is queued, and the host prepares the next chunk while this one is filtered (the probe spent ~0.4 ms per chunk idle)
     {
-        const size_t wb = (w1.size() + w2.size()) * 8, bb = (size_t)n_views * sizeof(CbBox), vb = (size_t)n_views * sizeof(DevView);
         char* hp = (char*)mvs_pinned_slot(c, 0, wb + bb + vb + 64);
         if (!hp) return mvs_alloc_failed(c);
         memcpy(hp, w1.data(), w1.size() * 8);
         memcpy(hp + w1.size() * 8, w2.data(), w2.size() * 8);
-        memcpy(hp + wb, boxes.data(), bb);
+        memcpy(hp + wb, boxes.data(), (size_t)n_views * sizeof(CbBox));
         memcpy(hp + wb + bb, &dvs[0], vb);
-        MVS_HIP_TRY(c, hipMemcpyAsync(dfw1, hp, wb, hipMemcpyHostToDevice, c->stream));
-        MVS_HIP_TRY(c, hipMemcpyAsync(dboxes, hp + wb, bb, hipMemcpyHostToDevice, c->stream));
-        MVS_HIP_TRY(c, hipMemcpyAsync(dviews_dev, hp + wb + bb, vb, hipMemcpyHostToDevice, c->stream));
+        MVS_HIP_TRY(c, hipMemcpyAsync(dblock, hp, wb + bb + vb, hipMemcpyHostToDevice, c->stream));
         mvs_pinned_mark(c, 0);
     }
 
