@@ -1210,14 +1210,16 @@ __global__ __launch_bounds__(CORR ? 256 : 1024) void hist_rank_kernel(const floa
 // out[0] = sum_v h[v] rc[v]^2, out[1] = m (the number of keys).  1024 threads, contiguous bin ranges, two passes.
 // sums the packed 16-bit histograms of `nparts` workgroups into the 32-bit histograms hx (bins < nbx) and hy: a workgroup
 // takes 64 words, its four wavefronts a quarter of the parts each
-__global__ __launch_bounds__(256) void hist_fold_kernel(const unsigned int* __restrict__ parts, int nparts, int nwords, int nbx, int nby,
-                                                        unsigned int* __restrict__ hx, unsigned int* __restrict__ hy) {
-    __shared__ unsigned int s0[4][64], s1[4][64];
+__global__ __launch_bounds__(1024) void hist_fold_kernel(const unsigned int* __restrict__ parts, int nparts, int nwords, int nbx, int nby,
+                                                         unsigned int* __restrict__ hx, unsigned int* __restrict__ hy) {
+    // sixteen wavefronts, a sixteenth of the parts each: a wavefront's loads are one dependent-latency chain (256 parts in four
+    // chains of 64 took 12 us for a few MB)
+    __shared__ unsigned int s0[16][64], s1[16][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + lane;
     unsigned int c0 = 0, c1 = 0;
     if (i < nwords)
-        for (int w = q; w < nparts; w += 4) {
+        for (int w = q; w < nparts; w += 16) {
             const unsigned int v = parts[(size_t)w * nwords + i];
             c0 += v & 0xffffu;
             c1 += v >> 16;
@@ -1225,8 +1227,8 @@ __global__ __launch_bounds__(256) void hist_fold_kernel(const unsigned int* __re
     s0[q][lane] = c0; s1[q][lane] = c1;
     __syncthreads();
     if (q == 0 && i < nwords) {
-        c0 = s0[0][lane] + s0[1][lane] + s0[2][lane] + s0[3][lane];
-        c1 = s1[0][lane] + s1[1][lane] + s1[2][lane] + s1[3][lane];
+        c0 = 0; c1 = 0;
+        for (int k = 0; k < 16; ++k) { c0 += s0[k][lane]; c1 += s1[k][lane]; }
         const int b0 = 2 * i, b1 = 2 * i + 1;
         if (b0 < nbx) hx[b0] = c0; else if (b0 - nbx < nby) hy[b0 - nbx] = c0;
         if (b1 < nbx) hx[b1] = c1; else if (b1 - nbx < nby) hy[b1 - nbx] = c1;
@@ -1244,12 +1246,22 @@ __global__ __launch_bounds__(1024) void rank_table_kernel(const unsigned int* __
     const int per = (nb + 1023) / 1024, b0 = threadIdx.x * per, b1 = min(b0 + per, nb);
     unsigned long long loc = 0;
     for (int b = b0; b < b1; ++b) loc += h[b];
-    s_part[threadIdx.x] = loc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long run = 0;
-        for (int i = 0; i < 1024; ++i) { const unsigned long long v = s_part[i]; s_part[i] = run; run += v; }
-        s_var[0] = (double)run;       // m
+    // exclusive prefix over the 1024 per-thread counts: shuffle scan inside every wavefront, then over the 16 wavefront totals
+    // (integers: any order gives the same sums; thread 0 walking the 1024 entries took 8 of this kernel's 19 us)
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        unsigned long long inc = loc;
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long up = __shfl_up(inc, off);
+            if (lane >= off) inc += up;
+        }
+        if (lane == 63) s_part[wv] = inc;          // wavefront totals
+        __syncthreads();
+        unsigned long long base = 0, total = 0;
+        for (int k = 0; k < 16; ++k) { const unsigned long long t = s_part[k]; if (k < wv) base += t; total += t; }
+        __syncthreads();
+        s_part[threadIdx.x] = base + inc - loc;
+        if (threadIdx.x == 0) s_var[0] = (double)total;       // m
     }
     __syncthreads();
     const double m = s_var[0];
@@ -1528,7 +1540,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                                    (const float*)nullptr, (double*)nullptr, fold ? d_parts : (unsigned int*)nullptr);
                 if (fold) {
                     const int nwords = (int)((nbx + nby + 1) / 2);
-                    hipLaunchKernelGGL(hist_fold_kernel, dim3((nwords + 63) / 64), dim3(256), 0, c->stream, d_parts, (int)hgb, nwords, (int)nbx, (int)nby,
+                    hipLaunchKernelGGL(hist_fold_kernel, dim3((nwords + 63) / 64), dim3(1024), 0, c->stream, d_parts, (int)hgb, nwords, (int)nbx, (int)nby,
                                        d_hist, d_hist + nbx);
                 }
                 hipLaunchKernelGGL(rank_table_kernel, dim3(2), dim3(1024), 0, c->stream, d_hist, (int)nbx, d_rank, d_hist + nbx, (int)nby,
