@@ -137,7 +137,8 @@ int mvs_synchronize(int device);
 int mvs_set_option(int device, const char* key, int64_t value);
 /* Measurement counters of one context (bench.py): "reg_alg_bytes" = algorithmic HBM bytes of the pairwise registrations
  * since the last reset (28 n per phase-correlation variant + 20 n per scored candidate + 64 n for the rank correlation, n = crop
- * voxels; a candidate the arg-max search stopped counts the fraction of its volume it was scored on), "reg_pairs",
+ * voxels; a candidate the arg-max search stopped counts the fraction of its volume it was scored on; "reg_alg_bytes_full": every
+ * scored candidate counted whole, the reference's formulation), "reg_pairs",
  * "reg_candidates" (candidates that entered the scoring), "reg_pruned" (of these, left unfinished), "reg_cand_volumes"
  * (candidate volumes the SSIM passes went through), "fuse_plan_ms" = host time the last mvs_fuse_chunk spent decomposing the chunk
  * (0 when the plan cached for the same geometry was reused).  reset != 0 clears an accumulating counter after reading. */

@@ -327,6 +327,7 @@ int mvs_get_counter(int device, const char* key, int32_t reset, double* value_ou
     if (!key || !value_out) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_get_counter: NULL argument");
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     if (!strcmp(key, "reg_alg_bytes")) { *value_out = c->reg_alg_bytes; if (reset) c->reg_alg_bytes = 0.0; return MVS_OK; }
+    if (!strcmp(key, "reg_alg_bytes_full")) { *value_out = c->reg_alg_bytes_full; if (reset) c->reg_alg_bytes_full = 0.0; return MVS_OK; }
     if (!strcmp(key, "reg_pairs")) { *value_out = (double)c->reg_pairs; if (reset) c->reg_pairs = 0; return MVS_OK; }
     if (!strcmp(key, "reg_candidates")) { *value_out = (double)c->reg_candidates; if (reset) c->reg_candidates = 0; return MVS_OK; }
     if (!strcmp(key, "reg_pruned")) { *value_out = (double)c->reg_pruned; if (reset) c->reg_pruned = 0; return MVS_OK; }

@@ -38,6 +38,7 @@ struct MvsContext {
     // measurement: algorithmic HBM bytes of the pairwise registrations run on this context since the last reset (SURVEY 8d:
     // 28 n per phase-correlation variant, 20 n per scored candidate, 64 n for the rank correlation; n = crop voxels)
     double reg_alg_bytes = 0.0;
+    double reg_alg_bytes_full = 0.0;   // the same model with every scored candidate counted whole (what the reference's formulation moves)
     long long reg_pairs = 0, reg_candidates = 0, reg_pruned = 0;   // reg_pruned: candidates the pruned arg-max search left unfinished
     double reg_cand_volumes = 0.0;     // candidate volumes the SSIM walk actually went through (a pruned candidate counts its fraction)
     float raw_range[4] = {0.f, 0.f, 0.f, 0.f};            // with raw_u16_keys: min, max of the fixed crop, min, max of the moving crop

@@ -168,6 +168,7 @@ extern "C" int mvs_register_crops(int device, const float* fixed, const float* m
     double cand_vol = c->reg_cand_volumes - cand_vol0;
     if (!(cand_vol > 0.0)) { cand_vol = (double)n_scored; c->reg_cand_volumes = cand_vol0 + cand_vol; }   // (paths that do not count themselves)
     c->reg_alg_bytes += (double)n * (2.0 * 28.0 + 20.0 * cand_vol + 64.0);
+    c->reg_alg_bytes_full += (double)n * (2.0 * 28.0 + 20.0 * (double)n_scored + 64.0);
     c->reg_pairs += 1;
     c->reg_candidates += n_scored;
 
