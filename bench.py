@@ -153,6 +153,19 @@ def _slabs_for_chunk(views, params, bbs, sub_bb, margin=2):
 _CPU_FARM = {}
 
 
+def _cpu_ranges(cpus):
+    """[0, 1, 2, 5] -> '0-2,5'"""
+    out, cpus = [], sorted(cpus)
+    i = 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else f"{cpus[i]}-{cpus[j]}")
+        i = j + 1
+    return ",".join(out)
+
+
 def _cpu_quota_cores():
     """CPU quota of this container in cores (cgroup v2 cpu.max / v1 cfs quota), None when unlimited or unknown."""
     try:
@@ -495,6 +508,12 @@ class _SignedView:
 
 def main():
     args = parse_args()
+    # one compact block of CPUs per process, before torch / HIP start their threads (executors.pin_process_to_compact_cpus: the
+    # 16 pair-worker threads of a step lose ~10 % when the scheduler spreads them over both sockets of the host)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from multiview_stitcher_amd.executors import pin_process_to_compact_cpus
+
+    pinned_cpus = pin_process_to_compact_cpus(slot=int(os.environ.get("LOCAL_RANK", "0")))
     import torch
     import torch.distributed as dist
 
@@ -731,7 +750,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u16 in/out, f32 accumulate, f64 coordinates",
             "data": "synthetic (seeded smoothed noise mosaic generated in HBM, integer jitter unknown to metadata)",
-            "host": "python gc.freeze() after setup (garbage collection stays enabled)",
+            "host": "python gc.freeze() after setup (garbage collection stays enabled); process pinned to CPUs "
+                    + (_cpu_ranges(pinned_cpus) if pinned_cpus else "(no affinity call)") + " (executors.pin_process_to_compact_cpus)",
             "value_incl_pcie": pcie,
             "config": {
                 "workload": f"{'x'.join(map(str, grid))} grid (z,y,x) of {'x'.join(map(str, tile))} uint16 tiles, "

@@ -141,3 +141,63 @@ def fuse_on_devices(sims, devices=(0,), **fuse_kwargs):
         data += np.asarray(p.data)   # disjoint chunks, untouched ones are zero
     out.data = data
     return out
+
+
+def cpu_quota_cores():
+    """CPU quota of this container in cores (cgroup v2 ``cpu.max`` / v1 cfs quota); None when unlimited or unknown."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        return None if q == "max" else float(q) / float(p)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = float(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = float(f.read())
+        return None if q <= 0 else q / p
+    except (OSError, ValueError):
+        return None
+
+
+def pin_process_to_compact_cpus(slot=0, n_cpus=None):
+    """Restrict this process (and every thread it starts afterwards: the pair workers of ``compute_pairwise_registrations``,
+    the HIP runtime's helper threads) to one compact block of CPUs.  Call it BEFORE the first HIP / torch call.
+
+    Why: the pairwise registrations are driven by 16 host threads that wake up for tens of microseconds between library
+    calls.  On a two-socket host with 256 hardware threads and no affinity the scheduler spreads and migrates them over
+    both sockets (cold caches, cross-socket wake-ups, and a cgroup quota that is charged per period whichever CPUs ran);
+    measured on the GPU box: north-star step 68-69 ms without affinity, 61-63 ms inside ANY block of 16 CPUs
+    (``taskset -c 0-15`` ... ``128-143``, either socket: ``tools/affinity_probe.sh``).
+
+    ``slot``: which block (one per process of a node: pass the local rank); ``n_cpus``: block size, default the container's
+    CPU quota (at least 8, at most the CPUs available).  An affinity mask that is already narrower than twice the block is
+    left alone (the caller -- taskset, numactl, a job scheduler -- has decided); ``MVS_PIN_CPUS=0`` switches this off,
+    ``MVS_PIN_CPUS=a-b`` names the CPUs.  Returns the list of CPUs the process may run on afterwards."""
+    import os
+
+    if not hasattr(os, "sched_setaffinity"):
+        return None
+    avail = sorted(os.sched_getaffinity(0))
+    env = os.environ.get("MVS_PIN_CPUS", "")
+    if env == "0":
+        return avail
+    if env:
+        cpus = set()
+        for part in env.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= set(avail)
+    else:
+        if n_cpus is None:
+            quota = cpu_quota_cores()
+            n_cpus = int(round(quota)) if quota else 16
+        n_cpus = max(8, min(int(n_cpus), len(avail)))
+        if len(avail) < 2 * n_cpus:
+            return avail
+        first = (int(slot) * n_cpus) % (len(avail) - n_cpus + 1)
+        cpus = set(avail[first:first + n_cpus])
+    if cpus:
+        os.sched_setaffinity(0, cpus)
+    return sorted(os.sched_getaffinity(0))
