@@ -19,7 +19,7 @@ def test_pin_process_to_compact_cpus(monkeypatch):
             got = executors.pin_process_to_compact_cpus(slot=1, n_cpus=8)
             assert got == before[8:16]
             os.sched_setaffinity(0, before)
-        monkeypatch.setenv("MVS_PIN_CPUS", f"{before[0]}")
+        monkeypatch.setenv("MVS_PIN_CPUS", f"{before[0]}-{before[0]}")        # ("0" alone means: off)
         assert executors.pin_process_to_compact_cpus() == [before[0]]
     finally:
         os.sched_setaffinity(0, before)
