@@ -513,7 +513,11 @@ def main():
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from multiview_stitcher_amd.executors import pin_process_to_compact_cpus
 
-    pinned_cpus = pin_process_to_compact_cpus(slot=int(os.environ.get("LOCAL_RANK", "0")))
+    # (MVS_PIN_PROCESS=0: only the library's own pair workers keep to the block -- what a caller of register() gets without asking)
+    n_cpus_before = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else 0
+    pinned_cpus = pin_process_to_compact_cpus(slot=int(os.environ.get("LOCAL_RANK", "0"))) if os.environ.get("MVS_PIN_PROCESS", "1") != "0" else None
+    if pinned_cpus is not None and len(pinned_cpus) >= n_cpus_before:
+        pinned_cpus = None          # (left alone: already narrow, or switched off)
     import torch
     import torch.distributed as dist
 
@@ -750,8 +754,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u16 in/out, f32 accumulate, f64 coordinates",
             "data": "synthetic (seeded smoothed noise mosaic generated in HBM, integer jitter unknown to metadata)",
-            "host": "python gc.freeze() after setup (garbage collection stays enabled); process pinned to CPUs "
-                    + (_cpu_ranges(pinned_cpus) if pinned_cpus else "(no affinity call)") + " (executors.pin_process_to_compact_cpus)",
+            "host": "python gc.freeze() after setup (garbage collection stays enabled); CPU affinity of the process: "
+                    + _cpu_ranges(os.sched_getaffinity(0)) + (" (executors.pin_process_to_compact_cpus)" if pinned_cpus else "")
+                    + ("; pair workers unpinned" if os.environ.get("MVS_PIN_CPUS", "") == "0" else "; pair workers on one block of CPUs"),
             "value_incl_pcie": pcie,
             "config": {
                 "workload": f"{'x'.join(map(str, grid))} grid (z,y,x) of {'x'.join(map(str, tile))} uint16 tiles, "

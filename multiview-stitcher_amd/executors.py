@@ -201,3 +201,25 @@ def pin_process_to_compact_cpus(slot=0, n_cpus=None):
     if cpus:
         os.sched_setaffinity(0, cpus)
     return sorted(os.sched_getaffinity(0))
+
+
+def pin_worker_thread():
+    """Initializer of the library's own worker threads (the pair pool of ``compute_pairwise_registrations``): the calling
+    THREAD is restricted to the compact CPU block ``pin_process_to_compact_cpus`` would choose for the process -- the
+    process itself (the caller's threads) is left alone.  No-op when the process mask is already narrow or ``MVS_PIN_CPUS=0``."""
+    import os
+    import threading
+
+    if not hasattr(os, "sched_setaffinity") or os.environ.get("MVS_PIN_CPUS", "") == "0":
+        return
+    avail = sorted(os.sched_getaffinity(0))
+    quota = cpu_quota_cores()
+    n = max(8, min(int(round(quota)) if quota else 16, len(avail)))
+    if len(avail) < 2 * n:
+        return
+    slot = int(os.environ.get("LOCAL_RANK", "0") or 0)
+    first = (slot * n) % (len(avail) - n + 1)
+    try:
+        os.sched_setaffinity(threading.get_native_id(), set(avail[first:first + n]))
+    except OSError:
+        pass
