@@ -213,13 +213,23 @@ def pin_worker_thread():
     if not hasattr(os, "sched_setaffinity") or os.environ.get("MVS_PIN_CPUS", "") == "0":
         return
     avail = sorted(os.sched_getaffinity(0))
-    quota = cpu_quota_cores()
-    n = max(8, min(int(round(quota)) if quota else 16, len(avail)))
-    if len(avail) < 2 * n:
-        return
-    slot = int(os.environ.get("LOCAL_RANK", "0") or 0)
-    first = (slot * n) % (len(avail) - n + 1)
+    env = os.environ.get("MVS_PIN_CPUS", "")
+    if env:
+        cpus = set()
+        for part in env.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= set(avail)
+    else:
+        quota = cpu_quota_cores()
+        n = max(8, min(int(round(quota)) if quota else 16, len(avail)))
+        if len(avail) < 2 * n:
+            return
+        slot = int(os.environ.get("LOCAL_RANK", "0") or 0)
+        first = (slot * n) % (len(avail) - n + 1)
+        cpus = set(avail[first:first + n])
     try:
-        os.sched_setaffinity(threading.get_native_id(), set(avail[first:first + n]))
+        if cpus:
+            os.sched_setaffinity(threading.get_native_id(), cpus)
     except OSError:
         pass

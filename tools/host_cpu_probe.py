@@ -2,6 +2,8 @@
 python tools/host_cpu_probe.py [lanes] [reps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from multiview_stitcher_amd.executors import pin_process_to_compact_cpus
+pin_process_to_compact_cpus()          # (before torch / HIP start their threads; MVS_PIN_CPUS=0: off)
 import numpy as np, torch
 import bench
 from multiview_stitcher_amd import _lib, registration
