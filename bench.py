@@ -40,8 +40,8 @@ HBM_PEAK_GBS = 8000.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3, help="untimed steps (the first handful of steps of a process run 5-8 ms slower)")
     ap.add_argument("--grid", type=str, default="4,4,4", help="tiles in z,y,x")
     ap.add_argument("--tile", type=str, default="512,512,512", help="tile shape z,y,x")
     ap.add_argument("--overlap-frac", type=float, default=0.2)
