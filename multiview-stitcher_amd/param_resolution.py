@@ -35,6 +35,7 @@ class RegGraph:
             i, j, transform = j, i, np.linalg.inv(np.asarray(transform, dtype=np.float64))
         self.edges[(i, j)] = {"transform": np.asarray(transform, dtype=np.float64), "quality": float(quality),
                               "overlap": float(overlap), "bbox": None if bbox is None else np.asarray(bbox, dtype=np.float64)}
+        self._beads = None          # (memo of _beads_of)
 
     @property
     def ndim(self):
@@ -79,6 +80,8 @@ class RegGraph:
         nodes = set(nodes)
         g = RegGraph([n for n in self.nodes if n in nodes], {n: self.stack_props[n] for n in nodes if n in self.stack_props})
         g.edges = {e: dict(v) for e, v in self.edges.items() if e[0] in nodes and e[1] in nodes}
+        if len(g.edges) == len(self.edges):
+            g._beads = getattr(self, "_beads", None)      # the same edges: the same virtual beads
         return g
 
 
@@ -113,6 +116,11 @@ def _beads_of(g):
     keys = list(g.edges)
     if not keys:
         return {}
+    # memo per graph object, valid while the edges still hold the very arrays it was made from
+    stamp = tuple((k, id(e["transform"]), id(e["bbox"])) for k, e in g.edges.items())
+    memo = getattr(g, "_beads", None)
+    if memo is not None and memo[0] == stamp:
+        return memo[1]
     n = g.ndim
     lo = np.array([g.edges[k]["bbox"][0] for k in keys], dtype=np.float64)
     hi = np.array([g.edges[k]["bbox"][1] for k in keys], dtype=np.float64)
@@ -120,7 +128,12 @@ def _beads_of(g):
     gv = np.array(list(np.ndindex(*([2] * n))), dtype=np.float64)
     verts = gv[None] * (hi - lo)[:, None, :] + lo[:, None, :]
     moved = np.einsum("eij,ebj->ebi", T[:, :n, :n], verts) + T[:, None, :n, n]
-    return {k: {k[0]: verts[i], k[1]: moved[i]} for i, k in enumerate(keys)}
+    out = {k: {k[0]: verts[i], k[1]: moved[i]} for i, k in enumerate(keys)}
+    try:
+        g._beads = (stamp, out)
+    except AttributeError:
+        pass
+    return out
 
 
 def compute_edge_residuals(g, params):
@@ -139,6 +152,17 @@ def compute_edge_residuals(g, params):
     return {k: float(r[i]) for i, k in enumerate(keys)}
 
 
+def _sum_like_numpy(values):
+    """np.sum of a short list without the ufunc machinery: below 8 elements numpy's reduction is the plain left-to-right loop
+    (its pairwise / unrolled summation starts at 8), so this is bitwise np.sum there; longer lists go to numpy."""
+    if len(values) >= 8:
+        return float(np.sum(values))
+    t = 0.0
+    for i, v in enumerate(values):
+        t = float(v) if i == 0 else t + float(v)
+    return t
+
+
 def get_node_with_maximal_edge_weight_sum_from_graph(g, weight_key="quality"):
     """mv_graph.py:341-352 (first maximum in node order)."""
     per_node = {n: [] for n in g.nodes}           # the weights of a node's edges in edge order, gathered in one pass
@@ -146,7 +170,7 @@ def get_node_with_maximal_edge_weight_sum_from_graph(g, weight_key="quality"):
         per_node[k[0]].append(e[weight_key])
         if k[1] != k[0]:
             per_node[k[1]].append(e[weight_key])
-    totals = {n: np.sum(w) for n, w in per_node.items()}
+    totals = {n: _sum_like_numpy(w) for n, w in per_node.items()}
     return max(totals, key=totals.get)
 
 
@@ -298,7 +322,7 @@ def groupwise_resolution_global_optimization(g, reference_view=None, transform="
     max_iter = 500 if max_iter is None else max_iter
     rel_tol = 1e-4 if rel_tol is None else rel_tol
     if abs_tol is None:   # voxel diagonal, max over tiles (global_optimization.py:104-121)
-        abs_tol = np.max([np.sum([v ** 2 for v in g.stack_props[n]["spacing"].values()]) ** 0.5 for n in g.nodes])
+        abs_tol = max(_sum_like_numpy([v ** 2 for v in g.stack_props[n]["spacing"].values()]) ** 0.5 for n in g.nodes)
     if transform.lower() not in _ESTIMATORS:
         raise ValueError(f"Unknown transformation type in parameter resolution: {transform}")
     estimate = _ESTIMATORS[transform.lower()]
@@ -645,6 +669,7 @@ def groupwise_resolution(g, method="global_optimization", **kwargs):
     if "reference_view" not in kwargs and len(g.nodes) == 2:
         kwargs["reference_view"] = min(g.nodes)
     params, metrics, used = {}, [], set()
+    _beads_of(g)          # (memoised: a component that keeps every edge inherits them, compute_edge_residuals below reuses them)
     for icc, cc in enumerate(g.connected_components()):
         sub = g.subgraph(cc)
         if not sub.edges:
