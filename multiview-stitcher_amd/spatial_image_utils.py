@@ -46,6 +46,13 @@ class SpatialImage:
         self.attrs = attrs if attrs is not None else {}
         self.name = name
 
+    @classmethod
+    def _from_parts(cls, data, dims, coords, attrs, name):
+        """Constructor for parts that are known to be consistent (slices / copies of a valid image): no coordinate checks."""
+        out = object.__new__(cls)
+        out.data, out.dims, out.coords, out.attrs, out.name = data, dims, coords, attrs, name
+        return out
+
     shape = property(lambda self: tuple(self.data.shape))
     dtype = property(lambda self: self.data.dtype)
     ndim = property(lambda self: self.data.ndim)
@@ -55,13 +62,11 @@ class SpatialImage:
         d = self.data if data is None else data
         if deep and data is None:
             d = np.array(d, copy=True)
-        return SpatialImage(
-            d,
-            self.dims,
-            {k: v.copy() for k, v in self.coords.items()},
-            _copy.deepcopy(self.attrs) if deep else dict(self.attrs, transforms=dict(self.attrs.get("transforms", {}))),
-            self.name,
-        )
+        attrs = _copy.deepcopy(self.attrs) if deep else dict(self.attrs, transforms=dict(self.attrs.get("transforms", {})))
+        coords = {k: v.copy() for k, v in self.coords.items()}
+        if data is None or tuple(d.shape) == tuple(self.data.shape):
+            return SpatialImage._from_parts(d, self.dims, coords, attrs, self.name)
+        return SpatialImage(d, self.dims, coords, attrs, self.name)
 
     def astype(self, dtype):
         return self.copy(data=self.data.astype(dtype))
@@ -78,9 +83,9 @@ class SpatialImage:
                 continue
             dims.append(dim)
             coords[dim] = self.coords[dim][sel]
-        out = SpatialImage(self.data[tuple(idx)], dims, coords, dict(self.attrs), self.name)
-        out.attrs["transforms"] = dict(self.attrs.get("transforms", {}))
-        return out
+        # (slices of consistent parts are consistent: no coordinate checks)
+        return SpatialImage._from_parts(self.data[tuple(idx)], tuple(dims), coords,
+                                        dict(self.attrs, transforms=dict(self.attrs.get("transforms", {}))), self.name)
 
     def sel(self, indexers):
         """Label selection: scalar (exact coordinate) or slice(lo, hi) inclusive, like xarray."""
