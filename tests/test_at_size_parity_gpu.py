@@ -520,3 +520,62 @@ def test_north_star_device_results_through_the_resolution_and_pruning_oracles(hi
         for got, want in ((r["fixed"], fixed), (r["moving"], moving)):
             n_equal += int(at_size.assert_crops_equal(got, want, exact=False))
     assert n_equal == 6          # half-pixel taps of integer-valued voxels are exact in float32: the crops are the same bits
+
+
+def test_north_star_pruned_search_equals_full_scoring_on_all_pairs(hip_device):
+    """The pruned arg-max search of mvs_register_crops (option "ssim_prune") on the north-star mosaic, every one of
+    the 144 pairs, on all 16 context lanes: the pairwise translations, qualities and the resolved parameters are those of the run
+    that scores every candidate in full -- bit for bit -- on the bench's clean tiles and on tiles with independent noise on top
+    (the overlaps are then no longer copies of each other: the winner's SSIM drops and candidates leave later or not at all)."""
+    _need_torch()
+    import bench
+    from multiview_stitcher_amd import _lib, param_utils, registration
+    from multiview_stitcher_amd import spatial_image_utils as si
+
+    dev = torch.device("cuda", 0)
+    grid, tile = np.array([4, 4, 4]), np.array([512, 512, 512])
+    overlap = np.round(tile * 0.2).astype(int)
+    tiles, jitters, origins = bench.make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=99)
+    key = si.DEFAULT_TRANSFORM_KEY
+    lanes = [lane << 8 for lane in range(16)]
+
+    def run(flag):
+        for d in lanes:
+            _lib.init(d)
+            _lib.set_option("ssim_prune", flag, d)
+            for k in ("reg_pruned", "reg_cand_volumes", "reg_candidates"):
+                _lib.get_counter(k, d, reset=True)
+        res = registration.register(sims, transform_key=key, new_transform_key="reg", device=0, return_dict=True)
+        stats = {k: sum(_lib.get_counter(k, d, reset=True) for d in lanes) for k in ("reg_pruned", "reg_cand_volumes", "reg_candidates")}
+        return res, stats
+
+    try:
+        for noise in (0, 40):
+            if noise:      # independent "camera noise" per tile (the mosaic's values span 0..4095)
+                g = torch.Generator(device=dev)
+                g.manual_seed(5)
+                for t in tiles:
+                    ti = t.view(torch.int16)          # (values stay far below 2^15: the signed view holds them)
+                    n = torch.randn(t.shape, generator=g, device=dev, dtype=torch.float16) * noise
+                    ti.copy_((ti.to(torch.float32) + n.to(torch.float32)).clamp_(0, 30000).to(torch.int16))
+                    del n
+            sims = bench.build_sims(tiles, origins, 0)
+            torch.cuda.synchronize()
+            got, st1 = run(1)
+            want, st0 = run(0)
+            assert got["pairwise_registration"]["edges"] == want["pairwise_registration"]["edges"]
+            assert len(got["pairwise_registration"]["edges"]) == 144
+            for a, b in zip(got["pairwise_registration"]["results"][0], want["pairwise_registration"]["results"][0]):
+                np.testing.assert_array_equal(np.asarray(a["transform"]), np.asarray(b["transform"]))
+                assert a["quality"] == b["quality"]
+            for p, q in zip(got["params"], want["params"]):
+                np.testing.assert_array_equal(param_utils.select_time(p, 0), param_utils.select_time(q, 0))
+            assert st0["reg_pruned"] == 0 and st0["reg_cand_volumes"] == st0["reg_candidates"]
+            assert st1["reg_cand_volumes"] < st1["reg_candidates"]
+            at_size._record({"config": "north star, pruned arg-max search vs full scoring, noise sigma %d" % noise, "pairs": 144,
+                             "candidates": st1["reg_candidates"], "left_unfinished": st1["reg_pruned"],
+                             "candidate_volumes_walked": round(st1["reg_cand_volumes"], 2), "identical": True, "voxels": 0,
+                             "beyond_plain_bar": 0})
+    finally:
+        for d in lanes:
+            _lib.set_option("ssim_prune", 1, d)
