@@ -161,6 +161,14 @@ def cpu_quota_cores():
         return None
 
 
+def _default_block():
+    """CPUs per process block: 16 (measured: 16 and 32 CPUs are equally good, 8 cost 2 ms of a 62-ms step), fewer only when the
+    container's quota is smaller -- a larger quota does not widen the block (the point is compactness; the ranks of a node take
+    consecutive blocks)."""
+    quota = cpu_quota_cores()
+    return 16 if (quota is None or quota >= 16) else max(8, int(round(quota)))
+
+
 def pin_process_to_compact_cpus(slot=0, n_cpus=None):
     """Restrict this process (and every thread it starts afterwards: the pair workers of ``compute_pairwise_registrations``,
     the HIP runtime's helper threads) to one compact block of CPUs.  Call it BEFORE the first HIP / torch call.
@@ -171,8 +179,8 @@ def pin_process_to_compact_cpus(slot=0, n_cpus=None):
     measured on the GPU box: north-star step 68-69 ms without affinity, 61-63 ms inside ANY block of 16 CPUs
     (``taskset -c 0-15`` ... ``128-143``, either socket: ``tools/affinity_probe.sh``).
 
-    ``slot``: which block (one per process of a node: pass the local rank); ``n_cpus``: block size, default the container's
-    CPU quota (at least 8, at most the CPUs available).  An affinity mask that is already narrower than twice the block is
+    ``slot``: which block (one per process of a node: pass the local rank); ``n_cpus``: block size, default 16 (the
+    container's CPU quota when that is smaller, at least 8).  An affinity mask that is already narrower than twice the block is
     left alone (the caller -- taskset, numactl, a job scheduler -- has decided); ``MVS_PIN_CPUS=0`` switches this off,
     ``MVS_PIN_CPUS=a-b`` names the CPUs.  Returns the list of CPUs the process may run on afterwards."""
     import os
@@ -191,8 +199,7 @@ def pin_process_to_compact_cpus(slot=0, n_cpus=None):
         cpus &= set(avail)
     else:
         if n_cpus is None:
-            quota = cpu_quota_cores()
-            n_cpus = int(round(quota)) if quota else 16
+            n_cpus = _default_block()
         n_cpus = max(8, min(int(n_cpus), len(avail)))
         if len(avail) < 2 * n_cpus:
             return avail
@@ -221,8 +228,7 @@ def pin_worker_thread():
             cpus.update(range(int(lo), int(hi or lo) + 1))
         cpus &= set(avail)
     else:
-        quota = cpu_quota_cores()
-        n = max(8, min(int(round(quota)) if quota else 16, len(avail)))
+        n = max(8, min(_default_block(), len(avail)))
         if len(avail) < 2 * n:
             return
         slot = int(os.environ.get("LOCAL_RANK", "0") or 0)
