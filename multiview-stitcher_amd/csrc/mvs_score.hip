@@ -606,7 +606,7 @@ __global__ __launch_bounds__(256) void ssim_yx_batch_kernel(YxBatch B, float* __
 // vector instructions per plane are f64 adds / multiplies / conversions, all at 1/2 of the fp32 issue rate on gfx950).
 // A candidate is its shifted copy (dz = dy = dx = 0) or, for an integer shift, the moving crop itself read in place.
 // sel: the work items (tile x z segment, numbered x fastest) this launch walks for the candidate, as a set of residues of the
-// item number modulo 16 -- 0xffff: all of them; the pruned argmax search (mvs_score_candidates) scores a candidate in rounds
+// item number modulo 32 -- 0xffffffff: all of them; the pruned argmax search (mvs_score_candidates) scores a candidate in rounds
 struct FusedCand { const float* src; int dz, dy, dx; unsigned int sel; };
 struct FusedBatch { FusedCand c[kMaxResident]; };
 template <int WIN>
@@ -614,7 +614,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
 void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch B,
                                                                const float* __restrict__ ux, const float* __restrict__ uxx, int zseg,
                                                                float cov_norm, float C1, float C2, float* __restrict__ pmax,
-                                                               int* __restrict__ phasnan, double* __restrict__ psum) {
+                                                               int* __restrict__ phasnan, double* __restrict__ psum, int selk) {
     constexpr int H = WIN / 2, pad = (WIN - 1) / 2, TY = 16, TX = 56, LY = TY + 2 * H, LX = TX + 2 * H;
     constexpr int NO = 4, NI = NO + 2 * H;           // outputs / inputs of one y- or x-pass item
     constexpr int NR = (LY + 3) / 4;                 // patch rows per thread: row = (tid >> 6) + 4 k, column = tid & 63
@@ -623,7 +623,7 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
     __shared__ float sz_[3][LY][LX + 1];             // z-filtered y, yy, xy of the current plane (tile + halo)
     __shared__ float sy_[3][TY][LX + 1];             // ... filtered along y as well
     const FusedCand C = B.c[blockIdx.y];
-    const int nselres = __popc(C.sel & 0xffffu);
+    const int nselres = __popc(C.sel);
     if (!C.src || nselres == 0) return;
     const int tid = threadIdx.x, col = tid & 63, wrow = tid >> 6;
     const int cz = S.nz - 2 * pad, cy = S.ny - 2 * pad, cx = S.nx - 2 * pad;
@@ -638,11 +638,11 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
         const int nty = (cy + TY - 1) / TY, ntx = (cx + TX - 1) / TX, nzs = (cz + zseg - 1) / zseg;
         const int nitems = nty * ntx * nzs;
         const int sy = S.nx, sz = S.ny * S.nx;
-        const int nsel = ((nitems + 15) >> 4) * nselres;             // selected items: residue k of group g is number g * nselres + k
+        const int nsel = ((nitems + selk - 1) / selk) * nselres;             // selected items: residue k of group g is number g * nselres + k
         for (int si = blockIdx.x; si < nsel; si += gridDim.x) {
-            unsigned int rest = C.sel & 0xffffu;
+            unsigned int rest = C.sel;
             for (int k = si % nselres; k > 0; --k) rest &= rest - 1;  // (uniform: scalar work)
-            const int item = (si / nselres) * 16 + (__ffs(rest) - 1);
+            const int item = (si / nselres) * selk + (__ffs(rest) - 1);
             if (item >= nitems) continue;
             const int tx = item % ntx, ty = (item / ntx) % nty, zs = item / (ntx * nty);
             const int z0 = pad + zs * zseg, z1 = min(z0 + zseg, S.nz - pad);
@@ -1712,7 +1712,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
         for (int j = 0; j < nb; ++j) {
             first_batch.c[j] = FirstCand{nullptr, nullptr, nullptr, nullptr, ShiftArg{0.0, 0.0, 0.0, 0}, 0};
             yx_batch.c[j] = YxCand{nullptr, nullptr, nullptr};
-            fused_batch.c[j] = FusedCand{nullptr, 0, 0, 0, 0xffffu};
+            fused_batch.c[j] = FusedCand{nullptr, 0, 0, 0, 0xffffffffu};
         }
         for (int j = 0; j < nb; ++j) {
             const int ic = todo[b0 + j];
@@ -1761,9 +1761,9 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 float* d1 = cand3[(size_t)3 * j], *d3 = cand3[(size_t)3 * j + 1], *d4 = cand3[(size_t)3 * j + 2];
                 first_batch.c[j] = FirstCand{second, d1, d3, d4, shifts[j], otf[j] ? 1 : 0};
                 yx_batch.c[j] = YxCand{d1, d3, d4};
-                fused_batch.c[j] = otf[j] ? FusedCand{im1, (int)shifts[j].tz, (int)shifts[j].ty, (int)shifts[j].tx, 0xffffu}
-                                   : cls_of[j] >= 0 ? FusedCand{cls[cls_of[j]].buf, (int)std::floor(shifts[j].tz), (int)std::floor(shifts[j].ty), (int)std::floor(shifts[j].tx), 0xffffu}
-                                                    : FusedCand{im1t_buf[j], 0, 0, 0, 0xffffu};
+                fused_batch.c[j] = otf[j] ? FusedCand{im1, (int)shifts[j].tz, (int)shifts[j].ty, (int)shifts[j].tx, 0xffffffffu}
+                                   : cls_of[j] >= 0 ? FusedCand{cls[cls_of[j]].buf, (int)std::floor(shifts[j].tz), (int)std::floor(shifts[j].ty), (int)std::floor(shifts[j].tx), 0xffffffffu}
+                                                    : FusedCand{im1t_buf[j], 0, 0, 0, 0xffffffffu};
                 any_batched = true;
                 batch_cov_norm = cov_norm;
             }
@@ -1783,11 +1783,11 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             // against C2 = (0.03 R)^2 in the denominator: S <= 1 + slack with the slack below).  So once ONE candidate is scored
             // completely (sum S*), a candidate with partial sum p over n of the N voxels can at best reach p + (N - n)(1 + slack); if
             // that is below S* it cannot be the arg max, whatever the rest of its volume holds -- the reference's nanargmax picks the
-            // same candidate, and the Spearman coefficient is only ever evaluated for that one.  All candidates are walked on 1 / 16 of
+            // same candidate, and the Spearman coefficient is only ever evaluated for that one.  All candidates are walked on 1 / 32 of
             // the work items (spread over the volume), the leader is completed, the others continue in rounds only while their bound
             // still reaches the best complete sum (see the plan inside the loop).  On the bench mosaic the decorrelated candidates
-            // (mean 0.01-0.15 against 0.90-0.975) leave after 2/16-4/16 of their volume, the sign flips of a half-pixel axis (0.6-0.94)
-            // after 3/16-11/16: 2.8 instead of 9.2 candidate volumes per pair (profiles/round4_prune_ab.txt).
+            // (mean 0.01-0.15 against 0.90-0.975) leave after 3/32-8/32 of their volume, the sign flips of a half-pixel axis (0.6-0.94)
+            // after 6/32-22/32: 2.6 instead of 9.2 candidate volumes per pair (profiles/round4_prune_ab.txt).
             bool prune = c->score_argmax_only && c->ssim_prune && todo.size() <= (size_t)nres;
             int n_in = 0;
             for (int j = 0; j < nb; ++j) {
@@ -1802,22 +1802,26 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 // time waiting (two barriers and a load round trip per plane), so a second round hides more than its 6 halo planes cost
                 const int nzs = std::max(1, std::min(1536 / std::max(tiles * nb, 1), (cz + 7) / 8));
                 hipLaunchKernelGGL(ssim_fused_batch_kernel<7>, dim3(kStatBlocks, nb), dim3(256), 0, c->stream, im0, S, fused_batch, setB[2], setB[3],
-                                   (cz + nzs - 1) / nzs, batch_cov_norm, C1, C2, pmax, phasnan, psum);
+                                   (cz + nzs - 1) / nzs, batch_cov_norm, C1, C2, pmax, phasnan, psum, 32);
                 c->reg_cand_volumes += (double)n_in;
             } else {
                 const int cy = S.ny - 6, cx = S.nx - 6, nty = (cy + 15) / 16, ntx = (cx + 55) / 56;
                 static const int target_items = [] { const char* e = getenv("MVS_SSIM_PRUNE_ITEMS"); return (e && atoi(e) > 0) ? atoi(e) : 320; }();
                 const int nzs0 = std::max(1, std::min(target_items / std::max(tiles, 1), (cz + 7) / 8));
                 const int zseg = (cz + nzs0 - 1) / nzs0, nzs = (cz + zseg - 1) / zseg, nitems = nty * ntx * nzs;
-                double vol_res[16];                     // output voxels of the work items of every residue class (the kernel's own geometry)
-                for (int r = 0; r < 16; ++r) vol_res[r] = 0.0;
+                // residue classes of the work items (a candidate's volume is walked in K-ths): 32 (measured against 16: 2.60 instead of
+                // 2.84 candidate volumes per pair on the bench mosaic); MVS_SSIM_PRUNE_CLASSES=16 for the A/B
+                static const int K = [] { const char* e = getenv("MVS_SSIM_PRUNE_CLASSES"); return (e && atoi(e) == 16) ? 16 : 32; }();
+                const unsigned int kAll = K == 32 ? 0xffffffffu : 0xffffu;
+                double vol_res[32];                     // output voxels of the work items of every residue class (the kernel's own geometry)
+                for (int r = 0; r < 32; ++r) vol_res[r] = 0.0;
                 for (int item = 0; item < nitems; ++item) {
                     const int tx = item % ntx, ty = (item / ntx) % nty, zs = item / (ntx * nty);
                     const int z0 = 3 + zs * zseg, z1 = std::min(z0 + zseg, S.nz - 3);
-                    vol_res[item & 15] += (double)(z1 - z0) * (double)std::min(16, cy - ty * 16) * (double)std::min(56, cx - tx * 56);
+                    vol_res[item % K] += (double)(z1 - z0) * (double)std::min(16, cy - ty * 16) * (double)std::min(56, cx - tx * 56);
                 }
                 const double Ntot = (double)cz * (double)cy * (double)cx;
-                auto vol_of = [&](unsigned int m) { double v = 0.0; for (int r = 0; r < 16; ++r) if ((m >> r) & 1u) v += vol_res[r]; return v; };
+                auto vol_of = [&](unsigned int m) { double v = 0.0; for (int r = 0; r < 32; ++r) if ((m >> r) & 1u) v += vol_res[r]; return v; };
                 double acc[kMaxResident];
                 float amx[kMaxResident];
                 int ahn[kMaxResident];
@@ -1829,12 +1833,12 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                     for (int j = 0; j < nb; ++j) {
                         fb.c[j].sel = masks[j];
                         if (!masks[j] || !fb.c[j].src) { fb.c[j].src = nullptr; masks[j] = 0; continue; }
-                        maxsel = std::max(maxsel, ((nitems + 15) >> 4) * __builtin_popcount(masks[j]));
+                        maxsel = std::max(maxsel, ((nitems + K - 1) / K) * __builtin_popcount(masks[j]));
                     }
                     if (maxsel == 0) return MVS_OK;
                     const int gx = std::min(kStatBlocks, maxsel);
                     hipLaunchKernelGGL(ssim_fused_batch_kernel<7>, dim3(gx, nb), dim3(256), 0, c->stream, im0, S, fb, setB[2], setB[3], zseg,
-                                       batch_cov_norm, C1, C2, pmax, phasnan, psum);
+                                       batch_cov_norm, C1, C2, pmax, phasnan, psum, K);
                     hipLaunchKernelGGL(finish_region_kernel, dim3(nb), dim3(256), 0, c->stream, pmax, phasnan, psum, reg_out, gx);
                     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
                     for (int j = 0; j < nb; ++j) {
@@ -1859,7 +1863,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 bool have_best = false;
                 double s_best = 0.0;
                 static const bool dbg = getenv("MVS_PRUNE_DEBUG") != nullptr;
-                for (int round = 0; round < 18; ++round) {
+                for (int round = 0; round < 34; ++round) {
                     // Plan: the leader is completed; every other open candidate advances to the fraction at which its bound would
                     // fall below the reference sum if its mean stayed what it is so far (residues are taken in rising order; the
                     // reference is the best complete sum, before there is one the leader's extrapolated sum -- a guess that only
@@ -1867,26 +1871,26 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                     const double s_ref = have_best ? s_best : acc[leader] / std::max(vol_of(done[leader]), 1.0) * Ntot;
                     bool more = false;
                     for (int j = 0; j < nb; ++j) {
-                        if (!fused_batch.c[j].src || done[j] == 0xffffu || pruned[j]) continue;
+                        if (!fused_batch.c[j].src || done[j] == kAll || pruned[j]) continue;
                         const int k_done = __builtin_popcount(done[j]);
-                        int k_to = 16;
+                        int k_to = K;
                         if (j != leader && (double)amx[j] > im1_min) {
                             const double mean_c = acc[j] / std::max(vol_of(done[j]), 1.0);
                             const double den = (1.0 + slack) - mean_c;
                             const double f = den > 0.0 ? ((1.0 + slack) - s_ref / Ntot) / den : 2.0;
-                            if (f < 1.0) k_to = std::min(16, std::max(k_done + 1, (int)std::ceil(16.0 * f * 1.15 + 0.25)));
-                            if (k_to >= 12) k_to = 16;
+                            if (f < 1.0) k_to = std::min(K, std::max(k_done + 1, (int)std::ceil((double)K * f * 1.15 + 0.25)));
+                            if (4 * k_to >= 3 * K) k_to = K;
                         }
-                        masks[j] = ((1u << k_to) - 1u) & ~((1u << k_done) - 1u);
+                        masks[j] = (unsigned int)((1ull << k_to) - 1ull) & ~(unsigned int)((1ull << k_done) - 1ull);
                         more = true;
                     }
                     if (!more) break;
                     rc = run_round();
                     if (rc) return rc;
                     for (int j = 0; j < nb; ++j)
-                        if (fused_batch.c[j].src && done[j] == 0xffffu && (!have_best || acc[j] > s_best)) { s_best = acc[j]; have_best = true; }
+                        if (fused_batch.c[j].src && done[j] == kAll && (!have_best || acc[j] > s_best)) { s_best = acc[j]; have_best = true; }
                     for (int j = 0; j < nb; ++j) {
-                        if (!fused_batch.c[j].src || done[j] == 0xffffu || pruned[j]) continue;
+                        if (!fused_batch.c[j].src || done[j] == kAll || pruned[j]) continue;
                         // (a candidate whose samples so far do not exceed im1_min may still be the reference's `continue` case: in full)
                         ub[j] = acc[j] + (Ntot - vol_of(done[j])) * (1.0 + slack);
                         if ((double)amx[j] > im1_min && ub[j] < s_best - 1e-9 * Ntot) pruned[j] = true;
@@ -1895,7 +1899,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 if (dbg) {
                     fprintf(stderr, "prune: best %.4f |", s_best / Ntot);
                     for (int j = 0; j < nb; ++j)
-                        if (fused_batch.c[j].src) fprintf(stderr, " %d/16:%.3f%s", __builtin_popcount(done[j]), acc[j] / std::max(vol_of(done[j]), 1.0), pruned[j] ? "x" : "");
+                        if (fused_batch.c[j].src) fprintf(stderr, " %d/%d:%.3f%s", __builtin_popcount(done[j]), K, acc[j] / std::max(vol_of(done[j]), 1.0), pruned[j] ? "x" : "");
                     fprintf(stderr, "\n");
                 }
                 for (int j = 0; j < nb; ++j) {
