@@ -170,3 +170,18 @@ def test_transform_models_match_oracle(transform, nd):
         g.edges[(a, b)]["transform"] = T
         h.edges[(a, b)]["transform"] = T
     _assert_same_resolution(g, h, transform=transform, max_iter=40)
+
+
+def test_short_sums_equal_numpy_bit_for_bit():
+    """param_resolution._sum_like_numpy replaces np.sum on the short lists of the resolution (a node's edge weights, the squared
+    spacings): below 8 elements numpy's reduction is the plain left-to-right loop, which the helper restates; from 8 on it hands
+    over to numpy (pairwise / unrolled summation).  Bitwise equality on random lists of every length, cancellation included."""
+    from multiview_stitcher_amd.param_resolution import _sum_like_numpy
+
+    rng = np.random.default_rng(0)
+    for n in range(0, 14):
+        for _ in range(200):
+            w = list((rng.standard_normal(n) * 10.0 ** rng.integers(-8, 8, n)).astype(np.float64))
+            a, b = _sum_like_numpy(w), float(np.sum(w))
+            assert a == b or (np.isnan(a) and np.isnan(b)), (n, w)
+    assert _sum_like_numpy([np.float64(0.1), 0.2, np.float32(0.3)]) == float(np.sum([np.float64(0.1), 0.2, np.float32(0.3)]))
