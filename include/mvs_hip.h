@@ -125,6 +125,8 @@ int mvs_synchronize(int device);
  * one refinement stage per normalisation, a min / max pass over the crops) instead of the fused passes at the ends of the two
  * transforms (bit for bit the same peaks and shifts; tests compare).  "fft_no_line" = 1: axes of 17-64 samples with prime factors
  * <= 19 run on the Bluestein kernels instead of the whole-line register transforms (mvs_dft_small.h; equal to float32 rounding).
+ * "fft_no_pair" = 1 (environment MVS_FFT_NO_PAIR for new contexts): the first pass of the inverse transform of the phase correlation takes
+ * its lines in flat order instead of as partner pairs (kz, ky), (-kz, -ky) (bit for bit the same; the pairs fetch the packed spectrum once).
  * "cb_unpaired" = 1: content-based weights filter value and mask lines in separate launches with separate preparation / quotient
  * kernels (rounds 1-3) instead of gauss1d_pair_kernel; "cb_nosplit" = 1: the paired path keeps both quantities in one workgroup
  * on every pass (all three bit for bit equal; tests compare).  "ssim_prune" = 0: mvs_register_crops / mvs_register_views score

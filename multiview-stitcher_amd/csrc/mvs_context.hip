@@ -190,6 +190,8 @@ int mvs_init(int device) {
     {   // A/B switch for all context lanes of a process (bench.py, tools/): MVS_SSIM_PRUNE=0 scores every candidate in full
         const char* ev = getenv("MVS_SSIM_PRUNE");
         if (ev && *ev) c->ssim_prune = atoi(ev) != 0;
+        ev = getenv("MVS_FFT_NO_PAIR");
+        if (ev && *ev) c->fft_no_pair = atoi(ev) != 0;
     }
     c->ready = true;
     c->last_error.clear();
@@ -304,6 +306,10 @@ int mvs_set_option(int device, const char* key, int64_t value) {
     }
     if (!strcmp(key, "cb_unpaired")) {
         c->cb_unpaired = value != 0;
+        return MVS_OK;
+    }
+    if (!strcmp(key, "fft_no_pair")) {
+        c->fft_no_pair = value != 0;
         return MVS_OK;
     }
     if (!strcmp(key, "fft_no_line")) {

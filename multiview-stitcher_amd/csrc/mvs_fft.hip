@@ -263,8 +263,34 @@ __global__ __launch_bounds__(256) void fft_reg2_kernel(FftArgs A) {
     // along x threads run along the line first, along y / z along the lines (adjacent x positions) first: coalesced either way
     const int line = contig ? (int)threadIdx.x / TPL : (int)threadIdx.x % LPB;
     const int idx = contig ? (int)threadIdx.x % TPL : (int)threadIdx.x / LPB;
-    const long long l = (long long)blockIdx.x * LPB + line;
-    const bool live = l < A.n_lines;
+    long long l = (long long)blockIdx.x * LPB + line;
+    bool live = l < A.n_lines;
+    if (A.xp_pair) {
+        // The cross power of line (kz, ky) needs the spectrum of its own line AND of the partner line (-kz, -ky), whose cross power
+        // needs the same two lines: line slots 2 p and 2 p + 1 of a workgroup take such a pair, so every element of the packed
+        // spectrum is fetched from HBM once instead of twice (53 -> 27 MB per 51 x 256 x 256 pass; the partner of a line used to be
+        // handled by a workgroup half a launch away).  Pairs are numbered over the canonical lines: row kz = 0 and, for even nz,
+        // row nz / 2 are their own partner rows (canonical: ky <= ny / 2), rows 1 .. (nz - 1) / 2 pair with rows nz - kz whole.
+        const int nyl = A.xp_ny, nzl = A.xp_nz, h = nyl / 2 + 1, F = (nzl - 1) / 2;
+        long long q = (long long)blockIdx.x * (LPB / 2) + (line >> 1);
+        int kz = -1, ky = 0;
+        if (q < h) { kz = 0; ky = (int)q; }
+        else {
+            q -= h;
+            if (q < (long long)F * nyl) { kz = 1 + (int)(q / nyl); ky = (int)(q % nyl); }
+            else {
+                q -= (long long)F * nyl;
+                if (!(nzl & 1) && q < h) { kz = nzl / 2; ky = (int)q; }
+            }
+        }
+        live = kz >= 0;
+        if (live && (line & 1)) {
+            const int my = ky ? nyl - ky : 0, mz = kz ? nzl - kz : 0;
+            if (my == ky && mz == kz) live = false;          // its own partner: the even slot has it
+            kz = mz; ky = my;
+        }
+        l = live ? (long long)kz * nyl + ky : 0;
+    }
     const long long base = live ? line_base(A, (int)l) : 0;
     float2* row = ex + line * LS;
     Peak2 pk;
@@ -712,7 +738,7 @@ int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inver
         const bool reg_line = mvs_dft_line_length(n) && !c->fft_no_line;
         if (reg_pow2 || reg_blue || reg_line) {
             const int lpw = reg_line ? 64 : ((reg_pow2 && n == 64) || (reg_blue && p.M == 64)) ? 32 : 16;      // lines per workgroup
-            const unsigned grid = (unsigned)((A.n_lines + lpw - 1) / lpw);
+            unsigned grid = (unsigned)((A.n_lines + lpw - 1) / lpw);
             // the fusions at the two ends of the transform (MvsFftFuse)
             if (fuse && axis == first_axis && fuse->re_src && fuse->im_src) {
                 A.re_src = fuse->re_src;
@@ -724,6 +750,11 @@ int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inver
                 A.xp_ny = (int)ny; A.xp_nz = (int)nz;
                 A.xp_sel_a = fuse->xp_sel_a; A.xp_sel_b = fuse->xp_sel_b;
                 fuse->xp_used = true;
+                if (reg_pow2 && lpw % 2 == 0 && !c->fft_no_pair) {      // partner lines side by side (fft_reg2_kernel)
+                    const long long h = ny / 2 + 1, ncanon = h + ((nz - 1) / 2) * ny + ((nz % 2 == 0) ? h : 0);
+                    A.xp_pair = 1;
+                    grid = (unsigned)((ncanon + lpw / 2 - 1) / (lpw / 2));
+                }
             }
             if (fuse && axis == last_axis && fuse->peak_val[0] && (long long)grid <= fuse->peak_cap) {
                 for (int k = 0; k < 2; ++k) { A.peak_val[k] = fuse->peak_val[k]; A.peak_idx[k] = fuse->peak_idx[k]; }

@@ -24,6 +24,7 @@ struct FftArgs {
     const float2* xp_src = nullptr;     // x pass only (stride 1, line = kz * xp_ny + ky)
     float2* xp_p2 = nullptr;
     int xp_ny = 0, xp_nz = 0, xp_sel_a = 0, xp_sel_b = 0;
+    int xp_pair = 0;                    // fft_reg2_kernel: a workgroup's lines come as partner pairs (kz, ky), (-kz, -ky): see there
 };
 
 // element offset of line l of this pass

@@ -53,6 +53,7 @@ struct MvsContext {
     bool score_argmax_only = false;    // set by mvs_register_crops around its mvs_score_candidates call: only the arg-max candidate is needed
     double score_value_bound = INFINITY;   // ... with the largest absolute value of the two (rescaled) crops
     bool ssim_prune = true;            // option "ssim_prune" (default 1; environment MVS_SSIM_PRUNE=0 turns it off for new contexts)
+    bool fft_no_pair = false;          // test switch: the first inverse pass of the phase correlation takes its lines in flat order (no partner pairs)
     bool ssim_two_pass = false;        // test switch: batched candidates go through the separate z and y/x SSIM launches instead of the fused walk
     bool materialize_shifts = false;   // test switch: candidate scoring always writes the shifted copies (no on-the-fly SSIM z pass)
     std::recursive_mutex mu;      // recursive: composite entry points (mvs_pair.hip) call the public ones under the lock

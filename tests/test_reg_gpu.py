@@ -612,3 +612,25 @@ def test_pruned_argmax_search_equals_full_scoring(hip_device, shape, shift, nois
     if noise == 0.0:      # the wrong-sign candidates of a clean pair leave after the first round
         assert stats[1]["reg_pruned"] >= stats[1]["reg_candidates"] - 2, stats
         assert stats[1]["reg_cand_volumes"] < 0.4 * stats[1]["reg_candidates"], stats
+
+
+@pytest.mark.parametrize("shape", [(24, 40, 256), (25, 41, 256), (1, 64, 128), (2, 3, 64), (51, 64, 256)])
+def test_partner_line_pairs_of_the_inverse_x_pass_equal_flat_order(hip_device, shape):
+    """The first pass of the inverse transform (along x, cross power formed on the fly) takes its lines as partner pairs (kz, ky),
+    (-kz, -ky) so that the packed spectrum is fetched once (fft_reg2_kernel, option "fft_no_pair" = flat order): even and odd
+    line-grid sizes, the self-partner rows and lines, a single plane.  Same arithmetic per line: peaks, heights, shifts bit for bit."""
+    from multiview_stitcher_amd import _lib, _reg_ops
+
+    a, b = _pair(shape, (0 if shape[0] < 8 else 2, -1 if shape[1] < 8 else -3, 4), noise=0.01, seed=2)
+    a, b = np.nan_to_num(ro.rescale_intensity_01(a)), np.nan_to_num(ro.rescale_intensity_01(b))
+    res = []
+    for flag in (0, 1):
+        _lib.set_option("fft_no_pair", flag)
+        try:
+            res.append(_reg_ops.phase_cross_correlation_multi(a, b, upsample_factor=2, normalizations=("phase", None)))
+        finally:
+            _lib.set_option("fft_no_pair", 0)
+    for (s0, d0), (s1, d1) in zip(*res):
+        np.testing.assert_array_equal(s0, s1)
+        np.testing.assert_array_equal(d0["peak_index"], d1["peak_index"])
+        assert d0["peak_abs"] == d1["peak_abs"]

@@ -1,4 +1,4 @@
-"""Register ONE pair of north-star sized tiles (for rocprofv3 --kernel-trace): python tools/reg_probe.py [reps]"""
+"""Register ONE pair of north-star sized tiles (for rocprofv3 --kernel-trace): python tools/reg_probe.py [reps] [grid z,y,x: the axis along which the two tiles are neighbours]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,7 +10,7 @@ from multiview_stitcher_amd import spatial_image_utils as si
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 dev = torch.device("cuda", 0)
 _lib.init(0)
-grid, tile = np.array([1, 1, 2]), np.array([512, 512, 512])
+grid, tile = np.array([int(v) for v in (sys.argv[2] if len(sys.argv) > 2 else "1,1,2").split(",")]), np.array([512, 512, 512])
 overlap = np.round(tile * 0.2).astype(int)
 tiles, jitters, origins = bench.make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=7)
 sims = bench.build_sims(tiles, origins, 0)
