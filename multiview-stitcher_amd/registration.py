@@ -659,7 +659,8 @@ def _prebin_views(sims, registration_binning, device, cache):
         out = pool[i]
         _lib.check(lib.mvs_bin_mean_async(lane_device, data.ptr, code, s3, _lib.i64x3(st3), b3, out.ptr), lane_device, "mvs_bin_mean_async")
         coords = {d: all_coords[d][i] for d in sdims}
-        binned = si_utils.SpatialImage(out, sdims, coords, {"transforms": dict(s.attrs.get("transforms", {}))})
+        # (coordinates of the right lengths by construction: no checks)
+        binned = si_utils.SpatialImage._from_parts(out, tuple(sdims), coords, {"transforms": dict(s.attrs.get("transforms", {}))}, None)
         cache.put((id(s.data), bkey), binned, keep=(s.data, data))
     return lane_device
 
