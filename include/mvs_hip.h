@@ -340,6 +340,22 @@ int mvs_fuse_plan(int32_t ndim, int32_t n_views, const double* view_origin, cons
 int mvs_edge_betweenness(int32_t n_nodes, int32_t n_edges, const int32_t* adj_offsets, const int32_t* adj_nodes,
                          const int32_t* adj_edge, double* bet_out);
 
+/* Host-only: the pairs registration.register registers, for views whose world frames are axis-aligned boxes -- the overlap
+ * graph of mv_graph.build_view_adjacency_graph_from_msims (mv_graph.py:35-180) and, with method 1, its pruning by
+ * prune_graph_to_alternating_colors (mv_graph.py:664-741, the default pre_registration_pruning_method) in one call.
+ * box_lo / box_hi: n_views x ndim world coordinates of the first / last sample of every view (after any overlap tolerance);
+ * pairs: n_pairs x 2 candidate view indices in the order the reference's cKDTree ball query lists them (i != j; (j, i) after
+ * (i, j) changes nothing).  An unordered pair becomes an edge at its first appearance when its intersection volume
+ * prod(min(hi) - max(lo)) is positive on every axis (the value Qhull returns for the box).  method 0: all edges; method 1:
+ * edges are removed level by level in rising order of overlap + betweenness bonus (an edge with an end point of degree 1 stays)
+ * until a greedy largest-first colouring needs at most n_colors colours.  Output: the surviving edges in networkx's edges()
+ * order (node by node, neighbours in insertion order), each (i, j) with i < j, and their overlap volumes; edges_out holds
+ * 2 * n_pairs int32, overlap_out n_pairs doubles at most.  n_graph_edges_out (optional): edges before pruning.
+ * MVS_ERR_UNSUPPORTED: a case the Python form decides (NaN volumes, no colouring within the levels). */
+int mvs_view_graph_prune(int32_t ndim, int32_t n_views, const double* box_lo, const double* box_hi, int64_t n_pairs,
+                         const int32_t* pairs, int32_t method, int32_t n_colors, int32_t* edges_out, double* overlap_out,
+                         int32_t* n_edges_out, int32_t* n_graph_edges_out);
+
 #ifdef __cplusplus
 }
 #endif

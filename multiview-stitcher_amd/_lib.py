@@ -125,6 +125,11 @@ SIGNATURES = {
          C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
          C.POINTER(C.c_int64), C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)],
     ),
+    "mvs_view_graph_prune": (
+        C.c_int,
+        [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int32), C.c_int32, C.c_int32,
+         C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    ),
     "mvs_edge_betweenness": (
         C.c_int,
         [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)],

@@ -1854,9 +1854,19 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 for (int j = 0; j < nb; ++j) masks[j] = fused_batch.c[j].src ? 0x0001u : 0u;
                 rc = run_round();
                 if (rc) return rc;
-                int leader = -1;
-                for (int j = 0; j < nb; ++j)
-                    if (fused_batch.c[j].src && (leader < 0 || acc[j] > acc[leader])) leader = j;
+                // A candidate whose region maximum does not exceed im1_min is the reference's `continue` case (registration.py:530-533):
+                // it takes no part in the arg max, so its sum must never be the one the others are dropped against (against a sparse
+                // fixed image an all-background candidate can hold the highest sum).  Complete candidates know their maximum; the
+                // leader is re-elected among the open candidates when it turns out to be such a candidate.
+                auto excluded = [&](int j) { return done[j] == kAll && !((double)amx[j] > im1_min); };
+                auto mean_of = [&](int j) { return acc[j] / std::max(vol_of(done[j]), 1.0); };
+                auto elect = [&]() {
+                    int l = -1;
+                    for (int j = 0; j < nb; ++j)
+                        if (fused_batch.c[j].src && !excluded(j) && !(done[j] == kAll && !std::isfinite(acc[j])) && (l < 0 || mean_of(j) > mean_of(l))) l = j;
+                    return l;
+                };
+                int leader = elect();
                 bool pruned[kMaxResident];
                 double ub[kMaxResident];
                 for (int j = 0; j < kMaxResident; ++j) { pruned[j] = false; ub[j] = 0.0; }
@@ -1868,7 +1878,8 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                     // fall below the reference sum if its mean stayed what it is so far (residues are taken in rising order; the
                     // reference is the best complete sum, before there is one the leader's extrapolated sum -- a guess that only
                     // sizes the round: candidates are dropped against complete sums alone).
-                    const double s_ref = have_best ? s_best : acc[leader] / std::max(vol_of(done[leader]), 1.0) * Ntot;
+                    if (!have_best && (leader < 0 || done[leader] == kAll)) leader = elect();      // the leader was a `continue` candidate / NaN
+                    const double s_ref = have_best ? s_best : leader >= 0 ? mean_of(leader) * Ntot : Ntot * (1.0 + slack);
                     bool more = false;
                     for (int j = 0; j < nb; ++j) {
                         if (!fused_batch.c[j].src || done[j] == kAll || pruned[j]) continue;
@@ -1888,7 +1899,10 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                     rc = run_round();
                     if (rc) return rc;
                     for (int j = 0; j < nb; ++j)
-                        if (fused_batch.c[j].src && done[j] == kAll && (!have_best || acc[j] > s_best)) { s_best = acc[j]; have_best = true; }
+                        if (fused_batch.c[j].src && done[j] == kAll && !excluded(j) && std::isfinite(acc[j]) && (!have_best || acc[j] > s_best)) {
+                            s_best = acc[j];
+                            have_best = true;
+                        }
                     for (int j = 0; j < nb; ++j) {
                         if (!fused_batch.c[j].src || done[j] == kAll || pruned[j]) continue;
                         // (a candidate whose samples so far do not exceed im1_min may still be the reference's `continue` case: in full)

@@ -489,6 +489,88 @@ def build_view_adjacency_graph(stack_props_list, overlap_tolerance=None, pairs=N
     return g
 
 
+def registration_edges_native(stack_props_list, overlap_tolerance=None, pairs=None, method="alternating_pattern",
+                              pruning_method_kwargs=None):
+    """The edge list ``prune_view_adjacency_graph(build_view_adjacency_graph(...), method, kwargs).edges()`` -- sorted tuples in
+    networkx's edges() order, i.e. registration.register's work list -- for the common case in ONE library call
+    (``mvs_view_graph_prune``, host code): every view an axis-aligned box in world coordinates (transform = positive diagonal +
+    shift, off-diagonal terms exactly zero, one static transform per view) and ``method`` None or "alternating_pattern".
+    Returns None when the case is not covered (the caller then takes the generic functions, which also raise the
+    reference's errors); the candidate pairs still come from scipy's cKDTree ball query, whose traversal order decides the
+    neighbour order of the graph (mv_graph.py:104-133).  tests/test_graph_native.py compares the two paths."""
+    import ctypes as C
+    from itertools import chain
+
+    from . import _lib
+
+    kw = dict(pruning_method_kwargs or {})
+    if method not in (None, "alternating_pattern") or set(kw) - {"n_colors"} or not stack_props_list:
+        return None
+    sps = stack_props_list
+    try:
+        sdims = [d for d in ("z", "y", "x") if d in sps[0]["spacing"]]
+        n = len(sdims)
+        keys = list(sps[0]["spacing"])
+        if not all("transform" in sp and list(sp["spacing"]) == keys and list(sp["origin"]) == list(sps[0]["origin"]) for sp in sps):
+            return None
+        origin = np.array([[sp["origin"][d] for d in sdims] for sp in sps], dtype=np.float64)
+        spacing = np.array([[sp["spacing"][d] for d in sdims] for sp in sps], dtype=np.float64)
+        shape = np.array([[sp["shape"][d] for d in sdims] for sp in sps])
+        a = np.array([np.asarray(sp["transform"], dtype=np.float64) for sp in sps])
+    except (KeyError, TypeError, ValueError):
+        return None
+    if a.shape != (len(sps), n + 1, n + 1) or shape.dtype.kind not in "iu":
+        return None
+    if overlap_tolerance is not None:       # extend_stack_props (spatial_image_utils.py:889-913), all views at once
+        tol = overlap_tolerance if isinstance(overlap_tolerance, dict) else {d: overlap_tolerance for d in keys}
+        if set(tol) - set(sdims):
+            return None
+        tv = np.array([float(tol.get(d, 0.0)) for d in sdims])
+        shape = shape + np.ceil(2 * tv / spacing).astype(np.int64)
+        origin = origin - tv
+    lin = a[:, :n, :n]
+    dg = np.diagonal(lin, axis1=1, axis2=2)
+    off = lin.copy()
+    off[:, np.arange(n), np.arange(n)] = 0.0
+    last = np.zeros(n + 1)
+    last[n] = 1.0
+    if np.any(off != 0.0) or np.any(dg <= 0) or np.any(a[:, n, :] != last):
+        return None
+    t = a[:, :n, n]
+    lo = origin
+    hi = lo + (shape - 1) * spacing
+    lo, hi = dg * lo + t, dg * hi + t
+    if not (np.all(np.isfinite(lo)) and np.all(np.isfinite(hi))):
+        return None
+    if pairs is None:
+        from scipy.spatial import cKDTree
+
+        centers = dg * (origin + spacing * (shape - 1) / 2) + t
+        diam = float(np.max(np.sqrt(np.sum((shape * spacing) ** 2, axis=1))))
+        near = cKDTree(centers).query_ball_point(centers, diam + 1)
+        lens = [len(x) for x in near]
+        second = np.fromiter(chain.from_iterable(near), dtype=np.int32, count=sum(lens))
+        first = np.repeat(np.arange(len(sps), dtype=np.int32), lens)
+        keep = first != second
+        pr = np.ascontiguousarray(np.stack([first[keep], second[keep]], axis=1), dtype=np.int32)
+    else:
+        pr = np.ascontiguousarray(np.asarray(pairs, dtype=np.int64).reshape(-1, 2), dtype=np.int32)
+        if pr.size and (pr.min() < 0 or pr.max() >= len(sps) or np.any(pr[:, 0] == pr[:, 1])):
+            return None
+    npairs = len(pr)
+    lo, hi = np.ascontiguousarray(lo), np.ascontiguousarray(hi)
+    edges = np.empty((max(npairs, 1), 2), dtype=np.int32)
+    ovl = np.empty(max(npairs, 1), dtype=np.float64)
+    ne = C.c_int32(0)
+    ptr = lambda arr, ty: arr.ctypes.data_as(C.POINTER(ty))
+    rc = _lib.load().mvs_view_graph_prune(n, len(sps), ptr(lo, C.c_double), ptr(hi, C.c_double), npairs, ptr(pr, C.c_int32),
+                                          0 if method is None else 1, int(kw.get("n_colors", 2)), ptr(edges, C.c_int32),
+                                          ptr(ovl, C.c_double), C.byref(ne), None)
+    if rc != 0 or ne.value == 0:      # not covered / no overlap at all: the generic path decides (and raises NotEnoughOverlapError)
+        return None
+    return [(i, j) for i, j in edges[: ne.value].tolist()]
+
+
 def edge_betweenness_centrality(g):
     """networkx.edge_betweenness_centrality(g) with its defaults (Brandes, unweighted, normalised by n (n - 1)): host code in
     the library (``mvs_edge_betweenness``: 10 ms -> 0.2 ms for the 64-view mosaic), same traversal and accumulation order as

@@ -495,6 +495,8 @@ def _lean_register_pair(g1b, g2b, g1, g2, sdims, tol, upsample_factor, transform
 
 
 _lean_enabled = [True]      # tests switch the lean path off to compare it with the generic one
+_native_graph = [True]      # tests: register() through mv_graph's generic graph functions instead of mvs_view_graph_prune
+_native_resolution = [True]     # tests: register() through param_resolution's generic functions instead of mvs_resolve_translations
 
 
 def _geom_of(sim, transform_key, cache):
@@ -893,9 +895,14 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
     if tol is not None and not isinstance(tol, dict):
         tol = {d: float(tol) for d in sps[0]["spacing"]}
     try:
-        g_views = mv_graph.build_view_adjacency_graph([dict(sp, transform=a) for sp, a in zip(sps, affs)], overlap_tolerance=tol, pairs=pairs)
-        g_views = mv_graph.prune_view_adjacency_graph(g_views, pre_registration_pruning_method, pre_reg_pruning_method_kwargs)
-        edges = [tuple(sorted(e)) for e in g_views.edges()]
+        views = [dict(sp, transform=a) for sp, a in zip(sps, affs)]
+        # axis-aligned views + the default pruning: graph, overlap volumes and pruning in one library call (host code)
+        edges = mv_graph.registration_edges_native(views, tol, pairs, pre_registration_pruning_method, pre_reg_pruning_method_kwargs) \
+            if _native_graph[0] else None
+        if edges is None:
+            g_views = mv_graph.build_view_adjacency_graph(views, overlap_tolerance=tol, pairs=pairs)
+            g_views = mv_graph.prune_view_adjacency_graph(g_views, pre_registration_pruning_method, pre_reg_pruning_method_kwargs)
+            edges = [tuple(sorted(e)) for e in g_views.edges()]
     finally:
         if prebin is not None:
             # the binned tiles are complete before any lane reads them (the pre-binning lane is the last context lane; the

@@ -614,6 +614,50 @@ def test_pruned_argmax_search_equals_full_scoring(hip_device, shape, shift, nois
         assert stats[1]["reg_cand_volumes"] < 0.4 * stats[1]["reg_candidates"], stats
 
 
+def _sparse_pair(shape, shift, seed, invert, blob_frac=0.25, noise=0.0):
+    """Zero background with one textured blob; the moving crop holds the same blob displaced by ``shift`` (optionally with
+    inverted contrast, which makes the aligned candidate score BELOW an all-background one)."""
+    rng = np.random.default_rng(seed)
+    a = np.zeros(shape, np.float32)
+    b = np.zeros(shape, np.float32)
+    ext = [max(8, int(n * blob_frac)) for n in shape]
+    lo = [int(n * 0.1) + 6 for n in shape]
+    blob = ndimage.gaussian_filter(rng.random(tuple(ext)), 1.0).astype(np.float32) + 0.5
+    a[tuple(slice(l, l + e) for l, e in zip(lo, ext))] = blob
+    blob_b = (blob.max() + 0.5 - blob) if invert else blob
+    if noise:
+        blob_b = blob_b + noise * rng.standard_normal(blob.shape).astype(np.float32)
+    b[tuple(slice(l - d, l - d + e) for l, d, e in zip(lo, shift, ext))] = np.maximum(blob_b, 0.05)
+    return a, b
+
+
+@pytest.mark.parametrize("shape,shift,invert,noise", [((40, 96, 120), (2, -3, 4), True, 0.0), ((40, 96, 120), (3, 4, 5), True, 0.0),
+                                                      ((40, 96, 120), (-1, -6, -5), True, 0.1), ((96, 40, 130), (3, 2, -5), True, 0.0),
+                                                      ((64, 64, 64), (-5, -5, -5), True, 0.1), ((40, 96, 120), (1, 0, -5), False, 0.4)])
+def test_pruned_search_ignores_background_only_candidates(hip_device, shape, shift, invert, noise):
+    """Sparse crops on a zero background: the wrapped-around candidates move the blob out of the frame, the region that stays holds
+    nothing above im1_min -- the reference's `continue` case (registration.py:530-533) -- and against the equally sparse fixed crop
+    such a candidate has a HIGH SSIM sum.  The pruned search must not drop the valid candidates against it: translation, quality and
+    status equal the full scoring's and the oracle's."""
+    from multiview_stitcher_amd import _lib, _reg_ops
+
+    a, b = _sparse_pair(shape, shift, seed=5, invert=invert, noise=noise)
+    res = {}
+    for flag in (1, 0):
+        _lib.set_option("ssim_prune", flag)
+        try:
+            res[flag] = _reg_ops.register_crops(a, b, 2)
+        finally:
+            _lib.set_option("ssim_prune", 1)
+    np.testing.assert_array_equal(res[1][0], res[0][0])
+    assert (res[1][1] == res[0][1] or (np.isnan(res[1][1]) and np.isnan(res[0][1]))) and res[1][2:] == res[0][2:]
+    want = ro.phase_correlation_registration(a, b, return_debug=True)
+    if invert:
+        assert 2 in want["debug"]["codes"], "the case must contain a background-only candidate"
+    np.testing.assert_array_equal(res[1][0], want["affine_matrix"][:-1, -1])
+    assert abs(res[1][1] - want["quality"]) <= 1e-5
+
+
 @pytest.mark.parametrize("shape", [(24, 40, 256), (25, 41, 256), (1, 64, 128), (2, 3, 64), (51, 64, 256)])
 def test_partner_line_pairs_of_the_inverse_x_pass_equal_flat_order(hip_device, shape):
     """The first pass of the inverse transform (along x, cross power formed on the fly) takes its lines as partner pairs (kz, ky),
