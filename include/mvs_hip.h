@@ -251,6 +251,19 @@ int mvs_bin_mean(int device, const void* in, int32_t dtype, int32_t mem, const i
 int mvs_bin_mean_async(int device, const void* in, int32_t dtype, const int64_t shape[3], const int64_t stride[3],
                        const int64_t bin[3], void* out);
 
+/* mvs_bin_mean_async for n_views views of one shape, stride and dtype (in[v] -> out[v], device memory) in one call: the
+ * binning of all tiles of a mosaic is queued with one library call (16-bit tiles binned by 2 along x: one launch per 32 views). */
+int mvs_bin_mean_batch_async(int device, int32_t n_views, const void* const* in, int32_t dtype, const int64_t shape[3],
+                             const int64_t stride[3], const int64_t bin[3], void* const* out);
+
+/* Stream-ordered dependencies between context lanes, no host wait (the reference's dask graph orders the binning of a view
+ * before the pairs that read it, registration.py:1732-1741 -> 2657-2664; here the binning runs on one lane and the pairs on
+ * the others).  mvs_event_record marks the work queued so far on this lane and returns a ticket; mvs_event_wait(device,
+ * ticket) makes the work queued LATER on `device`'s lane wait for that mark.  A lane keeps 32 tickets: an older one stands for
+ * the mark that replaced it (the wait is longer, never shorter). */
+int mvs_event_record(int device, uint64_t* ticket_out);
+int mvs_event_wait(int device, uint64_t ticket);
+
 /* Candidate scoring == the loop of registration.py:493-556 for n translation
  * candidates t (z,y,x rows): moving resampled by t (order 1, NaN outside),
  * masks, bounding-box region (region_mode 0 = "union", 1 = "intersection"),
@@ -289,6 +302,36 @@ int mvs_register_crops(int device, const float* fixed, const float* moving, int3
 int mvs_register_views(int device, const mvs_view_t* fixed_view, const mvs_view_t* moving_view, int32_t ndim,
                        const int64_t out_shape[3], int32_t upsample_factor, int32_t region_mode, int32_t constant_check,
                        double t_out[3], double* quality_out, int32_t* status_out, int32_t* n_candidates_out);
+
+/* All pairs of a mosaic in one call (registration.compute_pairwise_registrations, registration.py:2622-2714: one task per
+ * pair; here one library call, the pairs farmed over context lanes by native worker threads -- no interpreter in the loop).
+ *
+ * mvs_plan_pairs (host only): for pairs of views whose transform is a pure translation, what register_pair_of_msims ->
+ * sims_to_intrinsic_coord_system -> get_pixel_affine derive per pair (registration.py:194-350, 1547-2058; transformation.py:37-83).
+ * coords[v * ndim + k]: the coordinate array of view v along axis k (coord_len entries; origin = c[0], spacing = c[1] - c[0]);
+ * translation: n_views x ndim; tol: ndim overlap tolerances or NULL; pairs: n_pairs x 2 (fixed, moving).  Per pair p:
+ * windows_out[((p * 2 + i) * 3 + k) * 2 + {0, 1}] = first / one-past-last index of view i's crop window on axis k (the overlap
+ * + one sample + 1e-6 on either side), out_origin / out_spacing / out_shape (p * 3 + k) = the fixed view's overlap grid,
+ * matrix_diag / offset ((p * 2 + i) * 3 + k) = the pixel affine of crop i (output pixel -> window pixel; rounded to 10
+ * decimals, offsets within 1e-6 of an integer snapped), status_out[p] = 0 ok, 1 the views do not overlap.  Axes k < ndim.
+ *
+ * mvs_register_pairs: mvs_register_views for every job on n_lanes (<= 16) native worker threads, thread w driving context lane
+ * `device | w << 8`; `device` carries no lane.  wait_ticket: mvs_event_record tickets (0 = none) the lane's stream waits for
+ * before it reads the fixed / moving view (binned tiles still being produced on another lane).  Outputs per pair as
+ * mvs_register_views (t_out: n_pairs x 3); rc_out[p] = that pair's return code.  Returns 0, or the first failing pair's code
+ * with its message in mvs_last_error(device). */
+typedef struct mvs_pair_job_t {
+    mvs_view_t fixed;
+    mvs_view_t moving;
+    int64_t out_shape[3];
+    uint64_t wait_ticket[2];
+} mvs_pair_job_t;
+int mvs_plan_pairs(int32_t ndim, int32_t n_views, const double* const* coords, const int64_t* coord_len, const double* translation,
+                   const double* tol, int32_t n_pairs, const int32_t* pairs, int64_t* windows_out, double* out_origin_out,
+                   double* out_spacing_out, int64_t* out_shape_out, double* matrix_diag_out, double* offset_out, int32_t* status_out);
+int mvs_register_pairs(int device, int32_t n_pairs, const mvs_pair_job_t* jobs, int32_t ndim, int32_t upsample_factor,
+                       int32_t region_mode, int32_t constant_check, int32_t n_lanes, double* t_out, double* quality_out,
+                       int32_t* status_out, int32_t* n_candidates_out, int32_t* rc_out);
 
 /* Host-only (no device, no mvs_init needed): the inner loop of the reference's global optimisation for the translation
  * model -- optimize_bead_subgraph, param_resolution/global_optimization.py:313-417 with transforms.py:45-53 as estimator.
@@ -355,6 +398,22 @@ int mvs_edge_betweenness(int32_t n_nodes, int32_t n_edges, const int32_t* adj_of
 int mvs_view_graph_prune(int32_t ndim, int32_t n_views, const double* box_lo, const double* box_hi, int64_t n_pairs,
                          const int32_t* pairs, int32_t method, int32_t n_colors, int32_t* edges_out, double* overlap_out,
                          int32_t* n_edges_out, int32_t* n_graph_edges_out);
+
+/* Host-only: param_resolution.groupwise_resolution(method="global_optimization", transform="translation")
+ * (param_resolution/__init__.py:44-150, global_optimization.py:16-511, utils.py:42-101) for a CONNECTED mosaic whose pairwise
+ * results are pure translations, in one call.  edges: n_edges x 2 view indices (i < j) in the order the pairs were added to the
+ * registration graph; pair_t: n_edges x ndim translation of each pair's transform; quality: n_edges; bbox_lo / bbox_hi:
+ * n_edges x ndim overlap box of each pair in the fixed view's frame; spacing: n_views x ndim (abs_tol < 0: the largest voxel
+ * diagonal is used).  reference_view < 0: the view with the largest sum of edge qualities.  Outputs: translations_out
+ * (n_views x ndim, the reference view keeps 0), edge_rms_out (n_edges, RMS bead residual per edge in input edge order),
+ * mean_hist / max_hist (max_iter doubles each: mean of edge means / maximum of the bead residuals after every sweep),
+ * n_iter_out, ref_out (optional).  Returns MVS_ERR_UNSUPPORTED -- and the caller takes the Python form -- when the graph is not
+ * one component over all views, an edge is duplicated, an input is not finite, or the final maximal residual is not below
+ * abs_tol (the reference then starts removing edges: global_optimization.py:419-505). */
+int mvs_resolve_translations(int32_t ndim, int32_t n_views, int32_t n_edges, const int32_t* edges, const double* pair_t,
+                             const double* quality, const double* bbox_lo, const double* bbox_hi, const double* spacing,
+                             int32_t reference_view, int32_t max_iter, double rel_tol, double abs_tol, double* translations_out,
+                             double* edge_rms_out, double* mean_hist, double* max_hist, int32_t* n_iter_out, int32_t* ref_out);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,15 @@ class mvs_fuse_opts_t(C.Structure):
     ]
 
 
+class mvs_pair_job_t(C.Structure):
+    _fields_ = [
+        ("fixed", mvs_view_t),
+        ("moving", mvs_view_t),
+        ("out_shape", C.c_int64 * 3),
+        ("wait_ticket", C.c_uint64 * 2),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/mvs_hip.h declares
 SIGNATURES = {
     "mvs_version": (C.c_char_p, []),
@@ -108,6 +117,24 @@ SIGNATURES = {
         C.c_int,
         [C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p],
     ),
+    "mvs_bin_mean_batch_async": (
+        C.c_int,
+        [C.c_int, C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+         C.POINTER(C.c_void_p)],
+    ),
+    "mvs_event_record": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
+    "mvs_event_wait": (C.c_int, [C.c_int, C.c_uint64]),
+    "mvs_plan_pairs": (
+        C.c_int,
+        [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,
+         C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64),
+         C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)],
+    ),
+    "mvs_register_pairs": (
+        C.c_int,
+        [C.c_int, C.c_int32, C.POINTER(mvs_pair_job_t), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double),
+         C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    ),
     "mvs_register_views": (
         C.c_int,
         [C.c_int, C.POINTER(mvs_view_t), C.POINTER(mvs_view_t), C.c_int32, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32,
@@ -129,6 +156,12 @@ SIGNATURES = {
         C.c_int,
         [C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int64, C.POINTER(C.c_int32), C.c_int32, C.c_int32,
          C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
+    ),
+    "mvs_resolve_translations": (
+        C.c_int,
+        [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+         C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.c_int32, C.c_double, C.c_double, C.POINTER(C.c_double),
+         C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)],
     ),
     "mvs_edge_betweenness": (
         C.c_int,

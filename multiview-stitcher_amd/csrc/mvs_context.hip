@@ -229,6 +229,7 @@ void mvs_shutdown(int device) {
     if (c->ev_fork) { hipEventDestroy(c->ev_fork); c->ev_fork = nullptr; }
     hipEventDestroy(c->pinned_ev[0]);
     hipEventDestroy(c->pinned_ev[1]);
+    for (hipEvent_t& e : c->ticket_ev) { if (e) hipEventDestroy(e); e = nullptr; }
     c->pinned_pending[0] = c->pinned_pending[1] = false;
     hipStreamDestroy(c->own_stream);
     c->own_stream = c->stream = nullptr;
@@ -351,6 +352,44 @@ int mvs_synchronize(int device) {
     if (rc) return rc;
     MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MVS_OK;
+}
+
+// Stream-ordered dependencies between context lanes without a host wait.  mvs_event_record marks the work queued so far on this
+// lane's stream and hands out a ticket; mvs_event_wait makes everything queued LATER on another lane's stream (same GPU) wait for
+// that mark -- hipStreamWaitEvent, the host returns at once.  Tickets live in a ring of 32 events per lane: one that has been
+// overwritten by a later mvs_event_record stands for that later mark (waiting longer, never shorter).
+int mvs_event_record(int device, uint64_t* ticket_out) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    if (!ticket_out) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_event_record: NULL argument");
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
+    const uint32_t slot = c->ticket_next++ % 32u;
+    if (!c->ticket_ev[slot]) MVS_HIP_TRY(c, hipEventCreateWithFlags(&c->ticket_ev[slot], hipEventDisableTiming));
+    MVS_HIP_TRY(c, hipEventRecord(c->ticket_ev[slot], c->stream));
+    *ticket_out = ((uint64_t)(uint32_t)mvs_ctx_index(device) << 8) | slot | (1ull << 40);
+    return MVS_OK;
+}
+
+int mvs_event_wait(int device, uint64_t ticket) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    if (!(ticket >> 40 & 1ull)) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_event_wait: not a ticket");
+    const uint32_t slot = (uint32_t)(ticket & 0xffu), idx = (uint32_t)((ticket >> 8) & 0xffffffu);
+    if (slot >= 32u || idx >= (uint32_t)(MVS_MAX_DEVICES * MVS_MAX_LANES)) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_event_wait: bad ticket");
+    MvsContext* src = &g_ctx[idx];
+    hipEvent_t ev;
+    {
+        std::lock_guard<std::recursive_mutex> lock(src->mu);
+        if (!src->ready || !src->ticket_ev[slot]) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_event_wait: the recording context is gone");
+        ev = src->ticket_ev[slot];
+    }
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
+    MVS_HIP_TRY(c, hipStreamWaitEvent(c->stream, ev, 0));
     return MVS_OK;
 }
 

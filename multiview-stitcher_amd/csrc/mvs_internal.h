@@ -67,6 +67,9 @@ struct MvsContext {
     // an async upload out of a pinned staging buffer may still be in flight when the next call wants to refill it
     // (calls that leave their result on the device return without synchronising): one event per staging slot
     hipEvent_t pinned_ev[2] = {nullptr, nullptr};
+    // tickets of mvs_event_record: a ring of events other lanes (or other devices' contexts) make their streams wait for
+    hipEvent_t ticket_ev[32] = {};
+    uint32_t ticket_next = 0;
     bool pinned_pending[2] = {false, false};
     // "mailbox": pinned host memory the device writes small results into directly (reduction partials, peak candidates): the host
     // reads them after the stream wait -- no copy launch, no staging through pageable memory

@@ -234,3 +234,227 @@ extern "C" int mvs_register_views(int device, const mvs_view_t* fixed_view, cons
     c->crop_stats_done[0] = c->crop_stats_done[1] = false;
     return rc;
 }
+
+
+// ---- all pairs of a mosaic in one call --------------------------------------------------------------------------------------------
+// registration.compute_pairwise_registrations (registration.py:2622-2714) hands every pair to its own dask task; the Python
+// mirror ran them from a pool of 16 interpreter threads, one context lane each -- and spent a third of the pairwise wall time
+// in the interpreter (plans, slab views, ctypes marshalling: ~0.2 ms per pair with the GIL held, 144 pairs per mosaic).  Here the
+// same loop lives in the library: mvs_plan_pairs derives the crop windows and pixel affines of all pairs (host code, the float
+// operations of the Python form in the same order), mvs_register_pairs runs mvs_register_views for every job on `n_lanes` native
+// worker threads, each driving its own context lane (stream, scratch, lock) of the GPU.
+#include <atomic>
+#include <condition_variable>
+#include <thread>
+
+namespace {
+// Python's bisect.bisect_left / bisect_right on a float64 array
+inline int64_t bisect_left(const double* c, int64_t n, double x) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (c[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+inline int64_t bisect_right(const double* c, int64_t n, double x) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (x < c[mid]) hi = mid; else lo = mid + 1; }
+    return lo;
+}
+inline double around10(double x) { return std::rint(x * 1e10) / 1e10; }      // np.around(x, 10)
+inline double pymax(double a, double b) { return b > a ? b : a; }             // max(a, b): the first unless the second is larger
+inline double pymin(double a, double b) { return b < a ? b : a; }
+}   // namespace
+
+// One plan per pair of translated views (register_pair_of_msims -> sims_to_intrinsic_coord_system -> get_pixel_affine,
+// registration.py:194-350 with transformation.py:37-83, for views whose transform is a pure translation): the index window of
+// each view the overlap (+ one sample and 1e-6 on either side) selects, the output grid = the fixed view's overlap grid, and
+// the diagonal pixel affines (rounded to 10 decimals, near-integer offsets snapped) of both crops.
+extern "C" int mvs_plan_pairs(int32_t ndim, int32_t n_views, const double* const* coords, const int64_t* coord_len, const double* translation,
+                              const double* tol, int32_t n_pairs, const int32_t* pairs, int64_t* windows_out, double* out_origin_out,
+                              double* out_spacing_out, int64_t* out_shape_out, double* matrix_diag_out, double* offset_out, int32_t* status_out) {
+    if (ndim < 1 || ndim > 3 || n_views < 1 || n_pairs < 0 || !coords || !coord_len || !translation || (n_pairs > 0 && !pairs) || !windows_out ||
+        !out_origin_out || !out_spacing_out || !out_shape_out || !matrix_diag_out || !offset_out || !status_out)
+        return MVS_ERR_INVALID_ARG;
+    for (int v = 0; v < n_views * ndim; ++v)
+        if (!coords[v] || coord_len[v] < 1) return MVS_ERR_INVALID_ARG;
+    for (int p = 0; p < n_pairs; ++p) {
+        const int v[2] = {pairs[2 * p], pairs[2 * p + 1]};
+        status_out[p] = 1;                                  // no overlap until proven otherwise
+        if (v[0] < 0 || v[1] < 0 || v[0] >= n_views || v[1] >= n_views) return MVS_ERR_INVALID_ARG;
+        double lowers[2][3], uppers[2][3];
+        bool ok = true;
+        for (int k = 0; k < ndim && ok; ++k) {
+            double lo2[2], hi2[2];
+            for (int i = 0; i < 2; ++i) {
+                const double* c = coords[(size_t)v[i] * ndim + k];
+                int64_t n = coord_len[(size_t)v[i] * ndim + k];
+                double o = c[0];
+                const double s = n > 1 ? c[1] - c[0] : 1.0;
+                if (tol) { n = n + (int64_t)std::ceil(2 * tol[k] / s); o = o - tol[k]; }
+                const double t = translation[(size_t)v[i] * ndim + k];
+                lo2[i] = o + t;
+                hi2[i] = ((double)(n - 1) * 1.0 * s + o) + t;
+            }
+            const double lo = pymax(lo2[0], lo2[1]), hi = pymin(hi2[0], hi2[1]);
+            if (hi < lo) { ok = false; break; }
+            const double up = 1.0 * (hi - lo) + lo;
+            for (int i = 0; i < 2; ++i) {
+                const double t = translation[(size_t)v[i] * ndim + k];
+                lowers[i][k] = lo + (-t);
+                uppers[i][k] = up + (-t);
+            }
+        }
+        if (!ok) continue;
+        double origins[2][3], spacings[2][3];
+        for (int i = 0; i < 2 && ok; ++i)
+            for (int k = 0; k < ndim; ++k) {
+                const double* c = coords[(size_t)v[i] * ndim + k];
+                const int64_t n = coord_len[(size_t)v[i] * ndim + k];
+                const double gs = n > 1 ? c[1] - c[0] : 1.0;
+                const double start = lowers[i][k] - 1e-6 - gs, stop = uppers[i][k] + 1e-6 + gs;
+                const int64_t a = bisect_left(c, n, start), b = bisect_right(c, n, stop);
+                if (b <= a) { ok = false; break; }
+                windows_out[(((size_t)p * 2 + i) * 3 + k) * 2] = a;
+                windows_out[(((size_t)p * 2 + i) * 3 + k) * 2 + 1] = b;
+                origins[i][k] = c[a];
+                spacings[i][k] = (b - a > 1) ? c[a + 1] - c[a] : 1.0;
+            }
+        if (!ok) continue;
+        for (int k = 0; k < ndim; ++k) {
+            const double osp = pymax(spacings[0][k], spacings[1][k]);
+            const double oo = lowers[0][k];
+            out_spacing_out[(size_t)p * 3 + k] = osp;
+            out_origin_out[(size_t)p * 3 + k] = oo;
+            out_shape_out[(size_t)p * 3 + k] = (int64_t)std::floor((uppers[0][k] - lowers[0][k]) / osp + 1);
+            const double t_rel = translation[(size_t)v[0] * ndim + k] + (-translation[(size_t)v[1] * ndim + k]);     // inv(A2) @ A1
+            for (int i = 0; i < 2; ++i) {
+                const double tt = i == 0 ? 0.0 : t_rel;
+                matrix_diag_out[((size_t)p * 2 + i) * 3 + k] = around10((1.0 * osp) / spacings[i][k]);
+                const double val = around10(((tt + 0.0) - (origins[i][k] - oo)) / spacings[i][k]);
+                const double r = std::rint(val);
+                offset_out[((size_t)p * 2 + i) * 3 + k] = std::fabs(val - r) <= 1e-6 ? r : val;
+            }
+        }
+        status_out[p] = 0;
+    }
+    return MVS_OK;
+}
+
+namespace {
+// persistent worker threads of mvs_register_pairs (one set per process; a batch is handed over under the mutex)
+struct PairBatch {
+    int device = 0;
+    int n_pairs = 0;
+    const mvs_pair_job_t* jobs = nullptr;
+    int ndim = 3, upsample = 2, region_mode = -1, constant_check = 0;
+    double* t_out = nullptr;
+    double* quality_out = nullptr;
+    int32_t* status_out = nullptr;
+    int32_t* ncand_out = nullptr;
+    int32_t* rc_out = nullptr;
+    std::atomic<int> next{0};
+};
+
+void run_pairs_on_lane(PairBatch* b, int lane) {
+    const int dev = (b->device & 0xff) | (lane << 8);
+    int init_rc = mvs_init(dev);
+    for (;;) {
+        const int p = b->next.fetch_add(1);
+        if (p >= b->n_pairs) break;
+        const mvs_pair_job_t& j = b->jobs[p];
+        int rc = init_rc;
+        for (int k = 0; k < 2 && !rc; ++k)
+            if (j.wait_ticket[k]) rc = mvs_event_wait(dev, j.wait_ticket[k]);
+        int32_t status = 0, ncand = 0;
+        double t[3] = {0.0, 0.0, 0.0}, q = NAN;
+        if (!rc)
+            rc = mvs_register_views(dev, &j.fixed, &j.moving, b->ndim, j.out_shape, b->upsample, b->region_mode, b->constant_check, t, &q, &status, &ncand);
+        for (int k = 0; k < 3; ++k) b->t_out[(size_t)p * 3 + k] = t[k];
+        b->quality_out[p] = q;
+        b->status_out[p] = status;
+        if (b->ncand_out) b->ncand_out[p] = ncand;
+        b->rc_out[p] = rc;
+        if (rc) b->status_out[p] = -(lane + 1);      // (which lane's mvs_last_error holds the message)
+    }
+}
+
+struct PairPool {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> threads;
+    PairBatch* batch = nullptr;
+    uint64_t generation = 0;
+    int active_lanes = 0, pending = 0;
+    std::mutex call_mu;              // one batch at a time
+
+    void worker(int lane) {
+        uint64_t seen = 0;
+        for (;;) {
+            PairBatch* b;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return generation != seen; });
+                seen = generation;
+                b = lane < active_lanes ? batch : nullptr;
+            }
+            if (!b) continue;
+            run_pairs_on_lane(b, lane);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+};
+PairPool* pair_pool() {
+    static PairPool* pool = new PairPool();      // (never destroyed: its threads wait for work until the process ends)
+    return pool;
+}
+}   // namespace
+
+extern "C" int mvs_register_pairs(int device, int32_t n_pairs, const mvs_pair_job_t* jobs, int32_t ndim, int32_t upsample_factor,
+                                  int32_t region_mode, int32_t constant_check, int32_t n_lanes, double* t_out, double* quality_out,
+                                  int32_t* status_out, int32_t* n_candidates_out, int32_t* rc_out) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    if (n_pairs < 0 || (n_pairs > 0 && (!jobs || !t_out || !quality_out || !status_out || !rc_out)))
+        return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_register_pairs: NULL argument");
+    if (ndim != 2 && ndim != 3) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_register_pairs: ndim must be 2 or 3");
+    if (device >> 8) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_register_pairs: pass the device without a lane (the call uses lanes 0 .. n_lanes - 1)");
+    if (n_pairs == 0) return MVS_OK;
+    n_lanes = std::max(1, std::min(std::min((int)n_lanes, (int)MVS_MAX_LANES), (int)n_pairs));
+    PairBatch b;
+    b.device = device; b.n_pairs = n_pairs; b.jobs = jobs; b.ndim = ndim; b.upsample = upsample_factor; b.region_mode = region_mode;
+    b.constant_check = constant_check; b.t_out = t_out; b.quality_out = quality_out; b.status_out = status_out; b.ncand_out = n_candidates_out;
+    b.rc_out = rc_out;
+    if (n_lanes == 1) {
+        run_pairs_on_lane(&b, 0);
+    } else {
+        PairPool* pool = pair_pool();
+        std::lock_guard<std::mutex> call(pool->call_mu);
+        {
+            std::lock_guard<std::mutex> lk(pool->mu);
+            while ((int)pool->threads.size() < n_lanes - 1) {
+                const int lane = (int)pool->threads.size() + 1;          // (the calling thread drives lane 0)
+                pool->threads.emplace_back([pool, lane] { pool->worker(lane); });
+                pool->threads.back().detach();
+            }
+            pool->batch = &b;
+            pool->active_lanes = n_lanes;
+            pool->pending = n_lanes - 1;
+            ++pool->generation;
+        }
+        pool->cv_work.notify_all();
+        run_pairs_on_lane(&b, 0);
+        std::unique_lock<std::mutex> lk(pool->mu);
+        pool->cv_done.wait(lk, [&] { return pool->pending == 0; });
+        pool->batch = nullptr;
+    }
+    for (int p = 0; p < n_pairs; ++p)
+        if (rc_out[p]) {
+            const int lane = -status_out[p] - 1;
+            MvsContext* lc = mvs_ctx((device & 0xff) | (std::max(lane, 0) << 8));
+            return mvs_fail(c, rc_out[p], "mvs_register_pairs: pair %d failed: %s", p, lc ? lc->last_error.c_str() : "?");
+        }
+    return MVS_OK;
+}

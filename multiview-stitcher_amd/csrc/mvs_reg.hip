@@ -903,10 +903,77 @@ __global__ __launch_bounds__(256) void bin_mean_u16x2_kernel(const unsigned shor
             make_uint2((unsigned int)r[0] | ((unsigned int)r[1] << 16), (unsigned int)r[2] | ((unsigned int)r[3] << 16));
     }
 }
+// the same for up to kBinBatch views of one shape in one launch: blockIdx.y = view (pointer table in the kernel arguments)
+constexpr int kBinBatch = 32;
+struct BinBatch {
+    const unsigned short* in[kBinBatch];
+    unsigned short* out[kBinBatch];
+};
+__global__ __launch_bounds__(256) void bin_mean_u16x2_batch_kernel(BinBatch B, long long sz, long long sy, int oz, int oy, int ox, int bz, int by) {
+    const unsigned short* __restrict__ in = B.in[blockIdx.y];
+    unsigned short* __restrict__ out = B.out[blockIdx.y];
+    const int gx = ox >> 2;
+    const long long ngroups = (long long)oz * oy * gx;
+    const double inv = 1.0 / ((double)bz * by * 2);
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (long long)gridDim.x * blockDim.x) {
+        const int xg = (int)(g % gx);
+        const long long t = g / gx;
+        const int y = (int)(t % oy), z = (int)(t / oy);
+        unsigned int acc[4] = {0u, 0u, 0u, 0u};
+        for (int dz = 0; dz < bz; ++dz)
+            for (int dy = 0; dy < by; ++dy) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(in + (long long)(z * bz + dz) * sz + (long long)(y * by + dy) * sy + (long long)xg * 8);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k] += (v[k] & 0xffffu) + (v[k] >> 16);
+            }
+        unsigned short r[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = (unsigned short)((double)acc[k] * inv);   // astype: truncation
+        *reinterpret_cast<uint2*>(out + ((long long)z * oy + y) * ox + (long long)xg * 4) =
+            make_uint2((unsigned int)r[0] | ((unsigned int)r[1] << 16), (unsigned int)r[2] | ((unsigned int)r[3] << 16));
+    }
+}
 }  // namespace
 
 static int bin_mean_impl(int device, const void* in, int32_t dtype, int32_t mem, const int64_t shape[3], const int64_t stride[3],
                          const int64_t bin[3], void* out, int32_t out_mem, bool wait);
+
+// mvs_bin_mean_async for n views of one shape, stride and dtype in one call (and, for 16-bit tiles binned by 2 along x, one launch per
+// kBinBatch views): registration.register bins all tiles of a mosaic before its pairs start.
+extern "C" int mvs_bin_mean_batch_async(int device, int32_t n_views, const void* const* in, int32_t dtype, const int64_t shape[3],
+                                        const int64_t stride[3], const int64_t bin[3], void* const* out) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    if (n_views < 0 || (n_views > 0 && (!in || !out)) || !shape || !stride || !bin) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_bin_mean_batch_async: NULL argument");
+    bool vec = dtype == MVS_U16 && stride[2] == 1 && bin[2] == 2 && bin[0] >= 1 && bin[1] >= 1 && shape[0] >= bin[0] && shape[1] >= bin[1] &&
+               shape[2] >= 2 && (shape[2] / 2) % 4 == 0 && stride[1] % 8 == 0 && stride[0] % 8 == 0 && bin[0] * bin[1] <= 16384;
+    for (int v = 0; v < n_views && vec; ++v) vec = in[v] && out[v] && ((uintptr_t)in[v] % 16) == 0 && ((uintptr_t)out[v] % 8) == 0;
+    if (!vec) {
+        for (int v = 0; v < n_views; ++v) {
+            rc = bin_mean_impl(device, in[v], dtype, MVS_MEM_DEVICE, shape, stride, bin, out[v], MVS_MEM_DEVICE, false);
+            if (rc) return rc;
+        }
+        return MVS_OK;
+    }
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
+    const int oz = (int)(shape[0] / bin[0]), oy = (int)(shape[1] / bin[1]), ox = (int)(shape[2] / 2);
+    const long long n = (long long)oz * oy * ox;
+    for (int v0 = 0; v0 < n_views; v0 += kBinBatch) {
+        const int nb = std::min(kBinBatch, n_views - v0);
+        BinBatch B;
+        for (int k = 0; k < kBinBatch; ++k) {
+            B.in[k] = (const unsigned short*)in[v0 + std::min(k, nb - 1)];
+            B.out[k] = (unsigned short*)out[v0 + std::min(k, nb - 1)];
+        }
+        hipLaunchKernelGGL(bin_mean_u16x2_batch_kernel, dim3(grid_for(n / 4), nb), dim3(256), 0, c->stream, B, (long long)stride[0], (long long)stride[1],
+                           oz, oy, ox, (int)bin[0], (int)bin[1]);
+    }
+    MVS_HIP_TRY(c, hipGetLastError());
+    return MVS_OK;
+}
 
 extern "C" int mvs_bin_mean(int device, const void* in, int32_t dtype, int32_t mem, const int64_t shape[3],
                             const int64_t stride[3], const int64_t bin[3], void* out, int32_t out_mem) {

@@ -648,6 +648,69 @@ _METHODS = {
 }
 
 
+def resolve_translations_native(n_views, edges, results, spacings, reference_view=None, transform="translation", max_iter=None,
+                                rel_tol=None, abs_tol=None):
+    """``groupwise_resolution(g, "global_optimization", ...)`` for registration.register's common case in ONE library call
+    (``mvs_resolve_translations``, host code): views 0 .. n_views - 1 in one connected component, every pairwise result a pure
+    translation, the translation model, and sweeps that end below ``abs_tol`` (no edge is removed).  ``edges``: sorted view
+    pairs in the order they would be added to the RegGraph; ``results``: their {"transform", "quality", "bbox"}; ``spacings``:
+    (n_views, ndim).  Returns ``(params list, info)`` exactly as groupwise_resolution reports them, or None when the case is
+    not covered -- the caller then builds the RegGraph and takes the Python form (tests/test_resolve_native.py compares)."""
+    import ctypes as C
+
+    from . import _lib
+
+    ne = len(edges)
+    if ne < 1 or str(transform).lower() != "translation" or n_views < 2:
+        return None
+    if reference_view is None and n_views == 2:
+        reference_view = 0                                    # min(g.nodes) (param_resolution/__init__.py:97-98)
+    if reference_view is not None:
+        if isinstance(reference_view, bool) or not isinstance(reference_view, (int, np.integer)):
+            return None
+        if not 0 <= int(reference_view) < n_views:
+            reference_view = None                             # not a node: the maximal-quality view is taken
+    try:
+        T = np.array([r["transform"] for r in results], dtype=np.float64)
+        q = np.array([r["quality"] for r in results], dtype=np.float64)
+        bb = np.array([r["bbox"] for r in results], dtype=np.float64)
+        en = np.ascontiguousarray(edges, dtype=np.int32)
+    except (TypeError, ValueError, KeyError):
+        return None
+    sp = np.ascontiguousarray(spacings, dtype=np.float64)
+    nd = sp.shape[1] if sp.ndim == 2 else 0
+    if T.shape != (ne, nd + 1, nd + 1) or bb.shape != (ne, 2, nd) or q.shape != (ne,) or en.shape != (ne, 2) or sp.shape != (n_views, nd):
+        return None
+    if np.any(T[:, :nd, :nd] != np.eye(nd)) or np.any(T[:, nd, :nd] != 0.0) or np.any(T[:, nd, nd] != 1.0):
+        return None
+    max_iter = 500 if max_iter is None else int(max_iter)
+    rel_tol = 1e-4 if rel_tol is None else float(rel_tol)
+    if max_iter < 1:
+        return None
+    pt = np.ascontiguousarray(T[:, :nd, nd])
+    lo, hi = np.ascontiguousarray(bb[:, 0]), np.ascontiguousarray(bb[:, 1])
+    t_out = np.zeros((n_views, nd))
+    rms = np.zeros(ne)
+    mh, xh = np.zeros(max_iter), np.zeros(max_iter)
+    nit, ref = C.c_int32(0), C.c_int32(-1)
+    ptr = lambda a, ty: a.ctypes.data_as(C.POINTER(ty))
+    rc = _lib.load().mvs_resolve_translations(
+        nd, n_views, ne, ptr(en, C.c_int32), ptr(pt, C.c_double), ptr(q, C.c_double), ptr(lo, C.c_double), ptr(hi, C.c_double),
+        ptr(sp, C.c_double), -1 if reference_view is None else int(reference_view), max_iter, rel_tol,
+        -1.0 if abs_tol is None else float(abs_tol), ptr(t_out, C.c_double), ptr(rms, C.c_double), ptr(mh, C.c_double),
+        ptr(xh, C.c_double), C.byref(nit), C.byref(ref))
+    if rc != 0:
+        return None
+    n = int(nit.value)
+    params = np.zeros((n_views, nd + 1, nd + 1))
+    params[:, np.arange(nd + 1), np.arange(nd + 1)] = 1.0
+    params[:, :nd, nd] = t_out
+    keys = [(int(a), int(b)) for a, b in en.tolist()]
+    info = {"metrics": [{"mean_residual": mh[:n].tolist(), "max_residual": xh[:n].tolist(), "iteration": list(range(n)), "icc": 0}],
+            "edge_residuals": {0: dict(zip(keys, rms.tolist()))}, "used_edges": {0: sorted(keys)}}
+    return list(params), info
+
+
 def register_groupwise_resolution_method(name, resolver):
     """``resolver(RegGraph of one connected component, **kwargs) -> (params, info)`` (__init__.py:23-33)."""
     if not callable(resolver):

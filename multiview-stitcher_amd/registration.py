@@ -495,8 +495,176 @@ def _lean_register_pair(g1b, g2b, g1, g2, sdims, tol, upsample_factor, transform
 
 
 _lean_enabled = [True]      # tests switch the lean path off to compare it with the generic one
+_PREBIN_GROUP = [8]         # tiles per binning launch / ticket of register()'s pre-binning (the pairs of a group's tiles start after it)
 _native_graph = [True]      # tests: register() through mv_graph's generic graph functions instead of mvs_view_graph_prune
 _native_resolution = [True]     # tests: register() through param_resolution's generic functions instead of mvs_resolve_translations
+
+
+_JOB_DTYPE = np.dtype(_lib.mvs_pair_job_t)
+
+_BATCH_LANES = [8]          # context lanes / native worker threads of the batched pair path when the caller does not say (n_parallel_pairwise_regs)
+_batch_enabled = [True]     # tests: compute_pairwise_registrations through the per-pair worker threads instead of mvs_register_pairs
+
+
+def _pair_results_from_plan(ts, qualities, statuses, out_origin, out_spacing, out_shape, fixed_affines, lo_world, up_world):
+    """The result dicts of _lean_register_pair for all pairs at once: the pixel translation of every pair turned into the
+    physical affine (get_affine_from_intrinsic_affine with both crops on the fixed view's overlap grid, registration.py:1382-1474)
+    -- the same matmul / inverse chain per pair, on stacked (pairs, n + 1, n + 1) arrays -- and the overlap box in world
+    coordinates.  Statuses as mvs_register_crops reports them (2: constant overlap -> identity + warning; 1 / 3 raise)."""
+    ne, n = ts.shape
+    for k in range(ne):      # errors in pair order, like the futures of the worker pool
+        if statuses[k] == 1:
+            raise RuntimeError("phase correlation produced no admissible shift candidate (registration.py:479-480)")
+        if statuses[k] == 3:
+            raise ValueError("All-NaN slice encountered")
+    const = statuses == 2
+    for _ in range(int(np.count_nonzero(const))):
+        warnings.warn("An overlap region between tiles/views is all zero or constant. Assuming identity transform.", UserWarning, stacklevel=4)
+    affine = np.zeros((ne, n + 1, n + 1))
+    affine[:, np.arange(n + 1), np.arange(n + 1)] = 1.0
+    affine[:, :n, n] = np.where(const[:, None], 0.0, ts)
+    quality = np.where(const, np.nan, qualities)
+    # origin / spacing as the getters read them back from the crops' coordinate arrays (o + s * arange): c[0] and c[1] - c[0]
+    eff_spacing = np.where(out_shape > 1, (out_origin + out_spacing * 1.0) - (out_origin + out_spacing * 0.0), 1.0)
+    eff_origin = out_origin + out_spacing * 0.0
+    shift = np.zeros((ne, n + 1, n + 1))
+    shift[:, np.arange(n + 1), np.arange(n + 1)] = 1.0
+    shift[:, :n, n] = eff_origin
+    scale = np.zeros((ne, n + 1, n + 1))
+    scale[:, np.arange(n), np.arange(n)] = eff_spacing
+    scale[:, n, n] = 1.0
+    d_to_p = np.matmul(shift, scale)
+    D = np.matmul(fixed_affines, d_to_p)
+    affine_phys = np.matmul(D, np.matmul(affine, np.linalg.inv(D)))
+    return [{"transform": affine_phys[k], "quality": float(quality[k]), "bbox": np.array([lo_world[k], up_world[k]])} for k in range(ne)]
+
+
+def _register_pairs_batched(sims, edges, transform_key, registration_binning, overlap_tolerance, pairwise_reg_func_kwargs, device,
+                            n_lanes, cache):
+    """compute_pairwise_registrations for the common case in two library calls: plain device-resident images of one dtype whose
+    transforms are pure translations, one binning for all pairs, the built-in phase correlation.  ``mvs_plan_pairs`` derives the
+    crop windows and pixel affines of all pairs (host code), ``mvs_register_pairs`` registers them on ``n_lanes`` context lanes
+    driven by native threads; the interpreter only assembles the inputs and turns the pixel shifts into physical affines
+    (stacked matmuls).  Returns the list of result dicts, or None when the case is not covered (the caller then takes the
+    per-pair path).  Same plans, same kernels, same results as _lean_register_pair (tests/test_pair_batch.py, -m gpu tests)."""
+    import ctypes as C
+
+    from . import msi_utils
+    from . import spatial_image_utils as si_utils
+
+    if not edges or any(msi_utils.is_msim(m) for m in sims):
+        return None
+    used = sorted({v for e in edges for v in e})
+    sdims = si_utils.get_spatial_dims_from_sim(sims[used[0]])
+    n = len(sdims)
+    first = sims[used[0]]
+    for v in used:
+        s_ = sims[v]
+        if list(s_.dims) != list(sdims) or not is_device_array(s_.data) or s_.data.dtype != first.data.dtype or s_.data.dtype not in _lib.DTYPE_CODES:
+            return None
+    if registration_binning is None:
+        shape0, sp0 = si_utils.get_shape_from_sim(first), si_utils.get_spacing_from_sim(first)
+        if any(si_utils.get_shape_from_sim(sims[v]) != shape0 or si_utils.get_spacing_from_sim(sims[v]) != sp0 for v in used[1:]):
+            return None                  # the optimal binning would differ between pairs
+        binning = get_optimal_registration_binning(sims[edges[0][0]], sims[edges[0][1]])
+    else:
+        binning = dict(registration_binning)
+    if overlap_tolerance is None:
+        tol = [0.0] * n
+    elif isinstance(overlap_tolerance, (int, float)):
+        tol = [float(overlap_tolerance)] * n
+    else:
+        tol = [float(overlap_tolerance.get(d, 0.0)) for d in sdims]
+    bkey = tuple(sorted(binning.items()))
+    do_bin = max(binning.values()) > 1
+    geoms, geoms_b, binned, tickets = {}, {}, {}, {}
+    for v in used:
+        s_ = sims[v]
+        if do_bin:
+            key = (id(s_.data), bkey)
+            b_ = cache.get_or_compute(key, lambda s_=s_: _bin_sim(s_, binning, device), keep=s_.data)
+            tickets[v] = cache.ticket_of(key) or 0
+        else:
+            b_, tickets[v] = s_, 0
+        binned[v] = b_
+        geoms[v], geoms_b[v] = _geom_of(s_, transform_key, cache), _geom_of(b_, transform_key, cache)
+        if geoms[v].t is None or geoms_b[v].t is None or (b_.data.device & 0xff) != (device & 0xff) or b_.data.strides[-1] != 1:
+            return None
+    slot = {v: i for i, v in enumerate(used)}
+    nv, ne = len(used), len(edges)
+    # ---- plans of all pairs (mvs_plan_pairs: the arithmetic of _lean_pair_plan) ----
+    cptr = (C.c_void_p * (nv * n))(*[geoms_b[v].coords[k].ctypes.data for v in used for k in range(n)])
+    clen = np.array([len(geoms_b[v].coords[k]) for v in used for k in range(n)], dtype=np.int64)
+    tr = np.array([geoms_b[v].t for v in used], dtype=np.float64).reshape(nv, n)
+    tolv = np.array(tol, dtype=np.float64)
+    pr = np.array([[slot[a], slot[b]] for a, b in edges], dtype=np.int32).reshape(ne, 2)
+    windows = np.zeros((ne, 2, 3, 2), dtype=np.int64)
+    out_origin, out_spacing = np.zeros((ne, 3)), np.zeros((ne, 3))
+    out_shape = np.ones((ne, 3), dtype=np.int64)
+    mdiag, offs = np.zeros((ne, 2, 3)), np.zeros((ne, 2, 3))
+    pstat = np.zeros(ne, dtype=np.int32)
+    ptr = lambda a, ty: a.ctypes.data_as(C.POINTER(ty))
+    lib = _lib.init(device & 0xff)
+    rc = lib.mvs_plan_pairs(n, nv, cptr, ptr(clen, C.c_int64), ptr(tr, C.c_double), ptr(tolv, C.c_double), ne, ptr(pr, C.c_int32),
+                            ptr(windows, C.c_int64), ptr(out_origin, C.c_double), ptr(out_spacing, C.c_double), ptr(out_shape, C.c_int64),
+                            ptr(mdiag, C.c_double), ptr(offs, C.c_double), ptr(pstat, C.c_int32))
+    if rc != 0:
+        return None
+    if np.any(pstat != 0):
+        raise ValueError("views do not overlap")
+    # ---- jobs: the two crop windows of every pair as mvs_view_t (strided windows into the binned tiles) ----
+    jobs = (_lib.mvs_pair_job_t * ne)()
+    ja = np.frombuffer(jobs, dtype=_JOB_DTYPE)
+    k0 = 3 - n
+    base = np.array([binned[v].data.ptr for v in used], dtype=np.uint64)
+    strides = np.array([[int(x) for x in binned[v].data.strides] for v in used], dtype=np.int64).reshape(nv, n)
+    item = first.data.dtype.itemsize
+    code = _lib.DTYPE_CODES[first.data.dtype]
+    tk = np.array([tickets[v] for v in used], dtype=np.uint64)
+    for i, name in enumerate(("fixed", "moving")):
+        f = ja[name]
+        vi = pr[:, i]
+        a, b = windows[:, i, :n, 0], windows[:, i, :n, 1]
+        st = strides[vi]
+        f["data"] = base[vi] + (np.sum(a * st, axis=1) * item).astype(np.uint64)
+        f["dtype"] = code
+        f["mem"] = _lib.MVS_MEM_DEVICE
+        f["shape"][:, :k0] = 1
+        f["shape"][:, k0:] = b - a
+        if n == 3:
+            f["stride"][:] = st
+        else:       # a 2D slab is one z plane
+            f["stride"][:, 0] = st[:, 0] * (b - a)[:, 0]
+            f["stride"][:, 1:] = st
+        f["matrix"][:] = 0.0
+        f["matrix"][:, [0, 4, 8]] = 1.0
+        f["matrix"][:, [(k0 + k) * 4 for k in range(n)]] = mdiag[:, i, :n]
+        f["offset"][:] = 0.0
+        f["offset"][:, k0:] = offs[:, i, :n]
+        ja["wait_ticket"][:, i] = tk[vi]
+    ja["out_shape"][:, :k0] = 1
+    ja["out_shape"][:, k0:] = out_shape[:, :n]
+    upsample_factor = (pairwise_reg_func_kwargs or {}).get("upsample_factor")
+    uf = (10 if n == 2 else 2) if upsample_factor is None else upsample_factor
+    t3, q = np.zeros((ne, 3)), np.zeros(ne)
+    status, ncand, rcs = np.zeros(ne, dtype=np.int32), np.zeros(ne, dtype=np.int32), np.zeros(ne, dtype=np.int32)
+    rc = lib.mvs_register_pairs(device & 0xff, ne, jobs, n, int(uf), -1, 1, int(n_lanes), ptr(t3, C.c_double), ptr(q, C.c_double),
+                                ptr(status, C.c_int32), ptr(ncand, C.c_int32), ptr(rcs, C.c_int32))
+    _lib.check(rc, device & 0xff, "mvs_register_pairs")
+    # ---- overlap boxes in world coordinates (_lean_overlap on the UNBINNED views) and the physical affines ----
+    o = np.array([geoms[v].origin for v in used], dtype=np.float64).reshape(nv, n)
+    sp = np.array([geoms[v].spacing for v in used], dtype=np.float64).reshape(nv, n)
+    shp = np.array([geoms[v].shape for v in used], dtype=np.int64).reshape(nv, n)
+    tw = np.array([geoms[v].t for v in used], dtype=np.float64).reshape(nv, n)
+    shp = shp + np.ceil(2 * tolv / sp).astype(np.int64)
+    o = o - tolv
+    lo_v = o + tw
+    hi_v = ((shp - 1) * 1.0 * sp + o) + tw
+    lo = np.maximum(lo_v[pr[:, 0]], lo_v[pr[:, 1]])
+    hi = np.minimum(hi_v[pr[:, 0]], hi_v[pr[:, 1]])
+    up = 1.0 * (hi - lo) + lo
+    fixed_aff = np.array([geoms_b[v].affine for v in used], dtype=np.float64)[pr[:, 0]]
+    return _pair_results_from_plan(t3[:, k0:], q, status, out_origin[:, :n], out_spacing[:, :n], out_shape[:, :n], fixed_aff, lo, up)
 
 
 def _geom_of(sim, transform_key, cache):
@@ -578,7 +746,11 @@ def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=Non
         if _bin_cache is None:
             return _bin_sim(sim, registration_binning, device)
         # (the cache slot keeps sim.data alive, so its id() cannot be recycled for another tile while the cache lives)
-        return _bin_cache.get_or_compute(key, lambda: _bin_sim(sim, registration_binning, device), keep=sim.data)
+        out = _bin_cache.get_or_compute(key, lambda: _bin_sim(sim, registration_binning, device), keep=sim.data)
+        ticket = _bin_cache.ticket_of(key)
+        if ticket is not None:       # pre-binned on another lane, possibly still in flight: this lane's stream waits for it (no host wait)
+            _lib.check(_lib.init(device).mvs_event_wait(device, ticket), device, "mvs_event_wait")
+        return out
 
     reg_sims_b = [binned(sim1), binned(sim2)]
     if pairwise_reg_func is phase_correlation_registration and set(pairwise_reg_func_kwargs) <= {"upsample_factor"} and _lean_enabled[0] \
@@ -633,6 +805,8 @@ def _prebin_views(sims, registration_binning, device, cache):
     bkey = tuple(sorted(binning.items()))
     lane_device = (device & 0xff) | (15 << 8)        # the last context lane: the pair workers take lanes from 0 upwards
 
+    import ctypes as C
+
     from .device import DeviceArray
     from .transformation import shape3
 
@@ -644,9 +818,15 @@ def _prebin_views(sims, registration_binning, device, cache):
     nd = len(sdims)
     shape = [int(v) for v in sims[0].data.shape]
     oshape = tuple(n // b for n, b in zip(shape, bins))
+    datas = [s.data.on_device(lane_device) for s in sims]
+    st0 = tuple(datas[0].strides)
+    if any(tuple(d.strides) != st0 for d in datas):
+        return None
     pool = DeviceArray.empty((len(sims),) + oshape, dtype, lane_device)     # one allocation for all binned tiles
     lib = _lib.init(lane_device)
-    s3, b3 = _lib.i64x3(shape3(shape)), _lib.i64x3([1] * (3 - nd) + bins)
+    st = [int(v) for v in st0]
+    st3 = st if nd == 3 else [st[0] * shape[0], st[0], st[1]]
+    s3, b3, st3 = _lib.i64x3(shape3(shape)), _lib.i64x3([1] * (3 - nd) + bins), _lib.i64x3(st3)
     code = _lib.DTYPE_CODES[dtype]
     # the coarsened coordinates of _bin_sim (mean of each group of b: the sum divided by b, as numpy's mean does it), all views
     # of an axis in one reduction (the same additions per element as view by view)
@@ -654,22 +834,34 @@ def _prebin_views(sims, registration_binning, device, cache):
     for d, b, n in zip(sdims, bins, oshape):
         stack = np.stack([np.asarray(s.coords[d])[: n * b] for s in sims])
         all_coords[d] = np.add.reduce(stack.reshape(len(sims), n, b), axis=2) / b
+    # the tiles are binned in groups (one library call and one ticket each): a pair starts as soon as the groups of its two
+    # tiles are done, while the later groups are still being binned (mvs_event_record / mvs_event_wait, no host wait)
+    n_v = len(sims)
+    item = int(np.prod(oshape)) * dtype.itemsize
+    group = max(1, _PREBIN_GROUP[0])
+    tickets = []
+    for g0 in range(0, n_v, group):
+        g1 = min(g0 + group, n_v)
+        ins = (C.c_void_p * (g1 - g0))(*[datas[i].ptr for i in range(g0, g1)])
+        outs = (C.c_void_p * (g1 - g0))(*[pool.ptr + i * item for i in range(g0, g1)])
+        _lib.check(lib.mvs_bin_mean_batch_async(lane_device, g1 - g0, ins, code, s3, st3, b3, outs), lane_device, "mvs_bin_mean_batch_async")
+        tk = C.c_uint64(0)
+        _lib.check(lib.mvs_event_record(lane_device, C.byref(tk)), lane_device, "mvs_event_record")
+        tickets.append(int(tk.value))
+    tdims = tuple(sdims)
+    ostr = tuple(int(np.prod(oshape[i + 1:])) for i in range(nd))
     for i, s in enumerate(sims):
-        data = s.data.on_device(lane_device)
-        st = [int(v) for v in data.strides]
-        st3 = st if nd == 3 else [st[0] * shape[0], st[0], st[1]]
-        out = pool[i]
-        _lib.check(lib.mvs_bin_mean_async(lane_device, data.ptr, code, s3, _lib.i64x3(st3), b3, out.ptr), lane_device, "mvs_bin_mean_async")
+        out = DeviceArray(pool._buf, pool.ptr + i * item, oshape, ostr, dtype, lane_device)
         coords = {d: all_coords[d][i] for d in sdims}
         # (coordinates of the right lengths by construction: no checks)
-        binned = si_utils.SpatialImage._from_parts(out, tuple(sdims), coords, {"transforms": dict(s.attrs.get("transforms", {}))}, None)
-        cache.put((id(s.data), bkey), binned, keep=(s.data, data))
+        binned = si_utils.SpatialImage._from_parts(out, tdims, coords, {"transforms": dict(s.attrs.get("transforms", {}))}, None)
+        cache.put((id(s.data), bkey), binned, keep=(s.data, datas[i]), ticket=tickets[i // group])
     return lane_device
 
 
 def compute_pairwise_registrations(msims, edges, transform_key, registration_binning=None, overlap_tolerance=0.0,
                                    pairwise_reg_func=phase_correlation_registration, pairwise_reg_func_kwargs=None,
-                                   pairwise_executor=None, device=0, host_threads=16, _bin_cache=None, reg_res_level=None):
+                                   pairwise_executor=None, device=0, host_threads=None, _bin_cache=None, reg_res_level=None):
     """registration.compute_pairwise_registrations (registration.py:2622-2714): either hand all edges to a
     user ``pairwise_executor(msims, edges, register_kwargs)`` or loop over them on one device."""
     register_kwargs = dict(transform_key=transform_key, registration_binning=registration_binning,
@@ -684,7 +876,19 @@ def compute_pairwise_registrations(msims, edges, transform_key, registration_bin
         return results
     cache = _bin_cache if _bin_cache is not None else _BinCache()
     edges = list(edges)
+    _host_threads_default = host_threads is None
+    if host_threads is None:
+        host_threads = 16
     n_threads = max(1, min(int(host_threads), len(edges), 16))   # 16 = context lanes per GPU (MVS_MAX_LANES)
+    if _batch_enabled[0] and _lean_enabled[0] and pairwise_reg_func is phase_correlation_registration and reg_res_level is None \
+            and set(pairwise_reg_func_kwargs or {}) <= {"upsample_factor"}:
+        # all pairs in two library calls (plans + registrations on native worker threads): no interpreter in the pair loop
+        # (native workers spin inside the HIP runtime between launches: 6-12 of them reach the GPU's pair throughput, 16 exhaust a
+        # 16-core CPU quota and are throttled to half speed -- profiles/round5_lanes.txt; the default is 8)
+        batched = _register_pairs_batched(msims, edges, transform_key, registration_binning, overlap_tolerance, pairwise_reg_func_kwargs,
+                                          device, min(n_threads, _BATCH_LANES[0] if _host_threads_default else 12), cache)
+        if batched is not None:
+            return batched
     if n_threads == 1:
         return [register_pair_of_msims(msims[i], msims[j], device=device, _bin_cache=cache, **register_kwargs) for i, j in edges]
     # Pairs are independent.  Every call into libmvs_hip.so releases the GIL; each worker thread drives its own
@@ -746,11 +950,17 @@ class _BinCache:
         self._items = {}
         self.hits = self.misses = 0      # (tests: the pre-binned tiles of register() must be found by every pair)
 
-    def put(self, key, value, keep=None):
-        """Store a finished value (``keep``: the objects whose id() is part of ``key``; the slot holds them alive)."""
-        slot = {"event": _FINISHED, "value": value, "error": None, "keep": keep}      # (one shared, already set event)
+    def put(self, key, value, keep=None, ticket=None):
+        """Store a finished value (``keep``: the objects whose id() is part of ``key``; the slot holds them alive).  ``ticket``:
+        the value's device memory is complete once this mvs_event_record ticket has passed -- a lane that reads it first makes
+        its stream wait for the ticket (``ticket_of``)."""
+        slot = {"event": _FINISHED, "value": value, "error": None, "keep": keep, "ticket": ticket}      # (one shared, already set event)
         with self._lock:
             self._items[key] = slot
+
+    def ticket_of(self, key):
+        slot = self._items.get(key)
+        return None if slot is None else slot.get("ticket")
 
     def get_or_compute(self, key, fn, keep=None):
         """``keep``: the object whose id() is part of ``key``; the slot holds a reference to it."""
@@ -903,12 +1113,12 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
             g_views = mv_graph.build_view_adjacency_graph(views, overlap_tolerance=tol, pairs=pairs)
             g_views = mv_graph.prune_view_adjacency_graph(g_views, pre_registration_pruning_method, pre_reg_pruning_method_kwargs)
             edges = [tuple(sorted(e)) for e in g_views.edges()]
-    finally:
+    except BaseException:
         if prebin is not None:
-            # the binned tiles are complete before any lane reads them (the pre-binning lane is the last context lane; the
-            # pair workers, which may reuse it, only start after this point) -- also when graph building raised: nothing
-            # stays queued on tiles the caller may free
-            _lib.synchronize(prebin)
+            _lib.synchronize(prebin)     # graph building raised: nothing stays queued on tiles the caller may free
+        raise
+    # (no wait here: every lane that reads a binned tile makes its stream wait for the tile's ticket, see register_pair_of_msims;
+    # the pre-binning lane is the last context lane, a pair worker that reuses it queues behind the binning anyway)
 
     # (2) pairwise registrations per time point
     params_t, all_results, resolution_info = [], [], []
@@ -916,6 +1126,9 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
         # per-time-point fields are shallow copies with their OWN transforms dict: the caller's images are never modified
         # (t-stacked affines of an image without a t axis would otherwise collapse to one time point for good)
         def field_of(s):
+            tr = s.attrs.get("transforms", {})
+            if pairwise_executor is None and "t" not in s.dims and all(np.ndim(v) == 2 for v in tr.values()):
+                return s      # nothing to select and the built-in pair path only reads: the image itself (a user executor gets copies)
             f = s.isel({"t": it}) if "t" in s.dims else s.copy()
             f.attrs["transforms"] = {k: param_utils.select_time(v, it) for k, v in s.attrs.get("transforms", {}).items()}
             return f
@@ -927,12 +1140,18 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
                 fields.append(msi_utils.MultiscaleSpatialImage(fl, fl[0].attrs["transforms"]))
         else:
             fields = [field_of(s) for s in sims_reg]
-        results = compute_pairwise_registrations(
-            fields, edges, transform_key, registration_binning, overlap_tolerance, pairwise_reg_func,
-            pairwise_reg_func_kwargs, pairwise_executor, device,
-            host_threads=(16 if n_parallel_pairwise_regs is None else n_parallel_pairwise_regs),
-            _bin_cache=bin_cache, reg_res_level=reg_res_level,
-        )
+        try:
+            results = compute_pairwise_registrations(
+                fields, edges, transform_key, registration_binning, overlap_tolerance, pairwise_reg_func,
+                pairwise_reg_func_kwargs, pairwise_executor, device,
+                host_threads=n_parallel_pairwise_regs,
+                _bin_cache=bin_cache, reg_res_level=reg_res_level,
+            )
+        finally:
+            if prebin is not None:
+                # (done long ago unless a tile took part in no pair or a pair raised: nothing stays queued on the caller's tiles)
+                _lib.synchronize(prebin)
+                prebin = None
         keep = list(range(len(edges)))
         if post_registration_do_quality_filter:
             # mv_graph.filter_edges removes edges with quality < threshold only: a NaN quality (constant overlap ->
@@ -943,6 +1162,19 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
             params_t.append(resolve_translations(len(sims), [edges[k] for k in keep], [results[k] for k in keep]))
             resolution_info.append(None)
         else:
+            fast = None
+            gkw = dict(groupwise_resolution_kwargs or {})
+            if groupwise_resolution_method == "global_optimization" and _native_resolution[0] and keep and \
+                    set(gkw) <= {"reference_view", "transform", "max_iter", "rel_tol", "abs_tol"}:
+                # a connected translation mosaic whose sweeps end below abs_tol: the whole resolution in one library call (host code)
+                fast = param_resolution.resolve_translations_native(
+                    len(sims), [edges[k] for k in keep], [results[k] for k in keep],
+                    [[sp["spacing"][d] for d in sp["spacing"]] for sp in sps], **gkw)
+            if fast is not None:
+                params_t.append(fast[0])
+                resolution_info.append(fast[1])
+                all_results.append(results)
+                continue
             g = param_resolution.RegGraph(range(len(sims)), {v: sps[v] for v in range(len(sims))})
             for k in keep:
                 g.add_edge(edges[k][0], edges[k][1], results[k]["transform"], quality=results[k]["quality"], bbox=results[k]["bbox"])

@@ -150,7 +150,7 @@ class ShardedPairExecutor:
     registration.py:2634-2655): this rank registers the pairs whose fixed view it owns, then every rank receives all
     results (``gather(obj) -> list over ranks``; default torch.distributed.all_gather_object)."""
 
-    def __init__(self, rank, world_size, owners, device=0, gather=None, register_fn=None, host_threads=16):
+    def __init__(self, rank, world_size, owners, device=0, gather=None, register_fn=None, host_threads=None):
         self.rank, self.world_size, self.owners = int(rank), int(world_size), list(owners)
         self.device, self.gather, self.register_fn, self.host_threads = device, gather, register_fn, host_threads
         self.last_local_count = 0

@@ -37,7 +37,8 @@ def test_register_3d_with_binning_and_device_tiles(hip_device):
     # every pair found its two tiles pre-binned (register() bins all tiles of a regular mosaic while it builds the graph)
     stats = res["bin_cache_stats"]
     n_pairs = len(res["pairwise_registration"]["edges"])
-    assert stats is not None and stats["hits"] >= 2 * n_pairs
+    # (the batched pair path looks every view up once, the per-pair path twice per pair)
+    assert stats is not None and stats["misses"] == 0 and stats["hits"] >= len(sims) and n_pairs >= 3
 
 
 def test_peer_copy_follows_later_writes(hip_device):
@@ -253,6 +254,71 @@ def test_lean_pair_path_equals_generic_on_device(hip_device, ndim):
         assert ra["quality"] == rb["quality"]
     for pa, pb in zip(a["params"], b["params"]):
         np.testing.assert_array_equal(pa, pb)
+
+
+@pytest.mark.parametrize("ndim", [2, 3])
+def test_batched_pairs_and_native_host_steps_equal_the_per_pair_path(hip_device, ndim):
+    """register() with all pairs in one library call (mvs_plan_pairs + mvs_register_pairs on native worker threads), the overlap
+    graph + pruning in one call (mvs_view_graph_prune) and the groupwise resolution in one call (mvs_resolve_translations),
+    against the same run through the per-pair interpreter threads and the Python graph / resolution functions: identical edge
+    lists, pairwise transforms, qualities, boxes and parameters -- with pre-binned tiles (tickets instead of a host wait),
+    without binning, and with an overlap tolerance."""
+    import warnings
+
+    from multiview_stitcher_amd import device, registration, sample_data, spatial_image_utils as si
+
+    if ndim == 2:
+        sims, _, _ = sample_data.generate_tiled_dataset(ndim=2, tile_shape=(160, 144), tiles=(3, 3), overlap=(40, 36), dtype=np.uint16, max_jitter=3, seed=4,
+                                                        spacing=(0.7, 0.7))
+        variants = [dict(registration_binning={"y": 1, "x": 1}), dict(registration_binning={"y": 2, "x": 2}, overlap_tolerance=1.5)]
+    else:
+        sims, _, _ = sample_data.generate_tiled_dataset(ndim=3, tile_shape=(40, 96, 80), tiles=(2, 2, 3), overlap=(12, 24, 20), dtype=np.uint16, max_jitter=2,
+                                                        seed=9, spacing=(2.0, 0.5, 0.5))
+        variants = [dict(registration_binning={"z": 1, "y": 2, "x": 2}), dict(registration_binning={"z": 1, "y": 1, "x": 1}, overlap_tolerance={"z": 0.0, "y": 1.0, "x": 0.5})]
+    sims = [device.to_device(s.isel({d: 0 for d in si.get_nonspatial_dims_from_sim(s)}), 0) for s in sims]
+    for kw in variants:
+        out = []
+        for native in (True, False):
+            registration._batch_enabled[0] = registration._native_graph[0] = registration._native_resolution[0] = native
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    out.append(registration.register(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, return_dict=True, n_parallel_pairwise_regs=5, **kw))
+            finally:
+                registration._batch_enabled[0] = registration._native_graph[0] = registration._native_resolution[0] = True
+        a, b = out
+        assert a["pairwise_registration"]["edges"] == b["pairwise_registration"]["edges"] and len(a["pairwise_registration"]["edges"]) >= 10
+        for ra, rb in zip(a["pairwise_registration"]["results"][0], b["pairwise_registration"]["results"][0]):
+            np.testing.assert_array_equal(ra["transform"], rb["transform"])
+            np.testing.assert_array_equal(ra["bbox"], rb["bbox"])
+            assert ra["quality"] == rb["quality"]
+        for pa, pb in zip(a["params"], b["params"]):
+            np.testing.assert_array_equal(pa, pb)
+        ia, ib = a["groupwise_resolution"]["info"][0], b["groupwise_resolution"]["info"][0]
+        assert ia["used_edges"] == ib["used_edges"]
+        assert ia["metrics"][0]["max_residual"] == ib["metrics"][0]["max_residual"]
+
+
+def test_batched_pairs_report_constant_overlaps_and_errors(hip_device):
+    """A constant overlap gives the identity with a warning on the batched path too (registration.py:1500-1520), and a failing
+    pair surfaces as an exception that names the pair."""
+    from multiview_stitcher_amd import _lib, device, registration, spatial_image_utils as si
+
+    rng = np.random.default_rng(0)
+    tiles = []
+    for k in range(3):
+        data = rng.integers(0, 4000, (64, 80), dtype=np.uint16)
+        if k == 2:
+            data[:] = 7                                  # a constant tile: its overlap with tile 1 is constant
+        sim = si.to_spatial_image(data, dims=["y", "x"], scale={"y": 1.0, "x": 1.0}, translation={"y": 0.0, "x": 60.0 * k})
+        si.set_sim_affine(sim, np.eye(3), "stage")
+        tiles.append(device.to_device(sim, 0))
+    with pytest.warns(UserWarning, match="all zero or constant"):
+        res = registration.compute_pairwise_registrations(tiles, [(0, 1), (1, 2)], "stage", registration_binning={"y": 1, "x": 1})
+    assert np.isnan(res[1]["quality"]) and np.array_equal(res[1]["transform"], np.eye(3))
+    assert np.isfinite(res[0]["quality"])
+    with pytest.raises(ValueError, match="do not overlap"):
+        registration.compute_pairwise_registrations(tiles, [(0, 2)], "stage", registration_binning={"y": 1, "x": 1})
 
 
 def test_fuse_launch_blocks_respect_budget_and_fall_back(hip_device, monkeypatch):
