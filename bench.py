@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0
+HBM_COPY_CEILING_GBS = 6290.0      # measured float4-copy ceiling of the chip (MI355X_MICROARCH.md, chip-level parameters; SURVEY 8d: report both)
 
 
 def parse_args():
@@ -751,6 +752,18 @@ def main():
         except Exception as e:   # noqa: BLE001 - an optional leg must not take the bench line down
             pcie = {"error": repr(e)[:300]}
     traffic, traffic_src = fuse_traffic_bytes(grid, tile) if world == 1 else (None, "N > 1")
+    # per-rank phase figures (own step time: register + fuse of this rank, without the other ranks' tail)
+    own_ms = float(np.mean(reg_ms)) + float(np.mean(fuse_ms))
+    own_serial = own_ms - (pair_wall_ms or 0.0) - k_ms
+    own_pairs = reg_pairs / max(args.steps, 1) if do_register else 0.0
+    if world > 1:
+        tg = torch.tensor([own_serial, own_pairs], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        gathered = [torch.zeros_like(tg) for _ in range(world)]
+        dist.all_gather(gathered, tg)
+        serial_by_rank = [float(g[0].item()) for g in gathered]
+        pairs_by_rank = [float(g[1].item()) for g in gathered]
+    else:
+        serial_by_rank, pairs_by_rank = [own_serial], [own_pairs]
     if rank == 0:
         result = {
             "metric": "Mvoxels/s register+fuse, 3D tile grid" if do_register else "Mvoxels/s fuse only, 3D tile grid",
@@ -790,6 +803,12 @@ def main():
                 "candidate_volumes_walked_per_pair": (reg_cand_vols / reg_pairs) if reg_pairs else None,
                 "fuse_ms_per_step": float(np.mean(fuse_ms)),
                 "fuse_kernel_ms": k_ms,
+                # what the host does serially around the device work of a step: overlap graph + pruning, queueing the binning,
+                # assembling the pair jobs, groupwise resolution, writing the transforms back, fuse()'s host path
+                "serial_host_ms": (ms_per_step - pair_wall_ms - k_ms) if do_register else (ms_per_step - k_ms),
+                "serial_host_ms_by_rank": serial_by_rank,
+                "pairs_per_step_by_rank": pairs_by_rank,
+                "fuse_host_replay": bool(fusion._REPLAY[0]),
                 "fuse_plan_cold_ms": cold_plan_ms,
                 "fuse_default_chunksize_ms": default_chunks_ms,
                 "fuse_default_chunksize_first_call_ms": default_chunks_first_ms,
@@ -802,6 +821,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
+                "copy_ceiling": HBM_COPY_CEILING_GBS,
+                "frac_of_copy_ceiling": achieved / HBM_COPY_CEILING_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes,

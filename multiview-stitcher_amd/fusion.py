@@ -129,6 +129,7 @@ def fuse_np(
     device=0,
     out=None,
     frame_origin=None,
+    _record=None,
 ):
     """Fuse the slabs ``sims`` of one output chunk (fusion.fuse_np, _core.py:1513-1733).
 
@@ -290,6 +291,9 @@ def fuse_np(
         rc = lib.mvs_fuse_chunk(device, views, n, C.byref(opts), C.c_void_p(out.ptr))
         _lib.check(rc, device, "mvs_fuse_chunk")
         out.mark_written()
+        if _record is not None and bool(np.all(mems == _lib.MVS_MEM_DEVICE)):
+            # (fuse()'s geometry-keyed replay: the view records without their data pointers, the options, the result shape)
+            _record.update(views=bytes(views), opts=bytes(opts), n=n, res_shape=tuple(int(v) for v in res_shape), ptrs=ptrs.copy())
         return out
     result = np.empty(tuple(res_shape), dtype=input_dtype)
     opts.out_mem = _lib.MVS_MEM_HOST
@@ -631,6 +635,80 @@ def _plan_chunks(sparams, views_bb, output_stack_properties, output_chunksize, o
     return by_block, info
 
 
+_REPLAY = [True]           # tests / A-B: derive everything on every call
+_REPLAY_MEMO = {}
+
+
+def _hashable(v):
+    if v is None or isinstance(v, (int, float, str, bool)):
+        return v
+    if isinstance(v, dict):
+        return tuple(sorted((k, _hashable(x)) for k, x in v.items()))
+    if isinstance(v, (list, tuple)):
+        return tuple(_hashable(x) for x in v)
+    if isinstance(v, np.ndarray):
+        return (v.shape, str(v.dtype), v.tobytes())
+    if isinstance(v, (np.integer, np.floating)):
+        return v.item()
+    raise TypeError
+
+
+def _replay_key(images, transform_key, fusion_func, device, *args):
+    """Everything fuse()'s host work depends on for device-resident plain images, as a hashable -- or None when the call is not
+    of that kind.  Per image: the spatial dims, first / second coordinate and length of every axis (origin, spacing, shape as
+    the stack-property getters read them), the transform under ``transform_key``, dtype, strides and device of the tile."""
+    from . import msi_utils
+
+    try:
+        first = images[0]
+        if msi_utils.is_msim(first) or fusion_func not in _FUSION_CODES:
+            return None
+        dims = tuple(first.dims)
+        if any(d not in ("z", "y", "x") for d in dims):
+            return None
+        dtype = np.dtype(first.dtype)
+        geo = np.empty((len(images), len(dims), 3))
+        meta, trs = [], []
+        for i, im in enumerate(images):
+            data = im.data
+            if msi_utils.is_msim(im) or tuple(im.dims) != dims or not is_device_array(data) or data.dtype != dtype \
+                    or (data.device & 0xff) != (int(device) & 0xff):
+                return None
+            co = im.coords
+            for k, d in enumerate(dims):
+                c = co[d]
+                n = len(c)
+                geo[i, k, 0], geo[i, k, 1], geo[i, k, 2] = c[0], (c[1] if n > 1 else c[0]), n
+            meta.append((data.shape, data.strides, data.device))
+            trs.append(np.asarray(im.attrs["transforms"][transform_key], dtype=np.float64))
+        shape0 = trs[0].shape
+        if any(t.shape != shape0 for t in trs):
+            return None
+        return (dims, str(dtype), geo.tobytes(), np.stack(trs).tobytes(), shape0, tuple(meta), transform_key, fusion_func, int(device),
+                tuple(_hashable(a) for a in args))
+    except (KeyError, TypeError, AttributeError, IndexError):
+        return None
+
+
+def _replay_fuse(rec, images, transform_key, device):
+    """fuse() from a remembered derivation: the view records with the CURRENT tiles' pointers, one mvs_fuse_chunk launch."""
+    n = rec["n"]
+    views = (_lib.mvs_view_t * n).from_buffer_copy(rec["views"])
+    opts = _lib.mvs_fuse_opts_t.from_buffer_copy(rec["opts"])
+    ptrs = np.array([images[iv].data.ptr for iv in rec["view_index"]], dtype=np.uint64) + rec["byte_offsets"]
+    flat = np.frombuffer(views, dtype=np.uint8).reshape(n, C.sizeof(_lib.mvs_view_t))
+    off = _lib.mvs_view_t.data.offset
+    flat[:, off:off + 8].view(np.uint64)[:, 0] = ptrs
+    out = DeviceArray.empty(rec["res_shape"], rec["dtype"], device)
+    lib = _lib.init(device)
+    rc = lib.mvs_fuse_chunk(device, views, n, C.byref(opts), C.c_void_p(out.ptr))
+    _lib.check(rc, device, "mvs_fuse_chunk")
+    out.mark_written()
+    res = si_utils.to_spatial_image(out, dims=list(rec["dims"]), scale=rec["spacing"], translation=rec["origin"])
+    si_utils.set_sim_affine(res, param_utils.identity_transform(rec["ndim"]), transform_key)
+    return res
+
+
 def _fuse_once(
     images=None,
     transform_key=None,
@@ -690,6 +768,21 @@ def _fuse_once(
         raise TypeError("fuse() got both 'images' and deprecated 'sims'. Use only 'images'.")
     if not images:
         raise ValueError("images must contain at least one image.")
+    # Device-resident tiles fused into one device-resident launch block: everything the interpreter derives for the call -- output
+    # stack, chunk plan, slab windows, the view records of mvs_fuse_chunk -- is a function of the views' geometry and the
+    # arguments, not of the voxels.  It is derived once per geometry and replayed with the current data pointers afterwards
+    # (a register + fuse loop over time points or channels of one mosaic pays the ~2 ms of host work once).
+    fast_key, record = None, None
+    if (_REPLAY[0] and output_on_backend and output_zarr_url is None and not batch_options and chunk_filter is None and merge_chunks
+            and weights_func is None and not fusion_func_kwargs and not weights_func_kwargs and not zarr_options and backend in ("hip", None)):
+        fast_key = _replay_key(images, transform_key, fusion_func, device, output_spacing, output_stack_mode, output_origin, output_shape,
+                               output_stack_properties, output_chunksize, overlap_in_pixels, trim_overlap, interpolation_order,
+                               blending_widths, frame_origin)
+        if fast_key is not None:
+            hit = _REPLAY_MEMO.get(fast_key)
+            if hit is not None:
+                return _replay_fuse(hit, images, transform_key, device)
+            record = {}
     if output_zarr_url is not None and output_on_backend:
         raise ValueError("output_zarr_url streams chunks to disk; it cannot be combined with output_on_backend")
     if backend not in ("hip", None):
@@ -909,6 +1002,10 @@ def _fuse_once(
         if fusion_func in _FUSION_CODES and (weights_func is None or weights_func is content_based):
             fo_ = frame_origin if frame_origin is not None else output_stack_properties["origin"]
             kwargs["frame_origin"] = {d: fo_[d] for d in cbb_use["origin"]}
+            if record is not None and not entry["fuse_planewise"]:
+                kwargs["_record"] = record
+                record["calls"] = record.get("calls", 0) + 1
+                record["view_index"] = idxs
         return kwargs, sl
 
     if batch_options:
@@ -989,6 +1086,15 @@ def _fuse_once(
         dev_full.mark_written()
         data = dev_full
         dims = (list(nsdims) if n_fields > 1 else []) + list(sdims)
+        if record is not None and record.get("calls") == 1 and "views" in record and not nsdims and n_fields == 1 \
+                and tuple(dev_full.shape) == record["res_shape"]:
+            # one launch block wrote the whole result: replayable.  Slab pointers are remembered as offsets into their tiles.
+            base = np.array([images[iv].data.ptr for iv in record["view_index"]], dtype=np.uint64)
+            if len(_REPLAY_MEMO) >= 8:
+                _REPLAY_MEMO.pop(next(iter(_REPLAY_MEMO)))
+            _REPLAY_MEMO[fast_key] = dict(record, byte_offsets=(record["ptrs"] - base).astype(np.uint64), dims=tuple(dims),
+                                          spacing=dict(output_stack_properties["spacing"]), origin=dict(output_stack_properties["origin"]),
+                                          dtype=np.dtype(images[0].dtype), ndim=len(sdims))
     else:
         data = result if zarr_out is None else zarr_out[...]
         dims = list(nsdims) + list(sdims)

@@ -351,24 +351,42 @@ class _TileGeom:
     """What the pair plans need of one (binned) view: its coordinate arrays as lists, origin / spacing / shape as the
     spatial_image_utils getters derive them, and the translation of its transform."""
 
-    __slots__ = ("sim", "sdims", "coords", "origin", "spacing", "shape", "t", "affine")
+    __slots__ = ("sim", "sdims", "coords", "origin", "spacing", "shape", "t", "affine", "_src")
 
-    def __init__(self, sim, transform_key):
-        from . import spatial_image_utils as si_utils
-
+    def __init__(self, sim, transform_key, like=None):
         self.sim = sim
-        self.sdims = si_utils.get_spatial_dims_from_sim(sim)
+        dims = sim.dims
+        self.sdims = sd = [d for d in ("z", "y", "x") if d in dims]
         # (float64 arrays, not lists: 128 geometries of a 64-tile mosaic were 150 000 float objects to build under the GIL and
         # 2.5 ms to tear down when register() returns; float64 scalars subtract exactly like Python floats)
-        self.coords = [np.ascontiguousarray(sim.coords[d], dtype=np.float64) for d in self.sdims]
-        self.origin = [float(c[0]) for c in self.coords]
-        self.spacing = [float(c[1] - c[0]) if len(c) > 1 else 1.0 for c in self.coords]
-        self.shape = [len(c) for c in self.coords]
-        a = param_utils.select_time(np.asarray(sim.attrs["transforms"][transform_key], dtype=np.float64), 0)
-        n = len(self.sdims)
-        pure = a.shape == (n + 1, n + 1) and np.array_equal(a[:n, :n], np.eye(n)) and np.array_equal(a[n], np.eye(n + 1)[n])
+        co = sim.coords
+        self.coords = cs = [np.ascontiguousarray(co[d], dtype=np.float64) for d in sd]
+        self.origin = [float(c[0]) for c in cs]
+        self.spacing = [float(c[1] - c[0]) if len(c) > 1 else 1.0 for c in cs]
+        self.shape = [len(c) for c in cs]
+        src = sim.attrs["transforms"][transform_key]
+        self._src = src
+        if like is not None and like._src is src:       # the binned view of ``like``'s image: the very same transform array
+            self.t, self.affine = like.t, like.affine
+            return
+        a = param_utils.select_time(np.asarray(src, dtype=np.float64), 0)
+        n = len(sd)
+        pure = False
+        if a.shape == (n + 1, n + 1):
+            b = a.copy()
+            b[:n, n] = 0.0
+            pure = b.tobytes() == _eye_bytes(n)      # (a -0.0 entry counts as "not pure": the generic path handles it)
         self.t = [float(v) for v in a[:n, n]] if pure else None
         self.affine = a
+
+
+_EYE_BYTES = {}
+
+
+def _eye_bytes(n):
+    if n not in _EYE_BYTES:
+        _EYE_BYTES[n] = np.eye(n + 1).tobytes()
+    return _EYE_BYTES[n]
 
 
 def _lean_world_box(g, tol):
@@ -587,7 +605,8 @@ def _register_pairs_batched(sims, edges, transform_key, registration_binning, ov
         else:
             b_, tickets[v] = s_, 0
         binned[v] = b_
-        geoms[v], geoms_b[v] = _geom_of(s_, transform_key, cache), _geom_of(b_, transform_key, cache)
+        geoms[v] = _TileGeom(s_, transform_key)
+        geoms_b[v] = geoms[v] if b_ is s_ else _TileGeom(b_, transform_key, like=geoms[v])
         if geoms[v].t is None or geoms_b[v].t is None or (b_.data.device & 0xff) != (device & 0xff) or b_.data.strides[-1] != 1:
             return None
     slot = {v: i for i, v in enumerate(used)}
@@ -969,10 +988,11 @@ class _BinCache:
         with self._lock:
             slot = self._items.get(key)
             owner = slot is None
-            if owner:
-                self.misses += 1
-            else:
-                self.hits += 1
+            if key[0] != "geom":          # (the statistics count the binned tiles)
+                if owner:
+                    self.misses += 1
+                else:
+                    self.hits += 1
             if owner:
                 slot = self._items[key] = {"event": threading.Event(), "value": None, "error": None, "keep": keep}
         if owner:

@@ -148,7 +148,7 @@ class RemoteArray:
 class ShardedPairExecutor:
     """``pairwise_executor`` for one-process-per-GPU runs (registration.register(..., pairwise_executor=...),
     registration.py:2634-2655): this rank registers the pairs whose fixed view it owns, then every rank receives all
-    results (``gather(obj) -> list over ranks``; default torch.distributed.all_gather_object)."""
+    results (``gather(obj) -> list over ranks``; default: one fixed-size float64 tensor all-gather, see _gather_results)."""
 
     def __init__(self, rank, world_size, owners, device=0, gather=None, register_fn=None, host_threads=None):
         self.rank, self.world_size, self.owners = int(rank), int(world_size), list(owners)
@@ -174,10 +174,7 @@ class ShardedPairExecutor:
         elif self.gather is not None:
             parts = self.gather(payload)
         else:
-            import torch.distributed as dist
-
-            parts = [None] * self.world_size
-            dist.all_gather_object(parts, payload)
+            parts = self._gather_results(payload, len(edges))
         results = [None] * len(edges)
         for part in parts:
             for k, r in part.items():
@@ -186,6 +183,69 @@ class ShardedPairExecutor:
         if missing:
             raise RuntimeError(f"no rank registered edges {missing[:8]}")
         return results
+
+
+def _encode_pair_results(payload, n_edges):
+    """{edge index: {"transform" (n+1, n+1), "quality", "bbox" (2, n)}} as one float64 array (n_edges, 1 + (n+1)^2 + 1 + 2n): a
+    presence flag, the transform, the quality, the box; rows of edges this rank did not register are zero.  None when a result
+    is not of that form (custom registration functions may return anything: those go through all_gather_object)."""
+    n = None
+    for r in payload.values():
+        if not isinstance(r, dict) or set(r) != {"transform", "quality", "bbox"}:
+            return None, None
+        t, b = np.asarray(r["transform"]), np.asarray(r["bbox"])
+        if t.ndim != 2 or t.shape[0] != t.shape[1] or b.shape != (2, t.shape[0] - 1) or (n is not None and t.shape[0] - 1 != n):
+            return None, None
+        n = t.shape[0] - 1
+    if n is None:
+        return None, None
+    width = 1 + (n + 1) ** 2 + 1 + 2 * n
+    arr = np.zeros((n_edges, width), dtype=np.float64)
+    for k, r in payload.items():
+        arr[k, 0] = 1.0
+        arr[k, 1:1 + (n + 1) ** 2] = np.asarray(r["transform"], dtype=np.float64).reshape(-1)
+        arr[k, 1 + (n + 1) ** 2] = float(r["quality"])
+        arr[k, 2 + (n + 1) ** 2:] = np.asarray(r["bbox"], dtype=np.float64).reshape(-1)
+    return arr, n
+
+
+def _decode_pair_results(arr, n):
+    out = {}
+    m = (n + 1) ** 2
+    for k in np.nonzero(arr[:, 0] == 1.0)[0].tolist():
+        out[k] = {"transform": arr[k, 1:1 + m].reshape(n + 1, n + 1).copy(), "quality": float(arr[k, 1 + m]),
+                  "bbox": arr[k, 2 + m:].reshape(2, n).copy()}
+    return out
+
+
+def _gather_results_impl(self, payload, n_edges):
+    """Every rank's pairwise results on every rank: ONE all_gather of a fixed-size float64 tensor (kilobytes; no pickling, the
+    collective the backend is good at) when the results have the standard form on every rank, all_gather_object otherwise.
+    The tensor lives where the backend wants it: on this rank's GPU for nccl (RCCL), on the host for gloo."""
+    import torch
+    import torch.distributed as dist
+
+    arr, n = _encode_pair_results(payload, n_edges)
+    on_gpu = dist.get_backend() == "nccl"
+    dev = torch.device("cuda", self.device & 0xff) if on_gpu else torch.device("cpu")
+    # ranks without pairs cannot know the dimensionality, ranks with non-standard results cannot encode: agree first (one scalar)
+    flag = torch.tensor([float(-1 if (payload and arr is None) else (n or 0))], dtype=torch.float64, device=dev)
+    flags = [torch.zeros_like(flag) for _ in range(self.world_size)]
+    dist.all_gather(flags, flag)
+    dims = [int(f.item()) for f in flags]
+    if any(d < 0 for d in dims) or len({d for d in dims if d > 0}) != 1:
+        parts = [None] * self.world_size
+        dist.all_gather_object(parts, payload)
+        return parts
+    n = max(dims)
+    width = 1 + (n + 1) ** 2 + 1 + 2 * n
+    mine = torch.from_numpy(arr if arr is not None else np.zeros((n_edges, width))).to(dev)
+    bufs = [torch.zeros_like(mine) for _ in range(self.world_size)]
+    dist.all_gather(bufs, mine)
+    return [_decode_pair_results(b.cpu().numpy(), n) for b in bufs]
+
+
+ShardedPairExecutor._gather_results = _gather_results_impl
 
 
 def fuse_shard(sims, rank, world_size, transform_key, output_stack_properties=None, **fuse_kwargs):

@@ -104,5 +104,13 @@ def test_eight_ranks_one_mosaic_equals_single_rank(hip_device, tmp_path):
     # the 144 pairs of the pruned overlap graph are split by the owner of the fixed view; a rank holds its 2 x 2 x 2 brick plus a
     # one-tile halo (27 tiles at a corner brick of this grid), never the whole mosaic
     assert sum(pairs) == json.load(open(d1 / "fused_rank0of1.json"))["pairs_registered"] == 144
+    # the line itself carries the per-rank split: pairs per step by rank sum to the mosaic's 144, every
+    # rank reports the serial host share of its own step (graph + pruning + job assembly + resolution + fuse host path)
+    cfg = eight["config"]
+    assert len(cfg["pairs_per_step_by_rank"]) == 8 and sum(cfg["pairs_per_step_by_rank"]) == pytest.approx(144.0)
+    assert cfg["pairs_per_step_by_rank"] == pytest.approx([float(p) for p in pairs])
+    assert len(cfg["serial_host_ms_by_rank"]) == 8 and all(np.isfinite(v) for v in cfg["serial_host_ms_by_rank"])
+    assert one["config"]["pairs_per_step_by_rank"] == [144.0] and np.isfinite(one["config"]["serial_host_ms"])
+    assert one["roofline"]["frac_of_copy_ceiling"] == pytest.approx(one["roofline"]["achieved"] / 6290.0)
     assert all(8 <= h <= 27 for h in held), held
     np.testing.assert_array_equal(got, full)

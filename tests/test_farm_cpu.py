@@ -177,12 +177,23 @@ def test_gloo_two_ranks_sharded_pair_executor(tmp_path):
         calls = []
         def fake_register(a, b, **kw):
             calls.append((a, b))
-            return {{"transform": np.eye(4) * (a + 1), "quality": float(b), "bbox": np.zeros((2, 3))}}
+            return {{"transform": np.eye(4) * (a + 1) - 0.0, "quality": float("nan") if (a + b) % 5 == 0 else float(b) / 3,
+                    "bbox": np.array([[a, b, -0.0], [a + 0.1, b + 1e-17, 7.0]])}}
         ex = sharding.ShardedPairExecutor(r, w, owners, register_fn=fake_register)
+        # results of the standard form travel as ONE fixed-size float64 tensor (no pickling)
+        _orig = dist.all_gather_object
+        def _forbidden(*a, **k):
+            raise AssertionError("the pair results went through all_gather_object")
+        dist.all_gather_object = _forbidden
         res = ex(list(range(len(sps))), edges, {{}})
+        dist.all_gather_object = _orig
         assert len(res) == len(edges)
         for (i, j), q in zip(edges, res):
-            assert q["quality"] == float(j) and q["transform"][0, 0] == i + 1
+            want = fake_register(i, j)
+            assert np.array_equal(q["transform"], want["transform"]) and q["transform"].shape == (4, 4)
+            assert q["bbox"].tobytes() == want["bbox"].tobytes()               # bit for bit, the sign of a zero included
+            assert (np.isnan(q["quality"]) and np.isnan(want["quality"])) or q["quality"] == want["quality"]
+        calls[:] = [c for c in calls[: len(calls) - len(edges)]]
         mine = [e for e, o in zip(edges, sharding.edge_owners(edges, owners)) if o == r]
         assert calls == mine and 0 < len(mine) < len(edges)
         got = [None] * w

@@ -321,6 +321,61 @@ def test_batched_pairs_report_constant_overlaps_and_errors(hip_device):
         registration.compute_pairwise_registrations(tiles, [(0, 2)], "stage", registration_binning={"y": 1, "x": 1})
 
 
+def test_fuse_replay_of_a_remembered_geometry_equals_the_full_derivation(hip_device):
+    """fuse() of device-resident tiles into one device-resident launch block remembers what it derived for a geometry (output
+    stack, slab windows, view records) and replays it with the current tiles' pointers: same voxels as the full derivation, a hit
+    only for the same geometry AND parameters, new tiles at new addresses are read (not the remembered ones)."""
+    from multiview_stitcher_amd import device, fusion, sample_data, spatial_image_utils as si
+
+    def mosaic(seed):
+        sims, _, _ = sample_data.generate_tiled_dataset(ndim=3, tile_shape=(24, 64, 72), tiles=(1, 2, 3), overlap=(0, 16, 20), dtype=np.uint16, max_jitter=0, seed=seed)
+        return [device.to_device(s.isel({d: 0 for d in si.get_nonspatial_dims_from_sim(s)}), 0) for s in sims]
+
+    key = si.DEFAULT_TRANSFORM_KEY
+    sims = mosaic(1)
+    fusion._REPLAY_MEMO.clear()
+    first = fusion.fuse(sims, transform_key=key, output_on_backend=True)            # derives and remembers
+    assert len(fusion._REPLAY_MEMO) == 1
+    again = fusion.fuse(sims, transform_key=key, output_on_backend=True)            # replayed
+    fusion._REPLAY[0] = False
+    try:
+        full = fusion.fuse(sims, transform_key=key, output_on_backend=True)
+    finally:
+        fusion._REPLAY[0] = True
+    np.testing.assert_array_equal(np.asarray(again.data), np.asarray(full.data))
+    np.testing.assert_array_equal(np.asarray(first.data), np.asarray(full.data))
+    for d in "zyx":
+        np.testing.assert_array_equal(again.coords[d], full.coords[d])
+    np.testing.assert_array_equal(again.attrs["transforms"][key], full.attrs["transforms"][key])
+    # other voxels, same geometry: a hit that reads the NEW tiles
+    other = mosaic(2)
+    got = fusion.fuse(other, transform_key=key, output_on_backend=True)
+    assert len(fusion._REPLAY_MEMO) == 1
+    fusion._REPLAY[0] = False
+    try:
+        want = fusion.fuse(other, transform_key=key, output_on_backend=True)
+    finally:
+        fusion._REPLAY[0] = True
+    np.testing.assert_array_equal(np.asarray(got.data), np.asarray(want.data))
+    assert not np.array_equal(np.asarray(got.data), np.asarray(full.data))
+    # other parameters: a miss, derived anew
+    p = np.eye(4)
+    p[:3, 3] = [0.0, 1.5, -2.0]
+    si.set_sim_affine(other[1], p, key)
+    moved = fusion.fuse(other, transform_key=key, output_on_backend=True)
+    assert len(fusion._REPLAY_MEMO) == 2
+    fusion._REPLAY[0] = False
+    try:
+        want = fusion.fuse(other, transform_key=key, output_on_backend=True)
+    finally:
+        fusion._REPLAY[0] = True
+    np.testing.assert_array_equal(np.asarray(moved.data), np.asarray(want.data))
+    assert moved.shape == want.shape
+    # options that change the result are part of the key
+    mx = fusion.fuse(other, transform_key=key, output_on_backend=True, fusion_func=fusion.max_fusion)
+    assert len(fusion._REPLAY_MEMO) == 3 and not np.array_equal(np.asarray(mx.data), np.asarray(moved.data))
+
+
 def test_fuse_launch_blocks_respect_budget_and_fall_back(hip_device, monkeypatch):
     """fuse(merge_chunks=True) sizes its launch blocks from the output bytes PLUS the view slabs that must be staged on
     the device, against the free device memory (mvs_mem_info), and falls back to the requested chunk grid when a merged

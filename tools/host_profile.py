@@ -1,5 +1,5 @@
 """cProfile of the host side of one north-star step (register + fuse), tiles resident: where the Python time goes."""
-import cProfile, pstats, sys, io, time
+import cProfile, pstats, sys, io, time, os
 import numpy as np, torch
 sys.path.insert(0, ".")
 import bench
@@ -24,5 +24,11 @@ step(); step()
 for name, fn in (("register", lambda: registration.register(sims, transform_key=key, new_transform_key="reg", device=0, pre_registration_pruning_method="alternating_pattern")),
                  ("fuse", lambda: (fusion.fuse(sims, transform_key="reg", output_on_backend=True, device=0), _lib.synchronize(0)))):
     t0 = time.perf_counter(); fn(); print(name, "ms", (time.perf_counter() - t0) * 1e3)
-    pr = cProfile.Profile(); pr.enable(); fn(); pr.disable()
-    s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:6000])
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(10): fn()
+    pr.disable()
+    st = pstats.Stats(pr)
+    rows = sorted(((v[2], v[3], v[1], k) for k, v in st.stats.items()), reverse=True)[:45]
+    print("   tottime_us  cumtime_us  calls   (per call of the profiled function, 10 calls averaged)")
+    for tt, ct, nc, (fname, line, func) in rows:
+        print(f"   {tt * 1e5:9.1f}  {ct * 1e5:9.1f}  {nc / 10:6.1f}   {os.path.basename(fname)}:{line}({func})")
