@@ -411,11 +411,11 @@ def _axis_aligned_boxes(sps, tol=1e-12):
         return [_axis_aligned_box(sp, tol) for sp in sps]
 
 
-def get_overlap_between_pair_of_stack_props(stack_props1, stack_props2):
+def get_overlap_between_pair_of_stack_props(stack_props1, stack_props2, closed_form=True):
     """Volume (area in 2D) of the intersection of two views in world coordinates (mv_graph.py:301-338); -1 when the
     intersection is degenerate / empty.  Axis-aligned pairs: product of the interval overlaps, the value Qhull returns
     for a box; general pairs: the reference's linprog + HalfspaceIntersection + ConvexHull sequence."""
-    b1, b2 = _axis_aligned_box(stack_props1), _axis_aligned_box(stack_props2)
+    b1, b2 = (_axis_aligned_box(stack_props1), _axis_aligned_box(stack_props2)) if closed_form else (None, None)
     if b1 is not None and b2 is not None:
         ext = np.minimum(b1[1], b2[1]) - np.maximum(b1[0], b2[0])
         return (float(np.prod(ext)), None) if np.all(ext > 0) else (-1, None)

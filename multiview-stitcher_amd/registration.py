@@ -197,7 +197,7 @@ def _is_axis_aligned(affine, tol=1e-9):
     return bool(np.all(np.abs(A - np.diag(np.diag(A))) < tol))
 
 
-def _get_overlap_bboxes(sim1, sim2, input_transform_key=None, output_transform_key=None, overlap_tolerance=None):
+def _get_overlap_bboxes(sim1, sim2, input_transform_key=None, output_transform_key=None, overlap_tolerance=None, closed_form=True):
     """registration._get_overlap_bboxes (registration.py:194-277): the two view boxes are intersected as halfspaces in the
     coordinate system of ``input_transform_key`` (mv_graph.py:301-338) and the vertices of the intersection polytope are
     projected into each view's intrinsic frame; lowers / uppers are their extrema.  Axis-aligned pairs (every tile grid)
@@ -213,7 +213,7 @@ def _get_overlap_bboxes(sim1, sim2, input_transform_key=None, output_transform_k
     sps = [si_utils.get_stack_properties_from_sim(s) for s in sims]
     if overlap_tolerance is not None:
         sps = [si_utils_extend(sp, overlap_tolerance) for sp in sps]
-    if all(_is_axis_aligned(a) for a in affines):
+    if closed_form and all(_is_axis_aligned(a) for a in affines):
         res = mv_graph.get_overlap_aabb(sps[0], affines[0], sps[1], affines[1])
         if res is None:
             return None
@@ -222,7 +222,10 @@ def _get_overlap_bboxes(sim1, sim2, input_transform_key=None, output_transform_k
         corners = np.array(list(np.ndindex(*([2] * ndim)))) * (hi - lo) + lo
         vol = float(np.prod(hi - lo))
     else:
-        vol, hs = mv_graph.get_overlap_between_pair_of_stack_props(dict(sps[0], transform=affines[0]), dict(sps[1], transform=affines[1]))
+        # (closed_form=False: the reference's own sequence -- linprog feasible point, Qhull halfspace intersection -- also for
+        # axis-aligned pairs, whose vertices then carry Qhull's round-off like the reference's: registration.py:229-239)
+        vol, hs = mv_graph.get_overlap_between_pair_of_stack_props(dict(sps[0], transform=affines[0]), dict(sps[1], transform=affines[1]),
+                                                                   closed_form=closed_form)
         if hs is None:
             return None
         corners = np.asarray(hs.intersections)
@@ -740,7 +743,7 @@ def _select_registration_level(msim1, msim2, registration_binning, reg_res_level
 
 def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=None, overlap_tolerance=None,
                            pairwise_reg_func=phase_correlation_registration, pairwise_reg_func_kwargs=None, device=0,
-                           _bin_cache=None, reg_res_level=None):
+                           _bin_cache=None, reg_res_level=None, overlap_bbox="closed_form"):
     """registration.register_pair_of_msims (registration.py:1547-2058) for pixel-space registration functions
     (the form the reference's phase correlation has): returns {"transform", "quality", "bbox"}.  ``reg_res_level`` /
     ``registration_binning`` pick the pyramid level of multiscale inputs as the reference does (registration.py:1639-1717)."""
@@ -771,14 +774,17 @@ def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=Non
             _lib.check(_lib.init(device).mvs_event_wait(device, ticket), device, "mvs_event_wait")
         return out
 
+    if overlap_bbox not in ("closed_form", "reference"):
+        raise ValueError("overlap_bbox must be 'closed_form' or 'reference'")
+    closed_form = overlap_bbox == "closed_form"
     reg_sims_b = [binned(sim1), binned(sim2)]
-    if pairwise_reg_func is phase_correlation_registration and set(pairwise_reg_func_kwargs) <= {"upsample_factor"} and _lean_enabled[0] \
+    if closed_form and pairwise_reg_func is phase_correlation_registration and set(pairwise_reg_func_kwargs) <= {"upsample_factor"} and _lean_enabled[0] \
             and all(list(s_.dims) == list(sdims) for s_ in (sim1, sim2)):
         geoms = [_geom_of(s_, transform_key, _bin_cache) for s_ in (reg_sims_b[0], reg_sims_b[1], sim1, sim2)]
         if all(g.t is not None for g in geoms):
             return _lean_register_pair(geoms[0], geoms[1], geoms[2], geoms[3], sdims, [overlap_tolerance[d] for d in sdims],
                                        pairwise_reg_func_kwargs.get("upsample_factor"), transform_key, device)
-    ov = _get_overlap_bboxes(reg_sims_b[0], reg_sims_b[1], transform_key, None, overlap_tolerance)
+    ov = _get_overlap_bboxes(reg_sims_b[0], reg_sims_b[1], transform_key, None, overlap_tolerance, closed_form=closed_form)
     if ov is None:
         raise ValueError("views do not overlap")
     lowers, uppers = ov["lowers"], ov["uppers"]
@@ -797,7 +803,7 @@ def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=Non
         raise RuntimeError("phase correlation produced no admissible shift candidate (registration.py:479-480)")
     affine = np.asarray(res["affine_matrix"], dtype=np.float64)
     affine_phys = get_affine_from_intrinsic_affine(affine, fixed, moving, transform_key, transform_key)
-    ovp = _get_overlap_bboxes(sim1, sim2, transform_key, transform_key, overlap_tolerance)
+    ovp = _get_overlap_bboxes(sim1, sim2, transform_key, transform_key, overlap_tolerance, closed_form=closed_form)
     return {"transform": affine_phys, "quality": float(res["quality"]) if res["quality"] is not None else np.nan,
             "bbox": np.array([ovp["lowers"][0], ovp["uppers"][0]])}
 
@@ -880,7 +886,8 @@ def _prebin_views(sims, registration_binning, device, cache):
 
 def compute_pairwise_registrations(msims, edges, transform_key, registration_binning=None, overlap_tolerance=0.0,
                                    pairwise_reg_func=phase_correlation_registration, pairwise_reg_func_kwargs=None,
-                                   pairwise_executor=None, device=0, host_threads=None, _bin_cache=None, reg_res_level=None):
+                                   pairwise_executor=None, device=0, host_threads=None, _bin_cache=None, reg_res_level=None,
+                                   overlap_bbox="closed_form"):
     """registration.compute_pairwise_registrations (registration.py:2622-2714): either hand all edges to a
     user ``pairwise_executor(msims, edges, register_kwargs)`` or loop over them on one device."""
     register_kwargs = dict(transform_key=transform_key, registration_binning=registration_binning,
@@ -888,6 +895,8 @@ def compute_pairwise_registrations(msims, edges, transform_key, registration_bin
                            pairwise_reg_func_kwargs=pairwise_reg_func_kwargs)
     if reg_res_level is not None:       # (absent by default: executors written for the round-1 keyword set keep working)
         register_kwargs["reg_res_level"] = reg_res_level
+    if overlap_bbox != "closed_form":
+        register_kwargs["overlap_bbox"] = overlap_bbox
     if pairwise_executor is not None:
         results = pairwise_executor(msims, list(edges), register_kwargs)
         if len(results) != len(edges):
@@ -899,7 +908,7 @@ def compute_pairwise_registrations(msims, edges, transform_key, registration_bin
     if host_threads is None:
         host_threads = 16
     n_threads = max(1, min(int(host_threads), len(edges), 16))   # 16 = context lanes per GPU (MVS_MAX_LANES)
-    if _batch_enabled[0] and _lean_enabled[0] and pairwise_reg_func is phase_correlation_registration and reg_res_level is None \
+    if _batch_enabled[0] and _lean_enabled[0] and overlap_bbox == "closed_form" and pairwise_reg_func is phase_correlation_registration and reg_res_level is None \
             and set(pairwise_reg_func_kwargs or {}) <= {"upsample_factor"}:
         # all pairs in two library calls (plans + registrations on native worker threads): no interpreter in the pair loop
         # (native workers spin inside the HIP runtime between launches: 6-12 of them reach the GPU's pair throughput, 16 exhaust a
@@ -1070,7 +1079,8 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
              groupwise_resolution_kwargs=None, pre_registration_pruning_method="alternating_pattern",
              pre_reg_pruning_method_kwargs=None,
              post_registration_do_quality_filter=False, post_registration_quality_threshold=0.2, pairs=None,
-             n_parallel_pairwise_regs=None, pairwise_executor=None, return_dict=False, device=0, reg_res_level=None):
+             n_parallel_pairwise_regs=None, pairwise_executor=None, return_dict=False, device=0, reg_res_level=None,
+             overlap_bbox="closed_form"):
     """Register views to a common coordinate system (registration.register, registration.py:2227-2620).
 
     ``reg_res_level`` / ``registration_binning`` select the pyramid level of multiscale inputs per pair exactly as the
@@ -1084,6 +1094,11 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
     form for axis-aligned pairs, scipy's halfspace intersection otherwise) and is pruned by
     ``pre_registration_pruning_method`` (None, "alternating_pattern" (default), "shortest_paths_overlap_weighted",
     "otsu_threshold_on_overlap", "keep_axis_aligned").  The groupwise resolution is
+    ``overlap_bbox``: how the overlap crop of a pair is sized.  "closed_form" (default): the intersection of the two world boxes
+    of axis-aligned views in closed form -- N samples along an axis the views share exactly.  "reference": the reference's own
+    sequence for every pair (linprog feasible point + Qhull halfspace intersection, registration.py:229-239, 314-316), whose
+    vertices carry Qhull's round-off of ~1e-13, so that ``floor((upper - lower) / spacing + 1)`` comes out as N or N - 1
+    exactly as it does in the reference (per-pair host path, no batching).
     ``param_resolution.groupwise_resolution`` (``groupwise_resolution_method``: "global_optimization" (default),
     "shortest_paths", a callable, or "linear" for the plain least-squares solve of ``resolve_translations``;
     ``groupwise_resolution_kwargs`` e.g. ``{"transform": "rigid", "reference_view": 0}``)."""
@@ -1165,7 +1180,7 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
                 fields, edges, transform_key, registration_binning, overlap_tolerance, pairwise_reg_func,
                 pairwise_reg_func_kwargs, pairwise_executor, device,
                 host_threads=n_parallel_pairwise_regs,
-                _bin_cache=bin_cache, reg_res_level=reg_res_level,
+                _bin_cache=bin_cache, reg_res_level=reg_res_level, overlap_bbox=overlap_bbox,
             )
         finally:
             if prebin is not None:

@@ -167,7 +167,8 @@ class ShardedPairExecutor:
             local = registration.compute_pairwise_registrations(
                 msims, [edges[k] for k in mine], kw.pop("transform_key"), kw.pop("registration_binning", None),
                 kw.pop("overlap_tolerance", 0.0), kw.pop("pairwise_reg_func", registration.phase_correlation_registration),
-                kw.pop("pairwise_reg_func_kwargs", None), None, self.device, host_threads=self.host_threads) if mine else []
+                kw.pop("pairwise_reg_func_kwargs", None), None, self.device, host_threads=self.host_threads,
+                reg_res_level=kw.pop("reg_res_level", None), overlap_bbox=kw.pop("overlap_bbox", "closed_form")) if mine else []
         payload = {k: r for k, r in zip(mine, local)}
         if self.world_size == 1:
             parts = [payload]

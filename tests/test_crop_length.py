@@ -1,0 +1,57 @@
+"""Host-only part of the crop-length parity tests: the product's ``overlap_bbox="reference"`` boxes equal the oracle's
+Qhull boxes bit for bit, and how many pairs of each BASELINE.json geometry the N / N - 1 knife edge touches."""
+import numpy as np
+
+from multiview_stitcher_amd import registration
+from multiview_stitcher_amd import spatial_image_utils as si
+from multiview_stitcher_amd.sharding import RemoteArray
+from oracle import reg_oracle as ro
+from tests import crop_length
+
+
+def _sim(origin, spacing, shape):
+    nd = len(origin)
+    sd = "zyx"[-nd:]
+    s = si.to_spatial_image(RemoteArray(shape, np.uint16), dims=list(sd), scale=dict(zip(sd, spacing)), translation=dict(zip(sd, origin)))
+    si.set_sim_affine(s, np.eye(nd + 1), "k")
+    return s
+
+
+def test_reference_mode_boxes_equal_the_oracles_qhull_boxes():
+    rng = np.random.default_rng(0)
+    cases = [([0.0, 0.0], [1.0, 1.0], (512, 512), [0.0, 410.0]), ([0.5, 0.5, 0.5], [2.0, 2.0, 2.0], (256, 256, 256), [0.5, 0.5, 410.5])]
+    for _ in range(40):
+        nd = int(rng.integers(2, 4))
+        sp = rng.choice([1.0, 0.7, 0.3, 2.0], nd)
+        shp = tuple(int(v) for v in rng.integers(20, 60, nd))
+        o1 = rng.normal(0, 30, nd)
+        o2 = o1.copy()
+        ax = int(rng.integers(nd))
+        o2[ax] += 0.75 * shp[ax] * sp[ax]
+        if rng.random() < 0.5:
+            o2 += rng.integers(-3, 4, nd) * sp
+        cases.append((o1, sp, shp, o2))
+    shorter = 0
+    for o1, sp, shp, o2 in cases:
+        s1, s2 = _sim(o1, sp, shp), _sim(o2, sp, shp)
+        nd = len(shp)
+        got = registration._get_overlap_bboxes(s1, s2, "k", None, None, closed_form=False)
+        cf = registration._get_overlap_bboxes(s1, s2, "k", None, None, closed_form=True)
+        st = [{k: si.get_stack_properties_from_sim(s_, asarray=True)[k] for k in ("origin", "spacing", "shape")} for s_ in (s1, s2)]
+        lo, up, _ = ro.get_overlap_bboxes(st[0], np.eye(nd + 1), st[1], np.eye(nd + 1))
+        for a, b in zip(got["lowers"] + got["uppers"], lo + up):
+            np.testing.assert_array_equal(a, b)                       # the same vertices, bit for bit
+        n_ref = np.floor((got["uppers"][0] - got["lowers"][0]) / st[0]["spacing"] + 1).astype(int)
+        n_cf = np.floor((cf["uppers"][0] - cf["lowers"][0]) / st[0]["spacing"] + 1).astype(int)
+        assert np.all(np.abs(n_cf - n_ref) <= 1)                     # the knife edge moves the length by at most one sample per axis
+        shorter += int(np.any(n_ref != n_cf))
+        np.testing.assert_allclose(np.concatenate(got["lowers"] + got["uppers"]), np.concatenate(cf["lowers"] + cf["uppers"]), rtol=0, atol=1e-9)
+    assert shorter >= 1      # the set contains the case the mode exists for
+
+
+def test_knife_edge_counts_of_the_baseline_geometries():
+    counts = {name: crop_length.count_differing_pairs(*geo)[:2] for name, geo in crop_length.CONFIG_GEOMETRIES.items()}
+    assert counts["north_star"][0] == 144 and counts["C3"][0] == 64 and counts["C2"][0] == 12 and counts["C1"][0] == 1
+    # with this image's scipy / Qhull the 3D mosaics and C2 are not touched; C1's pair is (511 instead of 512 rows)
+    assert all(0 <= d <= n for n, d in counts.values())
+    assert counts["C1"][1] == 1
