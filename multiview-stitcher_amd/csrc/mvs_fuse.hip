@@ -1470,6 +1470,11 @@ int stage_single_view(MvsContext* c, const mvs_view_t* view, int ndim, bool need
 
 extern "C" int mvs_resample(int device, const mvs_view_t* view, const int64_t out_shape[3],
                             int32_t order, float cval, float* out, int32_t out_mem) {
+    return mvs_resample_impl(device, view, out_shape, order, cval, out, out_mem, MvsResampleOpts{});
+}
+
+int mvs_resample_impl(int device, const mvs_view_t* view, const int64_t out_shape[3], int32_t order, float cval, float* out, int32_t out_mem,
+                      const MvsResampleOpts& ro) {
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
@@ -1490,13 +1495,13 @@ extern "C" int mvs_resample(int device, const mvs_view_t* view, const int64_t ou
         if (!dout) return mvs_alloc_failed(c);
     }
     MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
-    mvs_launch_resample(c, d, view->dtype, order, cval, dout, out_shape);
+    mvs_launch_resample(c, d, view->dtype, order, cval, dout, out_shape, nullptr, out_mem == MVS_MEM_DEVICE ? ro.stats : nullptr, ro.stats_k);
     MVS_HIP_TRY(c, hipGetLastError());
     MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
     c->timing_valid = true;
     if (out_mem == MVS_MEM_HOST)
         MVS_HIP_TRY(c, hipMemcpyAsync(out, dout, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    if (!(c->defer_sync && out_mem == MVS_MEM_DEVICE)) MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!(ro.defer_sync && out_mem == MVS_MEM_DEVICE)) MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MVS_OK;
 }
 
@@ -1537,7 +1542,8 @@ int mvs_fill_dev_view(MvsContext* c, const mvs_view_t& v, int ndim, const void* 
     return fill_dev_view(c, v, ndim, dev_data, d);
 }
 
-void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, float cval, float* out, const int64_t shape[3], const int* box0) {
+void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, float cval, float* out, const int64_t shape[3], const int* box0,
+                         MvsCropStats* crop_stats, int crop_stats_k) {
     const long long n = (long long)shape[0] * shape[1] * shape[2];
     int t[3];
     const int b0[3] = {box0 ? box0[0] : 0, box0 ? box0[1] : 0, box0 ? box0[2] : 0};
@@ -1546,10 +1552,10 @@ void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, 
         const long long ng = (long long)shape[0] * shape[1] * ((shape[2] + 7) / 8);
         int nb = (int)std::min<long long>((ng + 255) / 256, 256 * 16);
         char* stats = nullptr;
-        if (c->crop_stats_dst && c->crop_stats_nb > 0 && cval != cval && !box0) {      // (NaN outside: "valid" == inside the tile)
-            stats = c->crop_stats_dst;
-            nb = c->crop_stats_nb;
-            c->crop_stats_done[c->crop_stats_k & 1] = true;
+        if (crop_stats && crop_stats->base && crop_stats->nb > 0 && cval != cval && !box0) {      // (NaN outside: "valid" == inside the tile)
+            stats = crop_stats->base + (size_t)(crop_stats_k & 1) * (size_t)crop_stats->nb * 16;
+            nb = crop_stats->nb;
+            crop_stats->done[crop_stats_k & 1] = true;
         }
         if (dtype == MVS_U8)
             hipLaunchKernelGGL(crop_int_kernel<unsigned char>, dim3(nb), dim3(256), 0, c->stream, (const unsigned char*)d.data, d.stride_z, d.stride_y,

@@ -32,7 +32,8 @@ struct DevView {
 int mvs_fill_dev_view(MvsContext* c, const mvs_view_t& v, int ndim, const void* dev_data, DevView* d);
 // `box0` (may be null): chunk index of the output array's first voxel -- the output is a sub-box of the chunk, evaluated with the
 // chunk's own coordinates
-void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, float cval, float* out, const int64_t shape[3], const int* box0 = nullptr);
+void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, float cval, float* out, const int64_t shape[3], const int* box0 = nullptr,
+                         MvsCropStats* crop_stats = nullptr, int crop_stats_k = 0);
 void mvs_launch_blend(MvsContext* c, const DevView& d, float* out, const int64_t shape[3], const int* box0 = nullptr);
 // both for the boxes of up to 8 views in two launches (`dviews`: the same records in device memory)
 void mvs_launch_boxes_batch(MvsContext* c, const DevView* hviews, const DevView* dviews, int n_views, int dtype, int order, float cval,

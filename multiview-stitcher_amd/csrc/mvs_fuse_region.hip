@@ -1085,8 +1085,12 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
                     if (nv > 0 && all_positive) R.allone_mask |= 1 << 15;
                     // profiling only (WRONG results): every view counts as a full unit view, i.e. every brick takes the plain-average
                     // path -- the floor of what the weight evaluation can be brought down to
+                    // (compiled only into profiling builds -- make CXXFLAGS+=-DMVS_PROFILING_ABLATIONS, tools/fuse_floor.sh: a stray
+                    // environment variable must not be able to corrupt the shipped path's output)
+#ifdef MVS_PROFILING_ABLATIONS
                     static const bool ablate_unit = getenv("MVS_FUSE_ALL_UNIT") != nullptr;
                     if (ablate_unit) R.allone_mask = ((1 << nv) - 1) | (1 << 15);
+#endif
                     // brick width: 16 voxels for thin boxes, 512 (one full tile row per load instruction: the longest
                     // contiguous runs, 4.0 instead of 3.0 TB/s on the copy class) for wide copy-class boxes, else 128
                     int lxb = (R.x1 - R.x0 <= 32) ? 1 : 4;

@@ -41,17 +41,11 @@ struct MvsContext {
     double reg_alg_bytes_full = 0.0;   // the same model with every scored candidate counted whole (what the reference's formulation moves)
     long long reg_pairs = 0, reg_candidates = 0, reg_pruned = 0;   // reg_pruned: candidates the pruned arg-max search left unfinished
     double reg_cand_volumes = 0.0;     // candidate volumes the SSIM walk actually went through (a pruned candidate counts its fraction)
-    float raw_range[4] = {0.f, 0.f, 0.f, 0.f};            // with raw_u16_keys: min, max of the fixed crop, min, max of the moving crop
-    const float* raw_u16_keys[2] = {nullptr, nullptr};   // set by mvs_register_crops: integer-valued originals of the two crops (16-bit rank keys)
     // the class kernels of one fuse launch run on side streams next to the main one (fork / join by events)
     hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     bool serial_classes = false;       // option "serial_classes": launch them one after the other on the main stream instead
-    bool defer_sync = false;           // set by composite entry points: mvs_resample to device memory returns without waiting
-    bool both_crops_finite = false;    // set by mvs_register_crops around its mvs_score_candidates call (under the context lock)
     bool reg_unfused = false;          // test switch: the phase correlation runs its separate launches (pack, cross power, peak search, min / max) instead of the fused passes
-    bool score_argmax_only = false;    // set by mvs_register_crops around its mvs_score_candidates call: only the arg-max candidate is needed
-    double score_value_bound = INFINITY;   // ... with the largest absolute value of the two (rescaled) crops
     bool ssim_prune = true;            // option "ssim_prune" (default 1; environment MVS_SSIM_PRUNE=0 turns it off for new contexts)
     bool fft_no_pair = false;          // test switch: the first inverse pass of the phase correlation takes its lines in flat order (no partner pairs)
     bool ssim_two_pass = false;        // test switch: batched candidates go through the separate z and y/x SSIM launches instead of the fused walk
@@ -78,14 +72,6 @@ struct MvsContext {
     void* mbox_dev = nullptr;
     size_t mbox_cap = 0;
     uint64_t mbox_gen = 0;        // bumped whenever the mailbox is reallocated (its old contents are gone)
-    // set by mvs_register_views around its two crops: the integer crop kernel also reduces min / max / #valid of what it writes into
-    // per-block partials (layout of nanminmax_pair_kernel) at crop_stats_dst, with crop_stats_nb blocks; crop_stats_done[k] tells
-    // mvs_rescale_pair_device that image k's partials are already there
-    char* crop_stats_dst = nullptr;
-    int crop_stats_nb = 0, crop_stats_k = 0;
-    uint64_t crop_stats_gen = 0;  // mbox_gen at the time the partials were parked: a reallocated mailbox invalidates them
-    void* crop_stats_base = nullptr;
-    bool crop_stats_done[2] = {false, false};
     bool cb_nosplit = false;      // test switch: the y / z passes of the paired path keep both quantities in one workgroup
     bool cb_unpaired = false;     // test switch: content-based weights through the separate value / mask line passes of rounds 1-3
     bool fft_no_line = false;     // test switch: lengths of the whole-line DFT kernel run on the Bluestein kernels instead
@@ -100,6 +86,35 @@ struct MvsContext {
     size_t pool_cached_bytes = 0;
     size_t pool_cache_limit = (size_t)32 << 30;
 };
+
+// ---- per-call options of the internal entry points (arguments, not context state: a failing inner call cannot leave them behind) ----
+// what mvs_register_crops knows about its two crops when it scores candidates (mvs_score_candidates_impl)
+struct MvsScoreOpts {
+    bool both_crops_finite = false;    // neither NaN nor inf in either crop: every voxel valid, boxes = the volume, no NaN handling
+    bool argmax_only = false;          // only the arg-max candidate (and its rank correlation) is needed: the pruned search may run
+    double value_bound = INFINITY;     // ... with the largest absolute value of the two (rescaled) crops
+    const float* raw_u16_keys[2] = {nullptr, nullptr};   // integer-valued originals of the two crops (16-bit rank keys), or NULL
+    float raw_range[4] = {0.f, 0.f, 0.f, 0.f};           // with raw_u16_keys: min, max of the fixed crop, min, max of the moving crop
+};
+// min / max / #valid partials the integer crop kernel leaves while it writes a crop (mvs_register_views -> mvs_resample_impl ->
+// mvs_rescale_pair_device): per-block partials in the layout of nanminmax_pair_kernel, `nb` blocks per image, image k at
+// base + k * nb * 16; done[k] is set by the launch that actually wrote them; gen = the mailbox generation they were parked in
+struct MvsCropStats {
+    char* base = nullptr;
+    int nb = 0;
+    uint64_t gen = 0;
+    bool done[2] = {false, false};
+};
+struct MvsResampleOpts {
+    bool defer_sync = false;           // a result in device memory is not waited for (the composite caller orders later work)
+    MvsCropStats* stats = nullptr;     // with stats_k: also reduce the crop's statistics (integer crops with NaN outside only)
+    int stats_k = 0;
+};
+int mvs_score_candidates_impl(int device, const float* fixed, const float* moving, int32_t mem, int32_t ndim, const int64_t shape[3],
+                              const double* t_candidates, int32_t n_candidates, int32_t region_mode, double data_range, double im1_min,
+                              int32_t quality_for_all, double* ssim_out, double* spearman_out, int32_t* code_out, const MvsScoreOpts& so);
+int mvs_resample_impl(int device, const mvs_view_t* view, const int64_t out_shape[3], int32_t order, float cval, float* out, int32_t out_mem,
+                      const MvsResampleOpts& ro);
 
 MvsContext* mvs_ctx(int device);                       // nullptr if out of range
 int mvs_fail(MvsContext* c, int code, const char* fmt, ...);

@@ -12,15 +12,27 @@
 #include "mvs_internal.h"
 
 int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, long long n, float* out0, float* out1,
-                            float mn[2], float mx[2], long long nvalid[2], long long n_not_u16[2]);   // mvs_reg.hip
+                            float mn[2], float mx[2], long long nvalid[2], long long n_not_u16[2], const MvsCropStats* parked);   // mvs_reg.hip
 
 #include <algorithm>
 #include <cmath>
 #include <vector>
 
+static int register_crops_impl(int device, const float* fixed, const float* moving, int32_t mem, int32_t ndim, const int64_t shape[3],
+                               int32_t upsample_factor, int32_t region_mode, int32_t constant_check, double t_out[3], double* quality_out,
+                               int32_t* status_out, int32_t* n_candidates_out, const MvsCropStats* parked);
+
 extern "C" int mvs_register_crops(int device, const float* fixed, const float* moving, int32_t mem, int32_t ndim, const int64_t shape[3],
                                   int32_t upsample_factor, int32_t region_mode, int32_t constant_check, double t_out[3], double* quality_out,
                                   int32_t* status_out, int32_t* n_candidates_out) {
+    return register_crops_impl(device, fixed, moving, mem, ndim, shape, upsample_factor, region_mode, constant_check, t_out, quality_out, status_out,
+                               n_candidates_out, nullptr);
+}
+
+// (parked: statistics the crop kernels of mvs_register_views left in the mailbox -- an argument of this call, not context state)
+static int register_crops_impl(int device, const float* fixed, const float* moving, int32_t mem, int32_t ndim, const int64_t shape[3],
+                               int32_t upsample_factor, int32_t region_mode, int32_t constant_check, double t_out[3], double* quality_out,
+                               int32_t* status_out, int32_t* n_candidates_out, const MvsCropStats* parked) {
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
@@ -50,7 +62,7 @@ extern "C" int mvs_register_crops(int device, const float* fixed, const float* m
         MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
         float mn[2], mx[2];
         long long nv[2], not_u16[2];
-        rc = mvs_rescale_pair_device(c, fixed, moving, n, r0, r1, mn, mx, nv, not_u16);
+        rc = mvs_rescale_pair_device(c, fixed, moving, n, r0, r1, mn, mx, nv, not_u16, parked);
         if (rc) return rc;
         // crops of integer tiles on the fixed grid hold 16-bit integers: rescaling is strictly increasing and one-to-one on them,
         // so the rank order (and every tie) of the rescaled image equals that of the raw integers -> 16-bit sort keys
@@ -145,22 +157,19 @@ extern "C" int mvs_register_crops(int device, const float* fixed, const float* m
     std::vector<double> ssim_u(n_uniq), spear_u(n_uniq);
     std::vector<int32_t> code_u(n_uniq);
     // rescaled crops are finite iff the inputs were: no NaN (all voxels counted) and finite extrema (no inf)
-    c->both_crops_finite = !has_nan && std::isfinite(min0) && std::isfinite(max0) && std::isfinite(min1) && std::isfinite(max1) &&
+    MvsScoreOpts so;
+    so.both_crops_finite = !has_nan && std::isfinite(min0) && std::isfinite(max0) && std::isfinite(min1) && std::isfinite(max1) &&
                            !c->materialize_shifts;
-    c->raw_u16_keys[0] = c->materialize_shifts ? nullptr : raw_keys0;
-    c->raw_u16_keys[1] = c->materialize_shifts ? nullptr : raw_keys1;
-    c->raw_range[0] = min0; c->raw_range[1] = max0; c->raw_range[2] = min1; c->raw_range[3] = max1;
+    so.raw_u16_keys[0] = c->materialize_shifts ? nullptr : raw_keys0;
+    so.raw_u16_keys[1] = c->materialize_shifts ? nullptr : raw_keys1;
+    so.raw_range[0] = min0; so.raw_range[1] = max0; so.raw_range[2] = min1; so.raw_range[3] = max1;
     // only the arg-max candidate (and its rank correlation) leaves this function: the scoring may stop a candidate as soon as
-    // it provably cannot win (see the pruned search in mvs_score_candidates); the rescaled values lie in [lo, hi]
-    c->score_argmax_only = true;
-    c->score_value_bound = (double)std::max(std::max(std::fabs(lo0), std::fabs(hi0)), std::max(std::fabs(lo1), std::fabs(hi1)));
+    // it provably cannot win (see the pruned search in mvs_score_candidates_impl); the rescaled values lie in [lo, hi]
+    so.argmax_only = true;
+    so.value_bound = (double)std::max(std::max(std::fabs(lo0), std::fabs(hi0)), std::max(std::fabs(lo1), std::fabs(hi1)));
     const double cand_vol0 = c->reg_cand_volumes;
-    rc = mvs_score_candidates(device, r0, r1, MVS_MEM_DEVICE, ndim, shape, uniq.data(), n_uniq, region_mode, (double)data_range, im1_min, 0,
-                              ssim_u.data(), spear_u.data(), code_u.data());
-    c->both_crops_finite = false;
-    c->score_argmax_only = false;
-    c->score_value_bound = INFINITY;
-    c->raw_u16_keys[0] = c->raw_u16_keys[1] = nullptr;
+    rc = mvs_score_candidates_impl(device, r0, r1, MVS_MEM_DEVICE, ndim, shape, uniq.data(), n_uniq, region_mode, (double)data_range, im1_min, 0,
+                                   ssim_u.data(), spear_u.data(), code_u.data(), so);
     if (rc) return rc;
     int n_scored = 0;      // candidates that went through the shift + SSIM kernels (the others were rejected from their boxes)
     for (int u = 0; u < n_uniq; ++u) n_scored += (code_u[u] == 0) ? 1 : 0;
@@ -215,24 +224,21 @@ extern "C" int mvs_register_views(int device, const mvs_view_t* fixed_view, cons
     void *mb_host = nullptr, *mb_dev = nullptr;
     rc = mvs_mailbox(c, (size_t)nb_stats * 32, &mb_host, &mb_dev);
     if (rc) return rc;
-    c->crop_stats_done[0] = c->crop_stats_done[1] = false;
-    c->crop_stats_nb = nb_stats;
-    c->crop_stats_gen = c->mbox_gen;
-    c->crop_stats_base = mb_dev;
-    c->defer_sync = true;
-    c->crop_stats_k = 0;
-    c->crop_stats_dst = c->reg_unfused ? nullptr : (char*)mb_dev;
-    rc = mvs_resample(device, fixed_view, out_shape, 1, NAN, crop0, MVS_MEM_DEVICE);
-    c->crop_stats_k = 1;
-    c->crop_stats_dst = c->reg_unfused ? nullptr : (char*)mb_dev + (size_t)nb_stats * 16;
-    if (!rc) rc = mvs_resample(device, moving_view, out_shape, 1, NAN, crop1, MVS_MEM_DEVICE);
-    c->defer_sync = false;
-    c->crop_stats_dst = nullptr;
-    if (rc) { c->crop_stats_done[0] = c->crop_stats_done[1] = false; return rc; }
-    rc = mvs_register_crops(device, crop0, crop1, MVS_MEM_DEVICE, ndim, out_shape, upsample_factor, region_mode, constant_check, t_out,
-                            quality_out, status_out, n_candidates_out);
-    c->crop_stats_done[0] = c->crop_stats_done[1] = false;
-    return rc;
+    MvsCropStats stats;                 // lives for this call only: nothing to clear on any return path
+    stats.base = c->reg_unfused ? nullptr : (char*)mb_dev;
+    stats.nb = nb_stats;
+    stats.gen = c->mbox_gen;
+    MvsResampleOpts ro;
+    ro.defer_sync = true;
+    ro.stats = &stats;
+    ro.stats_k = 0;
+    rc = mvs_resample_impl(device, fixed_view, out_shape, 1, NAN, crop0, MVS_MEM_DEVICE, ro);
+    if (rc) return rc;
+    ro.stats_k = 1;
+    rc = mvs_resample_impl(device, moving_view, out_shape, 1, NAN, crop1, MVS_MEM_DEVICE, ro);
+    if (rc) return rc;
+    return register_crops_impl(device, crop0, crop1, MVS_MEM_DEVICE, ndim, out_shape, upsample_factor, region_mode, constant_check, t_out,
+                               quality_out, status_out, n_candidates_out, &stats);
 }
 
 

@@ -467,7 +467,7 @@ int mvs_device_nanminmax(MvsContext* c, const float* d_in, long long n, float* m
 // queued together, their partials come back in one copy, then the two rescale kernels follow.  Same kernels and
 // arithmetic as two mvs_rescale_intensity calls.
 int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, long long n, float* out0, float* out1,
-                            float mn[2], float mx[2], long long nvalid[2], long long n_not_u16[2]) {
+                            float mn[2], float mx[2], long long nvalid[2], long long n_not_u16[2], const MvsCropStats* parked) {
     const int nb = std::min(grid_for(n), 512);      // (each block writes its partials over the host link: fewer, longer blocks)
     void *mb_host = nullptr, *mb_dev = nullptr;       // the per-block partials land in host memory directly
     int rcm = mvs_mailbox(c, (size_t)nb * 32, &mb_host, &mb_dev);
@@ -477,8 +477,7 @@ int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, l
     PP.in[0] = in0; PP.in[1] = in1; PP.out[0] = out0; PP.out[1] = out1;
     // (mvs_register_views: the crop kernels have left these partials already -- same layout, same block count)
     // ... and only in the very allocation they were written to: a mailbox that was reallocated in between has lost them
-    if (!(c->crop_stats_done[0] && c->crop_stats_done[1] && c->crop_stats_nb == nb && c->crop_stats_gen == c->mbox_gen &&
-          c->crop_stats_base == mb_dev))
+    if (!(parked && parked->done[0] && parked->done[1] && parked->nb == nb && parked->gen == c->mbox_gen && (void*)parked->base == mb_dev))
         hipLaunchKernelGGL(nanminmax_pair_kernel, dim3(nb, 2), dim3(256), 0, c->stream, PP, n, scratch, nb);
     MVS_HIP_TRY(c, hipGetLastError());
     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -1357,6 +1357,13 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                                     const int64_t shape[3], const double* t_candidates, int32_t n_candidates,
                                     int32_t region_mode, double data_range, double im1_min, int32_t quality_for_all,
                                     double* ssim_out, double* spearman_out, int32_t* code_out) {
+    return mvs_score_candidates_impl(device, fixed, moving, mem, ndim, shape, t_candidates, n_candidates, region_mode, data_range, im1_min,
+                                     quality_for_all, ssim_out, spearman_out, code_out, MvsScoreOpts{});
+}
+
+int mvs_score_candidates_impl(int device, const float* fixed, const float* moving, int32_t mem, int32_t ndim, const int64_t shape[3],
+                              const double* t_candidates, int32_t n_candidates, int32_t region_mode, double data_range, double im1_min,
+                              int32_t quality_for_all, double* ssim_out, double* spearman_out, int32_t* code_out, const MvsScoreOpts& so) {
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
@@ -1445,7 +1452,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
 
     // valid voxels of im1 and the bboxes of both images (registration.py:400, 491)
     VoxStats h_im[2];
-    if (c->both_crops_finite) {
+    if (so.both_crops_finite) {
         // the caller (mvs_register_crops) has just reduced both images and found neither NaN nor inf: every voxel is valid,
         // the boxes are the whole volume -- no reduction, no host round trip
         for (int k = 0; k < 2; ++k) {
@@ -1518,15 +1525,15 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             }
             int nf = 0;
             for (int k = 0; k < 3; ++k) nf += (std::floor(t[k]) != t[k]) ? 1 : 0;
-            // key ranges from the raw extrema of the crops (c->raw_range: min / max of the fixed and of the moving crop)
-            const long long kx0 = (long long)c->raw_range[0], nbx = (long long)c->raw_range[1] - kx0 + 1;
-            const long long ky0 = (long long)c->raw_range[2] * (1 << nf), nby = ((long long)c->raw_range[3] - (long long)c->raw_range[2]) * (1 << nf) + 1;
+            // key ranges from the raw extrema of the crops (so.raw_range: min / max of the fixed and of the moving crop)
+            const long long kx0 = (long long)so.raw_range[0], nbx = (long long)so.raw_range[1] - kx0 + 1;
+            const long long ky0 = (long long)so.raw_range[2] * (1 << nf), nby = ((long long)so.raw_range[3] - (long long)so.raw_range[2]) * (1 << nf) + 1;
             // < 65536 voxels per workgroup; up to kHistParts workgroups write their histograms out whole (folded by a
             // second kernel), beyond that the non-zero counters are flushed with atomics
             const long long hneed = ((long long)n / 4 + 16382) / 16383;
             const bool fold = hneed <= kHistParts;
             const long long hgb = fold ? std::max<long long>(hneed, std::min<long long>(kHistParts, ((long long)n + 8191) / 8192)) : std::max<long long>(gb, hneed);
-            if (halves && c->raw_u16_keys[0] && c->raw_u16_keys[1] && c->both_crops_finite && !c->materialize_shifts && nbx > 0 && nby > 0 &&
+            if (halves && so.raw_u16_keys[0] && so.raw_u16_keys[1] && so.both_crops_finite && !c->materialize_shifts && nbx > 0 && nby > 0 &&
                 nbx + nby <= kHistBinsMax && hgb <= 65535) {
                 static bool lds_attr[MVS_MAX_DEVICES] = {false};
                 if (!lds_attr[mvs_hip_device(device)]) {
@@ -1535,7 +1542,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 }
                 const size_t lds_bytes = (size_t)((nbx + nby + 1) / 2) * 4;
                 if (!fold) MVS_HIP_TRY(c, hipMemsetAsync(d_hist, 0, sizeof(unsigned int) * (size_t)(nbx + nby), c->stream));
-                hipLaunchKernelGGL(hist_rank_kernel<false>, dim3((unsigned)hgb), dim3(1024), lds_bytes, c->stream, c->raw_u16_keys[0], c->raw_u16_keys[1],
+                hipLaunchKernelGGL(hist_rank_kernel<false>, dim3((unsigned)hgb), dim3(1024), lds_bytes, c->stream, so.raw_u16_keys[0], so.raw_u16_keys[1],
                                    S, t[0], t[1], t[2], (int)kx0, (int)nbx, (int)ky0, (int)nby, d_hist, d_hist + nbx, (const float*)nullptr,
                                    (const float*)nullptr, (double*)nullptr, fold ? d_parts : (unsigned int*)nullptr);
                 if (fold) {
@@ -1545,7 +1552,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
                 }
                 hipLaunchKernelGGL(rank_table_kernel, dim3(2), dim3(1024), 0, c->stream, d_hist, (int)nbx, d_rank, d_hist + nbx, (int)nby,
                                    d_rank + nbx, partial);
-                hipLaunchKernelGGL(hist_rank_kernel<true>, dim3(gb), dim3(256), 0, c->stream, c->raw_u16_keys[0], c->raw_u16_keys[1], S, t[0], t[1],
+                hipLaunchKernelGGL(hist_rank_kernel<true>, dim3(gb), dim3(256), 0, c->stream, so.raw_u16_keys[0], so.raw_u16_keys[1], S, t[0], t[1],
                                    t[2], (int)kx0, (int)nbx, (int)ky0, (int)nby, d_hist, d_hist + nbx, d_rank, d_rank + nbx, partial + 4, (unsigned int*)nullptr);
                 MVS_HIP_TRY(c, hipGetLastError());
                 MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1565,7 +1572,7 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             im1t = im1t_buf[0];
         }
         MVS_HIP_TRY(c, hipMemsetAsync(d_counter, 0, 4, c->stream));
-        const float* raw0 = c->raw_u16_keys[0];      // 16-bit integer keys for the fixed image when the caller vouches for them
+        const float* raw0 = so.raw_u16_keys[0];      // 16-bit integer keys for the fixed image when the caller vouches for them
         hipLaunchKernelGGL(compact_kernel, dim3(gb), dim3(256), 0, c->stream, im0, im1t, n, setA[0], setA[1], d_counter, raw0);
         const unsigned int m = (unsigned int)cnts[ic];
         const int mgb = (int)std::min<long long>(((long long)m + kRankChunk - 1) / kRankChunk, 2048);   // one chunk of sorted keys per workgroup turn
@@ -1788,13 +1795,13 @@ extern "C" int mvs_score_candidates(int device, const float* fixed, const float*
             // still reaches the best complete sum (see the plan inside the loop).  On the bench mosaic the decorrelated candidates
             // (mean 0.01-0.15 against 0.90-0.975) leave after 3/32-8/32 of their volume, the sign flips of a half-pixel axis (0.6-0.94)
             // after 6/32-22/32: 2.6 instead of 9.2 candidate volumes per pair (profiles/round4_prune_ab.txt).
-            bool prune = c->score_argmax_only && c->ssim_prune && todo.size() <= (size_t)nres;
+            bool prune = so.argmax_only && c->ssim_prune && todo.size() <= (size_t)nres;
             int n_in = 0;
             for (int j = 0; j < nb; ++j) {
                 if (fused_batch.c[j].src) ++n_in;
                 else if (scored[j]) prune = false;          // a candidate on the separate passes: everything is scored in full
             }
-            const double vb = c->score_value_bound;
+            const double vb = so.value_bound;
             const double slack = 1e-2 * std::max(1.0, (vb / data_range) * (vb / data_range));
             prune = prune && n_in >= 2 && data_range > 0.0 && std::isfinite(slack) && slack <= 0.05;
             if (!prune) {

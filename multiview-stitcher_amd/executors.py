@@ -210,10 +210,23 @@ def pin_process_to_compact_cpus(slot=0, n_cpus=None):
     return sorted(os.sched_getaffinity(0))
 
 
+def local_rank_from_env():
+    """This process's index among the processes of its node as the common launchers export it, or None."""
+    import os
+
+    for key in ("LOCAL_RANK", "SLURM_LOCALID", "OMPI_COMM_WORLD_LOCAL_RANK", "MV2_COMM_WORLD_LOCAL_RANK", "MPI_LOCALRANKID"):
+        v = os.environ.get(key, "")
+        if v.strip().lstrip("-").isdigit():
+            return max(int(v), 0)
+    return None
+
+
 def pin_worker_thread():
     """Initializer of the library's own worker threads (the pair pool of ``compute_pairwise_registrations``): the calling
     THREAD is restricted to the compact CPU block ``pin_process_to_compact_cpus`` would choose for the process -- the
-    process itself (the caller's threads) is left alone.  No-op when the process mask is already narrow or ``MVS_PIN_CPUS=0``."""
+    process itself (the caller's threads) is left alone.  No-op when the process mask is already narrow, when ``MVS_PIN_CPUS=0``,
+    and when the environment does not say which process of the node this is (``local_rank_from_env``; ``MVS_PIN_CPUS=a-b`` names
+    the CPUs explicitly).  (The batched pair path runs on native worker threads, which inherit the caller's affinity.)"""
     import os
     import threading
 
@@ -228,10 +241,15 @@ def pin_worker_thread():
             cpus.update(range(int(lo), int(hi or lo) + 1))
         cpus &= set(avail)
     else:
+        # a block is chosen only when the launcher says which process of the node this is (torchrun / SLURM / Open MPI / MVAPICH):
+        # processes started without any of these -- dask or joblib workers, several notebooks -- would otherwise all pin their
+        # workers to the node's FIRST block.  No rank information: the threads stay where the scheduler puts them.
+        slot = local_rank_from_env()
+        if slot is None:
+            return
         n = max(8, min(_default_block(), len(avail)))
         if len(avail) < 2 * n:
             return
-        slot = int(os.environ.get("LOCAL_RANK", "0") or 0)
         first = (slot * n) % (len(avail) - n + 1)
         cpus = set(avail[first:first + n])
     try:

@@ -206,10 +206,11 @@ def fuse_np(
         else:
             import warnings
 
+            off_c = float(np.abs(io_ - np.round(io_)).max()) if io_.size else 0.0
+            off_s = float(np.abs(so_ - np.round(so_)).max()) if so_.size else 0.0      # (a chunk without views has no slabs)
             warnings.warn(
                 "fuse_np: frame_origin cannot be applied -- the chunk origin or a slab origin is not on the frame's grid "
-                f"(largest distance from it: chunk {float(np.abs(io_ - np.round(io_)).max()):.3g} px, slabs "
-                f"{float(np.abs(so_ - np.round(so_)).max()):.3g} px); the parameters of this chunk are derived per chunk, so its "
+                f"(largest distance from it: chunk {off_c:.3g} px, slabs {off_s:.3g} px); the parameters of this chunk are derived per chunk, so its "
                 "voxels may differ in the last bit from the same voxels fused through another chunk, launch block or shard",
                 IndexFrameWarning, stacklevel=2)
     matrices, offsets = get_pixel_affines(p_inv, ref_in_origins, in_spacings, ref_out_origin, out_spacing)
@@ -801,7 +802,7 @@ def _fuse_once(
                       weights_func=weights_func, weights_func_kwargs=weights_func_kwargs, output_stack_mode=output_stack_mode,
                       output_chunksize=output_chunksize, overlap_in_pixels=overlap_in_pixels, trim_overlap=trim_overlap,
                       interpolation_order=interpolation_order, blending_widths=blending_widths, backend=backend, device=device,
-                      chunk_filter=chunk_filter, merge_chunks=merge_chunks, frame_origin=frame_origin)
+                      chunk_filter=chunk_filter, merge_chunks=merge_chunks)
         scale0 = [msi_utils.get_sim_from_msim(m, scale="scale0") for m in msims]
         sdims0 = si_utils.get_spatial_dims_from_sim(scale0[0])
         osp0 = _bb_dicts(process_output_stack_properties(scale0, output_spacing, output_origin, output_shape, output_stack_properties,
@@ -812,7 +813,7 @@ def _fuse_once(
 
         if output_zarr_url is not None:
             fused = fuse(images=level_sims(osp0["spacing"]), output_stack_properties=osp0, output_zarr_url=output_zarr_url,
-                               zarr_options=zarr_options, batch_options=batch_options, **common)
+                               zarr_options=zarr_options, batch_options=batch_options, frame_origin=frame_origin, **common)
             if (zarr_options or {}).get("ome_zarr", False) and chunk_filter is None:
                 from . import ngff_utils
 
@@ -825,8 +826,11 @@ def _fuse_once(
             props = {"shape": dict(shape), "spacing": {d: osp0["spacing"][d] * f[d] for d in sdims0},
                      # centre-of-pixel convention of downsampled levels (as in the OME-Zarr pyramid)
                      "origin": {d: osp0["origin"][d] + (f[d] - 1) * osp0["spacing"][d] / 2 for d in sdims0}}
+            # (a caller's frame_origin refers to the scale0 grid: a coarser level's grid is displaced by (f - 1) * spacing / 2
+            # against it, so the level keeps its own frame = its own stack origin)
+            level0 = all(int(f[d]) == 1 for d in sdims0)
             fused_levels.append(fuse(images=level_sims(props["spacing"]), output_stack_properties=props,
-                                           output_on_backend=output_on_backend, **common))
+                                           output_on_backend=output_on_backend, frame_origin=frame_origin if level0 else None, **common))
         return msi_utils.get_msim_from_sims(fused_levels)
     sims_ = list(images)
 

@@ -132,7 +132,13 @@ def get_msim_from_sims(sims):
     for a, b in zip(sims, sims[1:]):
         if not all(b.sizes[d] <= a.sizes[d] for d in sdims):
             raise ValueError("sims cannot be ordered into resolution levels (shapes are not comparable).")
-    return MultiscaleSpatialImage(sims, copy.deepcopy(sims[0].attrs.get("transforms", {})))
+    # copies (shallow: the voxels are shared), so that the caller's images keep their attrs; the lower levels inherit exactly
+    # the transform keys of scale0 (msi_utils.py:466-480)
+    sims = [s.copy() for s in sims]
+    t0 = sims[0].attrs.get("transforms", {})
+    for s in sims[1:]:
+        s.attrs["transforms"] = {k: np.array(v, dtype=np.float64, copy=True) for k, v in t0.items()}
+    return MultiscaleSpatialImage(sims, copy.deepcopy(t0))
 
 
 def get_res_level_from_binning_factors(msim, binning_factors):

@@ -734,7 +734,8 @@ def _select_registration_level(msim1, msim2, registration_binning, reg_res_level
     if registration_binning is None:
         registration_binning = get_optimal_registration_binning(sim1_0, sim2_0)
     if ms[0] is None or len(scale_keys(0)) == 1:
-        return sim1_0, sim2_0, dict(registration_binning)
+        # (missing dims count as 1, like get_res_level_from_binning_factors: msi_utils.py:688-773)
+        return sim1_0, sim2_0, {d: registration_binning.get(d, 1) for d in sdims}
     scale_key, remaining = msi_utils.get_res_level_from_binning_factors(ms[0], registration_binning)
     if scale_key not in scale_keys(1):
         raise ValueError(f"{scale_key} does not exist in the second multiscale image")

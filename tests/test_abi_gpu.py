@@ -82,3 +82,65 @@ def test_out_of_memory_has_its_own_code_and_exception(hip_device):
     with pytest.raises(_lib.MvsError) as ei:
         _lib.set_option("rowlds", 1)                                             # retired in round 3
     assert ei.value.code == -1 and not isinstance(ei.value, _lib.DeviceMemoryError)
+
+
+def test_a_failing_composite_call_leaves_no_state_on_its_lane(hip_device):
+    """mvs_register_views / mvs_register_crops hand their per-call knowledge (statistics parked by the crop kernels, "only the
+    arg max is needed", "both crops are finite", deferred waits) to the inner steps as ARGUMENTS (MvsScoreOpts / MvsCropStats /
+    MvsResampleOpts in csrc/mvs_internal.h), not as context fields: a composite call that fails half way -- here the second crop
+    is refused after the first one has been queued with its statistics -- leaves nothing behind.  On the same lane afterwards the
+    public mvs_score_candidates scores every candidate in full (nothing pruned), mvs_resample to host memory has waited for its
+    result, and a registration equals the one of an untouched lane bit for bit."""
+    from scipy import ndimage
+
+    from multiview_stitcher_amd import _lib, _reg_ops
+    from multiview_stitcher_amd.device import DeviceArray
+    from oracle import reg_oracle as ro
+
+    lane_a, lane_b = 0 | (3 << 8), 0 | (4 << 8)
+    lib = _lib.init(lane_a)
+    _lib.init(lane_b)
+    rng = np.random.default_rng(4)
+    big = (ndimage.gaussian_filter(rng.random((44, 88, 140)), 1.2) * 4000).astype(np.uint16)
+    t0, t1 = np.ascontiguousarray(big[2:42, 4:84, 6:126]), np.ascontiguousarray(big[3:43, 2:82, 10:130])
+    d0, d1 = DeviceArray.from_host(t0, lane_a), DeviceArray.from_host(t1, lane_a)
+    shape = (40, 80, 120)
+
+    def view(d, bad=False):
+        v = _lib.mvs_view_t()
+        v.data, v.dtype, v.mem = d.ptr, _lib.MVS_U16, _lib.MVS_MEM_DEVICE
+        v.shape[:] = list(shape)
+        v.stride[:] = [80 * 120, 120, 2 if bad else 1]            # an x stride of 2 is refused by the resampler
+        v.matrix[:] = [1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0]
+        v.offset[:] = [0.0, 0.0, 0.0]
+        return v
+
+    t, q, status, ncand = (C.c_double * 3)(), C.c_double(), C.c_int32(), C.c_int32()
+
+    def register(lane, v0, v1):
+        return lib.mvs_register_views(lane, C.byref(v0), C.byref(v1), 3, _lib.i64x3(shape), 2, -1, 1, t, C.byref(q), C.byref(status), C.byref(ncand))
+
+    assert register(lane_b, view(d0), view(d1)) == 0                 # reference result from an untouched lane
+    want = (list(t), q.value, status.value, ncand.value)
+    for key in ("reg_pruned", "reg_cand_volumes", "reg_candidates"):
+        _lib.get_counter(key, lane_a, reset=True)
+    assert register(lane_a, view(d0), view(d1, bad=True)) < 0       # fails after the fixed crop (and its statistics) were queued
+    assert lib.mvs_last_error(lane_a)
+    # (1) the public scoring call on that lane: every candidate in full
+    a = ro.rescale_intensity_01(t0.astype(np.float32))
+    b = ro.rescale_intensity_01(t1.astype(np.float32))
+    cands = np.array([[-1.0, 2.0, -4.0], [1.0, -2.0, 4.0], [0.0, 0.0, 0.0], [-1.0, 2.0, 4.0]])
+    ssim, spear, codes = _reg_ops.score_candidates(a, b, cands, "union", 1.0, 0.0, device=lane_a)
+    assert _lib.get_counter("reg_pruned", lane_a) == 0
+    ssim_b, spear_b, codes_b = _reg_ops.score_candidates(a, b, cands, "union", 1.0, 0.0, device=lane_b)
+    np.testing.assert_array_equal(ssim, ssim_b)
+    np.testing.assert_array_equal(spear, spear_b)
+    # (2) a plain resample to HOST memory returns a finished result
+    out = np.full(shape, -1.0, np.float32)
+    v0 = view(d0)
+    assert lib.mvs_resample(lane_a, C.byref(v0), _lib.i64x3(shape), 1, np.nan, out.ctypes.data, _lib.MVS_MEM_HOST) == 0
+    np.testing.assert_array_equal(out, t0.astype(np.float32))
+    # (3) the same registration on the lane that failed == the untouched lane's
+    assert register(lane_a, view(d0), view(d1)) == 0
+    assert (list(t), q.value, status.value, ncand.value) == want
+    assert want[2] == 0 and [abs(v) for v in want[0]] == [1.0, 2.0, 4.0]

@@ -1,5 +1,6 @@
 #!/bin/bash
 # per-class alone-times of the fuse launch as it is and with every view counted as a unit view (timing floor, wrong results)
+# the "unit" leg needs a profiling build: make -C multiview-stitcher_amd/csrc EXTRA_CXXFLAGS=-DMVS_PROFILING_ABLATIONS (touch mvs_fuse_region.hip first)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/floor; rm -rf $O; mkdir -p $O
 for tag in asis unit; do
