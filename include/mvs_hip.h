@@ -115,7 +115,9 @@ int mvs_synchronize(int device);
  * pass; both ways must agree bit for bit) and mvs_phasecorr_multi runs one inverse transform per normalisation (by default
  * two normalisations share one); tests compare the plain and the default paths.  "serial_classes" = 1: the class kernels of
  * the translation fast path of mvs_fuse_chunk run one after the other on the context's stream (default: side by side on
- * side streams, joined before the call's work is considered done).  "rows_v1" = 1: the direct-load row-owning kernels
+ * side streams, joined before the call's work is considered done).  "fuse_mixed" = 1 (default 0): the copy class and the
+ * one- / two-view classes of that path run as ONE launch over a brick list ordered in space across the classes (measured: no
+ * faster, 2 % less HBM traffic -- profiles/round5_fuse_mixed.txt; same voxels).  "rows_v1" = 1: the direct-load row-owning kernels
  * (whole output rows per workgroup, mvs_fuse_rows.hip) are tried before the region kernels for every dtype (default: for
  * float32 tiles only, where they reproduce scipy's NaN propagation through zero-weight taps); it must agree with the
  * default path (tests compare both with the oracle).  Unknown keys -- among them the retired "rowlds" and "stream_rows"

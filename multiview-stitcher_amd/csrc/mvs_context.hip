@@ -190,6 +190,8 @@ int mvs_init(int device) {
     {   // A/B switch for all context lanes of a process (bench.py, tools/): MVS_SSIM_PRUNE=0 scores every candidate in full
         const char* ev = getenv("MVS_SSIM_PRUNE");
         if (ev && *ev) c->ssim_prune = atoi(ev) != 0;
+        ev = getenv("MVS_FUSE_MIXED");          // A/B switch of the one-launch fuse list (profiles/round5_fuse_mixed.txt)
+        if (ev && *ev) c->fuse_mixed = atoi(ev) != 0;
         ev = getenv("MVS_FFT_NO_PAIR");
         if (ev && *ev) c->fft_no_pair = atoi(ev) != 0;
     }
@@ -279,6 +281,10 @@ int mvs_set_option(int device, const char* key, int64_t value) {
     }
     if (!strcmp(key, "rows_v1")) {
         c->rows_v1 = value != 0;
+        return MVS_OK;
+    }
+    if (!strcmp(key, "fuse_mixed")) {
+        c->fuse_mixed = value != 0;
         return MVS_OK;
     }
     if (!strcmp(key, "serial_classes")) {

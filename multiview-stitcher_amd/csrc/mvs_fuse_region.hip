@@ -698,24 +698,15 @@ __device__ __forceinline__ void region_brick_generic(const RegionParams& P, cons
 // All constants are hoisted into scalar registers, the 8 row-group loads of a plane are issued back-to-back before
 // the first one is consumed (integer offsets), so a wavefront keeps 8 KiB in flight.
 template <typename TIn, typename TOut>
-__global__ __launch_bounds__(256) void copy_region_kernel(RegionParams P, int item0, int nitems) {
+__device__ __forceinline__ void copy_brick_item(const RegionParams& P, const Item it, const int lane, float* strip_w) {
     constexpr int ES = (int)sizeof(TIn);
-    __shared__ float s_strip[4][9 * 64];
-    const int lane = threadIdx.x & 63;
-    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD k takes the k-th
-    // contiguous eighth of the brick list -- neighbouring bricks, which share the cache lines at their edges and (with
-    // fractional offsets) whole planes, then meet in ONE L2 instead of being fetched once per XCD.
-    const int wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int li = wg * 4 + (threadIdx.x >> 6);
-    if (li >= nitems) return;
-    const Item it = P.items[item0 + li];
     const int rid = it.region_bx & 0xffff, bx = (unsigned)it.region_bx >> 16, by = it.by_bz & 0xffff, bz = (unsigned)it.by_bz >> 16;
     const int rw = reinterpret_cast<const int*>(P.regions + rid)[lane & 15];
     const int z1 = rli(rw, 1), y1 = rli(rw, 3), x1 = rli(rw, 5);
     const int lxb = (rli(rw, 6) >> 8) & 7;
     const LaneMap L(lane, lxb);
     const int z0b = rli(rw, 0) + kRB * bz, y0b = rli(rw, 2) + 32 * by, x0b = rli(rw, 4) + L.BXW * bx;
-    float* strip = &s_strip[threadIdx.x >> 6][lane];
+    float* strip = strip_w + lane;
     // the view's record: lane q < 10 holds float4 q
     RecRegs R;
     R.a = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -879,12 +870,9 @@ __global__ __launch_bounds__(256) void copy_region_kernel(RegionParams P, int it
     }
 }
 
-// One kernel per view-count class (NVC = 1, 2, 4: regions with <= NVC views, unrolled; NVC = 0: any count), so every
-// class gets its own register allocation and a small instruction footprint.  Items of a class are contiguous.
-template <typename TIn, typename TOut, int NVC>
-__global__ __launch_bounds__(256) void fuse_region_kernel(RegionParams P, int item0, int nitems) {
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void copy_region_kernel(RegionParams P, int item0, int nitems) {
     __shared__ float s_strip[4][9 * 64];
-    __shared__ float s_nodes[4][(NVC ? NVC : 1) * kRB * 32 * 3];
     const int lane = threadIdx.x & 63;
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD k takes the k-th
     // contiguous eighth of the brick list -- neighbouring bricks, which share the cache lines at their edges and (with
@@ -892,7 +880,13 @@ __global__ __launch_bounds__(256) void fuse_region_kernel(RegionParams P, int it
     const int wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int li = wg * 4 + (threadIdx.x >> 6);
     if (li >= nitems) return;
-    const Item it = P.items[item0 + li];
+    copy_brick_item<TIn, TOut>(P, P.items[item0 + li], lane, s_strip[threadIdx.x >> 6]);
+}
+
+// One kernel per view-count class (NVC = 1, 2, 4: regions with <= NVC views, unrolled; NVC = 0: any count), so every
+// class gets its own register allocation and a small instruction footprint.  Items of a class are contiguous.
+template <typename TIn, typename TOut, int NVC>
+__device__ __forceinline__ void fuse_brick_item(const RegionParams& P, const Item it, const int lane, float* strip_w, float* nodes_w) {
     const int rid = it.region_bx & 0xffff, bx = (unsigned)it.region_bx >> 16, by = it.by_bz & 0xffff, bz = (unsigned)it.by_bz >> 16;
     // region descriptor: lane l < 16 loads dword l, fields are pulled out with readlane
     const int rw = reinterpret_cast<const int*>(P.regions + rid)[lane & 15];
@@ -900,7 +894,7 @@ __global__ __launch_bounds__(256) void fuse_region_kernel(RegionParams P, int it
     const int nviews = rli(rw, 6) & 0xff, lxb = (rli(rw, 6) >> 8) & 7, masks = rli(rw, 7);
     const LaneMap L(lane, lxb);
     const int z0b = rli(rw, 0) + kRB * bz, y0b = rli(rw, 2) + 32 * by, x0b = rli(rw, 4) + L.BXW * bx;
-    float* strip = &s_strip[threadIdx.x >> 6][lane];
+    float* strip = strip_w + lane;
 
     if (nviews == 0) {   // nothing contributes: zeros (np.nansum of nothing, nan_to_num)
         const int r = L.r, c = L.c, xq = x0b + kRV * c;
@@ -926,7 +920,42 @@ __global__ __launch_bounds__(256) void fuse_region_kernel(RegionParams P, int it
         if ((NVC == 0 || NVC > 6) && nviews > 6 && va < nviews - 6) R.b = reinterpret_cast<const float4*>(P.views + idb)[qa];
     }
     if (NVC == 0) region_brick_generic<TIn, TOut>(P, R, rw, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane, lxb, strip);
-    else region_brick<TIn, TOut, (NVC ? NVC : 1)>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane, lxb, strip, s_nodes[threadIdx.x >> 6]);
+    else region_brick<TIn, TOut, (NVC ? NVC : 1)>(P, R, nviews, masks, z0b, z1, y0b, y1, x0b, x1, lane, lxb, strip, nodes_w);
+}
+
+template <typename TIn, typename TOut, int NVC>
+__global__ __launch_bounds__(256) void fuse_region_kernel(RegionParams P, int item0, int nitems) {
+    __shared__ float s_strip[4][9 * 64];
+    __shared__ float s_nodes[4][(NVC ? NVC : 1) * kRB * 32 * 3];
+    const int lane = threadIdx.x & 63;
+    // XCD-aware order: see copy_region_kernel
+    const int wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int li = wg * 4 + (threadIdx.x >> 6);
+    if (li >= nitems) return;
+    fuse_brick_item<TIn, TOut, NVC>(P, P.items[item0 + li], lane, s_strip[threadIdx.x >> 6], s_nodes[threadIdx.x >> 6]);
+}
+
+// The copy class and the classes with one and two views in ONE launch over a list that is ordered in space across the classes
+// (see mvs_fuse_regions): an overlap brick and the interior brick next to it -- different classes, the same cache lines of the
+// tile rows they share -- run back to back on one XCD instead of in two kernels at two times.  Every wavefront looks up the
+// class of its item's region (bits 12-14 of Region::nviews) and takes that class's code; the three bodies need at most 126
+// VGPRs each, so the launch keeps the occupancy the widest of them had on its own.  Items whose region id is 0xffff pad the
+// eight per-XCD stretches of the list to one length.
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void fuse_region_mixed_kernel(RegionParams P, int item0, int nitems) {
+    __shared__ float s_strip[4][9 * 64];
+    __shared__ float s_nodes[4][2 * kRB * 32 * 3];
+    const int lane = threadIdx.x & 63;
+    const int wg = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int li = wg * 4 + (threadIdx.x >> 6);
+    if (li >= nitems) return;
+    const Item it = P.items[item0 + li];
+    const int rid = it.region_bx & 0xffff;
+    if (rid == 0xffff) return;
+    const int cls = __builtin_amdgcn_readfirstlane((P.regions[rid].nviews >> 12) & 7);
+    if (cls == 4) copy_brick_item<TIn, TOut>(P, it, lane, s_strip[threadIdx.x >> 6]);
+    else if (cls == 0) fuse_brick_item<TIn, TOut, 1>(P, it, lane, s_strip[threadIdx.x >> 6], s_nodes[threadIdx.x >> 6]);
+    else fuse_brick_item<TIn, TOut, 2>(P, it, lane, s_strip[threadIdx.x >> 6], s_nodes[threadIdx.x >> 6]);
 }
 
 }  // namespace
@@ -939,6 +968,8 @@ struct PlanCache {
     int class_count[5] = {0, 0, 0, 0, 0};   // bricks of regions with <=1, 2, <=4, >4 views, and copy-class bricks (contiguous, in this order)
     size_t rbytes = 0;
     bool valid = false;
+    int mixed_count = 0;      // option "fuse_mixed": the padded, space-ordered list of the copy / one-view / two-view bricks (stored first)
+    bool mixed = false;
 };
 PlanCache g_plan[MVS_MAX_DEVICES * MVS_MAX_LANES];
 double g_region_plan_ms[MVS_MAX_DEVICES * MVS_MAX_LANES];
@@ -1027,6 +1058,8 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
     unsigned long long h = fnv1a(htr, sizeof(TrView) * (size_t)n_views, 1469598103934665603ull);
     h = fnv1a(t, sizeof(t), h);
     h = fnv1a(o, sizeof(o), h);
+    const int mixed_mode = c->fuse_mixed ? 1 : 0;
+    h = fnv1a(&mixed_mode, sizeof(mixed_mode), h);
     PlanCache& pc = g_plan[mvs_ctx_index(c->device)];
     g_region_plan_ms[mvs_ctx_index(c->device)] = 0.0;
     const auto t_plan0 = std::chrono::steady_clock::now();
@@ -1046,11 +1079,16 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
         std::vector<Item> items_by_class[5];
         regions.reserve(ncell);
         std::vector<int> zviews, yviews;
+        struct SlabRegion { int rid, nbx, bytes_per_item; };
+        std::vector<SlabRegion> slab;              // the mixed-class regions of the current (z, y) slab, in x order
+        std::vector<Item> mixed_items;
+        std::vector<int> mixed_work;
         for (size_t iz = 0; iz + 1 < pts[0].size(); ++iz) {
             zviews.clear();
             for (int v = 0; v < n_views; ++v)
                 if (htr[v].lo[0] < pts[0][iz + 1] && htr[v].hi[0] >= pts[0][iz] && htr[v].lo[1] <= htr[v].hi[1] && htr[v].lo[2] <= htr[v].hi[2]) zviews.push_back(v);
             for (size_t iy = 0; iy + 1 < pts[1].size(); ++iy) {
+                slab.clear();
                 yviews.clear();
                 for (int v : zviews)
                     if (htr[v].lo[1] < pts[1][iy + 1] && htr[v].hi[1] >= pts[1][iy]) yviews.push_back(v);
@@ -1100,21 +1138,40 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
                     if (nv >= 2 && R.x1 - R.x0 > 32 && R.x1 - R.x0 <= 136) lxb = 3;
                     // (measured, round 4: 256- / 512-voxel bricks for the wide NV >= 2 boxes -- the copy class's layout -- lose:
                     // launch 10.06 -> 10.3 / 11.2 ms; every wavefront then spans a ramp end and takes the per-voxel weights)
-                    R.nviews = nv | (lxb << 8);
+                    const bool copy_class = (nv == 1) && positive_full;   // one full view with positive weight everywhere
+                    const int cls = copy_class ? 4 : nv <= 1 ? 0 : nv == 2 ? 1 : nv <= 4 ? 2 : 3;
+                    R.nviews = nv | (lxb << 8) | (cls << 12);
                     const int rid = (int)regions.size();
-                    if (rid >= 65536) return MVS_OK;
+                    if (rid >= 65535) return MVS_OK;                     // (0xffff marks a padding item)
                     regions.push_back(R);
                     const int bxw = kRV << lxb;
                     const int nbz = (R.z1 - R.z0 + kRB - 1) / kRB, nby = (R.y1 - R.y0 + 31) / 32, nbx = (R.x1 - R.x0 + bxw - 1) / bxw;
                     if (nbz >= 65536 || nby >= 65536 || nbx >= 65536) return MVS_OK;
-                    const bool copy_class = (nv == 1) && positive_full;   // one full view with positive weight everywhere
-                    std::vector<Item>& dst = items_by_class[copy_class ? 4 : nv <= 1 ? 0 : nv == 2 ? 1 : nv <= 4 ? 2 : 3];
+                    if (mixed_mode && (cls == 4 || cls <= 1)) {         // joins the space-ordered list of this slab (below)
+                        slab.push_back(SlabRegion{rid, nbx, std::min(bxw, R.x1 - R.x0) * (std::max(nv, 1) + 1)});
+                        continue;
+                    }
+                    std::vector<Item>& dst = items_by_class[cls];
                     // x fastest, then z, then y: bricks that are neighbours along x share the cache lines at their common
                     // edge, neighbours along z share a whole plane when the offsets are fractional; both reuses then happen
                     // within a few bricks, i.e. inside the L2 of the XCD that owns this stretch of the list
                     for (int by = 0; by < nby; ++by)
                         for (int bz = 0; bz < nbz; ++bz)
                             for (int bx = 0; bx < nbx; ++bx) dst.push_back({rid | (bx << 16), by | (bz << 16)});
+                }
+                if (!slab.empty()) {
+                    // one (z, y) slab of the cell grid: its regions share the z / y extents and the brick grid; y block, then z
+                    // block, then ALL regions along x -- so the bricks of a row of the mosaic are neighbours in the list whatever
+                    // their class
+                    const int z0s = pts[0][iz], z1s = pts[0][iz + 1], y0s = pts[1][iy], y1s = pts[1][iy + 1];
+                    const int nbz = (z1s - z0s + kRB - 1) / kRB, nby = (y1s - y0s + 31) / 32;
+                    for (int by = 0; by < nby; ++by)
+                        for (int bz = 0; bz < nbz; ++bz)
+                            for (const SlabRegion& sr : slab)
+                                for (int bx = 0; bx < sr.nbx; ++bx) {
+                                    mixed_items.push_back({sr.rid | (bx << 16), by | (bz << 16)});
+                                    mixed_work.push_back(sr.bytes_per_item);
+                                }
                 }
             }
         }
@@ -1157,6 +1214,32 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
             fprintf(stderr, "\n");
         }
         std::vector<Item> items;
+        pc.mixed = mixed_mode != 0;
+        pc.mixed_count = 0;
+        if (!mixed_items.empty()) {
+            // eight stretches of equal WORK (bytes moved), one per XCD (see the workgroup -> item mapping of the kernels), padded to
+            // one length with no-op items
+            long long total = 0;
+            for (int w : mixed_work) total += w;
+            size_t cut[9];
+            cut[0] = 0;
+            long long acc = 0;
+            size_t i = 0;
+            for (int k = 1; k <= 8; ++k) {
+                const long long target = total * k / 8;
+                while (i < mixed_items.size() && acc < target) acc += mixed_work[i++];
+                cut[k] = k == 8 ? mixed_items.size() : i;
+            }
+            size_t longest = 0;
+            for (int k = 0; k < 8; ++k) longest = std::max(longest, cut[k + 1] - cut[k]);
+            const size_t L = (longest + 3) / 4 * 4;
+            items.reserve(8 * L);
+            for (int k = 0; k < 8; ++k) {
+                items.insert(items.end(), mixed_items.begin() + (long)cut[k], mixed_items.begin() + (long)cut[k + 1]);
+                items.resize((size_t)(k + 1) * L, Item{0xffff, 0});
+            }
+            pc.mixed_count = (int)items.size();
+        }
         for (int k = 0; k < 5; ++k) {
             pc.class_count[k] = (int)items_by_class[k].size();
             items.insert(items.end(), items_by_class[k].begin(), items_by_class[k].end());
@@ -1201,6 +1284,14 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
     const int side_of_class[5] = {0, -1, 1, 2, 3};          // class -> side stream (-1: main)
     bool side_used[4] = {false, false, false, false};
     int item0 = 0;
+    if (pc.mixed_count) {       // copy + one-view + two-view bricks: one launch over the space-ordered list, on the main stream
+        const int cnt = pc.mixed_count;                     // = 8 L, L a multiple of 4: grid = 2 L workgroups, a multiple of 8
+        const dim3 grid(cnt / 4), block(256);
+        if (dtype == MVS_U8) hipLaunchKernelGGL((fuse_region_mixed_kernel<unsigned char, unsigned char>), grid, block, 0, c->stream, P, 0, cnt);
+        else if (dtype == MVS_U16) hipLaunchKernelGGL((fuse_region_mixed_kernel<unsigned short, unsigned short>), grid, block, 0, c->stream, P, 0, cnt);
+        else hipLaunchKernelGGL((fuse_region_mixed_kernel<float, float>), grid, block, 0, c->stream, P, 0, cnt);
+        item0 = cnt;
+    }
     for (int k = 0; k < 5; ++k) {
         const int cnt = pc.class_count[k];
         hipStream_t kstream = c->stream;

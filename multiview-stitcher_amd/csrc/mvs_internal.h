@@ -44,6 +44,7 @@ struct MvsContext {
     // the class kernels of one fuse launch run on side streams next to the main one (fork / join by events)
     hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool fuse_mixed = false;           // option "fuse_mixed": copy / one-view / two-view bricks in ONE launch over a space-ordered list
     bool serial_classes = false;       // option "serial_classes": launch them one after the other on the main stream instead
     bool reg_unfused = false;          // test switch: the phase correlation runs its separate launches (pack, cross power, peak search, min / max) instead of the fused passes
     bool ssim_prune = true;            // option "ssim_prune" (default 1; environment MVS_SSIM_PRUNE=0 turns it off for new contexts)

@@ -84,6 +84,33 @@ def test_fuse_3d_grid(hip_device, dtype, frac_shift):
     assert_fused_close(got, want, want_f[0], noise_floor=want_f[1])
 
 
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint8, np.float32])
+@pytest.mark.parametrize("frac_shift", [False, True])
+def test_mixed_class_launch_equals_the_class_launches(hip_device, dtype, frac_shift, kernel_path):
+    """Option "fuse_mixed" (profiles/round5_fuse_mixed.txt): the copy / one-view / two-view bricks of the region decomposition in ONE
+    launch over a space-ordered, per-XCD balanced and padded list, the class chosen per wavefront -- the same bricks through the same
+    code as the per-class launches: identical voxels, and the oracle's."""
+    if kernel_path != "fast":
+        pytest.skip("the region kernels are the fast path")
+    from multiview_stitcher_amd import _lib
+
+    sims, params = _grid_case(3, dtype, (2, 3, 3), (24, 72, 136), (6, 18, 34), frac_shift, seed=3)
+    if dtype == np.uint8:
+        sims = [s.copy(data=(np.asarray(s.data) >> 4).astype(np.uint8)) for s in sims]
+    _, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(3))
+    outs = []
+    for flag in (0, 1):
+        _lib.set_option("fuse_mixed", flag)
+        try:
+            got, want, want_f = _run_both(sims, params, out_bb)
+        finally:
+            _lib.set_option("fuse_mixed", 0)
+        outs.append(np.asarray(got))
+        assert_fused_close(got, want, want_f[0], noise_floor=want_f[1])
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("ndim", [2, 3])
 def test_float_tiles_holding_nan_are_poisoned_like_scipy(hip_device, ndim):
     """scipy's linear interpolation reads both taps of every axis even at an integer offset (weights 1 and 0), so a NaN
