@@ -283,6 +283,14 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         c->rows_v1 = value != 0;
         return MVS_OK;
     }
+    if (!strcmp(key, "cb_mask_count")) {
+        c->cb_mask_count = value != 0;
+        return MVS_OK;
+    }
+    if (!strcmp(key, "cb_mask_closed_form")) {
+        c->cb_mask_closed_form = value != 0;
+        return MVS_OK;
+    }
     if (!strcmp(key, "fuse_mixed")) {
         c->fuse_mixed = value != 0;
         return MVS_OK;
@@ -345,6 +353,8 @@ int mvs_get_counter(int device, const char* key, int32_t reset, double* value_ou
     if (!strcmp(key, "reg_candidates")) { *value_out = (double)c->reg_candidates; if (reset) c->reg_candidates = 0; return MVS_OK; }
     if (!strcmp(key, "reg_pruned")) { *value_out = (double)c->reg_pruned; if (reset) c->reg_pruned = 0; return MVS_OK; }
     if (!strcmp(key, "reg_cand_volumes")) { *value_out = c->reg_cand_volumes; if (reset) c->reg_cand_volumes = 0.0; return MVS_OK; }
+    if (!strcmp(key, "cb_mask_views")) { *value_out = (double)c->cb_mask_views; if (reset) c->cb_mask_views = 0; return MVS_OK; }
+    if (!strcmp(key, "cb_mask_boxes")) { *value_out = (double)c->cb_mask_boxes; if (reset) c->cb_mask_boxes = 0; return MVS_OK; }
     if (!strcmp(key, "fuse_plan_ms")) {
         *value_out = mvs_rows_last_plan_ms(c) + mvs_regions_last_plan_ms(c);
         return MVS_OK;

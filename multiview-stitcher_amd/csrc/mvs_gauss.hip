@@ -132,6 +132,109 @@ __device__ __forceinline__ int box_reflect(int p, int b0, int len, int full) {
     return ((unsigned)q < (unsigned)len) ? q : -1;
 }
 
+// ---- the valid mask of a view as a BOX (round 5) ------------------------------------------------------------------------------
+// The mask term of the NaN-aware Gaussian filters M = (view is finite) & !(normalised blending weight < 1e-7).  For an integer tile
+// under a whole-pixel translation that set is a box -- the part of the tile inside the chunk minus the outermost layer, where the
+// blend weight vanishes -- and a separable indicator mz(z) my(y) mx(x) stays separable under the line filters: after the z pass
+// the array is A(z) my(y) mx(x), after the y pass B(z, y) mx(x), with A = float32(filter of mz) and B = float32(filter of A(z) my)
+// -- the very sums the line kernels form (same order, same fused multiply-adds, same float32 roundings), on 1-D and 2-D tables
+// instead of 3-D arrays.  So: (1) cb_mask_bbox_kernel counts the valid voxels of every view's box and takes their bounding box;
+// count == volume of the bounding box <=> the mask IS that box (checked on the device, per view and chunk: nothing is assumed);
+// (2) cb_mask_table_kernel builds A and B for both filters; (3) the mask workgroups of the z / y passes return at once, and the
+// x pass -- which divides value by mask -- stages B(z, y) mx(x) instead of loading a filtered mask.  A view whose mask is not a
+// box (rotated views, float tiles holding NaNs) keeps the filtered path, decided by the same record.  Per view and filter two
+// of the three mask passes disappear: a third of all line-filter work and of its HBM traffic.
+struct CbMaskRec { unsigned long long cnt; int lo[3]; int hi[3]; };      // lo / hi: box-local bounding box of the valid voxels
+static_assert(sizeof(CbMaskRec) == 32, "CbMaskRec layout");
+__device__ __forceinline__ bool cb_mask_is_box(const CbMaskRec& r) {
+    if (r.cnt == 0ull) return false;
+    const unsigned long long vol = (unsigned long long)(r.hi[0] - r.lo[0] + 1) * (unsigned long long)(r.hi[1] - r.lo[1] + 1) *
+                                   (unsigned long long)(r.hi[2] - r.lo[2] + 1);
+    return vol == r.cnt;
+}
+
+// blockIdx.y = view; the workgroups of a view stride over its box
+__global__ __launch_bounds__(256) void cb_mask_bbox_kernel(const float* __restrict__ im, const float* __restrict__ bw, CbBoxes8 BX, CbMaskRec* __restrict__ recs) {
+    const CbBox32 B = BX.b[blockIdx.y];
+    const long long n = (long long)B.n[0] * B.n[1] * B.n[2];
+    unsigned long long cnt = 0;
+    int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {-1, -1, -1};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float x = im[B.off + i], w = bw[B.off + i];
+        if ((x == x) && !(w < 1e-7f)) {
+            const int bx = (int)(i % B.n[2]);
+            const long long t = i / B.n[2];
+            const int by = (int)(t % B.n[1]), bz = (int)(t / B.n[1]);
+            ++cnt;
+            lo[0] = min(lo[0], bz); hi[0] = max(hi[0], bz);
+            lo[1] = min(lo[1], by); hi[1] = max(hi[1], by);
+            lo[2] = min(lo[2], bx); hi[2] = max(hi[2], bx);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        cnt += __shfl_down(cnt, off);
+        for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], __shfl_down(lo[k], off)); hi[k] = max(hi[k], __shfl_down(hi[k], off)); }
+    }
+    __shared__ unsigned long long s_cnt[4];
+    __shared__ int s_lo[4][3], s_hi[4][3];
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_cnt[w] = cnt;
+        for (int k = 0; k < 3; ++k) { s_lo[w][k] = lo[k]; s_hi[w][k] = hi[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {      // one set of atomics per workgroup (a few hundred per view)
+        for (int q = 1; q < 4; ++q) {
+            cnt += s_cnt[q];
+            for (int k = 0; k < 3; ++k) { lo[k] = min(lo[k], s_lo[q][k]); hi[k] = max(hi[k], s_hi[q][k]); }
+        }
+        if (cnt) {
+            CbMaskRec* r = recs + blockIdx.y;
+            atomicAdd(&r->cnt, cnt);
+            for (int k = 0; k < 3; ++k) { atomicMin(&r->lo[k], lo[k]); atomicMax(&r->hi[k], hi[k]); }
+        }
+    }
+}
+
+// tables of one view and filter: B(z, y) (box-local, n[0] x n[1] floats).  grid = (n[0] max over views, views, 2 filters)
+__global__ __launch_bounds__(256) void cb_mask_table_kernel(const CbMaskRec* __restrict__ recs, CbBoxes8 BX, Shape3 S, int ndim, int r1,
+                                                            const double* __restrict__ fw1, int r2, const double* __restrict__ fw2,
+                                                            float* __restrict__ tables, const long long* __restrict__ table_off) {
+    const int v = blockIdx.y, f = blockIdx.z, z = blockIdx.x;
+    const CbBox32 B = BX.b[v];
+    if (z >= B.n[0] || B.n[1] <= 0 || B.n[2] <= 0) return;
+    const CbMaskRec R = recs[v];
+    if (!cb_mask_is_box(R)) return;
+    const int radius = f ? r2 : r1;
+    const double* fw = f ? fw2 : fw1;
+    // A(z): the z pass over the indicator of [lo0, hi0] (3D); the raw indicator itself when there is no z pass (2D: n[0] == 1)
+    float Az;
+    if (ndim == 3) {
+        auto mz = [&](int p) -> double {
+            int q = p;
+            if ((unsigned)q >= (unsigned)B.n[0]) q = box_reflect(p, B.lo[0], B.n[0], S.nz);
+            return (q >= 0 && q >= R.lo[0] && q <= R.hi[0]) ? 1.0 : 0.0;
+        };
+        double acc = mz(z) * fw[radius];
+        for (int j = radius; j >= 1; --j) acc = fma(mz(z - j) + mz(z + j), fw[radius - j], acc);
+        Az = (float)acc;
+    } else {
+        Az = (z >= R.lo[0] && z <= R.hi[0]) ? 1.f : 0.f;
+    }
+    float* out = tables + table_off[v * 2 + f] + (long long)z * B.n[1];
+    const double a = (double)Az;
+    for (int y = threadIdx.x; y < B.n[1]; y += blockDim.x) {
+        auto my = [&](int p) -> double {
+            int q = p;
+            if ((unsigned)q >= (unsigned)B.n[1]) q = box_reflect(p, B.lo[1], B.n[1], S.ny);
+            return (q >= 0 && q >= R.lo[1] && q <= R.hi[1]) ? a : 0.0;
+        };
+        double acc = my(y) * fw[radius];
+        for (int j = radius; j >= 1; --j) acc = fma(my(y - j) + my(y + j), fw[radius - j], acc);
+        out[y] = (float)acc;
+    }
+}
+
 // scipy.ndimage.correlate1d with a symmetric kernel along one axis, mode="reflect": double accumulation in
 // scipy's order (centre tap, then pairs from the farthest to the nearest), float32 output.  The array is a box of the chunk:
 // b0 = its first position along the axis inside the chunk line, full = the chunk line's length.
@@ -280,6 +383,8 @@ struct PairIO {
     const float* im; const float* bw;      // resampled view and normalised blending weight (SRC_PREP / SRC_VMASK / DST_SQ / DST_F)
     float* oa; float* ob;                  // DST_AB: both results; DST_SQ / DST_F: oa = the single result
     int src, dst;
+    const CbMaskRec* rec;                  // the view's mask record (NULL: the mask is always filtered) ...
+    const float* mtab;                     // ... and its table B(z, y) for this filter (cb_mask_table_kernel)
 };
 
 __device__ __forceinline__ float cb_valid_value(const PairIO& P, long long i) {      // A: the view with NaN where bw < 1e-7
@@ -302,6 +407,15 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
     // are worked out once per workgroup (one 64-bit division per LINE instead of two per staged and stored SAMPLE)
     constexpr int NQ = SPLIT ? 1 : 2;
     const int qs = SPLIT ? (int)blockIdx.y : 0;       // SPLIT: the quantity of this workgroup
+    // the view's mask is a box (see cb_mask_bbox_kernel): its z / y passes are tables, the x pass stages B(z, y) mx(x)
+    bool mbox = false;
+    int mx0 = 0, mx1 = -1;
+    if (P.rec) {
+        const CbMaskRec R = *P.rec;
+        mbox = cb_mask_is_box(R);
+        mx0 = R.lo[2]; mx1 = R.hi[2];
+    }
+    if (SPLIT && qs == 1 && mbox) return;             // (uniform: the whole workgroup)
     const int T = L.T, TP = T + 1, len = L.len, lt = 31 - __clz(T);
     const int span = len + 2 * radius;
     float* sq[2] = {sl, sl + (SPLIT ? 0 : (size_t)(span + kGaussK) * TP)};      // (kGaussK spare rows behind each array: see the filter loop)
@@ -321,7 +435,7 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
     const float* Y = !SPLIT ? nullptr : (direct ? X : P.bw);
     auto load_raw = [&](long long i, float& r0, float& r1, float& r2, auto one_array) {
         if constexpr (SPLIT) { r0 = X[i]; r1 = decltype(one_array)::value ? r0 : Y[i]; r2 = 0.f; }
-        else if constexpr (SRC == SRC_AB) { r0 = P.a[i]; r1 = P.b[i]; r2 = 0.f; }
+        else if constexpr (SRC == SRC_AB) { r0 = P.a[i]; r1 = mbox ? 0.f : P.b[i]; r2 = 0.f; }
         else if constexpr (SRC == SRC_PREP) { r0 = P.im[i]; r1 = P.bw[i]; r2 = 0.f; }
         else { r0 = P.im[i]; r1 = P.bw[i]; r2 = P.a[i]; }
     };
@@ -340,6 +454,9 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
         float r0, r1, r2;
         load_raw(lbase[0], r0, r1, r2, std::false_type{});
         interpret(r0, r1, r2, first[0], first[1]);
+        if constexpr (!SPLIT && SRC == SRC_AB) {
+            if (mbox) first[1] = (0 >= mx0 && 0 <= mx1) ? P.mtab[l0] : 0.f;
+        }
     }
     int same0 = 1, same1 = 1;
     // A workgroup is a short dependent chain (stage -> filter -> store) and only a few of them fit a CU, so the staging loop
@@ -365,6 +482,9 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
             bl[u] = line; bp[u] = pos;
             // (clamped address: the load itself is unconditional, what it returns is discarded below when out of range)
             load_raw(lbase[min(line, nl - 1)] + (long long)min(pos, len - 1) * L.stride, q0[u], q1[u], q2[u], one_array);
+            if constexpr (!SPLIT && SRC == SRC_AB) {
+                if (mbox) q1[u] = P.mtab[l0 + min(line, nl - 1)];      // (requested with the batch: the table entry of line l = (z, y))
+            }
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {
@@ -373,6 +493,9 @@ __global__ __launch_bounds__(256) void gauss1d_pair_kernel(PairIO P, GaussLines 
                 float v = 0.f, m = 0.f;
                 if (bl[u] < nl) {
                     interpret(q0[u], q1[u], q2[u], v, m);
+                    if constexpr (!SPLIT && SRC == SRC_AB) {
+                        if (mbox) m = (bp[u] >= mx0 && bp[u] <= mx1) ? q1[u] : 0.f;      // B(z, y) mx(x)
+                    }
                     same0 &= (__float_as_uint(v) == __float_as_uint(first[0])) ? 1 : 0;
                     if (!SPLIT) same1 &= (__float_as_uint(m) == __float_as_uint(first[1])) ? 1 : 0;
                 }
@@ -728,7 +851,18 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
             if (boxes[i].n[axis] > 0 && (!pair_T(boxes[i].n[axis], r1, axis) || !pair_T(boxes[i].n[axis], r2, axis))) paired = false;
     // temporaries of the largest box, shared by the views: 5 arrays on the paired path, 6 on the separate-pass path
     const size_t tmp_total = (paired ? 5 : 6) * tmp_b;
-    const size_t need = 3 * pool_b + tmp_total + 64 * 1024 + (size_t)n_views * (sizeof(CbBox) + sizeof(DevView)) + 2048;
+    // mask records + table offsets (uploaded with the block below) and the mask tables B(z, y) of every view and filter
+    const bool mask_tables = paired && n_views <= 8 && pool < (1ll << 31) && c->cb_mask_closed_form;
+    std::vector<long long> table_off((size_t)n_views * 2, 0);
+    long long table_floats = 0;
+    if (mask_tables)
+        for (int i = 0; i < n_views; ++i)
+            for (int f = 0; f < 2; ++f) {
+                table_off[(size_t)i * 2 + f] = table_floats;
+                table_floats += ((long long)boxes[i].n[0] * boxes[i].n[1] + 63) / 64 * 64;
+            }
+    const size_t need = 3 * pool_b + tmp_total + 64 * 1024 + (size_t)n_views * (sizeof(CbBox) + sizeof(DevView) + sizeof(CbMaskRec) + 16) + 4096 +
+                        (size_t)table_floats * 4;
     char* base = (char*)mvs_scratch(c, 6, need);
     if (!base) return mvs_alloc_failed(c);
     float* I = (float*)base;
@@ -744,22 +878,33 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
     char* dblock = (char*)(((uintptr_t)(base + 3 * pool_b + tmp_total) + 255) / 256 * 256);
     if ((w1.size() + w2.size()) * 8 > 32 * 1024) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "content_based: sigma too large");
     const size_t wb = ((w1.size() + w2.size()) * 8 + 255) / 256 * 256, bb = ((size_t)n_views * sizeof(CbBox) + 255) / 256 * 256,
-                 vb = (size_t)n_views * sizeof(DevView);
+                 vb = ((size_t)n_views * sizeof(DevView) + 255) / 256 * 256, rb = ((size_t)n_views * sizeof(CbMaskRec) + 255) / 256 * 256,
+                 ob = ((size_t)n_views * 16 + 255) / 256 * 256;
     double* dfw1 = (double*)dblock;
     double* dfw2 = dfw1 + w1.size();
     CbBox* dboxes = (CbBox*)(dblock + wb);
     DevView* dviews_dev = (DevView*)(dblock + wb + bb);      // the views' records for the batched box launches
+    CbMaskRec* drecs = (CbMaskRec*)(dblock + wb + bb + vb);
+    long long* dtable_off = (long long*)(dblock + wb + bb + vb + rb);
+    float* dtables = (float*)(dblock + wb + bb + vb + rb + ob);
     // The block travels through the context's pinned staging slot (waited for before it is refilled: mvs_pinned_slot /
     // mvs_pinned_mark), so the call does not have to wait for its own work: with the result on the device it returns as soon as
     // everything is queued, and the host prepares the next chunk while this one is filtered (the probe spent ~0.4 ms per chunk idle)
     {
-        char* hp = (char*)mvs_pinned_slot(c, 0, wb + bb + vb + 64);
+        char* hp = (char*)mvs_pinned_slot(c, 0, wb + bb + vb + rb + ob + 64);
         if (!hp) return mvs_alloc_failed(c);
         memcpy(hp, w1.data(), w1.size() * 8);
         memcpy(hp + w1.size() * 8, w2.data(), w2.size() * 8);
         memcpy(hp + wb, boxes.data(), (size_t)n_views * sizeof(CbBox));
-        memcpy(hp + wb + bb, &dvs[0], vb);
-        MVS_HIP_TRY(c, hipMemcpyAsync(dblock, hp, wb + bb + vb, hipMemcpyHostToDevice, c->stream));
+        memcpy(hp + wb + bb, &dvs[0], (size_t)n_views * sizeof(DevView));
+        for (int i = 0; i < n_views; ++i) {      // empty records: count 0, inverted bounding box
+            CbMaskRec r;
+            r.cnt = 0;
+            for (int k = 0; k < 3; ++k) { r.lo[k] = 0x7fffffff; r.hi[k] = -1; }
+            memcpy(hp + wb + bb + vb + (size_t)i * sizeof(CbMaskRec), &r, sizeof(r));
+        }
+        memcpy(hp + wb + bb + vb + rb, table_off.data(), (size_t)n_views * 16);
+        MVS_HIP_TRY(c, hipMemcpyAsync(dblock, hp, wb + bb + vb + rb + ob, hipMemcpyHostToDevice, c->stream));
         mvs_pinned_mark(c, 0);
     }
 
@@ -788,6 +933,35 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
         }
     if (small) hipLaunchKernelGGL(mask_normalize8_kernel, dim3(gb), dim3(256), 0, c->stream, BW, I, bx8, n_views, S);
     else hipLaunchKernelGGL(mask_normalize_kernel, dim3(gb), dim3(256), 0, c->stream, BW, I, dboxes, n_views, S);
+
+    if (mask_tables) {      // is every view's valid mask a box?  (device-side: record + tables, no host round trip)
+        long long max_bv = 1;
+        int max_nz = 1;
+        for (int i = 0; i < n_views; ++i) {
+            max_bv = std::max(max_bv, (long long)boxes[i].n[0] * boxes[i].n[1] * boxes[i].n[2]);
+            max_nz = std::max(max_nz, boxes[i].n[0]);
+        }
+        hipLaunchKernelGGL(cb_mask_bbox_kernel, dim3((unsigned)std::min<long long>((max_bv + 2047) / 2048, 512), n_views), dim3(256), 0, c->stream,
+                           I, BW, bx8, drecs);
+        hipLaunchKernelGGL(cb_mask_table_kernel, dim3(max_nz, n_views, 2), dim3(256), 0, c->stream, drecs, bx8, S, ndim, r1, dfw1, r2, dfw2,
+                           dtables, dtable_off);
+        if (c->cb_mask_count) {      // test switch: read the records back and count the views whose mask was found to be a box
+            std::vector<CbMaskRec> hrec((size_t)n_views);
+            MVS_HIP_TRY(c, hipMemcpyAsync(hrec.data(), drecs, (size_t)n_views * sizeof(CbMaskRec), hipMemcpyDeviceToHost, c->stream));
+            MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+            for (const CbMaskRec& r : hrec) {
+                const unsigned long long vol = r.cnt ? (unsigned long long)(r.hi[0] - r.lo[0] + 1) * (unsigned long long)(r.hi[1] - r.lo[1] + 1) *
+                                                       (unsigned long long)(r.hi[2] - r.lo[2] + 1) : 0ull;
+                c->cb_mask_views += 1;
+                c->cb_mask_boxes += (r.cnt && vol == r.cnt) ? 1 : 0;
+                if (getenv("MVS_CB_DEBUG")) {
+                    const CbBox& Bd = boxes[(size_t)(&r - hrec.data())];
+                    fprintf(stderr, "[cb mask] view box lo %d %d %d n %d %d %d: valid %llu, bbox %d..%d %d..%d %d..%d (volume %llu)\n", Bd.lo[0], Bd.lo[1], Bd.lo[2],
+                            Bd.n[0], Bd.n[1], Bd.n[2], r.cnt, r.lo[0], r.hi[0], r.lo[1], r.hi[1], r.lo[2], r.hi[2], vol);
+                }
+            }
+        }
+    }
 
     auto gauss = [&](const float* src, float* dst, const CbBox& B, int radius, const double* fw) {
         // scipy filters axis 0, 1, 2 in turn; a 2D chunk has no z axis
@@ -853,6 +1027,8 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
                     P.dst = lastp ? (f ? DST_F : DST_SQ) : DST_AB;
                     P.oa = lastp ? (f ? F + B.off : t[4]) : t[2 * (pass & 1)];
                     P.ob = lastp ? nullptr : t[2 * (pass & 1) + 1];
+                    P.rec = mask_tables ? drecs + v : nullptr;
+                    P.mtab = mask_tables ? dtables + table_off[(size_t)v * 2 + f] : nullptr;
                     GaussLines L;
                     const long long nz = B.n[0], ny = B.n[1], nx = B.n[2];
                     if (axis == 2) { L.len = B.n[2]; L.stride = 1; L.n_lines = nz * ny; L.inner = 1; L.outer_stride = nx; }

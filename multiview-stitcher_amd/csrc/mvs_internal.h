@@ -73,6 +73,9 @@ struct MvsContext {
     void* mbox_dev = nullptr;
     size_t mbox_cap = 0;
     uint64_t mbox_gen = 0;        // bumped whenever the mailbox is reallocated (its old contents are gone)
+    bool cb_mask_closed_form = false;  // option "cb_mask_closed_form" (default 0, see profiles/round5_cb_mask.txt): a view whose valid mask is a box gets its mask filters from tables
+    bool cb_mask_count = false;        // test switch "cb_mask_count": count the views whose mask is a box (counters cb_mask_views / cb_mask_boxes)
+    long long cb_mask_views = 0, cb_mask_boxes = 0;
     bool cb_nosplit = false;      // test switch: the y / z passes of the paired path keep both quantities in one workgroup
     bool cb_unpaired = false;     // test switch: content-based weights through the separate value / mask line passes of rounds 1-3
     bool fft_no_line = false;     // test switch: lengths of the whole-line DFT kernel run on the Bluestein kernels instead

@@ -332,6 +332,62 @@ def test_content_based_paired_passes_equal_separate_passes(hip_device, ndim, dty
         _lib.set_option("cb_nosplit", 0)
 
 
+@pytest.mark.parametrize("case", ["u16_int", "u16_frac", "f32_frac", "2d", "long_z", "nan_blob"])
+def test_content_based_mask_tables_equal_the_filtered_mask(hip_device, case, kernel_path):
+    """Round 5: the valid mask of a view -- (view finite) & !(normalised blending weight < 1e-7) -- is checked on the device to be
+    a BOX (count of valid voxels == volume of their bounding box); its z / y mask passes then come from 1-D / 2-D tables and the x
+    pass stages table(z, y) mx(x) instead of a filtered mask (``cb_mask_bbox_kernel`` / ``cb_mask_table_kernel``, option
+    ``cb_mask_closed_form``; default OFF: at C3's tile size the mask is a box minus a few corner voxels, see profiles/round5_cb_mask.txt).  Same sums in the same order -> the fused chunk equals the fully filtered form BIT FOR
+    BIT: integer and fractional offsets, float tiles, 2D, boxes that start inside the chunk, and a float tile with a NaN blob
+    inside -- whose mask is NOT a box and must keep the filtered path (decided per view by the same record)."""
+    from multiview_stitcher_amd import _lib, fusion, spatial_image_utils as si
+
+    if kernel_path != "fast":
+        pytest.skip("content-based weights have a single implementation")
+    sig, halo, ndim = {"sigma_1": 5.0, "sigma_2": 11.0}, 22, 3
+    if case == "u16_int":
+        sims, params = _grid_case(3, np.uint16, (2, 2, 2), (70, 60, 66), (30, 24, 26), False, seed=31)
+    elif case == "u16_frac":
+        sims, params = _grid_case(3, np.uint16, (2, 2, 2), (70, 60, 66), (30, 24, 26), True, seed=32)
+    elif case == "f32_frac":
+        sims, params = _grid_case(3, np.float32, (1, 2, 2), (64, 72, 80), (0, 30, 34), True, seed=33)
+    elif case == "2d":
+        sims, params = _grid_case(2, np.uint16, (2, 2), (120, 140), (40, 44), True, seed=34)
+        sig, halo, ndim = {"sigma_1": 2.0, "sigma_2": 4.0}, 8, 2
+    elif case == "long_z":
+        sims, params = _grid_case(3, np.uint16, (2, 2, 2), (300, 60, 70), (80, 20, 24), True, seed=35)
+    else:
+        sims, params = _grid_case(3, np.float32, (1, 2, 2), (64, 72, 80), (0, 30, 34), False, seed=36)
+        d = np.array(sims[1].data, dtype=np.float32, copy=True)
+        d[20:30, 25:40, 30:50] = np.nan                       # a hole inside the tile: its mask is not a box
+        sims[1] = sims[1].copy(data=d)
+    sdims = si.get_spatial_dims_from_sim(sims[0])
+    views, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(ndim))
+    kw = dict(weights_func=fusion.content_based, weights_func_kwargs=sig, full_view_bbs=[bb_to_dicts(b, sdims) for b in bbs],
+              trim_overlap_in_pixels=halo)
+    _lib.set_option("cb_mask_count", 1)
+    _lib.set_option("cb_mask_closed_form", 1)
+    for key in ("cb_mask_views", "cb_mask_boxes"):
+        _lib.get_counter(key, reset=True)
+    try:
+        got = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw)
+        n_views, n_boxes = _lib.get_counter("cb_mask_views", reset=True), _lib.get_counter("cb_mask_boxes", reset=True)
+    finally:
+        _lib.set_option("cb_mask_count", 0)
+        _lib.set_option("cb_mask_closed_form", 0)
+    ref = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw)        # the default: every mask through the line filters
+    np.testing.assert_array_equal(got, ref)
+    assert n_views == len(sims)
+    if case == "nan_blob":
+        assert n_boxes == len(sims) - 1             # the tile with the hole keeps the filtered path
+    elif case == "long_z":
+        assert 1 <= n_boxes <= len(sims)            # (views that reach the chunk by a sliver thinner than the zero-weight rim have no valid voxel)
+    else:
+        assert n_boxes == len(sims)                 # every view's mask was found to be a box: the tables were used
+    assert np.isfinite(np.asarray(got, dtype=np.float64)).all() or case == "nan_blob"
+
+
 def test_fuse_content_based_chunked_workflow(hip_device, kernel_path):
     """fusion.fuse(weights_func=content_based): halo = 2*sigma_2 from required_overlap, chunks trimmed (T/test_fusion.py:845-896)."""
     from multiview_stitcher_amd import fusion, sample_data

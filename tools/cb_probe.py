@@ -14,11 +14,16 @@ sims = bench.build_sims(tiles, org, 0)
 _lib.set_option("serial_classes", int(os.environ.get("MVS_SERIAL", "0")))      # 1: the views' filter chains one after the other (per-kernel timings)
 _lib.set_option("cb_unpaired", int(os.environ.get("MVS_CB_UNPAIRED", "0")))
 _lib.set_option("cb_nosplit", int(os.environ.get("MVS_CB_NOSPLIT", "0")))
+_lib.set_option("cb_mask_closed_form", int(os.environ.get("MVS_CB_MASK", "0")))      # 1: masks that are boxes from tables (round 5; off by default)
+if os.environ.get("MVS_CB_COUNT"):
+    _lib.set_option("cb_mask_count", 1)
 torch.cuda.synchronize()   # the tiles are produced on torch's stream, the library runs on its own
-for rep in range(3):
+for rep in range(5):
     t0 = time.perf_counter()
     out = fusion.fuse(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, weights_func=fusion.content_based, output_chunksize={d: 256 for d in "zyx"},
                       output_on_backend=True, device=0)
     _lib.synchronize(0)
     dt = time.perf_counter() - t0
     print("content-based fuse %s: %.1f ms, %.1f Mvoxels/s" % (out.shape, dt * 1e3, np.prod(out.shape) / dt / 1e6), flush=True)
+if os.environ.get("MVS_CB_COUNT"):
+    print("views", _lib.get_counter("cb_mask_views"), "of them with a box mask", _lib.get_counter("cb_mask_boxes"))

@@ -1,0 +1,7 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r5gaps; rm -rf $O; mkdir -p $O
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/t -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pcie > $O/bench.log 2>&1
+python $R/tools/lane_gaps.py $(find $O/t -name "*kernel_trace.csv") > $O/lane_gaps.txt 2>&1
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*.db" -delete
+cat $O/lane_gaps.txt
