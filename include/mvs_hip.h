@@ -327,6 +327,12 @@ typedef struct mvs_pair_job_t {
     mvs_view_t moving;
     int64_t out_shape[3];
     uint64_t wait_ticket[2];
+    int32_t bin[3];          /* bin[0] > 0: `fixed` / `moving` are windows of RAW uint8 / uint16 tiles (shape = a whole number of bins
+                                per axis, identity matrix, offset = the whole-pixel translation in BINNED pixels) and the crops are
+                                taken with this registration binning applied on the fly -- sim.coarsen(bin).mean().astype(dtype)
+                                (registration.py:1732-1741) and the crop in one pass, no binned copy of the tiles; all zero: the
+                                views are used as they are (mvs_register_views) */
+    int32_t reserved;
 } mvs_pair_job_t;
 int mvs_plan_pairs(int32_t ndim, int32_t n_views, const double* const* coords, const int64_t* coord_len, const double* translation,
                    const double* tol, int32_t n_pairs, const int32_t* pairs, int64_t* windows_out, double* out_origin_out,

@@ -64,6 +64,8 @@ class mvs_pair_job_t(C.Structure):
         ("moving", mvs_view_t),
         ("out_shape", C.c_int64 * 3),
         ("wait_ticket", C.c_uint64 * 2),
+        ("bin", C.c_int32 * 3),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -1,5 +1,7 @@
 // mvs_context.hip -- device contexts, error reporting, memory helpers of libmvs_hip.so.
 #include "mvs_internal.h"
+#include <vector>
+#include <algorithm>
 
 #include <algorithm>
 #include <cstring>
@@ -177,7 +179,31 @@ int mvs_init(int device) {
         return mvs_fail(c, MVS_ERR_HIP, "no HIP device %d (count=%d, %s)", mvs_hip_device(device), n,
                         hipGetErrorString(e));
     MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
-    MVS_HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    {
+        // Experiment (profiles/round5_cu_mask.txt): a lane's stream restricted to a share of the compute units, so that the pairs of
+        // different lanes run next to each other instead of time-slicing the whole chip.  MVS_LANE_CU_MASK=xcd<k>: lane l gets the CUs
+        // of k XCDs starting at XCD (l * k) % 8 (CU i sits on XCD i % 8); spread<k>: k / 8 of the CUs, taken evenly from all XCDs.
+        const char* ev = getenv("MVS_LANE_CU_MASK");
+        const int lane = (device >> 8) & 0xff;
+        bool masked = false;
+        if (ev && *ev && lane < 15) {
+            hipDeviceProp_t prop;
+            MVS_HIP_TRY(c, hipGetDeviceProperties(&prop, mvs_hip_device(device)));
+            const int ncu = prop.multiProcessorCount;
+            const bool xcd = !strncmp(ev, "xcd", 3);
+            const int k = std::max(1, std::min(8, atoi(ev + (xcd ? 3 : 6))));
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            for (int i = 0; i < ncu; ++i) {
+                bool on;
+                if (xcd) { const int x = i % 8, first = (lane * k) % 8; on = ((x - first + 8) % 8) < k; }
+                else { const int slot = (i / 8) % 8, first = (lane * k) % 8; on = ((slot - first + 8) % 8) < k; }
+                if (on) mask[(size_t)i / 32] |= 1u << (i % 32);
+            }
+            if (hipExtStreamCreateWithCUMask(&c->own_stream, (uint32_t)mask.size(), mask.data()) == hipSuccess) masked = true;
+            else (void)hipGetLastError();
+        }
+        if (!masked) MVS_HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    }
     MVS_HIP_TRY(c, hipEventCreate(&c->ev_start));
     MVS_HIP_TRY(c, hipEventCreate(&c->ev_stop));
     MVS_HIP_TRY(c, hipEventCreateWithFlags(&c->pinned_ev[0], hipEventDisableTiming));

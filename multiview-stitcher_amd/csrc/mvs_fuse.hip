@@ -1052,6 +1052,93 @@ __global__ __launch_bounds__(256) void crop_int_kernel(const TIn* __restrict__ d
     }
 }
 
+// The same crop taken from the RAW tile with the registration binning applied on the fly (round 5): output voxel (z, y, x) is the
+// binned sample (z + tz, y + ty, x + tx) of the window -- the truncated block mean of its bz x by x bx raw voxels, exactly
+// bin_mean_kernel's arithmetic (integer sum, times 1 / (bz by bx) in double, cast to the tile's type) -- or `cval` outside the
+// window's nz x ny x nx binned samples.  `data` = first raw voxel of the window.  A pair then reads only the slab of each tile its
+// overlap needs (15 GB per north-star mosaic instead of binning all 17 GB of tiles and reading the binned windows back), and no
+// binned copy of a tile exists.  bx == 2: a thread makes 8 outputs of a row from two 16-byte loads per raw row.
+template <typename TIn>
+__global__ __launch_bounds__(1024) void crop_bin_kernel(const TIn* __restrict__ data, long long stride_z, long long stride_y, int nz, int ny,
+                                                       int nx, int bz, int by, int bx, int tz, int ty, int tx, float* __restrict__ out, int oz,
+                                                       int oy, int ox, float cval, char* __restrict__ stats) {
+    typedef float f4_t __attribute__((ext_vector_type(4), aligned(4)));
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4), aligned(4)));
+    const int gpr = (ox + 7) / 8;
+    const long long ngroups = (long long)oz * oy * gpr;
+    const double inv = 1.0 / ((double)bz * by * bx);
+    float smn = INFINITY, smx = -INFINITY;
+    long long snv = 0;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (long long)gridDim.x * blockDim.x) {
+        const int xg = (int)(g % gpr) * 8;
+        const long long row = g / gpr;
+        const int y = (int)(row % oy), z = (int)(row / oy);
+        const int iz = z + tz, iy = y + ty, ix = xg + tx;
+        float* o = out + row * ox + xg;
+        const bool zy = iz >= 0 && iz < nz && iy >= 0 && iy < ny;
+        const TIn* p = data + (long long)iz * bz * stride_z + (long long)iy * by * stride_y + (long long)ix * bx;
+        float v[8];
+        bool in[8];
+        if (sizeof(TIn) == 2 && bx == 2 && zy && xg + 8 <= ox && ix >= 0 && ix + 8 <= nx) {
+            unsigned int acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};       // at most 2 by bz 65535: fits for by bz <= 32767
+            for (int dz = 0; dz < bz; ++dz)
+                for (int dy = 0; dy < by; ++dy) {
+                    const TIn* r = p + (long long)dz * stride_z + (long long)dy * stride_y;
+                    const u32x4_t a = *reinterpret_cast<const u32x4_t*>(r);
+                    const u32x4_t b = *reinterpret_cast<const u32x4_t*>(r + 8);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { acc[k] += (a[k] & 0xffffu) + (a[k] >> 16); acc[4 + k] += (b[k] & 0xffffu) + (b[k] >> 16); }
+                }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { v[k] = (float)(TIn)((double)acc[k] * inv); in[k] = true; }
+        } else {
+            for (int j = 0; j < 8; ++j) {
+                in[j] = zy && xg + j < ox && ix + j >= 0 && ix + j < nx;
+                v[j] = cval;
+                if (!in[j]) continue;
+                double acc = 0.0;
+                for (int dz = 0; dz < bz; ++dz)
+                    for (int dy = 0; dy < by; ++dy) {
+                        const TIn* r = p + (long long)dz * stride_z + (long long)dy * stride_y + (long long)j * bx;
+                        for (int dx = 0; dx < bx; ++dx) acc += (double)r[dx];
+                    }
+                v[j] = (float)(TIn)(acc * inv);
+            }
+        }
+        if (xg + 8 <= ox) {
+            f4_t a, b;
+            a.x = v[0]; a.y = v[1]; a.z = v[2]; a.w = v[3];
+            b.x = v[4]; b.y = v[5]; b.z = v[6]; b.w = v[7];
+            *reinterpret_cast<f4_t*>(o) = a;
+            *reinterpret_cast<f4_t*>(o + 4) = b;
+        } else {
+            for (int j = 0; j < 8 && xg + j < ox; ++j) o[j] = v[j];
+        }
+        if (stats)
+            for (int j = 0; j < 8; ++j)
+                if (in[j] && xg + j < ox) { smn = fminf(smn, v[j]); smx = fmaxf(smx, v[j]); ++snv; }
+    }
+    if (stats) {
+        for (int off = 32; off > 0; off >>= 1) {
+            smn = fminf(smn, __shfl_down(smn, off));
+            smx = fmaxf(smx, __shfl_down(smx, off));
+            snv += __shfl_down(snv, off);
+        }
+        __shared__ float s_mn[16], s_mx[16];      // (up to 1024 threads per workgroup: the statistics' layout fixes the NUMBER of
+        __shared__ long long s_nv[16];            // workgroups, so the kernel gets its memory-level parallelism from their size)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) { s_mn[wave] = smn; s_mx[wave] = smx; s_nv[wave] = snv; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { smn = fminf(smn, s_mn[w]); smx = fmaxf(smx, s_mx[w]); snv += s_nv[w]; }
+            const int nb = gridDim.x;
+            ((float*)stats)[blockIdx.x] = smn;
+            ((float*)stats)[nb + blockIdx.x] = smx;
+            ((long long*)(stats + (size_t)nb * 8))[blockIdx.x] = snv;
+        }
+    }
+}
+
 // true when `V` is a whole-pixel translation of an integer tile (see crop_int_kernel); t = the integer offsets
 static bool is_integer_crop(const DevView& V, int dtype, int t[3]) {
     if (dtype != MVS_U8 && dtype != MVS_U16) return false;
@@ -1536,6 +1623,54 @@ extern "C" int mvs_blend_weights(int device, const mvs_view_t* view, int32_t ndi
     return MVS_OK;
 }
 
+
+// One registration crop straight from a RAW integer tile: `view` describes the raw window (data = its first voxel, shape = its raw
+// extent, a whole number of bins per axis; identity matrix, offset = the whole-pixel translation in BINNED pixels), `bin` the
+// registration binning.  Equals mvs_bin_mean of the window followed by mvs_resample(order 1, NaN outside) bit for bit
+// (crop_bin_kernel).  Device memory on both sides; never waits (the composite caller orders later work).
+int mvs_crop_bin_impl(int device, const mvs_view_t* view, const int32_t bin[3], const int64_t out_shape[3], float* out, const MvsResampleOpts& ro) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    if (!view || !bin || !out_shape || !out) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_crop_bin: NULL argument");
+    if ((view->dtype != MVS_U8 && view->dtype != MVS_U16) || view->mem != MVS_MEM_DEVICE || view->stride[2] != 1)
+        return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_crop_bin: needs a device-resident uint8 / uint16 window with unit x stride");
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    int t[3], nb3[3];
+    for (int k = 0; k < 9; ++k)
+        if (view->matrix[k] != I[k]) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_crop_bin: the view must be a whole-pixel translation");
+    for (int k = 0; k < 3; ++k) {
+        if (bin[k] < 1 || view->shape[k] < bin[k] || view->shape[k] % bin[k] || out_shape[k] < 1 || out_shape[k] > 0x7fffffffLL)
+            return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_crop_bin: bad bin / shape on axis %d", k);
+        if (!(view->offset[k] == std::floor(view->offset[k])) || std::fabs(view->offset[k]) > 1e9)
+            return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_crop_bin: the view must be a whole-pixel translation");
+        t[k] = (int)view->offset[k];
+        nb3[k] = (int)(view->shape[k] / bin[k]);
+    }
+    if ((long long)bin[0] * bin[1] > 16384) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_crop_bin: bin too large");
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
+    const long long ng = (long long)out_shape[0] * out_shape[1] * ((out_shape[2] + 7) / 8);
+    const int nthr = 1024;
+    int nblk = (int)std::min<long long>((ng + nthr - 1) / nthr, 256 * 8);
+    char* stats = nullptr;
+    if (ro.stats && ro.stats->base && ro.stats->nb > 0) {
+        stats = ro.stats->base + (size_t)(ro.stats_k & 1) * (size_t)ro.stats->nb * 16;
+        nblk = ro.stats->nb;
+        ro.stats->done[ro.stats_k & 1] = true;
+    }
+    if (view->dtype == MVS_U8)
+        hipLaunchKernelGGL(crop_bin_kernel<unsigned char>, dim3(nblk), dim3(nthr), 0, c->stream, (const unsigned char*)view->data, (long long)view->stride[0],
+                           (long long)view->stride[1], nb3[0], nb3[1], nb3[2], (int)bin[0], (int)bin[1], (int)bin[2], t[0], t[1], t[2], out,
+                           (int)out_shape[0], (int)out_shape[1], (int)out_shape[2], NAN, stats);
+    else
+        hipLaunchKernelGGL(crop_bin_kernel<unsigned short>, dim3(nblk), dim3(nthr), 0, c->stream, (const unsigned short*)view->data, (long long)view->stride[0],
+                           (long long)view->stride[1], nb3[0], nb3[1], nb3[2], (int)bin[0], (int)bin[1], (int)bin[2], t[0], t[1], t[2], out,
+                           (int)out_shape[0], (int)out_shape[1], (int)out_shape[2], NAN, stats);
+    MVS_HIP_TRY(c, hipGetLastError());
+    if (!ro.defer_sync) MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return MVS_OK;
+}
 
 // ---- helpers shared with mvs_gauss.hip (content-based weights) --------------------------------
 int mvs_fill_dev_view(MvsContext* c, const mvs_view_t& v, int ndim, const void* dev_data, DevView* d) {

@@ -117,6 +117,7 @@ struct MvsResampleOpts {
 int mvs_score_candidates_impl(int device, const float* fixed, const float* moving, int32_t mem, int32_t ndim, const int64_t shape[3],
                               const double* t_candidates, int32_t n_candidates, int32_t region_mode, double data_range, double im1_min,
                               int32_t quality_for_all, double* ssim_out, double* spearman_out, int32_t* code_out, const MvsScoreOpts& so);
+int mvs_crop_bin_impl(int device, const mvs_view_t* view, const int32_t bin[3], const int64_t out_shape[3], float* out, const MvsResampleOpts& ro);
 int mvs_resample_impl(int device, const mvs_view_t* view, const int64_t out_shape[3], int32_t order, float cval, float* out, int32_t out_mem,
                       const MvsResampleOpts& ro);
 

@@ -204,9 +204,22 @@ static int register_crops_impl(int device, const float* fixed, const float* movi
 // One call per image pair: both overlap crops are resampled onto the fixed view's grid (sims_to_intrinsic_coord_system,
 // registration.py:280-350: order 1, NaN outside) into library scratch and registered (mvs_register_crops), without a host
 // round trip in between.  Replaces three calls, two crop allocations and two waits of the Python flow.
+static int register_views_impl(int device, const mvs_view_t* fixed_view, const mvs_view_t* moving_view, int32_t ndim, const int64_t out_shape[3],
+                               int32_t upsample_factor, int32_t region_mode, int32_t constant_check, const int32_t* bin, double t_out[3],
+                               double* quality_out, int32_t* status_out, int32_t* n_candidates_out);
+
 extern "C" int mvs_register_views(int device, const mvs_view_t* fixed_view, const mvs_view_t* moving_view, int32_t ndim,
                                   const int64_t out_shape[3], int32_t upsample_factor, int32_t region_mode, int32_t constant_check,
                                   double t_out[3], double* quality_out, int32_t* status_out, int32_t* n_candidates_out) {
+    return register_views_impl(device, fixed_view, moving_view, ndim, out_shape, upsample_factor, region_mode, constant_check, nullptr, t_out,
+                               quality_out, status_out, n_candidates_out);
+}
+
+// bin != NULL: the views are windows of RAW integer tiles and the crops are taken with the registration binning applied on the fly
+// (mvs_crop_bin_impl: block mean + whole-pixel translation in one pass, no binned copy of the tiles)
+static int register_views_impl(int device, const mvs_view_t* fixed_view, const mvs_view_t* moving_view, int32_t ndim, const int64_t out_shape[3],
+                               int32_t upsample_factor, int32_t region_mode, int32_t constant_check, const int32_t* bin, double t_out[3],
+                               double* quality_out, int32_t* status_out, int32_t* n_candidates_out) {
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
@@ -232,10 +245,10 @@ extern "C" int mvs_register_views(int device, const mvs_view_t* fixed_view, cons
     ro.defer_sync = true;
     ro.stats = &stats;
     ro.stats_k = 0;
-    rc = mvs_resample_impl(device, fixed_view, out_shape, 1, NAN, crop0, MVS_MEM_DEVICE, ro);
+    rc = bin ? mvs_crop_bin_impl(device, fixed_view, bin, out_shape, crop0, ro) : mvs_resample_impl(device, fixed_view, out_shape, 1, NAN, crop0, MVS_MEM_DEVICE, ro);
     if (rc) return rc;
     ro.stats_k = 1;
-    rc = mvs_resample_impl(device, moving_view, out_shape, 1, NAN, crop1, MVS_MEM_DEVICE, ro);
+    rc = bin ? mvs_crop_bin_impl(device, moving_view, bin, out_shape, crop1, ro) : mvs_resample_impl(device, moving_view, out_shape, 1, NAN, crop1, MVS_MEM_DEVICE, ro);
     if (rc) return rc;
     return register_crops_impl(device, crop0, crop1, MVS_MEM_DEVICE, ndim, out_shape, upsample_factor, region_mode, constant_check, t_out,
                                quality_out, status_out, n_candidates_out, &stats);
@@ -373,7 +386,8 @@ void run_pairs_on_lane(PairBatch* b, int lane) {
         int32_t status = 0, ncand = 0;
         double t[3] = {0.0, 0.0, 0.0}, q = NAN;
         if (!rc)
-            rc = mvs_register_views(dev, &j.fixed, &j.moving, b->ndim, j.out_shape, b->upsample, b->region_mode, b->constant_check, t, &q, &status, &ncand);
+            rc = register_views_impl(dev, &j.fixed, &j.moving, b->ndim, j.out_shape, b->upsample, b->region_mode, b->constant_check,
+                                     j.bin[0] > 0 ? j.bin : nullptr, t, &q, &status, &ncand);
         for (int k = 0; k < 3; ++k) b->t_out[(size_t)p * 3 + k] = t[k];
         b->quality_out[p] = q;
         b->status_out[p] = status;

@@ -356,14 +356,15 @@ class _TileGeom:
 
     __slots__ = ("sim", "sdims", "coords", "origin", "spacing", "shape", "t", "affine", "_src")
 
-    def __init__(self, sim, transform_key, like=None):
+    def __init__(self, sim, transform_key, like=None, coords=None):
         self.sim = sim
         dims = sim.dims
         self.sdims = sd = [d for d in ("z", "y", "x") if d in dims]
         # (float64 arrays, not lists: 128 geometries of a 64-tile mosaic were 150 000 float objects to build under the GIL and
         # 2.5 ms to tear down when register() returns; float64 scalars subtract exactly like Python floats)
         co = sim.coords
-        self.coords = cs = [np.ascontiguousarray(co[d], dtype=np.float64) for d in sd]
+        # ``coords``: the geometry of a binned version of ``sim`` whose voxels do not exist (the batched pair path plans on it)
+        self.coords = cs = coords if coords is not None else [np.ascontiguousarray(co[d], dtype=np.float64) for d in sd]
         self.origin = [float(c[0]) for c in cs]
         self.spacing = [float(c[1] - c[0]) if len(c) > 1 else 1.0 for c in cs]
         self.shape = [len(c) for c in cs]
@@ -523,6 +524,7 @@ _native_resolution = [True]     # tests: register() through param_resolution's g
 
 _JOB_DTYPE = np.dtype(_lib.mvs_pair_job_t)
 
+_raw_crops_enabled = [True]  # tests: the batched pair path through binned copies of the tiles instead of binning inside the crop kernel
 _BATCH_LANES = [8]          # context lanes / native worker threads of the batched pair path when the caller does not say (n_parallel_pairwise_regs)
 _batch_enabled = [True]     # tests: compute_pairwise_registrations through the per-pair worker threads instead of mvs_register_pairs
 
@@ -598,24 +600,42 @@ def _register_pairs_batched(sims, edges, transform_key, registration_binning, ov
         tol = [float(overlap_tolerance.get(d, 0.0)) for d in sdims]
     bkey = tuple(sorted(binning.items()))
     do_bin = max(binning.values()) > 1
-    geoms, geoms_b, binned, tickets = {}, {}, {}, {}
+    bins = [int(binning.get(d, 1)) for d in sdims]
+    dev_ok = all((sims[v].data.device & 0xff) == (device & 0xff) and sims[v].data.strides[-1] == 1 for v in used)
+    if not dev_ok:
+        return None
+    # ---- geometry: the views as they are and as the registration binning leaves them (coordinates only: means of groups of b
+    # samples, the sum divided by b as numpy's mean does it -- _bin_sim's coordinates -- without touching a voxel) ----
+    geoms, geoms_b = {}, {}
     for v in used:
-        s_ = sims[v]
-        if do_bin:
-            key = (id(s_.data), bkey)
-            b_ = cache.get_or_compute(key, lambda s_=s_: _bin_sim(s_, binning, device), keep=s_.data)
-            tickets[v] = cache.ticket_of(key) or 0
-        else:
-            b_, tickets[v] = s_, 0
-        binned[v] = b_
-        geoms[v] = _TileGeom(s_, transform_key)
-        geoms_b[v] = geoms[v] if b_ is s_ else _TileGeom(b_, transform_key, like=geoms[v])
-        if geoms[v].t is None or geoms_b[v].t is None or (b_.data.device & 0xff) != (device & 0xff) or b_.data.strides[-1] != 1:
+        geoms[v] = _TileGeom(sims[v], transform_key)
+        if geoms[v].t is None:
             return None
+    if do_bin:
+        same_len = all(geoms[v].shape == geoms[used[0]].shape for v in used)
+        if same_len:
+            stacked = []
+            for k, b in enumerate(bins):
+                m = geoms[used[0]].shape[k] // b
+                st = np.stack([geoms[v].coords[k][: m * b] for v in used])
+                stacked.append(np.ascontiguousarray(np.add.reduce(st.reshape(len(used), m, b), axis=2) / b))
+            for i, v in enumerate(used):
+                geoms_b[v] = _TileGeom(sims[v], transform_key, like=geoms[v], coords=[stacked[k][i] for k in range(n)])
+        else:
+            for v in used:
+                cs = []
+                for k, b in enumerate(bins):
+                    m = geoms[v].shape[k] // b
+                    cs.append(np.ascontiguousarray(np.add.reduce(geoms[v].coords[k][: m * b].reshape(m, b), axis=1) / b))
+                geoms_b[v] = _TileGeom(sims[v], transform_key, like=geoms[v], coords=cs)
+        if any(min(g.shape) < 1 for g in geoms_b.values()):
+            return None
+    else:
+        geoms_b = geoms
     slot = {v: i for i, v in enumerate(used)}
     nv, ne = len(used), len(edges)
     # ---- plans of all pairs (mvs_plan_pairs: the arithmetic of _lean_pair_plan) ----
-    cptr = (C.c_void_p * (nv * n))(*[geoms_b[v].coords[k].ctypes.data for v in used for k in range(n)])
+    cptr = (C.c_void_p * (nv * n))(*[geoms_b[v].coords[k].__array_interface__["data"][0] for v in used for k in range(n)])
     clen = np.array([len(geoms_b[v].coords[k]) for v in used for k in range(n)], dtype=np.int64)
     tr = np.array([geoms_b[v].t for v in used], dtype=np.float64).reshape(nv, n)
     tolv = np.array(tol, dtype=np.float64)
@@ -634,19 +654,43 @@ def _register_pairs_batched(sims, edges, transform_key, registration_binning, ov
         return None
     if np.any(pstat != 0):
         raise ValueError("views do not overlap")
-    # ---- jobs: the two crop windows of every pair as mvs_view_t (strided windows into the binned tiles) ----
+    # ---- where the crops come from.  Binned integer tiles whose crops are whole-pixel translations (every regular mosaic): straight
+    # from the RAW tiles, the binning applied inside the crop kernel (job.bin) -- no binned copy of a tile is ever made, a pair reads
+    # only the slabs its overlap needs.  Otherwise from binned tiles (pre-binned in groups with stream tickets, see _prebin_views). ----
+    raw_crops = (do_bin and _raw_crops_enabled[0] and first.data.dtype in (np.dtype(np.uint8), np.dtype(np.uint16))
+                 and bool(np.all(mdiag[:, :, :n] == 1.0)) and bool(np.all(offs[:, :, :n] == np.floor(offs[:, :, :n]))))
+    tickets = {v: 0 for v in used}
+    prebin_lane = None
+    if raw_crops or not do_bin:
+        source = {v: sims[v].data for v in used}
+    else:
+        if all(cache.ticket_of((id(sims[v].data), bkey)) is None and (id(sims[v].data), bkey) not in cache._items for v in used):
+            # (queues the binning of all views on the last context lane; None: not a regular mosaic, the views are binned one by one below)
+            prebin_lane = _prebin_views([sims[v] for v in used], binning, device, cache)
+        source = {}
+        for v in used:
+            s_ = sims[v]
+            key = (id(s_.data), bkey)
+            b_ = cache.get_or_compute(key, lambda s_=s_: _bin_sim(s_, binning, device), keep=s_.data)
+            tickets[v] = cache.ticket_of(key) or 0
+            if (b_.data.device & 0xff) != (device & 0xff) or b_.data.strides[-1] != 1 or [len(b_.coords[d]) for d in sdims] != geoms_b[v].shape:
+                return None
+            source[v] = b_.data
+    cache.raw_crops = ne if raw_crops else 0
+    # ---- jobs: the two crop windows of every pair as mvs_view_t (strided windows into the tiles) ----
     jobs = (_lib.mvs_pair_job_t * ne)()
     ja = np.frombuffer(jobs, dtype=_JOB_DTYPE)
     k0 = 3 - n
-    base = np.array([binned[v].data.ptr for v in used], dtype=np.uint64)
-    strides = np.array([[int(x) for x in binned[v].data.strides] for v in used], dtype=np.int64).reshape(nv, n)
+    base = np.array([source[v].ptr for v in used], dtype=np.uint64)
+    strides = np.array([[int(x) for x in source[v].strides] for v in used], dtype=np.int64).reshape(nv, n)
     item = first.data.dtype.itemsize
     code = _lib.DTYPE_CODES[first.data.dtype]
     tk = np.array([tickets[v] for v in used], dtype=np.uint64)
+    scale = np.array(bins if raw_crops else [1] * n, dtype=np.int64)      # binned index -> index of the source array
     for i, name in enumerate(("fixed", "moving")):
         f = ja[name]
         vi = pr[:, i]
-        a, b = windows[:, i, :n, 0], windows[:, i, :n, 1]
+        a, b = windows[:, i, :n, 0] * scale, windows[:, i, :n, 1] * scale
         st = strides[vi]
         f["data"] = base[vi] + (np.sum(a * st, axis=1) * item).astype(np.uint64)
         f["dtype"] = code
@@ -666,12 +710,19 @@ def _register_pairs_batched(sims, edges, transform_key, registration_binning, ov
         ja["wait_ticket"][:, i] = tk[vi]
     ja["out_shape"][:, :k0] = 1
     ja["out_shape"][:, k0:] = out_shape[:, :n]
+    if raw_crops:
+        ja["bin"][:, :k0] = 1
+        ja["bin"][:, k0:] = scale
     upsample_factor = (pairwise_reg_func_kwargs or {}).get("upsample_factor")
     uf = (10 if n == 2 else 2) if upsample_factor is None else upsample_factor
     t3, q = np.zeros((ne, 3)), np.zeros(ne)
     status, ncand, rcs = np.zeros(ne, dtype=np.int32), np.zeros(ne, dtype=np.int32), np.zeros(ne, dtype=np.int32)
-    rc = lib.mvs_register_pairs(device & 0xff, ne, jobs, n, int(uf), -1, 1, int(n_lanes), ptr(t3, C.c_double), ptr(q, C.c_double),
-                                ptr(status, C.c_int32), ptr(ncand, C.c_int32), ptr(rcs, C.c_int32))
+    try:
+        rc = lib.mvs_register_pairs(device & 0xff, ne, jobs, n, int(uf), -1, 1, int(n_lanes), ptr(t3, C.c_double), ptr(q, C.c_double),
+                                    ptr(status, C.c_int32), ptr(ncand, C.c_int32), ptr(rcs, C.c_int32))
+    finally:
+        if prebin_lane is not None:
+            _lib.synchronize(prebin_lane)      # (done long ago unless a pair failed: nothing stays queued on the caller's tiles)
     _lib.check(rc, device & 0xff, "mvs_register_pairs")
     # ---- overlap boxes in world coordinates (_lean_overlap on the UNBINNED views) and the physical affines ----
     o = np.array([geoms[v].origin for v in used], dtype=np.float64).reshape(nv, n)
@@ -978,6 +1029,7 @@ class _BinCache:
         self._lock = threading.Lock()
         self._items = {}
         self.hits = self.misses = 0      # (tests: the pre-binned tiles of register() must be found by every pair)
+        self.raw_crops = 0               # pairs whose crops were taken from the raw tiles (no binned copies at all)
 
     def put(self, key, value, keep=None, ticket=None):
         """Store a finished value (``keep``: the objects whose id() is part of ``key``; the slot holds them alive).  ``ticket``:
@@ -1128,10 +1180,11 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
                       if msi_utils.is_msim(m) else [channel_of(m)] for m in msims]
 
     # tiles of a regular mosaic are binned while the graph is built (the GPU would idle otherwise)
+    # (binned copies of the tiles are only made when the batched pair path cannot take its crops from the raw tiles: it then
+    # queues the binning of all views itself, in groups with stream tickets -- see _register_pairs_batched / _prebin_views)
     bin_cache, prebin = None, None
     if pairwise_executor is None and nt == 1 and not multiscale:
         bin_cache = _BinCache()
-        prebin = _prebin_views(sims_reg, registration_binning, device, bin_cache)
 
     # (1) graph
     sps = [si_utils.get_stack_properties_from_sim(s) for s in sims_reg]
@@ -1229,7 +1282,8 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
             else:
                 si_utils.set_sim_affine(m, p, new_transform_key, base_transform_key=transform_key)
     if return_dict:
-        return {"params": params, "bin_cache_stats": None if bin_cache is None else {"hits": bin_cache.hits, "misses": bin_cache.misses},
+        return {"params": params, "bin_cache_stats": None if bin_cache is None else {"hits": bin_cache.hits, "misses": bin_cache.misses,
+                                                                                        "pairs_with_raw_crops": bin_cache.raw_crops},
                 "groupwise_resolution": {"info": resolution_info},
                 "pairwise_registration": {"edges": edges, "results": all_results,
                                           "metrics": {"qualities": {e: r["quality"] for e, r in zip(edges, all_results[0])}}}}

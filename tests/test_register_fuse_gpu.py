@@ -37,8 +37,20 @@ def test_register_3d_with_binning_and_device_tiles(hip_device):
     # every pair found its two tiles pre-binned (register() bins all tiles of a regular mosaic while it builds the graph)
     stats = res["bin_cache_stats"]
     n_pairs = len(res["pairwise_registration"]["edges"])
-    # (the batched pair path looks every view up once, the per-pair path twice per pair)
-    assert stats is not None and stats["misses"] == 0 and stats["hits"] >= len(sims) and n_pairs >= 3
+    # integer tiles on one pixel grid: the batched pair path takes its crops from the RAW tiles (binning inside the crop kernel), no
+    # binned copy of a tile is made
+    assert stats is not None and stats["pairs_with_raw_crops"] == n_pairs >= 3 and stats["misses"] == 0
+    # ... and through binned copies (queued in groups, stream tickets) the pairs find every view pre-binned; same result
+    registration._raw_crops_enabled[0] = False
+    try:
+        res2 = registration.register(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, registration_binning={"z": 1, "y": 2, "x": 2}, return_dict=True)
+    finally:
+        registration._raw_crops_enabled[0] = True
+    stats2 = res2["bin_cache_stats"]
+    assert stats2["pairs_with_raw_crops"] == 0 and stats2["misses"] == 0 and stats2["hits"] >= len(sims)
+    for ra, rb in zip(res["pairwise_registration"]["results"][0], res2["pairwise_registration"]["results"][0]):
+        np.testing.assert_array_equal(ra["transform"], rb["transform"])
+        assert ra["quality"] == rb["quality"]
 
 
 def test_peer_copy_follows_later_writes(hip_device):
@@ -276,6 +288,29 @@ def test_batched_pairs_and_native_host_steps_equal_the_per_pair_path(hip_device,
                                                         seed=9, spacing=(2.0, 0.5, 0.5))
         variants = [dict(registration_binning={"z": 1, "y": 2, "x": 2}), dict(registration_binning={"z": 1, "y": 1, "x": 1}, overlap_tolerance={"z": 0.0, "y": 1.0, "x": 0.5})]
     sims = [device.to_device(s.isel({d: 0 for d in si.get_nonspatial_dims_from_sim(s)}), 0) for s in sims]
+    # crops from the raw tiles (binning inside the crop kernel) == crops from binned copies, incl. bins that do not divide the tile
+    # and windows that start inside a tile
+    for binning in ([{"y": 2, "x": 2}, {"y": 3, "x": 2}] if ndim == 2 else [{"z": 1, "y": 2, "x": 2}, {"z": 3, "y": 2, "x": 2}, {"z": 2, "y": 3, "x": 3}]):
+        got = []
+        for raw in (True, False):
+            registration._raw_crops_enabled[0] = raw
+            try:
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    got.append(registration.register(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, return_dict=True, registration_binning=binning))
+            finally:
+                registration._raw_crops_enabled[0] = True
+        # (the raw tiles serve when every crop is a whole-pixel translation of the BINNED grid, i.e. the bins divide the tile step;
+        # otherwise the crops interpolate and the pairs go through binned copies either way)
+        steps = {"y": 120, "x": 108} if ndim == 2 else {"z": 28, "y": 72, "x": 60}
+        whole = all(steps[d] % b == 0 for d, b in binning.items())
+        n_edges = len(got[0]["pairwise_registration"]["edges"])
+        assert got[0]["bin_cache_stats"]["pairs_with_raw_crops"] == (n_edges if whole else 0) and n_edges > 0
+        assert got[1]["bin_cache_stats"]["pairs_with_raw_crops"] == 0
+        for ra, rb in zip(got[0]["pairwise_registration"]["results"][0], got[1]["pairwise_registration"]["results"][0]):
+            np.testing.assert_array_equal(ra["transform"], rb["transform"])
+            np.testing.assert_array_equal(ra["bbox"], rb["bbox"])
+            assert ra["quality"] == rb["quality"] or (np.isnan(ra["quality"]) and np.isnan(rb["quality"]))
     for kw in variants:
         out = []
         for native in (True, False):

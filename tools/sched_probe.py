@@ -21,6 +21,8 @@ tiles, jitters, origins = bench.make_mosaic_on_device(torch, dev, grid, tile, ov
 sims = bench.build_sims(tiles, origins, 0)
 torch.cuda.synchronize()
 key = si.DEFAULT_TRANSFORM_KEY
+if os.environ.get("MVS_RAW_CROPS") == "0":
+    registration._raw_crops_enabled[0] = False
 if os.environ.get("MVS_NO_BATCH"):
     registration._batch_enabled[0] = False
 import gc
@@ -33,4 +35,4 @@ for rep in range(reps + 3):
         gc.collect(); gc.freeze()
     if rep >= 3:
         walls.append(w * 1e3); cpus.append(cpu * 1e3)
-print(f"lanes {lanes} batch {registration._batch_enabled[0]} schedule {mode} (hipSetDeviceFlags rc {rc}): register ms min {min(walls):.1f} median {np.median(walls):.1f} max {max(walls):.1f}; {np.median(cpus) / np.median(walls):.1f} cores busy")
+print(f"lanes {lanes} batch {registration._batch_enabled[0]} raw_crops {registration._raw_crops_enabled[0]} schedule {mode} (hipSetDeviceFlags rc {rc}): register ms min {min(walls):.1f} median {np.median(walls):.1f} max {max(walls):.1f}; {np.median(cpus) / np.median(walls):.1f} cores busy")
