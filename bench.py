@@ -388,7 +388,7 @@ def fuse_traffic_bytes(grid, tile):
     another one, the figure would be stale and None is returned instead."""
     if not (list(grid) == [4, 4, 4] and list(tile) == [512, 512, 512]):
         return None, "no PMC pass for this workload"
-    for name in ("round4_fuse_traffic.json", "round3_fuse_traffic.json"):
+    for name in ("round5_fuse_traffic.json", "round4_fuse_traffic.json", "round3_fuse_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
