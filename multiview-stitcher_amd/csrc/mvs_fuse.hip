@@ -1091,6 +1091,21 @@ __global__ __launch_bounds__(1024) void crop_bin_kernel(const TIn* __restrict__ 
                 }
 #pragma unroll
             for (int k = 0; k < 8; ++k) { v[k] = (float)(TIn)((double)acc[k] * inv); in[k] = true; }
+        } else if (sizeof(TIn) == 2 && bx == 2) {
+            // a group that hangs over the crop or the window (the narrow crops of x neighbours end in one): one 4-byte load per
+            // output and raw row instead of the generic double-precision loops
+            for (int j = 0; j < 8; ++j) {
+                in[j] = zy && xg + j < ox && ix + j >= 0 && ix + j < nx;
+                v[j] = cval;
+                if (!in[j]) continue;
+                unsigned int acc = 0u;
+                for (int dz = 0; dz < bz; ++dz)
+                    for (int dy = 0; dy < by; ++dy) {
+                        const unsigned int w = *reinterpret_cast<const unsigned int*>(p + (long long)dz * stride_z + (long long)dy * stride_y + (long long)j * 2);
+                        acc += (w & 0xffffu) + (w >> 16);
+                    }
+                v[j] = (float)(TIn)((double)acc * inv);
+            }
         } else {
             for (int j = 0; j < 8; ++j) {
                 in[j] = zy && xg + j < ox && ix + j >= 0 && ix + j < nx;
