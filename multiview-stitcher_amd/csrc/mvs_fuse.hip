@@ -1070,7 +1070,12 @@ __global__ __launch_bounds__(1024) void crop_bin_kernel(const TIn* __restrict__ 
     float smn = INFINITY, smx = -INFINITY;
     long long snv = 0;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (long long)gridDim.x * blockDim.x) {
-        const int xg = (int)(g % gpr) * 8;
+        // the last group of a row whose length is no multiple of 8 is moved back to end with the row (it recomputes `dup` outputs of
+        // its neighbour, same values): every group of a narrow crop (51 samples for x neighbours) then takes the vector path -- no
+        // partial group, no divergence inside the wavefront
+        const int xg0 = (int)(g % gpr) * 8;
+        const int xg = (ox >= 8 && xg0 + 8 > ox) ? ox - 8 : xg0;
+        const int dup = xg0 - xg;
         const long long row = g / gpr;
         const int y = (int)(row % oy), z = (int)(row / oy);
         const int iz = z + tz, iy = y + ty, ix = xg + tx;
@@ -1131,7 +1136,7 @@ __global__ __launch_bounds__(1024) void crop_bin_kernel(const TIn* __restrict__ 
         }
         if (stats)
             for (int j = 0; j < 8; ++j)
-                if (in[j] && xg + j < ox) { smn = fminf(smn, v[j]); smx = fmaxf(smx, v[j]); ++snv; }
+                if (in[j] && xg + j < ox && j >= dup) { smn = fminf(smn, v[j]); smx = fmaxf(smx, v[j]); ++snv; }
     }
     if (stats) {
         for (int off = 32; off > 0; off >>= 1) {
