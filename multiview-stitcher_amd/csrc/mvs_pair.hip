@@ -425,8 +425,14 @@ struct PairPool {
         }
     }
 };
-PairPool* pair_pool() {
-    static PairPool* pool = new PairPool();      // (never destroyed: its threads wait for work until the process ends)
+PairPool* pair_pool(int device) {
+    // one set of workers per GPU: host threads that drive different devices of one process (executors.DevicePairExecutor) do not queue
+    // behind each other (never destroyed: the threads wait for work until the process ends)
+    static PairPool* pools[MVS_MAX_DEVICES] = {};
+    static std::mutex pools_mu;
+    std::lock_guard<std::mutex> lk(pools_mu);
+    PairPool*& pool = pools[mvs_hip_device(device) % MVS_MAX_DEVICES];
+    if (!pool) pool = new PairPool();
     return pool;
 }
 }   // namespace
@@ -450,7 +456,7 @@ extern "C" int mvs_register_pairs(int device, int32_t n_pairs, const mvs_pair_jo
     if (n_lanes == 1) {
         run_pairs_on_lane(&b, 0);
     } else {
-        PairPool* pool = pair_pool();
+        PairPool* pool = pair_pool(device);
         std::lock_guard<std::mutex> call(pool->call_mu);
         {
             std::lock_guard<std::mutex> lk(pool->mu);
