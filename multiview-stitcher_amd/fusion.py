@@ -672,15 +672,21 @@ def _replay_key(images, transform_key, fusion_func, device, *args):
         meta, trs = [], []
         for i, im in enumerate(images):
             data = im.data
-            if msi_utils.is_msim(im) or tuple(im.dims) != dims or not is_device_array(data) or data.dtype != dtype \
-                    or (data.device & 0xff) != (int(device) & 0xff):
+            if msi_utils.is_msim(im) or tuple(im.dims) != dims or np.dtype(data.dtype) != dtype:
+                return None
+            if type(data).__name__ == "RemoteArray":
+                # a tile this rank does not hold (sharding.RemoteArray: shape and dtype only): it takes part in the geometry; a
+                # record is only made -- and replayed -- when none of the contributing views is one of these
+                meta.append(("remote", tuple(data.shape)))
+            elif is_device_array(data) and (data.device & 0xff) == (int(device) & 0xff):
+                meta.append((data.shape, data.strides, data.device))
+            else:
                 return None
             co = im.coords
             for k, d in enumerate(dims):
                 c = co[d]
                 n = len(c)
                 geo[i, k, 0], geo[i, k, 1], geo[i, k, 2] = c[0], (c[1] if n > 1 else c[0]), n
-            meta.append((data.shape, data.strides, data.device))
             trs.append(np.asarray(im.attrs["transforms"][transform_key], dtype=np.float64))
         shape0 = trs[0].shape
         if any(t.shape != shape0 for t in trs):
@@ -1093,7 +1099,7 @@ def _fuse_once(
         if record is not None and record.get("calls") == 1 and "views" in record and not nsdims and n_fields == 1 \
                 and tuple(dev_full.shape) == record["res_shape"]:
             # one launch block wrote the whole result: replayable.  Slab pointers are remembered as offsets into their tiles.
-            base = np.array([images[iv].data.ptr for iv in record["view_index"]], dtype=np.uint64)
+            base = np.array([images[iv].data.ptr for iv in record["view_index"]], dtype=np.uint64)      # (all device-resident: fuse_np recorded)
             if len(_REPLAY_MEMO) >= 8:
                 _REPLAY_MEMO.pop(next(iter(_REPLAY_MEMO)))
             _REPLAY_MEMO[fast_key] = dict(record, byte_offsets=(record["ptrs"] - base).astype(np.uint64), dims=tuple(dims),

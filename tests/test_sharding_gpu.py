@@ -78,6 +78,17 @@ def test_two_rank_shard_equals_single_device(hip_device):
         assert not covered[sl].any()
         covered[sl] = True
     assert covered.all()
+    # the merged launch block of a rank (the bench's form: output on the device) is derived once and replayed afterwards, metadata-only
+    # tiles included in the geometry key: same sub-box, bit for bit
+    for r in range(world):
+        fusion._REPLAY_MEMO.clear()
+        a, _ = sharding.fuse_shard(rank_sims[r], r, world, "reg", output_chunksize={d: 1 << 20 for d in "zyx"}, device=0 | (r << 8), output_on_backend=True)
+        assert len(fusion._REPLAY_MEMO) == 1
+        b, box = sharding.fuse_shard(rank_sims[r], r, world, "reg", output_chunksize={d: 1 << 20 for d in "zyx"}, device=0 | (r << 8), output_on_backend=True)
+        assert len(fusion._REPLAY_MEMO) == 1
+        np.testing.assert_array_equal(np.asarray(a.data), np.asarray(b.data))
+        sl = tuple(slice(box["index_offset"][d], box["index_offset"][d] + box["shape"][d]) for d in "zyx")
+        np.testing.assert_array_equal(np.asarray(b.data), want[(Ellipsis,) + sl].reshape(np.asarray(b.data).shape))
     np.testing.assert_array_equal(got, want)
     # one launch block per sub-box (merge_chunks, the default): the same mosaic voxel for voxel -- the sub-boxes are fused in
     # the index frame of the whole mosaic, chunks and launch blocks only shift integer indices
