@@ -1216,8 +1216,11 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
         # (t-stacked affines of an image without a t axis would otherwise collapse to one time point for good)
         def field_of(s):
             tr = s.attrs.get("transforms", {})
-            if pairwise_executor is None and "t" not in s.dims and all(np.ndim(v) == 2 for v in tr.values()):
-                return s      # nothing to select and the built-in pair path only reads: the image itself (a user executor gets copies)
+            if (pairwise_executor is None or getattr(pairwise_executor, "reads_only", False)) and "t" not in s.dims \
+                    and all(np.ndim(v) == 2 for v in tr.values()):
+                # nothing to select and the built-in pair path (also behind sharding.ShardedPairExecutor, which says so) only reads:
+                # the image itself; any other user executor gets copies
+                return s
             f = s.isel({"t": it}) if "t" in s.dims else s.copy()
             f.attrs["transforms"] = {k: param_utils.select_time(v, it) for k, v in s.attrs.get("transforms", {}).items()}
             return f

@@ -9,8 +9,9 @@ once:
   same tiles);
 * a tile is OWNED by the rank whose sub-box holds its centre: with 8 ranks and the 4 x 4 x 4 grid every rank owns a
   2 x 2 x 2 brick of tiles;
-* a pair is registered by the owner of its fixed (first) view; an output chunk is fused by the rank whose sub-box it
-  lies in;
+* a pair inside a brick is registered by the brick's rank, a pair across two bricks by whichever of the two ranks has fewer
+  pairs (`edge_owners`: 18 pairs per rank on the 4 x 4 x 4 grid over 8 ranks); an output chunk is fused by the rank whose
+  sub-box it lies in;
 * a rank therefore needs its own tiles plus a one-tile HALO: the partners of its pairs and every tile that reaches into
   its sub-box.  In one process (threads, one context per GPU) the halo arrives by peer copies (`DeviceArray.on_device` ->
   mvs_memcpy_peer, xGMI); with one process per GPU it is exchanged once by point-to-point sends (`exchange_halo`,
@@ -93,8 +94,40 @@ def tile_owners(stack_props_list, affines, subboxes, sdims=None):
 
 
 def edge_owners(edges, owners):
-    """A pair is registered where its fixed (first) view lives."""
-    return [owners[i] for i, _ in edges]
+    """The rank that registers each pair.  A pair whose two views live on one rank stays there; a pair ACROSS two ranks goes, in edge
+    order, to whichever of the two has fewer pairs so far (ties: the owner of the fixed view) -- both hold the partner tile in their
+    halo anyway.  Always handing it to the fixed view's owner (rounds 3-4) loaded the ranks 12 ... 24 pairs on the 4 x 4 x 4 grid
+    over 8 ranks (the low corner brick owns the fixed view of every pair across its three inner faces); balanced it is 18 each, and
+    the pairwise phase of a step lasts as long as its busiest rank.  Deterministic: every rank derives the same assignment."""
+    load = {}
+    for i, j in edges:
+        if owners[i] == owners[j]:
+            load[owners[i]] = load.get(owners[i], 0) + 1
+    out = []
+    for i, j in edges:
+        a, b = owners[i], owners[j]
+        if a == b:
+            out.append(a)
+            continue
+        r = b if load.get(b, 0) < load.get(a, 0) else a
+        load[r] = load.get(r, 0) + 1
+        out.append(r)
+    # the greedy pass fills early ranks first: move cross pairs from the fuller to the emptier of their two ranks until no move helps
+    for _ in range(len(edges)):
+        moved = False
+        for k, (i, j) in enumerate(edges):
+            a, b = owners[i], owners[j]
+            if a == b:
+                continue
+            cur, other = out[k], (b if out[k] == a else a)
+            if load[cur] > load.get(other, 0) + 1:
+                load[cur] -= 1
+                load[other] = load.get(other, 0) + 1
+                out[k] = other
+                moved = True
+        if not moved:
+            break
+    return out
 
 
 def rank_tiles(stack_props_list, affines, subboxes, edges, owners, rank, margin=8.0, sdims=None):
@@ -150,9 +183,13 @@ class ShardedPairExecutor:
     registration.py:2634-2655): this rank registers the pairs whose fixed view it owns, then every rank receives all
     results (``gather(obj) -> list over ranks``; default: one fixed-size float64 tensor all-gather, see _gather_results)."""
 
+    reads_only = True      # register() may hand over the images themselves instead of per-time-point copies (with a custom register_fn: set False)
+
     def __init__(self, rank, world_size, owners, device=0, gather=None, register_fn=None, host_threads=None):
         self.rank, self.world_size, self.owners = int(rank), int(world_size), list(owners)
         self.device, self.gather, self.register_fn, self.host_threads = device, gather, register_fn, host_threads
+        if register_fn is not None:
+            self.reads_only = False
         self.last_local_count = 0
 
     def __call__(self, msims, edges, register_kwargs):

@@ -1,0 +1,12 @@
+#!/bin/bash
+# two and four ranks of the north-star bench SHARING the one GPU (gloo control plane): not a scaling measurement -- the per-rank host figures of the line
+cd $GRAFT_REPO_ROOT
+O=gpurun_out/r5ranks; mkdir -p $O
+for n in 2 4; do
+MVS_BENCH_BACKEND=gloo timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 2951$n bench.py --gpus $n --steps 5 --warmup 2 > $O/bench$n.json 2> $O/bench$n.err; echo "rc $?"
+python - <<PY
+import json
+d=json.load(open("gpurun_out/r5ranks/bench$n.json")); c=d["config"]
+print($n, "ranks: ms/step", round(d["ms_per_step"],1), "register", round(c["register_ms_per_step"],1), "pairwise", round(c["pairwise_ms_per_step"],1), "fuse", round(c["fuse_ms_per_step"],1), "kernel", round(c["fuse_kernel_ms"],1), "serial_host_ms_by_rank", [round(v,2) for v in c["serial_host_ms_by_rank"]], "pairs", c["pairs_per_step_by_rank"], "err", c["registration_max_abs_error_px"])
+PY
+done
