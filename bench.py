@@ -543,10 +543,15 @@ def main():
     if world > n_dev and backend == "nccl":
         raise SystemExit(f"{world} ranks but {n_dev} GPUs visible")
     local_rank = local_rank % max(n_dev, 1)
+    json_fd = None
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
+            # gloo's transport prints "[Gloo] Rank ... is connected" lines on fd 1; the contract is ONE JSON line on stdout
+            sys.stdout.flush()
+            json_fd = os.dup(1)
+            os.dup2(2, 1)
             dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -842,14 +847,17 @@ def main():
                                           "note": "the same model with every scored candidate counted whole (20 n each), i.e. the bytes the reference's "
                                                   "formulation of the same result moves, over the same duration: the rate at which this path does the "
                                                   "reference's job, not a measure of the kernels' own traffic"},
-                "note": "duration = wall time of compute_pairwise_registrations (kernels of the context lanes (default 16) overlap; includes host round trips)",
+                "note": "duration = wall time of compute_pairwise_registrations (kernels of the context lanes (8 by default) overlap; includes host round trips)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, grid, tile, overlap)
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result))
+        if json_fd is not None:
+            os.write(json_fd, (json.dumps(result) + "\n").encode())
+        else:
+            print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
 

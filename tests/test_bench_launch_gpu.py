@@ -29,6 +29,7 @@ def _run(cmd, env, timeout=900):
     assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
+    assert [ln for ln in p.stdout.splitlines() if ln.strip()] == lines, p.stdout[-2000:]     # rank 0's stdout is the JSON line alone
     return json.loads(lines[0])
 
 
