@@ -793,7 +793,7 @@ def main():
                             + (f"register (overlap graph, pre_registration_pruning_method={args.pruning!r}, phase-correlation "
                                f"registration of the kept pairs, global_optimization resolution) + " if do_register else "")
                             + "cosine-blend weighted-average fuse; "
-                            + ("ONE mosaic sharded over the ranks (tile bricks + halo, pairs by owner of the fixed view, output sub-boxes)"
+                            + ("ONE mosaic sharded over the ranks (tile bricks + halo, pairs balanced over the owners of their two views, output sub-boxes)"
                                if shard else "one mosaic per GPU"),
                 "mode": "shard" if shard else ("replica" if world > 1 else "single"),
                 "output_shape_rank0": [int(s) for s in out_shape],

@@ -129,6 +129,12 @@ int mvs_synchronize(int device);
  * <= 19 run on the Bluestein kernels instead of the whole-line register transforms (mvs_dft_small.h; equal to float32 rounding).
  * "fft_no_pair" = 1 (environment MVS_FFT_NO_PAIR for new contexts): the first pass of the inverse transform of the phase correlation takes
  * its lines in flat order instead of as partner pairs (kz, ky), (-kz, -ky) (bit for bit the same; the pairs fetch the packed spectrum once).
+ * "fft_slab_axes" = mask (bit k = axis k of (z, y, x); default 4; environment MVS_FFT_SLAB_AXES), "fft_no_slab" = 1 (MVS_FFT_NO_SLAB):
+ * crops with ONE short axis (17-64 samples, a whole-line length) and two axes of 64 / 128 / 256 samples whose short axis is in the mask
+ * run the phase correlation in three passes over HBM instead of six -- two axes per workgroup, the third forward / cross power /
+ * inverse in one kernel (mvs_fft_slab.hip); same peaks and shifts, peak heights to float32 rounding (tests compare).  By default only
+ * crops whose short axis is the contiguous one take it: inside the 8-lane pair loop the others are not faster for having half the traffic
+ * (profiles/round5_fft_slab.txt).
  * "cb_unpaired" = 1: content-based weights filter value and mask lines in separate launches with separate preparation / quotient
  * kernels (rounds 1-3) instead of gauss1d_pair_kernel; "cb_nosplit" = 1: the paired path keeps both quantities in one workgroup
  * on every pass (all three bit for bit equal; tests compare).  "ssim_prune" = 0: mvs_register_crops / mvs_register_views score
@@ -144,7 +150,8 @@ int mvs_set_option(int device, const char* key, int64_t value);
  * voxels; a candidate the arg-max search stopped counts the fraction of its volume it was scored on; "reg_alg_bytes_full": every
  * scored candidate counted whole, the reference's formulation), "reg_pairs",
  * "reg_candidates" (candidates that entered the scoring), "reg_pruned" (of these, left unfinished), "reg_cand_volumes"
- * (candidate volumes the SSIM passes went through), "fuse_plan_ms" = host time the last mvs_fuse_chunk spent decomposing the chunk
+ * (candidate volumes the SSIM passes went through), "reg_slab_pairs" (phase correlations that ran in three passes: crops with one
+ * short and two power-of-two axes; option "fft_no_slab" switches that form off), "fuse_plan_ms" = host time the last mvs_fuse_chunk spent decomposing the chunk
  * (0 when the plan cached for the same geometry was reused).  reset != 0 clears an accumulating counter after reading. */
 int mvs_get_counter(int device, const char* key, int32_t reset, double* value_out);
 /* Device time (ms, hipEvent) spent in the kernels of the most recent compute

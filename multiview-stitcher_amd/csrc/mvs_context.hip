@@ -218,6 +218,10 @@ int mvs_init(int device) {
         if (ev && *ev) c->ssim_prune = atoi(ev) != 0;
         ev = getenv("MVS_FUSE_MIXED");          // A/B switch of the one-launch fuse list (profiles/round5_fuse_mixed.txt)
         if (ev && *ev) c->fuse_mixed = atoi(ev) != 0;
+        ev = getenv("MVS_FFT_SLAB_AXES");       // ... and of the crop orientations that take it (bit k = short axis k of (z, y, x))
+        if (ev && *ev && atoi(ev) >= 0 && atoi(ev) <= 7) c->fft_slab_axes = atoi(ev);
+        ev = getenv("MVS_FFT_NO_SLAB");         // A/B switch of the three-pass phase correlation (mvs_fft_slab.hip)
+        if (ev && *ev) c->fft_no_slab = atoi(ev) != 0;
         ev = getenv("MVS_FFT_NO_PAIR");
         if (ev && *ev) c->fft_no_pair = atoi(ev) != 0;
     }
@@ -225,6 +229,13 @@ int mvs_init(int device) {
     c->last_error.clear();
     return MVS_OK;
 }
+
+#ifdef MVS_PROFILING_ABLATIONS
+extern "C++" bool mvs_dup_kernel(const char* tag) {
+    static const std::string list = [] { const char* e = getenv("MVS_DUP_KERNELS"); return std::string(",") + (e ? e : "") + ","; }();
+    return list.find(std::string(",") + tag + ",") != std::string::npos;
+}
+#endif
 
 void mvs_shutdown(int device) {
     MvsContext* c = mvs_ctx(device);
@@ -353,6 +364,15 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         c->fft_no_pair = value != 0;
         return MVS_OK;
     }
+    if (!strcmp(key, "fft_slab_axes")) {
+        if (value < 0 || value > 7) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_set_option: fft_slab_axes is a mask of 3 bits");
+        c->fft_slab_axes = (int)value;
+        return MVS_OK;
+    }
+    if (!strcmp(key, "fft_no_slab")) {
+        c->fft_no_slab = value != 0;
+        return MVS_OK;
+    }
     if (!strcmp(key, "fft_no_line")) {
         c->fft_no_line = value != 0;
         return MVS_OK;
@@ -379,6 +399,7 @@ int mvs_get_counter(int device, const char* key, int32_t reset, double* value_ou
     if (!strcmp(key, "reg_candidates")) { *value_out = (double)c->reg_candidates; if (reset) c->reg_candidates = 0; return MVS_OK; }
     if (!strcmp(key, "reg_pruned")) { *value_out = (double)c->reg_pruned; if (reset) c->reg_pruned = 0; return MVS_OK; }
     if (!strcmp(key, "reg_cand_volumes")) { *value_out = c->reg_cand_volumes; if (reset) c->reg_cand_volumes = 0.0; return MVS_OK; }
+    if (!strcmp(key, "reg_slab_pairs")) { *value_out = (double)c->reg_slab_pairs; if (reset) c->reg_slab_pairs = 0; return MVS_OK; }
     if (!strcmp(key, "cb_mask_views")) { *value_out = (double)c->cb_mask_views; if (reset) c->cb_mask_views = 0; return MVS_OK; }
     if (!strcmp(key, "cb_mask_boxes")) { *value_out = (double)c->cb_mask_boxes; if (reset) c->cb_mask_boxes = 0; return MVS_OK; }
     if (!strcmp(key, "fuse_plan_ms")) {

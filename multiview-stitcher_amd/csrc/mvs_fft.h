@@ -25,6 +25,12 @@ struct MvsFftFuse {
     bool src_used = false;   // out
 };
 int mvs_fft3_c2c(MvsContext* c, float2* data, const int64_t shape[3], bool inverse, MvsFftFuse* fuse = nullptr);
+// The three-pass form for crops with one short axis (mvs_fft_slab.hip): which axis is the short one (-1: not of that kind), the
+// number of per-workgroup peak entries its last pass writes, and the passes themselves.
+int mvs_phasecorr_slab_axis(const MvsContext* c, const int64_t shape[3]);
+int mvs_phasecorr_slab_peaks(const int64_t shape[3], int short_axis);
+int mvs_phasecorr_slab(MvsContext* c, const float* a, const float* b, float2* Z, float2* CC, float2* P2, float2* dc, const int64_t shape[3],
+                       int short_axis, int sel_a, int sel_b, float* const peak_val[2], long long* const peak_idx[2], float2* z0_out);
 bool mvs_fft_reg_length(int n);      // does a line of n samples run on the kernels that carry the fusions?
 
 // ---- the cross-power arithmetic of the phase correlation, shared by xpower_packed_kernel (mvs_reg.hip) and the fused first pass ----

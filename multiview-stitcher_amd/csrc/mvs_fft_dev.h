@@ -68,6 +68,47 @@ __device__ __forceinline__ void peak_add(Peak2& p, float2 o, long long idx) {
     for (int k = 0; k < 2; ++k)
         if (a[k] > p.v[k] || (a[k] == p.v[k] && idx < p.i[k])) { p.v[k] = a[k]; p.i[k] = idx; }
 }
+// ---- two axes of a 3D transform in one pass: the slab kernels (mvs_fft_slab.inc) ---------------------------------------------------
+// A slab = all samples of two axes at one index of the third: S (short axis: a whole-line DFT length, mvs_dft_small.h) x L (64, 128
+// or 256) complex samples, transformed along both axes by one workgroup.  Two layouts in memory:
+//   rows (short_contig = 0): S rows of L contiguous samples, row_stride elements apart (crops (S, ., L): rows = z at one y; crops
+//                            (., S, L): rows = y at one z);
+//   short_contig = 1:        L rows of S contiguous samples back to back (crops (., L, S) at one z: the slab is one contiguous block).
+struct SlabArgs {
+    float2* data = nullptr;             // in place; forward with re_src / im_src: output only
+    const float* re_src = nullptr;      // forward: the pair a + i b of two real volumes (NaN -> 0), see fft_load
+    const float* im_src = nullptr;
+    int S = 0, L = 0;
+    int short_contig = 0;
+    int inverse = 0;
+    long long slab_stride = 0;          // elements between slabs
+    long long row_stride = 0;           // rows layout: elements between the slab's rows
+    const float2* tw = nullptr;         // exp(-2 pi i m / L), m < L / 2
+    float2* dc = nullptr;               // forward: element (0, 0) of every slab's 2D spectrum (their sum is the DC term of the 3D one)
+    float* peak_val[2] = {nullptr, nullptr};      // inverse: argmax |Re| / |Im| per workgroup instead of a store (Peak2)
+    long long* peak_idx[2] = {nullptr, nullptr};
+};
+bool mvs_launch_slab_lo(MvsContext* c, const SlabArgs& A, unsigned grid, size_t lds_bytes, hipError_t* err);     // 17 <= S <= 44
+bool mvs_launch_slab_hi(MvsContext* c, const SlabArgs& A, unsigned grid, size_t lds_bytes, hipError_t* err);     // 45 <= S <= 64
+
+// the remaining (long) axis of the phase correlation in ONE pass: forward transform of a line and of its partner line, cross
+// power (mvs_xpower_value), inverse transform of both -- long_xp_kernel (mvs_fft_slab.hip)
+struct LongArgs {
+    const float2* Z = nullptr;          // spectrum along the two slab axes (in)
+    float2* CC = nullptr;               // out: packed correlation input, inverse transformed along this axis
+    float2* P2 = nullptr;               // out: plain cross power (for the upsampled refinement)
+    long long stride = 0;               // element stride along the transform axis
+    int PA = 0, PB = 0;                 // the lines' plane: PA rows of PB adjacent lines; line (a, b) starts at a * pa_stride + b
+    long long pa_stride = 0;
+    int sel_a = 0, sel_b = 0;
+    const float2* tw = nullptr;
+    const float2* dc = nullptr;         // per-slab DC terms (SlabArgs::dc), ndc <= 256 of them
+    int ndc = 0;
+    long long ntotal = 0;               // samples of the volume (scale of the phase channel)
+    float2* z0_out = nullptr;           // workgroup 0 writes the DC term of the packed spectrum here (host-visible)
+};
+int mvs_fft_twiddles(MvsContext* c, int n, const float2** tw);
+
 // lengths the whole-line kernel is built for: non-powers of two from 17 to 64 whose prime factors are <= 19 (mvs_dft_small.h)
 constexpr bool mvs_dft_line_length(int n) {
     if (n < 17 || n > 64 || (n & (n - 1)) == 0) return false;

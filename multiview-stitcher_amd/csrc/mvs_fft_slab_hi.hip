@@ -1,0 +1,2 @@
+#include "mvs_fft_slab.inc"
+bool mvs_launch_slab_hi(MvsContext* c, const SlabArgs& A, unsigned grid, size_t lds_bytes, hipError_t* err) { return launch_slab<64, 45>(c, A, grid, lds_bytes, err); }

@@ -1680,13 +1680,13 @@ int mvs_crop_bin_impl(int device, const mvs_view_t* view, const int32_t bin[3], 
         ro.stats->done[ro.stats_k & 1] = true;
     }
     if (view->dtype == MVS_U8)
-        hipLaunchKernelGGL(crop_bin_kernel<unsigned char>, dim3(nblk), dim3(nthr), 0, c->stream, (const unsigned char*)view->data, (long long)view->stride[0],
+        MVS_DUP("crop", hipLaunchKernelGGL(crop_bin_kernel<unsigned char>, dim3(nblk), dim3(nthr), 0, c->stream, (const unsigned char*)view->data, (long long)view->stride[0],
                            (long long)view->stride[1], nb3[0], nb3[1], nb3[2], (int)bin[0], (int)bin[1], (int)bin[2], t[0], t[1], t[2], out,
-                           (int)out_shape[0], (int)out_shape[1], (int)out_shape[2], NAN, stats);
+                           (int)out_shape[0], (int)out_shape[1], (int)out_shape[2], NAN, stats));
     else
-        hipLaunchKernelGGL(crop_bin_kernel<unsigned short>, dim3(nblk), dim3(nthr), 0, c->stream, (const unsigned short*)view->data, (long long)view->stride[0],
+        MVS_DUP("crop", hipLaunchKernelGGL(crop_bin_kernel<unsigned short>, dim3(nblk), dim3(nthr), 0, c->stream, (const unsigned short*)view->data, (long long)view->stride[0],
                            (long long)view->stride[1], nb3[0], nb3[1], nb3[2], (int)bin[0], (int)bin[1], (int)bin[2], t[0], t[1], t[2], out,
-                           (int)out_shape[0], (int)out_shape[1], (int)out_shape[2], NAN, stats);
+                           (int)out_shape[0], (int)out_shape[1], (int)out_shape[2], NAN, stats));
     MVS_HIP_TRY(c, hipGetLastError());
     if (!ro.defer_sync) MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
     return MVS_OK;

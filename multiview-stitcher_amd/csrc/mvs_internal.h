@@ -40,6 +40,7 @@ struct MvsContext {
     double reg_alg_bytes = 0.0;
     double reg_alg_bytes_full = 0.0;   // the same model with every scored candidate counted whole (what the reference's formulation moves)
     long long reg_pairs = 0, reg_candidates = 0, reg_pruned = 0;   // reg_pruned: candidates the pruned arg-max search left unfinished
+    long long reg_slab_pairs = 0;      // phase correlations that took the three-pass form (mvs_fft_slab.hip)
     double reg_cand_volumes = 0.0;     // candidate volumes the SSIM walk actually went through (a pruned candidate counts its fraction)
     // the class kernels of one fuse launch run on side streams next to the main one (fork / join by events)
     hipStream_t aux_stream[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -78,6 +79,9 @@ struct MvsContext {
     long long cb_mask_views = 0, cb_mask_boxes = 0;
     bool cb_nosplit = false;      // test switch: the y / z passes of the paired path keep both quantities in one workgroup
     bool cb_unpaired = false;     // test switch: content-based weights through the separate value / mask line passes of rounds 1-3
+    int fft_slab_axes = 4;        // short axes (bit k = axis k of (z, y, x)) whose crops take the three-pass phase correlation: by default only
+                                  // the contiguous one -- measured inside the 8-lane pair loop (profiles/round5_fft_slab.txt); 7 = all
+    bool fft_no_slab = false;     // test switch: crops of the slab kind (mvs_fft_slab.hip) run the six single-axis passes instead
     bool fft_no_line = false;     // test switch: lengths of the whole-line DFT kernel run on the Bluestein kernels instead
     bool no_regions = false;      // test switch: skip the region kernel (use the column kernel)
     bool rows_v1 = false;         // opt-in: direct-load row kernels (mvs_fuse_rows.hip) for every dtype (default: float tiles only)
@@ -103,6 +107,15 @@ struct MvsScoreOpts {
 // min / max / #valid partials the integer crop kernel leaves while it writes a crop (mvs_register_views -> mvs_resample_impl ->
 // mvs_rescale_pair_device): per-block partials in the layout of nanminmax_pair_kernel, `nb` blocks per image, image k at
 // base + k * nb * 16; done[k] is set by the launch that actually wrote them; gen = the mailbox generation they were parked in
+// Profiling builds only (-DMVS_PROFILING_ABLATIONS): a kernel whose tag is listed in the environment variable MVS_DUP_KERNELS is
+// launched twice (idempotent launches only: the second one rewrites the same results).  The difference in the pair loop's wall time
+// is that kernel's marginal cost among the concurrent context lanes -- which its duration alone in a trace does not tell.
+#ifdef MVS_PROFILING_ABLATIONS
+bool mvs_dup_kernel(const char* tag);
+#define MVS_DUP(tag, ...) do { __VA_ARGS__; if (mvs_dup_kernel(tag)) { __VA_ARGS__; } } while (0)
+#else
+#define MVS_DUP(tag, ...) do { __VA_ARGS__; } while (0)
+#endif
 struct MvsCropStats {
     char* base = nullptr;
     int nb = 0;

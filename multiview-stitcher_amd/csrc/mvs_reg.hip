@@ -495,7 +495,7 @@ int mvs_rescale_pair_device(MvsContext* c, const float* in0, const float* in1, l
         mn[k] = a; mx[k] = b; nvalid[k] = v;
         PP.lo[k] = a; PP.hi[k] = b; PP.degenerate[k] = a == b ? 1 : 0;
     }
-    hipLaunchKernelGGL(rescale_pair_kernel, dim3(nb, 2), dim3(256), 0, c->stream, PP, n);
+    MVS_DUP("rescale", hipLaunchKernelGGL(rescale_pair_kernel, dim3(nb, 2), dim3(256), 0, c->stream, PP, n));
     MVS_HIP_TRY(c, hipGetLastError());
     return MVS_OK;
 }
@@ -612,7 +612,14 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
     int first_axis = -1, last_axis = -1;
     for (int axis = 2; axis >= 0; --axis)
         if (shape[axis] > 1) { if (first_axis < 0) first_axis = axis; last_axis = axis; }
-    if (first_axis >= 0 && mvs_fft_reg_length((int)shape[first_axis]) && !c->reg_unfused) {
+    // crops with one short axis and two power-of-two axes, two normalisations, small refinement: three passes in all
+    // (mvs_fft_slab.hip) -- the forward transform happens there, together with the cross power and the inverse transform
+    const int slab_axis = (ndim == 3 && n_norm == 2 && (normalizations[0] != 0) != (normalizations[1] != 0) && !c->materialize_shifts &&
+                           (int)ceilf((float)upsample_factor * 1.5f) <= 4)
+                              ? mvs_phasecorr_slab_axis(c, shape) : -1;
+    if (slab_axis >= 0) {
+        rc = MVS_OK;
+    } else if (first_axis >= 0 && mvs_fft_reg_length((int)shape[first_axis]) && !c->reg_unfused) {
         MvsFftFuse ff;      // the first pass reads a and b themselves: no packed copy is written and read back
         ff.re_src = da;
         ff.im_src = db;
@@ -635,6 +642,7 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
       int la = -1;
       for (int axis = 2; axis >= 0; --axis) if (shape[axis] > 1) la = axis;
       if (la >= 0 && mvs_fft_reg_length((int)shape[la])) ga = std::max<long long>(ga, (n / shape[la] + 15) / 16);
+      if (slab_axis >= 0) ga = std::max(ga, mvs_phasecorr_slab_peaks(shape, slab_axis));
   }
   const size_t mb_red = (size_t)ga * 32, mb_z0 = mb_red, mb_res = mb_red + 256, mb_res_stride = (res_elems * sizeof(float2) + 255) / 256 * 256;
   void *mb_host = nullptr, *mb_dev = nullptr;
@@ -650,12 +658,26 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
   // ... and when its first pass (along x) runs on them and the refinement is small, the cross power is formed inside that pass
   // (MvsFftFuse::xp_src) and both refinements' first stage read it in one launch (updft_x2_kernel): the combined spectrum and the
   // phase-normalised cross power are never stored.
-  const bool fuse_xp = packed && first_axis == 2 && mvs_fft_reg_length((int)nx) && up_U0 <= 4 && !c->reg_unfused;
+  const bool fuse_xp = slab_axis >= 0 || (packed && first_axis == 2 && mvs_fft_reg_length((int)nx) && up_U0 <= 4 && !c->reg_unfused);
   // ... and in 3D (refinement of 3 samples per axis: upsample factor 2) the first TWO stages of both refinements are one pass
   // over it (updft_yx2_kernel): a lane sums its columns over the rows of a chunk before anything is reduced across lanes
   const bool fuse_yx = fuse_xp && ndim == 3 && up_U0 == 3 && nx <= 256 && ny >= 4;
   const int yx_chunks = fuse_yx ? std::max(1, std::min(kYxChunksMax, ((int)ny + kYxRows - 1) / kYxRows)) : 1;
-  if (packed) {
+  if (packed && slab_axis >= 0) {
+    float* pv[2] = {(float*)red, (float*)(red + (size_t)ga * 16)};
+    long long* pi[2] = {(long long*)(red + (size_t)ga * 8), (long long*)(red + (size_t)ga * 24)};
+    rc = mvs_phasecorr_slab(c, da, db, Z, CC, P2, P1 /* scratch: the slabs' DC terms */, shape, slab_axis, normalizations[0] ? 1 : 0,
+                            normalizations[1] ? 1 : 0, pv, pi, (float2*)((char*)mb_dev + mb_z0));
+    if (rc) return rc;
+    n_red_packed = mvs_phasecorr_slab_peaks(shape, slab_axis);
+    c->reg_slab_pairs += 1;
+    MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const float2 z0 = *(const float2*)((const char*)mb_host + mb_z0);
+    const float dc = std::fabs(z0.x * z0.y);
+    const float s_plain = (dc > 0.f && dc < INFINITY) ? std::ldexp(1.f, -std::ilogb(dc)) : 1.f;
+    const float s_phase = std::ldexp(1.f, -std::ilogb((float)n));
+    for (int ch = 0; ch < 2; ++ch) packed_scale[ch] = normalizations[ch] ? s_phase : s_plain;
+  } else if (packed) {
     if (!fuse_xp)
         hipLaunchKernelGGL(xpower_packed_kernel, dim3(gb), dim3(256), 0, c->stream, Z, P1, P2, CC, nz, ny, nx, normalizations[0] ? 1 : 0,
                            normalizations[1] ? 1 : 0);
@@ -795,8 +817,8 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
                     q.phase[j] = normalizations[j] ? 1 : 0;
                 }
                 const int rows_per_chunk = ((int)ny + yx_chunks - 1) / yx_chunks;
-                hipLaunchKernelGGL(updft_yx2_kernel<3>, dim3((unsigned)(nz * yx_chunks)), dim3(256), 0, c->stream, P2, q, (int)nz, (int)ny, (int)nx,
-                                   rows_per_chunk, yx_chunks);
+                MVS_DUP("updft", hipLaunchKernelGGL(updft_yx2_kernel<3>, dim3((unsigned)(nz * yx_chunks)), dim3(256), 0, c->stream, P2, q, (int)nz, (int)ny, (int)nx,
+                                   rows_per_chunk, yx_chunks));
                 for (int j = 0; j < n_norm; ++j)
                     hipLaunchKernelGGL(updft_mid_kernel, dim3((unsigned)std::min<long long>(((long long)s3 + 3) / 4, 4096)), dim3(256), 0, c->stream,
                                        state[j].o1, state[j].dk + state[j].koff[0], state[j].o3, 1, (int)nz * yx_chunks, U * U, U, yx_chunks);

@@ -609,8 +609,12 @@ __global__ __launch_bounds__(256) void ssim_yx_batch_kernel(YxBatch B, float* __
 // item number modulo 32 -- 0xffffffff: all of them; the pruned argmax search (mvs_score_candidates) scores a candidate in rounds
 struct FusedCand { const float* src; int dz, dy, dx; unsigned int sel; };
 struct FusedBatch { FusedCand c[kMaxResident]; };
+#ifndef MVS_SSIM_WPE_LO
+#define MVS_SSIM_WPE_LO 3
+#define MVS_SSIM_WPE_HI 4
+#endif
 template <int WIN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVS_SSIM_WPE_LO, MVS_SSIM_WPE_HI)))
 void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch B,
                                                                const float* __restrict__ ux, const float* __restrict__ uxx, int zseg,
                                                                float cov_norm, float C1, float C2, float* __restrict__ pmax,
@@ -1308,7 +1312,7 @@ void launch_ssim_shared_x(hipStream_t stream, const float* im0, Shape3 S, Shape3
         // one launch: z walk per (y, x) tile, about one resident round of work items
         const int tiles = ((S.ny - 6 + 15) / 16) * ((S.nx - 6 + 55) / 56), cz = S.nz - 6;
         const int nzs = std::max(1, std::min(768 / std::max(tiles, 1), (cz + 7) / 8));
-        hipLaunchKernelGGL(ssim_fixed_walk_kernel<7>, dim3(kStatBlocks), dim3(256), 0, stream, im0, S, setB[2], setB[3], (cz + nzs - 1) / nzs);
+        MVS_DUP("ssim_fixed", hipLaunchKernelGGL(ssim_fixed_walk_kernel<7>, dim3(kStatBlocks), dim3(256), 0, stream, im0, S, setB[2], setB[3], (cz + nzs - 1) / nzs));
         return;
     }
     hipLaunchKernelGGL((ssim_first_pass_kernel<WIN, false, 1>), dim3(kStatBlocks), dim3(256), 0, stream, im0, im0, S, 0, 0, 0, R, 0, P1, pmax, phasnan,
@@ -1542,9 +1546,9 @@ int mvs_score_candidates_impl(int device, const float* fixed, const float* movin
                 }
                 const size_t lds_bytes = (size_t)((nbx + nby + 1) / 2) * 4;
                 if (!fold) MVS_HIP_TRY(c, hipMemsetAsync(d_hist, 0, sizeof(unsigned int) * (size_t)(nbx + nby), c->stream));
-                hipLaunchKernelGGL(hist_rank_kernel<false>, dim3((unsigned)hgb), dim3(1024), lds_bytes, c->stream, so.raw_u16_keys[0], so.raw_u16_keys[1],
+                MVS_DUP("hist_count", hipLaunchKernelGGL(hist_rank_kernel<false>, dim3((unsigned)hgb), dim3(1024), lds_bytes, c->stream, so.raw_u16_keys[0], so.raw_u16_keys[1],
                                    S, t[0], t[1], t[2], (int)kx0, (int)nbx, (int)ky0, (int)nby, d_hist, d_hist + nbx, (const float*)nullptr,
-                                   (const float*)nullptr, (double*)nullptr, fold ? d_parts : (unsigned int*)nullptr);
+                                   (const float*)nullptr, (double*)nullptr, fold ? d_parts : (unsigned int*)nullptr));
                 if (fold) {
                     const int nwords = (int)((nbx + nby + 1) / 2);
                     hipLaunchKernelGGL(hist_fold_kernel, dim3((nwords + 63) / 64), dim3(1024), 0, c->stream, d_parts, (int)hgb, nwords, (int)nbx, (int)nby,
@@ -1552,8 +1556,8 @@ int mvs_score_candidates_impl(int device, const float* fixed, const float* movin
                 }
                 hipLaunchKernelGGL(rank_table_kernel, dim3(2), dim3(1024), 0, c->stream, d_hist, (int)nbx, d_rank, d_hist + nbx, (int)nby,
                                    d_rank + nbx, partial);
-                hipLaunchKernelGGL(hist_rank_kernel<true>, dim3(gb), dim3(256), 0, c->stream, so.raw_u16_keys[0], so.raw_u16_keys[1], S, t[0], t[1],
-                                   t[2], (int)kx0, (int)nbx, (int)ky0, (int)nby, d_hist, d_hist + nbx, d_rank, d_rank + nbx, partial + 4, (unsigned int*)nullptr);
+                MVS_DUP("hist_corr", hipLaunchKernelGGL(hist_rank_kernel<true>, dim3(gb), dim3(256), 0, c->stream, so.raw_u16_keys[0], so.raw_u16_keys[1], S, t[0], t[1],
+                                   t[2], (int)kx0, (int)nbx, (int)ky0, (int)nby, d_hist, d_hist + nbx, d_rank, d_rank + nbx, partial + 4, (unsigned int*)nullptr));
                 MVS_HIP_TRY(c, hipGetLastError());
                 MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
                 const double* hp = h_partial;
@@ -1700,7 +1704,7 @@ int mvs_score_candidates_impl(int device, const float* fixed, const float* movin
             resident[ic] = j;
         }
         if (n_shift_batch)
-            hipLaunchKernelGGL(shift_batch_kernel, dim3(kStatBlocks, n_shift_batch), dim3(256), 0, c->stream, im1, im0, S, shift_batch, im1_all_finite);
+            MVS_DUP("shift", hipLaunchKernelGGL(shift_batch_kernel, dim3(kStatBlocks, n_shift_batch), dim3(256), 0, c->stream, im1, im0, S, shift_batch, im1_all_finite));
         if (!on_the_fly) {
             hipLaunchKernelGGL(finish_voxstats_kernel, dim3(nb), dim3(256), 0, c->stream, vox_partial, vox_out);
             MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1808,8 +1812,8 @@ int mvs_score_candidates_impl(int device, const float* fixed, const float* movin
                 // ~1536 workgroups (two resident rounds of 3 per CU): 243 instead of 282 us per pair with 768 -- a workgroup spends its
                 // time waiting (two barriers and a load round trip per plane), so a second round hides more than its 6 halo planes cost
                 const int nzs = std::max(1, std::min(1536 / std::max(tiles * nb, 1), (cz + 7) / 8));
-                hipLaunchKernelGGL(ssim_fused_batch_kernel<7>, dim3(kStatBlocks, nb), dim3(256), 0, c->stream, im0, S, fused_batch, setB[2], setB[3],
-                                   (cz + nzs - 1) / nzs, batch_cov_norm, C1, C2, pmax, phasnan, psum, 32);
+                MVS_DUP("ssim_fused", hipLaunchKernelGGL(ssim_fused_batch_kernel<7>, dim3(kStatBlocks, nb), dim3(256), 0, c->stream, im0, S, fused_batch, setB[2], setB[3],
+                                   (cz + nzs - 1) / nzs, batch_cov_norm, C1, C2, pmax, phasnan, psum, 32));
                 c->reg_cand_volumes += (double)n_in;
             } else {
                 const int cy = S.ny - 6, cx = S.nx - 6, nty = (cy + 15) / 16, ntx = (cx + 55) / 56;
@@ -1844,8 +1848,8 @@ int mvs_score_candidates_impl(int device, const float* fixed, const float* movin
                     }
                     if (maxsel == 0) return MVS_OK;
                     const int gx = std::min(kStatBlocks, maxsel);
-                    hipLaunchKernelGGL(ssim_fused_batch_kernel<7>, dim3(gx, nb), dim3(256), 0, c->stream, im0, S, fb, setB[2], setB[3], zseg,
-                                       batch_cov_norm, C1, C2, pmax, phasnan, psum, K);
+                    MVS_DUP("ssim_fused", hipLaunchKernelGGL(ssim_fused_batch_kernel<7>, dim3(gx, nb), dim3(256), 0, c->stream, im0, S, fb, setB[2], setB[3], zseg,
+                                       batch_cov_norm, C1, C2, pmax, phasnan, psum, K));
                     hipLaunchKernelGGL(finish_region_kernel, dim3(nb), dim3(256), 0, c->stream, pmax, phasnan, psum, reg_out, gx);
                     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
                     for (int j = 0; j < nb; ++j) {

@@ -506,12 +506,16 @@ def test_fused_transform_ends_equal_separate_launches(hip_device, shape):
     a, b = _pair(shape, (2, -3, 4), noise=0.01)
     a, b = np.nan_to_num(ro.rescale_intensity_01(a)), np.nan_to_num(ro.rescale_intensity_01(b))
     res = []
-    for flag in (1, 0):
-        _lib.set_option("reg_unfused", flag)
-        try:
-            res.append(_reg_ops.phase_cross_correlation_multi(a, b, upsample_factor=2, normalizations=("phase", None)))
-        finally:
-            _lib.set_option("reg_unfused", 0)
+    _lib.set_option("fft_no_slab", 1)        # (crops of the slab kind take three passes of their own: compared in the test below)
+    try:
+        for flag in (1, 0):
+            _lib.set_option("reg_unfused", flag)
+            try:
+                res.append(_reg_ops.phase_cross_correlation_multi(a, b, upsample_factor=2, normalizations=("phase", None)))
+            finally:
+                _lib.set_option("reg_unfused", 0)
+    finally:
+        _lib.set_option("fft_no_slab", 0)
     for (s0, d0), (s1, d1) in zip(*res):
         np.testing.assert_array_equal(s0, s1)
         np.testing.assert_array_equal(d0["peak_index"], d1["peak_index"])
@@ -678,3 +682,39 @@ def test_partner_line_pairs_of_the_inverse_x_pass_equal_flat_order(hip_device, s
         np.testing.assert_array_equal(s0, s1)
         np.testing.assert_array_equal(d0["peak_index"], d1["peak_index"])
         assert d0["peak_abs"] == d1["peak_abs"]
+
+@pytest.mark.parametrize("shape", [(51, 256, 256), (256, 51, 256), (256, 256, 51), (20, 64, 128), (128, 33, 64), (64, 128, 45),
+                                   (63, 256, 128), (256, 64, 63), (17, 256, 64), (128, 256, 26)])
+def test_three_pass_phase_correlation_equals_the_single_axis_passes(hip_device, shape):
+    """Crops with one short axis (a whole-line DFT length) and two power-of-two axes run the phase correlation in three passes:
+    short + one long axis inside LDS (slab_kernel), the remaining axis forward / cross power / inverse in one kernel over partner line
+    pairs (long_xp_kernel), the inverse slabs reduced to their peaks (mvs_fft_slab.hip; option "fft_no_slab" = the six single-axis
+    passes).  All three orientations of the short axis, slab lengths 64 / 128 / 256, even and odd short lengths: the same peaks and
+    shifts; the peak heights agree to float32 rounding (the transforms add in a different order)."""
+    from multiview_stitcher_amd import _lib, _reg_ops
+
+    sh = tuple(int(np.clip(v, -(n // 4), n // 4)) for v, n in zip((3, -5, 4), shape))
+    a, b = _pair(shape, sh, noise=0.01, seed=5)
+    a, b = np.nan_to_num(ro.rescale_intensity_01(a)), np.nan_to_num(ro.rescale_intensity_01(b))
+    res, taken = [], []
+    _lib.set_option("fft_slab_axes", 7)          # (default: crops whose short axis is the contiguous one)
+    try:
+        for flag in (0, 1):
+            _lib.set_option("fft_no_slab", flag)
+            _lib.get_counter("reg_slab_pairs", reset=True)
+            try:
+                res.append(_reg_ops.phase_cross_correlation_multi(a, b, upsample_factor=2, normalizations=("phase", None)))
+            finally:
+                _lib.set_option("fft_no_slab", 0)
+            taken.append(_lib.get_counter("reg_slab_pairs", reset=True))
+    finally:
+        _lib.set_option("fft_slab_axes", 4)
+    assert taken == [1.0, 0.0]
+    for (s0, d0), (s1, d1) in zip(*res):
+        np.testing.assert_array_equal(s0, s1)
+        np.testing.assert_array_equal(d0["peak_index"], d1["peak_index"])
+        assert abs(d0["peak_abs"] - d1["peak_abs"]) <= 2e-5 * abs(d1["peak_abs"]) + 1e-7
+    # and the expected translation is found at all (guards against both paths failing alike)
+    got, want = np.asarray(res[0][0][0], dtype=float), np.array(sh, dtype=float)
+    assert min(np.abs(got - want).max(), np.abs(got + want).max()) <= 0.5
+

@@ -29,7 +29,7 @@ print("pairs per orientation:", dict(cnt), "(crop shapes: x = 256 x 256 x 51, y 
 print(f"{'kernel':44s} {'x us/pair':>10s} {'y us/pair':>10s} {'z us/pair':>10s}")
 tot = collections.defaultdict(float)
 for name, d in sorted(acc.items(), key=lambda kv: -sum(kv[1].values())):
-    if not any(k in name for k in ("ssim", "fft", "dft", "hist", "rank", "updft", "crop", "shift", "rescale", "finish", "peek", "small_copy", "fold")):
+    if not any(k in name for k in ("ssim", "fft", "dft", "slab", "long_xp", "hist", "rank", "updft", "crop", "shift", "rescale", "finish", "peek", "small_copy", "fold")):
         continue
     vals = [d.get(o, 0.0) / max(cnt[o], 1) for o in "xyz"]
     for o, v in zip("xyz", vals):
