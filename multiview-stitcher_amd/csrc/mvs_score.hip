@@ -607,6 +607,10 @@ __global__ __launch_bounds__(256) void ssim_yx_batch_kernel(YxBatch B, float* __
 // A candidate is its shifted copy (dz = dy = dx = 0) or, for an integer shift, the moving crop itself read in place.
 // sel: the work items (tile x z segment, numbered x fastest) this launch walks for the candidate, as a set of residues of the
 // item number modulo 32 -- 0xffffffff: all of them; the pruned argmax search (mvs_score_candidates) scores a candidate in rounds
+// Residue r of group g (items g K .. g K + K - 1) is item g K + (r + kSelRot g) mod K: without the rotation a residue class of a crop with
+// 16 tiles per z segment (x neighbours: 256 x 256 x 51) is ONE tile row -- class 0 the row along the crop's border -- and the first
+// 1 / 32 of a candidate says little about the rest of it (a wrong leader is completed, the others are walked further than needed).
+constexpr int kSelRot = 7;
 struct FusedCand { const float* src; int dz, dy, dx; unsigned int sel; };
 struct FusedBatch { FusedCand c[kMaxResident]; };
 #ifndef MVS_SSIM_WPE_LO
@@ -646,7 +650,8 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
         for (int si = blockIdx.x; si < nsel; si += gridDim.x) {
             unsigned int rest = C.sel;
             for (int k = si % nselres; k > 0; --k) rest &= rest - 1;  // (uniform: scalar work)
-            const int item = (si / nselres) * selk + (__ffs(rest) - 1);
+            const int grp = si / nselres;
+            const int item = grp * selk + (__ffs(rest) - 1 + kSelRot * grp) % selk;      // (residue rotated per group: see kSelRot)
             if (item >= nitems) continue;
             const int tx = item % ntx, ty = (item / ntx) % nty, zs = item / (ntx * nty);
             const int z0 = pad + zs * zseg, z1 = min(z0 + zseg, S.nz - pad);
@@ -1829,7 +1834,8 @@ int mvs_score_candidates_impl(int device, const float* fixed, const float* movin
                 for (int item = 0; item < nitems; ++item) {
                     const int tx = item % ntx, ty = (item / ntx) % nty, zs = item / (ntx * nty);
                     const int z0 = 3 + zs * zseg, z1 = std::min(z0 + zseg, S.nz - 3);
-                    vol_res[item % K] += (double)(z1 - z0) * (double)std::min(16, cy - ty * 16) * (double)std::min(56, cx - tx * 56);
+                    const int res = (((item % K) - kSelRot * (item / K)) % K + K) % K;      // the residue class whose member this item is (kSelRot)
+                    vol_res[res] += (double)(z1 - z0) * (double)std::min(16, cy - ty * 16) * (double)std::min(56, cx - tx * 56);
                 }
                 const double Ntot = (double)cz * (double)cy * (double)cx;
                 auto vol_of = [&](unsigned int m) { double v = 0.0; for (int r = 0; r < 32; ++r) if ((m >> r) & 1u) v += vol_res[r]; return v; };
