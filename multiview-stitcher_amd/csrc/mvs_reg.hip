@@ -820,8 +820,8 @@ extern "C" int mvs_phasecorr_multi(int device, const float* fixed, const float* 
                 MVS_DUP("updft", hipLaunchKernelGGL(updft_yx2_kernel<3>, dim3((unsigned)(nz * yx_chunks)), dim3(256), 0, c->stream, P2, q, (int)nz, (int)ny, (int)nx,
                                    rows_per_chunk, yx_chunks));
                 for (int j = 0; j < n_norm; ++j)
-                    hipLaunchKernelGGL(updft_mid_kernel, dim3((unsigned)std::min<long long>(((long long)s3 + 3) / 4, 4096)), dim3(256), 0, c->stream,
-                                       state[j].o1, state[j].dk + state[j].koff[0], state[j].o3, 1, (int)nz * yx_chunks, U * U, U, yx_chunks);
+                    MVS_DUP("updft_mid", hipLaunchKernelGGL(updft_mid_kernel, dim3((unsigned)std::min<long long>(((long long)s3 + 3) / 4, 4096)), dim3(256), 0, c->stream,
+                                       state[j].o1, state[j].dk + state[j].koff[0], state[j].o3, 1, (int)nz * yx_chunks, U * U, U, yx_chunks));
             }
             MVS_HIP_TRY(c, hipGetLastError());
             continue;

@@ -1556,11 +1556,11 @@ int mvs_score_candidates_impl(int device, const float* fixed, const float* movin
                                    (const float*)nullptr, (double*)nullptr, fold ? d_parts : (unsigned int*)nullptr));
                 if (fold) {
                     const int nwords = (int)((nbx + nby + 1) / 2);
-                    hipLaunchKernelGGL(hist_fold_kernel, dim3((nwords + 63) / 64), dim3(1024), 0, c->stream, d_parts, (int)hgb, nwords, (int)nbx, (int)nby,
-                                       d_hist, d_hist + nbx);
+                    MVS_DUP("hist_fold", hipLaunchKernelGGL(hist_fold_kernel, dim3((nwords + 63) / 64), dim3(1024), 0, c->stream, d_parts, (int)hgb, nwords, (int)nbx, (int)nby,
+                                       d_hist, d_hist + nbx));
                 }
-                hipLaunchKernelGGL(rank_table_kernel, dim3(2), dim3(1024), 0, c->stream, d_hist, (int)nbx, d_rank, d_hist + nbx, (int)nby,
-                                   d_rank + nbx, partial);
+                MVS_DUP("rank_table", hipLaunchKernelGGL(rank_table_kernel, dim3(2), dim3(1024), 0, c->stream, d_hist, (int)nbx, d_rank, d_hist + nbx, (int)nby,
+                                   d_rank + nbx, partial));
                 MVS_DUP("hist_corr", hipLaunchKernelGGL(hist_rank_kernel<true>, dim3(gb), dim3(256), 0, c->stream, so.raw_u16_keys[0], so.raw_u16_keys[1], S, t[0], t[1],
                                    t[2], (int)kx0, (int)nbx, (int)ky0, (int)nby, d_hist, d_hist + nbx, d_rank, d_rank + nbx, partial + 4, (unsigned int*)nullptr));
                 MVS_HIP_TRY(c, hipGetLastError());
@@ -1856,7 +1856,7 @@ int mvs_score_candidates_impl(int device, const float* fixed, const float* movin
                     const int gx = std::min(kStatBlocks, maxsel);
                     MVS_DUP("ssim_fused", hipLaunchKernelGGL(ssim_fused_batch_kernel<7>, dim3(gx, nb), dim3(256), 0, c->stream, im0, S, fb, setB[2], setB[3], zseg,
                                        batch_cov_norm, C1, C2, pmax, phasnan, psum, K));
-                    hipLaunchKernelGGL(finish_region_kernel, dim3(nb), dim3(256), 0, c->stream, pmax, phasnan, psum, reg_out, gx);
+                    MVS_DUP("finish", hipLaunchKernelGGL(finish_region_kernel, dim3(nb), dim3(256), 0, c->stream, pmax, phasnan, psum, reg_out, gx));
                     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
                     for (int j = 0; j < nb; ++j) {
                         if (!masks[j]) continue;

@@ -3,7 +3,7 @@ idle share inside the window of the registration kernels (between the first and 
 import csv, re, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 ev = []
-reg = re.compile(r"ssim|fft_lines|radix|shift_kernel|updft|rankcorr|argmax|xpower|nanminmax|rescale|resample|compact|fillBuffer|copyBuffer|pack_pair|image_stats|finish|ranks_sorted|bin_mean")
+reg = re.compile(r"ssim|fft|dft_line|slab_kernel|long_xp|hist_|rank|updft|crop_|shift_|rescale|finish_region|peek|small_copy|fold|radix|argmax|xpower|compact|image_stats|bin_mean|pack_pair")
 iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows if reg.search(r["Kernel_Name"]))
 if not iv:
     sys.exit("no registration kernels")
