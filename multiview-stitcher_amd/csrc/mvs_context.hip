@@ -258,6 +258,8 @@ void mvs_shutdown(int device) {
     if (c->mbox_host) hipHostFree(c->mbox_host);
     c->mbox_host = c->mbox_dev = nullptr;
     c->mbox_cap = 0;
+    if (c->cb_flag_host) hipHostFree(c->cb_flag_host);
+    c->cb_flag_host = c->cb_flag_dev = nullptr;
     if (c->pinned) hipHostFree(c->pinned);
     if (c->pinned2) hipHostFree(c->pinned2);
     c->pinned = c->pinned2 = nullptr;
@@ -352,6 +354,14 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         c->materialize_shifts = value != 0;
         return MVS_OK;
     }
+    if (!strcmp(key, "cb_exact")) {
+        c->cb_exact = value != 0;
+        return MVS_OK;
+    }
+    if (!strcmp(key, "cb_taps_f64")) {
+        c->cb_taps_f64 = value != 0;
+        return MVS_OK;
+    }
     if (!strcmp(key, "cb_nosplit")) {
         c->cb_nosplit = value != 0;
         return MVS_OK;
@@ -402,6 +412,21 @@ int mvs_get_counter(int device, const char* key, int32_t reset, double* value_ou
     if (!strcmp(key, "reg_slab_pairs")) { *value_out = (double)c->reg_slab_pairs; if (reset) c->reg_slab_pairs = 0; return MVS_OK; }
     if (!strcmp(key, "cb_mask_views")) { *value_out = (double)c->cb_mask_views; if (reset) c->cb_mask_views = 0; return MVS_OK; }
     if (!strcmp(key, "cb_mask_boxes")) { *value_out = (double)c->cb_mask_boxes; if (reset) c->cb_mask_boxes = 0; return MVS_OK; }
+    if (!strcmp(key, "cb_line_launches")) { *value_out = (double)c->cb_line_launches; if (reset) c->cb_line_launches = 0; return MVS_OK; }
+    if (!strcmp(key, "cb_overflow")) {
+        // chunks of the fast content-based path whose mask list overflowed: the ones a host-result call redid by itself are counted,
+        // a raised flag means device-result chunks that still hold a wrong result (the caller redoes them with option cb_exact)
+        double pending = 0.0;
+        if (c->cb_flag_host) {
+            MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
+            MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+            pending = *c->cb_flag_host ? 1.0 : 0.0;
+            if (reset) *c->cb_flag_host = 0;
+        }
+        *value_out = pending;
+        return MVS_OK;
+    }
+    if (!strcmp(key, "cb_overflows_redone")) { *value_out = (double)c->cb_overflows; if (reset) c->cb_overflows = 0; return MVS_OK; }
     if (!strcmp(key, "fuse_plan_ms")) {
         *value_out = mvs_rows_last_plan_ms(c) + mvs_regions_last_plan_ms(c);
         return MVS_OK;

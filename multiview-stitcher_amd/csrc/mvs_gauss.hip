@@ -79,7 +79,9 @@ __device__ __forceinline__ int box_index32(const CbBox32& B, int z, int y, int x
     if ((unsigned)bz >= (unsigned)B.n[0] || (unsigned)by >= (unsigned)B.n[1] || (unsigned)bx >= (unsigned)B.n[2]) return -1;
     return B.off + (bz * B.n[1] + by) * B.n[2] + bx;
 }
-__global__ __launch_bounds__(256) void mask_normalize8_kernel(float* __restrict__ bw, const float* __restrict__ im, CbBoxes8 BX, int nviews, Shape3 S) {
+// nan_masked (fast path, mvs_gauss_fast.inc): the view itself becomes NaN where its normalised weight is < 1e-7 (weights.py:54-55), so
+// that "valid" is "finite" for every later pass; the final sum skips such a view there either way (its F is NaN).
+__global__ __launch_bounds__(256) void mask_normalize8_kernel(float* __restrict__ bw, float* __restrict__ im, CbBoxes8 BX, int nviews, Shape3 S, int nan_masked) {
     const long long n = (long long)S.nz * S.ny * S.nx;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const int x = (int)(i % S.nx);
@@ -102,7 +104,11 @@ __global__ __launch_bounds__(256) void mask_normalize8_kernel(float* __restrict_
         if (wsum == 0.f) wsum = 1.f;
 #pragma unroll
         for (int v = 0; v < 8; ++v)
-            if (kk[v] >= 0) bw[kk[v]] = w[v] / wsum;
+            if (kk[v] >= 0) {
+                const float wn = w[v] / wsum;
+                bw[kk[v]] = wn;
+                if (nan_masked && wn < 1e-7f) im[kk[v]] = NAN;
+            }
     }
 }
 
@@ -766,10 +772,19 @@ void gaussian_kernel(double sigma, int* radius_out, std::vector<double>* w) {
     *radius_out = radius;
 }
 
+#include "mvs_gauss_fast.inc"
+
 }  // namespace
+
+static int cb_fast_chunk(MvsContext* c, const mvs_view_t* views, int32_t n_views, const mvs_fuse_opts_t* opts, void* out, bool* taken);
 
 int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_views, const mvs_fuse_opts_t* opts, void* out) {
     if (opts->order != 0 && opts->order != 1) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "content_based: order 0|1 only");
+    if (!c->cb_exact) {      // the default: mask from a box + list, one quantity per pass, float32 taps (mvs_gauss_fast.inc)
+        bool taken = false;
+        const int rc = cb_fast_chunk(c, views, n_views, opts, out, &taken);
+        if (rc || taken) return rc;
+    }
     const int dtype = views[0].dtype;
     const size_t es = mvs_dtype_size(dtype);
     const int64_t* cs = opts->out_shape;
@@ -931,7 +946,7 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
             for (int k = 0; k < 3; ++k) { bx8.b[i].lo[k] = boxes[i].lo[k]; bx8.b[i].n[k] = boxes[i].n[k]; }
             bx8.b[i].off = (int)boxes[i].off;
         }
-    if (small) hipLaunchKernelGGL(mask_normalize8_kernel, dim3(gb), dim3(256), 0, c->stream, BW, I, bx8, n_views, S);
+    if (small) hipLaunchKernelGGL(mask_normalize8_kernel, dim3(gb), dim3(256), 0, c->stream, BW, I, bx8, n_views, S, 0);
     else hipLaunchKernelGGL(mask_normalize_kernel, dim3(gb), dim3(256), 0, c->stream, BW, I, dboxes, n_views, S);
 
     if (mask_tables) {      // is every view's valid mask a box?  (device-side: record + tables, no host round trip)
@@ -1108,6 +1123,256 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
     if (opts->out_mem == MVS_MEM_HOST) {
         MVS_HIP_TRY(c, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
         MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+    } else if (host_bytes) {
+        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));      // host slabs were staged through scratch that the next call may overwrite
+    }
+    return MVS_OK;
+}
+
+// ---- the fast path of one chunk (kernels: mvs_gauss_fast.inc).  *taken = false: this chunk is not its kind (more than 8 views, a
+// rotated / scaled view, a chunk axis shorter than a filter radius, a line that does not fit LDS, or -- host results only, where the
+// call waits anyway -- a mask list that overflowed) and the caller runs the bit-faithful passes. ----
+static int cb_fast_chunk(MvsContext* c, const mvs_view_t* views, int32_t n_views, const mvs_fuse_opts_t* opts, void* out, bool* taken) {
+    *taken = false;
+    if (n_views > 8 || n_views < 1) return MVS_OK;
+    const int dtype = views[0].dtype;
+    const size_t es = mvs_dtype_size(dtype);
+    const int64_t* cs = opts->out_shape;
+    const Shape3 S = {(int)cs[0], (int)cs[1], (int)cs[2]};
+    const long long n = (long long)S.nz * S.ny * S.nx;
+    const int ndim = opts->ndim;
+    int64_t os[3];
+    for (int k = 0; k < 3; ++k) os[k] = cs[k] - 2 * opts->trim[k];
+    const Shape3 O = {(int)os[0], (int)os[1], (int)os[2]};
+    const long long no = (long long)O.nz * O.ny * O.nx;
+    int r1, r2;
+    std::vector<double> w1, w2;
+    gaussian_kernel((double)opts->sigma_1, &r1, &w1);
+    gaussian_kernel((double)opts->sigma_2, &r2, &w2);
+    for (int axis = 3 - ndim; axis < 3; ++axis)
+        if (cs[axis] < std::max(r1, r2)) return MVS_OK;      // (further images of a voxel under the reflection would be in reach)
+    static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int i = 0; i < n_views; ++i)
+        for (int k = 0; k < 9; ++k)
+            if (views[i].matrix[k] != I9[k]) return MVS_OK;
+    if ((w1.size() + w2.size()) * 8 > 32 * 1024) return MVS_OK;
+
+    // ---- device views and their boxes inside the chunk ----
+    std::vector<DevView> dvs((size_t)n_views);
+    size_t host_bytes = 0;
+    for (int i = 0; i < n_views; ++i)
+        if (views[i].mem == MVS_MEM_HOST) {
+            if (views[i].stride[1] != views[i].shape[2] || views[i].stride[0] != views[i].shape[1] * views[i].shape[2])
+                return mvs_fail(c, MVS_ERR_UNSUPPORTED, "host slabs must be C-contiguous");
+            host_bytes += ((size_t)views[i].shape[0] * views[i].shape[1] * views[i].shape[2] * es + 255) / 256 * 256;
+        }
+    CbFastViews VS;
+    memset(&VS, 0, sizeof(VS));
+    VS.nv = n_views;
+    long long pool = 0, total_rows = 0, tab_doubles = 0;
+    {
+        for (int i = 0; i < n_views; ++i) {
+            // (slab pointers of host views are filled in below, once the scratch exists; the geometry does not depend on them)
+            int rc = mvs_fill_dev_view(c, views[i], ndim, views[i].data, &dvs[i]);
+            if (rc) return rc;
+            mvs_view_to_chunk_frame(&dvs[i], opts->index_origin, views[i].index_offset);
+            int lo[3], hi[3];
+            mvs_view_chunk_box(dvs[i], cs, lo, hi);
+            CbFastView& B = VS.v[i];
+            long long bv = 1;
+            for (int k = 0; k < 3; ++k) {
+                B.lo[k] = lo[k];
+                B.n[k] = std::max(hi[k] - lo[k] + 1, 0);
+                bv *= B.n[k];
+            }
+            if (bv == 0) { B.n[0] = B.n[1] = B.n[2] = 0; }
+            if (pool + bv >= (1ll << 31)) return MVS_OK;
+            B.off = (int)pool;
+            pool += (bv + 63) / 64 * 64;
+            B.row0 = (int)total_rows;
+            total_rows += (long long)B.n[0] * B.n[1];
+            B.tab0 = (int)tab_doubles;
+            tab_doubles += 2ll * (B.n[0] + B.n[1] + B.n[2]);
+        }
+    }
+    // lines per workgroup of every (axis, filter, view): 0 = a line does not fit -> not this path
+    int Tsel[3][2][8];
+    int xt_lo = 8, xt_hi = 32, dbg = 0;
+    if (const char* e = getenv("MVS_CBF_XT")) { xt_lo = xt_hi = atoi(e); }
+    if (const char* e = getenv("MVS_CBF_DBG")) dbg = atoi(e);
+    for (int axis = 3 - ndim; axis < 3; ++axis)
+        for (int f = 0; f < 2; ++f)
+            for (int i = 0; i < n_views; ++i) {
+                const int len = VS.v[i].n[axis];
+                Tsel[axis][f][i] = len > 0 ? cb_fast_T(len, f ? r2 : r1, axis == 2 ? xt_lo : 32, axis == 2 ? xt_hi : 64, axis == 2) : 8;
+                if (!Tsel[axis][f][i]) return MVS_OK;
+            }
+    char* slab_base = nullptr;
+    if (host_bytes) {
+        slab_base = (char*)mvs_scratch(c, 0, host_bytes);
+        if (!slab_base) return mvs_alloc_failed(c);
+    }
+    if (!c->cb_flag_host) {
+        MVS_HIP_TRY(c, hipHostMalloc((void**)&c->cb_flag_host, 64, hipHostMallocMapped));
+        MVS_HIP_TRY(c, hipHostGetDevicePointer((void**)&c->cb_flag_dev, c->cb_flag_host, 0));
+        *c->cb_flag_host = 0;
+    }
+    MVS_HIP_TRY(c, hipEventRecord(c->ev_start, c->stream));
+    {
+        size_t cursor = 0;
+        for (int i = 0; i < n_views; ++i)
+            if (views[i].mem == MVS_MEM_HOST) {
+                const size_t nb = (size_t)views[i].shape[0] * views[i].shape[1] * views[i].shape[2] * es;
+                MVS_HIP_TRY(c, hipMemcpyAsync(slab_base + cursor, views[i].data, nb, hipMemcpyHostToDevice, c->stream));
+                dvs[i].data = slab_base + cursor;
+                cursor += (nb + 255) / 256 * 256;
+            }
+    }
+
+    // ---- scratch (slot 6): pools I, BW, F, T0; row records; [uploaded block: weights f64 / f32, view records, mask records]; lists; tables ----
+    const size_t pool_b = ((size_t)pool * 4 + 255) / 256 * 256;
+    const size_t rows_b = ((size_t)total_rows * 16 + 255) / 256 * 256;
+    const size_t nw = w1.size() + w2.size();
+    const size_t wdb = (nw * 8 + 255) / 256 * 256, wfb = (nw * 4 + 255) / 256 * 256, vb = ((size_t)n_views * sizeof(DevView) + 255) / 256 * 256,
+                 rb = ((size_t)n_views * sizeof(CbFastRec) + 255) / 256 * 256;
+    const size_t up_b = wdb + wfb + vb + rb;
+    const size_t miss_b = (size_t)n_views * kCbMissCap * 16, tab_b = ((size_t)tab_doubles * 8 + 255) / 256 * 256;
+    long long max_rows = 1;
+    for (int i = 0; i < n_views; ++i) max_rows = std::max(max_rows, (long long)VS.v[i].n[0] * VS.v[i].n[1]);
+    const unsigned rows_grid = (unsigned)std::min<long long>((max_rows + 15) / 16, 1024);      // a workgroup: 4 wavefronts x 4 rows per sweep
+    const size_t part_b = ((size_t)n_views * rows_grid * sizeof(CbPartial) + 255) / 256 * 256;
+    const size_t need = 4 * pool_b + rows_b + up_b + miss_b + tab_b + part_b + 4096;
+    char* base = (char*)mvs_scratch(c, 6, need);
+    if (!base) return mvs_alloc_failed(c);
+    float* I = (float*)base;
+    float* BW = (float*)(base + pool_b);
+    float* F = (float*)(base + 2 * pool_b);
+    float* T0 = (float*)(base + 3 * pool_b);
+    int4* rows = (int4*)(base + 4 * pool_b);
+    char* dblock = base + 4 * pool_b + rows_b;
+    double* dfw1 = (double*)dblock;
+    double* dfw2 = dfw1 + w1.size();
+    float* ffw1 = (float*)(dblock + wdb);
+    float* ffw2 = ffw1 + w1.size();
+    DevView* dviews_dev = (DevView*)(dblock + wdb + wfb);
+    CbFastRec* drecs = (CbFastRec*)(dblock + wdb + wfb + vb);
+    int4* dmiss = (int4*)(dblock + up_b);
+    double* dtabs = (double*)(dblock + up_b + miss_b);
+    CbPartial* dpart = (CbPartial*)(dblock + up_b + miss_b + tab_b);
+    {
+        char* hp = (char*)mvs_pinned_slot(c, 0, up_b + 64);
+        if (!hp) return mvs_alloc_failed(c);
+        memcpy(hp, w1.data(), w1.size() * 8);
+        memcpy(hp + w1.size() * 8, w2.data(), w2.size() * 8);
+        float* hf = (float*)(hp + wdb);
+        for (size_t k = 0; k < w1.size(); ++k) hf[k] = (float)w1[k];
+        for (size_t k = 0; k < w2.size(); ++k) hf[w1.size() + k] = (float)w2[k];
+        memcpy(hp + wdb + wfb, &dvs[0], (size_t)n_views * sizeof(DevView));
+        for (int i = 0; i < n_views; ++i) {
+            CbFastRec r;
+            memset(&r, 0, sizeof(r));
+            for (int k = 0; k < 3; ++k) { r.lo[k] = 0x7fffffff; r.hi[k] = -1; }
+            memcpy(hp + wdb + wfb + vb + (size_t)i * sizeof(CbFastRec), &r, sizeof(r));
+        }
+        MVS_HIP_TRY(c, hipMemcpyAsync(dblock, hp, up_b, hipMemcpyHostToDevice, c->stream));
+        mvs_pinned_mark(c, 0);
+    }
+
+    {   // resampled views and blend weights on the views' boxes: two launches for all views of the chunk
+        std::vector<float*> res_out(n_views), blend_out(n_views);
+        std::vector<int64_t> shp((size_t)n_views * 3);
+        std::vector<int> b0((size_t)n_views * 3);
+        for (int i = 0; i < n_views; ++i) {
+            const CbFastView& B = VS.v[i];
+            res_out[i] = I + B.off;
+            blend_out[i] = BW + B.off;
+            for (int k = 0; k < 3; ++k) { shp[(size_t)i * 3 + k] = B.n[k]; b0[(size_t)i * 3 + k] = B.lo[k]; }
+        }
+        mvs_launch_boxes_batch(c, &dvs[0], dviews_dev, n_views, dtype, opts->order, NAN, res_out.data(), blend_out.data(),
+                               (const int64_t (*)[3])shp.data(), (const int (*)[3])b0.data());
+    }
+    CbBoxes8 bx8;
+    memset(&bx8, 0, sizeof(bx8));
+    for (int i = 0; i < n_views; ++i) {
+        for (int k = 0; k < 3; ++k) { bx8.b[i].lo[k] = VS.v[i].lo[k]; bx8.b[i].n[k] = VS.v[i].n[k]; }
+        bx8.b[i].off = VS.v[i].off;
+    }
+    hipLaunchKernelGGL(mask_normalize8_kernel, dim3(grid_for(n)), dim3(256), 0, c->stream, BW, I, bx8, n_views, S, 1);
+    // ---- the valid mask of every view: bounding box + listed voxels; tables of the box under both filters ----
+    hipLaunchKernelGGL(cb_rows_kernel, dim3(rows_grid, n_views), dim3(256), 0, c->stream, I, VS, rows, dpart);
+    hipLaunchKernelGGL(cb_rec_reduce_kernel, dim3(n_views), dim3(256), 0, c->stream, dpart, (int)rows_grid, drecs);
+    hipLaunchKernelGGL(cb_missing_kernel, dim3((unsigned)std::min<long long>((max_rows + 255) / 256, 1024), n_views), dim3(256), 0, c->stream, I, VS, rows, drecs, dmiss,
+                       c->cb_flag_dev);
+    hipLaunchKernelGGL(cb_sort_missing_kernel, dim3(n_views), dim3(kCbMissCap), 0, c->stream, drecs, dmiss);
+    hipLaunchKernelGGL(cb_tables_kernel, dim3(3, n_views, 2), dim3(256), 0, c->stream, VS, drecs, S, ndim, r1, dfw1, r2, dfw2, dtabs);
+    MVS_HIP_TRY(c, hipGetLastError());
+
+    // ---- 2 * ndim line passes, each ONE launch over all views: I -> T0 -> F -> (squared deviation) T0 -> F -> T0 -> F (3D) ----
+    const bool f64 = c->cb_taps_f64;
+    int pass = 0;
+    for (int f = 0; f < 2; ++f)
+        for (int axis = 3 - ndim; axis < 3; ++axis, ++pass) {
+            const bool firstp = axis == 3 - ndim, lastp = axis == 2;
+            CbLineArgs A;
+            A.src = (pass == 0) ? I : ((pass & 1) ? T0 : F);
+            A.dst = (pass & 1) ? F : T0;
+            A.I = I;
+            A.axis = axis; A.radius = f ? r2 : r1; A.ndim = ndim; A.filt = f;
+            A.S = S;
+            A.fwf = f ? ffw2 : ffw1; A.fwd = f ? dfw2 : dfw1;
+            A.tabs = dtabs; A.recs = drecs; A.miss = dmiss; A.dbg = dbg;
+            CbFastViews B = VS;
+            int nb = 0;
+            size_t lds = 0;
+            for (int i = 0; i < n_views; ++i) {
+                CbFastView& V = B.v[i];
+                V.T = Tsel[axis][f][i];
+                V.blk0 = nb;
+                const long long bn = (long long)V.n[0] * V.n[1] * V.n[2];
+                if (bn == 0) continue;
+                const long long n_lines = bn / V.n[axis];
+                nb += (int)((n_lines + V.T - 1) / V.T);
+                lds = std::max(lds, cb_fast_lds(V.n[axis], A.radius, V.T, axis == 2));
+            }
+            if (nb == 0) continue;
+            const int src = (pass == 0) ? CBS_NAN0 : CBS_PLAIN;
+            const int dst = lastp ? (f ? CBD_F : CBD_SQ) : CBD_PLAIN;
+            (void)firstp;
+#define MVS_CBL(S_, D_, PF_) do { if (f64) hipLaunchKernelGGL((cb_line_kernel<S_, D_, double, PF_>), dim3(nb), dim3(256), lds, c->stream, A, B); \
+                                  else hipLaunchKernelGGL((cb_line_kernel<S_, D_, float, PF_>), dim3(nb), dim3(256), lds, c->stream, A, B); } while (0)
+            if (!lastp) { if (src == CBS_NAN0) MVS_CBL(CBS_NAN0, CBD_PLAIN, false); else MVS_CBL(CBS_PLAIN, CBD_PLAIN, false); }
+            else if (dst == CBD_SQ) MVS_CBL(CBS_PLAIN, CBD_SQ, true);
+            else MVS_CBL(CBS_PLAIN, CBD_F, true);
+#undef MVS_CBL
+            c->cb_line_launches += 1;
+        }
+    MVS_HIP_TRY(c, hipGetLastError());
+
+    const size_t out_bytes = (size_t)no * es;
+    void* dout = out;
+    if (opts->out_mem == MVS_MEM_HOST) {
+        dout = mvs_scratch(c, 1, out_bytes);
+        if (!dout) return mvs_alloc_failed(c);
+    }
+    const int gbo = grid_for(no);
+    const int tz = (int)opts->trim[0], ty = (int)opts->trim[1], tx = (int)opts->trim[2];
+    switch (dtype) {
+        case MVS_U8: hipLaunchKernelGGL(cb_fuse8_kernel<unsigned char>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, bx8, n_views, tz, ty, tx, O, (unsigned char*)dout); break;
+        case MVS_U16: hipLaunchKernelGGL(cb_fuse8_kernel<unsigned short>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, bx8, n_views, tz, ty, tx, O, (unsigned short*)dout); break;
+        default: hipLaunchKernelGGL(cb_fuse8_kernel<float>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, bx8, n_views, tz, ty, tx, O, (float*)dout); break;
+    }
+    MVS_HIP_TRY(c, hipGetLastError());
+    MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));
+    c->timing_valid = true;
+    *taken = true;
+    if (opts->out_mem == MVS_MEM_HOST) {
+        MVS_HIP_TRY(c, hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, c->stream));
+        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (*c->cb_flag_host) {      // a mask list overflowed: this chunk again, through the bit-faithful passes (the caller falls through)
+            *c->cb_flag_host = 0;
+            c->cb_overflows += 1;
+            *taken = false;
+        }
     } else if (host_bytes) {
         MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));      // host slabs were staged through scratch that the next call may overwrite
     }

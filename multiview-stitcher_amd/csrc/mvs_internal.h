@@ -77,6 +77,12 @@ struct MvsContext {
     bool cb_mask_closed_form = false;  // option "cb_mask_closed_form" (default 0, see profiles/round5_cb_mask.txt): a view whose valid mask is a box gets its mask filters from tables
     bool cb_mask_count = false;        // test switch "cb_mask_count": count the views whose mask is a box (counters cb_mask_views / cb_mask_boxes)
     long long cb_mask_views = 0, cb_mask_boxes = 0;
+    bool cb_exact = false;        // option "cb_exact": content-based weights through the bit-faithful passes (float64 taps, filtered masks) instead of
+                                  // the default fast path (mvs_gauss_fast.inc: mask = box + list, one quantity per pass, float32 taps)
+    bool cb_taps_f64 = false;     // option "cb_taps_f64": the fast path accumulates its taps in float64 (A/B of the accumulator alone)
+    int* cb_flag_host = nullptr;  // mapped pinned word the device raises when a view's mask list overflows (fast path) ...
+    int* cb_flag_dev = nullptr;   // ... its device alias; read by the call itself (host results) or through counter "cb_overflow"
+    long long cb_overflows = 0, cb_line_launches = 0;
     bool cb_nosplit = false;      // test switch: the y / z passes of the paired path keep both quantities in one workgroup
     bool cb_unpaired = false;     // test switch: content-based weights through the separate value / mask line passes of rounds 1-3
     int fft_slab_axes = 4;        // short axes (bit k = axis k of (z, y, x)) whose crops take the three-pass phase correlation: by default only

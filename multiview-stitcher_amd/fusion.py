@@ -109,6 +109,26 @@ def _bb_dicts(bb, sdims):
     return out
 
 
+def _cb_overflowed(device):
+    """True when a chunk of the fast content-based path since the last check could not list the voxels its mask lacks
+    (counter ``cb_overflow``: waits for the context's stream, clears the flag)."""
+    return _lib.get_counter("cb_overflow", device, reset=True) > 0
+
+
+class _cb_exact:
+    """Context manager: content-based weights through the bit-faithful passes (option ``cb_exact``) on ``device``."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        _lib.set_option("cb_exact", 1, self.device)
+
+    def __exit__(self, *exc):
+        _lib.set_option("cb_exact", 0, self.device)
+        return False
+
+
 def fuse_np(
     sims,
     params,
@@ -130,6 +150,7 @@ def fuse_np(
     out=None,
     frame_origin=None,
     _record=None,
+    _cb_check=True,
 ):
     """Fuse the slabs ``sims`` of one output chunk (fusion.fuse_np, _core.py:1513-1733).
 
@@ -291,6 +312,12 @@ def fuse_np(
         opts.out_mem = _lib.MVS_MEM_DEVICE
         rc = lib.mvs_fuse_chunk(device, views, n, C.byref(opts), C.c_void_p(out.ptr))
         _lib.check(rc, device, "mvs_fuse_chunk")
+        if weights_code and _cb_check and _cb_overflowed(device):
+            # the fast content-based path lists the voxels its box-shaped mask lacks; a list that did not fit raised a flag
+            # (a result left on the device is not waited for inside the call): this chunk again through the bit-faithful passes
+            with _cb_exact(device):
+                rc = lib.mvs_fuse_chunk(device, views, n, C.byref(opts), C.c_void_p(out.ptr))
+                _lib.check(rc, device, "mvs_fuse_chunk")
         out.mark_written()
         if _record is not None and bool(np.all(mems == _lib.MVS_MEM_DEVICE)):
             # (fuse()'s geometry-keyed replay: the view records without their data pointers, the options, the result shape)
@@ -1007,7 +1034,7 @@ def _fuse_once(
             weights_func_kwargs=weights_func_kwargs,
             trim_overlap_in_pixels=(overlap_in_pixels if trim_overlap else 0),
             interpolation_order=interpolation_order, full_view_bbs=fvb, blending_widths=blending_widths,
-            shrink_distance=shrink_distance, backend="hip", device=dev,
+            shrink_distance=shrink_distance, backend="hip", device=dev, _cb_check=False,
         )
         if fusion_func in _FUSION_CODES and (weights_func is None or weights_func is content_based):
             fo_ = frame_origin if frame_origin is not None else output_stack_properties["origin"]
@@ -1130,7 +1157,15 @@ def fuse(*args, **kwargs):
     bound = inspect.signature(_fuse_once).bind(*args, **kwargs)      # wherever merge_chunks was passed, it can be overridden
     failure = None
     try:
-        return _fuse_once(*bound.args, **bound.kwargs)
+        res = _fuse_once(*bound.args, **bound.kwargs)
+        if bound.arguments.get("weights_func") is content_based and bound.arguments.get("output_on_backend"):
+            # chunks left on the device are not waited for one by one; a mask list of the fast content-based path that overflowed
+            # in any of them shows here, and the mosaic is fused again through the bit-faithful passes
+            dev_ = bound.arguments.get("device", 0)
+            if _cb_overflowed(dev_):
+                with _cb_exact(dev_):
+                    res = _fuse_once(*bound.args, **bound.kwargs)
+        return res
     except _lib.DeviceMemoryError as exc:
         # A merged launch block is sized from an ESTIMATE of what has to be staged on the device (_launch_budget); if the
         # device still runs out of memory the requested chunk grid -- the unit the caller sized for -- is used instead.

@@ -315,21 +315,25 @@ def test_content_based_paired_passes_equal_separate_passes(hip_device, ndim, dty
     out_bb = union_bb(bbs, params, np.ones(ndim))
     kw = dict(weights_func=fusion.content_based, weights_func_kwargs=sig, full_view_bbs=[bb_to_dicts(b, sdims) for b in bbs],
               trim_overlap_in_pixels=halo)
-    got = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw)
-    _lib.set_option("cb_unpaired", 1)
+    _lib.set_option("cb_exact", 1)      # (round 6: the default is the fast path of mvs_gauss_fast.inc; these are the bit-faithful passes)
     try:
-        ref = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw)
+        got = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw)
+        _lib.set_option("cb_unpaired", 1)
+        try:
+            ref = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw)
+        finally:
+            _lib.set_option("cb_unpaired", 0)
+        np.testing.assert_array_equal(got, ref)
+        assert len(sims) == 2 ** ndim and np.isfinite(got.astype(np.float64)).all()
+        # ... and so are the paired y / z passes that keep both quantities in one workgroup (the default splits them: one quantity
+        # per workgroup, twice the lines)
+        _lib.set_option("cb_nosplit", 1)
+        try:
+            np.testing.assert_array_equal(fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw), ref)
+        finally:
+            _lib.set_option("cb_nosplit", 0)
     finally:
-        _lib.set_option("cb_unpaired", 0)
-    np.testing.assert_array_equal(got, ref)
-    assert len(sims) == 2 ** ndim and np.isfinite(got.astype(np.float64)).all()
-    # ... and so are the paired y / z passes that keep both quantities in one workgroup (the default splits them: one quantity
-    # per workgroup, twice the lines)
-    _lib.set_option("cb_nosplit", 1)
-    try:
-        np.testing.assert_array_equal(fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw), ref)
-    finally:
-        _lib.set_option("cb_nosplit", 0)
+        _lib.set_option("cb_exact", 0)
 
 
 @pytest.mark.parametrize("case", ["u16_int", "u16_frac", "f32_frac", "2d", "long_z", "nan_blob"])
@@ -366,6 +370,7 @@ def test_content_based_mask_tables_equal_the_filtered_mask(hip_device, case, ker
     out_bb = union_bb(bbs, params, np.ones(ndim))
     kw = dict(weights_func=fusion.content_based, weights_func_kwargs=sig, full_view_bbs=[bb_to_dicts(b, sdims) for b in bbs],
               trim_overlap_in_pixels=halo)
+    _lib.set_option("cb_exact", 1)      # (round 6: both sides of this comparison are forms of the bit-faithful passes)
     _lib.set_option("cb_mask_count", 1)
     _lib.set_option("cb_mask_closed_form", 1)
     for key in ("cb_mask_views", "cb_mask_boxes"):
@@ -373,10 +378,13 @@ def test_content_based_mask_tables_equal_the_filtered_mask(hip_device, case, ker
     try:
         got = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw)
         n_views, n_boxes = _lib.get_counter("cb_mask_views", reset=True), _lib.get_counter("cb_mask_boxes", reset=True)
+        _lib.set_option("cb_mask_count", 0)
+        _lib.set_option("cb_mask_closed_form", 0)
+        ref = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw)        # every mask through the line filters
     finally:
         _lib.set_option("cb_mask_count", 0)
         _lib.set_option("cb_mask_closed_form", 0)
-    ref = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw)        # the default: every mask through the line filters
+        _lib.set_option("cb_exact", 0)
     np.testing.assert_array_equal(got, ref)
     assert n_views == len(sims)
     if case == "nan_blob":
@@ -386,6 +394,90 @@ def test_content_based_mask_tables_equal_the_filtered_mask(hip_device, case, ker
     else:
         assert n_boxes == len(sims)                 # every view's mask was found to be a box: the tables were used
     assert np.isfinite(np.asarray(got, dtype=np.float64)).all() or case == "nan_blob"
+
+
+def _cb_case(case):
+    sig, halo, ndim = {"sigma_1": 5.0, "sigma_2": 11.0}, 22, 3
+    if case == "u16_int":
+        sims, params = _grid_case(3, np.uint16, (2, 2, 2), (70, 60, 66), (30, 24, 26), False, seed=41)
+    elif case == "u16_frac":
+        sims, params = _grid_case(3, np.uint16, (2, 2, 2), (70, 60, 66), (30, 24, 26), True, seed=42)
+    elif case == "f32_frac":
+        sims, params = _grid_case(3, np.float32, (1, 2, 2), (64, 72, 80), (0, 30, 34), True, seed=43)
+    elif case == "2d":
+        sims, params = _grid_case(2, np.float32, (2, 2), (120, 140), (40, 44), True, seed=44)
+        sig, halo, ndim = {"sigma_1": 2.0, "sigma_2": 4.0}, 8, 2
+    elif case == "long_z":
+        sims, params = _grid_case(3, np.uint16, (2, 2, 2), (300, 60, 70), (80, 20, 24), True, seed=45)
+    elif case in ("nan_pinholes", "nan_blob"):
+        sims, params = _grid_case(3, np.float32, (1, 2, 2), (64, 72, 80), (0, 30, 34), False, seed=46)
+        d = np.array(sims[1].data, dtype=np.float32, copy=True)
+        if case == "nan_blob":
+            d[20:30, 25:40, 30:50] = np.nan                   # 3 000 voxels: more than a list holds
+        else:
+            d[20:22, 25:27, 30:33] = np.nan                   # 12 voxels in the interior ...
+            d[3, 70, 5] = np.nan                              # ... and single ones next to the tile's border and the chunk's reflection
+            d[60, 2, 77] = np.nan
+        sims[1] = sims[1].copy(data=d)
+    else:
+        raise ValueError(case)
+    return sims, params, sig, halo, ndim
+
+
+@pytest.mark.parametrize("taps", ["f32", "f64"])
+@pytest.mark.parametrize("case", ["u16_int", "u16_frac", "f32_frac", "2d", "long_z", "nan_pinholes", "nan_blob"])
+def test_content_based_fast_path_against_oracle_and_exact_passes(hip_device, case, taps, kernel_path):
+    """Round 6: the DEFAULT content-based path (csrc/mvs_gauss_fast.inc): the valid mask of a view is its box minus a short list of
+    voxels found on the device, gaussian(mask) comes from 1-D tables minus the listed voxels' separable bumps, every line pass
+    carries one quantity and all views of the chunk share one launch per pass; float32 taps (``cb_taps_f64`` = 1: float64).
+    Bar: the ORACLE at north_star's tolerance (float 1e-4 relative, u16 +-1 LSB at truncation boundaries) -- and the same bar
+    against the bit-faithful passes (option ``cb_exact``).  ``nan_pinholes``: NaN voxels inside a float tile go through the list
+    (their bumps, incl. the images under the chunk's reflection); ``nan_blob``: a hole larger than the list raises the overflow
+    flag and the chunk is redone on the exact passes -- bit for bit their result."""
+    from multiview_stitcher_amd import _lib, fusion, spatial_image_utils as si
+
+    if kernel_path != "fast":
+        pytest.skip("content-based weights have a single implementation")
+    sims, params, sig, halo, ndim = _cb_case(case)
+    sdims = si.get_spatial_dims_from_sim(sims[0])
+    views, bbs = zip(*[sim_to_view(s) for s in sims])
+    out_bb = union_bb(bbs, params, np.ones(ndim))
+    kw = dict(weights_func=fusion.content_based, weights_func_kwargs=sig, full_view_bbs=[bb_to_dicts(b, sdims) for b in bbs],
+              trim_overlap_in_pixels=halo)
+    want, want_f, dbg = fo.fuse_np(list(views), params, out_bb, full_view_bbs=list(bbs), weights="content_based",
+                                   weights_kwargs=sig, trim_overlap_in_pixels=halo, return_debug=True)
+    _lib.set_option("cb_exact", 1)
+    try:
+        exact = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw)
+    finally:
+        _lib.set_option("cb_exact", 0)
+    for key in ("cb_line_launches", "cb_overflows_redone"):
+        _lib.get_counter(key, reset=True)
+    _lib.set_option("cb_taps_f64", 1 if taps == "f64" else 0)
+    try:
+        got = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw)
+        got_dev = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), output_on_backend=True, **kw).get()
+    finally:
+        _lib.set_option("cb_taps_f64", 0)
+    launches, redone = _lib.get_counter("cb_line_launches", reset=True), _lib.get_counter("cb_overflows_redone", reset=True)
+    assert launches == 2 * (2 * ndim)                          # one launch per pass for ALL views of the chunk, two calls
+    np.testing.assert_array_equal(got, got_dev)                # (deterministic: the list is sorted, the bumps are summed in list order)
+    if case == "nan_blob":
+        assert redone == 1                                     # the host-result call noticed the overflow and redid the chunk itself ...
+        np.testing.assert_array_equal(got, exact)              # ... and so did the device-result call, through fuse_np's check
+        return
+    assert redone == 0
+    for ref in (want, exact):
+        if np.issubdtype(got.dtype, np.integer):
+            d = np.abs(got.astype(np.int64) - ref.astype(np.int64))
+            assert d.max() <= 1 and (d > 0).mean() < 0.02
+            if ref is want:
+                frac = want_f - np.floor(want_f)
+                assert np.all(np.minimum(frac, 1 - frac)[d == 1] < 1e-4 * np.maximum(np.abs(want_f[d == 1]), 1.0))
+        else:
+            ok = np.isfinite(ref)
+            assert np.array_equal(np.isfinite(got), ok)
+            _assert_cb_float_close(got[ok], ref[ok])
 
 
 def test_fuse_content_based_chunked_workflow(hip_device, kernel_path):

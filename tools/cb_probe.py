@@ -15,6 +15,8 @@ _lib.set_option("serial_classes", int(os.environ.get("MVS_SERIAL", "0")))      #
 _lib.set_option("cb_unpaired", int(os.environ.get("MVS_CB_UNPAIRED", "0")))
 _lib.set_option("cb_nosplit", int(os.environ.get("MVS_CB_NOSPLIT", "0")))
 _lib.set_option("cb_mask_closed_form", int(os.environ.get("MVS_CB_MASK", "0")))      # 1: masks that are boxes from tables (round 5; off by default)
+_lib.set_option("cb_exact", int(os.environ.get("MVS_CB_EXACT", "0")))                # 1: the bit-faithful passes (rounds 1-5); default: the fast path (round 6)
+_lib.set_option("cb_taps_f64", int(os.environ.get("MVS_CB_TAPS_F64", "0")))          # 1: float64 accumulators on the fast path
 if os.environ.get("MVS_CB_COUNT"):
     _lib.set_option("cb_mask_count", 1)
 torch.cuda.synchronize()   # the tiles are produced on torch's stream, the library runs on its own
@@ -25,5 +27,6 @@ for rep in range(5):
     _lib.synchronize(0)
     dt = time.perf_counter() - t0
     print("content-based fuse %s: %.1f ms, %.1f Mvoxels/s" % (out.shape, dt * 1e3, np.prod(out.shape) / dt / 1e6), flush=True)
+print("line launches per fuse():", _lib.get_counter("cb_line_launches", reset=True) / 5, " overflow flag:", _lib.get_counter("cb_overflow", reset=True))
 if os.environ.get("MVS_CB_COUNT"):
     print("views", _lib.get_counter("cb_mask_views"), "of them with a box mask", _lib.get_counter("cb_mask_boxes"))
