@@ -1155,7 +1155,7 @@ static int cb_fast_chunk(MvsContext* c, const mvs_view_t* views, int32_t n_views
     for (int i = 0; i < n_views; ++i)
         for (int k = 0; k < 9; ++k)
             if (views[i].matrix[k] != I9[k]) return MVS_OK;
-    if ((w1.size() + w2.size()) * 8 > 32 * 1024) return MVS_OK;
+    if (std::max(r1, r2) > kCbMaxRadius) return MVS_OK;
 
     // ---- device views and their boxes inside the chunk ----
     std::vector<DevView> dvs((size_t)n_views);
