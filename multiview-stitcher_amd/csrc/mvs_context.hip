@@ -358,8 +358,13 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         c->cb_exact = value != 0;
         return MVS_OK;
     }
+    if (!strcmp(key, "cb_blend_generic")) {
+        c->cb_blend_generic = value != 0;
+        return MVS_OK;
+    }
     if (!strcmp(key, "cb_taps_f64")) {
-        c->cb_taps_f64 = value != 0;
+        if (value < 0 || value > 3) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_set_option: cb_taps_f64 is 0, 1, 2 or 3");
+        c->cb_taps = (int)value;
         return MVS_OK;
     }
     if (!strcmp(key, "cb_nosplit")) {

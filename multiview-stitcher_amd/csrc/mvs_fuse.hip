@@ -1228,6 +1228,22 @@ __global__ __launch_bounds__(256) void crop_int_batch_kernel(BoxBatch B, float c
         }
     }
 }
+// the same from the closed form of the translation path (mvs_fuse_tr.h: float arithmetic, the weights the region kernels fuse with)
+struct TrViews8 { TrView v[8]; };
+__global__ __launch_bounds__(256) void blend_tr_batch_kernel(TrViews8 TV, BoxBatch B) {
+    int v = 0;
+    while (v < 7 && (int)blockIdx.x >= B.blk0[v + 1]) ++v;
+    const BoxItem& I = B.v[v];
+    const TrView& V = TV.v[v];
+    const int bx = (int)blockIdx.x - B.blk0[v], nbk = B.blk0[v + 1] - B.blk0[v];
+    const long long n = (long long)I.oz * I.oy * I.ox;
+    for (long long i = (long long)bx * blockDim.x + threadIdx.x; i < n; i += (long long)nbk * blockDim.x) {
+        const int x = (int)(i % I.ox);
+        const long long t = i / I.ox;
+        const int y = (int)(t % I.oy), z = (int)(t / I.oy);
+        I.out[i] = blend_ramp_nb(tr_weight_profile(V, z + I.z0, y + I.y0, x + I.x0));
+    }
+}
 __global__ __launch_bounds__(256) void blend_batch_kernel(const DevView* __restrict__ views, BoxBatch B) {
     int v = 0;
     while (v < 7 && (int)blockIdx.x >= B.blk0[v + 1]) ++v;
@@ -1321,6 +1337,17 @@ void launch_fuse_tr(const TrParams& P, int fusion, int nblocks, hipStream_t s) {
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 }  // namespace
+
+// Translation-path record of a view for callers outside this file (mvs_gauss.hip): prepare_translation_view + the chunk frame +
+// fill_tr_view.  Returns false when the view does not qualify (rotated / scaled views, a support table that is not the closed form).
+bool mvs_prepare_tr_view(DevView* d, int order, const int64_t chunk_shape[3], size_t elem_size, const int64_t org[3], const int64_t ioff[3],
+                         TrView* out) {
+    prepare_translation_view(d, order, MVS_FUSE_WEIGHTED_AVERAGE, chunk_shape, elem_size, org, ioff);
+    mvs_view_to_chunk_frame(d, org, ioff);
+    if (!d->tr_ok) return false;
+    fill_tr_view(*d, out);
+    return true;
+}
 
 int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_views, int dtype, void* dout, const int64_t os[3],
                      const int64_t trim[3], bool* done);   // mvs_fuse_region.hip
@@ -1742,7 +1769,7 @@ void mvs_launch_blend(MvsContext* c, const DevView& d, float* out, const int64_t
 // device memory (same order as `hviews`); boxes with no voxels are skipped.  Falls back to one launch per view for what the batched
 // kernels do not cover (a view that is not a whole-pixel translation of an integer tile goes through mvs_launch_resample).
 void mvs_launch_boxes_batch(MvsContext* c, const DevView* hviews, const DevView* dviews, int n_views, int dtype, int order, float cval,
-                            float* const* res_out, float* const* blend_out, const int64_t (*shapes)[3], const int (*box0)[3]) {
+                            float* const* res_out, float* const* blend_out, const int64_t (*shapes)[3], const int (*box0)[3], const TrView* tr) {
     if (n_views > 8 || c->force_generic) {
         for (int i = 0; i < n_views; ++i) {
             if (shapes[i][0] * shapes[i][1] * shapes[i][2] == 0) continue;
@@ -1787,7 +1814,12 @@ void mvs_launch_boxes_batch(MvsContext* c, const DevView* hviews, const DevView*
         if (dtype == MVS_U8) hipLaunchKernelGGL(crop_int_batch_kernel<unsigned char>, dim3(nr), dim3(256), 0, c->stream, R, cval);
         else hipLaunchKernelGGL(crop_int_batch_kernel<unsigned short>, dim3(nr), dim3(256), 0, c->stream, R, cval);
     }
-    if (nw > 0) hipLaunchKernelGGL(blend_batch_kernel, dim3(nw), dim3(256), 0, c->stream, dviews, W);
+    if (nw > 0 && tr) {
+        TrViews8 TV;
+        memset(&TV, 0, sizeof(TV));
+        for (int i = 0; i < n_views; ++i) TV.v[i] = tr[i];
+        hipLaunchKernelGGL(blend_tr_batch_kernel, dim3(nw), dim3(256), 0, c->stream, TV, W);
+    } else if (nw > 0) hipLaunchKernelGGL(blend_batch_kernel, dim3(nw), dim3(256), 0, c->stream, dviews, W);
 }
 
 // Index frame -> chunk frame for the kernels that evaluate the full affine map per voxel (generic fuse kernel, resample,

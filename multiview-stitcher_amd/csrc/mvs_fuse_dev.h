@@ -36,7 +36,12 @@ void mvs_launch_resample(MvsContext* c, const DevView& d, int dtype, int order, 
                          MvsCropStats* crop_stats = nullptr, int crop_stats_k = 0);
 void mvs_launch_blend(MvsContext* c, const DevView& d, float* out, const int64_t shape[3], const int* box0 = nullptr);
 // both for the boxes of up to 8 views in two launches (`dviews`: the same records in device memory)
+// (`tr`: the views' translation-path records, or NULL -- with them the blend weights come from the closed form in float arithmetic)
+struct TrView;
 void mvs_launch_boxes_batch(MvsContext* c, const DevView* hviews, const DevView* dviews, int n_views, int dtype, int order, float cval,
-                            float* const* res_out, float* const* blend_out, const int64_t (*shapes)[3], const int (*box0)[3]);
+                            float* const* res_out, float* const* blend_out, const int64_t (*shapes)[3], const int (*box0)[3],
+                            const TrView* tr = nullptr);
+bool mvs_prepare_tr_view(DevView* d, int order, const int64_t chunk_shape[3], size_t elem_size, const int64_t org[3], const int64_t ioff[3],
+                         TrView* out);
 void mvs_view_chunk_box(const DevView& d, const int64_t shape[3], int lo[3], int hi[3]);
 void mvs_view_to_chunk_frame(DevView* d, const int64_t org[3], const int64_t ioff[3]);

@@ -21,6 +21,7 @@
 // are skipped are exact zeros).  A chunk of a tile grid sees one view nearly whole and up to seven by a corner or a face:
 // 1.3 chunk volumes of filter work instead of 8 on the 2x2x2 probe.
 #include "mvs_fuse_dev.h"
+#include "mvs_fuse_tr.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1170,12 +1171,15 @@ static int cb_fast_chunk(MvsContext* c, const mvs_view_t* views, int32_t n_views
     memset(&VS, 0, sizeof(VS));
     VS.nv = n_views;
     long long pool = 0, total_rows = 0, tab_doubles = 0;
+    std::vector<TrView> trv((size_t)n_views);
+    bool tr_all = !c->cb_blend_generic;
     {
         for (int i = 0; i < n_views; ++i) {
             // (slab pointers of host views are filled in below, once the scratch exists; the geometry does not depend on them)
             int rc = mvs_fill_dev_view(c, views[i], ndim, views[i].data, &dvs[i]);
             if (rc) return rc;
-            mvs_view_to_chunk_frame(&dvs[i], opts->index_origin, views[i].index_offset);
+            // (also moves the view into the chunk's frame; a view without the closed-form blend weight: the generic blend launch)
+            if (!mvs_prepare_tr_view(&dvs[i], opts->order, cs, es, opts->index_origin, views[i].index_offset, &trv[i])) tr_all = false;
             int lo[3], hi[3];
             mvs_view_chunk_box(dvs[i], cs, lo, hi);
             CbFastView& B = VS.v[i];
@@ -1289,7 +1293,7 @@ static int cb_fast_chunk(MvsContext* c, const mvs_view_t* views, int32_t n_views
             for (int k = 0; k < 3; ++k) { shp[(size_t)i * 3 + k] = B.n[k]; b0[(size_t)i * 3 + k] = B.lo[k]; }
         }
         mvs_launch_boxes_batch(c, &dvs[0], dviews_dev, n_views, dtype, opts->order, NAN, res_out.data(), blend_out.data(),
-                               (const int64_t (*)[3])shp.data(), (const int (*)[3])b0.data());
+                               (const int64_t (*)[3])shp.data(), (const int (*)[3])b0.data(), tr_all ? trv.data() : nullptr);
     }
     CbBoxes8 bx8;
     memset(&bx8, 0, sizeof(bx8));
@@ -1297,7 +1301,7 @@ static int cb_fast_chunk(MvsContext* c, const mvs_view_t* views, int32_t n_views
         for (int k = 0; k < 3; ++k) { bx8.b[i].lo[k] = VS.v[i].lo[k]; bx8.b[i].n[k] = VS.v[i].n[k]; }
         bx8.b[i].off = VS.v[i].off;
     }
-    hipLaunchKernelGGL(mask_normalize8_kernel, dim3(grid_for(n)), dim3(256), 0, c->stream, BW, I, bx8, n_views, S, 1);
+    hipLaunchKernelGGL(cb_normalize8_runs_kernel, dim3(grid_for((n + kCbRun - 1) / kCbRun)), dim3(256), 0, c->stream, BW, I, bx8, n_views, S);
     // ---- the valid mask of every view: bounding box + listed voxels; tables of the box under both filters ----
     hipLaunchKernelGGL(cb_rows_kernel, dim3(rows_grid, n_views), dim3(256), 0, c->stream, I, VS, rows, dpart);
     hipLaunchKernelGGL(cb_rec_reduce_kernel, dim3(n_views), dim3(256), 0, c->stream, dpart, (int)rows_grid, drecs);
@@ -1308,10 +1312,15 @@ static int cb_fast_chunk(MvsContext* c, const mvs_view_t* views, int32_t n_views
     MVS_HIP_TRY(c, hipGetLastError());
 
     // ---- 2 * ndim line passes, each ONE launch over all views: I -> T0 -> F -> (squared deviation) T0 -> F -> T0 -> F (3D) ----
-    const bool f64 = c->cb_taps_f64;
     int pass = 0;
     for (int f = 0; f < 2; ++f)
         for (int axis = 3 - ndim; axis < 3; ++axis, ++pass) {
+            // accumulators (option cb_taps_f64): 1 (default) = float64 for both filters, 0 = float32 for both, 2 / 3 = float64 for the
+            // first / second filter only.  C3 at size, one-count flips of the fused uint16 voxels against the oracle (all of them at
+            // truncation boundaries, none beyond the 1e-4 bar): 0.04 % (1; the bit-faithful passes: 0.04 %), 0.10 % (3), 0.21 % (2),
+            // 0.22 % (0) -- the noise of float32 taps enters through the second filter, whose result IS the weight; the probe takes
+            // 11.8 ms with 0 and 12.4 ms with 1 (the passes are bound by memory and latency, not by the taps)
+            const bool f64 = c->cb_taps == 1 || (c->cb_taps == 2 && f == 0) || (c->cb_taps == 3 && f == 1);
             const bool firstp = axis == 3 - ndim, lastp = axis == 2;
             CbLineArgs A;
             A.src = (pass == 0) ? I : ((pass & 1) ? T0 : F);
@@ -1354,12 +1363,12 @@ static int cb_fast_chunk(MvsContext* c, const mvs_view_t* views, int32_t n_views
         dout = mvs_scratch(c, 1, out_bytes);
         if (!dout) return mvs_alloc_failed(c);
     }
-    const int gbo = grid_for(no);
+    const int gbo = grid_for((no + kCbRun - 1) / kCbRun);
     const int tz = (int)opts->trim[0], ty = (int)opts->trim[1], tx = (int)opts->trim[2];
     switch (dtype) {
-        case MVS_U8: hipLaunchKernelGGL(cb_fuse8_kernel<unsigned char>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, bx8, n_views, tz, ty, tx, O, (unsigned char*)dout); break;
-        case MVS_U16: hipLaunchKernelGGL(cb_fuse8_kernel<unsigned short>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, bx8, n_views, tz, ty, tx, O, (unsigned short*)dout); break;
-        default: hipLaunchKernelGGL(cb_fuse8_kernel<float>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, bx8, n_views, tz, ty, tx, O, (float*)dout); break;
+        case MVS_U8: hipLaunchKernelGGL(cb_fuse8_runs_kernel<unsigned char>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, bx8, n_views, tz, ty, tx, O, (unsigned char*)dout); break;
+        case MVS_U16: hipLaunchKernelGGL(cb_fuse8_runs_kernel<unsigned short>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, bx8, n_views, tz, ty, tx, O, (unsigned short*)dout); break;
+        default: hipLaunchKernelGGL(cb_fuse8_runs_kernel<float>, dim3(gbo), dim3(256), 0, c->stream, I, BW, F, bx8, n_views, tz, ty, tx, O, (float*)dout); break;
     }
     MVS_HIP_TRY(c, hipGetLastError());
     MVS_HIP_TRY(c, hipEventRecord(c->ev_stop, c->stream));

@@ -79,7 +79,8 @@ struct MvsContext {
     long long cb_mask_views = 0, cb_mask_boxes = 0;
     bool cb_exact = false;        // option "cb_exact": content-based weights through the bit-faithful passes (float64 taps, filtered masks) instead of
                                   // the default fast path (mvs_gauss_fast.inc: mask = box + list, one quantity per pass, float32 taps)
-    bool cb_taps_f64 = false;     // option "cb_taps_f64": the fast path accumulates its taps in float64 (A/B of the accumulator alone)
+    bool cb_blend_generic = false; // test switch: the fast path takes its blending weights from the generic (float64 coordinate) blend launch instead of the closed form
+    int cb_taps = 1;              // option "cb_taps_f64": accumulators of the fast path's taps: 0 float32, 1 float64 (default), 2 / 3 float64 for the first / second filter only
     int* cb_flag_host = nullptr;  // mapped pinned word the device raises when a view's mask list overflows (fast path) ...
     int* cb_flag_dev = nullptr;   // ... its device alias; read by the call itself (host results) or through counter "cb_overflow"
     long long cb_overflows = 0, cb_line_launches = 0;

@@ -429,7 +429,7 @@ def _cb_case(case):
 def test_content_based_fast_path_against_oracle_and_exact_passes(hip_device, case, taps, kernel_path):
     """Round 6: the DEFAULT content-based path (csrc/mvs_gauss_fast.inc): the valid mask of a view is its box minus a short list of
     voxels found on the device, gaussian(mask) comes from 1-D tables minus the listed voxels' separable bumps, every line pass
-    carries one quantity and all views of the chunk share one launch per pass; float32 taps (``cb_taps_f64`` = 1: float64).
+    carries one quantity and all views of the chunk share one launch per pass; float64 taps (``cb_taps_f64`` = 0: float32).
     Bar: the ORACLE at north_star's tolerance (float 1e-4 relative, u16 +-1 LSB at truncation boundaries) -- and the same bar
     against the bit-faithful passes (option ``cb_exact``).  ``nan_pinholes``: NaN voxels inside a float tile go through the list
     (their bumps, incl. the images under the chunk's reflection); ``nan_blob``: a hole larger than the list raises the overflow
@@ -458,7 +458,7 @@ def test_content_based_fast_path_against_oracle_and_exact_passes(hip_device, cas
         got = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), **kw)
         got_dev = fusion.fuse_np(list(sims), params, bb_to_dicts(out_bb, sdims), output_on_backend=True, **kw).get()
     finally:
-        _lib.set_option("cb_taps_f64", 0)
+        _lib.set_option("cb_taps_f64", 1)      # (the default)
     launches, redone = _lib.get_counter("cb_line_launches", reset=True), _lib.get_counter("cb_overflows_redone", reset=True)
     assert launches == 2 * (2 * ndim)                          # one launch per pass for ALL views of the chunk, two calls
     np.testing.assert_array_equal(got, got_dev)                # (deterministic: the list is sorted, the bumps are summed in list order)

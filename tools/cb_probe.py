@@ -16,7 +16,8 @@ _lib.set_option("cb_unpaired", int(os.environ.get("MVS_CB_UNPAIRED", "0")))
 _lib.set_option("cb_nosplit", int(os.environ.get("MVS_CB_NOSPLIT", "0")))
 _lib.set_option("cb_mask_closed_form", int(os.environ.get("MVS_CB_MASK", "0")))      # 1: masks that are boxes from tables (round 5; off by default)
 _lib.set_option("cb_exact", int(os.environ.get("MVS_CB_EXACT", "0")))                # 1: the bit-faithful passes (rounds 1-5); default: the fast path (round 6)
-_lib.set_option("cb_taps_f64", int(os.environ.get("MVS_CB_TAPS_F64", "0")))          # 1: float64 accumulators on the fast path
+if os.environ.get("MVS_CB_TAPS_F64"):
+    _lib.set_option("cb_taps_f64", int(os.environ["MVS_CB_TAPS_F64"]))               # accumulators of the fast path: 1 float64 (default), 0 float32, 2 / 3 mixed
 if os.environ.get("MVS_CB_COUNT"):
     _lib.set_option("cb_mask_count", 1)
 torch.cuda.synchronize()   # the tiles are produced on torch's stream, the library runs on its own
@@ -24,9 +25,10 @@ for rep in range(5):
     t0 = time.perf_counter()
     out = fusion.fuse(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, weights_func=fusion.content_based, output_chunksize={d: 256 for d in "zyx"},
                       output_on_backend=True, device=0)
+    t_host = time.perf_counter() - t0
     _lib.synchronize(0)
     dt = time.perf_counter() - t0
-    print("content-based fuse %s: %.1f ms, %.1f Mvoxels/s" % (out.shape, dt * 1e3, np.prod(out.shape) / dt / 1e6), flush=True)
+    print("content-based fuse %s: %.1f ms, %.1f Mvoxels/s (calls queued after %.1f ms)" % (out.shape, dt * 1e3, np.prod(out.shape) / dt / 1e6, t_host * 1e3), flush=True)
 print("line launches per fuse():", _lib.get_counter("cb_line_launches", reset=True) / 5, " overflow flag:", _lib.get_counter("cb_overflow", reset=True))
 if os.environ.get("MVS_CB_COUNT"):
     print("views", _lib.get_counter("cb_mask_views"), "of them with a box mask", _lib.get_counter("cb_mask_boxes"))
