@@ -56,6 +56,7 @@ def parse_args():
     ap.add_argument("--pruning", default="alternating_pattern",
                     help="pre_registration_pruning_method (reference default: alternating_pattern)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pipeline leg (N = 1 only)")
+    ap.add_argument("--no-c3", action="store_true", help="skip the content-based leg (BASELINE config C3; N = 1 only)")
     return ap.parse_args()
 
 
@@ -374,7 +375,8 @@ def csrc_digest():
     import hashlib
 
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "multiview-stitcher_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "multiview-stitcher_amd", "csrc", "*.h"))):
+    for f in sorted(glob.glob(os.path.join(ROOT, "multiview-stitcher_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "multiview-stitcher_amd", "csrc", "*.h"))
+                    + glob.glob(os.path.join(ROOT, "multiview-stitcher_amd", "csrc", "*.inc"))):
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
@@ -399,6 +401,93 @@ def fuse_traffic_bytes(grid, tile):
         except (OSError, KeyError, ValueError):
             continue
     return None, "no PMC pass committed for the current kernels"
+
+
+def c3_content_based_leg(torch, dev, local_rank, args):
+    """BASELINE.json config C3 -- 4 x 4 x 2 (x, y, z) grid of 256 x 512 x 512 uint16 tiles, content-based weights (weights.py:22-74,
+    sigma 5 / 11, halo 22) in the reference's default 256^3 chunks -- as its own leg of the bench line: fuse() of the whole mosaic
+    with the tiles resident in HBM, timed after one warm call; algorithmic bytes per SURVEY 8d (every input voxel once + every output
+    voxel once + 16 B per voxel of every (halo chunk, view) box: two filters x (read + write) x 4 B at minimum); and the oracle's
+    (scipy's) time for one halo chunk of a small mosaic with 8 views beside it, on one core."""
+    from multiview_stitcher_amd import _lib, fusion
+    from multiview_stitcher_amd import spatial_image_utils as si
+
+    grid, tile = np.array([2, 4, 4]), np.array([256, 512, 512])
+    overlap = np.round(tile * args.overlap_frac).astype(int)
+    tiles, _, org = make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=7, max_jitter=0)
+    sims = build_sims(tiles, org, local_rank)
+    torch.cuda.synchronize()
+    cs, halo = 256, 22
+    for key in ("cb_line_launches", "cb_overflows_redone"):
+        _lib.get_counter(key, local_rank, reset=True)
+    ms = []
+    for rep in range(4):
+        _lib.synchronize(local_rank)
+        t0 = time.perf_counter()
+        out = fusion.fuse(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, weights_func=fusion.content_based,
+                          output_chunksize={d: cs for d in "zyx"}, output_on_backend=True, device=local_rank)
+        _lib.synchronize(local_rank)
+        ms.append((time.perf_counter() - t0) * 1e3)
+        shape = np.array(out.shape)
+        del out
+    launches = _lib.get_counter("cb_line_launches", local_rank, reset=True) / len(ms)
+    redone = _lib.get_counter("cb_overflows_redone", local_rank, reset=True)
+    t_ms = float(np.mean(ms[1:]))
+    fo_ = np.min(np.array(org), axis=0)
+    box_vox, nchunks = 0.0, 0
+    for cz in range(0, int(shape[0]), cs):
+        for cy in range(0, int(shape[1]), cs):
+            for cx in range(0, int(shape[2]), cs):
+                c0 = np.array([cz, cy, cx])
+                c1 = np.minimum(c0 + cs, shape)
+                nchunks += 1
+                for o in org:
+                    lo = np.maximum(np.round(np.array(o) - fo_).astype(int), c0 - halo)
+                    hi = np.minimum(np.round(np.array(o) - fo_).astype(int) + tile, c1 + halo)
+                    if np.all(hi > lo):
+                        box_vox += float(np.prod(hi - lo))
+    out_vox = float(np.prod(shape))
+    alg = float(len(tiles)) * float(np.prod(tile)) * 2 + out_vox * 2 + 16.0 * box_vox
+    achieved = alg / (t_ms * 1e-3) / 1e9
+    leg = {
+        "workload": "C3: 4x4x2 (x,y,z) grid of 256x512x512 uint16 tiles, 20% overlap, weights_func=content_based (sigma 5 / 11), "
+                    "256^3 output chunks + 22 px halo, tiles and result resident in HBM",
+        "output_shape": [int(v) for v in shape], "chunks": nchunks, "ms": t_ms, "first_call_ms": float(ms[0]),
+        "mvoxels_s": out_vox / (t_ms * 1e-3) / 1e6, "line_launches_per_fuse": launches, "chunks_redone_on_exact_passes": redone,
+        "roofline": {"bound": "hbm", "kernel": "content-based fuse() call: crop / blend / normalise, mask scan, 6 line passes, final sum, per chunk",
+                     "algorithmic_bytes": alg, "model": "SURVEY 8d: inputs once + output once + 16 B x voxels of every (halo chunk, view) box",
+                     "box_voxel_views": box_vox, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS},
+    }
+    del tiles, sims
+    if not args.no_cpu_baseline:
+        try:
+            leg["cpu_baseline"] = _cpu_content_based()
+        except Exception as e:   # noqa: BLE001
+            leg["cpu_baseline"] = {"error": repr(e)[:200]}
+    return leg
+
+
+def _cpu_content_based(ts=104):
+    """The oracle (scipy's gaussian_filter / affine_transform, one core) on ONE halo chunk seen by 8 views: 2x2x2 tiles of ts^3."""
+    from multiview_stitcher_amd import sample_data
+    from oracle import fuse_oracle as fo
+    from tests.helpers import sim_to_view, squeeze_field, union_bb
+
+    ov = max(int(ts * 0.2), 1)
+    sims, _, _ = sample_data.generate_tiled_dataset(ndim=3, tile_shape=(ts,) * 3, tiles=(2, 2, 2), overlap=(ov,) * 3, dtype=np.uint16, seed=5)
+    sims = [squeeze_field(s) for s in sims]
+    views, bbs = zip(*[sim_to_view(s) for s in sims])
+    params = [np.eye(4) for _ in sims]
+    out_bb = union_bb(bbs, params, np.ones(3))
+    t0 = time.perf_counter()
+    fused = fo.fuse_np(list(views), params, out_bb, full_view_bbs=list(bbs), weights="content_based",
+                       weights_kwargs={"sigma_1": 5, "sigma_2": 11}, trim_overlap_in_pixels=22)
+    dt = time.perf_counter() - t0
+    fused = fused[0] if isinstance(fused, tuple) else fused
+    vox = float(np.prod(np.asarray(fused).shape))
+    return {"value": vox / dt / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port", "seconds": dt,
+            "sample": f"oracle fuse_np(weights='content_based', sigma 5 / 11) of one chunk of {[int(v) for v in out_bb['shape']]} voxels incl. the 22 px halo, "
+                      f"8 views (2x2x2 uint16 tiles of {ts}^3), {int(vox)} voxels after the trim"}
 
 
 def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
@@ -756,6 +845,12 @@ def main():
             pcie = pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out)
         except Exception as e:   # noqa: BLE001 - an optional leg must not take the bench line down
             pcie = {"error": repr(e)[:300]}
+    c3 = None
+    if world == 1 and not args.no_c3:
+        try:
+            c3 = c3_content_based_leg(torch, dev, local_rank, args)
+        except Exception as e:   # noqa: BLE001 - an optional leg must not take the bench line down
+            c3 = {"error": repr(e)[:300]}
     traffic, traffic_src = fuse_traffic_bytes(grid, tile) if world == 1 else (None, "N > 1")
     # per-rank phase figures (own step time: register + fuse of this rank, without the other ranks' tail)
     own_ms = float(np.mean(reg_ms)) + float(np.mean(fuse_ms))
@@ -818,7 +913,9 @@ def main():
                 "fuse_default_chunksize_ms": default_chunks_ms,
                 "fuse_default_chunksize_first_call_ms": default_chunks_first_ms,
                 "registration_max_abs_error_px": reg_err,
+                "c3_fuse_mvoxels_s": c3.get("mvoxels_s") if c3 else None,
             },
+            "c3_content_based": c3,
             "roofline": {
                 "bound": "hbm",
                 "kernel": "fuse launch of rank 0 = copy_region_kernel + fuse_region_kernel<1|2|4|8> (u16) side by side on forked streams, timed as one unit (first start to last end)",

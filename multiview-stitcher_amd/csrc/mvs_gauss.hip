@@ -1310,6 +1310,19 @@ static int cb_fast_chunk(MvsContext* c, const mvs_view_t* views, int32_t n_views
     hipLaunchKernelGGL(cb_sort_missing_kernel, dim3(n_views), dim3(kCbMissCap), 0, c->stream, drecs, dmiss);
     hipLaunchKernelGGL(cb_tables_kernel, dim3(3, n_views, 2), dim3(256), 0, c->stream, VS, drecs, S, ndim, r1, dfw1, r2, dfw2, dtabs);
     MVS_HIP_TRY(c, hipGetLastError());
+    if (c->cb_mask_count) {      // test / profiling switch: the views' records (how many voxels their masks lack inside the bounding box)
+        std::vector<CbFastRec> hrec((size_t)n_views);
+        MVS_HIP_TRY(c, hipMemcpyAsync(hrec.data(), drecs, (size_t)n_views * sizeof(CbFastRec), hipMemcpyDeviceToHost, c->stream));
+        MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
+        for (int i = 0; i < n_views; ++i) {
+            c->cb_mask_views += 1;
+            c->cb_mask_boxes += hrec[i].nmiss;      // (fast path: the sum of the list lengths)
+            if (getenv("MVS_CB_DEBUG"))
+                fprintf(stderr, "[cb fast] view box lo %d %d %d n %d %d %d: valid %llu, bbox %d..%d %d..%d %d..%d, listed %d\n", VS.v[i].lo[0], VS.v[i].lo[1],
+                        VS.v[i].lo[2], VS.v[i].n[0], VS.v[i].n[1], VS.v[i].n[2], hrec[i].cnt, hrec[i].lo[0], hrec[i].hi[0], hrec[i].lo[1], hrec[i].hi[1],
+                        hrec[i].lo[2], hrec[i].hi[2], hrec[i].nmiss);
+        }
+    }
 
     // ---- 2 * ndim line passes, each ONE launch over all views: I -> T0 -> F -> (squared deviation) T0 -> F -> T0 -> F (3D) ----
     int pass = 0;
@@ -1337,8 +1350,22 @@ static int cb_fast_chunk(MvsContext* c, const mvs_view_t* views, int32_t n_views
                 CbFastView& V = B.v[i];
                 V.T = Tsel[axis][f][i];
                 V.blk0 = nb;
-                const long long bn = (long long)V.n[0] * V.n[1] * V.n[2];
-                if (bn == 0) continue;
+                V.zr0 = 0; V.nzr = V.n[0]; V.yr0 = 0; V.nyr = V.n[1];
+                long long bn = (long long)V.n[0] * V.n[1] * V.n[2];
+                // the weight F of a view is read on the TRIMMED chunk only: a view that does not reach it (a sliver of a neighbour in the
+                // halo) is not filtered at all, and the last pass works on the rows inside it
+                int tl[3], th[3];
+                bool reaches = bn > 0;
+                for (int k = 0; k < 3; ++k) {
+                    tl[k] = std::max(V.lo[k], (int)opts->trim[k]) - V.lo[k];
+                    th[k] = std::min(V.lo[k] + V.n[k], (int)(cs[k] - opts->trim[k])) - V.lo[k];
+                    if (th[k] <= tl[k]) reaches = false;
+                }
+                if (!reaches) { V.nzr = V.nyr = 0; continue; }
+                if (lastp && f == 1) {
+                    V.zr0 = tl[0]; V.nzr = th[0] - tl[0]; V.yr0 = tl[1]; V.nyr = th[1] - tl[1];
+                    bn = (long long)V.nzr * V.nyr * V.n[2];
+                }
                 const long long n_lines = bn / V.n[axis];
                 nb += (int)((n_lines + V.T - 1) / V.T);
                 lds = std::max(lds, cb_fast_lds(V.n[axis], A.radius, V.T, axis == 2));

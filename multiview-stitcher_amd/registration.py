@@ -9,6 +9,7 @@
 from __future__ import annotations
 
 import logging
+import os
 import warnings
 
 import threading
@@ -424,6 +425,60 @@ def _lean_overlap(g1, g2, tol, to_intrinsic):
     return lowers, uppers
 
 
+# ---- crop length on the knife edge (registration.py:229-239, 314-316; mv_graph.py:301-338) ----------------------------------------
+# The reference sizes the overlap crop from the vertices Qhull returns for the intersection of the two view boxes:
+# floor((upper - lower) / spacing + 1).  For views on one pixel grid that quotient is an integer up to Qhull's round-off, so the
+# reference registers N or N - 1 samples along an axis depending on the SIGN of a 1e-13 term that no closed form predicts (it
+# depends on linprog's interior point and Qhull's elimination order).  The closed form registers N.  The default mode therefore
+# asks the reference's own sequence ONCE per pair geometry whether it lands on N - 1 somewhere (memo below: a register + fuse loop
+# over one mosaic pays the ~3 ms per pair once), and only such pairs leave the fast path for the ``overlap_bbox="reference"`` one.
+_KNIFE_MEMO = {}
+_KNIFE_LOCK = threading.Lock()
+_KNIFE_CHECK = [os.environ.get("MVS_KNIFE_CHECK", "1") != "0"]
+
+
+def _reference_crop_shape(g1, g2, tol):
+    """Crop shape of the pair (binned views ``g1``, ``g2``: _TileGeom) as the reference derives it, or None without overlap."""
+    from . import mv_graph
+    from .transformation import transform_pts
+
+    sps = []
+    for g in (g1, g2):
+        sp = {"origin": dict(zip(g.sdims, g.origin)), "spacing": dict(zip(g.sdims, g.spacing)), "shape": dict(zip(g.sdims, g.shape))}
+        if any(tol):
+            sp = si_utils_extend(sp, dict(zip(g.sdims, tol)))
+        sps.append(dict(sp, transform=g.affine))
+    vol, hs = mv_graph.get_overlap_between_pair_of_stack_props(sps[0], sps[1], closed_form=False)
+    if hs is None:
+        return None
+    c = transform_pts(np.asarray(hs.intersections), np.linalg.inv(g1.affine))
+    lo, up = np.min(c, axis=0), np.max(c, axis=0)
+    out_spacing = np.maximum(np.asarray(g1.spacing), np.asarray(g2.spacing))
+    return np.floor((up - lo) / out_spacing + 1).astype(np.int64)
+
+
+def _knife_key(g1, g2, tol):
+    return (tuple(g1.origin), tuple(g1.spacing), tuple(g1.shape), tuple(g1.t), tuple(g2.origin), tuple(g2.spacing), tuple(g2.shape),
+            tuple(g2.t), tuple(tol))
+
+
+def _reference_crop_differs(g1, g2, tol, closed_form_shape):
+    """True when the reference's crop of this pair is not the closed form's (one sample shorter along some axis)."""
+    if not _KNIFE_CHECK[0]:
+        return False
+    key = _knife_key(g1, g2, tol)
+    with _KNIFE_LOCK:
+        hit = _KNIFE_MEMO.get(key)
+    if hit is None:
+        ref = _reference_crop_shape(g1, g2, tol)
+        hit = bool(ref is not None and not np.array_equal(ref, np.asarray(closed_form_shape, dtype=np.int64)))
+        with _KNIFE_LOCK:
+            if len(_KNIFE_MEMO) > 65536:
+                _KNIFE_MEMO.clear()
+            _KNIFE_MEMO[key] = hit
+    return hit
+
+
 def _around10(x):
     """np.around(x, 10) for a Python float: rint(x * 1e10) / 1e10 (round() is half-to-even like rint)."""
     return round(x * 1e10) / 1e10
@@ -563,7 +618,7 @@ def _pair_results_from_plan(ts, qualities, statuses, out_origin, out_spacing, ou
 
 
 def _register_pairs_batched(sims, edges, transform_key, registration_binning, overlap_tolerance, pairwise_reg_func_kwargs, device,
-                            n_lanes, cache):
+                            n_lanes, cache, knife_check=True):
     """compute_pairwise_registrations for the common case in two library calls: plain device-resident images of one dtype whose
     transforms are pure translations, one binning for all pairs, the built-in phase correlation.  ``mvs_plan_pairs`` derives the
     crop windows and pixel affines of all pairs (host code), ``mvs_register_pairs`` registers them on ``n_lanes`` context lanes
@@ -654,6 +709,34 @@ def _register_pairs_batched(sims, edges, transform_key, registration_binning, ov
         return None
     if np.any(pstat != 0):
         raise ValueError("views do not overlap")
+    if knife_check and _KNIFE_CHECK[0]:
+        # pairs whose reference crop is one sample shorter (see _reference_crop_differs) take the overlap_bbox="reference" path one by
+        # one; the others stay here.  One memo entry per MOSAIC geometry: a list of pair indices, looked up with a few hundred bytes.
+        mkey = ("mosaic", n, tr.tobytes(), clen.tobytes(), pr.tobytes(), tolv.tobytes(),
+                np.array([[geoms_b[v].coords[k][0], geoms_b[v].spacing[k]] for v in used for k in range(n)]).tobytes())
+        with _KNIFE_LOCK:
+            odd = _KNIFE_MEMO.get(mkey)
+        if odd is None:
+            odd = [e for e in range(ne) if _reference_crop_differs(geoms_b[edges[e][0]], geoms_b[edges[e][1]], tol, out_shape[e, :n])]
+            with _KNIFE_LOCK:
+                _KNIFE_MEMO[mkey] = odd
+        if odd:
+            odd_set = set(odd)
+            keep = [e for e in range(ne) if e not in odd_set]
+            res = [None] * ne
+            if keep:
+                part = _register_pairs_batched(sims, [edges[e] for e in keep], transform_key, registration_binning, overlap_tolerance,
+                                               pairwise_reg_func_kwargs, device, n_lanes, cache, knife_check=False)
+                if part is None:
+                    return None
+                for e, r in zip(keep, part):
+                    res[e] = r
+            for e in odd:
+                i, j = edges[e]
+                res[e] = register_pair_of_msims(sims[i], sims[j], transform_key, registration_binning=registration_binning,
+                                                overlap_tolerance=overlap_tolerance, pairwise_reg_func_kwargs=pairwise_reg_func_kwargs,
+                                                device=device, _bin_cache=cache, overlap_bbox="reference")
+            return res
     # ---- where the crops come from.  Binned integer tiles whose crops are whole-pixel translations (every regular mosaic): straight
     # from the RAW tiles, the binning applied inside the crop kernel (job.bin) -- no binned copy of a tile is ever made, a pair reads
     # only the slabs its overlap needs.  Otherwise from binned tiles (pre-binned in groups with stream tickets, see _prebin_views). ----
@@ -834,13 +917,26 @@ def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=Non
             and all(list(s_.dims) == list(sdims) for s_ in (sim1, sim2)):
         geoms = [_geom_of(s_, transform_key, _bin_cache) for s_ in (reg_sims_b[0], reg_sims_b[1], sim1, sim2)]
         if all(g.t is not None for g in geoms):
-            return _lean_register_pair(geoms[0], geoms[1], geoms[2], geoms[3], sdims, [overlap_tolerance[d] for d in sdims],
-                                       pairwise_reg_func_kwargs.get("upsample_factor"), transform_key, device)
+            tol_l = [overlap_tolerance[d] for d in sdims]
+            plan = _lean_pair_plan(geoms[0], geoms[1], tol_l) if _KNIFE_CHECK[0] else None
+            if plan is None or not _reference_crop_differs(geoms[0], geoms[1], tol_l, plan["out_shape"]):
+                return _lean_register_pair(geoms[0], geoms[1], geoms[2], geoms[3], sdims, tol_l,
+                                           pairwise_reg_func_kwargs.get("upsample_factor"), transform_key, device)
+            closed_form = False      # the reference registers a crop one sample shorter: this pair takes its sequence
     ov = _get_overlap_bboxes(reg_sims_b[0], reg_sims_b[1], transform_key, None, overlap_tolerance, closed_form=closed_form)
     if ov is None:
         raise ValueError("views do not overlap")
-    lowers, uppers = ov["lowers"], ov["uppers"]
     spacings = [si_utils.get_spacing_from_sim(s) for s in reg_sims_b]
+    if closed_form and _KNIFE_CHECK[0]:
+        # (the generic path -- user registration functions, scaled views: the same rule as the fast paths, see _reference_crop_differs)
+        ov_ref = _get_overlap_bboxes(reg_sims_b[0], reg_sims_b[1], transform_key, None, overlap_tolerance, closed_form=False)
+        if ov_ref is not None:
+            osp = np.maximum(np.array([spacings[0][d] for d in sdims]), np.array([spacings[1][d] for d in sdims]))
+            n_cf = np.floor((ov["uppers"][0] - ov["lowers"][0]) / osp + 1)
+            n_ref = np.floor((ov_ref["uppers"][0] - ov_ref["lowers"][0]) / osp + 1)
+            if not np.array_equal(n_cf, n_ref):
+                ov, closed_form = ov_ref, False
+    lowers, uppers = ov["lowers"], ov["uppers"]
     tol = 1e-6
     reg_sims_b = [
         si_utils.sim_sel_coords(
@@ -1148,10 +1244,13 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
     ``pre_registration_pruning_method`` (None, "alternating_pattern" (default), "shortest_paths_overlap_weighted",
     "otsu_threshold_on_overlap", "keep_axis_aligned").  The groupwise resolution is
     ``overlap_bbox``: how the overlap crop of a pair is sized.  "closed_form" (default): the intersection of the two world boxes
-    of axis-aligned views in closed form -- N samples along an axis the views share exactly.  "reference": the reference's own
-    sequence for every pair (linprog feasible point + Qhull halfspace intersection, registration.py:229-239, 314-316), whose
-    vertices carry Qhull's round-off of ~1e-13, so that ``floor((upper - lower) / spacing + 1)`` comes out as N or N - 1
-    exactly as it does in the reference (per-pair host path, no batching).
+    of axis-aligned views in closed form -- N samples along an axis the views share exactly -- EXCEPT for the pairs on which the
+    reference's own sequence (linprog feasible point + Qhull halfspace intersection, registration.py:229-239, 314-316) lands on
+    N - 1: its vertices carry Qhull's round-off of ~1e-13, so ``floor((upper - lower) / spacing + 1)`` comes out as N or N - 1,
+    and which one no closed form predicts.  The sequence is therefore asked once per pair geometry (~3 ms per pair, memoised: a
+    register + fuse loop over one mosaic pays it in its first call; ``MVS_KNIFE_CHECK=0`` switches the question off), and only
+    the N - 1 pairs (0 of 144 on the north star, 0 of 64 on C3, C1's one pair) leave the batched path for the reference's
+    sequence.  "reference": that sequence for every pair (per-pair host path, no batching).
     ``param_resolution.groupwise_resolution`` (``groupwise_resolution_method``: "global_optimization" (default),
     "shortest_paths", a callable, or "linear" for the plain least-squares solve of ``resolve_translations``;
     ``groupwise_resolution_kwargs`` e.g. ``{"transform": "rigid", "reference_view": 0}``)."""

@@ -495,14 +495,33 @@ def _knife_edge_pairs(n_knife=4, n_plain=2):
     return knife + plain
 
 
+def _routed_to_reference(st1, st2, closed_form_shape):
+    """registration._reference_crop_differs on two stack-property records (zyx arrays) under identity transforms."""
+    from multiview_stitcher_amd import registration
+    from multiview_stitcher_amd import spatial_image_utils as si
+    from multiview_stitcher_amd.sharding import RemoteArray
+
+    geoms = []
+    for st in (st1, st2):
+        nd = len(st["origin"])
+        sd = "zyx"[-nd:]
+        s_ = si.to_spatial_image(RemoteArray(tuple(int(v) for v in st["shape"]), np.uint16), dims=list(sd), scale=dict(zip(sd, st["spacing"])),
+                                 translation=dict(zip(sd, st["origin"])))
+        si.set_sim_affine(s_, np.eye(nd + 1), "k")
+        geoms.append(registration._TileGeom(s_, "k"))
+    return registration._reference_crop_differs(geoms[0], geoms[1], [0.0] * len(st1["origin"]), closed_form_shape)
+
+
 def test_crop_length_knife_edge_reference_mode_end_to_end(hip_device):
     """VERDICT round 4 item 2.  (a) How many pairs of every BASELINE.json geometry have a reference crop (Qhull vertices,
     registration.py:229-239, 314-316) that differs from the product's closed-form crop: recorded in the at-size statistics.
     (b) For every pair that does -- C1's own pair at size and synthetic pairs at fractional stage positions -- the oracle runs end to
     end from the RAW tiles on ITS crop, and the device in ``overlap_bbox="reference"`` mode registers crops of exactly that shape
-    and content and returns the oracle's pixel translation bit for bit, the quality to 1e-5.  What the default mode (closed
-    form, N samples) does on the same pairs is recorded next to it: same integer shift, the sub-pixel refinement may move by
-    one upsampling step because an N-long and an (N - 1)-long crop are different circular correlations."""
+    and content and returns the oracle's pixel translation bit for bit, the quality to 1e-5.  Round 6: so does the DEFAULT mode --
+    it asks the reference's sequence once per pair geometry whether it lands on N - 1 and sends such pairs through it
+    (registration._reference_crop_differs); with that question switched off (the plain closed form, rounds 4-5) the same pairs give
+    the same integer shift, the sub-pixel refinement may move by one upsampling step because an N-long and an (N - 1)-long crop are
+    different circular correlations -- recorded next to it."""
     from multiview_stitcher_amd import registration, sample_data
     from multiview_stitcher_amd import spatial_image_utils as si
     from oracle import reg_oracle as ro
@@ -518,7 +537,7 @@ def test_crop_length_knife_edge_reference_mode_end_to_end(hip_device):
     cases.append({"name": "C1", "sims": flat, "tiles": [np.asarray(f.data) for f in flat], "key": sample_data.METADATA_TRANSFORM_KEY})
     for k, c in enumerate(_knife_edge_pairs()):
         cases.append(dict(c, name=f"synthetic{k}", key="k"))
-    n_knife = n_default_equal = 0
+    n_knife = n_default_equal = n_default_checked = 0
     max_default_shift_diff = 0.0
     for c in cases:
         s0, s1 = c["sims"]
@@ -529,7 +548,22 @@ def test_crop_length_knife_edge_reference_mode_end_to_end(hip_device):
         want = ro.phase_correlation_registration(fixed, moving)
         cap_ref, cap_def = at_size.CapturePairs(keep=300), at_size.CapturePairs(keep=300)
         r_ref = registration.register_pair_of_msims(s0, s1, c["key"], device=0, pairwise_reg_func=cap_ref, overlap_bbox="reference")
-        r_def = registration.register_pair_of_msims(s0, s1, c["key"], device=0, pairwise_reg_func=cap_def)
+        # the default mode: through the generic path (captured crops) and through the lean path (built-in phase correlation)
+        cap_auto = at_size.CapturePairs(keep=300)
+        r_auto = registration.register_pair_of_msims(s0, s1, c["key"], device=0, pairwise_reg_func=cap_auto)
+        r_lean = registration.register_pair_of_msims(s0, s1, c["key"], device=0)
+        got_auto = cap_auto.records[0]
+        assert got_auto["fixed"].shape == fixed.shape, (c["name"], got_auto["fixed"].shape, fixed.shape)
+        np.testing.assert_array_equal(got_auto["got"]["affine_matrix"], want["affine_matrix"])
+        np.testing.assert_array_equal(np.asarray(r_auto["transform"]), np.asarray(r_ref["transform"]))
+        np.testing.assert_array_equal(np.asarray(r_lean["transform"]), np.asarray(r_ref["transform"]))
+        n_default_checked += 1
+        # ... and the plain closed form (the question switched off)
+        registration._KNIFE_CHECK[0] = False
+        try:
+            r_def = registration.register_pair_of_msims(s0, s1, c["key"], device=0, pairwise_reg_func=cap_def)
+        finally:
+            registration._KNIFE_CHECK[0] = True
         got_ref, got_def = cap_ref.records[0], cap_def.records[0]
         # reference mode: the oracle's crop -- shape and samples -- and its result
         assert got_ref["fixed"].shape == fixed.shape and got_ref["moving"].shape == moving.shape, (c["name"], got_ref["fixed"].shape, fixed.shape)
@@ -552,9 +586,19 @@ def test_crop_length_knife_edge_reference_mode_end_to_end(hip_device):
             np.testing.assert_array_equal(got_def["got"]["affine_matrix"], want["affine_matrix"])
             np.testing.assert_array_equal(np.asarray(r_ref["transform"]), np.asarray(r_def["transform"]))
     assert n_knife >= 5
-    at_size._record({"knife_edge_pairs_by_config": {k: {"pairs": v[0], "reference_crop_differs": v[1]} for k, v in counts.items()},
-                     "end_to_end_cases": len(cases), "knife_edge_cases": n_knife, "default_mode_equal_to_reference": n_default_equal,
-                     "default_mode_max_abs_shift_difference_px": max_default_shift_diff,
+    # per config, through the product's own rule: pairs whose DEFAULT-mode crop differs from the reference's (the N - 1 pairs are
+    # routed through the reference's sequence, so none is left)
+    left = {}
+    for name, geo in crop_length.CONFIG_GEOMETRIES.items():
+        _, _, differing = crop_length.count_differing_pairs(*geo)
+        stacks = crop_length.grid_stacks(*geo)
+        left[name] = sum(0 if _routed_to_reference(stacks[e[0]], stacks[e[1]], cf) else 1 for e, _, cf in differing)
+    assert all(v == 0 for v in left.values()), left
+    at_size._record({"knife_edge_pairs_by_config": {k: {"pairs": v[0], "closed_form_crop_differs": v[1], "reference_crop_differs": left[k]}
+                                                    for k, v in counts.items()},
+                     "end_to_end_cases": len(cases), "knife_edge_cases": n_knife, "default_mode_equal_to_reference": n_default_checked,
+                     "plain_closed_form_equal_to_reference": n_default_equal,
+                     "plain_closed_form_max_abs_shift_difference_px": max_default_shift_diff,
                      "voxels": 0, "beyond_plain_bar": 0, "lsb_flips": 0, "max_floor_used": 0.0, "boxes": 0})
 
 

@@ -52,6 +52,41 @@ def test_reference_mode_boxes_equal_the_oracles_qhull_boxes():
 def test_knife_edge_counts_of_the_baseline_geometries():
     counts = {name: crop_length.count_differing_pairs(*geo)[:2] for name, geo in crop_length.CONFIG_GEOMETRIES.items()}
     assert counts["north_star"][0] == 144 and counts["C3"][0] == 64 and counts["C2"][0] == 12 and counts["C1"][0] == 1
-    # with this image's scipy / Qhull the 3D mosaics and C2 are not touched; C1's pair is (511 instead of 512 rows)
+    # (which pairs Qhull's round-off shortens depends on the scipy / Qhull build: with this image's the 3D mosaics and C2 are not
+    # touched and C1's pair is, 511 instead of 512 rows -- only the invariant is asserted)
     assert all(0 <= d <= n for n, d in counts.values())
-    assert counts["C1"][1] == 1
+
+
+def test_default_mode_sends_the_knife_edge_pairs_through_the_reference_sequence():
+    """Round 6: the default ``overlap_bbox="closed_form"`` asks the reference's sequence once per pair geometry whether its crop is
+    one sample shorter than the closed form's (registration._reference_crop_differs, memoised) and routes such pairs through it:
+    the rule's answer equals the oracle's comparison on every pair of the BASELINE geometries and on random grid-aligned pairs."""
+    rng = np.random.default_rng(3)
+    pairs = []
+    for name, geo in crop_length.CONFIG_GEOMETRIES.items():
+        stacks = crop_length.grid_stacks(*geo)
+        idx = [(0, 1)] if len(stacks) == 2 else [(0, 1), (0, geo[0][-1]), (0, len(stacks) - 1 if len(stacks) > 8 else 2)]
+        for a, b in idx:
+            pairs.append((stacks[a], stacks[b]))
+    for _ in range(12):
+        nd = int(rng.integers(2, 4))
+        shp = rng.integers(24, 64, nd)
+        o2 = np.zeros(nd)
+        ax = int(rng.integers(nd))
+        o2[ax] = float(int(0.75 * shp[ax]))
+        pairs.append(({"origin": np.zeros(nd), "spacing": np.ones(nd), "shape": shp}, {"origin": o2, "spacing": np.ones(nd), "shape": shp}))
+    n_odd = 0
+    for st1, st2 in pairs:
+        nd = len(st1["origin"])
+        sims = [_sim(st["origin"], st["spacing"], tuple(int(v) for v in st["shape"])) for st in (st1, st2)]
+        g = [registration._TileGeom(s_, "k") for s_ in sims]
+        plan = registration._lean_pair_plan(g[0], g[1], [0.0] * nd)
+        if plan is None:
+            continue
+        cf = crop_length.closed_form_shape(st1, st2)
+        np.testing.assert_array_equal(plan["out_shape"], cf)
+        want = not np.array_equal(crop_length.reference_shape(st1, st2), cf)
+        assert registration._reference_crop_differs(g[0], g[1], [0.0] * nd, plan["out_shape"]) == want
+        assert registration._reference_crop_differs(g[0], g[1], [0.0] * nd, plan["out_shape"]) == want      # (the memo's answer)
+        n_odd += int(want)
+    assert 0 <= n_odd <= len(pairs)      # (with this image's Qhull: C1's pair and a few of the random ones)

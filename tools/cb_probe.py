@@ -7,7 +7,9 @@ import bench
 from multiview_stitcher_amd import _lib, fusion
 from multiview_stitcher_amd import spatial_image_utils as si
 dev = torch.device("cuda", 0); _lib.init(0)
-grid, tile = np.array([2, 2, 2]), np.array([256, 256, 256])
+# MVS_CB_GRID / MVS_CB_TILE (z,y,x): another mosaic, e.g. BASELINE's C3 itself: MVS_CB_GRID=2,4,4 MVS_CB_TILE=256,512,512
+grid = np.array([int(v) for v in os.environ.get("MVS_CB_GRID", "2,2,2").split(",")])
+tile = np.array([int(v) for v in os.environ.get("MVS_CB_TILE", "256,256,256").split(",")])
 overlap = np.round(tile * 0.2).astype(int)
 tiles, jit, org = bench.make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=5, max_jitter=0)
 sims = bench.build_sims(tiles, org, 0)
@@ -21,6 +23,12 @@ if os.environ.get("MVS_CB_TAPS_F64"):
 if os.environ.get("MVS_CB_COUNT"):
     _lib.set_option("cb_mask_count", 1)
 torch.cuda.synchronize()   # the tiles are produced on torch's stream, the library runs on its own
+if os.environ.get("MVS_CB_PROFILE"):      # where the interpreter spends a fuse() call
+    import cProfile, pstats
+    fusion.fuse(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, weights_func=fusion.content_based, output_chunksize={d: 256 for d in "zyx"}, output_on_backend=True, device=0)
+    pr = cProfile.Profile(); pr.enable()
+    fusion.fuse(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, weights_func=fusion.content_based, output_chunksize={d: 256 for d in "zyx"}, output_on_backend=True, device=0)
+    pr.disable(); pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
 for rep in range(5):
     t0 = time.perf_counter()
     out = fusion.fuse(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, weights_func=fusion.content_based, output_chunksize={d: 256 for d in "zyx"},
