@@ -183,10 +183,19 @@ int mvs_init(int device) {
         // Experiment (profiles/round5_cu_mask.txt): a lane's stream restricted to a share of the compute units, so that the pairs of
         // different lanes run next to each other instead of time-slicing the whole chip.  MVS_LANE_CU_MASK=xcd<k>: lane l gets the CUs
         // of k XCDs starting at XCD (l * k) % 8 (CU i sits on XCD i % 8); spread<k>: k / 8 of the CUs, taken evenly from all XCDs.
-        const char* ev = getenv("MVS_LANE_CU_MASK");
+        // Profiling builds only (-DMVS_PROFILING_ABLATIONS), and only for values of the form xcd[1-8] / spread[1-8]: a stray
+        // environment variable must not change how every lane's stream is created.
+        const char* ev = nullptr;
+#ifdef MVS_PROFILING_ABLATIONS
+        ev = getenv("MVS_LANE_CU_MASK");
+        if (ev) {
+            const size_t pre = !strncmp(ev, "xcd", 3) ? 3 : (!strncmp(ev, "spread", 6) ? 6 : 0);
+            if (!pre || ev[pre] < '1' || ev[pre] > '8' || ev[pre + 1] != '\0') ev = nullptr;
+        }
+#endif
         const int lane = (device >> 8) & 0xff;
         bool masked = false;
-        if (ev && *ev && lane < 15) {
+        if (ev && lane < 15) {
             hipDeviceProp_t prop;
             MVS_HIP_TRY(c, hipGetDeviceProperties(&prop, mvs_hip_device(device)));
             const int ncu = prop.multiProcessorCount;
@@ -216,6 +225,8 @@ int mvs_init(int device) {
     {   // A/B switch for all context lanes of a process (bench.py, tools/): MVS_SSIM_PRUNE=0 scores every candidate in full
         const char* ev = getenv("MVS_SSIM_PRUNE");
         if (ev && *ev) c->ssim_prune = atoi(ev) != 0;
+        ev = getenv("MVS_SSIM_F32");      // (the same for the float32 walk of the pruned search)
+        if (ev && *ev) c->ssim_f32 = atoi(ev) != 0;
         ev = getenv("MVS_FUSE_MIXED");          // A/B switch of the one-launch fuse list (profiles/round5_fuse_mixed.txt)
         if (ev && *ev) c->fuse_mixed = atoi(ev) != 0;
         ev = getenv("MVS_FFT_SLAB_AXES");       // ... and of the crop orientations that take it (bit k = short axis k of (z, y, x))
@@ -346,6 +357,10 @@ int mvs_set_option(int device, const char* key, int64_t value) {
         c->ssim_two_pass = value != 0;
         return MVS_OK;
     }
+    if (!strcmp(key, "ssim_f32")) {
+        c->ssim_f32 = value != 0;
+        return MVS_OK;
+    }
     if (!strcmp(key, "ssim_prune")) {
         c->ssim_prune = value != 0;
         return MVS_OK;
@@ -412,6 +427,7 @@ int mvs_get_counter(int device, const char* key, int32_t reset, double* value_ou
     if (!strcmp(key, "reg_alg_bytes_full")) { *value_out = c->reg_alg_bytes_full; if (reset) c->reg_alg_bytes_full = 0.0; return MVS_OK; }
     if (!strcmp(key, "reg_pairs")) { *value_out = (double)c->reg_pairs; if (reset) c->reg_pairs = 0; return MVS_OK; }
     if (!strcmp(key, "reg_candidates")) { *value_out = (double)c->reg_candidates; if (reset) c->reg_candidates = 0; return MVS_OK; }
+    if (!strcmp(key, "reg_rewalks")) { *value_out = (double)c->reg_rewalks; if (reset) c->reg_rewalks = 0; return MVS_OK; }
     if (!strcmp(key, "reg_pruned")) { *value_out = (double)c->reg_pruned; if (reset) c->reg_pruned = 0; return MVS_OK; }
     if (!strcmp(key, "reg_cand_volumes")) { *value_out = c->reg_cand_volumes; if (reset) c->reg_cand_volumes = 0.0; return MVS_OK; }
     if (!strcmp(key, "reg_slab_pairs")) { *value_out = (double)c->reg_slab_pairs; if (reset) c->reg_slab_pairs = 0; return MVS_OK; }

@@ -1067,6 +1067,9 @@ __global__ __launch_bounds__(1024) void crop_bin_kernel(const TIn* __restrict__ 
     const int gpr = (ox + 7) / 8;
     const long long ngroups = (long long)oz * oy * gpr;
     const double inv = 1.0 / ((double)bz * by * bx);
+    // the 4-byte / 16-byte loads of the bx == 2 branches read PAIRS of 16-bit samples: every pair must start on a 4-byte boundary
+    // (window base and both strides; a tile of odd width has odd strides) -- otherwise the generic branch
+    const bool pairs_aligned = (((unsigned long long)data & 3ull) == 0ull) && ((stride_z & 1ll) == 0ll) && ((stride_y & 1ll) == 0ll);
     float smn = INFINITY, smx = -INFINITY;
     long long snv = 0;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (long long)gridDim.x * blockDim.x) {
@@ -1084,7 +1087,7 @@ __global__ __launch_bounds__(1024) void crop_bin_kernel(const TIn* __restrict__ 
         const TIn* p = data + (long long)iz * bz * stride_z + (long long)iy * by * stride_y + (long long)ix * bx;
         float v[8];
         bool in[8];
-        if (sizeof(TIn) == 2 && bx == 2 && zy && xg + 8 <= ox && ix >= 0 && ix + 8 <= nx) {
+        if (sizeof(TIn) == 2 && bx == 2 && pairs_aligned && zy && xg + 8 <= ox && ix >= 0 && ix + 8 <= nx) {
             unsigned int acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};       // at most 2 by bz 65535: fits for by bz <= 32767
             for (int dz = 0; dz < bz; ++dz)
                 for (int dy = 0; dy < by; ++dy) {
@@ -1096,7 +1099,7 @@ __global__ __launch_bounds__(1024) void crop_bin_kernel(const TIn* __restrict__ 
                 }
 #pragma unroll
             for (int k = 0; k < 8; ++k) { v[k] = (float)(TIn)((double)acc[k] * inv); in[k] = true; }
-        } else if (sizeof(TIn) == 2 && bx == 2) {
+        } else if (sizeof(TIn) == 2 && bx == 2 && pairs_aligned) {
             // a group that hangs over the crop or the window (the narrow crops of x neighbours end in one): one 4-byte load per
             // output and raw row instead of the generic double-precision loops
             for (int j = 0; j < 8; ++j) {

@@ -48,6 +48,8 @@ struct MvsContext {
     bool fuse_mixed = false;           // option "fuse_mixed": copy / one-view / two-view bricks in ONE launch over a space-ordered list
     bool serial_classes = false;       // option "serial_classes": launch them one after the other on the main stream instead
     bool reg_unfused = false;          // test switch: the phase correlation runs its separate launches (pack, cross power, peak search, min / max) instead of the fused passes
+    bool ssim_f32 = true;              // option "ssim_f32" (default 1): the pruned arg-max search walks in float32 and re-walks near ties in float64
+    long long reg_rewalks = 0;         // candidates the pruned search walked again in float64 (counter "reg_rewalks")
     bool ssim_prune = true;            // option "ssim_prune" (default 1; environment MVS_SSIM_PRUNE=0 turns it off for new contexts)
     bool fft_no_pair = false;          // test switch: the first inverse pass of the phase correlation takes its lines in flat order (no partner pairs)
     bool ssim_two_pass = false;        // test switch: batched candidates go through the separate z and y/x SSIM launches instead of the fused walk

@@ -305,13 +305,13 @@ __device__ __forceinline__ int reflect_index(int p, int len) {
 // per thread.  2 double operations and one float->double conversion per output instead of WIN of each, and no double
 // division (x * (1 / WIN) rounds to the same float32 as x / WIN except on exact ties of the final rounding): these
 // kernels were bound by exactly that arithmetic, not by memory.
-template <int WIN, int NOUT>
+template <int WIN, int NOUT, typename ACC = double>
 __device__ __forceinline__ void box_means(const float (&v)[NOUT + WIN - 1], float (&out)[NOUT]) {
-    constexpr double inv = 1.0 / (double)WIN;
-    double d[NOUT + WIN - 1];
+    constexpr ACC inv = (ACC)(1.0 / (double)WIN);
+    ACC d[NOUT + WIN - 1];
 #pragma unroll
-    for (int k = 0; k < NOUT + WIN - 1; ++k) d[k] = (double)v[k];
-    double run = 0.0;
+    for (int k = 0; k < NOUT + WIN - 1; ++k) d[k] = (ACC)v[k];
+    ACC run = (ACC)0;
 #pragma unroll
     for (int j = 0; j < WIN; ++j) run += d[j];
     out[0] = (float)(run * inv);
@@ -617,16 +617,20 @@ struct FusedBatch { FusedCand c[kMaxResident]; };
 #define MVS_SSIM_WPE_LO 3
 #define MVS_SSIM_WPE_HI 4
 #endif
-template <int WIN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVS_SSIM_WPE_LO, MVS_SSIM_WPE_HI)))
-void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch B,
+// F32 (round 6): the running sums and the box means in float32.  The SSIM of a candidate never leaves the registration -- only its
+// arg max does (registration.py:558-563) -- so the pruned search walks in float32 and re-walks, with this kernel's float64 form, the
+// candidates that end within a margin of the leader (see the search).  The running sums restart with every z segment, so their
+// drift is bounded by the segment length; the means of the fixed image (ux / uxx) stay the float64 ones.
+template <int WIN, bool F32>
+__device__ __forceinline__ void ssim_fused_batch_body(const float* __restrict__ im0, Shape3 S, const FusedBatch& B,
                                                                const float* __restrict__ ux, const float* __restrict__ uxx, int zseg,
                                                                float cov_norm, float C1, float C2, float* __restrict__ pmax,
                                                                int* __restrict__ phasnan, double* __restrict__ psum, int selk) {
     constexpr int H = WIN / 2, pad = (WIN - 1) / 2, TY = 16, TX = 56, LY = TY + 2 * H, LX = TX + 2 * H;
     constexpr int NO = 4, NI = NO + 2 * H;           // outputs / inputs of one y- or x-pass item
     constexpr int NR = (LY + 3) / 4;                 // patch rows per thread: row = (tid >> 6) + 4 k, column = tid & 63
-    constexpr double inv = 1.0 / (double)WIN;
+    typedef typename std::conditional<F32, float, double>::type run_t;
+    constexpr run_t inv = (run_t)(1.0 / (double)WIN);
     static_assert(LX <= 64 && TY % NO == 0 && TX % NO == 0 && (TY * TX) / NO <= 256 && TY / NO == 4, "tile layout");
     __shared__ float sz_[3][LY][LX + 1];             // z-filtered y, yy, xy of the current plane (tile + halo)
     __shared__ float sy_[3][TY][LX + 1];             // ... filtered along y as well
@@ -673,9 +677,9 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
                 out1 = out1 || (!in1[k] && prow < LY && col < LX);
             }
             if (out1) hn = 1;
-            double s1[NR], s3[NR], s4[NR];
+            run_t s1[NR], s3[NR], s4[NR];
 #pragma unroll
-            for (int k = 0; k < NR; ++k) { s1[k] = 0.0; s3[k] = 0.0; s4[k] = 0.0; }
+            for (int k = 0; k < NR; ++k) { s1[k] = (run_t)0; s3[k] = (run_t)0; s4[k] = (run_t)0; }
             // plane p + 1's samples (new: plane p + 1, old: plane p + 1 - WIN) are requested right after plane p's have been
             // folded into the running sums, so that their latency hides behind the LDS phases of plane p
             float an[NR], bn[NR], ao[NR], bo[NR];
@@ -720,9 +724,9 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
                         b = (b != b) ? 0.f : b;
                         b2 = (b2 != b2) ? 0.f : b2;
                         // products in float32 like `im * im`; tmp += new - old like uniform_filter1d
-                        s1[k] += (double)b - (double)b2;
-                        s3[k] += (double)(b * b) - (double)(b2 * b2);
-                        s4[k] += (double)(a * b) - (double)(a2 * b2);
+                        s1[k] += (run_t)b - (run_t)b2;
+                        s3[k] += (run_t)(b * b) - (run_t)(b2 * b2);
+                        s4[k] += (run_t)(a * b) - (run_t)(a2 * b2);
                         if (p >= z0 + H) {
                             sz_[0][row][col] = (float)(s1[k] * inv);
                             sz_[1][row][col] = (float)(s3[k] * inv);
@@ -742,7 +746,7 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
                         float v[NI], f[NO];
 #pragma unroll
                         for (int k = 0; k < NI; ++k) v[k] = sz_[a][rc * NO + k][c];
-                        box_means<WIN, NO>(v, f);
+                        box_means<WIN, NO, run_t>(v, f);
 #pragma unroll
                         for (int k = 0; k < NO; ++k) sy_[a][rc * NO + k][c] = f[k];
                     }
@@ -758,7 +762,7 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
                             float v[NI];
 #pragma unroll
                             for (int k = 0; k < NI; ++k) v[k] = sy_[a][row][ch * NO + k];
-                            box_means<WIN, NO>(v, f[a]);
+                            box_means<WIN, NO, run_t>(v, f[a]);
                         }
 #pragma unroll
                         for (int k = 0; k < NO; ++k) {
@@ -793,6 +797,23 @@ void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch
         const size_t o = (size_t)blockIdx.y * kStatBlocks + blockIdx.x;
         pmax[o] = mx; phasnan[o] = hn; psum[o] = acc;
     }
+}
+
+#ifndef MVS_SSIM_F32_WPE_LO
+#define MVS_SSIM_F32_WPE_LO 3
+#define MVS_SSIM_F32_WPE_HI 4
+#endif
+template <int WIN, bool F32 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVS_SSIM_WPE_LO, MVS_SSIM_WPE_HI)))
+void ssim_fused_batch_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch B, const float* __restrict__ ux, const float* __restrict__ uxx, int zseg,
+                             float cov_norm, float C1, float C2, float* __restrict__ pmax, int* __restrict__ phasnan, double* __restrict__ psum, int selk) {
+    ssim_fused_batch_body<WIN, false>(im0, S, B, ux, uxx, zseg, cov_norm, C1, C2, pmax, phasnan, psum, selk);
+}
+template <int WIN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MVS_SSIM_F32_WPE_LO, MVS_SSIM_F32_WPE_HI)))
+void ssim_fused_batch_f32_kernel(const float* __restrict__ im0, Shape3 S, FusedBatch B, const float* __restrict__ ux, const float* __restrict__ uxx, int zseg,
+                                 float cov_norm, float C1, float C2, float* __restrict__ pmax, int* __restrict__ phasnan, double* __restrict__ psum, int selk) {
+    ssim_fused_batch_body<WIN, true>(im0, S, B, ux, uxx, zseg, cov_norm, C1, C2, pmax, phasnan, psum, selk);
 }
 
 // ---- the fixed image's own window means (x, x * x) by the same walk: one launch instead of the z pass + the y / x pass, and the
@@ -1844,6 +1865,13 @@ int mvs_score_candidates_impl(int device, const float* fixed, const float* movin
                 int ahn[kMaxResident];
                 unsigned int done[kMaxResident], masks[kMaxResident];
                 for (int j = 0; j < kMaxResident; ++j) { acc[j] = 0.0; amx[j] = -INFINITY; ahn[j] = 0; done[j] = 0; masks[j] = 0; }
+                // float32 walk (option ssim_f32, default on) + float64 re-walk of the candidates that end within `margin` (mean SSIM) of
+                // the best: a float32 window variance is off by <= a few 1e-7 (values rescaled to [0, 1], sums restarted per segment)
+                // against C2 = 9e-4 in the denominator -- up to ~1e-3 of a voxel's value in flat regions, far less in the mean over a
+                // crop; 1e-3 of the MEAN is the margin.  Candidates are dropped only when their bound stays below the best sum by it.
+                const bool walk_f32 = c->ssim_f32;
+                const double margin = walk_f32 ? 1e-3 : 0.0;
+                bool rewalk = false;
                 auto run_round = [&]() -> int {
                     FusedBatch fb = fused_batch;
                     int maxsel = 0;
@@ -1854,8 +1882,13 @@ int mvs_score_candidates_impl(int device, const float* fixed, const float* movin
                     }
                     if (maxsel == 0) return MVS_OK;
                     const int gx = std::min(kStatBlocks, maxsel);
-                    MVS_DUP("ssim_fused", hipLaunchKernelGGL(ssim_fused_batch_kernel<7>, dim3(gx, nb), dim3(256), 0, c->stream, im0, S, fb, setB[2], setB[3], zseg,
-                                       batch_cov_norm, C1, C2, pmax, phasnan, psum, K));
+                    // (117 VGPRs at 3-4 waves per SIMD; forced to 5 waves it spills: pairwise 38.9 -> 43.2 ms, measured)
+                    if (walk_f32 && !rewalk)
+                        MVS_DUP("ssim_fused", hipLaunchKernelGGL(ssim_fused_batch_f32_kernel<7>, dim3(gx, nb), dim3(256), 0, c->stream, im0, S, fb, setB[2], setB[3], zseg,
+                                           batch_cov_norm, C1, C2, pmax, phasnan, psum, K));
+                    else
+                        MVS_DUP("ssim_fused", hipLaunchKernelGGL(ssim_fused_batch_kernel<7>, dim3(gx, nb), dim3(256), 0, c->stream, im0, S, fb, setB[2], setB[3], zseg,
+                                           batch_cov_norm, C1, C2, pmax, phasnan, psum, K));
                     MVS_DUP("finish", hipLaunchKernelGGL(finish_region_kernel, dim3(nb), dim3(256), 0, c->stream, pmax, phasnan, psum, reg_out, gx));
                     MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
                     for (int j = 0; j < nb; ++j) {
@@ -1924,7 +1957,24 @@ int mvs_score_candidates_impl(int device, const float* fixed, const float* movin
                         if (!fused_batch.c[j].src || done[j] == kAll || pruned[j]) continue;
                         // (a candidate whose samples so far do not exceed im1_min may still be the reference's `continue` case: in full)
                         ub[j] = acc[j] + (Ntot - vol_of(done[j])) * (1.0 + slack);
-                        if ((double)amx[j] > im1_min && ub[j] < s_best - 1e-9 * Ntot) pruned[j] = true;
+                        if ((double)amx[j] > im1_min && ub[j] < s_best - (1e-9 + margin) * Ntot) pruned[j] = true;
+                    }
+                }
+                if (walk_f32 && have_best) {
+                    // the complete candidates within the margin of the best float32 sum: with two or more of them the arg max is decided
+                    // by their float64 sums (whole volume, fresh accumulators)
+                    int near = 0;
+                    for (int j = 0; j < nb; ++j)
+                        if (fused_batch.c[j].src && done[j] == kAll && !pruned[j] && !excluded(j) && std::isfinite(acc[j]) && acc[j] >= s_best - margin * Ntot) ++near;
+                    if (near >= 2) {
+                        rewalk = true;
+                        for (int j = 0; j < nb; ++j) {
+                            const bool sel = fused_batch.c[j].src && done[j] == kAll && !pruned[j] && !excluded(j) && std::isfinite(acc[j]) && acc[j] >= s_best - margin * Ntot;
+                            masks[j] = sel ? kAll : 0u;
+                            if (sel) { acc[j] = 0.0; c->reg_rewalks += 1; c->reg_cand_volumes += 1.0; }
+                        }
+                        rc = run_round();
+                        if (rc) return rc;
                     }
                 }
                 if (dbg) {

@@ -17,6 +17,8 @@ from itertools import product
 import os
 import shutil
 
+import threading
+
 import numpy as np
 
 from . import _lib, mv_graph, param_utils, weights
@@ -234,6 +236,8 @@ def fuse_np(
                 f"(largest distance from it: chunk {off_c:.3g} px, slabs {off_s:.3g} px); the parameters of this chunk are derived per chunk, so its "
                 "voxels may differ in the last bit from the same voxels fused through another chunk, launch block or shard",
                 IndexFrameWarning, stacklevel=2)
+            if _record is not None:
+                _record["no_replay"] = True      # (a replayed call would not repeat the warning)
     matrices, offsets = get_pixel_affines(p_inv, ref_in_origins, in_spacings, ref_out_origin, out_spacing)
     tables, sup_origins, sup_spacings = weights.blending_supports(
         full_origins, np.stack([_as_zyx(b["spacing"], sdims) for b in fv]),
@@ -665,6 +669,8 @@ def _plan_chunks(sparams, views_bb, output_stack_properties, output_chunksize, o
 
 _REPLAY = [True]           # tests / A-B: derive everything on every call
 _REPLAY_MEMO = {}
+_REPLAY_CAP = 32                     # geometries kept (8 ranks x a few mosaics; an entry is a few KB of view records)
+_REPLAY_LOCK = threading.Lock()      # fuse() is also driven from one thread per GPU: lookups, evictions and inserts are serialised
 
 
 def _hashable(v):
@@ -813,7 +819,8 @@ def _fuse_once(
                                output_stack_properties, output_chunksize, overlap_in_pixels, trim_overlap, interpolation_order,
                                blending_widths, frame_origin)
         if fast_key is not None:
-            hit = _REPLAY_MEMO.get(fast_key)
+            with _REPLAY_LOCK:
+                hit = _REPLAY_MEMO.get(fast_key)
             if hit is not None:
                 return _replay_fuse(hit, images, transform_key, device)
             record = {}
@@ -1123,15 +1130,17 @@ def _fuse_once(
         dev_full.mark_written()
         data = dev_full
         dims = (list(nsdims) if n_fields > 1 else []) + list(sdims)
-        if record is not None and record.get("calls") == 1 and "views" in record and not nsdims and n_fields == 1 \
+        if record is not None and record.get("calls") == 1 and "views" in record and not record.get("no_replay") and not nsdims and n_fields == 1 \
                 and tuple(dev_full.shape) == record["res_shape"]:
             # one launch block wrote the whole result: replayable.  Slab pointers are remembered as offsets into their tiles.
             base = np.array([images[iv].data.ptr for iv in record["view_index"]], dtype=np.uint64)      # (all device-resident: fuse_np recorded)
-            if len(_REPLAY_MEMO) >= 8:
-                _REPLAY_MEMO.pop(next(iter(_REPLAY_MEMO)))
-            _REPLAY_MEMO[fast_key] = dict(record, byte_offsets=(record["ptrs"] - base).astype(np.uint64), dims=tuple(dims),
-                                          spacing=dict(output_stack_properties["spacing"]), origin=dict(output_stack_properties["origin"]),
-                                          dtype=np.dtype(images[0].dtype), ndim=len(sdims))
+            entry = dict(record, byte_offsets=(record["ptrs"] - base).astype(np.uint64), dims=tuple(dims),
+                         spacing=dict(output_stack_properties["spacing"]), origin=dict(output_stack_properties["origin"]),
+                         dtype=np.dtype(images[0].dtype), ndim=len(sdims))
+            with _REPLAY_LOCK:
+                while len(_REPLAY_MEMO) >= _REPLAY_CAP:
+                    _REPLAY_MEMO.pop(next(iter(_REPLAY_MEMO)), None)      # (oldest first: dicts keep insertion order)
+                _REPLAY_MEMO[fast_key] = entry
     else:
         data = result if zarr_out is None else zarr_out[...]
         dims = list(nsdims) + list(sdims)

@@ -721,6 +721,7 @@ def _register_pairs_batched(sims, edges, transform_key, registration_binning, ov
             with _KNIFE_LOCK:
                 _KNIFE_MEMO[mkey] = odd
         if odd:
+            cache.reference_pairs = len(odd)
             odd_set = set(odd)
             keep = [e for e in range(ne) if e not in odd_set]
             res = [None] * ne
@@ -1126,6 +1127,7 @@ class _BinCache:
         self._items = {}
         self.hits = self.misses = 0      # (tests: the pre-binned tiles of register() must be found by every pair)
         self.raw_crops = 0               # pairs whose crops were taken from the raw tiles (no binned copies at all)
+        self.reference_pairs = 0         # pairs the default crop rule sent through the reference's Qhull sequence (N - 1 samples)
 
     def put(self, key, value, keep=None, ticket=None):
         """Store a finished value (``keep``: the objects whose id() is part of ``key``; the slot holds them alive).  ``ticket``:
@@ -1385,7 +1387,8 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
                 si_utils.set_sim_affine(m, p, new_transform_key, base_transform_key=transform_key)
     if return_dict:
         return {"params": params, "bin_cache_stats": None if bin_cache is None else {"hits": bin_cache.hits, "misses": bin_cache.misses,
-                                                                                        "pairs_with_raw_crops": bin_cache.raw_crops},
+                                                                                        "pairs_with_raw_crops": bin_cache.raw_crops,
+                                                                                        "pairs_on_reference_sequence": bin_cache.reference_pairs},
                 "groupwise_resolution": {"info": resolution_info},
                 "pairwise_registration": {"edges": edges, "results": all_results,
                                           "metrics": {"qualities": {e: r["quality"] for e, r in zip(edges, all_results[0])}}}}

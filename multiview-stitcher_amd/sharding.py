@@ -95,8 +95,11 @@ def tile_owners(stack_props_list, affines, subboxes, sdims=None):
 
 def edge_owners(edges, owners):
     """The rank that registers each pair.  A pair whose two views live on one rank stays there; a pair ACROSS two ranks goes, in edge
-    order, to whichever of the two has fewer pairs so far (ties: the owner of the fixed view) -- both hold the partner tile in their
-    halo anyway.  Always handing it to the fixed view's owner (rounds 3-4) loaded the ranks 12 ... 24 pairs on the 4 x 4 x 4 grid
+    order, to whichever of the two has fewer pairs so far (ties: the owner of the fixed view).  INVARIANT: the assignment is a function
+    of the WHOLE ordered edge list, not of a pair alone -- ``rank_tiles`` (which puts the partners of a rank's assigned pairs into its
+    halo) and ``ShardedPairExecutor`` must be given the same ordered list, the one ``register()`` produces after pruning; a halo
+    derived from another pruning, a ``pairs=`` subset or a quality-filtered list does not hold the tiles this assignment needs (the
+    executor then raises "voxels live on rank N").  Always handing it to the fixed view's owner (rounds 3-4) loaded the ranks 12 ... 24 pairs on the 4 x 4 x 4 grid
     over 8 ranks (the low corner brick owns the fixed view of every pair across its three inner faces); balanced it is 18 each, and
     the pairwise phase of a step lasts as long as its busiest rank.  Deterministic: every rank derives the same assignment."""
     load = {}
@@ -180,7 +183,8 @@ class RemoteArray:
 
 class ShardedPairExecutor:
     """``pairwise_executor`` for one-process-per-GPU runs (registration.register(..., pairwise_executor=...),
-    registration.py:2634-2655): this rank registers the pairs whose fixed view it owns, then every rank receives all
+    registration.py:2634-2655): this rank registers the pairs ``edge_owners`` assigns to it (pairs inside its brick, and its share
+    of the pairs across two bricks -- a function of the whole ordered edge list, see there), then every rank receives all
     results (``gather(obj) -> list over ranks``; default: one fixed-size float64 tensor all-gather, see _gather_results)."""
 
     reads_only = True      # register() may hand over the images themselves instead of per-time-point copies (with a custom register_fn: set False)
