@@ -491,118 +491,58 @@ def _cpu_content_based(ts=104):
 
 
 def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
-    """PCIe-inclusive run of one mosaic: the tiles start in pinned host memory and the fused mosaic ends
-    there.  Uploads run on a copy stream in tile order while the pairs whose two tiles have arrived are registered;
-    the mosaic is fused in z slabs and every finished slab is downloaded while the next one is fused."""
-    from multiview_stitcher_amd import _lib, fusion, registration, sharding
-    from multiview_stitcher_amd import spatial_image_utils as si
+    """PCIe-inclusive run of one mosaic through the PUBLIC API only: the tiles start in pinned host memory
+    (device.pinned_empty) and the fused mosaic ends there.  ``device.to_device_async`` queues the uploads in tile order on the
+    device's copy stream (csrc/mvs_transfer.hip), ``registration.register`` registers every pair when its two tiles have landed
+    (the pair jobs carry the uploads' tickets), ``fusion.fuse_to_host`` fuses the mosaic in z slabs and downloads every finished
+    slab while the next one is fused."""
+    from multiview_stitcher_amd import device as dv
+    from multiview_stitcher_amd import _lib, fusion, registration
 
-    host_tiles = []
-    for t in tiles:
-        h = torch.empty(t.shape, dtype=torch.int16, pin_memory=True)
-        h.copy_(t.view(torch.int16))
-        host_tiles.append(h)
-    torch.cuda.synchronize()
-    # The copy stream gets a priority of its own: HIP multiplexes the streams of a process onto a few hardware queues PER PRIORITY
-    # LEVEL, and a stream whose queue holds the barrier packets of 64 queued tile uploads stalls every compute stream that
-    # shares the queue -- with a normal-priority copy stream the first wave of pairs took 242 ms (until the last tile had
-    # arrived) instead of ~11 and the registration did not overlap with the uploads at all.
-    copy_stream = torch.cuda.Stream(device=dev, priority=-1)
+    host_sims = []
+    for s_ in sims:
+        h = dv.pinned_empty(s_.data.shape, s_.data.dtype)
+        h[...] = s_.data.get()
+        host_sims.append(s_.copy(data=h))
     n_slabs = 8
-
     trace = {}
+    out_host = [None]
 
     def run():
-        import threading
-
-        events = []
-        t0 = time.perf_counter()
-        with torch.cuda.stream(copy_stream):
-            for t, h in zip(tiles, host_tiles):
-                t.view(torch.int16).copy_(h, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(copy_stream)
-                events.append(ev)
-        trace.clear()
-        trace["waves"] = []
-
-        def upload_watch():      # when did the last tile arrive?  (H2D rate of the phase, reported next to the pipeline's figures)
-            events[-1].synchronize()
-            trace["upload_done_ms"] = (time.perf_counter() - t0) * 1e3
-        watcher = threading.Thread(target=upload_watch)
-        watcher.start()
-
-        def executor(msims, edges, register_kwargs):
-            # one task per pair, in the order in which the pairs' later tile arrives; a worker waits for THAT tile's upload and
-            # registers the pair on its own context lane -- no wave barrier, so what runs after the last tile has arrived is
-            # the three pairs of the last tile (waves of 18 pairs left an 11 ms tail)
-            order = sorted(range(len(edges)), key=lambda k: max(edges[k]))
-            results = [None] * len(edges)
-            pool, lanes, lane_lock = registration._pair_pool(8)
-            cache = registration._BinCache()
-            t_first = [None]
-
-            def work(k):
-                events[max(edges[k])].synchronize()      # both tiles of the pair are resident
-                if t_first[0] is None:
-                    t_first[0] = (time.perf_counter() - t0) * 1e3
-                tid = threading.get_ident()
-                with lane_lock:
-                    lane = lanes.setdefault(tid, len(lanes))
-                i, j = edges[k]
-                results[k] = registration.register_pair_of_msims(msims[i], msims[j], device=(local_rank & 0xff) | (lane << 8),
-                                                                 _bin_cache=cache, **register_kwargs)
-
-            futs = [pool.submit(work, k) for k in order]
-            for f in futs:
-                f.result()
-            trace["waves"].append((round(t_first[0], 1), round((time.perf_counter() - t0) * 1e3, 1), len(edges)))
-            return results
-
-        registration.register(sims, transform_key=key_in, new_transform_key=key_out, device=local_rank,
-                              pre_registration_pruning_method=args.pruning, pairwise_executor=executor)
-        t_reg = time.perf_counter()
-        osp = fusion._bb_dicts(fusion.process_output_stack_properties(sims, None, None, None, None, "union", key_out), ["z", "y", "x"])
-        nz = int(osp["shape"]["z"])
-        cuts = np.linspace(0, nz, n_slabs + 1).round().astype(int)
-        host_slabs, keep = [], []
-        for k in range(n_slabs):
-            sub = {"origin": dict(osp["origin"], z=osp["origin"]["z"] + cuts[k] * osp["spacing"]["z"]), "spacing": osp["spacing"],
-                   "shape": dict(osp["shape"], z=int(cuts[k + 1] - cuts[k]))}
-            fused = fusion.fuse(sims, transform_key=key_out, output_stack_properties=sub, output_chunksize={d: 1 << 30 for d in "zyx"},
-                                output_on_backend=True, device=local_rank)
+        registration._pair_timeline = pairs = []
+        try:
             _lib.synchronize(local_rank)
-            d = torch.as_tensor(_SignedView(fused.data), device="cuda")
-            if len(host_slabs) <= k:
-                host_slabs.append(torch.empty(d.shape, dtype=torch.int16, pin_memory=True))
-            with torch.cuda.stream(copy_stream):
-                host_slabs[k].copy_(d, non_blocking=True)
-            keep.append((fused, d))
-        copy_stream.synchronize()
+            t0 = time.perf_counter()
+            m0 = dv.mark(local_rank)
+            a_sims = dv.to_device_async(host_sims, local_rank)
+            uploads = [a.data.ready_ticket for a in a_sims]
+            registration.register(a_sims, transform_key=key_in, new_transform_key=key_out, device=local_rank,
+                                  pre_registration_pruning_method=args.pruning)
+        finally:
+            registration._pair_timeline = None
+        t_reg = time.perf_counter()
+        fused, slabs = fusion.fuse_to_host(a_sims, transform_key=key_out, n_slabs=n_slabs, out=out_host[0], device=local_rank, return_timeline=True)
         t1 = time.perf_counter()
-        watcher.join()
-        vox = float(nz) * osp["shape"]["y"] * osp["shape"]["x"]
-        return t1 - t0, t_reg - t0, vox, host_slabs
+        out_host[0] = np.asarray(fused.data)
+        up_ms = [dv.ticket_elapsed_ms(m0, t) for t in uploads]
+        pair_ms = sorted(dv.ticket_elapsed_ms(m0, t) for _, t in pairs)
+        trace.update(upload_done_ms=max(up_ms), first_pair_done_ms=pair_ms[0] if pair_ms else None, last_pair_done_ms=pair_ms[-1] if pair_ms else None,
+                     pairs_done_before_last_upload=int(sum(t < max(up_ms) for t in pair_ms)), pairs=len(pair_ms),
+                     slab_fused_ms=[round(f, 1) for f, _ in slabs], slab_downloaded_ms=[round(d, 1) for _, d in slabs])
+        return t1 - t0, t_reg - t0, float(np.prod(out_host[0].shape))
 
-    run()                                  # warm-up (pinned result buffers, plans)
-    total, t_reg, vox, _ = run()
-    h2d_gb = sum(t.numel() * 2 for t in tiles) / 1e9
+    run()                                  # warm-up (pinned result buffer, device blocks of the uploads, plans)
+    total, t_reg, vox = run()
+    h2d_gb = sum(int(np.prod(h.data.shape)) * 2 for h in host_sims) / 1e9
     return {"value": vox / total / 1e6, "unit": "Mvoxels/s", "ms": total * 1e3, "register_phase_ms": t_reg * 1e3,
             "h2d_gb": h2d_gb, "d2h_gb": vox * 2 / 1e9, "fuse_slabs": n_slabs,
             "upload_done_ms": trace.get("upload_done_ms"), "h2d_gb_per_s": h2d_gb / (trace["upload_done_ms"] * 1e-3) if trace.get("upload_done_ms") else None,
-            "d2h_gb_per_s": vox * 2 / 1e9 / max(total - t_reg, 1e-9), "register_waves_ms": trace.get("waves"),
-            "note": "tiles in pinned host memory -> async uploads in tile order (copy stream of its own priority) overlapped with the "
-                    "registration of the pairs whose tiles have arrived (one task per pair, 8 lanes) -> resolution -> fuse in z slabs, "
-                    "each slab's download overlapped with the next slab's fuse; register_waves_ms = (first pair started, last pair "
-                    "done, pairs)"}
-
-
-class _SignedView:
-    """torch's __cuda_array_interface__ import has no uint16: hand the bytes over as int16."""
-
-    def __init__(self, arr):
-        self.__cuda_array_interface__ = dict(arr.__cuda_array_interface__, typestr="<i2")
-        self.owner = arr
+            "d2h_gb_per_s": vox * 2 / 1e9 / max(total - t_reg, 1e-9), "timeline": trace,
+            "api": "device.pinned_empty, device.to_device_async, registration.register, fusion.fuse_to_host (no torch streams, no private helpers)",
+            "note": "tiles in pinned host memory -> uploads in tile order on the device's copy stream, overlapped with the registration of "
+                    "the pairs whose tiles have arrived (pair jobs wait for their tiles' tickets on their lanes) -> resolution -> fuse in z "
+                    "slabs, each slab's download overlapped with the next slab's fuse; timeline: timed tickets, ms since the first upload "
+                    "was queued"}
 
 
 def main():

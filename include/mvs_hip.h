@@ -273,6 +273,24 @@ int mvs_bin_mean_batch_async(int device, int32_t n_views, const void* const* in,
 int mvs_event_record(int device, uint64_t* ticket_out);
 int mvs_event_wait(int device, uint64_t ticket);
 
+/* ---- Transfers that overlap with the kernels (csrc/mvs_transfer.hip).  The reference's users hand fuse() host- or Zarr-backed
+ * arrays and stream the fused chunks out (fusion/_core.py:1068-1170, 2044-2156; spatial_image_utils.py:712-860); SURVEY 8d(2)
+ * counts H2D / D2H into the end-to-end figure.  mvs_host_alloc: pinned host memory (what an asynchronous copy needs to be
+ * asynchronous).  mvs_copy_async: one copy (kind 0: host -> device, 1: device -> host) on the device's COPY STREAM -- one per
+ * device, created with a priority of its own so that its queued copies do not stall the compute streams -- started after ticket
+ * `after` (0: at once; a ticket of mvs_event_record, mvs_mark or an earlier mvs_copy_async) and marked by the ticket *done_out.
+ * Tickets of this group are timed events from a ring of 4096 per device; mvs_event_wait accepts them, so a pair job of
+ * mvs_register_pairs (wait_ticket) starts when its two tiles have landed, and a download starts when the launch that produced
+ * its data is done (mvs_mark on the producing lane).  mvs_ticket_sync: the host waits for a ticket; mvs_ticket_elapsed_ms: the
+ * time between two tickets of one device (both must have passed or the call waits for them).  Host pointers must stay valid, and
+ * unchanged for uploads, until the ticket has passed. */
+int mvs_host_alloc(uint64_t nbytes, void** host_ptr);
+int mvs_host_free(void* host_ptr);
+int mvs_copy_async(int device, void* dst, const void* src, uint64_t nbytes, int32_t kind, uint64_t after, uint64_t* done_out);
+int mvs_mark(int device, uint64_t* ticket_out);
+int mvs_ticket_sync(uint64_t ticket);
+int mvs_ticket_elapsed_ms(uint64_t t0, uint64_t t1, double* ms_out);
+
 /* Candidate scoring == the loop of registration.py:493-556 for n translation
  * candidates t (z,y,x rows): moving resampled by t (order 1, NaN outside),
  * masks, bounding-box region (region_mode 0 = "union", 1 = "intersection"),
@@ -339,12 +357,13 @@ typedef struct mvs_pair_job_t {
                                 taken with this registration binning applied on the fly -- sim.coarsen(bin).mean().astype(dtype)
                                 (registration.py:1732-1741) and the crop in one pass, no binned copy of the tiles; all zero: the
                                 views are used as they are (mvs_register_views) */
-    int32_t reserved;
+    int32_t flags;           /* bit 0: when the pair is done, wait_ticket[0] is OVERWRITTEN with a timed ticket (mvs_mark) of the pair's
+                                lane -- when its last kernel finished, for timelines (mvs_ticket_elapsed_ms); 0: the job is only read */
 } mvs_pair_job_t;
 int mvs_plan_pairs(int32_t ndim, int32_t n_views, const double* const* coords, const int64_t* coord_len, const double* translation,
                    const double* tol, int32_t n_pairs, const int32_t* pairs, int64_t* windows_out, double* out_origin_out,
                    double* out_spacing_out, int64_t* out_shape_out, double* matrix_diag_out, double* offset_out, int32_t* status_out);
-int mvs_register_pairs(int device, int32_t n_pairs, const mvs_pair_job_t* jobs, int32_t ndim, int32_t upsample_factor,
+int mvs_register_pairs(int device, int32_t n_pairs, mvs_pair_job_t* jobs, int32_t ndim, int32_t upsample_factor,
                        int32_t region_mode, int32_t constant_check, int32_t n_lanes, double* t_out, double* quality_out,
                        int32_t* status_out, int32_t* n_candidates_out, int32_t* rc_out);
 

@@ -65,7 +65,7 @@ class mvs_pair_job_t(C.Structure):
         ("out_shape", C.c_int64 * 3),
         ("wait_ticket", C.c_uint64 * 2),
         ("bin", C.c_int32 * 3),
-        ("reserved", C.c_int32),
+        ("flags", C.c_int32),
     ]
 
 
@@ -126,6 +126,12 @@ SIGNATURES = {
     ),
     "mvs_event_record": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
     "mvs_event_wait": (C.c_int, [C.c_int, C.c_uint64]),
+    "mvs_host_alloc": (C.c_int, [C.c_uint64, C.POINTER(C.c_void_p)]),
+    "mvs_host_free": (C.c_int, [C.c_void_p]),
+    "mvs_copy_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "mvs_mark": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
+    "mvs_ticket_sync": (C.c_int, [C.c_uint64]),
+    "mvs_ticket_elapsed_ms": (C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]),
     "mvs_plan_pairs": (
         C.c_int,
         [C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,

@@ -254,6 +254,7 @@ void mvs_shutdown(int device) {
     std::lock_guard<std::recursive_mutex> lock(c->mu);
     hipSetDevice(mvs_hip_device(device));
     hipStreamSynchronize(c->stream);
+    if (((device >> 8) & 0xff) == 0) mvs_transfer_shutdown(mvs_hip_device(device));      // the device's copy stream and timed tickets go with lane 0
     {
         std::lock_guard<std::mutex> plock(c->pool_mu);
         for (auto& kv : c->pool_free) hipFree(kv.second);
@@ -486,6 +487,15 @@ int mvs_event_wait(int device, uint64_t ticket) {
     MvsContext* c;
     int rc = mvs_check_ready(device, &c);
     if (rc) return rc;
+    if (mvs_transfer_is_ticket(ticket)) {      // a timed ticket of mvs_copy_async / mvs_mark (mvs_transfer.hip)
+        hipEvent_t tev;
+        rc = mvs_transfer_event(c, ticket, &tev);
+        if (rc) return rc;
+        std::lock_guard<std::recursive_mutex> lock(c->mu);
+        MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
+        MVS_HIP_TRY(c, hipStreamWaitEvent(c->stream, tev, 0));
+        return MVS_OK;
+    }
     if (!(ticket >> 40 & 1ull)) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_event_wait: not a ticket");
     const uint32_t slot = (uint32_t)(ticket & 0xffu), idx = (uint32_t)((ticket >> 8) & 0xffffffu);
     if (slot >= 32u || idx >= (uint32_t)(MVS_MAX_DEVICES * MVS_MAX_LANES)) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_event_wait: bad ticket");

@@ -144,6 +144,10 @@ int mvs_resample_impl(int device, const mvs_view_t* view, const int64_t out_shap
                       const MvsResampleOpts& ro);
 
 MvsContext* mvs_ctx(int device);                       // nullptr if out of range
+// mvs_transfer.hip: timed tickets of the copy stream (mvs_copy_async / mvs_mark)
+bool mvs_transfer_is_ticket(uint64_t ticket);
+int mvs_transfer_event(MvsContext* c, uint64_t ticket, hipEvent_t* ev);
+void mvs_transfer_shutdown(int dev);
 int mvs_fail(MvsContext* c, int code, const char* fmt, ...);
 int mvs_check_ready(int device, MvsContext** out);     // locks nothing; returns code
 void* mvs_scratch(MvsContext* c, int slot, size_t nbytes);   // nullptr on failure (error set)

@@ -363,7 +363,7 @@ namespace {
 struct PairBatch {
     int device = 0;
     int n_pairs = 0;
-    const mvs_pair_job_t* jobs = nullptr;
+    mvs_pair_job_t* jobs = nullptr;
     int ndim = 3, upsample = 2, region_mode = -1, constant_check = 0;
     double* t_out = nullptr;
     double* quality_out = nullptr;
@@ -379,7 +379,7 @@ void run_pairs_on_lane(PairBatch* b, int lane) {
     for (;;) {
         const int p = b->next.fetch_add(1);
         if (p >= b->n_pairs) break;
-        const mvs_pair_job_t& j = b->jobs[p];
+        mvs_pair_job_t& j = b->jobs[p];
         int rc = init_rc;
         for (int k = 0; k < 2 && !rc; ++k)
             if (j.wait_ticket[k]) rc = mvs_event_wait(dev, j.wait_ticket[k]);
@@ -394,6 +394,10 @@ void run_pairs_on_lane(PairBatch* b, int lane) {
         if (b->ncand_out) b->ncand_out[p] = ncand;
         b->rc_out[p] = rc;
         if (rc) b->status_out[p] = -(lane + 1);      // (which lane's mvs_last_error holds the message)
+        if ((j.flags & 1) && !rc) {                  // timeline: when this pair's last kernel finished
+            uint64_t m = 0;
+            if (mvs_mark(dev, &m) == MVS_OK) j.wait_ticket[0] = m;
+        }
     }
 }
 
@@ -437,7 +441,7 @@ PairPool* pair_pool(int device) {
 }
 }   // namespace
 
-extern "C" int mvs_register_pairs(int device, int32_t n_pairs, const mvs_pair_job_t* jobs, int32_t ndim, int32_t upsample_factor,
+extern "C" int mvs_register_pairs(int device, int32_t n_pairs, mvs_pair_job_t* jobs, int32_t ndim, int32_t upsample_factor,
                                   int32_t region_mode, int32_t constant_check, int32_t n_lanes, double* t_out, double* quality_out,
                                   int32_t* status_out, int32_t* n_candidates_out, int32_t* rc_out) {
     MvsContext* c;

@@ -16,14 +16,102 @@ import numpy as np
 from . import _lib
 
 
+class _Pending:
+    """The upload a DeviceArray's allocation is still waiting for (shared by all windows cut from it): a ticket of mvs_copy_async
+    and the pinned host array it reads, kept alive until the ticket has been waited for on the host."""
+
+    __slots__ = ("ticket", "source")
+
+    def __init__(self, ticket, source):
+        self.ticket, self.source = int(ticket), source
+
+
+def pinned_empty(shape, dtype):
+    """numpy array in pinned (page-locked) host memory (mvs_host_alloc): what asynchronous uploads read and downloads write.
+    The memory is released when the array and all its views are gone."""
+    import weakref
+
+    dtype = np.dtype(dtype)
+    shape = tuple(int(v) for v in shape)
+    nbytes = max(int(np.prod(shape)) * dtype.itemsize, 1)
+    lib = _lib.load()
+    p = C.c_void_p()
+    rc = lib.mvs_host_alloc(nbytes, C.byref(p))
+    if rc != 0 or not p.value:
+        raise MemoryError(f"mvs_host_alloc({nbytes}) failed with code {rc}")
+    raw = (C.c_ubyte * nbytes).from_address(p.value)
+    arr = np.frombuffer(raw, dtype=np.uint8, count=int(np.prod(shape)) * dtype.itemsize).view(dtype).reshape(shape)
+    weakref.finalize(raw, lib.mvs_host_free, C.c_void_p(p.value))      # (`arr.base` chain holds `raw`)
+    return arr
+
+
+def is_pinned(array):
+    """True for arrays made by ``pinned_empty`` (and views of them)."""
+    b = array
+    while isinstance(b, np.ndarray) and b.base is not None:
+        b = b.base
+    return isinstance(b, C.Array) or type(b).__name__.startswith("c_ubyte_Array")
+
+
 class DeviceArray:
-    def __init__(self, buf, ptr, shape, strides, dtype, device):
+    def __init__(self, buf, ptr, shape, strides, dtype, device, pending=None):
         self._buf = buf            # DeviceBuffer keeping the allocation alive (or any owner object)
         self.ptr = int(ptr)
         self.shape = tuple(int(s) for s in shape)
         self.strides = tuple(int(s) for s in strides)   # in elements
         self.dtype = np.dtype(dtype)
         self.device = int(device)
+        self._pending = pending    # _Pending of an asynchronous upload that may still be in flight (from_host_async), or None
+
+    @property
+    def ready_ticket(self):
+        """Ticket of the upload this array still waits for (0: none).  Work queued on a lane after ``wait_ready(lane)`` -- or a
+        pair job carrying the ticket (mvs_register_pairs) -- starts when the upload has landed; the host never waits."""
+        return self._pending.ticket if self._pending is not None and self._pending.ticket else 0
+
+    def wait_ready(self, device=None):
+        """Make the stream of context ``device`` (default: the array's own device, lane 0) wait for the pending upload."""
+        t = self.ready_ticket
+        if t:
+            dev = self.device if device is None else int(device)
+            _lib.check(_lib.init(dev).mvs_event_wait(dev, t), dev, "mvs_event_wait")
+        return self
+
+    def sync_ready(self):
+        """The HOST waits for the pending upload; afterwards the array is an ordinary resident one."""
+        t = self.ready_ticket
+        if t:
+            _lib.check(_lib.load().mvs_ticket_sync(t), self.device, "mvs_ticket_sync")
+            self._pending.ticket, self._pending.source = 0, None
+        return self
+
+    @classmethod
+    def from_host_async(cls, array, device=0):
+        """Upload ``array`` (pinned host memory: ``pinned_empty``; contiguous) on the device's copy stream without waiting: the
+        returned array carries the upload's ticket (``ready_ticket``).  ``array`` must not be written until the upload has landed."""
+        if not (isinstance(array, np.ndarray) and array.flags.c_contiguous and is_pinned(array)):
+            raise ValueError("from_host_async needs a C-contiguous array in pinned host memory (device.pinned_empty)")
+        if array.dtype not in _lib.DTYPE_CODES:
+            raise TypeError(f"unsupported dtype {array.dtype} (uint8/uint16/float32)")
+        buf = _lib.DeviceBuffer(device, max(array.nbytes, 1))
+        t = C.c_uint64()
+        lib = _lib.init(device)
+        _lib.check(lib.mvs_copy_async(device, C.c_void_p(buf.ptr), C.c_void_p(array.ctypes.data), array.nbytes, 0, 0, C.byref(t)), device, "mvs_copy_async")
+        buf.mark_written()
+        strides = [s // array.itemsize for s in array.strides]
+        return cls(buf, buf.ptr, array.shape, strides, array.dtype, device, pending=_Pending(t.value, array))
+
+    def download_async(self, out, after=0):
+        """Copy this (contiguous) array into the pinned host array ``out`` on the copy stream, after ticket ``after`` (e.g. an
+        ``mvs_mark`` on the lane that produces the data); returns the download's ticket (``_lib.ticket_sync`` waits for it)."""
+        if not self.is_contiguous() or not (isinstance(out, np.ndarray) and out.flags.c_contiguous and is_pinned(out)) \
+                or out.nbytes != self.nbytes or out.dtype != self.dtype:
+            raise ValueError("download_async needs a contiguous device array and a pinned C-contiguous host array of the same size and dtype")
+        t = C.c_uint64()
+        lib = _lib.init(self.device)
+        _lib.check(lib.mvs_copy_async(self.device, C.c_void_p(out.ctypes.data), C.c_void_p(self.ptr), self.nbytes, 1, int(after), C.byref(t)),
+                   self.device, "mvs_copy_async")
+        return int(t.value)
 
     ndim = property(lambda self: len(self.shape))
     size = property(lambda self: int(np.prod(self.shape)))
@@ -63,6 +151,7 @@ class DeviceArray:
         dev = int(device)
         if (self.device & 0xff) == (dev & 0xff):
             return self
+        self.sync_ready()      # (a peer copy reads the memory from another GPU's stream)
         item = self.dtype.itemsize
         owner = self._buf
         lib = _lib.init(dev)
@@ -143,10 +232,11 @@ class DeviceArray:
                 strides.append(st)
             else:
                 raise IndexError("DeviceArray supports ints and slices only")
-        return DeviceArray(self._buf, self.ptr + off * self.dtype.itemsize, shape, strides, self.dtype, self.device)
+        return DeviceArray(self._buf, self.ptr + off * self.dtype.itemsize, shape, strides, self.dtype, self.device, pending=self._pending)
 
     def get(self):
         """Copy to a numpy array."""
+        self.sync_ready()
         if self.is_contiguous():
             out = np.empty(self.shape, dtype=self.dtype)
             _lib.check(_lib.load().mvs_memcpy_d2h(self.device, out.ctypes.data, self.ptr, out.nbytes), self.device, "d2h")
@@ -181,3 +271,28 @@ def to_device(sim, device=0):
     if is_device_array(sim.data):
         return sim
     return sim.copy(data=DeviceArray.from_host(sim.data, device))
+
+
+def to_device_async(sims, device=0):
+    """Copies of the SpatialImages ``sims`` (spatial dims only; data in pinned host memory, ``pinned_empty``) whose data is being
+    uploaded to ``device`` on its copy stream, in list order, without waiting: ``register()`` starts a pair when its two tiles have
+    landed, ``fuse()`` / ``fuse_np`` make their stream wait for the tiles they read (``DeviceArray.ready_ticket``)."""
+    return [s if is_device_array(s.data) else s.copy(data=DeviceArray.from_host_async(np.asarray(s.data), device)) for s in sims]
+
+
+def mark(device=0):
+    """A timed ticket on the stream of context ``device`` (mvs_mark): passes when the work queued so far is done."""
+    t = C.c_uint64()
+    _lib.check(_lib.init(device).mvs_mark(device, C.byref(t)), device, "mvs_mark")
+    return int(t.value)
+
+
+def ticket_sync(ticket):
+    if ticket:
+        _lib.check(_lib.load().mvs_ticket_sync(int(ticket)), 0, "mvs_ticket_sync")
+
+
+def ticket_elapsed_ms(t0, t1):
+    ms = C.c_double()
+    _lib.check(_lib.load().mvs_ticket_elapsed_ms(int(t0), int(t1), C.byref(ms)), 0, "mvs_ticket_elapsed_ms")
+    return float(ms.value)

@@ -251,6 +251,7 @@ def fuse_np(
             if data.dtype != input_dtype:
                 raise TypeError("all views of a chunk must share one dtype")
             data = data.on_device(device)     # a tile resident on another GPU: peer copy, cached per (tile, device)
+            data.wait_ready(device)           # a tile still on its way (device.to_device_async): this call's stream waits for the upload
             ptrs[i], st = data.ptr, [int(v) for v in data.strides]
         else:
             data = np.ascontiguousarray(data, dtype=input_dtype)
@@ -735,6 +736,8 @@ def _replay_fuse(rec, images, transform_key, device):
     n = rec["n"]
     views = (_lib.mvs_view_t * n).from_buffer_copy(rec["views"])
     opts = _lib.mvs_fuse_opts_t.from_buffer_copy(rec["opts"])
+    for iv in rec["view_index"]:
+        images[iv].data.wait_ready(device)
     ptrs = np.array([images[iv].data.ptr for iv in rec["view_index"]], dtype=np.uint64) + rec["byte_offsets"]
     flat = np.frombuffer(views, dtype=np.uint8).reshape(n, C.sizeof(_lib.mvs_view_t))
     off = _lib.mvs_view_t.data.offset
@@ -1195,3 +1198,59 @@ def fuse(*args, **kwargs):
 
 fuse.__doc__ = _fuse_once.__doc__
 fuse.__wrapped__ = _fuse_once
+
+
+def fuse_to_host(images, transform_key=None, n_slabs=8, out=None, device=0, return_timeline=False, **fuse_kwargs):
+    """``fuse()`` of views resident on (or on their way to) the device with the RESULT in host memory, the download overlapped with
+    the kernels: the output stack is cut into ``n_slabs`` slabs along its first axis, every slab is fused in one launch block
+    (``output_on_backend=True``) and copied into its window of a pinned host array on the device's copy stream while the next
+    slab is fused (mvs_mark on the fuse lane -> mvs_copy_async, csrc/mvs_transfer.hip).  The reference streams fused chunks out of a
+    dask graph into host memory / a Zarr store (_core.py:1068-1170, 2044-2156); SURVEY 8d(2)'s end-to-end figure includes this
+    D2H.  Every slab is fused in the index frame of the WHOLE stack (``frame_origin``), so the result equals ``fuse()`` of the
+    whole stack voxel for voxel.  ``out``: a pinned C-contiguous array of the result's shape (``device.pinned_empty``) to fill
+    instead of a new one.  ``return_timeline``: also return [(fuse done, download done)] per slab in ms since the first slab's
+    launch block was queued (timed tickets) -- the overlap test reads it.  Remaining keyword arguments: those of ``fuse()``
+    (single field images: spatial dims only)."""
+    from . import device as dev_mod
+
+    for bad in ("output_zarr_url", "batch_options", "output_on_backend", "chunk_filter", "sims"):
+        if fuse_kwargs.get(bad):
+            raise TypeError(f"fuse_to_host does not take {bad}")
+    images = list(images)
+    sdims = si_utils.get_spatial_dims_from_sim(images[0])
+    if list(images[0].dims) != list(sdims):
+        raise ValueError("fuse_to_host fuses single fields (spatial dims only)")
+    osp = _bb_dicts(process_output_stack_properties(
+        images, fuse_kwargs.pop("output_spacing", None), fuse_kwargs.pop("output_origin", None), fuse_kwargs.pop("output_shape", None),
+        fuse_kwargs.pop("output_stack_properties", None), fuse_kwargs.pop("output_stack_mode", "union"), transform_key), sdims)
+    shape = tuple(int(osp["shape"][d]) for d in sdims)
+    dtype = np.dtype(images[0].dtype)
+    if out is None:
+        out = dev_mod.pinned_empty(shape, dtype)
+    elif tuple(out.shape) != shape or out.dtype != dtype or not out.flags.c_contiguous or not dev_mod.is_pinned(out):
+        raise ValueError(f"out must be a pinned C-contiguous {dtype} array of shape {shape}")
+    d0 = sdims[0]
+    n0 = shape[0]
+    n_slabs = max(1, min(int(n_slabs), n0))
+    cuts = np.linspace(0, n0, n_slabs + 1).round().astype(int)
+    fuse_kwargs.setdefault("frame_origin", dict(osp["origin"]))
+    fuse_kwargs.setdefault("output_chunksize", {d: 1 << 30 for d in sdims})
+    t_start = dev_mod.mark(device)
+    pending, timeline = [], []
+    for k in range(n_slabs):
+        a, b = int(cuts[k]), int(cuts[k + 1])
+        if b <= a:
+            continue
+        sub = {"origin": dict(osp["origin"], **{d0: osp["origin"][d0] + a * osp["spacing"][d0]}), "spacing": dict(osp["spacing"]),
+               "shape": dict(osp["shape"], **{d0: b - a})}
+        fused = fuse(images, transform_key=transform_key, output_stack_properties=sub, output_on_backend=True, device=device, **fuse_kwargs)
+        t_fused = dev_mod.mark(device)
+        t_down = fused.data.download_async(out[a:b], after=t_fused)
+        pending.append((fused, t_fused, t_down))      # (the slab stays alive until its download has passed)
+    for fused, t_fused, t_down in pending:
+        dev_mod.ticket_sync(t_down)
+        if return_timeline:
+            timeline.append((dev_mod.ticket_elapsed_ms(t_start, t_fused), dev_mod.ticket_elapsed_ms(t_start, t_down)))
+    res = si_utils.to_spatial_image(out, dims=list(sdims), scale=osp["spacing"], translation=osp["origin"])
+    si_utils.set_sim_affine(res, param_utils.identity_transform(len(sdims)), transform_key)
+    return (res, timeline) if return_timeline else res

@@ -259,6 +259,8 @@ def _bin_sim(sim, binning, device, wait=True, out=None):
     bins = [int(binning.get(d, 1)) for d in sdims]
     if max(bins) == 1:
         return sim
+    if is_device_array(sim.data):
+        sim.data.wait_ready(device)      # (an upload still in flight: this lane's stream waits for it)
     data = _reg_ops.bin_mean(sim.data, bins, device, wait=wait) if out is None else _reg_ops.bin_mean(sim.data, bins, device, wait=wait, out=out)
     coords = {}
     for d, b, n in zip(sdims, bins, data.shape):
@@ -579,6 +581,7 @@ _native_resolution = [True]     # tests: register() through param_resolution's g
 
 _JOB_DTYPE = np.dtype(_lib.mvs_pair_job_t)
 
+_pair_timeline = None         # tests / bench: a list that the batched pair path fills with ((i, j), done ticket) per registered pair
 _raw_crops_enabled = [True]  # tests: the batched pair path through binned copies of the tiles instead of binning inside the crop kernel
 _BATCH_LANES = [8]          # context lanes / native worker threads of the batched pair path when the caller does not say (n_parallel_pairwise_regs)
 _batch_enabled = [True]     # tests: compute_pairwise_registrations through the per-pair worker threads instead of mvs_register_pairs
@@ -632,6 +635,18 @@ def _register_pairs_batched(sims, edges, transform_key, registration_binning, ov
 
     if not edges or any(msi_utils.is_msim(m) for m in sims):
         return None
+    if any(is_device_array(sims[v].data) and sims[v].data.ready_ticket for e in edges for v in e):
+        # uploads in flight (in list order): the pairs in the order in which their later tile lands, results back in edge order
+        order = sorted(range(len(edges)), key=lambda k: max(edges[k]))
+        if order != list(range(len(edges))):
+            part = _register_pairs_batched(sims, [edges[k] for k in order], transform_key, registration_binning, overlap_tolerance,
+                                           pairwise_reg_func_kwargs, device, n_lanes, cache, knife_check=knife_check)
+            if part is None:
+                return None
+            res = [None] * len(edges)
+            for k, r in zip(order, part):
+                res[k] = r
+            return res
     used = sorted({v for e in edges for v in e})
     sdims = si_utils.get_spatial_dims_from_sim(sims[used[0]])
     n = len(sdims)
@@ -747,6 +762,8 @@ def _register_pairs_batched(sims, edges, transform_key, registration_binning, ov
     prebin_lane = None
     if raw_crops or not do_bin:
         source = {v: sims[v].data for v in used}
+        # tiles still on their way to the device (device.to_device_async): a pair's lane waits for the uploads of ITS two tiles
+        tickets = {v: source[v].ready_ticket for v in used}
     else:
         if all(cache.ticket_of((id(sims[v].data), bkey)) is None and (id(sims[v].data), bkey) not in cache._items for v in used):
             # (queues the binning of all views on the last context lane; None: not a regular mosaic, the views are binned one by one below)
@@ -797,6 +814,8 @@ def _register_pairs_batched(sims, edges, transform_key, registration_binning, ov
     if raw_crops:
         ja["bin"][:, :k0] = 1
         ja["bin"][:, k0:] = scale
+    if _pair_timeline is not None:
+        ja["flags"][:] = 1       # every pair leaves a timed ticket of its last kernel (read below)
     upsample_factor = (pairwise_reg_func_kwargs or {}).get("upsample_factor")
     uf = (10 if n == 2 else 2) if upsample_factor is None else upsample_factor
     t3, q = np.zeros((ne, 3)), np.zeros(ne)
@@ -808,6 +827,8 @@ def _register_pairs_batched(sims, edges, transform_key, registration_binning, ov
         if prebin_lane is not None:
             _lib.synchronize(prebin_lane)      # (done long ago unless a pair failed: nothing stays queued on the caller's tiles)
     _lib.check(rc, device & 0xff, "mvs_register_pairs")
+    if _pair_timeline is not None:
+        _pair_timeline.extend((tuple(edges[e]), int(ja["wait_ticket"][e, 0])) for e in range(ne))
     # ---- overlap boxes in world coordinates (_lean_overlap on the UNBINNED views) and the physical affines ----
     o = np.array([geoms[v].origin for v in used], dtype=np.float64).reshape(nv, n)
     sp = np.array([geoms[v].spacing for v in used], dtype=np.float64).reshape(nv, n)
@@ -888,6 +909,9 @@ def register_pair_of_msims(msim1, msim2, transform_key, registration_binning=Non
 
     pairwise_reg_func_kwargs = dict(pairwise_reg_func_kwargs or {})
     sim1, sim2, registration_binning = _select_registration_level(msim1, msim2, registration_binning, reg_res_level)
+    for s_ in (sim1, sim2):
+        if is_device_array(s_.data):
+            s_.data.wait_ready(device)       # (tiles uploaded with device.to_device_async: this lane's stream waits for them)
     sdims = si_utils.get_spatial_dims_from_sim(sim1)
     ndim = len(sdims)
     if overlap_tolerance is None:
@@ -992,7 +1016,7 @@ def _prebin_views(sims, registration_binning, device, cache):
     nd = len(sdims)
     shape = [int(v) for v in sims[0].data.shape]
     oshape = tuple(n // b for n, b in zip(shape, bins))
-    datas = [s.data.on_device(lane_device) for s in sims]
+    datas = [s.data.on_device(lane_device).wait_ready(lane_device) for s in sims]      # (uploads in flight: the binning lane waits for them)
     st0 = tuple(datas[0].strides)
     if any(tuple(d.strides) != st0 for d in datas):
         return None

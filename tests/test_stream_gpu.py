@@ -1,0 +1,82 @@
+"""The transfer-overlapped path of the product (csrc/mvs_transfer.hip, device.to_device_async, fusion.fuse_to_host): tiles that
+start in host memory and a result that ends there (fusion/_core.py:1068-1170, 2044-2156)."""
+import numpy as np
+import pytest
+
+from tests.helpers import squeeze_field
+
+pytestmark = pytest.mark.gpu
+
+
+def _mosaic(tile=256, jitter=2, seed=3):
+    from multiview_stitcher_amd import sample_data
+
+    sims, _, _ = sample_data.generate_tiled_dataset(ndim=3, tile_shape=(tile,) * 3, tiles=(2, 2, 2), overlap=(int(tile * 0.2),) * 3, dtype=np.uint16,
+                                                    max_jitter=jitter, seed=seed)
+    return [squeeze_field(s) for s in sims]
+
+
+def test_pinned_arrays_and_async_round_trip(hip_device):
+    from multiview_stitcher_amd import device
+
+    a = device.pinned_empty((5, 7, 9), np.uint16)
+    assert device.is_pinned(a) and device.is_pinned(a[1:3]) and not device.is_pinned(np.zeros(4))
+    a[:] = np.arange(a.size, dtype=np.uint16).reshape(a.shape)
+    d = device.DeviceArray.from_host_async(a, 0)
+    assert d.ready_ticket != 0 and d[1:3].ready_ticket == d.ready_ticket      # windows share the pending upload
+    b = device.pinned_empty(a.shape, a.dtype)
+    b[:] = 0
+    device.ticket_sync(d.download_async(b, after=d.ready_ticket))
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(d.get(), a)          # (get() waits for the upload itself)
+    assert d.ready_ticket == 0
+    with pytest.raises(ValueError):
+        device.DeviceArray.from_host_async(np.zeros((3, 3), np.uint16), 0)      # pageable memory: refused, not silently synchronous
+
+
+def test_streamed_register_and_fuse_equal_the_resident_run_and_overlap(hip_device):
+    """Tiles uploaded with ``to_device_async`` while ``register()`` registers the pairs whose tiles have landed, the mosaic fused in
+    slabs with every slab's download under the next slab's fuse (``fuse_to_host``): (1) parameters and fused voxels equal the run
+    on resident tiles bit for bit; (2) the timeline -- timed tickets of the uploads, of every pair's last kernel, of every slab's
+    fuse and download -- shows pairs finished before the last tile had landed and slabs fused before the previous slab's download
+    was through: upload, kernels and download overlap."""
+    from multiview_stitcher_amd import device, fusion, registration, sample_data
+
+    key = sample_data.METADATA_TRANSFORM_KEY
+    sims = _mosaic()
+    res_sims = [device.to_device(s, 0) for s in sims]
+    p_ref = registration.register(res_sims, transform_key=key, new_transform_key="reg", device=0)
+    want = fusion.fuse(res_sims, transform_key="reg", output_on_backend=True, device=0).data.get()
+
+    host = []
+    for s in sims:
+        h = device.pinned_empty(s.data.shape, s.data.dtype)
+        h[:] = np.asarray(s.data)
+        host.append(s.copy(data=h))
+    registration._pair_timeline = pairs = []
+    try:
+        t0 = device.mark(0)
+        a_sims = device.to_device_async(host, 0)
+        uploads = [s.data.ready_ticket for s in a_sims]
+        assert all(uploads)
+        p_got = registration.register(a_sims, transform_key=key, new_transform_key="reg", device=0)
+    finally:
+        registration._pair_timeline = None
+    fused, slabs = fusion.fuse_to_host(a_sims, transform_key="reg", n_slabs=4, device=0, return_timeline=True)
+    for a, b in zip(p_got, p_ref):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    got = np.asarray(fused.data)
+    assert device.is_pinned(got) and got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
+
+    up_ms = [device.ticket_elapsed_ms(t0, t) for t in uploads]
+    pair_ms = [device.ticket_elapsed_ms(t0, t) for _, t in pairs]
+    assert len(pairs) >= 7 and all(t > 0 for t in pair_ms)
+    assert up_ms == sorted(up_ms)                                   # the copy stream keeps the order of the list
+    # a pair cannot end before its two tiles have landed ...
+    for (i, j), t in zip([e for e, _ in pairs], pair_ms):
+        assert t >= max(up_ms[i], up_ms[j]) - 1e-3
+    # ... and the first pairs are done while later tiles are still on their way
+    assert min(pair_ms) < max(up_ms), (sorted(pair_ms)[:3], up_ms)
+    assert len(slabs) == 4 and all(d >= f for f, d in slabs)
+    assert any(slabs[k + 1][0] < slabs[k][1] for k in range(3)), slabs      # slab k + 1 was fused before slab k's download was through
