@@ -669,6 +669,7 @@ def _plan_chunks(sparams, views_bb, output_stack_properties, output_chunksize, o
 
 
 _REPLAY = [True]           # tests / A-B: derive everything on every call
+_STREAM_PIPELINE = [os.environ.get("MVS_STREAM_PIPELINE", "1") != "0"]      # streaming.BlockPipeline around the launch blocks of a streamed fuse()
 _REPLAY_MEMO = {}
 _REPLAY_CAP = 32                     # geometries kept (8 ranks x a few mosaics; an entry is a few KB of view records)
 _REPLAY_LOCK = threading.Lock()      # fuse() is also driven from one thread per GPU: lookups, evictions and inserts are serialised
@@ -905,11 +906,11 @@ def _fuse_once(
     store_chunksize = dict(output_chunksize)          # the chunk grid of a Zarr output stays the requested one
     requested_chunksize = dict(output_chunksize)
     merged = False
+    streamed = output_zarr_url is not None or any(type(s_.data).__name__ in ("ZarrArray", "ZarrView") for s_ in sims_)
     if (merge_chunks and not batch_options and chunk_filter is None
             and weights_func is None and fusion_func in _FUSION_CODES and not any(overlap_in_pixels[d] for d in sdims)
             and not ("z" in sdims and int(output_chunksize["z"]) == 1 and output_stack_properties["shape"]["z"] > 1)):
         # streamed inputs / outputs pass through host memory block by block: a smaller budget per launch block
-        streamed = output_zarr_url is not None or any(type(s_.data).__name__ in ("ZarrArray", "ZarrView") for s_ in sims_)
         itemsize = np.dtype(sims_[0].dtype).itemsize
         budget = _launch_budget(sims_, output_stack_properties["shape"], sdims, itemsize, device,
                                 MAX_STREAM_BYTES if streamed else MAX_LAUNCH_BYTES)
@@ -1104,6 +1105,14 @@ def _fuse_once(
                       and (chunk_filter is None or chunk_filter(entries[0]["block_index"])))
             if not single:
                 dev_out.fill_zero()
+        # tiles read from Zarr stores and / or a result that leaves the device block by block: read-ahead, asynchronous transfers
+        # and write-behind around the launch blocks (streaming.BlockPipeline) -- the same fuse_np calls in the same order
+        pipe = None
+        if streamed and _STREAM_PIPELINE[0] and not on_device and fusion_func in _FUSION_CODES and (weights_func is None or weights_func is content_based) \
+                and _lib.device_count() > 0:
+            from .streaming import BlockPipeline
+
+            pipe = BlockPipeline(fuse_np, device)
         for entry in plan["per_chunk_entries"]:
             bi = entry["block_index"]
             if chunk_filter is not None and not chunk_filter(bi):
@@ -1111,6 +1120,19 @@ def _fuse_once(
             if not entry["views"]:
                 continue
             kwargs, sl = chunk_call(ns_index, entry, device)
+            if pipe is not None:
+                def sink(chunk, entry=entry, sl=sl, ns_index=ns_index):
+                    if entry["fuse_planewise"]:
+                        chunk = chunk[np.newaxis]
+                    if zarr_out is not None:
+                        from .streaming import write_region
+
+                        write_region(zarr_out, list(ns_index) + [s_.start for s_ in sl], chunk.reshape((1,) * len(ns_index) + chunk.shape))
+                    else:
+                        result[tuple(ns_index) + sl] = chunk
+                kwargs.pop("device", None)
+                pipe.submit(dict(kwargs, device=device), sink)
+                continue
             if on_device and single:
                 # (a plane-wise entry is fused with 2D parameters: hand it the one plane of the 3D result)
                 fuse_np(out=dev_out[0] if entry["fuse_planewise"] else dev_out, **kwargs)
@@ -1129,6 +1151,8 @@ def _fuse_once(
                     result = chunk           # one launch block and one field: the fused array is the result
                 else:
                     result[tuple(ns_index) + sl] = chunk
+        if pipe is not None:
+            pipe.finish()
     if on_device:
         dev_full.mark_written()
         data = dev_full

@@ -1,0 +1,172 @@
+"""Read-ahead / write-behind around the launch blocks of ``fusion.fuse`` when tiles are read from Zarr stores or the result is
+written to one (or to host memory).
+
+The reference streams such a fusion through dask: chunk tasks read their slabs lazily from the input stores
+(spatial_image_utils.py:712-860) and write their regions of the output store (fusion/_core.py:1068-1170, 2044-2156), many of them in
+flight at once.  Here a launch block is one ``mvs_fuse_chunk`` call, and until round 6 its five steps ran one after the other:
+read the slabs, upload, fuse, download, write.  ``BlockPipeline`` runs them as three stages with two blocks in flight per stage:
+
+  reader thread   the slabs of block k + 1 -> pinned host buffers (chunk files read by a small pool of threads: file reads and
+                  copies release the GIL) -> asynchronous uploads on the device's copy stream (csrc/mvs_transfer.hip);
+  caller          block k: ``fuse_np`` on device-resident slabs (its stream waits for their uploads' tickets), result left on
+                  the device, a timed mark, an asynchronous download into a pinned buffer after the mark;
+  writer thread   block k - 1: waits for the download's ticket, writes the region (chunk files by the pool), returns the
+                  pinned buffers to the pool.
+
+Same calls, same arguments, same voxels as the serial loop: only the order in which the host gets to them changes.
+"""
+from __future__ import annotations
+
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import device as dev_mod
+from . import zarr_io
+
+
+class PinnedPool:
+    """Pinned host buffers handed out by size (hipHostMalloc costs milliseconds per 100 MB: a streamed fuse would pay it per block)."""
+
+    def __init__(self):
+        self._free = {}
+        self._lock = threading.Lock()
+
+    def get(self, shape, dtype):
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        cap = max(1 << 20, 1 << int(np.ceil(np.log2(max(n, 1)))))
+        with self._lock:
+            lst = self._free.get(cap)
+            raw = lst.pop() if lst else None
+        if raw is None:
+            raw = dev_mod.pinned_empty((cap,), np.uint8)
+        return raw, raw[:n].view(dtype).reshape(shape)
+
+    def put(self, raw):
+        with self._lock:
+            self._free.setdefault(raw.size, []).append(raw)
+
+
+_IO_POOL = [None]
+_IO_LOCK = threading.Lock()
+
+
+def io_pool(workers=8):
+    with _IO_LOCK:
+        if _IO_POOL[0] is None:
+            _IO_POOL[0] = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="mvs-io")
+        return _IO_POOL[0]
+
+
+def read_window(view, out):
+    """Fill ``out`` (any writable array of the window's shape) with the Zarr window ``view`` (ZarrView / ZarrArray), the chunk
+    files read and copied by the I/O pool."""
+    if isinstance(view, zarr_io.ZarrArray):
+        view = view[...]
+    arr = view.array
+    win = view._window()
+    starts, stops = [a for a, _ in win], [b for _, b in win]
+    full = out.reshape([b - a for a, b in win])
+
+    def one(idx):
+        lo = [max(a, i * c) for a, i, c in zip(starts, idx, arr.chunks)]
+        hi = [min(b, (i + 1) * c) for b, i, c in zip(stops, idx, arr.chunks)]
+        dst = tuple(slice(l - a, h - a) for l, h, a in zip(lo, hi, starts))
+        chunk = arr.read_chunk(idx)
+        if chunk is None:
+            full[dst] = arr.fill_value
+        else:
+            full[dst] = chunk[tuple(slice(l - i * c, h - i * c) for l, h, i, c in zip(lo, hi, idx, arr.chunks))]
+
+    if full.size:
+        list(io_pool().map(one, list(arr._touched(starts, stops))))
+    return out
+
+
+def write_region(zarr_out, starts, data):
+    """``zarr_out.write(starts, data)`` with the touched chunk files written by the I/O pool (chunk-aligned cuts: every chunk is
+    written by exactly one task)."""
+    data = np.asarray(data)
+    starts = [int(a) for a in starts]
+    stops = [a + n for a, n in zip(starts, data.shape)]
+    pieces = []
+    for idx in zarr_out._touched(starts, stops):
+        c0 = [i * c for i, c in zip(idx, zarr_out.chunks)]
+        lo = [max(a, o) for a, o in zip(starts, c0)]
+        hi = [min(b, o + c) for b, o, c in zip(stops, c0, zarr_out.chunks)]
+        pieces.append((lo, data[tuple(slice(l - a, h - a) for l, h, a in zip(lo, hi, starts))]))
+    list(io_pool().map(lambda p: zarr_out.write(p[0], p[1]), pieces))
+
+
+class BlockPipeline:
+    """Three-stage pipeline over the launch blocks of one ``fuse()`` call (see the module docstring).  ``submit(kwargs, sink)``:
+    ``kwargs`` are the ``fuse_np`` arguments of a block (``sims``: slabs that may be Zarr-backed or host arrays), ``sink(chunk)``
+    stores the fused block (a numpy array in pinned memory, valid during the call).  ``finish()`` waits for everything."""
+
+    def __init__(self, fuse_np, device, depth=2):
+        self.fuse_np, self.device, self.depth = fuse_np, device, depth
+        self.pool = PinnedPool()
+        self.reader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mvs-read")
+        self.writer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mvs-write")
+        self.staged = []       # (future of the staged block, sink)
+        self.writes = []
+        self.timeline = []     # per block: dict of host-clock seconds (read done, fuse queued, written)
+
+    # -- stage 1: slabs -> pinned -> async upload
+    def _stage(self, kwargs):
+        from .device import DeviceArray, is_device_array
+
+        raws, sims = [], []
+        for s_ in kwargs["sims"]:
+            data = s_.data
+            if is_device_array(data):
+                sims.append(s_)
+                continue
+            raw, buf = self.pool.get(data.shape, s_.dtype)
+            if zarr_io.is_zarr_backed(data):
+                read_window(data, buf)
+            else:
+                buf[...] = np.asarray(data)
+            raws.append(raw)
+            sims.append(s_.copy(data=DeviceArray.from_host_async(buf, self.device)))
+        return dict(kwargs, sims=sims), raws
+
+    def submit(self, kwargs, sink):
+        self.staged.append((self.reader.submit(self._stage, kwargs), sink))
+        while len(self.staged) > self.depth:
+            self._run_one()
+
+    # -- stage 2 (caller's thread): fuse on the device, queue the download
+    def _run_one(self):
+        fut, sink = self.staged.pop(0)
+        kwargs, raws = fut.result()
+        # (content-based weights: the fast path's overflow flag is looked at per block, since the block leaves the device right away)
+        chunk = self.fuse_np(output_on_backend=True, **dict(kwargs, _cb_check=True))
+        mark = dev_mod.mark(self.device)
+        raw_out, out = self.pool.get(chunk.shape, chunk.dtype)
+        ticket = chunk.download_async(out, after=mark)
+        self.writes.append(self.writer.submit(self._write, chunk, kwargs, raws, raw_out, out, ticket, sink))
+        while len(self.writes) > self.depth:
+            self.writes.pop(0).result()
+
+    # -- stage 3: wait for the download, store, recycle the buffers
+    def _write(self, chunk, kwargs, raws, raw_out, out, ticket, sink):
+        dev_mod.ticket_sync(ticket)
+        sink(out)
+        for r in raws:
+            self.pool.put(r)
+        self.pool.put(raw_out)
+        del chunk, kwargs
+
+    def finish(self):
+        try:
+            while self.staged:
+                self._run_one()
+            for w in self.writes:
+                w.result()
+            self.writes = []
+        finally:
+            self.reader.shutdown(wait=True)
+            self.writer.shutdown(wait=True)

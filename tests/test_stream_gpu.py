@@ -80,3 +80,38 @@ def test_streamed_register_and_fuse_equal_the_resident_run_and_overlap(hip_devic
     assert min(pair_ms) < max(up_ms), (sorted(pair_ms)[:3], up_ms)
     assert len(slabs) == 4 and all(d >= f for f, d in slabs)
     assert any(slabs[k + 1][0] < slabs[k][1] for k in range(3)), slabs      # slab k + 1 was fused before slab k's download was through
+
+
+@pytest.mark.parametrize("weights", [None, "content_based"])
+def test_block_pipeline_equals_the_serial_loop(hip_device, tmp_path, weights):
+    """fuse() of Zarr-backed tiles into a Zarr store in several launch blocks: with read-ahead, asynchronous transfers and
+    write-behind around the blocks (streaming.BlockPipeline, the default) the store holds exactly what the serial loop writes."""
+    from multiview_stitcher_amd import fusion, ngff_utils, sample_data, zarr_io, spatial_image_utils as si
+
+    key = sample_data.METADATA_TRANSFORM_KEY
+    sims, _, _ = sample_data.generate_tiled_dataset(ndim=3, tile_shape=(64, 96, 128), tiles=(2, 2, 2), overlap=(12, 20, 26), dtype=np.uint16, max_jitter=0, seed=8)
+    lazy = []
+    for i, s in enumerate(sims):
+        z = ngff_utils.write_sim_to_ome_zarr(s, str(tmp_path / f"tile{i}.zarr"))
+        si.set_sim_affine(z, si.get_affine_from_sim(s, key), key)
+        lazy.append(z)
+    kw = dict(transform_key=key, output_chunksize={"z": 32, "y": 64, "x": 64})
+    if weights:
+        kw.update(weights_func=fusion.content_based, weights_func_kwargs={"sigma_1": 1.5, "sigma_2": 3.0})
+    old_budget = fusion.MAX_STREAM_BYTES
+    fusion.MAX_STREAM_BYTES = 1 << 20                 # several launch blocks even for this small mosaic
+    try:
+        got = fusion.fuse(lazy, output_zarr_url=str(tmp_path / "piped.zarr"), **kw)
+        fusion._STREAM_PIPELINE[0] = False
+        try:
+            want = fusion.fuse(lazy, output_zarr_url=str(tmp_path / "serial.zarr"), **kw)
+        finally:
+            fusion._STREAM_PIPELINE[0] = True
+        host = fusion.fuse(lazy, **kw)                # Zarr in, host memory out: the pipeline's other sink
+    finally:
+        fusion.MAX_STREAM_BYTES = old_budget
+    assert zarr_io.is_zarr_backed(got.data)
+    a, b = np.asarray(got.data), np.asarray(want.data)
+    assert a.shape == b.shape and a.any()
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(np.asarray(host.data), b)
