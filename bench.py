@@ -57,6 +57,7 @@ def parse_args():
                     help="pre_registration_pruning_method (reference default: alternating_pattern)")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pipeline leg (N = 1 only)")
     ap.add_argument("--no-c3", action="store_true", help="skip the content-based leg (BASELINE config C3; N = 1 only)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the Zarr-streamed leg (BASELINE config C5, a z-slab of its grid; N = 1 only)")
     return ap.parse_args()
 
 
@@ -385,12 +386,12 @@ def csrc_digest():
 
 def fuse_traffic_bytes(grid, tile):
     """(HBM bytes per fuse launch, where the figure comes from).  The bytes are PMC counters (FETCH_SIZE x2 per the
-    calibration + WRITE_SIZE, separate rocprofv3 --pmc passes: tools/profile_round4.sh) committed under profiles/ together
+    calibration + WRITE_SIZE, separate rocprofv3 --pmc passes: tools/profile_round.sh) committed under profiles/ together
     with the digest of the kernel sources they were measured with; when the sources have changed since, or the workload is
     another one, the figure would be stale and None is returned instead."""
     if not (list(grid) == [4, 4, 4] and list(tile) == [512, 512, 512]):
         return None, "no PMC pass for this workload"
-    for name in ("round5_fuse_traffic.json", "round4_fuse_traffic.json", "round3_fuse_traffic.json"):
+    for name in ("round6_fuse_traffic.json", "round5_fuse_traffic.json", "round4_fuse_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 t = json.load(f)
@@ -401,6 +402,38 @@ def fuse_traffic_bytes(grid, tile):
         except (OSError, KeyError, ValueError):
             continue
     return None, "no PMC pass committed for the current kernels"
+
+
+FUSE_CLASSES = ((4, "copy"), (0, "NV1"), (1, "NV2"), (2, "NV4"), (3, "NV8"))
+
+
+def fuse_by_class(_lib, fusion, sims, key, device, es_in=2, es_out=2):
+    """Per class of the fuse launch (copy = one view, weight > 0 everywhere: value passes through; NV1 = one-view rim boxes;
+    NV2 / NV4 / NV8 = boxes seen by <= 2 / 4 / 8 views): algorithmic bytes (voxels x views read + voxels written, counted by
+    the planner), the class kernel's duration ALONE (one extra launch with option serial_classes: the kernels run one after the
+    other between HIP events) and the rate that gives -- so that the class furthest from the 8 TB/s ceiling is named in every line.
+    In the timed loop the five kernels run side by side on forked streams (roofline.achieved is that launch)."""
+    _lib.set_option("serial_classes", 1, device)
+    try:
+        for _ in range(2):
+            out = fusion.fuse(sims, transform_key=key, output_chunksize={d: 1 << 30 for d in "zyx"}, output_on_backend=True, device=device)
+            total_ms = _lib.last_kernel_ms(device)
+            del out
+        res = {}
+        for k, name in FUSE_CLASSES:
+            in_vox = _lib.get_counter(f"fuse_class_in_vox_{k}", device)
+            out_vox = _lib.get_counter(f"fuse_class_out_vox_{k}", device)
+            ms = _lib.get_counter(f"fuse_class_ms_{k}", device)
+            if out_vox <= 0:
+                continue
+            byt = in_vox * es_in + out_vox * es_out
+            gbs = byt / (ms * 1e-3) / 1e9 if ms > 0 else None
+            res[name] = {"output_voxels": out_vox, "algorithmic_bytes": byt, "ms_alone": ms if ms > 0 else None, "GB/s": gbs,
+                         "frac": gbs / HBM_PEAK_GBS if gbs else None}
+        res["serial_launch_ms"] = total_ms
+        return res
+    finally:
+        _lib.set_option("serial_classes", 0, device)
 
 
 def c3_content_based_leg(torch, dev, local_rank, args):
@@ -488,6 +521,96 @@ def _cpu_content_based(ts=104):
     return {"value": vox / dt / 1e6, "unit": "Mvoxels/s", "cores": 1, "kind": "port", "seconds": dt,
             "sample": f"oracle fuse_np(weights='content_based', sigma 5 / 11) of one chunk of {[int(v) for v in out_bb['shape']]} voxels incl. the 22 px halo, "
                       f"8 views (2x2x2 uint16 tiles of {ts}^3), {int(vox)} voxels after the trim"}
+
+
+def c5_stream_leg(torch, dev, local_rank, args):
+    """BASELINE.json config C5 (exaSPIM-style 512 x 1024 x 1024 uint16 tiles streamed from Zarr, chunked fuse) on a z-slab of its
+    grid: 1 x 2 x 3 tiles written as Zarr arrays (128^3 chunks, uncompressed) on local disk, ``fusion.fuse`` from the Zarr-backed
+    sims into an output Zarr store in the reference's default 256^3 chunks.  fuse() streams the launch blocks through
+    streaming.BlockPipeline (reader thread: chunk files -> pinned -> async upload; fuse on resident slabs; writer thread: async
+    download -> chunk files).  The rate is (tile bytes + output bytes) / wall; the ceiling is the SLOWEST stage run alone on the same
+    files with the same I/O pool: reading every tile once into pinned memory, writing the result once, and the two PCIe
+    directions at the rate the PCIe leg measured -- a perfectly overlapped pipeline takes max(stage), so frac = max(stage) / wall."""
+    import shutil
+    import tempfile
+
+    from multiview_stitcher_amd import _lib, fusion, ngff_utils, streaming, zarr_io
+    from multiview_stitcher_amd import device as dv
+    from multiview_stitcher_amd import spatial_image_utils as si
+
+    grid, tile = np.array([1, 2, 3]), np.array([512, 1024, 1024])
+    overlap = np.round(tile * args.overlap_frac).astype(int)
+    need = int(np.prod(tile)) * 2 * int(np.prod(grid)) * 2.2
+    base = os.environ.get("MVS_BENCH_TMP")
+    if base is None:
+        for cand in (tempfile.gettempdir(), "/dev/shm"):
+            try:
+                if shutil.disk_usage(cand).free > need * 1.3:
+                    base = cand
+                    break
+            except OSError:
+                continue
+    if base is None:
+        return {"skipped": "no directory with %.0f GB free" % (need * 1.3 / 1e9)}
+    tmp = tempfile.mkdtemp(prefix="mvs_c5_", dir=base)
+    try:
+        tiles, _, org = make_mosaic_on_device(torch, dev, grid, tile, overlap, seed=11, max_jitter=0)
+        lazy = []
+        t_w0 = time.perf_counter()
+        for i, (t, o) in enumerate(zip(tiles, org)):
+            host = t.view(torch.int16).cpu().numpy().view(np.uint16)
+            s_ = si.to_spatial_image(host, dims=["z", "y", "x"], scale={d: 1.0 for d in "zyx"}, translation=dict(zip("zyx", o)))
+            z = ngff_utils.write_sim_to_ome_zarr(s_, os.path.join(tmp, f"tile{i}.zarr"), zarr_array_creation_kwargs={"chunks": (128, 128, 128)})
+            si.set_sim_affine(z, np.eye(4), si.DEFAULT_TRANSFORM_KEY)
+            lazy.append(z)
+            del host
+        setup_s = time.perf_counter() - t_w0
+        del tiles
+        torch.cuda.empty_cache()
+        in_bytes = float(np.prod(tile)) * 2 * len(lazy)
+        walls = []
+        for rep in range(2):                 # (the first call sizes the pinned pool and the device blocks)
+            out_url = os.path.join(tmp, f"fused{rep}.zarr")
+            _lib.synchronize(local_rank)
+            t0 = time.perf_counter()
+            fused = fusion.fuse(lazy, transform_key=si.DEFAULT_TRANSFORM_KEY, output_chunksize={d: 256 for d in "zyx"},
+                                output_zarr_url=out_url, zarr_options={"ome_zarr": False}, device=local_rank)
+            _lib.synchronize(local_rank)
+            walls.append(time.perf_counter() - t0)
+            shape = [int(v) for v in fused.data.shape[-3:]]
+            if rep == 0:
+                shutil.rmtree(out_url, ignore_errors=True)
+        wall = walls[-1]
+        out_bytes = float(np.prod(shape)) * 2
+        # the stages alone, same files, same pool
+        raw, buf = streaming.PinnedPool().get(tuple(int(v) for v in tile), np.uint16)
+        t0 = time.perf_counter()
+        for z in lazy:
+            streaming.read_window(z.data, buf)
+        read_s = time.perf_counter() - t0
+        res_host = np.asarray(fused.data[...]) if not isinstance(fused.data, np.ndarray) else fused.data
+        res_host = res_host.reshape(shape)
+        arr2 = zarr_io.ZarrArray.create(os.path.join(tmp, "again.zarr"), shape, [256] * 3, np.uint16)
+        t0 = time.perf_counter()
+        streaming.write_region(arr2, [0, 0, 0], res_host)
+        write_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        d_ = dv.DeviceArray.from_host_async(buf, local_rank)
+        dv.ticket_sync(d_.ready_ticket)
+        h2d_rate = float(np.prod(tile)) * 2 / (time.perf_counter() - t0)
+        del d_, raw, buf
+        stages = {"read_tiles_s": read_s, "write_result_s": write_s, "h2d_s": in_bytes / h2d_rate, "d2h_s": out_bytes / h2d_rate}
+        floor = max(stages.values())
+        return {"workload": "C5 z-slab: 1x2x3 (z,y,x) grid of 512x1024x1024 uint16 tiles, 20% overlap, Zarr in (128^3 chunks, uncompressed) -> "
+                            "fuse (256^3 output chunks merged into launch blocks) -> Zarr out, on " + base,
+                "output_shape": shape, "wall_s": wall, "first_call_s": walls[0], "tile_store_setup_s": setup_s,
+                "gb_per_s": (in_bytes + out_bytes) / wall / 1e9, "mvoxels_s": float(np.prod(shape)) / wall / 1e6,
+                "in_gb": in_bytes / 1e9, "out_gb": out_bytes / 1e9, "stages_alone": stages,
+                "slowest_stage": max(stages, key=stages.get), "ceiling_gb_per_s": (in_bytes + out_bytes) / floor / 1e9,
+                "frac_of_slowest_stage": floor / wall, "h2d_gb_per_s_one_tile": h2d_rate / 1e9,
+                "note": "files were written just before: reads come from the page cache (a cold disk would lower read_tiles_s' rate and the ceiling with it)"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
@@ -690,8 +813,16 @@ def main():
             else:
                 print(f"gc gen{info['generation']} {1e3 * (time.perf_counter() - gc_t['t']):.1f} ms collected {info['collected']}", file=sys.stderr)
         gc.callbacks.append(gc_cb)
-    for _ in range(max(args.warmup, 0)):
+    # the first step of the process is the COLD one: library just loaded, no plan / replay memo, no pooled device blocks, the
+    # mosaic-sized result hipMalloc'ed -- what a caller with ONE mosaic sees (config.step_cold_ms)
+    cold = {}
+    for w in range(max(args.warmup, 0)):
+        t_w = time.perf_counter()
         step()
+        torch.cuda.synchronize()
+        if w == 0:
+            cold = {"step_cold_ms": (time.perf_counter() - t_w) * 1e3, "register_first_call_ms": reg_ms[0] if do_register else None,
+                    "fuse_first_call_ms": fuse_ms[0], "pairwise_first_call_ms": pair_ms[0] if do_register else None}
     cold_plan_ms = plan_ms[0] if plan_ms else None      # the first call of a geometry builds (and caches) the decomposition
     for lst in (kernel_ms, reg_ms, fuse_ms, pair_ms, plan_ms):
         lst.clear()
@@ -779,6 +910,12 @@ def main():
             if rep == 0:
                 default_chunks_first_ms = ms_d
             default_chunks_ms = ms_d
+    by_class = None
+    if world == 1:
+        try:
+            by_class = fuse_by_class(_lib, fusion, sims, key_out if do_register else key_in, local_rank)
+        except Exception as e:   # noqa: BLE001 - an optional leg must not take the bench line down
+            by_class = {"error": repr(e)[:300]}
     pcie = None
     if world == 1 and do_register and not args.no_pcie:
         try:
@@ -791,6 +928,13 @@ def main():
             c3 = c3_content_based_leg(torch, dev, local_rank, args)
         except Exception as e:   # noqa: BLE001 - an optional leg must not take the bench line down
             c3 = {"error": repr(e)[:300]}
+    c5 = None
+    if world == 1 and not args.no_c5:
+        out_holder.clear()
+        try:
+            c5 = c5_stream_leg(torch, dev, local_rank, args)
+        except Exception as e:   # noqa: BLE001 - an optional leg must not take the bench line down
+            c5 = {"error": repr(e)[:300]}
     traffic, traffic_src = fuse_traffic_bytes(grid, tile) if world == 1 else (None, "N > 1")
     # per-rank phase figures (own step time: register + fuse of this rank, without the other ranks' tail)
     own_ms = float(np.mean(reg_ms)) + float(np.mean(fuse_ms))
@@ -814,7 +958,9 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "strong" if shard else "weak",
+            # what `--gpus N` does with N > 1: 'shard' (the default) cuts ONE mosaic over the ranks = strong scaling; the N = 1 line
+            # carries the label of the mode its N > 1 siblings will be compared under
+            "scaling": "weak" if mode == "replica" else "strong",
             "vs_baseline": None,
             "dtype": "u16 in/out, f32 accumulate, f64 coordinates",
             "data": "synthetic (seeded smoothed noise mosaic generated in HBM, integer jitter unknown to metadata)",
@@ -850,12 +996,19 @@ def main():
                 "pairs_per_step_by_rank": pairs_by_rank,
                 "fuse_host_replay": bool(fusion._REPLAY[0]),
                 "fuse_plan_cold_ms": cold_plan_ms,
+                # first register() + fuse() of this process (library loaded, nothing cached, result buffer not yet allocated):
+                # the figures of a one-mosaic caller; `value` / ms_per_step are the steady state of a series of mosaics
+                "step_cold_ms": cold.get("step_cold_ms"),
+                "register_first_call_ms": cold.get("register_first_call_ms"),
+                "pairwise_first_call_ms": cold.get("pairwise_first_call_ms"),
+                "fuse_first_call_ms": cold.get("fuse_first_call_ms"),
                 "fuse_default_chunksize_ms": default_chunks_ms,
                 "fuse_default_chunksize_first_call_ms": default_chunks_first_ms,
                 "registration_max_abs_error_px": reg_err,
                 "c3_fuse_mvoxels_s": c3.get("mvoxels_s") if c3 else None,
             },
             "c3_content_based": c3,
+            "c5_stream": c5,
             "roofline": {
                 "bound": "hbm",
                 "kernel": "fuse launch of rank 0 = copy_region_kernel + fuse_region_kernel<1|2|4|8> (u16) side by side on forked streams, timed as one unit (first start to last end)",
@@ -868,6 +1021,7 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": alg_bytes,
+                "by_class": by_class,
             },
             "roofline_register": None if not (do_register and reg_pairs) else {
                 "bound": "hbm",

@@ -152,7 +152,10 @@ int mvs_set_option(int device, const char* key, int64_t value);
  * "reg_candidates" (candidates that entered the scoring), "reg_pruned" (of these, left unfinished), "reg_cand_volumes"
  * (candidate volumes the SSIM passes went through), "reg_slab_pairs" (phase correlations that ran in three passes: crops with one
  * short and two power-of-two axes; option "fft_no_slab" switches that form off), "fuse_plan_ms" = host time the last mvs_fuse_chunk spent decomposing the chunk
- * (0 when the plan cached for the same geometry was reused).  reset != 0 clears an accumulating counter after reading. */
+ * (0 when the plan cached for the same geometry was reused).  Per class k of the last region-kernel launch (0 one-view rim
+ * boxes, 1 NV = 2, 2 NV <= 4, 3 NV <= 8, 4 copy): "fuse_class_in_vox_<k>" (voxels x views of the class's boxes),
+ * "fuse_class_out_vox_<k>", and "fuse_class_ms_<k>" = the class kernel's own duration when that launch ran with option
+ * "serial_classes" = 1 (-1 otherwise).  reset != 0 clears an accumulating counter after reading. */
 int mvs_get_counter(int device, const char* key, int32_t reset, double* value_out);
 /* Device time (ms, hipEvent) spent in the kernels of the most recent compute
  * call on this device; blocks until that work has finished. */

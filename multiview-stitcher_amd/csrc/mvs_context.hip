@@ -157,6 +157,7 @@ static void pool_flush(MvsContext* c) {
 
 double mvs_rows_last_plan_ms(MvsContext* c);       // mvs_fuse_rows.hip
 double mvs_regions_last_plan_ms(MvsContext* c);    // mvs_fuse_region.hip
+double mvs_regions_class_stat(MvsContext* c, int what, int cls);   // mvs_fuse_region.hip
 
 extern "C" {
 
@@ -235,6 +236,12 @@ int mvs_init(int device) {
         if (ev && *ev) c->fft_no_slab = atoi(ev) != 0;
         ev = getenv("MVS_FFT_NO_PAIR");
         if (ev && *ev) c->fft_no_pair = atoi(ev) != 0;
+    }
+    // lane 0 fuses whole mosaics: its side streams (mvs_fuse_regions forks the class kernels onto them) are created here and not
+    // inside the first large launch, where their one-off cost (tens of ms) showed up in a one-mosaic caller's first fuse()
+    if (((device >> 8) & 0xff) == 0) {
+        const int rca = mvs_ensure_aux_streams(c);
+        if (rca) return rca;
     }
     c->ready = true;
     c->last_error.clear();
@@ -452,6 +459,21 @@ int mvs_get_counter(int device, const char* key, int32_t reset, double* value_ou
     if (!strcmp(key, "fuse_plan_ms")) {
         *value_out = mvs_rows_last_plan_ms(c) + mvs_regions_last_plan_ms(c);
         return MVS_OK;
+    }
+    // per-class figures of the last region-kernel launch of this context, <k> = 0 (one-view rim boxes), 1 (NV = 2), 2 (NV <= 4),
+    // 3 (NV <= 8), 4 (copy): "fuse_class_in_vox_<k>" / "fuse_class_out_vox_<k>" = input voxel reads (sum over the class's boxes of
+    // voxels x views) and output voxels of the class; "fuse_class_ms_<k>" = the class kernel's own duration, measured only by a
+    // launch made with option "serial_classes" = 1 (the kernels then run one after the other between timing events; -1 otherwise)
+    {
+        static const char* const names[3] = {"fuse_class_in_vox_", "fuse_class_out_vox_", "fuse_class_ms_"};
+        for (int w = 0; w < 3; ++w) {
+            const size_t n = strlen(names[w]);
+            if (!strncmp(key, names[w], n) && key[n] >= '0' && key[n] <= '4' && key[n + 1] == '\0') {
+                if (w == 2) MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
+                *value_out = mvs_regions_class_stat(c, w, key[n] - '0');
+                return MVS_OK;
+            }
+        }
     }
     return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_get_counter: unknown key '%s'", key);
 }

@@ -970,6 +970,12 @@ struct PlanCache {
     bool valid = false;
     int mixed_count = 0;      // option "fuse_mixed": the padded, space-ordered list of the copy / one-view / two-view bricks (stored first)
     bool mixed = false;
+    double class_in_vox[5] = {0, 0, 0, 0, 0};    // sum over the class's boxes of voxels x views (input voxel reads the class cannot avoid)
+    double class_out_vox[5] = {0, 0, 0, 0, 0};   // voxels of the class's boxes
+    // measurement (counters "fuse_class_ms_<k>"): with option serial_classes the class kernels of a launch run one after the other
+    // and are bracketed by these timing events (created at the first such launch)
+    hipEvent_t class_ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool class_timed[5] = {false, false, false, false, false};
 };
 PlanCache g_plan[MVS_MAX_DEVICES * MVS_MAX_LANES];
 double g_region_plan_ms[MVS_MAX_DEVICES * MVS_MAX_LANES];
@@ -1048,6 +1054,19 @@ void axis_breakpoints(const TrView* htr, int n_views, int d, int t, int o, std::
 
 double mvs_regions_last_plan_ms(MvsContext* c) { return g_region_plan_ms[mvs_ctx_index(c->device)]; }
 
+// what = 0: input voxel reads, 1: output voxels, 2: kernel ms of class `cls` in the last launch (-1: that launch was not a serial one)
+double mvs_regions_class_stat(MvsContext* c, int what, int cls) {
+    PlanCache& pc = g_plan[mvs_ctx_index(c->device)];
+    if (cls < 0 || cls > 4) return -1.0;
+    if (what == 0) return pc.class_in_vox[cls];
+    if (what == 1) return pc.class_out_vox[cls];
+    if (!pc.class_timed[cls] || !pc.class_ev[cls] || !pc.class_ev[cls + 1]) return -1.0;
+    float ms = -1.f;
+    if (hipEventSynchronize(pc.class_ev[cls + 1]) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, pc.class_ev[cls], pc.class_ev[cls + 1]) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
 // Returns MVS_OK and sets *done = true when the chunk was fused by the region kernel; *done = false means the
 // caller must use the column kernel (more than kMaxRV views on one region, or too many regions/bricks).
 int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_views, int dtype, void* dout, const int64_t os[3],
@@ -1077,6 +1096,7 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
         if (ncell == 0 || ncell > 60000) return MVS_OK;
         std::vector<Region> regions;
         std::vector<Item> items_by_class[5];
+        double in_vox[5] = {0, 0, 0, 0, 0}, out_vox[5] = {0, 0, 0, 0, 0};
         regions.reserve(ncell);
         std::vector<int> zviews, yviews;
         struct SlabRegion { int rid, nbx, bytes_per_item; };
@@ -1141,6 +1161,11 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
                     const bool copy_class = (nv == 1) && positive_full;   // one full view with positive weight everywhere
                     const int cls = copy_class ? 4 : nv <= 1 ? 0 : nv == 2 ? 1 : nv <= 4 ? 2 : 3;
                     R.nviews = nv | (lxb << 8) | (cls << 12);
+                    {
+                        const double vox = (double)(R.z1 - R.z0) * (double)(R.y1 - R.y0) * (double)(R.x1 - R.x0);
+                        in_vox[cls] += vox * nv;
+                        out_vox[cls] += vox;
+                    }
                     const int rid = (int)regions.size();
                     if (rid >= 65535) return MVS_OK;                     // (0xffff marks a padding item)
                     regions.push_back(R);
@@ -1242,6 +1267,8 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
         }
         for (int k = 0; k < 5; ++k) {
             pc.class_count[k] = (int)items_by_class[k].size();
+            pc.class_in_vox[k] = in_vox[k];
+            pc.class_out_vox[k] = out_vox[k];
             items.insert(items.end(), items_by_class[k].begin(), items_by_class[k].end());
         }
         if (items.empty() || items.size() > (1u << 28)) return MVS_OK;
@@ -1292,8 +1319,14 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
         else hipLaunchKernelGGL((fuse_region_mixed_kernel<float, float>), grid, block, 0, c->stream, P, 0, cnt);
         item0 = cnt;
     }
+    const bool time_classes = c->serial_classes && !pc.mixed_count;
+    if (time_classes)
+        for (hipEvent_t& e : pc.class_ev)
+            if (!e) MVS_HIP_TRY(c, hipEventCreate(&e));
     for (int k = 0; k < 5; ++k) {
         const int cnt = pc.class_count[k];
+        pc.class_timed[k] = time_classes && cnt > 0;
+        if (time_classes) MVS_HIP_TRY(c, hipEventRecord(pc.class_ev[k], c->stream));
         hipStream_t kstream = c->stream;
         if (fork && cnt && side_of_class[k] >= 0) {
             kstream = c->aux_stream[side_of_class[k]];
@@ -1315,6 +1348,7 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
         }
         item0 += cnt;
     }
+    if (time_classes) MVS_HIP_TRY(c, hipEventRecord(pc.class_ev[5], c->stream));
     MVS_HIP_TRY(c, hipGetLastError());
     for (int a = 0; a < 4; ++a)
         if (side_used[a]) {

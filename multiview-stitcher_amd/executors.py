@@ -177,7 +177,7 @@ def pin_process_to_compact_cpus(slot=0, n_cpus=None):
     calls.  On a two-socket host with 256 hardware threads and no affinity the scheduler spreads and migrates them over
     both sockets (cold caches, cross-socket wake-ups, and a cgroup quota that is charged per period whichever CPUs ran);
     measured on the GPU box: north-star step 68-69 ms without affinity, 61-63 ms inside ANY block of 16 CPUs
-    (``taskset -c 0-15`` ... ``128-143``, either socket: ``tools/affinity_probe.sh``).
+    (``taskset -c 0-15`` ... ``128-143``, either socket; `lscpu` / `rocm-smi --showtoponuma` on the box).
 
     ``slot``: which block (one per process of a node: pass the local rank); ``n_cpus``: block size, default 16 (the
     container's CPU quota when that is smaller, at least 8).  An affinity mask that is already narrower than twice the block is

@@ -163,7 +163,7 @@ def check_boxes(fused_data, tasks, los, shapes, rtol=1e-4, int_boundary_rtol=1e-
 
 def _record(agg):
     """With MVS_AT_SIZE_STATS=<file> every check appends its statistics (test id + counts) as one JSON line: the numbers behind
-    "how many voxels needed the noise floor" end up under profiles/ (tools/profile_round3.sh)."""
+    "how many voxels needed the noise floor" end up under profiles/ (tools/profile_round.sh)."""
     import json
     import os
 

@@ -4,6 +4,14 @@ import numpy as np
 from oracle import fuse_oracle as fo
 
 
+class SignedView:
+    """torch's __cuda_array_interface__ import has no uint16: hand a DeviceArray's bytes over as int16 (the test mosaics stay below 4096)."""
+
+    def __init__(self, arr):
+        self.__cuda_array_interface__ = dict(arr.__cuda_array_interface__, typestr="<i2")
+        self.owner = arr
+
+
 def sim_to_view(sim):
     from multiview_stitcher_amd import spatial_image_utils as si
 

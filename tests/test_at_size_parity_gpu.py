@@ -16,6 +16,7 @@ except ImportError:   # pragma: no cover
     torch = None
 
 from tests import at_size
+from tests.helpers import SignedView
 
 pytestmark = pytest.mark.gpu
 
@@ -138,8 +139,8 @@ def test_north_star_fractional_offsets_sampled_oracle_parity(hip_device):
     # weight's last bit depended on where a lane's 8-voxel group started; it is (base + j) - fraction now, as in fold_u.)
     fused_c = fusion.fuse(sims, transform_key=key, output_on_backend=True, device=0, merge_chunks=False)
     _lib.synchronize(0)
-    a = torch.as_tensor(bench._SignedView(fused.data), device="cuda")
-    b = torch.as_tensor(bench._SignedView(fused_c.data), device="cuda")
+    a = torch.as_tensor(SignedView(fused.data), device="cuda")
+    b = torch.as_tensor(SignedView(fused_c.data), device="cuda")
     assert bool((a == b).all())
     d = None
     del a, b, d, fused_c

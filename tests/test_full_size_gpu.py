@@ -3,6 +3,8 @@ seconds, so the checks are size-independent properties of register + fuse on a m
 import numpy as np
 import pytest
 
+from tests.helpers import SignedView
+
 try:   # torch brings its own HIP runtime: it has to be loaded before libmvs_hip.so pulls in the system one (as in bench.py)
     import torch
 except ImportError:   # pragma: no cover
@@ -11,17 +13,9 @@ except ImportError:   # pragma: no cover
 pytestmark = pytest.mark.gpu
 
 
-class _SignedView:
-    """torch's __cuda_array_interface__ import has no uint16: hand the bytes over as int16 and view them back."""
-
-    def __init__(self, arr):
-        self.__cuda_array_interface__ = dict(arr.__cuda_array_interface__, typestr="<i2")
-        self.owner = arr
-
-
 def _as_torch(torch, arr):
     assert arr.dtype == np.uint16
-    return torch.as_tensor(_SignedView(arr), device="cuda")      # int16 view: the mosaic's values stay below 4096
+    return torch.as_tensor(SignedView(arr), device="cuda")      # int16 view: the mosaic's values stay below 4096
 
 
 def test_north_star_register_and_fuse_properties(hip_device):

@@ -1,10 +1,13 @@
-"""Copies the summaries of tools/profile_round4.sh from gpurun_out/r4prof into profiles/round4_* and derives
-profiles/round4_fuse_traffic.json (HBM bytes per fuse launch from the PMC passes, corrected as MI355X_MICROARCH.md prescribes:
+"""usage: python tools/collect_round.py round6
+Copies the summaries of tools/profile_round.sh from gpurun_out/prof_<round> into profiles/<round>_* and derives
+profiles/<round>_fuse_traffic.json (HBM bytes per fuse launch from the PMC passes, corrected as MI355X_MICROARCH.md prescribes:
 FETCH_SIZE is in KB and counts half of the bytes on gfx950 -- checked by the single-tile calibration pass -- WRITE_SIZE in KB)."""
-import csv, glob, json, os, re, shutil, collections
+import csv, glob, json, os, re, shutil, collections, sys
+
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "round6"
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r4prof")
+SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
 DST = os.path.join(ROOT, "profiles")
 
 
@@ -24,44 +27,49 @@ def per_kernel(path, reps):
 
 
 copies = {
-    "bench/**/*kernel_stats.csv": "round4_bench_kernel_stats.csv",
-    "bench1/**/*kernel_stats.csv": "round4_bench_kernel_stats_1lane.csv",
-    "fuse_launch_windows.csv": "round4_fuse_launch_windows.csv",
-    "fuse_variants.txt": "round4_fuse_variants.txt",
-    "cb_kstats.txt": "round4_cb_kstats.txt",
-    "bench_kstats.txt": "round4_bench_kstats.txt",
-    "bench1_kstats.txt": "round4_bench_kstats_1lane.txt",
-    "cb_probe.txt": "round4_cb_probe.txt",
-    "pair_overhead.txt": "round4_pair_overhead.txt",
-    "host_profile.txt": "round4_host_profile.txt",
-    "bench_line.json": "round4_bench_line.json",
-    "pmc_summary.txt": "round4_pmc_summary.txt",
-    "at_size_parity.jsonl": "round4_at_size_parity.jsonl",
-    "h2d_probe.txt": "round4_h2d_probe.txt",
-    "fuse_classes.txt": "round4_fuse_classes.txt",
+    "bench/**/*kernel_stats.csv": ROUND + "_bench_kernel_stats.csv",
+    "bench1/**/*kernel_stats.csv": ROUND + "_bench_kernel_stats_1lane.csv",
+    "fuse_launch_windows.csv": ROUND + "_fuse_launch_windows.csv",
+    "fuse_variants.txt": ROUND + "_fuse_variants.txt",
+    "cb_kstats.txt": ROUND + "_cb_kstats.txt",
+    "bench_kstats.txt": ROUND + "_bench_kstats.txt",
+    "bench1_kstats.txt": ROUND + "_bench_kstats_1lane.txt",
+    "cb_probe.txt": ROUND + "_cb_probe.txt",
+    "pair_overhead.txt": ROUND + "_pair_overhead.txt",
+    "host_profile.txt": ROUND + "_host_profile.txt",
+    "bench_line.json": ROUND + "_bench_line.json",
+    "pmc_summary.txt": ROUND + "_pmc_summary.txt",
+    "at_size_parity.jsonl": ROUND + "_at_size_parity.jsonl",
+    "h2d_probe.txt": ROUND + "_h2d_probe.txt",
+    "fuse_classes.txt": ROUND + "_fuse_classes.txt",
+    "bench_busy.txt": ROUND + "_bench_busy.txt",
+    "lane_gaps.txt": ROUND + "_lane_gaps.txt",
+    "launch_rate.txt": ROUND + "_launch_rate.txt",
+    "register_phases.txt": ROUND + "_register_phases.txt",
+    "fuse_alignment.txt": ROUND + "_fuse_alignment.txt",
 }
 for pat, name in copies.items():
     f = find(pat)
     if f:
         shutil.copyfile(f, os.path.join(DST, name))
-for d in ("int", "frac", "cal", "cb"):
+for d in ("int", "frac", "cal", "al128", "cb"):
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         f = find(f"pmc_{d}_{c}/**/*counter_collection.csv")
         if f:
-            shutil.copyfile(f, os.path.join(DST, f"round4_pmc_{d}_{c.lower()}.csv"))
+            shutil.copyfile(f, os.path.join(DST, fROUND + "_pmc_{d}_{c.lower()}.csv"))
 log = open(os.path.join(SRC, "bench.log")).read()
 m = re.findall(r"^\{.*\}$", log, flags=re.M)
 if m:
-    open(os.path.join(DST, "round4_bench_line_under_rocprof.json"), "w").write(m[-1] + "\n")
+    open(os.path.join(DST, ROUND + "_bench_line_under_rocprof.json"), "w").write(m[-1] + "\n")
 
-out = {"fetch_correction": 2.0, "source": "profiles/round4_pmc_{int,frac,cal,cb}_{fetch,write}_size.csv (rocprofv3 --pmc, one counter per run, kernel-filtered)"}
+out = {"fetch_correction": 2.0, "source": "profiles/" + ROUND + "_pmc_{int,frac,cal,al128,cb}_{fetch,write}_size.csv (rocprofv3 --pmc, one counter per run, kernel-filtered)"}
 cal_f = per_kernel(find("pmc_cal_FETCH_SIZE/**/*counter_collection.csv"), 2)
 cal_w = per_kernel(find("pmc_cal_WRITE_SIZE/**/*counter_collection.csv"), 2)
 out["calibration"] = {"case": "single 512^3 tile: copy_region_kernel reads exactly what it writes",
                       "copy_fetch_size_kb": cal_f["copy_region_kernel<unsigned short, unsigned short>"][0],
                       "copy_write_size_kb": cal_w["copy_region_kernel<unsigned short, unsigned short>"][0]}
 out["calibration"]["fetch_over_write"] = out["calibration"]["copy_fetch_size_kb"] / out["calibration"]["copy_write_size_kb"]
-for tag, key, reps in (("int", "integer_offsets", 2), ("frac", "fractional_offsets", 2), ("cb", "content_based_probe", 3)):
+for tag, key, reps in (("int", "integer_offsets", 2), ("frac", "fractional_offsets", 2), ("al128", "aligned_128B_geometry", 2), ("cb", "content_based_probe", 5)):
     f = per_kernel(find(f"pmc_{tag}_FETCH_SIZE/**/*counter_collection.csv"), reps)
     w = per_kernel(find(f"pmc_{tag}_WRITE_SIZE/**/*counter_collection.csv"), reps)
     fk = sum(v * n for v, n in f.values())
@@ -72,7 +80,7 @@ for tag, key, reps in (("int", "integer_offsets", 2), ("frac", "fractional_offse
 out["workload"] = "4x4x4 grid of 512^3 uint16 tiles, 20 % overlap (content_based_probe: 2x2x2 grid of 256^3 tiles, 256^3 chunks + 22 px halo, whole fuse() call)"
 out["hbm_bytes_per_launch"] = out["integer_offsets"]["hbm_bytes_per_launch"]
 out["note"] = "bench.py's registered mosaic has (recovered) integer offsets, so its 'traffic' is the integer_offsets figure"
-import subprocess, sys
+import subprocess
 sys.path.insert(0, ROOT)
 import bench
 out["csrc_digest"] = bench.csrc_digest()
@@ -81,5 +89,5 @@ try:
 except Exception:
     out["git_hash"] = "?"
 out["integer_offsets_case"] = "4x4x4 grid of 512^3 uint16 tiles with +-3 px integer jitter (tools/fuse_probe.py 2 2): the geometry of bench.py's registered mosaic"
-json.dump(out, open(os.path.join(DST, "round4_fuse_traffic.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(DST, ROUND + "_fuse_traffic.json"), "w"), indent=1)
 print(json.dumps({k: (v["hbm_bytes_per_launch"] if isinstance(v, dict) and "hbm_bytes_per_launch" in v else None) for k, v in out.items()}, indent=1))

@@ -41,6 +41,11 @@ for _ in range(reps):
 vox = float(np.prod(out.shape))
 byt = len(sims) * float(np.prod(tile)) * 2 + vox * 2
 print("shape", out.shape, "kernel ms", ms, "GB/s", byt / (min(ms) * 1e-3) / 1e9)
+if os.environ.get("MVS_SERIAL", "0") == "1":      # the class kernels ran one after the other: their own durations and rates
+    for k, name in ((4, "copy"), (0, "NV1"), (1, "NV2"), (2, "NV4"), (3, "NV8")):
+        iv, ov_, t = (_lib.get_counter(f"fuse_class_{w}_{k}") for w in ("in_vox", "out_vox", "ms"))
+        if ov_ > 0:
+            print("   class %-4s out %7.1f Mvox  alg %6.2f GB  alone %6.3f ms  %6.0f GB/s" % (name, ov_ / 1e6, (iv + ov_) * 2 / 1e9, t, (iv + ov_) * 2 / (t * 1e-3) / 1e9))
 if os.environ.get("MVS_COMPARE"):        # the same mosaic through the generic kernel: must agree up to the knife-edge voxels
     a = out.data.get().astype(np.int32)
     _lib.set_option("rows_v1", 0); _lib.set_option("force_generic", 1)
