@@ -20,7 +20,7 @@ roofline = algorithmic HBM bytes of the dominant kernel (fuse: every input voxel
            output voxel once) / its HIP-event duration, vs 8 TB/s
 roofline_register = algorithmic bytes of the pairwise registrations / their wall time
 value_incl_pcie = the same mosaic with tiles starting and the result ending in pinned host memory
-           (uploads overlapped with registration, downloads with fusion), N = 1 only
+           (uploads overlapped with registration, downloads with fusion); N > 1 (shard): every rank its own pipeline
 cpu_baseline = the numpy/scipy oracle timed on this box on a bounded sample (rank 0, N=1 only)
 """
 import argparse
@@ -55,7 +55,7 @@ def parse_args():
                          "(strong scaling); 'replica' = one mosaic per rank (weak scaling)")
     ap.add_argument("--pruning", default="alternating_pattern",
                     help="pre_registration_pruning_method (reference default: alternating_pattern)")
-    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pipeline leg (N = 1 only)")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive pipeline leg (N = 1 and --mode shard)")
     ap.add_argument("--no-c3", action="store_true", help="skip the content-based leg (BASELINE config C3; N = 1 only)")
     ap.add_argument("--no-c5", action="store_true", help="skip the Zarr-streamed leg (BASELINE config C5, a z-slab of its grid; N = 1 only)")
     return ap.parse_args()
@@ -577,6 +577,7 @@ def c5_stream_leg(torch, dev, local_rank, args):
                                 output_zarr_url=out_url, zarr_options={"ome_zarr": False}, device=local_rank)
             _lib.synchronize(local_rank)
             walls.append(time.perf_counter() - t0)
+            blocks = [{k: round(v, 3) for k, v in b.items()} for b in streaming.LAST_TIMELINE]
             shape = [int(v) for v in fused.data.shape[-3:]]
             if rep == 0:
                 shutil.rmtree(out_url, ignore_errors=True)
@@ -608,43 +609,61 @@ def c5_stream_leg(torch, dev, local_rank, args):
                 "in_gb": in_bytes / 1e9, "out_gb": out_bytes / 1e9, "stages_alone": stages,
                 "slowest_stage": max(stages, key=stages.get), "ceiling_gb_per_s": (in_bytes + out_bytes) / floor / 1e9,
                 "frac_of_slowest_stage": floor / wall, "h2d_gb_per_s_one_tile": h2d_rate / 1e9,
+                "launch_blocks": len(blocks), "block_timeline_s": blocks,
                 "note": "files were written just before: reads come from the page cache (a cold disk would lower read_tiles_s' rate and the ceiling with it)"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
+def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out, shard=None):
     """PCIe-inclusive run of one mosaic through the PUBLIC API only: the tiles start in pinned host memory
     (device.pinned_empty) and the fused mosaic ends there.  ``device.to_device_async`` queues the uploads in tile order on the
     device's copy stream (csrc/mvs_transfer.hip), ``registration.register`` registers every pair when its two tiles have landed
     (the pair jobs carry the uploads' tickets), ``fusion.fuse_to_host`` fuses the mosaic in z slabs and downloads every finished
-    slab while the next one is fused."""
+    slab while the next one is fused.  N > 1 (``shard`` = {rank, world, executor, dist, backend}): every rank runs this pipeline on
+    ITS tiles (brick + halo, from its own pinned host memory over its own link) and ITS output sub-box
+    (sharding.fuse_shard_to_host); the time is the max over ranks between two barriers, the voxels the sum."""
     from multiview_stitcher_amd import device as dv
-    from multiview_stitcher_amd import _lib, fusion, registration
+    from multiview_stitcher_amd import _lib, fusion, registration, sharding
 
     host_sims = []
     for s_ in sims:
+        if not dv.is_device_array(s_.data):       # (N > 1: a view another rank holds -- metadata only)
+            host_sims.append(s_)
+            continue
         h = dv.pinned_empty(s_.data.shape, s_.data.dtype)
         h[...] = s_.data.get()
         host_sims.append(s_.copy(data=h))
-    n_slabs = 8
+    n_slabs = 8 if shard is None else max(2, 8 // shard["world"])
     trace = {}
     out_host = [None]
+    executor = shard["executor"] if shard else None
+
+    def sync_ranks():
+        if shard:
+            shard["dist"].barrier()
 
     def run():
         registration._pair_timeline = pairs = []
         try:
             _lib.synchronize(local_rank)
+            sync_ranks()
             t0 = time.perf_counter()
             m0 = dv.mark(local_rank)
             a_sims = dv.to_device_async(host_sims, local_rank)
-            uploads = [a.data.ready_ticket for a in a_sims]
+            uploads = [a.data.ready_ticket for a in a_sims if dv.is_device_array(a.data)]
             registration.register(a_sims, transform_key=key_in, new_transform_key=key_out, device=local_rank,
-                                  pre_registration_pruning_method=args.pruning)
+                                  pre_registration_pruning_method=args.pruning, pairwise_executor=executor)
         finally:
             registration._pair_timeline = None
         t_reg = time.perf_counter()
-        fused, slabs = fusion.fuse_to_host(a_sims, transform_key=key_out, n_slabs=n_slabs, out=out_host[0], device=local_rank, return_timeline=True)
+        if shard:
+            (fused, slabs), _ = sharding.fuse_shard_to_host(a_sims, shard["rank"], shard["world"], key_out, n_slabs=n_slabs, out=out_host[0],
+                                                             device=local_rank, return_timeline=True)
+        else:
+            fused, slabs = fusion.fuse_to_host(a_sims, transform_key=key_out, n_slabs=n_slabs, out=out_host[0], device=local_rank, return_timeline=True)
+        t_own = time.perf_counter()
+        sync_ranks()
         t1 = time.perf_counter()
         out_host[0] = np.asarray(fused.data)
         up_ms = [dv.ticket_elapsed_ms(m0, t) for t in uploads]
@@ -652,20 +671,35 @@ def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out):
         trace.update(upload_done_ms=max(up_ms), first_pair_done_ms=pair_ms[0] if pair_ms else None, last_pair_done_ms=pair_ms[-1] if pair_ms else None,
                      pairs_done_before_last_upload=int(sum(t < max(up_ms) for t in pair_ms)), pairs=len(pair_ms),
                      slab_fused_ms=[round(f, 1) for f, _ in slabs], slab_downloaded_ms=[round(d, 1) for _, d in slabs])
-        return t1 - t0, t_reg - t0, float(np.prod(out_host[0].shape))
+        return t1 - t0, t_reg - t0, float(np.prod(out_host[0].shape)), t_own - t0
 
     run()                                  # warm-up (pinned result buffer, device blocks of the uploads, plans)
-    total, t_reg, vox = run()
-    h2d_gb = sum(int(np.prod(h.data.shape)) * 2 for h in host_sims) / 1e9
+    total, t_reg, vox, own = run()
+    h2d_gb = sum(int(np.prod(h.data.shape)) * 2 for h in host_sims if isinstance(h.data, np.ndarray)) / 1e9
+    d2h_gb = vox * 2 / 1e9
+    by_rank = None
+    if shard:
+        dist, cpu = shard["dist"], shard["backend"] != "nccl"
+        t = torch.tensor([total, vox, h2d_gb, d2h_gb, own], dtype=torch.float64, device="cpu" if cpu else dev)
+        g = [torch.zeros_like(t) for _ in range(shard["world"])]
+        dist.all_gather(g, t)
+        total = max(float(x[0]) for x in g)
+        vox = sum(float(x[1]) for x in g)
+        by_rank = {"own_ms": [float(x[4]) * 1e3 for x in g], "h2d_gb": [float(x[2]) for x in g], "d2h_gb": [float(x[3]) for x in g]}
+        h2d_gb_all, d2h_gb_all = sum(by_rank["h2d_gb"]), sum(by_rank["d2h_gb"])
+    else:
+        h2d_gb_all, d2h_gb_all = h2d_gb, d2h_gb
     return {"value": vox / total / 1e6, "unit": "Mvoxels/s", "ms": total * 1e3, "register_phase_ms": t_reg * 1e3,
-            "h2d_gb": h2d_gb, "d2h_gb": vox * 2 / 1e9, "fuse_slabs": n_slabs,
+            "h2d_gb": h2d_gb_all, "d2h_gb": d2h_gb_all, "fuse_slabs": n_slabs, "by_rank": by_rank,
             "upload_done_ms": trace.get("upload_done_ms"), "h2d_gb_per_s": h2d_gb / (trace["upload_done_ms"] * 1e-3) if trace.get("upload_done_ms") else None,
-            "d2h_gb_per_s": vox * 2 / 1e9 / max(total - t_reg, 1e-9), "timeline": trace,
-            "api": "device.pinned_empty, device.to_device_async, registration.register, fusion.fuse_to_host (no torch streams, no private helpers)",
+            "d2h_gb_per_s": d2h_gb / max(own - t_reg, 1e-9), "timeline": trace,
+            "api": "device.pinned_empty, device.to_device_async, registration.register, fusion.fuse_to_host"
+                   + (" / sharding.fuse_shard_to_host" if shard else "") + " (no torch streams, no private helpers)",
             "note": "tiles in pinned host memory -> uploads in tile order on the device's copy stream, overlapped with the registration of "
                     "the pairs whose tiles have arrived (pair jobs wait for their tiles' tickets on their lanes) -> resolution -> fuse in z "
-                    "slabs, each slab's download overlapped with the next slab's fuse; timeline: timed tickets, ms since the first upload "
-                    "was queued"}
+                    "slabs, each slab's download overlapped with the next slab's fuse; timeline (rank 0): timed tickets, ms since the first "
+                    "upload was queued" + ("; N > 1: every rank uploads its brick + halo (halo tiles cross the host link once per rank "
+                                           "that needs them: h2d_gb is their sum) and downloads its sub-box" if shard else "")}
 
 
 def main():
@@ -917,11 +951,16 @@ def main():
         except Exception as e:   # noqa: BLE001 - an optional leg must not take the bench line down
             by_class = {"error": repr(e)[:300]}
     pcie = None
-    if world == 1 and do_register and not args.no_pcie:
-        try:
-            pcie = pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out)
-        except Exception as e:   # noqa: BLE001 - an optional leg must not take the bench line down
-            pcie = {"error": repr(e)[:300]}
+    if (world == 1 or shard) and do_register and not args.no_pcie:
+        out_holder.clear()
+        shard_ctx = {"rank": rank, "world": world, "executor": executor, "dist": dist, "backend": backend} if shard else None
+        if shard:
+            pcie = pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out, shard=shard_ctx)     # (collective: no rank may skip it)
+        else:
+            try:
+                pcie = pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out)
+            except Exception as e:   # noqa: BLE001 - an optional leg must not take the bench line down
+                pcie = {"error": repr(e)[:300]}
     c3 = None
     if world == 1 and not args.no_c3:
         try:

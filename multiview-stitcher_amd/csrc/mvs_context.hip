@@ -223,6 +223,15 @@ int mvs_init(int device) {
     c->device = device;
     // extra lanes serve pair-sized work: keep their allocation caches small (lane 0 may hold whole mosaics)
     c->pool_cache_limit = ((device >> 8) ? (size_t)4 : (size_t)32) << 30;
+    if (((device >> 8) & 0xff) == 0) {
+        // lane 0 holds whole mosaics and the tiles of asynchronous uploads: its cache may keep half of the device's memory (144 GB of
+        // an MI355X's 288; at least 32 GB).  A block freed above the limit costs a stream wait + hipFree now and a hipMalloc (~25 ms
+        // per GB) at its next use -- the PCIe-inclusive pipeline (17 GB of tiles + 11 GB of slabs per mosaic) stalled for 250 ms per
+        // mosaic against the flat 32 GB limit once a previous mosaic was still cached.  mvs_malloc hands the cache back before it fails.
+        size_t f = 0, t = 0;
+        if (hipMemGetInfo(&f, &t) == hipSuccess) c->pool_cache_limit = std::max(c->pool_cache_limit, t / 2);
+        else (void)hipGetLastError();
+    }
     {   // A/B switch for all context lanes of a process (bench.py, tools/): MVS_SSIM_PRUNE=0 scores every candidate in full
         const char* ev = getenv("MVS_SSIM_PRUNE");
         if (ev && *ev) c->ssim_prune = atoi(ev) != 0;

@@ -276,8 +276,12 @@ def to_device(sim, device=0):
 def to_device_async(sims, device=0):
     """Copies of the SpatialImages ``sims`` (spatial dims only; data in pinned host memory, ``pinned_empty``) whose data is being
     uploaded to ``device`` on its copy stream, in list order, without waiting: ``register()`` starts a pair when its two tiles have
-    landed, ``fuse()`` / ``fuse_np`` make their stream wait for the tiles they read (``DeviceArray.ready_ticket``)."""
-    return [s if is_device_array(s.data) else s.copy(data=DeviceArray.from_host_async(np.asarray(s.data), device)) for s in sims]
+    landed, ``fuse()`` / ``fuse_np`` make their stream wait for the tiles they read (``DeviceArray.ready_ticket``).  Views that
+    are already on a device, and the metadata-only placeholders of views another rank holds (``sharding.RemoteArray``), pass through."""
+    from .sharding import RemoteArray
+
+    return [s if (is_device_array(s.data) or isinstance(s.data, RemoteArray))
+            else s.copy(data=DeviceArray.from_host_async(np.asarray(s.data), device)) for s in sims]
 
 
 def mark(device=0):

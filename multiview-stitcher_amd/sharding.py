@@ -317,6 +317,31 @@ def fuse_shard(sims, rank, world_size, transform_key, output_stack_properties=No
     return fused, box
 
 
+def fuse_shard_to_host(sims, rank, world_size, transform_key, output_stack_properties=None, **fuse_kwargs):
+    """``fuse_shard`` with the rank's sub-box ending in pinned host memory: ``fusion.fuse_to_host`` on the rank's part of the global
+    output stack (z slabs of the sub-box, every slab's download under the next slab's fuse), in the index frame of the whole mosaic.
+    Returns (fused sub-image or (sub-image, timeline) with ``return_timeline``, sub-box)."""
+    from . import fusion
+    from . import spatial_image_utils as si_utils
+
+    sdims = si_utils.get_spatial_dims_from_sim(sims[0])
+    if output_stack_properties is None:
+        output_stack_properties = fusion.process_output_stack_properties(
+            list(sims), fuse_kwargs.pop("output_spacing", None), fuse_kwargs.pop("output_origin", None),
+            fuse_kwargs.pop("output_shape", None), None, fuse_kwargs.pop("output_stack_mode", "union"), transform_key)
+    osp = fusion._bb_dicts(output_stack_properties, sdims)
+    boxes, _ = output_subboxes(osp, world_size, sdims)
+    box = boxes[rank]
+    sub = {k: box[k] for k in ("origin", "spacing", "shape")}
+    fuse_kwargs.setdefault("frame_origin", dict(osp["origin"]))
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", fusion.IndexFrameWarning)
+        fused = fusion.fuse_to_host(list(sims), transform_key=transform_key, output_stack_properties=sub, **fuse_kwargs)
+    return fused, box
+
+
 def exchange_halo(torch, dist, tiles, owners, needs, rank, world_size, device, via_host=False):
     """One-process-per-GPU halo exchange (setup, once): ``tiles[v]`` is a device tensor on the owner and None elsewhere;
     afterwards it is a tensor for every v in ``needs[rank]``.  ``needs``: list over ranks of view-index lists (every rank

@@ -17,7 +17,9 @@ Same calls, same arguments, same voxels as the serial loop: only the order in wh
 """
 from __future__ import annotations
 
+import os
 import threading
+import time
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -27,11 +29,16 @@ from . import zarr_io
 
 
 class PinnedPool:
-    """Pinned host buffers handed out by size (hipHostMalloc costs milliseconds per 100 MB: a streamed fuse would pay it per block)."""
+    """Pinned host buffers handed out by size.  hipHostMalloc pins pages at a few GB/s -- 100+ ms for the 1 GiB staging buffer of a
+    launch block -- so buffers go back to the pool and the pool outlives the pipeline that filled it (``shared_pinned_pool``: the
+    second streamed ``fuse()`` of a process finds its buffers); what the pool keeps is capped (``cap_bytes``, default 16 GiB or
+    ``MVS_PINNED_POOL_MB``), buffers returned beyond the cap are released."""
 
-    def __init__(self):
+    def __init__(self, cap_bytes=None):
         self._free = {}
         self._lock = threading.Lock()
+        self._held = 0
+        self.cap_bytes = int(os.environ.get("MVS_PINNED_POOL_MB", 16 << 10)) << 20 if cap_bytes is None else int(cap_bytes)
 
     def get(self, shape, dtype):
         dtype = np.dtype(dtype)
@@ -40,24 +47,48 @@ class PinnedPool:
         with self._lock:
             lst = self._free.get(cap)
             raw = lst.pop() if lst else None
+            if raw is not None:
+                self._held -= raw.size
         if raw is None:
             raw = dev_mod.pinned_empty((cap,), np.uint8)
         return raw, raw[:n].view(dtype).reshape(shape)
 
     def put(self, raw):
         with self._lock:
+            if self._held + raw.size > self.cap_bytes:
+                return                    # (dropped: the memory is unpinned when the last view of it is gone)
             self._free.setdefault(raw.size, []).append(raw)
+            self._held += raw.size
+
+    def clear(self):
+        with self._lock:
+            self._free.clear()
+            self._held = 0
 
 
-_IO_POOL = [None]
+_SHARED_POOL = [None]
+
+
+def shared_pinned_pool():
+    """The process-wide pool the pipelines of streamed ``fuse()`` calls draw their staging buffers from."""
+    with _IO_LOCK:
+        if _SHARED_POOL[0] is None:
+            _SHARED_POOL[0] = PinnedPool()
+        return _SHARED_POOL[0]
+
+
+LAST_TIMELINE = []     # (measurement) the per-block records of the most recent finished pipeline
+_IO_POOL = {}
 _IO_LOCK = threading.Lock()
 
 
-def io_pool(workers=8):
+def io_pool(workers=8, kind="read"):
+    """Thread pool of the chunk-file tasks of one direction ("read" / "write"): two pools, so that the write-behind of block k - 1 does
+    not queue behind the read-ahead of block k + 1 (file reads, writes and the numpy copies around them release the GIL)."""
     with _IO_LOCK:
-        if _IO_POOL[0] is None:
-            _IO_POOL[0] = ThreadPoolExecutor(max_workers=workers, thread_name_prefix="mvs-io")
-        return _IO_POOL[0]
+        if _IO_POOL.get(kind) is None:
+            _IO_POOL[kind] = ThreadPoolExecutor(max_workers=int(os.environ.get("MVS_IO_THREADS", workers)), thread_name_prefix="mvs-io-" + kind)
+        return _IO_POOL[kind]
 
 
 def read_window(view, out):
@@ -74,7 +105,7 @@ def read_window(view, out):
         lo = [max(a, i * c) for a, i, c in zip(starts, idx, arr.chunks)]
         hi = [min(b, (i + 1) * c) for b, i, c in zip(stops, idx, arr.chunks)]
         dst = tuple(slice(l - a, h - a) for l, h, a in zip(lo, hi, starts))
-        chunk = arr.read_chunk(idx)
+        chunk = arr.read_chunk(idx, scratch=True)
         if chunk is None:
             full[dst] = arr.fill_value
         else:
@@ -97,7 +128,7 @@ def write_region(zarr_out, starts, data):
         lo = [max(a, o) for a, o in zip(starts, c0)]
         hi = [min(b, o + c) for b, o, c in zip(stops, c0, zarr_out.chunks)]
         pieces.append((lo, data[tuple(slice(l - a, h - a) for l, h, a in zip(lo, hi, starts))]))
-    list(io_pool().map(lambda p: zarr_out.write(p[0], p[1]), pieces))
+    list(io_pool(kind="write").map(lambda p: zarr_out.write(p[0], p[1]), pieces))
 
 
 class BlockPipeline:
@@ -107,18 +138,20 @@ class BlockPipeline:
 
     def __init__(self, fuse_np, device, depth=2):
         self.fuse_np, self.device, self.depth = fuse_np, device, depth
-        self.pool = PinnedPool()
+        self.pool = shared_pinned_pool()
         self.reader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mvs-read")
         self.writer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mvs-write")
         self.staged = []       # (future of the staged block, sink)
         self.writes = []
-        self.timeline = []     # per block: dict of host-clock seconds (read done, fuse queued, written)
+        self.timeline = []     # per block: host-clock seconds since the pipeline was made (slabs staged, fuse queued, downloaded, written)
+        self._t0 = time.perf_counter()
 
     # -- stage 1: slabs -> pinned -> async upload
     def _stage(self, kwargs):
         from .device import DeviceArray, is_device_array
 
         raws, sims = [], []
+        t_in = time.perf_counter() - self._t0
         for s_ in kwargs["sims"]:
             data = s_.data
             if is_device_array(data):
@@ -131,7 +164,9 @@ class BlockPipeline:
                 buf[...] = np.asarray(data)
             raws.append(raw)
             sims.append(s_.copy(data=DeviceArray.from_host_async(buf, self.device)))
-        return dict(kwargs, sims=sims), raws
+        self._staged_mb = sum(r.size for r in raws) / 2 ** 20      # (pool buffers: powers of two >= the slabs)
+        self._slab_mb = sum(int(np.prod(s_.data.shape)) * np.dtype(s_.dtype).itemsize for s_ in sims) / 2 ** 20
+        return dict(kwargs, sims=sims), raws, (t_in, time.perf_counter() - self._t0)
 
     def submit(self, kwargs, sink):
         self.staged.append((self.reader.submit(self._stage, kwargs), sink))
@@ -141,20 +176,26 @@ class BlockPipeline:
     # -- stage 2 (caller's thread): fuse on the device, queue the download
     def _run_one(self):
         fut, sink = self.staged.pop(0)
-        kwargs, raws = fut.result()
+        kwargs, raws, (t_in, t_staged) = fut.result()
+        rec = {"read_start": t_in, "staged": t_staged, "fuse_start": time.perf_counter() - self._t0, "slab_mb": self._slab_mb,
+               "views": len(kwargs["sims"])}
+        self.timeline.append(rec)
         # (content-based weights: the fast path's overflow flag is looked at per block, since the block leaves the device right away)
         chunk = self.fuse_np(output_on_backend=True, **dict(kwargs, _cb_check=True))
         mark = dev_mod.mark(self.device)
         raw_out, out = self.pool.get(chunk.shape, chunk.dtype)
         ticket = chunk.download_async(out, after=mark)
-        self.writes.append(self.writer.submit(self._write, chunk, kwargs, raws, raw_out, out, ticket, sink))
+        rec["fuse_queued"] = time.perf_counter() - self._t0
+        self.writes.append(self.writer.submit(self._write, chunk, kwargs, raws, raw_out, out, ticket, sink, rec))
         while len(self.writes) > self.depth:
             self.writes.pop(0).result()
 
     # -- stage 3: wait for the download, store, recycle the buffers
-    def _write(self, chunk, kwargs, raws, raw_out, out, ticket, sink):
+    def _write(self, chunk, kwargs, raws, raw_out, out, ticket, sink, rec):
         dev_mod.ticket_sync(ticket)
+        rec["downloaded"] = time.perf_counter() - self._t0
         sink(out)
+        rec["written"] = time.perf_counter() - self._t0
         for r in raws:
             self.pool.put(r)
         self.pool.put(raw_out)
@@ -170,3 +211,4 @@ class BlockPipeline:
         finally:
             self.reader.shutdown(wait=True)
             self.writer.shutdown(wait=True)
+            LAST_TIMELINE[:] = self.timeline

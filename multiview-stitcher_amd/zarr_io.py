@@ -63,6 +63,18 @@ def _encode_fill(value, dtype):
 _tmp_counter = itertools.count()
 
 
+_TLS = threading.local()
+
+
+def _thread_scratch(kind, nbytes):
+    """A byte buffer of at least ``nbytes`` owned by the calling thread (one per ``kind``), grown when needed, reused otherwise."""
+    buf = getattr(_TLS, kind, None)
+    if buf is None or buf.size < nbytes:
+        buf = np.empty(int(nbytes), dtype=np.uint8)
+        setattr(_TLS, kind, buf)
+    return buf[:nbytes]
+
+
 def _tmp_name(path):
     """Unique per process, thread and call: writers of the same key (metadata written by every farm worker) never share
     a temporary file; the rename is atomic."""
@@ -84,6 +96,7 @@ class _Codec:
         self.config = config
         cid = None if config is None else config.get("id")
         level = 1 if config is None else int(config.get("level", 1))
+        self.raw = cid is None      # chunk files hold the array's bytes as they are: read / written without an intermediate bytes object
         if cid is None:
             self.decode, self.encode = (lambda b, n=None: b), (lambda b: b)
         elif cid == "zlib":
@@ -268,10 +281,20 @@ class ZarrArray:
         key = self.separator.join(([self.key_prefix] if self.key_prefix else []) + [str(int(i)) for i in idx])
         return os.path.join(self.path, *key.split("/"))
 
-    def read_chunk(self, idx):
-        """Full-shape chunk ``idx`` or None when it was never written."""
+    def read_chunk(self, idx, scratch=False):
+        """Full-shape chunk ``idx`` or None when it was never written.  ``scratch``: an uncompressed chunk may be returned in a
+        buffer that belongs to the calling THREAD and is overwritten by its next such call (``streaming.read_window`` copies the part
+        it needs at once): a fresh 4-32 MiB array per chunk is an mmap + thousands of page faults + an munmap, all of which contend
+        for the process's address-space lock when sixteen I/O threads do it -- reads and writes then take turns instead of overlapping."""
         try:
-            with open(self.chunk_path(idx), "rb") as f:
+            with open(self.chunk_path(idx), "rb", buffering=0) as f:
+                if self.codec.raw:
+                    n = int(np.prod(self.chunks))
+                    arr = _thread_scratch("r", n * self.dtype.itemsize).view(self.dtype)[:n] if scratch else np.empty(n, dtype=self.dtype)
+                    got = f.readinto(memoryview(arr).cast("B"))
+                    if got != n * self.dtype.itemsize or f.read(1):
+                        raise ValueError(f"chunk {idx} of {self.path} holds {got}+ bytes, expected {n * self.dtype.itemsize}")
+                    return arr.reshape(self.chunks)
                 raw = f.read()
         except FileNotFoundError:
             return None
@@ -281,13 +304,23 @@ class ZarrArray:
         return arr.reshape(self.chunks)
 
     def write_chunk(self, idx, data):
-        data = np.ascontiguousarray(data, dtype=self.dtype)
-        assert data.shape == self.chunks, (data.shape, self.chunks)
+        assert tuple(data.shape) == self.chunks, (data.shape, self.chunks)
+        if self.codec.raw and not (isinstance(data, np.ndarray) and data.flags.c_contiguous and data.dtype == self.dtype):
+            # gather the (strided) region into this thread's staging buffer instead of a fresh array (see read_chunk)
+            n = int(np.prod(self.chunks))
+            stage = _thread_scratch("w", n * self.dtype.itemsize).view(self.dtype)[:n].reshape(self.chunks)
+            np.copyto(stage, data, casting="unsafe")
+            data = stage
+        else:
+            data = np.ascontiguousarray(data, dtype=self.dtype)
         path = self.chunk_path(idx)
         os.makedirs(os.path.dirname(path), exist_ok=True)
         tmp = _tmp_name(path)
-        with open(tmp, "wb") as f:
-            f.write(self.codec.encode(data.tobytes()))
+        with open(tmp, "wb", buffering=0) as f:
+            if self.codec.raw:
+                f.write(memoryview(data).cast("B"))      # (a 32 MiB chunk: one copy into the page cache instead of three)
+            else:
+                f.write(self.codec.encode(data.tobytes()))
         os.replace(tmp, path)
 
     def _touched(self, starts, stops):
@@ -329,6 +362,9 @@ class ZarrArray:
             valid_hi = [min(o + c, s) for o, c, s in zip(c0, self.chunks, self.shape)]
             src = data[tuple(slice(l - a, h - a) for l, h, a in zip(lo, hi, starts))]
             full = all(l == o and h == v for l, h, o, v in zip(lo, hi, c0, valid_hi))
+            if full and tuple(src.shape) == tuple(self.chunks):
+                self.write_chunk(idx, src)               # a whole interior chunk: no fill, no patching
+                continue
             chunk = None if full else self.read_chunk(idx)
             if chunk is None:
                 chunk = np.full(self.chunks, self.fill_value, dtype=self.dtype)

@@ -34,7 +34,8 @@ def _run(cmd, env, timeout=900):
 
 
 def test_two_ranks_one_mosaic_equals_single_rank(hip_device, tmp_path):
-    common = ["--grid", "2,2,2", "--tile", "256,256,256", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pcie"]
+    # (the PCIe-inclusive leg stays on: at N = 2 every rank runs its own upload -> register -> fuse -> download pipeline)
+    common = ["--grid", "2,2,2", "--tile", "256,256,256", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-c3", "--no-c5"]
     d1, d2 = tmp_path / "n1", tmp_path / "n2"
     d1.mkdir()
     d2.mkdir()
@@ -53,6 +54,13 @@ def test_two_ranks_one_mosaic_equals_single_rank(hip_device, tmp_path):
         assert line["steps"] == 1 and line["warmup"] == 0 and line["unit"] == "Mvoxels/s" and line["value"] > 0
     # both ranks registered a share of the pairs and fused a share of the mosaic
     assert 0 < two["config"]["pairs_per_step_rank0"] < one["config"]["pairs_per_step_rank0"]
+    # PCIe-inclusive leg: defined at N = 2 as well -- both ranks uploaded their tiles (brick + halo: together at least the mosaic's
+    # 8 tiles), downloaded disjoint sub-boxes that add up to the mosaic, and the rate covers the whole mosaic
+    p1, p2 = one["value_incl_pcie"], two["value_incl_pcie"]
+    assert "error" not in p1 and p1["value"] > 0 and p2["value"] > 0
+    assert len(p2["by_rank"]["own_ms"]) == 2 and all(v > 0 for v in p2["by_rank"]["own_ms"])
+    assert p2["d2h_gb"] == pytest.approx(p1["d2h_gb"], rel=1e-9)
+    assert p2["h2d_gb"] >= p1["h2d_gb"] - 1e-9 and all(v > 0 for v in p2["by_rank"]["h2d_gb"])
     full = np.load(d1 / "fused_rank0of1.npy")
     got = np.zeros_like(full)
     covered = np.zeros(full.shape, dtype=bool)
@@ -75,7 +83,7 @@ def test_eight_ranks_one_mosaic_equals_single_rank(hip_device, tmp_path):
     the isend / irecv schedule of ``sharding.exchange_halo`` (seven peers per rank instead of the one the 2-rank test has),
     register the pairs whose fixed view they own, all-gather the results, resolve replicated and fuse their sub-box.  Small
     tiles (96^3) keep eight contexts on one GPU cheap; the partition logic does not depend on the tile size."""
-    common = ["--grid", "4,4,4", "--tile", "96,96,96", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pcie"]
+    common = ["--grid", "4,4,4", "--tile", "96,96,96", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-pcie", "--no-c3", "--no-c5"]
     d1, d8 = tmp_path / "n1", tmp_path / "n8"
     d1.mkdir()
     d8.mkdir()
