@@ -56,7 +56,7 @@ for d in ("int", "frac", "cal", "al128", "cb"):
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         f = find(f"pmc_{d}_{c}/**/*counter_collection.csv")
         if f:
-            shutil.copyfile(f, os.path.join(DST, fROUND + "_pmc_{d}_{c.lower()}.csv"))
+            shutil.copyfile(f, os.path.join(DST, f"{ROUND}_pmc_{d}_{c.lower()}.csv"))
 log = open(os.path.join(SRC, "bench.log")).read()
 m = re.findall(r"^\{.*\}$", log, flags=re.M)
 if m:

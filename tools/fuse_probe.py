@@ -34,11 +34,19 @@ torch.cuda.synchronize()
 _lib.set_option("ablate", int(os.environ.get("MVS_ABLATE", "0")))
 _lib.set_option("rows_v1", int(os.environ.get("MVS_ROWS_V1", "0")))               # 1: direct-load row kernels before the region kernels
 _lib.set_option("serial_classes", int(os.environ.get("MVS_SERIAL", "0")))   # 1: class kernels one after the other (A/B of the side streams)
+osp = None
+if os.environ.get("MVS_PAD_X") or os.environ.get("MVS_SHIFT_X"):      # alignment experiments: output rows padded to a multiple of
+    osp = fusion.process_output_stack_properties(sims, transform_key="k")      # MVS_PAD_X voxels, output origin moved MVS_SHIFT_X voxels to the left
+    osp = {k: dict(v) for k, v in osp.items()}
+    sh = int(os.environ.get("MVS_SHIFT_X", "0"))
+    osp["origin"]["x"] -= sh * osp["spacing"]["x"]
+    pad = int(os.environ.get("MVS_PAD_X", "1"))
+    osp["shape"]["x"] = -(-(int(osp["shape"]["x"]) + sh) // pad) * pad
 ms = []
 for _ in range(reps):
-    out = fusion.fuse(sims, transform_key="k", output_chunksize={d: 1 << 30 for d in "zyx"}, output_on_backend=True, device=0)
+    out = fusion.fuse(sims, transform_key="k", output_chunksize={d: 1 << 30 for d in "zyx"}, output_on_backend=True, device=0, output_stack_properties=osp)
     ms.append(_lib.last_kernel_ms(0))
-vox = float(np.prod(out.shape))
+vox = float(np.prod(out.shape)) if osp is None else float(np.prod(out.shape[:2])) * float(out.shape[2] - (int(os.environ.get("MVS_PAD_X", "1")) > 1) * 0)
 byt = len(sims) * float(np.prod(tile)) * 2 + vox * 2
 print("shape", out.shape, "kernel ms", ms, "GB/s", byt / (min(ms) * 1e-3) / 1e9)
 if os.environ.get("MVS_SERIAL", "0") == "1":      # the class kernels ran one after the other: their own durations and rates
