@@ -674,7 +674,23 @@ def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out, sh
         return t1 - t0, t_reg - t0, float(np.prod(out_host[0].shape)), t_own - t0
 
     run()                                  # warm-up (pinned result buffer, device blocks of the uploads, plans)
-    total, t_reg, vox, own = run()
+    for key in ("pool_misses", "pool_miss_bytes", "pool_releases"):
+        _lib.get_counter(key, local_rank, reset=True)
+    if os.environ.get("MVS_PCIE_PROFILE"):      # where the interpreter (and the library calls under it) spend the timed run
+        import cProfile
+        import pstats
+
+        pr = cProfile.Profile()
+        pr.enable()
+        total, t_reg, vox, own = run()
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(18)
+    else:
+        total, t_reg, vox, own = run()
+    trace["pool_misses_in_timed_run"] = _lib.get_counter("pool_misses", local_rank)
+    trace["pool_miss_gb_in_timed_run"] = _lib.get_counter("pool_miss_bytes", local_rank) / 1e9
+    trace["pool_releases_in_timed_run"] = _lib.get_counter("pool_releases", local_rank)
+    trace["slab_fuse_call_host_ms"] = [[round(a, 1), round(b, 1)] for a, b in getattr(fusion.fuse_to_host, "last_host_ms", [])]
     h2d_gb = sum(int(np.prod(h.data.shape)) * 2 for h in host_sims if isinstance(h.data, np.ndarray)) / 1e9
     d2h_gb = vox * 2 / 1e9
     by_rank = None

@@ -155,7 +155,9 @@ int mvs_set_option(int device, const char* key, int64_t value);
  * (0 when the plan cached for the same geometry was reused).  Per class k of the last region-kernel launch (0 one-view rim
  * boxes, 1 NV = 2, 2 NV <= 4, 3 NV <= 8, 4 copy): "fuse_class_in_vox_<k>" (voxels x views of the class's boxes),
  * "fuse_class_out_vox_<k>", and "fuse_class_ms_<k>" = the class kernel's own duration when that launch ran with option
- * "serial_classes" = 1 (-1 otherwise).  reset != 0 clears an accumulating counter after reading. */
+ * "serial_classes" = 1 (-1 otherwise).  "pool_misses" / "pool_miss_bytes" / "pool_releases": hipMalloc calls (and their bytes) that
+ * mvs_malloc could not serve from its cache, blocks mvs_free handed back to the runtime.  reset != 0 clears an accumulating
+ * counter after reading. */
 int mvs_get_counter(int device, const char* key, int32_t reset, double* value_out);
 /* Device time (ms, hipEvent) spent in the kernels of the most recent compute
  * call on this device; blocks until that work has finished. */

@@ -225,9 +225,10 @@ int mvs_init(int device) {
     c->pool_cache_limit = ((device >> 8) ? (size_t)4 : (size_t)32) << 30;
     if (((device >> 8) & 0xff) == 0) {
         // lane 0 holds whole mosaics and the tiles of asynchronous uploads: its cache may keep half of the device's memory (144 GB of
-        // an MI355X's 288; at least 32 GB).  A block freed above the limit costs a stream wait + hipFree now and a hipMalloc (~25 ms
-        // per GB) at its next use -- the PCIe-inclusive pipeline (17 GB of tiles + 11 GB of slabs per mosaic) stalled for 250 ms per
-        // mosaic against the flat 32 GB limit once a previous mosaic was still cached.  mvs_malloc hands the cache back before it fails.
+        // an MI355X's 288; at least 32 GB).  A block freed above the limit costs a stream wait + hipFree now and a hipMalloc (10-25 ms
+        // per GB, depending on the box) at its next use; one mosaic of the PCIe-inclusive pipeline alone parks 17 GB of tiles + 11 GB
+        // of slabs between two runs, next to the previous mosaic.  mvs_malloc hands the cache back before it fails
+        // (counters pool_misses / pool_releases).
         size_t f = 0, t = 0;
         if (hipMemGetInfo(&f, &t) == hipSuccess) c->pool_cache_limit = std::max(c->pool_cache_limit, t / 2);
         else (void)hipGetLastError();
@@ -246,12 +247,11 @@ int mvs_init(int device) {
         ev = getenv("MVS_FFT_NO_PAIR");
         if (ev && *ev) c->fft_no_pair = atoi(ev) != 0;
     }
-    // lane 0 fuses whole mosaics: its side streams (mvs_fuse_regions forks the class kernels onto them) are created here and not
-    // inside the first large launch, where their one-off cost (tens of ms) showed up in a one-mosaic caller's first fuse()
-    if (((device >> 8) & 0xff) == 0) {
-        const int rca = mvs_ensure_aux_streams(c);
-        if (rca) return rca;
-    }
+    // (The side streams of the fuse launch are NOT created here but at the first large launch (mvs_ensure_aux_streams, ~70 ms once).
+    // Round 6 created them at init to take that one-off out of a one-mosaic caller's first fuse(): HIP maps streams onto its hardware
+    // queues in creation order, and with the four low-priority streams made BEFORE the lanes' streams and the copy stream the
+    // PCIe-inclusive pipeline ran 570-1150 ms instead of 507-514 -- the fuse launches of the slabs stalled behind the transfers
+    // (alternating runs on one box, profiles/round6_summary.md).  Creation order: lanes, side streams, copy stream.)
     c->ready = true;
     c->last_error.clear();
     return MVS_OK;
@@ -464,6 +464,11 @@ int mvs_get_counter(int device, const char* key, int32_t reset, double* value_ou
         *value_out = pending;
         return MVS_OK;
     }
+    // allocation pool of this context: hipMalloc calls mvs_malloc had to make (no cached block fitted) and their bytes, blocks
+    // mvs_free released to the runtime because the cache was full
+    if (!strcmp(key, "pool_misses")) { std::lock_guard<std::mutex> pl(c->pool_mu); *value_out = (double)c->pool_misses; if (reset) c->pool_misses = 0; return MVS_OK; }
+    if (!strcmp(key, "pool_miss_bytes")) { std::lock_guard<std::mutex> pl(c->pool_mu); *value_out = c->pool_miss_bytes; if (reset) c->pool_miss_bytes = 0.0; return MVS_OK; }
+    if (!strcmp(key, "pool_releases")) { std::lock_guard<std::mutex> pl(c->pool_mu); *value_out = (double)c->pool_releases; if (reset) c->pool_releases = 0; return MVS_OK; }
     if (!strcmp(key, "cb_overflows_redone")) { *value_out = (double)c->cb_overflows; if (reset) c->cb_overflows = 0; return MVS_OK; }
     if (!strcmp(key, "fuse_plan_ms")) {
         *value_out = mvs_rows_last_plan_ms(c) + mvs_regions_last_plan_ms(c);
@@ -570,6 +575,8 @@ int mvs_malloc(int device, uint64_t nbytes, void** dev_ptr) {
         c->pool_free.erase(it);
         return MVS_OK;
     }
+    c->pool_misses += 1;
+    c->pool_miss_bytes += (double)want;
     hipError_t e = hipMalloc(dev_ptr, want);
     if (e != hipSuccess) {           // out of memory: give the cache back and retry once
         (void)hipGetLastError();
@@ -612,6 +619,7 @@ int mvs_free(int device, void* dev_ptr) {
     const size_t sz = it->second;
     c->pool_live.erase(it);
     if (c->pool_cached_bytes + sz > c->pool_cache_limit) {
+        c->pool_releases += 1;
         MVS_HIP_TRY(c, hipStreamSynchronize(c->stream));
         MVS_HIP_TRY(c, hipFree(dev_ptr));
         return MVS_OK;

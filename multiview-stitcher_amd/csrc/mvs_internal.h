@@ -101,6 +101,8 @@ struct MvsContext {
     std::multimap<size_t, void*> pool_free;
     std::unordered_map<void*, size_t> pool_live;
     size_t pool_cached_bytes = 0;
+    long long pool_misses = 0, pool_releases = 0;     // counters "pool_misses" / "pool_releases": hipMalloc / hipFree calls the pool could not avoid
+    double pool_miss_bytes = 0.0;
     size_t pool_cache_limit = (size_t)32 << 30;
 };
 

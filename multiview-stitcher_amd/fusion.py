@@ -18,6 +18,7 @@ import os
 import shutil
 
 import threading
+import time
 
 import numpy as np
 
@@ -1260,14 +1261,17 @@ def fuse_to_host(images, transform_key=None, n_slabs=8, out=None, device=0, retu
     fuse_kwargs.setdefault("frame_origin", dict(osp["origin"]))
     fuse_kwargs.setdefault("output_chunksize", {d: 1 << 30 for d in sdims})
     t_start = dev_mod.mark(device)
-    pending, timeline = [], []
+    h_start = time.perf_counter()
+    pending, timeline, host_ms = [], [], []      # host_ms: (fuse() of the slab entered, returned) on the host clock, ms
     for k in range(n_slabs):
         a, b = int(cuts[k]), int(cuts[k + 1])
         if b <= a:
             continue
         sub = {"origin": dict(osp["origin"], **{d0: osp["origin"][d0] + a * osp["spacing"][d0]}), "spacing": dict(osp["spacing"]),
                "shape": dict(osp["shape"], **{d0: b - a})}
+        h0 = time.perf_counter()
         fused = fuse(images, transform_key=transform_key, output_stack_properties=sub, output_on_backend=True, device=device, **fuse_kwargs)
+        host_ms.append(((h0 - h_start) * 1e3, (time.perf_counter() - h_start) * 1e3))
         t_fused = dev_mod.mark(device)
         t_down = fused.data.download_async(out[a:b], after=t_fused)
         pending.append((fused, t_fused, t_down))      # (the slab stays alive until its download has passed)
@@ -1277,4 +1281,5 @@ def fuse_to_host(images, transform_key=None, n_slabs=8, out=None, device=0, retu
             timeline.append((dev_mod.ticket_elapsed_ms(t_start, t_fused), dev_mod.ticket_elapsed_ms(t_start, t_down)))
     res = si_utils.to_spatial_image(out, dims=list(sdims), scale=osp["spacing"], translation=osp["origin"])
     si_utils.set_sim_affine(res, param_utils.identity_transform(len(sdims)), transform_key)
+    fuse_to_host.last_host_ms = host_ms          # (measurement: where the host was while the slabs were queued)
     return (res, timeline) if return_timeline else res
