@@ -863,8 +863,10 @@ def main():
             else:
                 print(f"gc gen{info['generation']} {1e3 * (time.perf_counter() - gc_t['t']):.1f} ms collected {info['collected']}", file=sys.stderr)
         gc.callbacks.append(gc_cb)
-    # the first step of the process is the COLD one: library just loaded, no plan / replay memo, no pooled device blocks, the
-    # mosaic-sized result hipMalloc'ed -- what a caller with ONE mosaic sees (config.step_cold_ms)
+    # the first step of the process is the COLD one: no plan / replay memo, no pooled device blocks, the mosaic-sized result
+    # hipMalloc'ed, and -- the largest part, 300-430 ms for 144 pairs -- the crop-length question asked once per pair geometry
+    # (the reference's linprog + Qhull sequence, ~2-3 ms of scipy per pair; registration._reference_crop_differs, memoised;
+    # MVS_KNIFE_CHECK=0 or overlap_bbox="closed_form" skips it): what a caller with ONE mosaic sees (config.step_cold_ms)
     cold = {}
     for w in range(max(args.warmup, 0)):
         t_w = time.perf_counter()
