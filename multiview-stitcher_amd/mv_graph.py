@@ -353,8 +353,8 @@ def get_center_from_stack_props(stack_props):
     return c
 
 
-def get_halfspace_equations_from_stack_props(stack_props):
-    """Rows [n, c] with n . x + c <= 0 inside the stack (mv_graph.py:183-218)."""
+def _halfspace_equations_generic(stack_props):
+    """The reference's face-by-face construction (mv_graph.py:183-218): any transform."""
     faces = get_faces_from_stack_props(stack_props)
     ndim = faces.shape[-1]
     center = get_center_from_stack_props(stack_props)
@@ -369,6 +369,42 @@ def get_halfspace_equations_from_stack_props(stack_props):
             normal = -normal
         eqs.append(np.concatenate([normal, [-np.dot(normal, face[0])]]))
     return np.array(eqs)
+
+
+def _is_pure_translation(stack_props, ndim):
+    if "transform" not in stack_props:
+        return True
+    a = param_utils.select_time(np.asarray(stack_props["transform"], dtype=np.float64), 0)
+    return a.shape == (ndim + 1, ndim + 1) and np.array_equal(a[:ndim, :ndim], np.eye(ndim))
+
+
+def get_halfspace_equations_from_stack_props(stack_props):
+    """Rows [n, c] with n . x + c <= 0 inside the stack (mv_graph.py:183-218).
+
+    Views whose transform is a pure translation -- every tile of a stage-positioned mosaic -- take all faces in ONE set of array
+    operations with the face-by-face form's arithmetic per element: the edge vectors of a face of such a box have one non-zero
+    component each, so the cross product has one (a product of two extents; the others are exact zeros), its norm is that
+    component's magnitude exactly (sqrt(x * x) == |x| in IEEE arithmetic) and every dot product has one non-zero term -- no sum in the
+    chain depends on the order of its terms, and the rows come out bit for bit those of the loop (signed zeros of the normals
+    included; tests/test_mv_graph_host.py).  The default crop sizing asks this once per pair geometry (registration.
+    _reference_crop_differs): 144 pairs x 2 views x 6 faces of np.cross / norm / dot calls were a third of a process's first
+    register()."""
+    sdims = [d for d in ["z", "y", "x"] if d in stack_props["spacing"]]
+    ndim = len(sdims)
+    if ndim != 3 or not _is_pure_translation(stack_props, ndim):
+        return _halfspace_equations_generic(stack_props)
+    faces = get_faces_from_stack_props(stack_props)
+    center = get_center_from_stack_props(stack_props)
+    f0 = faces[:, 0]
+    a, b = faces[:, 1] - f0, faces[:, 2] - f0
+    normal = np.empty_like(f0)
+    normal[:, 0] = a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1]      # (np.cross's own expressions)
+    normal[:, 1] = a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2]
+    normal[:, 2] = a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]
+    normal = normal / np.sqrt((normal * normal).sum(axis=1))[:, None]
+    flip = ((normal * center).sum(axis=1) - (normal * f0).sum(axis=1)) > 0
+    normal[flip] = -normal[flip]
+    return np.concatenate([normal, -(normal * f0).sum(axis=1)[:, None]], axis=1)
 
 
 def _axis_aligned_box(stack_props, tol=1e-12):
@@ -411,7 +447,7 @@ def _axis_aligned_boxes(sps, tol=1e-12):
         return [_axis_aligned_box(sp, tol) for sp in sps]
 
 
-def get_overlap_between_pair_of_stack_props(stack_props1, stack_props2, closed_form=True):
+def get_overlap_between_pair_of_stack_props(stack_props1, stack_props2, closed_form=True, need_volume=True):
     """Volume (area in 2D) of the intersection of two views in world coordinates (mv_graph.py:301-338); -1 when the
     intersection is degenerate / empty.  Axis-aligned pairs: product of the interval overlaps, the value Qhull returns
     for a box; general pairs: the reference's linprog + HalfspaceIntersection + ConvexHull sequence."""
@@ -432,7 +468,7 @@ def get_overlap_between_pair_of_stack_props(stack_props1, stack_props2, closed_f
         return -1, None
     try:
         hs = HalfspaceIntersection(eqs, res.x[:-1])
-        return float(ConvexHull(hs.intersections).volume), hs
+        return (float(ConvexHull(hs.intersections).volume) if need_volume else None), hs      # (callers that only want the vertices)
     except QhullError:
         return -1, None
 

@@ -450,7 +450,7 @@ def _reference_crop_shape(g1, g2, tol):
         if any(tol):
             sp = si_utils_extend(sp, dict(zip(g.sdims, tol)))
         sps.append(dict(sp, transform=g.affine))
-    vol, hs = mv_graph.get_overlap_between_pair_of_stack_props(sps[0], sps[1], closed_form=False)
+    vol, hs = mv_graph.get_overlap_between_pair_of_stack_props(sps[0], sps[1], closed_form=False, need_volume=False)
     if hs is None:
         return None
     c = transform_pts(np.asarray(hs.intersections), np.linalg.inv(g1.affine))
