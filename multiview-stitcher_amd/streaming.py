@@ -4,7 +4,8 @@ written to one (or to host memory).
 The reference streams such a fusion through dask: chunk tasks read their slabs lazily from the input stores
 (spatial_image_utils.py:712-860) and write their regions of the output store (fusion/_core.py:1068-1170, 2044-2156), many of them in
 flight at once.  Here a launch block is one ``mvs_fuse_chunk`` call, and until round 6 its five steps ran one after the other:
-read the slabs, upload, fuse, download, write.  ``BlockPipeline`` runs them as three stages with two blocks in flight per stage:
+read the slabs, upload, fuse, download, write.  ``BlockPipeline`` runs them as three stages with up to three blocks staged ahead / written behind and two blocks being read and two
+being written at any time (MVS_STREAM_DEPTH / MVS_STREAM_READERS / MVS_STREAM_WRITERS):
 
   reader thread   the slabs of block k + 1 -> pinned host buffers (chunk files read by a small pool of threads: file reads and
                   copies release the GIL) -> asynchronous uploads on the device's copy stream (csrc/mvs_transfer.hip);
@@ -136,11 +137,14 @@ class BlockPipeline:
     ``kwargs`` are the ``fuse_np`` arguments of a block (``sims``: slabs that may be Zarr-backed or host arrays), ``sink(chunk)``
     stores the fused block (a numpy array in pinned memory, valid during the call).  ``finish()`` waits for everything."""
 
-    def __init__(self, fuse_np, device, depth=2):
+    def __init__(self, fuse_np, device, depth=None):
+        depth = int(os.environ.get("MVS_STREAM_DEPTH", "3")) if depth is None else depth
         self.fuse_np, self.device, self.depth = fuse_np, device, depth
         self.pool = shared_pinned_pool()
-        self.reader = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mvs-read")
-        self.writer = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mvs-write")
+        # (blocks in flight per stage: the chunk files of a block are 20-300 tasks for the I/O pool of its direction, and the last
+        # round of one block's tasks leaves threads idle unless another block's are queued behind them)
+        self.reader = ThreadPoolExecutor(max_workers=int(os.environ.get("MVS_STREAM_READERS", "2")), thread_name_prefix="mvs-read")
+        self.writer = ThreadPoolExecutor(max_workers=int(os.environ.get("MVS_STREAM_WRITERS", "2")), thread_name_prefix="mvs-write")
         self.staged = []       # (future of the staged block, sink)
         self.writes = []
         self.timeline = []     # per block: host-clock seconds since the pipeline was made (slabs staged, fuse queued, downloaded, written)
@@ -164,9 +168,8 @@ class BlockPipeline:
                 buf[...] = np.asarray(data)
             raws.append(raw)
             sims.append(s_.copy(data=DeviceArray.from_host_async(buf, self.device)))
-        self._staged_mb = sum(r.size for r in raws) / 2 ** 20      # (pool buffers: powers of two >= the slabs)
-        self._slab_mb = sum(int(np.prod(s_.data.shape)) * np.dtype(s_.dtype).itemsize for s_ in sims) / 2 ** 20
-        return dict(kwargs, sims=sims), raws, (t_in, time.perf_counter() - self._t0)
+        slab_mb = sum(int(np.prod(s_.data.shape)) * np.dtype(s_.dtype).itemsize for s_ in sims) / 2 ** 20
+        return dict(kwargs, sims=sims), raws, (t_in, time.perf_counter() - self._t0, slab_mb)
 
     def submit(self, kwargs, sink):
         self.staged.append((self.reader.submit(self._stage, kwargs), sink))
@@ -176,8 +179,8 @@ class BlockPipeline:
     # -- stage 2 (caller's thread): fuse on the device, queue the download
     def _run_one(self):
         fut, sink = self.staged.pop(0)
-        kwargs, raws, (t_in, t_staged) = fut.result()
-        rec = {"read_start": t_in, "staged": t_staged, "fuse_start": time.perf_counter() - self._t0, "slab_mb": self._slab_mb,
+        kwargs, raws, (t_in, t_staged, slab_mb) = fut.result()
+        rec = {"read_start": t_in, "staged": t_staged, "fuse_start": time.perf_counter() - self._t0, "slab_mb": slab_mb,
                "views": len(kwargs["sims"])}
         self.timeline.append(rec)
         # (content-based weights: the fast path's overflow flag is looked at per block, since the block leaves the device right away)
