@@ -540,6 +540,16 @@ def c5_stream_leg(torch, dev, local_rank, args):
 
     grid, tile = np.array([1, 2, 3]), np.array([512, 1024, 1024])
     overlap = np.round(tile * args.overlap_frac).astype(int)
+    # the I/O threads of this leg are made with the affinity the process was STARTED with: the block of 16 CPUs main() pinned the
+    # registration loop to is two CCDs of the host, whose links to memory carry ~2/3 of what the chunk-file copies of sixteen I/O
+    # threads ask for (same box, alternating: 0.46-0.52 s inside the block, 0.39-0.42 s with the threads where the scheduler puts them;
+    # host-only probe, reads + writes at once: 0.26 against 0.19 s).  A streaming application does not pin itself to two CCDs.
+    pinned_now = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
+    if _ORIG_AFFINITY and hasattr(os, "sched_setaffinity"):
+        try:
+            os.sched_setaffinity(0, _ORIG_AFFINITY)
+        except OSError:
+            pass
     need = int(np.prod(tile)) * 2 * int(np.prod(grid)) * 2.2
     base = os.environ.get("MVS_BENCH_TMP")
     if base is None:
@@ -551,6 +561,8 @@ def c5_stream_leg(torch, dev, local_rank, args):
             except OSError:
                 continue
     if base is None:
+        if pinned_now and hasattr(os, "sched_setaffinity"):
+            os.sched_setaffinity(0, pinned_now)
         return {"skipped": "no directory with %.0f GB free" % (need * 1.3 / 1e9)}
     tmp = tempfile.mkdtemp(prefix="mvs_c5_", dir=base)
     try:
@@ -613,6 +625,11 @@ def c5_stream_leg(torch, dev, local_rank, args):
                 "note": "files were written just before: reads come from the page cache (a cold disk would lower read_tiles_s' rate and the ceiling with it)"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+        if pinned_now and hasattr(os, "sched_setaffinity"):
+            try:
+                os.sched_setaffinity(0, pinned_now)
+            except OSError:
+                pass
 
 
 def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out, shard=None):

@@ -1114,44 +1114,49 @@ def _fuse_once(
             from .streaming import BlockPipeline
 
             pipe = BlockPipeline(fuse_np, device)
-        for entry in plan["per_chunk_entries"]:
-            bi = entry["block_index"]
-            if chunk_filter is not None and not chunk_filter(bi):
-                continue
-            if not entry["views"]:
-                continue
-            kwargs, sl = chunk_call(ns_index, entry, device)
-            if pipe is not None:
-                def sink(chunk, entry=entry, sl=sl, ns_index=ns_index):
+        try:
+            for entry in plan["per_chunk_entries"]:
+                bi = entry["block_index"]
+                if chunk_filter is not None and not chunk_filter(bi):
+                    continue
+                if not entry["views"]:
+                    continue
+                kwargs, sl = chunk_call(ns_index, entry, device)
+                if pipe is not None:
+                    def sink(chunk, entry=entry, sl=sl, ns_index=ns_index):
+                        if entry["fuse_planewise"]:
+                            chunk = chunk[np.newaxis]
+                        if zarr_out is not None:
+                            from .streaming import write_region
+
+                            write_region(zarr_out, list(ns_index) + [s_.start for s_ in sl], chunk.reshape((1,) * len(ns_index) + chunk.shape))
+                        else:
+                            result[tuple(ns_index) + sl] = chunk
+                    kwargs.pop("device", None)
+                    pipe.submit(dict(kwargs, device=device), sink)
+                    continue
+                if on_device and single:
+                    # (a plane-wise entry is fused with 2D parameters: hand it the one plane of the 3D result)
+                    fuse_np(out=dev_out[0] if entry["fuse_planewise"] else dev_out, **kwargs)
+                elif on_device:
+                    # chunked workflow with a device-resident mosaic: every chunk is fused on the device and copied into
+                    # its window of the mosaic device-to-device (stream-ordered, no host round trip)
+                    chunk = fuse_np(output_on_backend=True, **kwargs)
+                    chunk.copy_into(dev_out, [s_.start for s_ in sl])
+                else:
+                    chunk = np.asarray(fuse_np(**kwargs))
                     if entry["fuse_planewise"]:
                         chunk = chunk[np.newaxis]
                     if zarr_out is not None:
-                        from .streaming import write_region
-
-                        write_region(zarr_out, list(ns_index) + [s_.start for s_ in sl], chunk.reshape((1,) * len(ns_index) + chunk.shape))
+                        zarr_out.write(list(ns_index) + [s_.start for s_ in sl], chunk.reshape((1,) * len(ns_index) + chunk.shape))
+                    elif chunk.shape == result.shape:
+                        result = chunk           # one launch block and one field: the fused array is the result
                     else:
                         result[tuple(ns_index) + sl] = chunk
-                kwargs.pop("device", None)
-                pipe.submit(dict(kwargs, device=device), sink)
-                continue
-            if on_device and single:
-                # (a plane-wise entry is fused with 2D parameters: hand it the one plane of the 3D result)
-                fuse_np(out=dev_out[0] if entry["fuse_planewise"] else dev_out, **kwargs)
-            elif on_device:
-                # chunked workflow with a device-resident mosaic: every chunk is fused on the device and copied into
-                # its window of the mosaic device-to-device (stream-ordered, no host round trip)
-                chunk = fuse_np(output_on_backend=True, **kwargs)
-                chunk.copy_into(dev_out, [s_.start for s_ in sl])
-            else:
-                chunk = np.asarray(fuse_np(**kwargs))
-                if entry["fuse_planewise"]:
-                    chunk = chunk[np.newaxis]
-                if zarr_out is not None:
-                    zarr_out.write(list(ns_index) + [s_.start for s_ in sl], chunk.reshape((1,) * len(ns_index) + chunk.shape))
-                elif chunk.shape == result.shape:
-                    result = chunk           # one launch block and one field: the fused array is the result
-                else:
-                    result[tuple(ns_index) + sl] = chunk
+        except BaseException:
+            if pipe is not None:
+                pipe.abort()      # (queued reads are dropped, the stage threads end; the error of the block that failed goes up)
+            raise
         if pipe is not None:
             pipe.finish()
     if on_device:

@@ -204,6 +204,14 @@ class BlockPipeline:
         self.pool.put(raw_out)
         del chunk, kwargs
 
+    def abort(self):
+        """A block failed on the caller's thread: drop what is queued, let the blocks already in a stage run out, keep no threads."""
+        for fut, _ in self.staged:
+            fut.cancel()
+        self.staged, self.writes = [], []
+        self.reader.shutdown(wait=False, cancel_futures=True)
+        self.writer.shutdown(wait=False, cancel_futures=True)
+
     def finish(self):
         try:
             while self.staged:

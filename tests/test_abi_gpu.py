@@ -144,3 +144,47 @@ def test_a_failing_composite_call_leaves_no_state_on_its_lane(hip_device):
     assert register(lane_a, view(d0), view(d1)) == 0
     assert (list(t), q.value, status.value, ncand.value) == want
     assert want[2] == 0 and [abs(v) for v in want[0]] == [1.0, 2.0, 4.0]
+
+
+def test_measurement_counters_of_the_fuse_classes_and_the_pool(hip_device):
+    """mvs_get_counter: "fuse_class_{in_vox,out_vox,ms}_<k>" of the last region-kernel launch -- the classes' boxes tile the chunk (their
+    voxels add up to it; views x voxels is what the launch cannot avoid reading), a class kernel's own time exists only for a launch
+    made with option serial_classes -- and "pool_misses" / "pool_miss_bytes" / "pool_releases" of a lane's allocation cache."""
+    from multiview_stitcher_amd import _lib, fusion, sample_data
+    from multiview_stitcher_amd import spatial_image_utils as si
+    from multiview_stitcher_amd.device import to_device
+    from tests.helpers import squeeze_field
+
+    lib = _lib.init(0)
+    sims, _, _ = sample_data.generate_tiled_dataset(ndim=3, tile_shape=(40, 48, 56), tiles=(2, 2, 2), overlap=(8, 10, 12), dtype=np.uint16, seed=2)
+    sims = [to_device(squeeze_field(s), 0) for s in sims]
+    key = si.DEFAULT_TRANSFORM_KEY
+    for serial in (1, 0):
+        _lib.set_option("serial_classes", serial, 0)
+        try:
+            out = fusion.fuse(sims, transform_key=key, output_chunksize={d: 1 << 30 for d in "zyx"}, output_on_backend=True, device=0)
+            _lib.synchronize(0)
+        finally:
+            _lib.set_option("serial_classes", 0, 0)
+        ov = [_lib.get_counter(f"fuse_class_out_vox_{k}", 0) for k in range(5)]
+        iv = [_lib.get_counter(f"fuse_class_in_vox_{k}", 0) for k in range(5)]
+        ms = [_lib.get_counter(f"fuse_class_ms_{k}", 0) for k in range(5)]
+        assert sum(ov) == float(np.prod(out.shape))
+        assert ov[4] > 0 and iv[4] == ov[4]                       # copy class: one view per voxel
+        assert iv[1] == 2 * ov[1] and ov[1] > 0                   # faces: exactly two views
+        assert ov[2] > 0 and 2 * ov[2] < iv[2] <= 4 * ov[2]      # edges: three or four views
+        assert ov[3] == 0 or 4 * ov[3] < iv[3] <= 8 * ov[3]     # corners: five to eight
+        for k in range(5):
+            assert (ms[k] >= 0.0) if (serial and ov[k] > 0) else (ms[k] == -1.0)
+    v = C.c_double()
+    assert lib.mvs_get_counter(0, b"fuse_class_ms_5", 0, C.byref(v)) < 0 and b"unknown key" in lib.mvs_last_error(0)
+    _lib.get_counter("pool_misses", 0, reset=True)
+    _lib.get_counter("pool_miss_bytes", 0, reset=True)
+    p = C.c_void_p()
+    odd = (7 << 20) + 12345 * 4096                                 # a size class nothing else in the suite uses
+    assert lib.mvs_malloc(0, odd, C.byref(p)) == 0
+    assert _lib.get_counter("pool_misses", 0) == 1 and _lib.get_counter("pool_miss_bytes", 0) >= odd
+    assert lib.mvs_free(0, p) == 0
+    assert lib.mvs_malloc(0, odd, C.byref(p)) == 0 and _lib.get_counter("pool_misses", 0) == 1      # served from the cache
+    assert lib.mvs_free(0, p) == 0
+    assert _lib.get_counter("pool_releases", 0) >= 0
