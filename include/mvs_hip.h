@@ -192,6 +192,11 @@ int mvs_memset(int device, void* dst_dev, int32_t byte_value, uint64_t nbytes);
  * device-resident mosaic (the reference's chunks each go to their own zarr region, fusion/_core.py:1123-1141). */
 int mvs_copy_into(int device, const void* src_dev, int32_t dtype, const int64_t shape[3],
                   void* dst_dev, const int64_t dst_shape[3], const int64_t dst_offset[3]);
+/* Device-to-device copy of a box of box[0] planes x box[1] rows x box[2] BYTES per row between two pitched arrays on this device
+ * (pitch[0]: bytes from row to row, pitch[1]: from plane to plane; rows contiguous; stream-ordered, returns without waiting).  A
+ * streamed fuse() re-tiles a fused launch block with it so that every Zarr chunk of the block is ONE contiguous piece of the
+ * download and goes to its chunk file without a gather on the host (fusion/_core.py:1123-1171 writes regions of a dask array). */
+int mvs_copy_box(int device, const void* src_dev, const int64_t src_pitch[2], void* dst_dev, const int64_t dst_pitch[2], const int64_t box[3]);
 
 /* ---- fusion ------------------------------------------------------------------ *
  * mvs_fuse_chunk == the body of fusion.fuse_np (fusion/_core.py:1608-1713) for

@@ -130,6 +130,7 @@ SIGNATURES = {
     "mvs_host_free": (C.c_int, [C.c_void_p]),
     "mvs_copy_async": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64)]),
     "mvs_mark": (C.c_int, [C.c_int, C.POINTER(C.c_uint64)]),
+    "mvs_copy_box": (C.c_int, [C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "mvs_ticket_sync": (C.c_int, [C.c_uint64]),
     "mvs_ticket_elapsed_ms": (C.c_int, [C.c_uint64, C.c_uint64, C.POINTER(C.c_double)]),
     "mvs_plan_pairs": (

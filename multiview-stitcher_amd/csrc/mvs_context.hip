@@ -699,17 +699,18 @@ int mvs_upload_tile(int device, const void* host, int32_t dtype, const int64_t s
     return mvs_memcpy_h2d(device, *dev_ptr, host, n);
 }
 
-// rows of `nbytes_row` bytes: src is contiguous (row r at r * nbytes_row), dst rows sit at (z * dst_pitch_z + y * dst_pitch_y).
+// rows of `nbytes_row` bytes: src rows sit at (z * src_pitch_z + y * src_pitch_y), dst rows at (z * dst_pitch_z + y * dst_pitch_y).
 // A thread moves 16-byte pieces (work items = (row, piece), so short rows fill the launch as well as long ones); neither end
 // needs any alignment (rows of a uint16 mosaic of odd width start at odd 2-byte offsets): global memory takes unaligned vectors.
 __global__ __launch_bounds__(256) void copy_box_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int nz, int ny,
-                                                       long long nbytes_row, long long dst_pitch_y, long long dst_pitch_z) {
+                                                       long long nbytes_row, long long src_pitch_y, long long src_pitch_z, long long dst_pitch_y,
+                                                       long long dst_pitch_z) {
     typedef unsigned int u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
     const long long rows = (long long)nz * ny, ppr = (nbytes_row + 15) >> 4, total = rows * ppr;
     for (long long w = (long long)blockIdx.x * blockDim.x + threadIdx.x; w < total; w += (long long)gridDim.x * blockDim.x) {
         const long long r = w / ppr, pc = w - r * ppr;
         const int z = (int)(r / ny), y = (int)(r - (long long)z * ny);
-        const unsigned char* s = src + r * nbytes_row + pc * 16;
+        const unsigned char* s = src + (long long)z * src_pitch_z + (long long)y * src_pitch_y + pc * 16;
         unsigned char* d = dst + (long long)z * dst_pitch_z + (long long)y * dst_pitch_y + pc * 16;
         const long long left = nbytes_row - pc * 16;
         if (left >= 16) *reinterpret_cast<u32x4_a1*>(d) = *reinterpret_cast<const u32x4_a1*>(s);
@@ -748,8 +749,28 @@ int mvs_copy_into(int device, const void* src_dev, int32_t dtype, const int64_t 
     unsigned char* d0 = (unsigned char*)dst_dev + dst_offset[0] * pz + dst_offset[1] * py + dst_offset[2] * (long long)es;
     const int rows = (int)(shape[0] * shape[1]);
     const long long pieces = (long long)rows * ((shape[2] * (long long)es + 15) >> 4);
+    const long long row = (long long)shape[2] * (long long)es;
     hipLaunchKernelGGL(copy_box_kernel, dim3((unsigned)std::min<long long>((pieces + 255) / 256, 65536)), dim3(256), 0, c->stream, (const unsigned char*)src_dev, d0, (int)shape[0],
-                       (int)shape[1], (long long)shape[2] * (long long)es, py, pz);
+                       (int)shape[1], row, row, row * shape[1], py, pz);
+    MVS_HIP_TRY(c, hipGetLastError());
+    return MVS_OK;
+}
+
+int mvs_copy_box(int device, const void* src_dev, const int64_t src_pitch[2], void* dst_dev, const int64_t dst_pitch[2], const int64_t box[3]) {
+    MvsContext* c;
+    int rc = mvs_check_ready(device, &c);
+    if (rc) return rc;
+    if (!src_dev || !dst_dev || !src_pitch || !dst_pitch || !box) return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_copy_box: NULL argument");
+    if (box[0] < 0 || box[1] < 0 || box[2] < 0 || src_pitch[0] < box[2] || dst_pitch[0] < box[2] || src_pitch[1] < 0 || dst_pitch[1] < 0)
+        return mvs_fail(c, MVS_ERR_INVALID_ARG, "mvs_copy_box: negative extent or a row pitch shorter than the row");
+    if (box[0] * box[1] * box[2] == 0) return MVS_OK;
+    if (box[0] * box[1] >= (1ll << 31)) return mvs_fail(c, MVS_ERR_UNSUPPORTED, "mvs_copy_box: too many rows");
+    std::lock_guard<std::recursive_mutex> lock(c->mu);
+    MVS_HIP_TRY(c, hipSetDevice(mvs_hip_device(device)));
+    const long long pieces = box[0] * box[1] * ((box[2] + 15) >> 4);
+    hipLaunchKernelGGL(copy_box_kernel, dim3((unsigned)std::min<long long>((pieces + 255) / 256, 65536)), dim3(256), 0, c->stream, (const unsigned char*)src_dev,
+                       (unsigned char*)dst_dev, (int)box[0], (int)box[1], (long long)box[2], (long long)src_pitch[0], (long long)src_pitch[1], (long long)dst_pitch[0],
+                       (long long)dst_pitch[1]);
     MVS_HIP_TRY(c, hipGetLastError());
     return MVS_OK;
 }

@@ -201,6 +201,30 @@ class DeviceArray:
         _lib.check(rc, dst.device, "mvs_copy_into")
         dst.mark_written()
 
+    def copy_box_to(self, dst):
+        """Copy this array (any unit-step window of an allocation: rows contiguous) into ``dst``, a window of the same shape and dtype
+        on the same device -- device to device, stream-ordered (mvs_copy_box).  <= 3 axes after leading axes of extent 1."""
+        if self.dtype != dst.dtype or tuple(self.shape) != tuple(dst.shape) or (self.device & 0xff) != (dst.device & 0xff):
+            raise ValueError("copy_box_to needs two windows of one shape and dtype on one device")
+        lead = max(self.ndim - 3, 0)
+        if any(n != 1 for n in self.shape[:lead]) or self.ndim == 0:
+            raise ValueError("copy_box_to handles boxes of up to three axes")
+        sh = (1,) * (3 - min(self.ndim, 3)) + tuple(self.shape[lead:])
+        item = self.dtype.itemsize
+
+        def pitches(a):
+            st = (0,) * (3 - min(a.ndim, 3)) + tuple(a.strides[lead:])
+            if sh[2] > 1 and st[2] != 1:
+                raise ValueError("copy_box_to needs contiguous rows")
+            py = st[1] * item if sh[1] > 1 else sh[2] * item
+            pz = st[0] * item if sh[0] > 1 else max(py, 0) * sh[1]
+            return (C.c_int64 * 2)(py, pz)
+
+        box = (C.c_int64 * 3)(sh[0], sh[1], sh[2] * item)
+        _lib.check(_lib.init(dst.device).mvs_copy_box(dst.device, C.c_void_p(self.ptr), pitches(self), C.c_void_p(dst.ptr), pitches(dst), box),
+                   dst.device, "mvs_copy_box")
+        dst.mark_written()
+
     @property
     def __cuda_array_interface__(self):
         """Zero-copy hand-over to torch / cupy-style consumers (``torch.as_tensor(arr, device="cuda")``); the array must

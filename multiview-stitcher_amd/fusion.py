@@ -670,6 +670,7 @@ def _plan_chunks(sparams, views_bb, output_stack_properties, output_chunksize, o
 
 
 _REPLAY = [True]           # tests / A-B: derive everything on every call
+_STREAM_TILES = [os.environ.get("MVS_STREAM_TILES", "1") != "0"]            # fused blocks re-tiled on the device into chunk-major order before the download
 _STREAM_PIPELINE = [os.environ.get("MVS_STREAM_PIPELINE", "1") != "0"]      # streaming.BlockPipeline around the launch blocks of a streamed fuse()
 _REPLAY_MEMO = {}
 _REPLAY_CAP = 32                     # geometries kept (8 ranks x a few mosaics; an entry is a few KB of view records)
@@ -1133,7 +1134,10 @@ def _fuse_once(
                         else:
                             result[tuple(ns_index) + sl] = chunk
                     kwargs.pop("device", None)
-                    pipe.submit(dict(kwargs, device=device), sink)
+                    tiling = None
+                    if zarr_out is not None and not entry["fuse_planewise"] and _STREAM_TILES[0]:
+                        tiling = (zarr_out, list(ns_index) + [s_.start for s_ in sl])
+                    pipe.submit(dict(kwargs, device=device), sink, tiling)
                     continue
                 if on_device and single:
                     # (a plane-wise entry is fused with 2D parameters: hand it the one plane of the 3D result)

@@ -101,7 +101,19 @@ def test_block_pipeline_equals_the_serial_loop(hip_device, tmp_path, weights):
     old_budget = fusion.MAX_STREAM_BYTES
     fusion.MAX_STREAM_BYTES = 1 << 20                 # several launch blocks even for this small mosaic
     try:
+        from multiview_stitcher_amd import streaming
+
         got = fusion.fuse(lazy, output_zarr_url=str(tmp_path / "piped.zarr"), **kw)
+        # (the blocks of this store are whole chunks up to the array's border -- shape (116, 172, 230) in (32, 64, 64) chunks -- so they
+        # left the device re-tiled into chunk-major order, border chunks padded with the fill value: mvs_copy_box)
+        assert streaming.LAST_TIMELINE and all(b.get("tiles", 0) >= 1 for b in streaming.LAST_TIMELINE)
+        fusion._STREAM_TILES[0] = False
+        try:
+            plain = fusion.fuse(lazy, output_zarr_url=str(tmp_path / "piped_rows.zarr"), **kw)      # row-major download + host gather
+        finally:
+            fusion._STREAM_TILES[0] = True
+        assert all("tiles" not in b for b in streaming.LAST_TIMELINE)
+        np.testing.assert_array_equal(np.asarray(plain.data), np.asarray(got.data))
         fusion._STREAM_PIPELINE[0] = False
         try:
             want = fusion.fuse(lazy, output_zarr_url=str(tmp_path / "serial.zarr"), **kw)
@@ -115,3 +127,36 @@ def test_block_pipeline_equals_the_serial_loop(hip_device, tmp_path, weights):
     assert a.shape == b.shape and a.any()
     np.testing.assert_array_equal(a, b)
     np.testing.assert_array_equal(np.asarray(host.data), b)
+    # the chunk FILES are the same bytes too (border chunks are stored whole, padded with the fill value, by both paths)
+    za, zb = zarr_io.ZarrArray.open(got.data.array.path if hasattr(got.data, "array") else got.data.path), \
+        zarr_io.ZarrArray.open(want.data.array.path if hasattr(want.data, "array") else want.data.path)
+    for idx in np.ndindex(*za.grid):
+        ca, cb = za.read_chunk(idx), zb.read_chunk(idx)
+        assert (ca is None) == (cb is None)
+        if ca is not None:
+            np.testing.assert_array_equal(ca, cb)
+
+
+def test_copy_box_between_pitched_windows(hip_device):
+    """DeviceArray.copy_box_to / mvs_copy_box: a window of one allocation into a window of another, both pitched (rows contiguous),
+    odd extents and offsets, 2 and 3 axes, leading axes of extent 1."""
+    from multiview_stitcher_amd import _lib
+    from multiview_stitcher_amd.device import DeviceArray
+
+    rng = np.random.default_rng(4)
+    for dtype, shape_a, shape_b, lo_a, lo_b, ext in (
+            (np.uint16, (9, 37, 53), (5, 64, 64), (2, 5, 7), (1, 3, 11), (4, 29, 41)),
+            (np.uint8, (1, 1, 20, 45), (1, 1, 33, 71), (0, 0, 3, 2), (0, 0, 10, 30), (1, 1, 17, 41)),
+            (np.float32, (31, 17), (40, 40), (4, 0), (7, 23), (25, 17))):
+        a = (rng.random(shape_a) * 200).astype(dtype)
+        b = (rng.random(shape_b) * 200).astype(dtype)
+        da, db = DeviceArray.from_host(a, 0), DeviceArray.from_host(b, 0)
+        sa = tuple(slice(l, l + e) for l, e in zip(lo_a, ext))
+        sb = tuple(slice(l, l + e) for l, e in zip(lo_b, ext))
+        da[sa].copy_box_to(db[sb])
+        _lib.synchronize(0)
+        want = b.copy()
+        want[sb] = a[sa]
+        np.testing.assert_array_equal(db.get(), want)
+    with pytest.raises(ValueError):
+        da[:3, :3].copy_box_to(db[:3, :4])
