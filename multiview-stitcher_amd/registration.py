@@ -439,6 +439,17 @@ _KNIFE_LOCK = threading.Lock()
 _KNIFE_CHECK = [os.environ.get("MVS_KNIFE_CHECK", "1") != "0"]
 
 
+def set_crop_length_check(enabled):
+    """Switch the default crop rule's question to the reference's Qhull sequence on or off for this process (on by default; the
+    environment variable MVS_KNIFE_CHECK=0 starts a process with it off).  Off: every pair of views on one pixel grid registers the
+    closed form's N samples -- the reference registers N - 1 on some of them (BASELINE config C1's pair), so its translation is
+    then not guaranteed -- and a mosaic whose geometry has not been seen before saves ~2 ms of host time per pair.  Returns the
+    previous setting."""
+    old = _KNIFE_CHECK[0]
+    _KNIFE_CHECK[0] = bool(enabled)
+    return old
+
+
 def _reference_crop_shape(g1, g2, tol):
     """Crop shape of the pair (binned views ``g1``, ``g2``: _TileGeom) as the reference derives it, or None without overlap."""
     from . import mv_graph
@@ -724,6 +735,7 @@ def _register_pairs_batched(sims, edges, transform_key, registration_binning, ov
         return None
     if np.any(pstat != 0):
         raise ValueError("views do not overlap")
+    knife_thread = None
     if knife_check and _KNIFE_CHECK[0]:
         # pairs whose reference crop is one sample shorter (see _reference_crop_differs) take the overlap_bbox="reference" path one by
         # one; the others stay here.  One memo entry per MOSAIC geometry: a list of pair indices, looked up with a few hundred bytes.
@@ -732,10 +744,21 @@ def _register_pairs_batched(sims, edges, transform_key, registration_binning, ov
         with _KNIFE_LOCK:
             odd = _KNIFE_MEMO.get(mkey)
         if odd is None:
-            odd = [e for e in range(ne) if _reference_crop_differs(geoms_b[edges[e][0]], geoms_b[edges[e][1]], tol, out_shape[e, :n])]
-            with _KNIFE_LOCK:
-                _KNIFE_MEMO[mkey] = odd
-        if odd:
+            # a geometry seen for the first time: the question costs ~2 ms of scipy per pair on the host (GIL-bound), the pairs
+            # themselves ~0.3 ms each on the GPU -- so it is asked on a thread of its own WHILE all pairs are registered with the
+            # closed-form crops below (mvs_register_pairs releases the interpreter lock), and the pairs it names, if any, are
+            # registered again through the reference's sequence afterwards: the result is the reference's crop for every pair either way.
+            knife_box = {}
+
+            def ask(box=knife_box, shapes=out_shape[:, :n].copy()):
+                try:
+                    box["odd"] = [e for e in range(ne) if _reference_crop_differs(geoms_b[edges[e][0]], geoms_b[edges[e][1]], tol, shapes[e])]
+                except BaseException as exc:      # noqa: BLE001 - handed to the caller's thread below
+                    box["error"] = exc
+
+            knife_thread = threading.Thread(target=ask, name="mvs-crop-length", daemon=True)
+            knife_thread.start()
+        elif odd:
             cache.reference_pairs = len(odd)
             odd_set = set(odd)
             keep = [e for e in range(ne) if e not in odd_set]
@@ -753,96 +776,131 @@ def _register_pairs_batched(sims, edges, transform_key, registration_binning, ov
                                                 overlap_tolerance=overlap_tolerance, pairwise_reg_func_kwargs=pairwise_reg_func_kwargs,
                                                 device=device, _bin_cache=cache, overlap_bbox="reference")
             return res
-    # ---- where the crops come from.  Binned integer tiles whose crops are whole-pixel translations (every regular mosaic): straight
-    # from the RAW tiles, the binning applied inside the crop kernel (job.bin) -- no binned copy of a tile is ever made, a pair reads
-    # only the slabs its overlap needs.  Otherwise from binned tiles (pre-binned in groups with stream tickets, see _prebin_views). ----
-    raw_crops = (do_bin and _raw_crops_enabled[0] and first.data.dtype in (np.dtype(np.uint8), np.dtype(np.uint16))
-                 and bool(np.all(mdiag[:, :, :n] == 1.0)) and bool(np.all(offs[:, :, :n] == np.floor(offs[:, :, :n]))))
-    tickets = {v: 0 for v in used}
-    prebin_lane = None
-    if raw_crops or not do_bin:
-        source = {v: sims[v].data for v in used}
-        # tiles still on their way to the device (device.to_device_async): a pair's lane waits for the uploads of ITS two tiles
-        tickets = {v: source[v].ready_ticket for v in used}
-    else:
-        if all(cache.ticket_of((id(sims[v].data), bkey)) is None and (id(sims[v].data), bkey) not in cache._items for v in used):
-            # (queues the binning of all views on the last context lane; None: not a regular mosaic, the views are binned one by one below)
-            prebin_lane = _prebin_views([sims[v] for v in used], binning, device, cache)
-        source = {}
-        for v in used:
-            s_ = sims[v]
-            key = (id(s_.data), bkey)
-            b_ = cache.get_or_compute(key, lambda s_=s_: _bin_sim(s_, binning, device), keep=s_.data)
-            tickets[v] = cache.ticket_of(key) or 0
-            if (b_.data.device & 0xff) != (device & 0xff) or b_.data.strides[-1] != 1 or [len(b_.coords[d]) for d in sdims] != geoms_b[v].shape:
-                return None
-            source[v] = b_.data
-    cache.raw_crops = ne if raw_crops else 0
-    # ---- jobs: the two crop windows of every pair as mvs_view_t (strided windows into the tiles) ----
-    jobs = (_lib.mvs_pair_job_t * ne)()
-    ja = np.frombuffer(jobs, dtype=_JOB_DTYPE)
-    k0 = 3 - n
-    base = np.array([source[v].ptr for v in used], dtype=np.uint64)
-    strides = np.array([[int(x) for x in source[v].strides] for v in used], dtype=np.int64).reshape(nv, n)
-    item = first.data.dtype.itemsize
-    code = _lib.DTYPE_CODES[first.data.dtype]
-    tk = np.array([tickets[v] for v in used], dtype=np.uint64)
-    scale = np.array(bins if raw_crops else [1] * n, dtype=np.int64)      # binned index -> index of the source array
-    for i, name in enumerate(("fixed", "moving")):
-        f = ja[name]
-        vi = pr[:, i]
-        a, b = windows[:, i, :n, 0] * scale, windows[:, i, :n, 1] * scale
-        st = strides[vi]
-        f["data"] = base[vi] + (np.sum(a * st, axis=1) * item).astype(np.uint64)
-        f["dtype"] = code
-        f["mem"] = _lib.MVS_MEM_DEVICE
-        f["shape"][:, :k0] = 1
-        f["shape"][:, k0:] = b - a
-        if n == 3:
-            f["stride"][:] = st
-        else:       # a 2D slab is one z plane
-            f["stride"][:, 0] = st[:, 0] * (b - a)[:, 0]
-            f["stride"][:, 1:] = st
-        f["matrix"][:] = 0.0
-        f["matrix"][:, [0, 4, 8]] = 1.0
-        f["matrix"][:, [(k0 + k) * 4 for k in range(n)]] = mdiag[:, i, :n]
-        f["offset"][:] = 0.0
-        f["offset"][:, k0:] = offs[:, i, :n]
-        ja["wait_ticket"][:, i] = tk[vi]
-    ja["out_shape"][:, :k0] = 1
-    ja["out_shape"][:, k0:] = out_shape[:, :n]
-    if raw_crops:
-        ja["bin"][:, :k0] = 1
-        ja["bin"][:, k0:] = scale
-    if _pair_timeline is not None:
-        ja["flags"][:] = 1       # every pair leaves a timed ticket of its last kernel (read below)
-    upsample_factor = (pairwise_reg_func_kwargs or {}).get("upsample_factor")
-    uf = (10 if n == 2 else 2) if upsample_factor is None else upsample_factor
-    t3, q = np.zeros((ne, 3)), np.zeros(ne)
-    status, ncand, rcs = np.zeros(ne, dtype=np.int32), np.zeros(ne, dtype=np.int32), np.zeros(ne, dtype=np.int32)
+
+    def knife_fixup(res):
+        """(first call of a geometry) wait for the crop-length answers, remember them, redo the pairs they name the reference's way."""
+        if knife_thread is None:
+            return res
+        knife_thread.join()
+        if "error" in knife_box:
+            raise knife_box["error"]
+        odd_ = knife_box["odd"]
+        with _KNIFE_LOCK:
+            _KNIFE_MEMO[mkey] = odd_
+        if res is None:
+            return None
+        if odd_:
+            cache.reference_pairs = len(odd_)
+            if raw_before is not None and cache.raw_crops > raw_before:
+                cache.raw_crops = max(raw_before, cache.raw_crops - len(odd_))      # (their closed-form results are discarded)
+            for e in odd_:
+                i, j = edges[e]
+                res[e] = register_pair_of_msims(sims[i], sims[j], transform_key, registration_binning=registration_binning,
+                                                overlap_tolerance=overlap_tolerance, pairwise_reg_func_kwargs=pairwise_reg_func_kwargs,
+                                                device=device, _bin_cache=cache, overlap_bbox="reference")
+        return res
+
+    def _register_planned_pairs():
+        """Jobs of all planned pairs -> mvs_register_pairs -> result dicts (None: not covered, the caller takes the per-pair path)."""
+        # ---- where the crops come from.  Binned integer tiles whose crops are whole-pixel translations (every regular mosaic): straight
+        # from the RAW tiles, the binning applied inside the crop kernel (job.bin) -- no binned copy of a tile is ever made, a pair reads
+        # only the slabs its overlap needs.  Otherwise from binned tiles (pre-binned in groups with stream tickets, see _prebin_views). ----
+        raw_crops = (do_bin and _raw_crops_enabled[0] and first.data.dtype in (np.dtype(np.uint8), np.dtype(np.uint16))
+                     and bool(np.all(mdiag[:, :, :n] == 1.0)) and bool(np.all(offs[:, :, :n] == np.floor(offs[:, :, :n]))))
+        tickets = {v: 0 for v in used}
+        prebin_lane = None
+        if raw_crops or not do_bin:
+            source = {v: sims[v].data for v in used}
+            # tiles still on their way to the device (device.to_device_async): a pair's lane waits for the uploads of ITS two tiles
+            tickets = {v: source[v].ready_ticket for v in used}
+        else:
+            if all(cache.ticket_of((id(sims[v].data), bkey)) is None and (id(sims[v].data), bkey) not in cache._items for v in used):
+                # (queues the binning of all views on the last context lane; None: not a regular mosaic, the views are binned one by one below)
+                prebin_lane = _prebin_views([sims[v] for v in used], binning, device, cache)
+            source = {}
+            for v in used:
+                s_ = sims[v]
+                key = (id(s_.data), bkey)
+                b_ = cache.get_or_compute(key, lambda s_=s_: _bin_sim(s_, binning, device), keep=s_.data)
+                tickets[v] = cache.ticket_of(key) or 0
+                if (b_.data.device & 0xff) != (device & 0xff) or b_.data.strides[-1] != 1 or [len(b_.coords[d]) for d in sdims] != geoms_b[v].shape:
+                    return None
+                source[v] = b_.data
+        cache.raw_crops = ne if raw_crops else 0
+        # ---- jobs: the two crop windows of every pair as mvs_view_t (strided windows into the tiles) ----
+        jobs = (_lib.mvs_pair_job_t * ne)()
+        ja = np.frombuffer(jobs, dtype=_JOB_DTYPE)
+        k0 = 3 - n
+        base = np.array([source[v].ptr for v in used], dtype=np.uint64)
+        strides = np.array([[int(x) for x in source[v].strides] for v in used], dtype=np.int64).reshape(nv, n)
+        item = first.data.dtype.itemsize
+        code = _lib.DTYPE_CODES[first.data.dtype]
+        tk = np.array([tickets[v] for v in used], dtype=np.uint64)
+        scale = np.array(bins if raw_crops else [1] * n, dtype=np.int64)      # binned index -> index of the source array
+        for i, name in enumerate(("fixed", "moving")):
+            f = ja[name]
+            vi = pr[:, i]
+            a, b = windows[:, i, :n, 0] * scale, windows[:, i, :n, 1] * scale
+            st = strides[vi]
+            f["data"] = base[vi] + (np.sum(a * st, axis=1) * item).astype(np.uint64)
+            f["dtype"] = code
+            f["mem"] = _lib.MVS_MEM_DEVICE
+            f["shape"][:, :k0] = 1
+            f["shape"][:, k0:] = b - a
+            if n == 3:
+                f["stride"][:] = st
+            else:       # a 2D slab is one z plane
+                f["stride"][:, 0] = st[:, 0] * (b - a)[:, 0]
+                f["stride"][:, 1:] = st
+            f["matrix"][:] = 0.0
+            f["matrix"][:, [0, 4, 8]] = 1.0
+            f["matrix"][:, [(k0 + k) * 4 for k in range(n)]] = mdiag[:, i, :n]
+            f["offset"][:] = 0.0
+            f["offset"][:, k0:] = offs[:, i, :n]
+            ja["wait_ticket"][:, i] = tk[vi]
+        ja["out_shape"][:, :k0] = 1
+        ja["out_shape"][:, k0:] = out_shape[:, :n]
+        if raw_crops:
+            ja["bin"][:, :k0] = 1
+            ja["bin"][:, k0:] = scale
+        if _pair_timeline is not None:
+            ja["flags"][:] = 1       # every pair leaves a timed ticket of its last kernel (read below)
+        upsample_factor = (pairwise_reg_func_kwargs or {}).get("upsample_factor")
+        uf = (10 if n == 2 else 2) if upsample_factor is None else upsample_factor
+        t3, q = np.zeros((ne, 3)), np.zeros(ne)
+        status, ncand, rcs = np.zeros(ne, dtype=np.int32), np.zeros(ne, dtype=np.int32), np.zeros(ne, dtype=np.int32)
+        try:
+            rc = lib.mvs_register_pairs(device & 0xff, ne, jobs, n, int(uf), -1, 1, int(n_lanes), ptr(t3, C.c_double), ptr(q, C.c_double),
+                                        ptr(status, C.c_int32), ptr(ncand, C.c_int32), ptr(rcs, C.c_int32))
+        finally:
+            if prebin_lane is not None:
+                _lib.synchronize(prebin_lane)      # (done long ago unless a pair failed: nothing stays queued on the caller's tiles)
+        _lib.check(rc, device & 0xff, "mvs_register_pairs")
+        if _pair_timeline is not None:
+            _pair_timeline.extend((tuple(edges[e]), int(ja["wait_ticket"][e, 0])) for e in range(ne))
+        # ---- overlap boxes in world coordinates (_lean_overlap on the UNBINNED views) and the physical affines ----
+        o = np.array([geoms[v].origin for v in used], dtype=np.float64).reshape(nv, n)
+        sp = np.array([geoms[v].spacing for v in used], dtype=np.float64).reshape(nv, n)
+        shp = np.array([geoms[v].shape for v in used], dtype=np.int64).reshape(nv, n)
+        tw = np.array([geoms[v].t for v in used], dtype=np.float64).reshape(nv, n)
+        shp = shp + np.ceil(2 * tolv / sp).astype(np.int64)
+        o = o - tolv
+        lo_v = o + tw
+        hi_v = ((shp - 1) * 1.0 * sp + o) + tw
+        lo = np.maximum(lo_v[pr[:, 0]], lo_v[pr[:, 1]])
+        hi = np.minimum(hi_v[pr[:, 0]], hi_v[pr[:, 1]])
+        up = 1.0 * (hi - lo) + lo
+        fixed_aff = np.array([geoms_b[v].affine for v in used], dtype=np.float64)[pr[:, 0]]
+        return _pair_results_from_plan(t3[:, k0:], q, status, out_origin[:, :n], out_spacing[:, :n], out_shape[:, :n], fixed_aff, lo, up)
+
+    raw_before = getattr(cache, "raw_crops", None)
     try:
-        rc = lib.mvs_register_pairs(device & 0xff, ne, jobs, n, int(uf), -1, 1, int(n_lanes), ptr(t3, C.c_double), ptr(q, C.c_double),
-                                    ptr(status, C.c_int32), ptr(ncand, C.c_int32), ptr(rcs, C.c_int32))
-    finally:
-        if prebin_lane is not None:
-            _lib.synchronize(prebin_lane)      # (done long ago unless a pair failed: nothing stays queued on the caller's tiles)
-    _lib.check(rc, device & 0xff, "mvs_register_pairs")
-    if _pair_timeline is not None:
-        _pair_timeline.extend((tuple(edges[e]), int(ja["wait_ticket"][e, 0])) for e in range(ne))
-    # ---- overlap boxes in world coordinates (_lean_overlap on the UNBINNED views) and the physical affines ----
-    o = np.array([geoms[v].origin for v in used], dtype=np.float64).reshape(nv, n)
-    sp = np.array([geoms[v].spacing for v in used], dtype=np.float64).reshape(nv, n)
-    shp = np.array([geoms[v].shape for v in used], dtype=np.int64).reshape(nv, n)
-    tw = np.array([geoms[v].t for v in used], dtype=np.float64).reshape(nv, n)
-    shp = shp + np.ceil(2 * tolv / sp).astype(np.int64)
-    o = o - tolv
-    lo_v = o + tw
-    hi_v = ((shp - 1) * 1.0 * sp + o) + tw
-    lo = np.maximum(lo_v[pr[:, 0]], lo_v[pr[:, 1]])
-    hi = np.minimum(hi_v[pr[:, 0]], hi_v[pr[:, 1]])
-    up = 1.0 * (hi - lo) + lo
-    fixed_aff = np.array([geoms_b[v].affine for v in used], dtype=np.float64)[pr[:, 0]]
-    return _pair_results_from_plan(t3[:, k0:], q, status, out_origin[:, :n], out_spacing[:, :n], out_shape[:, :n], fixed_aff, lo, up)
+        res_all = _register_planned_pairs()
+    except BaseException:
+        if knife_thread is not None:
+            knife_thread.join()
+        raise
+    return knife_fixup(res_all)
 
 
 def _geom_of(sim, transform_key, cache):
