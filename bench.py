@@ -727,7 +727,8 @@ def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out, sh
             "upload_done_ms": trace.get("upload_done_ms"), "h2d_gb_per_s": h2d_gb / (trace["upload_done_ms"] * 1e-3) if trace.get("upload_done_ms") else None,
             "d2h_gb_per_s": d2h_gb / max(own - t_reg, 1e-9), "timeline": trace,
             "api": "device.pinned_empty, device.to_device_async, registration.register, fusion.fuse_to_host"
-                   + (" / sharding.fuse_shard_to_host" if shard else "") + " (no torch streams, no private helpers)",
+                   + (" / sharding.fuse_shard_to_host" if shard else "") + " (no torch streams; the one private hook, "
+                   "registration._pair_timeline, only collects the pairs' tickets for the timeline below)",
             "note": "tiles in pinned host memory -> uploads in tile order on the device's copy stream, overlapped with the registration of "
                     "the pairs whose tiles have arrived (pair jobs wait for their tiles' tickets on their lanes) -> resolution -> fuse in z "
                     "slabs, each slab's download overlapped with the next slab's fuse; timeline (rank 0): timed tickets, ms since the first "
