@@ -134,6 +134,32 @@ int mvs_ensure_aux_streams(MvsContext* c) {
     return MVS_OK;
 }
 
+// Host -> device upload of a parameter block out of a pinned staging slot (mvs_pinned_slot), stream-ordered like the hipMemcpyAsync it
+// replaces: up to 32 MiB travel as a KERNEL that reads the pinned block over the link (see mvs_small_copy_kernel), because a DMA copy
+// queues behind whatever large transfer its copy engine is busy with -- the view records and the brick list of a slab's fuse launch
+// (a few hundred KB) sat behind the previous slab's 1.3 GB download for its whole 24 ms, i.e. fuse_to_host / the block pipeline of a
+// streamed fuse() overlapped kernels and transfers only when the two happened to land on different engines (round 6: in most runs
+// for some slabs, in one of ten for none).  Larger blocks, odd alignments and memory the device cannot map take the DMA copy.
+__global__ void mvs_copy_bytes_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, size_t nbytes) {
+    const size_t n16 = nbytes >> 4, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n16; i += nth) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (size_t i = (n16 << 4) + tid; i < nbytes; i += nth) dst[i] = src[i];
+}
+int mvs_upload_small(MvsContext* c, void* dst_dev, const void* src_pinned, size_t nbytes) {
+    if (!nbytes) return MVS_OK;
+    void* sdev = nullptr;
+    if (nbytes <= ((size_t)32 << 20) && !(((uintptr_t)dst_dev | (uintptr_t)src_pinned) & 15) &&
+        hipHostGetDevicePointer(&sdev, const_cast<void*>(src_pinned), 0) == hipSuccess && sdev) {
+        const unsigned blocks = (unsigned)std::min<size_t>(((nbytes >> 4) + 255) / 256 + 1, 512);
+        hipLaunchKernelGGL(mvs_copy_bytes_kernel, dim3(blocks), dim3(256), 0, c->stream, (const unsigned char*)sdev, (unsigned char*)dst_dev, nbytes);
+        MVS_HIP_TRY(c, hipGetLastError());
+        return MVS_OK;
+    }
+    (void)hipGetLastError();
+    MVS_HIP_TRY(c, hipMemcpyAsync(dst_dev, src_pinned, nbytes, hipMemcpyHostToDevice, c->stream));
+    return MVS_OK;
+}
+
 void mvs_pinned_mark(MvsContext* c, int slot) {
     const int k = slot ? 1 : 0;
     if (hipEventRecord(c->pinned_ev[k], c->stream) == hipSuccess) c->pinned_pending[k] = true;

@@ -1456,7 +1456,7 @@ extern "C" int mvs_fuse_chunk(int device, const mvs_view_t* views, int32_t n_vie
             htr[i].xtab_off = (int)xtab_total + kXTabMargin;
             xtab_total += (size_t)std::max(hviews[i].hi[2] - hviews[i].lo[2] + 1, 0) + 2 * kXTabMargin;
         }
-    MVS_HIP_TRY(c, hipMemcpyAsync(dviews, hviews, params_bytes, hipMemcpyHostToDevice, c->stream));
+    { const int rcu = mvs_upload_small(c, dviews, hviews, params_bytes); if (rcu) return rcu; }
     mvs_pinned_mark(c, 0);
 
     const size_t out_bytes = (size_t)os[0] * os[1] * os[2] * es;

@@ -1281,7 +1281,7 @@ int mvs_fuse_regions(MvsContext* c, const TrView* htr, const TrView* dtr, int n_
         if (!dbuf) return mvs_alloc_failed(c);
         memcpy(hbuf, regions.data(), regions.size() * sizeof(Region));
         memcpy(hbuf + rbytes, items.data(), ibytes);
-        MVS_HIP_TRY(c, hipMemcpyAsync(dbuf, hbuf, rbytes + ibytes, hipMemcpyHostToDevice, c->stream));
+        { const int rcu = mvs_upload_small(c, dbuf, hbuf, rbytes + ibytes); if (rcu) return rcu; }
         mvs_pinned_mark(c, 1);
         nitems = (int)items.size();
         pc.hash = h;

@@ -150,7 +150,7 @@ int mvs_fuse_rows(MvsContext* c, const TrView* htr, const TrView* dtr, int n_vie
             memcpy(hbuf + cur, items_by_class[k].data(), items_by_class[k].size() * sizeof(RowItem));
             cur += items_by_class[k].size() * sizeof(RowItem);
         }
-        MVS_HIP_TRY(c, hipMemcpyAsync(dbuf, hbuf, total, hipMemcpyHostToDevice, c->stream));
+        { const int rcu = mvs_upload_small(c, dbuf, hbuf, total); if (rcu) return rcu; }
         mvs_pinned_mark(c, 1);
         pc.hash = h;
         pc.nstrips = (int)strips.size();

@@ -920,7 +920,7 @@ int mvs_fuse_content_based(MvsContext* c, const mvs_view_t* views, int32_t n_vie
             memcpy(hp + wb + bb + vb + (size_t)i * sizeof(CbMaskRec), &r, sizeof(r));
         }
         memcpy(hp + wb + bb + vb + rb, table_off.data(), (size_t)n_views * 16);
-        MVS_HIP_TRY(c, hipMemcpyAsync(dblock, hp, wb + bb + vb + rb + ob, hipMemcpyHostToDevice, c->stream));
+        { const int rcu = mvs_upload_small(c, dblock, hp, wb + bb + vb + rb + ob); if (rcu) return rcu; }
         mvs_pinned_mark(c, 0);
     }
 
@@ -1278,7 +1278,7 @@ static int cb_fast_chunk(MvsContext* c, const mvs_view_t* views, int32_t n_views
             for (int k = 0; k < 3; ++k) { r.lo[k] = 0x7fffffff; r.hi[k] = -1; }
             memcpy(hp + wdb + wfb + vb + (size_t)i * sizeof(CbFastRec), &r, sizeof(r));
         }
-        MVS_HIP_TRY(c, hipMemcpyAsync(dblock, hp, up_b, hipMemcpyHostToDevice, c->stream));
+        { const int rcu = mvs_upload_small(c, dblock, hp, up_b); if (rcu) return rcu; }
         mvs_pinned_mark(c, 0);
     }
 

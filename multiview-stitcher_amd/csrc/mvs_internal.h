@@ -163,6 +163,7 @@ int mvs_mailbox(MvsContext* c, size_t nbytes, void** host, void** dev);
 int mvs_ensure_aux_streams(MvsContext* c);
 // stream-ordered copy of a few KB out of the mailbox (device-visible pointer) by a kernel, not by the copy engine; 16-byte granularity
 int mvs_upload_from_mapped(MvsContext* c, void* dst_dev, const void* src_mapped_dev, size_t nbytes);
+int mvs_upload_small(MvsContext* c, void* dst_dev, const void* src_pinned, size_t nbytes);   // parameter blocks out of a pinned staging slot: by a kernel, not a copy engine
 
 // the code of the failure mvs_scratch / mvs_pinned recorded when they returned NULL (MVS_ERR_OUT_OF_MEMORY or MVS_ERR_HIP)
 static inline int mvs_alloc_failed(const MvsContext* c) { return c->last_code ? c->last_code : MVS_ERR_HIP; }

@@ -1272,6 +1272,26 @@ def fuse_to_host(images, transform_key=None, n_slabs=8, out=None, device=0, retu
     t_start = dev_mod.mark(device)
     h_start = time.perf_counter()
     pending, timeline, host_ms = [], [], []      # host_ms: (fuse() of the slab entered, returned) on the host clock, ms
+    # The class kernels of a slab's launch stay on the lane's own stream (option serial_classes) while downloads are in flight: forked
+    # onto the LOW-priority side streams they were served only when the HIGH-priority copy stream's queue had drained -- slab k + 1 was
+    # fused when slab k's download was through, in most runs for some slabs, in one run of ten for all of them, once 377 ms late
+    # (A/B on one box, profiles/round6_summary.md 4).  A slab is 1/8 of a mosaic; forking saves it ~0.1 ms.  (The other half of the
+    # same symptom: parameter blocks uploaded by a copy engine queued behind the downloads -- csrc/mvs_context.hip: mvs_upload_small.)
+    serial_slabs = True
+    if serial_slabs:
+        _lib.set_option("serial_classes", 1, device)
+    try:
+        return _fuse_to_host_slabs(images, transform_key, n_slabs, cuts, osp, d0, out, device, return_timeline, fuse_kwargs, sdims, t_start, h_start,
+                                   pending, timeline, host_ms)
+    finally:
+        if serial_slabs:
+            _lib.set_option("serial_classes", 0, device)
+
+
+def _fuse_to_host_slabs(images, transform_key, n_slabs, cuts, osp, d0, out, device, return_timeline, fuse_kwargs, sdims, t_start, h_start, pending,
+                        timeline, host_ms):
+    from . import device as dev_mod
+
     for k in range(n_slabs):
         a, b = int(cuts[k]), int(cuts[k + 1])
         if b <= a:

@@ -38,8 +38,11 @@ def test_streamed_register_and_fuse_equal_the_resident_run_and_overlap(hip_devic
     """Tiles uploaded with ``to_device_async`` while ``register()`` registers the pairs whose tiles have landed, the mosaic fused in
     slabs with every slab's download under the next slab's fuse (``fuse_to_host``): (1) parameters and fused voxels equal the run
     on resident tiles bit for bit; (2) the timeline -- timed tickets of the uploads, of every pair's last kernel, of every slab's
-    fuse and download -- shows pairs finished before the last tile had landed and slabs fused before the previous slab's download
-    was through: upload, kernels and download overlap."""
+    fuse and download -- shows that kernels do not wait for transfers they do not depend on.  The test mosaic is small (uploads of
+    5 ms, downloads of 1 ms: too short to show anything against the host's own milliseconds), so the copy stream is given a backlog
+    on purpose: a 1 GiB upload queued BEFORE the last tile (the pairs of the other tiles must be done long before that tile lands)
+    and a 1 GiB download queued before ``fuse_to_host`` (all slabs must be fused while it still runs, i.e. before the first slab's
+    own download can even start -- with parameter blocks uploaded by a copy engine they queued behind it: round 6)."""
     from multiview_stitcher_amd import device, fusion, registration, sample_data
 
     key = sample_data.METADATA_TRANSFORM_KEY
@@ -53,16 +56,24 @@ def test_streamed_register_and_fuse_equal_the_resident_run_and_overlap(hip_devic
         h = device.pinned_empty(s.data.shape, s.data.dtype)
         h[:] = np.asarray(s.data)
         host.append(s.copy(data=h))
+    ballast_host = device.pinned_empty((1 << 30,), np.uint8)            # ~19 ms of the host link per direction
+    ballast_host[:] = 0
+    ballast_dev = device.DeviceArray.empty((1 << 30,), np.uint8, 0)
     registration._pair_timeline = pairs = []
     try:
         t0 = device.mark(0)
-        a_sims = device.to_device_async(host, 0)
+        a_sims = device.to_device_async(host[:-1], 0)
+        ballast_up = device.DeviceArray.from_host_async(ballast_host, 0)           # the copy stream keeps the order: tiles 0-6, ballast, tile 7
+        a_sims += device.to_device_async(host[-1:], 0)
         uploads = [s.data.ready_ticket for s in a_sims]
         assert all(uploads)
         p_got = registration.register(a_sims, transform_key=key, new_transform_key="reg", device=0)
     finally:
         registration._pair_timeline = None
-    fused, slabs = fusion.fuse_to_host(a_sims, transform_key="reg", n_slabs=4, device=0, return_timeline=True)
+    out_host = device.pinned_empty(want.shape, want.dtype)          # (made before the clock starts: pinning 200 MB takes longer than the ballast)
+    t1 = device.mark(0)
+    ballast_down = ballast_dev.download_async(ballast_host, after=ballast_up.ready_ticket)
+    fused, slabs = fusion.fuse_to_host(a_sims, transform_key="reg", n_slabs=4, out=out_host, device=0, return_timeline=True)
     for a, b in zip(p_got, p_ref):
         np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
     got = np.asarray(fused.data)
@@ -73,13 +84,21 @@ def test_streamed_register_and_fuse_equal_the_resident_run_and_overlap(hip_devic
     pair_ms = [device.ticket_elapsed_ms(t0, t) for _, t in pairs]
     assert len(pairs) >= 7 and all(t > 0 for t in pair_ms)
     assert up_ms == sorted(up_ms)                                   # the copy stream keeps the order of the list
+    assert up_ms[-1] - up_ms[-2] > 8.0                              # (the ballast sits in front of the last tile)
     # a pair cannot end before its two tiles have landed ...
+    last = len(host) - 1
     for (i, j), t in zip([e for e, _ in pairs], pair_ms):
         assert t >= max(up_ms[i], up_ms[j]) - 1e-3
-    # ... and the first pairs are done while later tiles are still on their way
-    assert min(pair_ms) < max(up_ms), (sorted(pair_ms)[:3], up_ms)
+    # ... and pairs that do not touch the last tile are done while it is still on its way (not necessarily all of them: the lanes'
+    # streams share hardware queues, and a lane that already waits for the last tile holds up the stream behind it in its queue)
+    early = [t for (i, j), t in zip([e for e, _ in pairs], pair_ms) if last not in (i, j)]
+    assert len(early) >= 6 and sum(t < up_ms[-1] - 5.0 for t in early) >= len(early) // 2, (sorted(early), up_ms)
+    # every slab was fused while the ballast download was still running -- before the first slab's own download could start
+    down_ms = device.ticket_elapsed_ms(t1, ballast_down)
+    assert down_ms > 8.0
     assert len(slabs) == 4 and all(d >= f for f, d in slabs)
-    assert any(slabs[k + 1][0] < slabs[k][1] for k in range(3)), slabs      # slab k + 1 was fused before slab k's download was through
+    assert max(f for f, _ in slabs) < min(d for _, d in slabs), slabs
+    assert slabs[0][1] - slabs[0][0] > 4.0, slabs                   # (slab 0's download waited behind the ballast; its fuse did not)
 
 
 @pytest.mark.parametrize("weights", [None, "content_based"])
