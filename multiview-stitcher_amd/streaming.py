@@ -155,6 +155,12 @@ class BlockPipeline:
         self.writes = []
         self.timeline = []     # per block: host-clock seconds since the pipeline was made (slabs staged, fuse queued, downloaded, written)
         self._t0 = time.perf_counter()
+        # the class kernels of the blocks' launches stay on the lane's own stream while the copy stream is busy (see fusion.fuse_to_host)
+        self._serial = os.environ.get("MVS_STREAM_FORK", "0") != "1"
+        if self._serial:
+            from . import _lib
+
+            _lib.set_option("serial_classes", 1, device)
 
     # -- stage 1: slabs -> pinned -> async upload
     def _stage(self, kwargs):
@@ -267,6 +273,14 @@ class BlockPipeline:
         self.staged, self.writes = [], []
         self.reader.shutdown(wait=False, cancel_futures=True)
         self.writer.shutdown(wait=False, cancel_futures=True)
+        self._restore()
+
+    def _restore(self):
+        if self._serial:
+            from . import _lib
+
+            self._serial = False
+            _lib.set_option("serial_classes", 0, self.device)
 
     def finish(self):
         try:
@@ -278,4 +292,5 @@ class BlockPipeline:
         finally:
             self.reader.shutdown(wait=True)
             self.writer.shutdown(wait=True)
+            self._restore()
             LAST_TIMELINE[:] = self.timeline
