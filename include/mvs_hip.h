@@ -286,8 +286,9 @@ int mvs_event_wait(int device, uint64_t ticket);
 /* ---- Transfers that overlap with the kernels (csrc/mvs_transfer.hip).  The reference's users hand fuse() host- or Zarr-backed
  * arrays and stream the fused chunks out (fusion/_core.py:1068-1170, 2044-2156; spatial_image_utils.py:712-860); SURVEY 8d(2)
  * counts H2D / D2H into the end-to-end figure.  mvs_host_alloc: pinned host memory (what an asynchronous copy needs to be
- * asynchronous).  mvs_copy_async: one copy (kind 0: host -> device, 1: device -> host) on the device's COPY STREAM -- one per
- * device, created with a priority of its own so that its queued copies do not stall the compute streams -- started after ticket
+ * asynchronous).  mvs_copy_async: one copy (kind 0: host -> device, 1: device -> host) on the device's COPY STREAM of that direction -- one
+ * per device and direction (uploads and downloads run side by side, each direction in the order queued), created with a priority of
+ * their own so that queued copies do not stall the compute streams -- started after ticket
  * `after` (0: at once; a ticket of mvs_event_record, mvs_mark or an earlier mvs_copy_async) and marked by the ticket *done_out.
  * Tickets of this group are timed events from a ring of 4096 per device; mvs_event_wait accepts them, so a pair job of
  * mvs_register_pairs (wait_ticket) starts when its two tiles have landed, and a download starts when the launch that produced

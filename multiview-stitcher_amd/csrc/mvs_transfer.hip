@@ -5,7 +5,7 @@
 // pinned asynchronous copies overlapped with the work.  Rounds 2-5 had that pipeline only inside bench.py (torch streams); this
 // unit puts its pieces behind the C ABI:
 //   * mvs_host_alloc / mvs_host_free: pinned host memory (the only kind an asynchronous copy really is asynchronous from);
-//   * mvs_copy_async: one copy on the device's COPY STREAM -- created with a priority of its own, because HIP multiplexes the
+//   * mvs_copy_async: one copy on the device's COPY STREAM of its direction (uploads and downloads have one each) -- created with a priority of its own, because HIP multiplexes the
 //     streams of a process onto a few hardware queues PER PRIORITY LEVEL and a stream holding the barrier packets of 64 queued tile
 //     uploads stalls every compute stream that shares its queue (measured in round 4: the first wave of pairs took 242 ms instead
 //     of ~11 with a normal-priority copy stream) -- optionally after a ticket, returning a ticket of its own;
@@ -15,6 +15,7 @@
 //     makes the host wait; mvs_ticket_elapsed_ms reads the time between two of them (the overlap test reads its timeline there).
 #include "mvs_internal.h"
 
+#include <cstdlib>
 #include <mutex>
 
 namespace {
@@ -22,7 +23,12 @@ namespace {
 constexpr uint32_t kRing = 4096;
 struct TransferQueue {
     std::mutex mu;
-    hipStream_t stream = nullptr;
+    hipStream_t stream[2] = {nullptr, nullptr};      // [0] host -> device, [1] device -> host: one copy stream per DIRECTION, so that the
+                                                     // uploads of block k + 1 and the download of block k - 1 of a streamed fuse() run side by
+                                                     // side (the link is full duplex: 96 GB/s both ways at once against 55 one way); each
+                                                     // direction keeps the order in which its copies were queued.  (Measured on the C5
+                                                     // z-slab, whose pipeline is bound by the host's chunk-file copies: 0.27-0.33 s with one
+                                                     // stream or two.)
     hipEvent_t ev[kRing] = {};
     uint32_t next = 0;
 };
@@ -31,10 +37,10 @@ TransferQueue g_tq[MVS_MAX_DEVICES];
 constexpr uint64_t kTransferTag = 1ull << 41;
 
 int ensure_stream(MvsContext* c, TransferQueue& q, int dev) {
-    if (q.stream) return MVS_OK;
+    if (q.stream[0]) return MVS_OK;
     int lo = 0, hi = 0;
     MVS_HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));      // (lo: numerically greatest = least urgent)
-    MVS_HIP_TRY(c, hipStreamCreateWithPriority(&q.stream, hipStreamNonBlocking, hi));
+    for (int k = 0; k < 2; ++k) MVS_HIP_TRY(c, hipStreamCreateWithPriority(&q.stream[k], hipStreamNonBlocking, hi));
     (void)dev;
     return MVS_OK;
 }
@@ -104,13 +110,14 @@ extern "C" int mvs_copy_async(int device, void* dst, const void* src, uint64_t n
     MVS_HIP_TRY(c, hipSetDevice(dev));
     rc = ensure_stream(c, q, dev);
     if (rc) return rc;
-    if (after_ev) MVS_HIP_TRY(c, hipStreamWaitEvent(q.stream, after_ev, 0));
-    if (nbytes) MVS_HIP_TRY(c, hipMemcpyAsync(dst, src, (size_t)nbytes, kind == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, q.stream));
+    hipStream_t cs = q.stream[kind];
+    if (after_ev) MVS_HIP_TRY(c, hipStreamWaitEvent(cs, after_ev, 0));
+    if (nbytes) MVS_HIP_TRY(c, hipMemcpyAsync(dst, src, (size_t)nbytes, kind == 0 ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, cs));
     hipEvent_t ev;
     uint64_t ticket;
     rc = next_event(c, q, dev, &ev, &ticket);
     if (rc) return rc;
-    MVS_HIP_TRY(c, hipEventRecord(ev, q.stream));
+    MVS_HIP_TRY(c, hipEventRecord(ev, cs));
     if (done_out) *done_out = ticket;
     return MVS_OK;
 }
@@ -166,7 +173,8 @@ void mvs_transfer_shutdown(int dev) {
     if (dev < 0 || dev >= MVS_MAX_DEVICES) return;
     TransferQueue& q = g_tq[dev];
     std::lock_guard<std::mutex> lock(q.mu);
-    if (q.stream) { hipStreamSynchronize(q.stream); hipStreamDestroy(q.stream); q.stream = nullptr; }
+    for (hipStream_t& st : q.stream)
+        if (st) { hipStreamSynchronize(st); hipStreamDestroy(st); st = nullptr; }
     for (auto& e : q.ev)
         if (e) { hipEventDestroy(e); e = nullptr; }
     q.next = 0;
