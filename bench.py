@@ -523,6 +523,51 @@ def _cpu_content_based(ts=104):
                       f"8 views (2x2x2 uint16 tiles of {ts}^3), {int(vox)} voxels after the trim"}
 
 
+class _original_affinity:
+    """The legs whose work is done by host I/O threads (chunk files, staging copies) make those threads with the CPU affinity the process
+    was STARTED with: the block of 16 CPUs main() pinned the registration loop to is two CCDs of the host, whose links to memory carry
+    ~2/3 of what sixteen copying threads ask for (C5 leg, same box: 0.46-0.52 s inside the block, 0.39-0.42 s outside).  An application
+    that streams data does not pin itself to two CCDs."""
+
+    def __enter__(self):
+        self.pinned = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
+        if _ORIG_AFFINITY and hasattr(os, "sched_setaffinity"):
+            try:
+                os.sched_setaffinity(0, _ORIG_AFFINITY)
+            except OSError:
+                pass
+        return self
+
+    def __exit__(self, *exc):
+        if self.pinned and hasattr(os, "sched_setaffinity"):
+            try:
+                os.sched_setaffinity(0, self.pinned)
+            except OSError:
+                pass
+        return False
+
+
+def host_arrays_leg(sims, key, device):
+    """``fusion.fuse`` the way a user of the reference calls it: the tiles are plain (pageable) numpy arrays in host memory, the result is
+    one.  Both transfers are inside the figure; the launch blocks go through the block pipeline (pinned staging by the I/O pool,
+    asynchronous transfers under the blocks)."""
+    from multiview_stitcher_amd import fusion
+
+    host_sims = [s_.copy(data=np.array(s_.data.get())) for s_ in sims]
+    ms = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        out = fusion.fuse(host_sims, transform_key=key, device=device)
+        a = np.asarray(out.data)
+        ms.append((time.perf_counter() - t0) * 1e3)
+        vox, out_gb = float(a.size), a.nbytes / 1e9
+        del out, a
+    in_gb = sum(s_.data.nbytes for s_ in host_sims) / 1e9
+    return {"workload": "fusion.fuse(sims, transform_key=...) of the registered north-star mosaic with the 64 tiles as pageable numpy arrays, result a numpy array",
+            "ms": ms[-1], "first_call_ms": ms[0], "mvoxels_s": vox / (ms[-1] * 1e-3) / 1e6, "in_gb": in_gb, "out_gb": out_gb,
+            "gb_per_s": (in_gb + out_gb) / (ms[-1] * 1e-3), "floor_ms_h2d_at_55_gb_s": in_gb / 55.0 * 1e3}
+
+
 def c5_stream_leg(torch, dev, local_rank, args):
     """BASELINE.json config C5 (exaSPIM-style 512 x 1024 x 1024 uint16 tiles streamed from Zarr, chunked fuse) on a z-slab of its
     grid: 1 x 2 x 3 tiles written as Zarr arrays (128^3 chunks, uncompressed) on local disk, ``fusion.fuse`` from the Zarr-backed
@@ -540,16 +585,6 @@ def c5_stream_leg(torch, dev, local_rank, args):
 
     grid, tile = np.array([1, 2, 3]), np.array([512, 1024, 1024])
     overlap = np.round(tile * args.overlap_frac).astype(int)
-    # the I/O threads of this leg are made with the affinity the process was STARTED with: the block of 16 CPUs main() pinned the
-    # registration loop to is two CCDs of the host, whose links to memory carry ~2/3 of what the chunk-file copies of sixteen I/O
-    # threads ask for (same box, alternating: 0.46-0.52 s inside the block, 0.39-0.42 s with the threads where the scheduler puts them;
-    # host-only probe, reads + writes at once: 0.26 against 0.19 s).  A streaming application does not pin itself to two CCDs.
-    pinned_now = set(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else set()
-    if _ORIG_AFFINITY and hasattr(os, "sched_setaffinity"):
-        try:
-            os.sched_setaffinity(0, _ORIG_AFFINITY)
-        except OSError:
-            pass
     need = int(np.prod(tile)) * 2 * int(np.prod(grid)) * 2.2
     base = os.environ.get("MVS_BENCH_TMP")
     if base is None:
@@ -561,8 +596,6 @@ def c5_stream_leg(torch, dev, local_rank, args):
             except OSError:
                 continue
     if base is None:
-        if pinned_now and hasattr(os, "sched_setaffinity"):
-            os.sched_setaffinity(0, pinned_now)
         return {"skipped": "no directory with %.0f GB free" % (need * 1.3 / 1e9)}
     tmp = tempfile.mkdtemp(prefix="mvs_c5_", dir=base)
     try:
@@ -625,11 +658,6 @@ def c5_stream_leg(torch, dev, local_rank, args):
                 "note": "files were written just before: reads come from the page cache (a cold disk would lower read_tiles_s' rate and the ceiling with it)"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-        if pinned_now and hasattr(os, "sched_setaffinity"):
-            try:
-                os.sched_setaffinity(0, pinned_now)
-            except OSError:
-                pass
 
 
 def pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out, shard=None):
@@ -1023,11 +1051,20 @@ def main():
             c3 = c3_content_based_leg(torch, dev, local_rank, args)
         except Exception as e:   # noqa: BLE001 - an optional leg must not take the bench line down
             c3 = {"error": repr(e)[:300]}
+    host_fuse = None
+    if world == 1 and not args.no_pcie:
+        out_holder.clear()
+        try:
+            with _original_affinity():
+                host_fuse = host_arrays_leg(sims, key_out if do_register else key_in, local_rank)
+        except Exception as e:   # noqa: BLE001 - an optional leg must not take the bench line down
+            host_fuse = {"error": repr(e)[:300]}
     c5 = None
     if world == 1 and not args.no_c5:
         out_holder.clear()
         try:
-            c5 = c5_stream_leg(torch, dev, local_rank, args)
+            with _original_affinity():
+                c5 = c5_stream_leg(torch, dev, local_rank, args)
         except Exception as e:   # noqa: BLE001 - an optional leg must not take the bench line down
             c5 = {"error": repr(e)[:300]}
     traffic, traffic_src = fuse_traffic_bytes(grid, tile) if world == 1 else (None, "N > 1")
@@ -1107,6 +1144,7 @@ def main():
             },
             "c3_content_based": c3,
             "c5_stream": c5,
+            "fuse_host_arrays": host_fuse,
             "roofline": {
                 "bound": "hbm",
                 "kernel": "fuse launch of rank 0 = copy_region_kernel + fuse_region_kernel<1|2|4|8> (u16) side by side on forked streams, timed as one unit (first start to last end)",

@@ -93,6 +93,19 @@ def io_pool(workers=8, kind="read"):
         return _IO_POOL[kind]
 
 
+def parallel_copy(dst, src, kind="read"):
+    """``dst[...] = src`` cut along the first axis into pieces for the I/O pool of ``kind`` (a single thread copies ~8 GB/s; the
+    staging buffers of a streamed fuse() of host arrays want the link's 55)."""
+    src = np.asarray(src)
+    n = dst.shape[0] if dst.ndim else 1
+    if dst.ndim == 0 or dst.nbytes < (8 << 20) or n < 2:
+        dst[...] = src
+        return
+    pieces = min(n, 16)
+    cuts = np.linspace(0, n, pieces + 1).astype(int)
+    list(io_pool(kind=kind).map(lambda k: np.copyto(dst[cuts[k]:cuts[k + 1]], src[cuts[k]:cuts[k + 1]], casting="unsafe"), range(pieces)))
+
+
 def read_window(view, out):
     """Fill ``out`` (any writable array of the window's shape) with the Zarr window ``view`` (ZarrView / ZarrArray), the chunk
     files read and copied by the I/O pool."""
@@ -177,7 +190,7 @@ class BlockPipeline:
             if zarr_io.is_zarr_backed(data):
                 read_window(data, buf)
             else:
-                buf[...] = np.asarray(data)
+                parallel_copy(buf, data)
             raws.append(raw)
             sims.append(s_.copy(data=DeviceArray.from_host_async(buf, self.device)))
         slab_mb = sum(int(np.prod(s_.data.shape)) * np.dtype(s_.dtype).itemsize for s_ in sims) / 2 ** 20

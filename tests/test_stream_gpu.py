@@ -179,3 +179,30 @@ def test_copy_box_between_pitched_windows(hip_device):
         np.testing.assert_array_equal(db.get(), want)
     with pytest.raises(ValueError):
         da[:3, :3].copy_box_to(db[:3, :4])
+
+
+def test_fuse_of_plain_host_arrays_takes_the_block_pipeline_and_equals_one_launch_block(hip_device):
+    """``fuse()`` of host numpy tiles (>= 256 MiB) into a host numpy result -- the reference's own call -- runs its launch blocks through
+    the block pipeline by default; same voxels as the single launch block ``mvs_fuse_chunk`` uploads, fuses and downloads itself."""
+    from multiview_stitcher_amd import fusion, sample_data, streaming
+
+    key = sample_data.METADATA_TRANSFORM_KEY
+    sims = _mosaic()
+    assert sum(s.data.nbytes for s in sims) >= fusion._HOST_STREAM_MIN_BYTES and all(isinstance(s.data, np.ndarray) for s in sims)
+    old_budget = fusion.MAX_STREAM_BYTES
+    fusion.MAX_STREAM_BYTES = 64 << 20                # several launch blocks
+    try:
+        streaming.LAST_TIMELINE[:] = []
+        got = fusion.fuse(sims, transform_key=key, device=0)
+        assert len(streaming.LAST_TIMELINE) >= 2      # (the pipeline ran)
+    finally:
+        fusion.MAX_STREAM_BYTES = old_budget
+    fusion._HOST_STREAM[0] = False
+    try:
+        streaming.LAST_TIMELINE[:] = []
+        want = fusion.fuse(sims, transform_key=key, device=0)
+        assert not streaming.LAST_TIMELINE
+    finally:
+        fusion._HOST_STREAM[0] = True
+    assert isinstance(got.data, np.ndarray) and got.data.any()
+    np.testing.assert_array_equal(np.asarray(got.data), np.asarray(want.data))
