@@ -434,6 +434,7 @@ def _lean_overlap(g1, g2, tol, to_intrinsic):
 # depends on linprog's interior point and Qhull's elimination order).  The closed form registers N.  The default mode therefore
 # asks the reference's own sequence ONCE per pair geometry whether it lands on N - 1 somewhere (memo below: a register + fuse loop
 # over one mosaic pays the ~3 ms per pair once), and only such pairs leave the fast path for the ``overlap_bbox="reference"`` one.
+_HOST_UPLOAD_ASYNC = [os.environ.get("MVS_HOST_STREAM", "1") != "0"]      # register() of plain host tiles: pinned staging + asynchronous uploads
 _KNIFE_MEMO = {}
 _KNIFE_LOCK = threading.Lock()
 _KNIFE_CHECK = [os.environ.get("MVS_KNIFE_CHECK", "1") != "0"]
@@ -1355,6 +1356,17 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
         return s.isel({"c": ci}) if "c" in s.dims else s
 
     sims_reg = [channel_of(s) for s in sims]
+    if _HOST_UPLOAD_ASYNC[0] and pairwise_executor is None and not any(msi_utils.is_msim(m) and len(m.keys()) > 1 for m in msims) \
+            and reg_res_level is None and pairwise_reg_func is phase_correlation_registration \
+            and all(isinstance(s.data, np.ndarray) and list(s.dims) == list(si_utils.get_spatial_dims_from_sim(s)) for s in sims_reg) \
+            and sum(int(s.data.nbytes) for s in sims_reg) >= (256 << 20) and _lib.device_count() > 0 \
+            and all(s.data.dtype in _lib.DTYPE_CODES for s in sims_reg):
+        # plain host numpy tiles -- what a user of the reference hands over: staged through pinned buffers and uploaded on the copy stream
+        # while the overlap graph is built and the first pairs are registered (north star: 1.7-2.0 s of one synchronous pageable upload
+        # per tile before; streaming.upload_host_sims_async).  The caller's images are only read; results are written to them below.
+        from .streaming import upload_host_sims_async
+
+        sims_reg = upload_host_sims_async(sims_reg, device & 0xff)
     nt = sims_reg[0].sizes.get("t", 1) if "t" in sims_reg[0].dims else 1
     # pyramid levels take part only when an image has more than scale0 or a level is asked for (registration.py:1639-1717)
     multiscale = reg_res_level is not None or any(msi_utils.is_msim(m) and len(m.keys()) > 1 for m in msims)

@@ -38,6 +38,8 @@ class PinnedPool:
 
     def __init__(self, cap_bytes=None):
         self._free = {}
+        self._busy = {}       # id(raw) -> ticket of a transfer that was still reading the buffer when it came back
+        self._limbo = []
         self._lock = threading.Lock()
         self._held = 0
         self.cap_bytes = int(os.environ.get("MVS_PINNED_POOL_MB", 16 << 10)) << 20 if cap_bytes is None else int(cap_bytes)
@@ -51,20 +53,35 @@ class PinnedPool:
             raw = lst.pop() if lst else None
             if raw is not None:
                 self._held -= raw.size
+                ticket = self._busy.pop(id(raw), 0)
         if raw is None:
             raw = dev_mod.pinned_empty((cap,), np.uint8)
+        elif ticket:
+            dev_mod.ticket_sync(ticket)      # (handed back while a transfer still read it: that transfer has to be through)
         return raw, raw[:n].view(dtype).reshape(shape)
 
-    def put(self, raw):
+    def put(self, raw, after=0):
+        """Hand ``raw`` back; ``after``: ticket of a transfer that may still be reading it (waited for when the buffer is given out again)."""
         with self._lock:
             if self._held + raw.size > self.cap_bytes:
+                if after:
+                    self._limbo.append((raw, after))      # (kept alive until the transfer is through, then dropped)
+                    self._limbo = [(r, t) for r, t in self._limbo[-64:]]
                 return                    # (dropped: the memory is unpinned when the last view of it is gone)
             self._free.setdefault(raw.size, []).append(raw)
             self._held += raw.size
+            if after:
+                self._busy[id(raw)] = int(after)
 
     def clear(self):
         with self._lock:
+            busy = list(self._busy.values())
+        for t in busy:
+            dev_mod.ticket_sync(t)
+        with self._lock:
             self._free.clear()
+            self._busy.clear()
+            self._limbo = []
             self._held = 0
 
 
@@ -104,6 +121,35 @@ def parallel_copy(dst, src, kind="read"):
     pieces = min(n, 16)
     cuts = np.linspace(0, n, pieces + 1).astype(int)
     list(io_pool(kind=kind).map(lambda k: np.copyto(dst[cuts[k]:cuts[k + 1]], src[cuts[k]:cuts[k + 1]], casting="unsafe"), range(pieces)))
+
+
+def upload_host_sims_async(sims, device, depth=4):
+    """Copies of the SpatialImages ``sims`` (plain host numpy data) whose data is on its way to ``device``: every tile is copied into a
+    pinned staging buffer by the I/O pool and uploaded on the copy stream without waiting (``DeviceArray.from_host_async``; the
+    returned arrays carry the uploads' tickets, so ``register()`` starts a pair when its two tiles have landed).  ``depth`` staging
+    buffers are cycled: a buffer is reused when the upload that read it is through."""
+    from .device import DeviceArray
+
+    pool = shared_pinned_pool()
+    ring, out = [], []
+    for s_ in sims:
+        data = np.asarray(s_.data)
+        if len(ring) >= depth:
+            raw, ticket = ring.pop(0)
+            dev_mod.ticket_sync(ticket)
+            buf = raw[:data.nbytes].view(data.dtype).reshape(data.shape) if raw.size >= data.nbytes else None
+            if buf is None:
+                pool.put(raw)
+                raw, buf = pool.get(data.shape, data.dtype)
+        else:
+            raw, buf = pool.get(data.shape, data.dtype)
+        parallel_copy(buf, data)
+        d = DeviceArray.from_host_async(buf, device)
+        ring.append((raw, d.ready_ticket))
+        out.append(s_.copy(data=d))
+    for raw, ticket in ring:
+        pool.put(raw, after=ticket)
+    return out
 
 
 def read_window(view, out):

@@ -206,3 +206,17 @@ def test_fuse_of_plain_host_arrays_takes_the_block_pipeline_and_equals_one_launc
         fusion._HOST_STREAM[0] = True
     assert isinstance(got.data, np.ndarray) and got.data.any()
     np.testing.assert_array_equal(np.asarray(got.data), np.asarray(want.data))
+    # register() of the same host tiles: staged through pinned buffers and uploaded while the pairs start (upload_host_sims_async);
+    # same parameters as with one synchronous upload per tile, and the caller's arrays are left alone
+    from multiview_stitcher_amd import registration
+
+    before = [s.data for s in sims]
+    p_async = registration.register(sims, transform_key=key, new_transform_key="reg_a", device=0)
+    registration._HOST_UPLOAD_ASYNC[0] = False
+    try:
+        p_sync = registration.register(sims, transform_key=key, new_transform_key="reg_s", device=0)
+    finally:
+        registration._HOST_UPLOAD_ASYNC[0] = True
+    assert all(s.data is b for s, b in zip(sims, before))
+    for a, b in zip(p_async, p_sync):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))

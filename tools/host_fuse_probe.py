@@ -30,3 +30,9 @@ for mode in (os.environ.get("MODES", "serial,pipeline,serial,pipeline").split(",
     a = np.asarray(out.data)
     print("%-8s %.3f s  %.0f Mvoxels/s  in %.1f GB out %.1f GB -> %.1f GB/s  checksum %d" % (mode, dt, a.size / dt / 1e6, in_gb, a.nbytes / 1e9, (in_gb + a.nbytes / 1e9) / dt, int(a[::7, ::11, ::13].sum())), flush=True)
     del out, a
+if os.environ.get("REGISTER"):
+    from multiview_stitcher_amd import registration
+    for rep in range(3):
+        t0 = time.perf_counter()
+        registration.register(sims, transform_key=si.DEFAULT_TRANSFORM_KEY, new_transform_key="r", device=0)
+        print("register(host numpy tiles) %.3f s" % (time.perf_counter() - t0), flush=True)
