@@ -206,6 +206,13 @@ def test_fuse_of_plain_host_arrays_takes_the_block_pipeline_and_equals_one_launc
         fusion._HOST_STREAM[0] = True
     assert isinstance(got.data, np.ndarray) and got.data.any()
     np.testing.assert_array_equal(np.asarray(got.data), np.asarray(want.data))
+    # tiles resident on the device, result a host array: the same pipeline (the blocks' downloads under the next blocks' launches)
+    from multiview_stitcher_amd import device
+
+    streaming.LAST_TIMELINE[:] = []
+    got_d = fusion.fuse([device.to_device(s, 0) for s in sims], transform_key=key, device=0)
+    assert streaming.LAST_TIMELINE and isinstance(got_d.data, np.ndarray)
+    np.testing.assert_array_equal(np.asarray(got_d.data), np.asarray(want.data))
     # register() of the same host tiles: staged through pinned buffers and uploaded while the pairs start (upload_host_sims_async);
     # same parameters as with one synchronous upload per tile, and the caller's arrays are left alone
     from multiview_stitcher_amd import registration

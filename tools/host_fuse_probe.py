@@ -19,9 +19,12 @@ for t, o in zip(tiles, org):
     s = si.to_spatial_image(h, dims=["z", "y", "x"], scale={d: 1.0 for d in "zyx"}, translation=dict(zip("zyx", o)))
     si.set_sim_affine(s, np.eye(4), si.DEFAULT_TRANSFORM_KEY)
     sims.append(s)
-del tiles
-torch.cuda.empty_cache()
-in_gb = sum(s.data.nbytes for s in sims) / 1e9
+if os.environ.get("DEVICE_TILES"):       # tiles resident on the device, result still a host array
+    sims = bench.build_sims(tiles, org, 0)
+else:
+    del tiles
+    torch.cuda.empty_cache()
+in_gb = sum(int(np.prod(s.data.shape)) * 2 for s in sims) / 1e9
 for mode in (os.environ.get("MODES", "serial,pipeline,serial,pipeline").split(",")):
     fusion._HOST_STREAM[0] = mode == "pipeline"
     t0 = time.perf_counter()
