@@ -40,6 +40,7 @@ class PinnedPool:
         self._free = {}
         self._busy = {}       # id(raw) -> ticket of a transfer that was still reading the buffer when it came back
         self._limbo = []
+        self._order = []      # free buffers, oldest first (what makes room when the cap is reached)
         self._lock = threading.Lock()
         self._held = 0
         self.cap_bytes = int(os.environ.get("MVS_PINNED_POOL_MB", 16 << 10)) << 20 if cap_bytes is None else int(cap_bytes)
@@ -54,6 +55,7 @@ class PinnedPool:
             if raw is not None:
                 self._held -= raw.size
                 ticket = self._busy.pop(id(raw), 0)
+                self._order = [o for o in self._order if o is not raw]
         if raw is None:
             raw = dev_mod.pinned_empty((cap,), np.uint8)
         elif ticket:
@@ -61,14 +63,26 @@ class PinnedPool:
         return raw, raw[:n].view(dtype).reshape(shape)
 
     def put(self, raw, after=0):
-        """Hand ``raw`` back; ``after``: ticket of a transfer that may still be reading it (waited for when the buffer is given out again)."""
+        """Hand ``raw`` back; ``after``: ticket of a transfer that may still be reading it (waited for when the buffer is given out again).
+        Over the cap the buffers that have lain in the pool longest make room (a pipeline's own sizes stay: dropping the buffer that
+        comes back, as the first version did, made a pipeline whose sizes were not the previous one's re-pin every buffer on every
+        call -- 100-150 ms stalls per block on the C5 leg after the host-array leg had filled the pool)."""
         with self._lock:
-            if self._held + raw.size > self.cap_bytes:
+            if raw.size > self.cap_bytes:
                 if after:
-                    self._limbo.append((raw, after))      # (kept alive until the transfer is through, then dropped)
-                    self._limbo = [(r, t) for r, t in self._limbo[-64:]]
-                return                    # (dropped: the memory is unpinned when the last view of it is gone)
+                    self._limbo = self._limbo[-63:] + [(raw, after)]      # (kept alive until the transfer is through, then dropped)
+                return
+            while self._held + raw.size > self.cap_bytes and self._order:
+                old = self._order.pop(0)
+                lst = self._free.get(old.size)
+                if lst and any(o is old for o in lst):
+                    lst[:] = [o for o in lst if o is not old]
+                    self._held -= old.size
+                    t = self._busy.pop(id(old), 0)
+                    if t:
+                        self._limbo = self._limbo[-63:] + [(old, t)]
             self._free.setdefault(raw.size, []).append(raw)
+            self._order.append(raw)
             self._held += raw.size
             if after:
                 self._busy[id(raw)] = int(after)
@@ -82,6 +96,7 @@ class PinnedPool:
             self._free.clear()
             self._busy.clear()
             self._limbo = []
+            self._order = []
             self._held = 0
 
 
