@@ -1358,10 +1358,11 @@ def register(msims, transform_key=None, reg_channel_index=None, reg_channel=None
     sims_reg = [channel_of(s) for s in sims]
     if _HOST_UPLOAD_ASYNC[0] and pairwise_executor is None and not any(msi_utils.is_msim(m) and len(m.keys()) > 1 for m in msims) \
             and reg_res_level is None and pairwise_reg_func is phase_correlation_registration \
-            and all(isinstance(s.data, np.ndarray) and list(s.dims) == list(si_utils.get_spatial_dims_from_sim(s)) for s in sims_reg) \
-            and sum(int(s.data.nbytes) for s in sims_reg) >= (256 << 20) and _lib.device_count() > 0 \
-            and all(s.data.dtype in _lib.DTYPE_CODES for s in sims_reg):
-        # plain host numpy tiles -- what a user of the reference hands over: staged through pinned buffers and uploaded on the copy stream
+            and all((isinstance(s.data, np.ndarray) or type(s.data).__name__ in ("ZarrArray", "ZarrView"))
+                    and list(s.dims) == list(si_utils.get_spatial_dims_from_sim(s)) for s in sims_reg) \
+            and sum(int(np.prod(s.data.shape)) * np.dtype(s.data.dtype).itemsize for s in sims_reg) >= (256 << 20) and _lib.device_count() > 0 \
+            and all(np.dtype(s.data.dtype) in _lib.DTYPE_CODES for s in sims_reg):
+        # plain host numpy tiles (or windows of Zarr arrays) -- what a user of the reference hands over: staged through pinned buffers and uploaded on the copy stream
         # while the overlap graph is built and the first pairs are registered (north star: 1.7-2.0 s of one synchronous pageable upload
         # per tile before; streaming.upload_host_sims_async).  The caller's images are only read; results are written to them below.
         from .streaming import upload_host_sims_async

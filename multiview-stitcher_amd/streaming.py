@@ -139,8 +139,9 @@ def parallel_copy(dst, src, kind="read"):
 
 
 def upload_host_sims_async(sims, device, depth=4):
-    """Copies of the SpatialImages ``sims`` (plain host numpy data) whose data is on its way to ``device``: every tile is copied into a
-    pinned staging buffer by the I/O pool and uploaded on the copy stream without waiting (``DeviceArray.from_host_async``; the
+    """Copies of the SpatialImages ``sims`` (plain host numpy data, or windows of Zarr arrays) whose data is on its way to ``device``:
+    every tile is copied -- or read, chunk file by chunk file -- into a pinned staging buffer by the I/O pool and uploaded on the copy
+    stream without waiting (``DeviceArray.from_host_async``; the
     returned arrays carry the uploads' tickets, so ``register()`` starts a pair when its two tiles have landed).  ``depth`` staging
     buffers are cycled: a buffer is reused when the upload that read it is through."""
     from .device import DeviceArray
@@ -148,17 +149,23 @@ def upload_host_sims_async(sims, device, depth=4):
     pool = shared_pinned_pool()
     ring, out = [], []
     for s_ in sims:
-        data = np.asarray(s_.data)
+        lazy = zarr_io.is_zarr_backed(s_.data)
+        data = s_.data if lazy else np.asarray(s_.data)
+        shape, dtype = tuple(data.shape), np.dtype(data.dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
         if len(ring) >= depth:
             raw, ticket = ring.pop(0)
             dev_mod.ticket_sync(ticket)
-            buf = raw[:data.nbytes].view(data.dtype).reshape(data.shape) if raw.size >= data.nbytes else None
+            buf = raw[:nbytes].view(dtype).reshape(shape) if raw.size >= nbytes else None
             if buf is None:
                 pool.put(raw)
-                raw, buf = pool.get(data.shape, data.dtype)
+                raw, buf = pool.get(shape, dtype)
         else:
-            raw, buf = pool.get(data.shape, data.dtype)
-        parallel_copy(buf, data)
+            raw, buf = pool.get(shape, dtype)
+        if lazy:
+            read_window(data, buf)
+        else:
+            parallel_copy(buf, data)
         d = DeviceArray.from_host_async(buf, device)
         ring.append((raw, d.ready_ticket))
         out.append(s_.copy(data=d))

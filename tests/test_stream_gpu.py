@@ -181,7 +181,7 @@ def test_copy_box_between_pitched_windows(hip_device):
         da[:3, :3].copy_box_to(db[:3, :4])
 
 
-def test_fuse_of_plain_host_arrays_takes_the_block_pipeline_and_equals_one_launch_block(hip_device):
+def test_fuse_of_plain_host_arrays_takes_the_block_pipeline_and_equals_one_launch_block(hip_device, tmp_path):
     """``fuse()`` of host numpy tiles (>= 256 MiB) into a host numpy result -- the reference's own call -- runs its launch blocks through
     the block pipeline by default; same voxels as the single launch block ``mvs_fuse_chunk`` uploads, fuses and downloads itself."""
     from multiview_stitcher_amd import fusion, sample_data, streaming
@@ -226,4 +226,16 @@ def test_fuse_of_plain_host_arrays_takes_the_block_pipeline_and_equals_one_launc
         registration._HOST_UPLOAD_ASYNC[0] = True
     assert all(s.data is b for s, b in zip(sims, before))
     for a, b in zip(p_async, p_sync):
+        np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    # ... and of the same tiles as windows of Zarr arrays: chunk files read straight into the pinned staging buffers
+    from multiview_stitcher_amd import ngff_utils, zarr_io, spatial_image_utils as si
+
+    lazy = []
+    for i, s in enumerate(sims):
+        z = ngff_utils.write_sim_to_ome_zarr(s, str(tmp_path / f"tile{i}.zarr"))
+        si.set_sim_affine(z, si.get_affine_from_sim(s, key), key)
+        assert zarr_io.is_zarr_backed(z.data)
+        lazy.append(z)
+    p_zarr = registration.register(lazy, transform_key=key, new_transform_key="reg_z", device=0)
+    for a, b in zip(p_zarr, p_sync):
         np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
