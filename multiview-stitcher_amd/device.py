@@ -16,6 +16,9 @@ import numpy as np
 from . import _lib
 
 
+_STAGED_GET_MIN_BYTES = [256 << 20]      # DeviceArray.get() of at least this many (contiguous) bytes goes through pinned staging buffers
+
+
 class _Pending:
     """The upload a DeviceArray's allocation is still waiting for (shared by all windows cut from it): a ticket of mvs_copy_async
     and the pinned host array it reads, kept alive until the ticket has been waited for on the host."""
@@ -258,10 +261,41 @@ class DeviceArray:
                 raise IndexError("DeviceArray supports ints and slices only")
         return DeviceArray(self._buf, self.ptr + off * self.dtype.itemsize, shape, strides, self.dtype, self.device, pending=self._pending)
 
+    def _get_staged(self, piece=128 << 20, depth=3):
+        """A large contiguous array to the host through pinned staging buffers: asynchronous downloads of ``piece`` bytes on the copy
+        stream (after everything queued on this array's context so far), each copied into the result by the I/O pool while the next
+        ones are in flight.  One synchronous copy into pageable memory moves 17 GB/s; this way the link's 50+."""
+        from . import streaming
+
+        out = np.empty(self.shape, dtype=self.dtype)
+        flat = out.reshape(-1).view(np.uint8)
+        pool = streaming.shared_pinned_pool()
+        after = mark(self.device)
+        inflight = []
+
+        def drain():
+            a, n, raw, buf, t = inflight.pop(0)
+            ticket_sync(t)
+            streaming.parallel_copy(flat[a:a + n], buf, kind="write")
+            pool.put(raw)
+
+        for a in range(0, flat.size, piece):
+            n = min(piece, flat.size - a)
+            raw, buf = pool.get((n,), np.uint8)
+            src = DeviceArray(self._buf, self.ptr + a, (n,), (1,), np.uint8, self.device)
+            inflight.append((a, n, raw, buf, src.download_async(buf, after=after)))
+            if len(inflight) >= depth:
+                drain()
+        while inflight:
+            drain()
+        return out
+
     def get(self):
         """Copy to a numpy array."""
         self.sync_ready()
         if self.is_contiguous():
+            if self.nbytes >= _STAGED_GET_MIN_BYTES[0] and _lib.device_count() > 0:
+                return self._get_staged()
             out = np.empty(self.shape, dtype=self.dtype)
             _lib.check(_lib.load().mvs_memcpy_d2h(self.device, out.ctypes.data, self.ptr, out.nbytes), self.device, "d2h")
             return out

@@ -34,6 +34,25 @@ def test_pinned_arrays_and_async_round_trip(hip_device):
         device.DeviceArray.from_host_async(np.zeros((3, 3), np.uint16), 0)      # pageable memory: refused, not silently synchronous
 
 
+def test_large_get_goes_through_pinned_staging(hip_device):
+    """DeviceArray.get() of a large contiguous array: pieces downloaded asynchronously into pinned buffers and copied out by the I/O
+    pool (3 x the rate of one copy into pageable memory); same bytes, piece sizes that do not divide the array, windows untouched."""
+    from multiview_stitcher_amd import device
+
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 65535, (7, 333, 1001), dtype=np.uint16)
+    d = device.DeviceArray.from_host(a, 0)
+    old = device._STAGED_GET_MIN_BYTES[0]
+    device._STAGED_GET_MIN_BYTES[0] = 1 << 20
+    try:
+        np.testing.assert_array_equal(d.get(), a)
+        np.testing.assert_array_equal(d._get_staged(piece=(1 << 20) + 12346, depth=2), a)
+        np.testing.assert_array_equal(d[2:5, 10:300, 7:900].get(), a[2:5, 10:300, 7:900])      # (a strided window: the plain path)
+        np.testing.assert_array_equal(d[3].get(), a[3])                                       # (a contiguous window)
+    finally:
+        device._STAGED_GET_MIN_BYTES[0] = old
+
+
 def test_streamed_register_and_fuse_equal_the_resident_run_and_overlap(hip_device):
     """Tiles uploaded with ``to_device_async`` while ``register()`` registers the pairs whose tiles have landed, the mosaic fused in
     slabs with every slab's download under the next slab's fuse (``fuse_to_host``): (1) parameters and fused voxels equal the run
