@@ -1047,7 +1047,18 @@ def main():
         out_holder.clear()
         shard_ctx = {"rank": rank, "world": world, "executor": executor, "dist": dist, "backend": backend} if shard else None
         if shard:
-            pcie = pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out, shard=shard_ctx)     # (collective: no rank may skip it)
+            # (collective: every rank enters it; a rank that fails says so to the others before anybody reads the result, so that the
+            # line of the main loop -- what a scaling run is after -- is printed either way.  MVS_BENCH_PCIE_SHARDED=0 skips the leg.)
+            err = None
+            if os.environ.get("MVS_BENCH_PCIE_SHARDED", "1") != "0":
+                try:
+                    pcie = pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out, shard=shard_ctx)
+                except Exception as e:   # noqa: BLE001
+                    err = repr(e)[:300]
+                flag = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if float(flag.item()) < 1.0:
+                    pcie = {"error": err or "another rank failed in the PCIe-inclusive leg"}
         else:
             try:
                 pcie = pcie_pipeline(torch, dev, local_rank, sims, tiles, args, key_in, key_out)
